@@ -1,0 +1,253 @@
+/*
+ * vspg.h -- C-ABI of the MI355X-native GuidedVolPathVSPG hot path.
+ *
+ * The reference (kehanxuuu/vspg-pbrt-v4) has no FFI: the path sits behind C++ plugin
+ * classes chosen by string in static Create() functions.  This header is
+ * the boundary a maintainer would bind instead; every entry point names the reference
+ * interface it replaces (paths relative to the reference root, file:line).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types.
+ *   - every function returns 0 on success, a negative VSPG_E* code on failure;
+ *     vspg_last_error() returns a human-readable message for the calling thread.
+ *     (The reference aborts the process via ErrorExit/LOG_FATAL,
+ *     src/pbrt/cpu/integrators.cpp:3760-3766; a library must not, so fatal conditions
+ *     become error codes with the same trigger conditions.)
+ *   - the library owns all device memory behind the opaque handle; host buffers are owned
+ *     by the caller.  `stream` arguments are hipStream_t passed as void* (NULL = default).
+ *   - one renderer per GPU; one host thread drives it (this replaces the
+ *     ParallelFor2D thread-pool fan-out of src/pbrt/cpu/integrators.cpp:183-207).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point
+ *     fails with VSPG_ENODEVICE.
+ */
+#ifndef VSPG_H
+#define VSPG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSPG_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------- */
+#define VSPG_OK 0
+#define VSPG_EINVAL (-1)     /* bad argument / unsupported parameter combination          */
+#define VSPG_ENODEVICE (-2)  /* no HIP device / kernels not loadable                      */
+#define VSPG_EHIP (-3)       /* a HIP runtime call failed (message has the hipError name) */
+#define VSPG_ESCOPE (-4)     /* valid in the reference, outside this library's hot path   */
+
+/* ---- scene description (synthetic analytic scene) ---------------- */
+#define VSPG_MAX_QUADS 16
+
+/* A rectangle p00 + u*e1 + v*e2, u,v in [0,1], e1 perpendicular to e2.  Stands in for a
+ * pbrt "bilinearmesh" rectangle with a "diffuse" material and, when Le != 0, a "diffuse"
+ * area light (src/pbrt/shapes.cpp:1128-1143, src/pbrt/bxdfs.h:31-80,
+ * src/pbrt/lights.cpp:796-820). */
+typedef struct VspgQuad {
+    float p00[3];
+    float e1[3];
+    float e2[3];
+    float Kd[3];                  /* diffuse reflectance R (RGB) */
+    float Le[3];                  /* emitted radiance (RGB); all zero = not a light */
+    int32_t two_sided;            /* DiffuseAreaLight "twosided" */
+    int32_t reverse_orientation;  /* flips the geometric normal normalize(e1 x e2) */
+} VspgQuad;
+
+/* Pinhole camera: raster point (x,y) -> camera-space point (sx*x+ox, sy*y+oy, 1),
+ * normalised, then rotated into render space by the orthonormal frame (right, up, fwd).
+ * Replaces PerspectiveCamera::GenerateRayDifferential (src/pbrt/cameras.cpp:435-447)
+ * for lensRadius == 0.  Fill with vspg_camera_look_at(). */
+typedef struct VspgCamera {
+    float origin[3];
+    float right[3], up[3], fwd[3];
+    float sx, ox, sy, oy;
+} VspgCamera;
+
+enum { VSPG_MEDIUM_NONE = 0, VSPG_MEDIUM_HOMOGENEOUS = 1, VSPG_MEDIUM_GRID = 2 };
+
+/* The single medium filling the scene (ray.medium for every ray).
+ * HOMOGENEOUS mirrors HomogeneousMedium (src/pbrt/media.h:221-283; parameters
+ * src/pbrt/media.cpp:167-206): sigma_a/sigma_s are RGB, already multiplied by "scale";
+ * Le already multiplied by "Lescale".
+ * GRID mirrors GridMedium ("uniformgrid", src/pbrt/media.h:284-390,
+ * src/pbrt/media.cpp:209-361): density grid nx*ny*nz, x fastest, over `bounds` in medium
+ * space == render space (identity renderFromMedium); sigma_a/sigma_s are the RGB spectra
+ * already multiplied by "scale"; majorant grid is 16^3 (media.cpp:252). */
+typedef struct VspgMedium {
+    int32_t type;
+    float sigma_a[3];
+    float sigma_s[3];
+    float g;
+    float Le[3];
+    /* grid only */
+    int32_t nx, ny, nz;
+    float bounds_min[3], bounds_max[3];
+    const float *density; /* HOST pointer, nx*ny*nz floats; copied at create time */
+} VspgMedium;
+
+typedef struct VspgScene {
+    int32_t n_quads;
+    VspgQuad quads[VSPG_MAX_QUADS];
+    VspgCamera camera;
+    VspgMedium medium;
+} VspgScene;
+
+/* ---- integrator parameters: same names and defaults as
+ * GuidedVolPathVSPGIntegrator::Create (src/pbrt/cpu/guidedvolpathvspgintegrator.cpp:
+ * 1260-1322).  Use vspg_integrator_params_default() then override. ------------------ */
+enum { VSPG_GUIDE_MIS = 0, VSPG_GUIDE_RIS = 1 };              /* guiding.h:52-55 */
+enum { VSPG_VSP_CONTRIBUTION = 0, VSPG_VSP_VARIANCE = 1 };    /* "vspcriterion" */
+enum { VSPG_VSP_RESAMPLING = 0, VSPG_VSP_NDS = 1 };           /* "vspsamplingmethod" */
+enum { VSPG_LIGHTSAMPLER_UNIFORM = 0, VSPG_LIGHTSAMPLER_POWER = 1, VSPG_LIGHTSAMPLER_BVH = 2 };
+
+typedef struct VspgIntegratorParams {
+    int32_t maxdepth;                  /* 5 */
+    int32_t minrrdepth;                /* 1 */
+    int32_t usenee;                    /* true */
+    int32_t surfaceguiding;            /* true  (directional guiding of BSDF sampling) */
+    int32_t volumeguiding;             /* true  (directional guiding of phase sampling) */
+    int32_t surfaceguidingtype;        /* "ris" */
+    int32_t volumeguidingtype;         /* "mis" */
+    int32_t vspguiding;                /* true */
+    int32_t vspprimaryguiding;         /* true */
+    int32_t vspsecondaryguiding;       /* true */
+    float vspmisratio;                 /* 0.5 */
+    int32_t vspcriterion;              /* "variance" */
+    int32_t vspsamplingmethod;         /* "resampling" */
+    int32_t collisionProbabilityBias;  /* false (NDS+; out of scope -> VSPG_ESCOPE if set) */
+    int32_t rrguiding;                 /* false (guided RR; out of scope if set) */
+    int32_t lightsampler;              /* "bvh" */
+    int32_t regularize;                /* false (no-op for diffuse BxDFs) */
+    int32_t guide_num_training_waves;  /* 128, hidden constant integrators.h:502 */
+} VspgIntegratorParams;
+
+/* Film "rgb" + Sampler "independent" + PixelFilter "box" (SURVEY.md App. F). */
+typedef struct VspgRenderConfig {
+    int32_t xres, yres;   /* Film xresolution / yresolution */
+    int32_t spp;          /* Sampler "pixelsamples" (only used for bookkeeping) */
+    int32_t seed;         /* --seed / sampler "seed" (src/pbrt/samplers.h:457-460) */
+    /* multi-GPU sharding of sample indices: this renderer handles wave w iff
+     * w % shard_count == shard_index.  1-GPU: index 0, count 1. */
+    int32_t shard_index, shard_count;
+    int32_t device;       /* HIP device ordinal */
+} VspgRenderConfig;
+
+typedef struct VspgCounters {
+    uint64_t paths;             /* camera samples run to termination */
+    uint64_t segments;          /* iterations of the Li() path loop (roofline unit, 8d) */
+    uint64_t volume_scatters;   /* real scattering events ("Volume interactions") */
+    uint64_t surface_hits;      /* "Surface interactions" */
+    uint64_t density_queries;   /* tentative collisions ("Integrator/Density query") */
+    uint64_t shadow_rays;
+} VspgCounters;
+
+typedef struct VspgRenderer VspgRenderer; /* opaque */
+
+/* ---- helpers (host only, no device needed) ----------------------------------------- */
+int vspg_abi_version(void);
+const char *vspg_last_error(void);
+void vspg_integrator_params_default(VspgIntegratorParams *p);
+/* pbrt "LookAt" + Camera "perspective" "float fov" (fov spans the shorter image axis,
+ * src/pbrt/cameras.cpp:474-489), world == render space. */
+int vspg_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3],
+                        const float up[3], float fov_degrees, int xres, int yres);
+/* Fills `scene` with the App.-F fog box: box [-1,1]^3, Kd .73 walls, 0.5x0.5 ceiling
+ * light Le (17,12,4) at y=.999, homogeneous fog sigma_a .05 sigma_s .45 g 0, camera at
+ * (0,0,-.95) looking +z, fov 60. */
+int vspg_scene_fog_box(VspgScene *scene, int xres, int yres);
+
+/* ---- renderer life cycle ----------------------------------------------------------- */
+/* Replaces Integrator::Create("guidedvolpathvspg", ...) + the integrator constructor
+ * (src/pbrt/cpu/integrators.cpp:3739-3744, guidedvolpathvspgintegrator.cpp:61-198):
+ * validates parameters, uploads scene and medium, allocates film, image-space VSP buffer
+ * and path-state queues on `cfg->device`. */
+int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *params,
+                         const VspgRenderConfig *cfg, VspgRenderer **out);
+/* Replaces ~GuidedVolPathVSPGIntegrator (guidedvolpathvspgintegrator.cpp:200-228). */
+int vspg_renderer_destroy(VspgRenderer *r);
+
+/* Replaces one wave of ImageTileIntegrator::Render -- the ParallelFor2D over all pixels
+ * for sample indices [wave_start, wave_end) (src/pbrt/cpu/integrators.cpp:183-207),
+ * i.e. EvaluatePixelSample -> Li -> SampleDistance -> film.AddSample for every pixel.
+ * Asynchronous on `stream`. */
+int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream);
+
+/* Replaces GuidedVolPathVSPGIntegrator::PostProcessWave
+ * (guidedvolpathvspgintegrator.cpp:230-260): waveCounter++, image-space VSP buffer update
+ * when waveCounter == 2^bufferWave.  Asynchronous on `stream`. */
+int vspg_post_process_wave(VspgRenderer *r, void *stream);
+
+/* Film access.  The film is W*H float4 {sum w*r, sum w*g, sum w*b, sum w} in HBM
+ * (the accumulate contract of RGBFilm::AddSample, src/pbrt/film.h:251-267, in float).
+ * vspg_film_device_ptr exposes it for the frame-end RCCL all-reduce. */
+int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);
+int vspg_film_read(VspgRenderer *r, float *host_rgbw /* W*H*4 */, void *stream);
+int vspg_film_clear(VspgRenderer *r, void *stream);
+
+/* Image-space VSP buffer (stands in for openpgl ImageSpaceGuidingBuffer,
+ * guidedvolpathvspgintegrator.cpp:161-178, 1098-1112). */
+int vspg_vsp_buffer_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);
+int vspg_vsp_buffer_read(VspgRenderer *r, float *host_vsp /* W*H */, int *is_ready,
+                         void *stream);
+/* per-pixel sufficient statistics (W*H*VSPG_ISG_STATS floats) for multi-GPU all-reduce */
+#define VSPG_ISG_STATS 8
+int vspg_isg_stats_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);
+
+int vspg_get_counters(VspgRenderer *r, VspgCounters *out, void *stream);
+int vspg_reset_counters(VspgRenderer *r, void *stream);
+
+/* ---- parity / debug entry points ---------------------------------------------------- */
+/* Runs EvaluatePixelSample for n explicit (pixel, sampleIndex) pairs with the renderer's
+ * current VSP buffer and returns the camera-weighted radiance L (RGB) per path plus the
+ * number of path-loop segments -- the analogue of --debugstart x,y,n
+ * (src/pbrt/cpu/integrators.cpp:77-95).  Host arrays. */
+int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy /* 2n */,
+                     const int32_t *sample_index /* n */, float *out_L /* 3n */,
+                     int32_t *out_segments /* n or NULL */, void *stream);
+
+/* Batch drivers of the free-flight layer on device, for bit-level checks against the
+ * oracle and the reference known answers.  All arrays are HOST
+ * arrays of length n (or 3n where noted). */
+typedef struct VspgTmajQuery {
+    float o[3], d[3];  /* ray (d need not be normalised) */
+    float tMax;
+    float u;           /* traversal sample */
+    float rng_a, rng_b;/* RNG(Hash(rng_a), Hash(rng_b)), integrator.cpp:323-325 */
+    float vsp;         /* <0: guideScatterDecision=false */
+    int32_t channel;   /* hero channel lambda.ChannelIdx() */
+    int32_t stop_after;/* callback returns false at this (1-based) callback; 0 = never */
+} VspgTmajQuery;
+
+typedef struct VspgTmajResult {
+    float T_maj[3];       /* returned majorant transmittance */
+    float r_u_factor[3];  /* OpticalDepthSpace only (else 1) */
+    float last_t;         /* distance along the NORMALISED ray of the last callback, -1 if none */
+    float last_p[3];      /* its position */
+    int32_t n_callbacks;
+    float sum_sigt_over_maj; /* sum over callbacks of (sigma_t/sigma_maj)[channel] */
+    float vrc;            /* Resampling: volumeRatioZeroCandidateCompensation */
+    float majorant_scale; /* Resampling */
+} VspgTmajResult;
+
+enum { VSPG_TMAJ_PLAIN = 0, VSPG_TMAJ_OPTICAL_DEPTH = 1, VSPG_TMAJ_RESAMPLING = 2 };
+/* Replaces SampleT_maj / SampleT_maj_OpticalDepthSpace / SampleT_maj_Resampling
+ * (src/pbrt/media_sampleTMaj.h:49-117, 269-491, 136-248) on the renderer's medium with a
+ * recording callback. */
+int vspg_sample_tmaj_batch(VspgRenderer *r, int variant, int n, const VspgTmajQuery *q,
+                           VspgTmajResult *out, void *stream);
+
+/* Primitive batch (bit-exact layer): for each i computes on device
+ *   hash[i]   = Hash(f[i])                      (src/pbrt/util/hash.h:100)
+ *   rng_u32[i]= RNG(Hash(f[i]),Hash(g[i])).Uniform<uint32_t>()  (util/rng.h:82-88,119-125)
+ *   fastexp[i]= FastExp(f[i])                   (util/math.h:450-474)
+ */
+int vspg_primitives_batch(VspgRenderer *r, int n, const float *f, const float *g,
+                          uint64_t *hash, uint32_t *rng_u32, float *fastexp, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSPG_H */

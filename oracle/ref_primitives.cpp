@@ -1,0 +1,247 @@
+// ref_primitives.cpp -- golden-vector generator for the bit-exact primitive layer.
+//
+// TEST INFRASTRUCTURE.  This driver #includes the reference's OWN headers where they lie
+// under /root/reference (nothing is copied, no stand-in headers are written) and links the
+// reference's src/pbrt/util/sampling.cpp compiled in place.  It only builds in the container
+// that has /root/reference; its binary lives in oracle/_ref/ (git-ignored) and its output is
+// committed as tests/golden/primitives.json by oracle/make_golden.py.
+//
+// Covered (SURVEY.md 8a rows a1-a4 + helpers): Hash / MurmurHash64A / MixBits, RNG (PCG32)
+// incl. SetSequence / Advance / Uniform<float>, IndependentSampler, FastExp, SampleExponential,
+// SampleDiscrete, HenyeyGreenstein, SampleHenyeyGreenstein, SampleUniformSphere,
+// SampleCosineHemisphere, CoordinateSystem, OffsetRayOrigin, SampledWavelengths::ChannelIdx.
+// NOT buildable without the absent third-party headers (nanovdb, openpgl, ...): media.h,
+// media_sampleTMaj.h, the integrator -- see DESIGN.md.
+#include <pbrt/pbrt.h>
+#include <pbrt/ray.h>
+#include <pbrt/samplers.h>
+#include <pbrt/util/hash.h>
+#include <pbrt/util/math.h>
+#include <pbrt/util/rng.h>
+#include <pbrt/util/sampling.h>
+#include <pbrt/util/scattering.h>
+#include <pbrt/util/spectrum.h>
+#include <pbrt/util/vecmath.h>
+
+#include <cstdio>
+#include <vector>
+
+using namespace pbrt;
+
+static void pf(float v) { printf("\"%a\"", v); }
+static void sep(bool &first) {
+    if (!first) printf(",");
+    first = false;
+}
+
+int main() {
+    RNG gen(12345, 678);  // input generator
+    auto U = [&]() { return gen.Uniform<Float>(); };
+    printf("{\n");
+
+    // ---- Hash(float) ----
+    {
+        printf("\"hash_float\": [");
+        bool first = true;
+        std::vector<float> in = {0.25f, 0.75f, 0.f, -0.f, 1.f, 0.5f, 1e-20f, 123456.f};
+        for (int i = 0; i < 56; ++i) in.push_back(U());
+        for (float f : in) {
+            sep(first);
+            printf("[");
+            pf(f);
+            printf(",\"%016llx\"]", (unsigned long long)Hash(f));
+        }
+        printf("],\n");
+    }
+    // ---- Hash(Point2i, int) and Hash(Point3f) and MixBits ----
+    {
+        printf("\"hash_pixel_seed\": [");
+        bool first = true;
+        int px[] = {0, 1, 0, 1919, 511, 37, 1000, 77};
+        int py[] = {0, 0, 1, 1079, 511, 911, 3, 77};
+        int sd[] = {0, 0, 0, 0, 7, 123456, -1, 2147483647};
+        for (int i = 0; i < 8; ++i) {
+            sep(first);
+            printf("[%d,%d,%d,\"%016llx\"]", px[i], py[i], sd[i],
+                   (unsigned long long)Hash(Point2i(px[i], py[i]), sd[i]));
+        }
+        printf("],\n\"hash_point3\": [");
+        first = true;
+        for (int i = 0; i < 32; ++i) {
+            Point3f p(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            sep(first);
+            printf("[");
+            pf(p.x); printf(","); pf(p.y); printf(","); pf(p.z);
+            printf(",\"%016llx\"]", (unsigned long long)Hash(p));
+        }
+        printf("],\n\"mix_bits\": [");
+        first = true;
+        uint64_t vals[] = {0ull, 1ull, 0xdeadbeefcafef00dull, 0xffffffffffffffffull, 0x3eb9f34ec52a56a0ull};
+        for (uint64_t v : vals) {
+            sep(first);
+            printf("[\"%016llx\",\"%016llx\"]", (unsigned long long)v, (unsigned long long)MixBits(v));
+        }
+        printf("],\n");
+    }
+    // ---- RNG ----
+    {
+        printf("\"rng\": [");
+        bool first = true;
+        struct C { uint64_t seq, seed; int has_seed; int64_t adv; };
+        C cases[] = {{0, 0, 1, 0}, {Hash(0.25f), Hash(0.75f), 1, 0}, {7, 0, 0, 0}, {42, 99, 1, 65536},
+                     {Hash(Point2i(5, 9), 0), 0, 0, 3 * 65536ull}, {0xffffffffffffffffull, 1, 1, 1234567}};
+        for (auto &c : cases) {
+            RNG a, b;
+            if (c.has_seed) { a.SetSequence(c.seq, c.seed); } else { a.SetSequence(c.seq); }
+            a.Advance(c.adv);
+            b = a;
+            sep(first);
+            printf("{\"seq\":\"%016llx\",\"seed\":\"%016llx\",\"has_seed\":%d,\"advance\":%lld,\"u32\":[",
+                   (unsigned long long)c.seq, (unsigned long long)c.seed, c.has_seed, (long long)c.adv);
+            for (int i = 0; i < 16; ++i) printf("%s%u", i ? "," : "", a.Uniform<uint32_t>());
+            printf("],\"f\":[");
+            for (int i = 0; i < 16; ++i) { if (i) printf(","); pf(b.Uniform<float>()); }
+            printf("]}");
+        }
+        printf("],\n");
+    }
+    // ---- IndependentSampler ----
+    {
+        printf("\"independent_sampler\": [");
+        bool first = true;
+        int cs[][4] = {{0, 0, 0, 0}, {17, 33, 0, 5}, {1919, 1079, 0, 255}, {3, 4, 11, 1000}};
+        for (auto &c : cs) {
+            IndependentSampler s(256, c[2]);
+            s.StartPixelSample(Point2i(c[0], c[1]), c[3], 0);
+            sep(first);
+            printf("{\"px\":%d,\"py\":%d,\"seed\":%d,\"sample\":%d,\"f\":[", c[0], c[1], c[2], c[3]);
+            for (int i = 0; i < 12; ++i) { if (i) printf(","); pf(s.Get1D()); }
+            printf("]}");
+        }
+        printf("],\n");
+    }
+    // ---- FastExp ----
+    {
+        printf("\"fast_exp\": [");
+        bool first = true;
+        std::vector<float> in = {-1.5f, 0.f, -0.f, 1.f, -1.f, -87.f, -88.f, -100.f, 88.f, 89.f, -1e-8f, 1e-8f, -20.f, 20.f};
+        for (int i = 0; i < 200; ++i) in.push_back(-12.f * U());
+        for (int i = 0; i < 50; ++i) in.push_back(40.f * U() - 20.f);
+        for (float f : in) { sep(first); printf("["); pf(f); printf(","); pf(FastExp(f)); printf("]"); }
+        printf("],\n");
+    }
+    // ---- SampleExponential ----
+    {
+        printf("\"sample_exponential\": [");
+        bool first = true;
+        std::vector<std::pair<float, float>> in = {{0.3f, 2.f}, {0.f, 1.f}, {OneMinusEpsilon, 0.5f}};
+        for (int i = 0; i < 64; ++i) in.push_back({U(), 0.01f + 10.f * U()});
+        for (auto &c : in) {
+            sep(first); printf("["); pf(c.first); printf(","); pf(c.second); printf(",");
+            pf(SampleExponential(c.first, c.second)); printf("]");
+        }
+        printf("],\n");
+    }
+    // ---- SampleDiscrete (two weights) ----
+    {
+        printf("\"sample_discrete2\": [");
+        bool first = true;
+        struct C { float w0, w1, u; };
+        std::vector<C> in = {{0.3f, 0.7f, 0.5f}, {1.f, 0.f, 0.f}, {1.f, 0.f, OneMinusEpsilon}, {0.5f, 0.5f, 0.5f}, {0.f, 1.f, 0.f}};
+        for (int i = 0; i < 64; ++i) { float w = U(); in.push_back({w, std::max<Float>(0, 1 - w), U()}); }
+        for (auto &c : in) {
+            Float w[2] = {c.w0, c.w1};
+            sep(first); printf("["); pf(c.w0); printf(","); pf(c.w1); printf(","); pf(c.u);
+            printf(",%d]", SampleDiscrete(w, c.u));
+        }
+        printf("],\n");
+    }
+    // ---- HenyeyGreenstein / SampleHenyeyGreenstein ----
+    {
+        printf("\"henyey_greenstein\": [");
+        bool first = true;
+        float gs[] = {0.f, 0.5f, -0.5f, 0.877f, 0.999f, -0.999f, 0.0005f};
+        for (float g : gs)
+            for (int i = 0; i < 8; ++i) {
+                float c = 2 * U() - 1;
+                sep(first); printf("["); pf(c); printf(","); pf(g); printf(","); pf(HenyeyGreenstein(c, g)); printf("]");
+            }
+        printf("],\n\"sample_henyey_greenstein\": [");
+        first = true;
+        for (float g : gs)
+            for (int i = 0; i < 8; ++i) {
+                Vector3f wo = Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1));
+                Point2f u(U(), U());
+                Float pdf;
+                Vector3f wi = SampleHenyeyGreenstein(wo, g, u, &pdf);
+                sep(first); printf("[");
+                pf(wo.x); printf(","); pf(wo.y); printf(","); pf(wo.z); printf(","); pf(g); printf(",");
+                pf(u[0]); printf(","); pf(u[1]); printf(",");
+                pf(wi.x); printf(","); pf(wi.y); printf(","); pf(wi.z); printf(","); pf(pdf); printf("]");
+            }
+        printf("],\n");
+    }
+    // ---- SampleUniformSphere / SampleCosineHemisphere / CoordinateSystem ----
+    {
+        printf("\"sample_uniform_sphere\": [");
+        bool first = true;
+        for (int i = 0; i < 32; ++i) {
+            Point2f u(U(), U());
+            Vector3f v = SampleUniformSphere(u);
+            sep(first); printf("["); pf(u[0]); printf(","); pf(u[1]); printf(","); pf(v.x); printf(","); pf(v.y); printf(","); pf(v.z); printf("]");
+        }
+        printf("],\n\"sample_cosine_hemisphere\": [");
+        first = true;
+        std::vector<Point2f> us = {{0.5f, 0.5f}, {0.f, 0.f}, {0.25f, 0.75f}};
+        for (int i = 0; i < 32; ++i) us.push_back({U(), U()});
+        for (auto u : us) {
+            Vector3f v = SampleCosineHemisphere(u);
+            sep(first); printf("["); pf(u[0]); printf(","); pf(u[1]); printf(","); pf(v.x); printf(","); pf(v.y); printf(","); pf(v.z); printf("]");
+        }
+        printf("],\n\"coordinate_system\": [");
+        first = true;
+        for (int i = 0; i < 24; ++i) {
+            Vector3f v = Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1)), a, b;
+            CoordinateSystem(v, &a, &b);
+            sep(first); printf("[");
+            pf(v.x); printf(","); pf(v.y); printf(","); pf(v.z); printf(",");
+            pf(a.x); printf(","); pf(a.y); printf(","); pf(a.z); printf(",");
+            pf(b.x); printf(","); pf(b.y); printf(","); pf(b.z); printf("]");
+        }
+        printf("],\n");
+    }
+    // ---- OffsetRayOrigin ----
+    {
+        printf("\"offset_ray_origin\": [");
+        bool first = true;
+        for (int i = 0; i < 32; ++i) {
+            Point3f p(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            Vector3f e(1e-6f * U(), 1e-6f * U(), 1e-6f * U());
+            Normal3f n = (i % 4 == 0) ? Normal3f(0, 0, 0)
+                                      : Normal3f(Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1)));
+            if (i % 4 == 1) n = Normal3f(0, 1, 0);
+            Vector3f w(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            Point3f o = OffsetRayOrigin(Point3fi(p, e), n, w);
+            sep(first); printf("[");
+            pf(p.x); printf(","); pf(p.y); printf(","); pf(p.z); printf(",");
+            pf(e.x); printf(","); pf(e.y); printf(","); pf(e.z); printf(",");
+            pf(n.x); printf(","); pf(n.y); printf(","); pf(n.z); printf(",");
+            pf(w.x); printf(","); pf(w.y); printf(","); pf(w.z); printf(",");
+            pf(o.x); printf(","); pf(o.y); printf(","); pf(o.z); printf("]");
+        }
+        printf("],\n");
+    }
+    // ---- hero channel of SampledWavelengths::SampleVisible (RGB build) ----
+    {
+        printf("\"channel_idx\": [");
+        bool first = true;
+        float us[] = {0.f, 0.1f, 0.333f, 0.3333333f, 0.35f, 0.6f, 0.6666667f, 0.85f, OneMinusEpsilon};
+        for (float u : us) {
+            SampledWavelengths swl = SampledWavelengths::SampleVisible(u);
+            sep(first); printf("["); pf(u); printf(",%d]", swl.ChannelIdx());
+        }
+        printf("]\n");
+    }
+    printf("}\n");
+    return 0;
+}

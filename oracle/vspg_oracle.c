@@ -1,0 +1,1786 @@
+/*
+ * vspg_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See vspg_oracle.h.
+ *
+ * Plain-C restatement of the GuidedVolPathVSPG hot path of kehanxuuu/vspg-pbrt-v4.
+ * Reference paths are relative to the reference root.  Build with
+ *   gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math   (see oracle/Makefile)
+ * so that float arithmetic follows the reference's default x86-64 build (no FMA contraction;
+ * explicit FMA() in the reference == fmaf() here).
+ *
+ * Float-evaluation notes that matter for seed parity:
+ *   - `std::log(1.0 - x)` in media_sampleTMaj.h is DOUBLE precision (1.0 is a double literal);
+ *     `std::log(1 - u)` in SampleExponential is FLOAT (logf).
+ *   - FastExp is the reference's own 2^x polynomial, not libm.
+ */
+#define _GNU_SOURCE
+#include "vspg_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* small vector / spectrum types (RGB mode: SampledSpectrum == 3 floats,                 */
+/* src/pbrt/util/spectrum.h:40-44)                                                        */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { float x, y, z; } v3;
+typedef struct { float c[3]; } spec;
+
+#define PI_F 3.14159265358979323846f
+#define INV_PI_F 0.31830988618379067154f
+#define INV_4PI_F 0.07957747154594766788f
+#define PI_OVER_2_F 1.57079632679489661923f
+#define PI_OVER_4_F 0.78539816339744830961f
+#define ONE_MINUS_EPS 0x1.fffffep-1f   /* util/float.h:27 */
+#define MACHINE_EPS 0x1p-24f           /* numeric_limits<float>::epsilon()*0.5 */
+#define SHADOW_EPS 0.0001f             /* util/math.h:42 */
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 v3_from(const float *p) { return V3(p[0], p[1], p[2]); }
+static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v_scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 v_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline v3 v_abs(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+static inline float sqr(float x) { return x * x; }
+/* util/vecmath.h:964 */
+static inline float v_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float v_absdot(v3 a, v3 b) { return fabsf(v_dot(a, b)); }
+/* util/vecmath.h:948-961: Normalize divides every component by the length */
+static inline float v_len2(v3 a) { return sqr(a.x) + sqr(a.y) + sqr(a.z); }
+static inline float v_len(v3 a) { return sqrtf(v_len2(a)); }
+static inline v3 v_normalize(v3 a) { float l = v_len(a); return V3(a.x / l, a.y / l, a.z / l); }
+/* util/math.h:569-574 */
+static inline float diff_of_products(float a, float b, float c, float d) {
+    float cd = c * d;
+    float dop = fmaf(a, b, -cd);
+    float err = fmaf(-c, d, cd);
+    return dop + err;
+}
+/* util/vecmath.h:999-1004 */
+static inline v3 v_cross(v3 v, v3 w) {
+    return V3(diff_of_products(v.y, w.z, v.z, w.y), diff_of_products(v.z, w.x, v.x, w.z),
+              diff_of_products(v.x, w.y, v.y, w.x));
+}
+/* Lerp(t, p0, p1) = (1-t)*p0 + t*p1 (util/math.h:210) */
+static inline v3 v_lerp(float t, v3 a, v3 b) { return v_add(v_scale(a, 1 - t), v_scale(b, t)); }
+static inline float safe_sqrt(float x) { return sqrtf(fmaxf(0.f, x)); }
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static inline spec S1(float v) { spec s = {{v, v, v}}; return s; }
+static inline spec s_from(const float *p) { spec s = {{p[0], p[1], p[2]}}; return s; }
+#define S_BINOP(name, op)                                                  \
+    static inline spec name(spec a, spec b) {                              \
+        spec r;                                                            \
+        for (int i = 0; i < 3; ++i) r.c[i] = a.c[i] op b.c[i];             \
+        return r;                                                          \
+    }
+S_BINOP(s_add, +)
+S_BINOP(s_sub, -)
+S_BINOP(s_mul, *)
+S_BINOP(s_div, /)
+static inline spec s_scale(spec a, float f) { spec r; for (int i = 0; i < 3; ++i) r.c[i] = a.c[i] * f; return r; }
+static inline spec s_divf(spec a, float f) { spec r; for (int i = 0; i < 3; ++i) r.c[i] = a.c[i] / f; return r; }
+static inline int s_nonzero(spec a) { return a.c[0] != 0 || a.c[1] != 0 || a.c[2] != 0; }
+/* util/spectrum.h:288-294 */
+static inline float s_avg(spec a) { float sum = a.c[0]; sum += a.c[1]; sum += a.c[2]; return sum / 3; }
+static inline float s_max(spec a) { float m = a.c[0]; m = fmaxf(m, a.c[1]); m = fmaxf(m, a.c[2]); return m; }
+static inline spec s_clamp_zero(spec a) { spec r; for (int i = 0; i < 3; ++i) r.c[i] = fmaxf(0.f, a.c[i]); return r; }
+static inline int s_has_nan(spec a) { return isnan(a.c[0]) || isnan(a.c[1]) || isnan(a.c[2]); }
+static inline int s_has_inf(spec a) { return isinf(a.c[0]) || isinf(a.c[1]) || isinf(a.c[2]); }
+
+/* ------------------------------------------------------------------------------------ */
+/* a2: hashing (src/pbrt/util/hash.h:19-107)                                              */
+/* ------------------------------------------------------------------------------------ */
+uint64_t oracle_murmur64a(const unsigned char *key, size_t len, uint64_t seed) {
+    const uint64_t m = 0xc6a4a7935bd1e995ull;
+    const int r = 47;
+    uint64_t h = seed ^ (len * m);
+    const unsigned char *end = key + 8 * (len / 8);
+    while (key != end) {
+        uint64_t k;
+        memcpy(&k, key, 8);
+        key += 8;
+        k *= m;
+        k ^= k >> r;
+        k *= m;
+        h ^= k;
+        h *= m;
+    }
+    switch (len & 7) {
+    case 7: h ^= (uint64_t)key[6] << 48; /* fallthrough */
+    case 6: h ^= (uint64_t)key[5] << 40; /* fallthrough */
+    case 5: h ^= (uint64_t)key[4] << 32; /* fallthrough */
+    case 4: h ^= (uint64_t)key[3] << 24; /* fallthrough */
+    case 3: h ^= (uint64_t)key[2] << 16; /* fallthrough */
+    case 2: h ^= (uint64_t)key[1] << 8;  /* fallthrough */
+    case 1: h ^= (uint64_t)key[0]; h *= m;
+    }
+    h ^= h >> r;
+    h *= m;
+    h ^= h >> r;
+    return h;
+}
+/* hash.h:70-77 */
+uint64_t oracle_mix_bits(uint64_t v) {
+    v ^= (v >> 31);
+    v *= 0x7fb5d329728ea185ull;
+    v ^= (v >> 27);
+    v *= 0x81dadef4bc2dd44dull;
+    v ^= (v >> 33);
+    return v;
+}
+/* Hash(args...) (hash.h:96-103): the arguments are memcpy'd back to back, seed 0 */
+uint64_t oracle_hash_float(float f) { return oracle_murmur64a((const unsigned char *)&f, 4, 0); }
+uint64_t oracle_hash_pixel_seed(int32_t x, int32_t y, int32_t seed) {
+    int32_t buf[3] = {x, y, seed};
+    return oracle_murmur64a((const unsigned char *)buf, 12, 0);
+}
+uint64_t oracle_hash_point3(float x, float y, float z) {
+    float buf[3] = {x, y, z};
+    return oracle_murmur64a((const unsigned char *)buf, 12, 0);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a1: PCG32 RNG (src/pbrt/util/rng.h:30-150)                                             */
+/* ------------------------------------------------------------------------------------ */
+#define PCG32_MULT 0x5851f42d4c957f2dULL
+typedef struct { uint64_t state, inc; } rng_t;
+
+static inline uint32_t rng_u32(rng_t *r) { /* rng.h:82-88 */
+    uint64_t oldstate = r->state;
+    r->state = oldstate * PCG32_MULT + r->inc;
+    uint32_t xorshifted = (uint32_t)(((oldstate >> 18u) ^ oldstate) >> 27u);
+    uint32_t rot = (uint32_t)(oldstate >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+}
+static inline void rng_set_sequence2(rng_t *r, uint64_t seq, uint64_t seed) { /* rng.h:119-125 */
+    r->state = 0u;
+    r->inc = (seq << 1u) | 1u;
+    rng_u32(r);
+    r->state += seed;
+    rng_u32(r);
+}
+static inline void rng_set_sequence1(rng_t *r, uint64_t seq) { /* rng.h:43-45 */
+    rng_set_sequence2(r, seq, oracle_mix_bits(seq));
+}
+static inline float rng_float(rng_t *r) { /* rng.h:128-130 */
+    float f = (float)rng_u32(r) * 0x1p-32f;
+    return f < ONE_MINUS_EPS ? f : ONE_MINUS_EPS;
+}
+static inline void rng_advance(rng_t *r, int64_t idelta) { /* rng.h:137-150 */
+    uint64_t curMult = PCG32_MULT, curPlus = r->inc, accMult = 1u;
+    uint64_t accPlus = 0u, delta = (uint64_t)idelta;
+    while (delta > 0) {
+        if (delta & 1) {
+            accMult *= curMult;
+            accPlus = accPlus * curMult + curPlus;
+        }
+        curPlus = (curMult + 1) * curPlus;
+        curMult *= curMult;
+        delta /= 2;
+    }
+    r->state = accMult * r->state + accPlus;
+}
+void oracle_rng_seq(uint64_t seq, uint64_t seed, int has_seed, int64_t advance, int n,
+                    uint32_t *out_u32, float *out_f) {
+    rng_t a, b;
+    if (has_seed) rng_set_sequence2(&a, seq, seed); else rng_set_sequence1(&a, seq);
+    rng_advance(&a, advance);
+    b = a;
+    for (int i = 0; i < n; ++i) {
+        if (out_u32) out_u32[i] = rng_u32(&a);
+        if (out_f) out_f[i] = rng_float(&b);
+    }
+}
+
+/* IndependentSampler (src/pbrt/samplers.h:442-476) */
+typedef struct { rng_t rng; } sampler_t;
+static inline void sampler_start_pixel_sample(sampler_t *s, int32_t px, int32_t py, int32_t seed,
+                                              int sampleIndex, int dimension) {
+    rng_set_sequence1(&s->rng, oracle_hash_pixel_seed(px, py, seed));
+    rng_advance(&s->rng, (int64_t)((uint64_t)sampleIndex * 65536ull + (uint64_t)dimension));
+}
+static inline float sampler_get1d(sampler_t *s) { return rng_float(&s->rng); }
+void oracle_independent_sampler(int32_t px, int32_t py, int32_t seed, int32_t sampleIndex, int n,
+                                float *out) {
+    sampler_t s;
+    sampler_start_pixel_sample(&s, px, py, seed, sampleIndex, 0);
+    for (int i = 0; i < n; ++i) out[i] = sampler_get1d(&s);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a3: FastExp / SampleExponential / SampleDiscrete                                       */
+/* ------------------------------------------------------------------------------------ */
+static inline uint32_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float b2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+/* util/math.h:450-474 (CPU branch) */
+float oracle_fast_exp(float x) {
+    float xp = x * 1.442695041f;
+    float fxp = floorf(xp), f = xp - fxp;
+    int i = (int)fxp;
+    /* EvaluatePolynomial(f, 1, c1, c2, c3) = FMA(f, FMA(f, FMA(f, c3, c2), c1), 1) (math.h:334-337) */
+    float twoToF = fmaf(f, fmaf(f, fmaf(f, 0.0781455737f, 0.226173572f), 0.695556856f), 1.f);
+    int exponent = (int)((f2b(twoToF) >> 23) & 0xff) - 127 + i; /* Exponent(), util/float.h */
+    if (exponent < -126) return 0;
+    if (exponent > 127) return INFINITY;
+    uint32_t bits = f2b(twoToF);
+    bits &= 0x807fffffu;
+    bits |= (uint32_t)(exponent + 127) << 23;
+    return b2f(bits);
+}
+static inline spec s_fast_exp(spec a) { spec r; for (int i = 0; i < 3; ++i) r.c[i] = oracle_fast_exp(a.c[i]); return r; }
+/* util/sampling.h:222-225 -- float log */
+float oracle_sample_exponential(float u, float a) { return -logf(1 - u) / a; }
+/* util/float.h:164-193 */
+static inline float next_float_up(float v) {
+    if (isinf(v) && v > 0.f) return v;
+    if (v == -0.f) v = 0.f;
+    uint32_t ui = f2b(v);
+    if (v >= 0) ++ui; else --ui;
+    return b2f(ui);
+}
+static inline float next_float_down(float v) {
+    if (isinf(v) && v < 0.f) return v;
+    if (v == 0.f) v = -0.f;
+    uint32_t ui = f2b(v);
+    if (v > 0) --ui; else ++ui;
+    return b2f(ui);
+}
+/* util/sampling.h:79-113 for two weights */
+int oracle_sample_discrete2(float w0, float w1, float u) {
+    float weights[2] = {w0, w1};
+    float sumWeights = 0;
+    sumWeights += w0;
+    sumWeights += w1;
+    float up = u * sumWeights;
+    if (up == sumWeights) up = next_float_down(up);
+    int offset = 0;
+    float sum = 0;
+    while (sum + weights[offset] <= up) sum += weights[offset++];
+    return offset;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a4: Henyey-Greenstein + direction sampling                                             */
+/* ------------------------------------------------------------------------------------ */
+/* util/scattering.h:50-59 */
+float oracle_henyey_greenstein(float cosTheta, float g) {
+    g = clampf(g, (float)-.99, (float).99);
+    float denom = 1 + sqr(g) + 2 * g * cosTheta;
+    return INV_4PI_F * (1 - sqr(g)) / (denom * safe_sqrt(denom));
+}
+/* util/vecmath.h:1007-1013 */
+static inline void coordinate_system(v3 v1, v3 *v2, v3 *v3o) {
+    float sign = copysignf(1.f, v1.z);
+    float a = -1 / (sign + v1.z);
+    float b = v1.x * v1.y * a;
+    *v2 = V3(1 + sign * sqr(v1.x) * a, sign * b, -sign * v1.x);
+    *v3o = V3(b, sign + sqr(v1.y) * a, -v1.y);
+}
+void oracle_coordinate_system(const float v[3], float v2[3], float v3o[3]) {
+    v3 a, b;
+    coordinate_system(v3_from(v), &a, &b);
+    v2[0] = a.x; v2[1] = a.y; v2[2] = a.z;
+    v3o[0] = b.x; v3o[1] = b.y; v3o[2] = b.z;
+}
+typedef struct { v3 x, y, z; } frame_t;
+/* Frame::FromLocal (vecmath.h:1914): v.x*x + v.y*y + v.z*z */
+static inline v3 frame_from_local(const frame_t *f, v3 v) {
+    return v_add(v_add(v_scale(f->x, v.x), v_scale(f->y, v.y)), v_scale(f->z, v.z));
+}
+static inline v3 frame_to_local(const frame_t *f, v3 v) { return V3(v_dot(v, f->x), v_dot(v, f->y), v_dot(v, f->z)); }
+/* util/vecmath.h:1666-1672 */
+static inline v3 spherical_direction(float sinTheta, float cosTheta, float phi) {
+    return V3(clampf(sinTheta, -1, 1) * cosf(phi), clampf(sinTheta, -1, 1) * sinf(phi),
+              clampf(cosTheta, -1, 1));
+}
+/* util/sampling.cpp:348-374 */
+static v3 sample_henyey_greenstein(v3 wo, float g, float u0, float u1, float *pdf) {
+    g = clampf(g, (float)-.99, (float).99);
+    float cosTheta;
+    if (fabsf(g) < 1e-3f)
+        cosTheta = 1 - 2 * u0;
+    else
+        cosTheta = -1 / (2 * g) * (1 + sqr(g) - sqr((1 - sqr(g)) / (1 + g - 2 * g * u0)));
+    float sinTheta = safe_sqrt(1 - sqr(cosTheta));
+    float phi = 2 * PI_F * u1;
+    frame_t wFrame;
+    wFrame.z = wo;
+    coordinate_system(wo, &wFrame.x, &wFrame.y); /* Frame::FromZ (vecmath.h:1867-1871) */
+    v3 wi = frame_from_local(&wFrame, spherical_direction(sinTheta, cosTheta, phi));
+    if (pdf) *pdf = oracle_henyey_greenstein(cosTheta, g);
+    return wi;
+}
+void oracle_sample_henyey_greenstein(const float wo[3], float g, float u0, float u1, float wi[3],
+                                     float *pdf) {
+    v3 r = sample_henyey_greenstein(v3_from(wo), g, u0, u1, pdf);
+    wi[0] = r.x; wi[1] = r.y; wi[2] = r.z;
+}
+/* util/sampling.h:391-396 */
+void oracle_sample_uniform_sphere(float u0, float u1, float out[3]) {
+    float z = 1 - 2 * u0;
+    float r = safe_sqrt(1 - sqr(z));
+    float phi = 2 * PI_F * u1;
+    out[0] = r * cosf(phi); out[1] = r * sinf(phi); out[2] = z;
+}
+/* util/sampling.h:325-341, 409-413 */
+static v3 sample_cosine_hemisphere(float u0, float u1) {
+    float ox = 2 * u0 - 1, oy = 2 * u1 - 1;
+    float dx, dy;
+    if (ox == 0 && oy == 0) {
+        dx = 0; dy = 0;
+    } else {
+        float theta, r;
+        if (fabsf(ox) > fabsf(oy)) {
+            r = ox;
+            theta = PI_OVER_4_F * (oy / ox);
+        } else {
+            r = oy;
+            theta = PI_OVER_2_F - PI_OVER_4_F * (ox / oy);
+        }
+        dx = r * cosf(theta); dy = r * sinf(theta);
+    }
+    float z = safe_sqrt(1 - sqr(dx) - sqr(dy));
+    return V3(dx, dy, z);
+}
+void oracle_sample_cosine_hemisphere(float u0, float u1, float out[3]) {
+    v3 r = sample_cosine_hemisphere(u0, u1);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ray spawning (src/pbrt/ray.h:75-108)                                                   */
+/* ------------------------------------------------------------------------------------ */
+/* Point3fi (util/vecmath.h:737-760) over Interval (util/math.h:815-862): a point with
+ * error bounds is stored as [low, high] per axis; p() is the midpoint, Error() half the width. */
+typedef struct { v3 lo, hi; } p3i;
+static inline p3i p3i_exact(v3 p) { p3i r = {p, p}; return r; }
+static inline void interval_from_value_and_error(float v, float err, float *lo, float *hi) {
+    if (err == 0) { *lo = *hi = v; }
+    else { *lo = next_float_down(v - err); *hi = next_float_up(v + err); } /* SubRoundDown / AddRoundUp */
+}
+static inline p3i p3i_from_err(v3 p, v3 e) {
+    p3i r;
+    interval_from_value_and_error(p.x, e.x, &r.lo.x, &r.hi.x);
+    interval_from_value_and_error(p.y, e.y, &r.lo.y, &r.hi.y);
+    interval_from_value_and_error(p.z, e.z, &r.lo.z, &r.hi.z);
+    return r;
+}
+static inline v3 p3i_mid(p3i a) { return V3((a.lo.x + a.hi.x) / 2, (a.lo.y + a.hi.y) / 2, (a.lo.z + a.hi.z) / 2); }
+static inline v3 p3i_err(p3i a) { return V3((a.hi.x - a.lo.x) / 2, (a.hi.y - a.lo.y) / 2, (a.hi.z - a.lo.z) / 2); }
+
+static v3 offset_ray_origin(p3i pi, v3 n, v3 w) {
+    float d = v_dot(v_abs(n), p3i_err(pi));
+    v3 offset = v_scale(n, d);
+    if (v_dot(w, n) < 0) offset = v_neg(offset);
+    v3 po = v_add(p3i_mid(pi), offset);
+    float *o = &offset.x, *q = &po.x;
+    for (int i = 0; i < 3; ++i) {
+        if (o[i] > 0) q[i] = next_float_up(q[i]);
+        else if (o[i] < 0) q[i] = next_float_down(q[i]);
+    }
+    return po;
+}
+void oracle_offset_ray_origin(const float p[3], const float perr[3], const float n[3],
+                              const float w[3], float out[3]) {
+    v3 r = offset_ray_origin(p3i_from_err(v3_from(p), v3_from(perr)), v3_from(n), v3_from(w));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* scene: rectangles standing in for "bilinearmesh" quads (out-of-scope geometry restated */
+/* minimally; the formulas follow the cited pbrt code)            */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    v3 p00, p10, p01, p11, e1, e2;
+    v3 n;          /* Normalize(Cross(e1,e2)), negated if reverse_orientation */
+    v3 dpdu_n;     /* Normalize(e1): BSDF shading frame x (bsdf.h:25-26) */
+    v3 perr;       /* gamma(6) * (|p00|+|p01|+|p10|+|p11|) (shapes.cpp:1207-1208) */
+    float inv_l1, inv_l2; /* 1/|e1|^2, 1/|e2|^2 */
+    float area;
+    spec Kd, Le;
+    int two_sided, is_light, has_bsdf_lobes;
+} rquad_t;
+
+typedef struct {
+    int hit;
+    float t;
+    int quad;
+    v3 p, n;
+} isect_t;
+
+static void quad_init(rquad_t *q, const VspgQuad *in) {
+    q->p00 = v3_from(in->p00);
+    q->e1 = v3_from(in->e1);
+    q->e2 = v3_from(in->e2);
+    q->p10 = v_add(q->p00, q->e1);
+    q->p01 = v_add(q->p00, q->e2);
+    q->p11 = v_add(q->p10, q->e2);
+    v3 c = v_cross(q->e1, q->e2);
+    q->area = v_len(c);
+    q->n = v_normalize(c);
+    if (in->reverse_orientation) q->n = v_neg(q->n);
+    q->dpdu_n = v_normalize(q->e1);
+    float g6 = (6 * MACHINE_EPS) / (1 - 6 * MACHINE_EPS); /* gamma(6), util/float.h:195 */
+    v3 s = v_add(v_add(v_abs(q->p00), v_abs(q->p01)), v_add(v_abs(q->p10), v_abs(q->p11)));
+    q->perr = v_scale(s, g6);
+    q->inv_l1 = 1.f / v_len2(q->e1);
+    q->inv_l2 = 1.f / v_len2(q->e2);
+    q->Kd = s_from(in->Kd);
+    for (int i = 0; i < 3; ++i) q->Kd.c[i] = clampf(q->Kd.c[i], 0, 1); /* DiffuseMaterial clamps R */
+    q->Le = s_from(in->Le);
+    q->two_sided = in->two_sided;
+    q->is_light = s_nonzero(q->Le);
+    q->has_bsdf_lobes = s_nonzero(q->Kd); /* DiffuseBxDF::Flags (bxdfs.h:82-84) */
+}
+
+/* ray / rectangle: plane hit, then parametric (u,v) test; the reported point is re-projected
+ * onto the rectangle (p00 + u e1 + v e2) as pbrt does for bilinear patches
+ * (shapes.h InteractionFromIntersection). */
+static int quad_intersect(const rquad_t *q, v3 o, v3 d, float tMax, float *tHit, v3 *pHit) {
+    float denom = v_dot(q->n, d);
+    if (denom == 0) return 0;
+    float t = v_dot(q->n, v_sub(q->p00, o)) / denom;
+    if (!(t > 0) || !(t < tMax)) return 0;
+    v3 p = v_add(o, v_scale(d, t));
+    v3 rel = v_sub(p, q->p00);
+    float u = v_dot(rel, q->e1) * q->inv_l1;
+    float v = v_dot(rel, q->e2) * q->inv_l2;
+    if (u < 0 || u > 1 || v < 0 || v > 1) return 0;
+    *tHit = t;
+    *pHit = v_add(q->p00, v_add(v_scale(q->e1, u), v_scale(q->e2, v)));
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* renderer state                                                                         */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    spec sigma_a, sigma_s, Le;
+    float g; /* HG phase */
+} medium_props_t; /* MediumProperties, media.h:77-82 */
+
+struct OracleRenderer {
+    VspgScene scene;
+    VspgIntegratorParams prm;
+    VspgRenderConfig cfg;
+    int n_quads;
+    rquad_t quads[VSPG_MAX_QUADS];
+    int n_lights;
+    int light_quads[VSPG_MAX_QUADS];
+    /* film: RGBFilm::Pixel (film.h:314-318) */
+    double *film; /* W*H*4 */
+    /* image-space VSP buffer (own design; OpenPGL absent) */
+    float *isg_stats; /* W*H*VSPG_ISG_STATS */
+    float *vsp;       /* W*H */
+    int vsp_ready;
+    int wave_counter, buffer_wave;
+    VspgCounters counters;
+};
+
+typedef struct { /* LightSampleContext (base/light.h) */
+    p3i pi;
+    v3 n, ns;
+} lsctx_t;
+
+typedef struct {
+    uint64_t segments, volume_scatters, surface_hits, density_queries, shadow_rays;
+} path_counters_t;
+
+typedef struct {
+    int valid;        /* an event was recorded */
+    int surface_event;
+    float vsp_used;   /* clamped primary VSP used on the first segment, -1 if unguided */
+} isg_sample_t;
+
+/* closest hit over all quads (stands in for Integrator::Intersect, integrators.cpp:341-349) */
+static isect_t scene_intersect(const OracleRenderer *r, v3 o, v3 d, float tMax) {
+    isect_t best;
+    memset(&best, 0, sizeof best);
+    best.t = tMax;
+    for (int i = 0; i < r->n_quads; ++i) {
+        float t;
+        v3 p;
+        if (quad_intersect(&r->quads[i], o, d, best.t, &t, &p)) {
+            best.hit = 1; best.t = t; best.quad = i; best.p = p; best.n = r->quads[i].n;
+        }
+    }
+    return best;
+}
+static int scene_intersect_any(const OracleRenderer *r, v3 o, v3 d, float tMax) {
+    for (int i = 0; i < r->n_quads; ++i) {
+        float t;
+        v3 p;
+        if (quad_intersect(&r->quads[i], o, d, tMax, &t, &p)) return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a5/a6: media -- majorant iterators                                                     */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { float tMin, tMax; spec sigma_maj; } majseg_t; /* RayMajorantSegment */
+typedef struct {
+    int type;
+    int called;   /* HomogeneousMajorantIterator (media.h:84-106) */
+    majseg_t seg;
+} majiter_t;
+
+static int majiter_next(majiter_t *it, majseg_t *seg) {
+    if (it->type == VSPG_MEDIUM_HOMOGENEOUS) {
+        if (it->called) return 0;
+        it->called = 1;
+        *seg = it->seg;
+        return 1;
+    }
+    return 0;
+}
+/* Medium::SampleRay: HomogeneousMedium (media.h:263-269) */
+static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tMax) {
+    majiter_t it;
+    memset(&it, 0, sizeof it);
+    const VspgMedium *m = &r->scene.medium;
+    it.type = m->type;
+    (void)o; (void)d;
+    if (m->type == VSPG_MEDIUM_HOMOGENEOUS) {
+        it.called = 0;
+        it.seg.tMin = 0;
+        it.seg.tMax = tMax;
+        it.seg.sigma_maj = s_add(s_from(m->sigma_a), s_from(m->sigma_s));
+    } else {
+        it.called = 1;
+    }
+    return it;
+}
+/* Medium::SamplePoint: HomogeneousMedium (media.h:256-261) */
+static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
+    medium_props_t mp;
+    const VspgMedium *m = &r->scene.medium;
+    (void)p;
+    mp.sigma_a = s_from(m->sigma_a);
+    mp.sigma_s = s_from(m->sigma_s);
+    mp.Le = s_from(m->Le);
+    mp.g = m->g;
+    return mp;
+}
+static int medium_is_homogeneous(const OracleRenderer *r) { return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS; }
+
+/* ------------------------------------------------------------------------------------ */
+/* a7: SampleT_maj (src/pbrt/media_sampleTMaj.h:49-117)                                   */
+/* ------------------------------------------------------------------------------------ */
+typedef int (*tmaj_cb_t)(void *ctx, v3 p, const medium_props_t *mp, spec sigma_maj, spec T_maj,
+                         int activateNDS);
+
+static spec sample_T_maj(const OracleRenderer *r, v3 ro, v3 rd, float tMax, float u, rng_t *rng,
+                         int ch, tmaj_cb_t cb, void *cbctx) {
+    tMax *= v_len(rd);
+    rd = v_normalize(rd);
+    majiter_t iter = medium_sample_ray(r, ro, rd, tMax);
+    spec T_maj = S1(1.f);
+    int done = 0;
+    while (!done) {
+        majseg_t seg;
+        if (!majiter_next(&iter, &seg)) return T_maj;
+        if (seg.sigma_maj.c[ch] == 0) {
+            float dt = seg.tMax - seg.tMin;
+            if (isinf(dt)) dt = FLT_MAX;
+            T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -dt)));
+            continue;
+        }
+        float tMin = seg.tMin;
+        while (1) {
+            float t = tMin + oracle_sample_exponential(u, seg.sigma_maj.c[ch]);
+            u = rng_float(rng);
+            if (t < seg.tMax) {
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -(t - tMin))));
+                v3 p = v_add(ro, v_scale(rd, t));
+                medium_props_t mp = medium_sample_point(r, p);
+                if (!cb(cbctx, p, &mp, seg.sigma_maj, T_maj, 0)) {
+                    done = 1;
+                    break;
+                }
+                T_maj = S1(1.f);
+                tMin = t;
+            } else {
+                float dt = seg.tMax - tMin;
+                if (isinf(dt)) dt = FLT_MAX;
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -dt)));
+                break;
+            }
+        }
+    }
+    return S1(1.f);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a9: SampleT_maj_Resampling (media_sampleTMaj.h:136-248)                                */
+/* ------------------------------------------------------------------------------------ */
+static spec sample_T_maj_resampling(const OracleRenderer *r, v3 ro, v3 rd, float tMax, float u,
+                                    rng_t *rng, int ch, int guide, float vsp, float *vrc,
+                                    float *majorantScale, tmaj_cb_t cb, void *cbctx) {
+    tMax *= v_len(rd);
+    rd = v_normalize(rd);
+    majiter_t iter = medium_sample_ray(r, ro, rd, tMax);
+    majiter_t pre = iter;
+    float totalLength = 0.f;
+    while (1) {
+        majseg_t seg;
+        if (!majiter_next(&pre, &seg)) break;
+        if (seg.sigma_maj.c[ch] == 0) continue;
+        totalLength += seg.sigma_maj.c[ch] * (seg.tMax - seg.tMin);
+    }
+    if (totalLength == 0.f) return S1(1.f);
+    *majorantScale = 1.0f;
+    *vrc = vsp;
+    if (guide) {
+        float minTotalLength = -logf(1 - vsp);
+        if (minTotalLength > totalLength) {
+            *majorantScale = minTotalLength / totalLength;
+            totalLength = minTotalLength;
+        }
+        float expNegTotalLength = oracle_fast_exp(-totalLength);
+        *vrc = vsp / (1 - expNegTotalLength);
+    }
+    spec T_maj = S1(1.f);
+    int done = 0, count = 0;
+    while (!done) {
+        majseg_t seg;
+        if (!majiter_next(&iter, &seg)) return T_maj;
+        seg.sigma_maj = s_scale(seg.sigma_maj, *majorantScale);
+        if (seg.sigma_maj.c[ch] == 0) {
+            float dt = seg.tMax - seg.tMin;
+            if (isinf(dt)) dt = FLT_MAX;
+            T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -dt)));
+            continue;
+        }
+        float tMin = seg.tMin;
+        while (1) {
+            count++;
+            float t = tMin + oracle_sample_exponential(u, seg.sigma_maj.c[ch]);
+            u = rng_float(rng);
+            if (t < seg.tMax) {
+                if (count > 10000) break;
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -(t - tMin))));
+                v3 p = v_add(ro, v_scale(rd, t));
+                medium_props_t mp = medium_sample_point(r, p);
+                if (!cb(cbctx, p, &mp, seg.sigma_maj, T_maj, 0)) {
+                    done = 1;
+                    break;
+                }
+                T_maj = S1(1.f);
+                tMin = t;
+            } else {
+                float dt = seg.tMax - tMin;
+                if (isinf(dt)) dt = FLT_MAX;
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -dt)));
+                break;
+            }
+        }
+    }
+    return S1(1.f);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a8: SampleT_maj_OpticalDepthSpace (media_sampleTMaj.h:269-491)                         */
+/* ------------------------------------------------------------------------------------ */
+static spec sample_T_maj_ods(const OracleRenderer *r, v3 ro, v3 rd, float tMax, float u, rng_t *rng,
+                             int ch, int guide, float vsp, float vspMISRatio, int NDS,
+                             spec *beta_factor, spec *r_u_factor, tmaj_cb_t cb, void *cbctx) {
+    (void)beta_factor; /* never written by the reference */
+    if (!guide || vspMISRatio == 0.f) return sample_T_maj(r, ro, rd, tMax, u, rng, ch, cb, cbctx);
+
+    v3 ro0 = ro, rd0 = rd;
+    float tMax0 = tMax;
+    tMax *= v_len(rd);
+    rd = v_normalize(rd);
+    majiter_t iter = medium_sample_ray(r, ro, rd, tMax);
+    majiter_t pre = iter;
+    float t_v = 0.f;
+    while (1) {
+        majseg_t seg;
+        if (!majiter_next(&pre, &seg)) break;
+        if (isinf(seg.tMax)) return sample_T_maj(r, ro0, rd0, tMax0, u, rng, ch, cb, cbctx);
+        if (seg.sigma_maj.c[ch] == 0) continue;
+        t_v += seg.sigma_maj.c[ch] * (seg.tMax - seg.tMin);
+    }
+    if (t_v == 0.f) return S1(1.f);
+
+    float OneMinusENegTv = 1.f - oracle_fast_exp(-t_v);
+    float t_n = -1.f, t_n_current = -1.f;
+    if (NDS) {
+        if (vsp < 1 - oracle_fast_exp(-t_v))
+            return sample_T_maj(r, ro0, rd0, tMax0, u, rng, ch, cb, cbctx);
+        else {
+            t_n = (float)(-log(1.0 - (double)(OneMinusENegTv / vsp)));
+            t_n_current = t_n;
+        }
+    }
+    spec T_maj = S1(1.f), tpScaleFactor = S1(1.f);
+    float t_v_current = t_v;
+    float remainingDist = 0;
+    int deltaTracking = 0;
+    if (u > vspMISRatio) {
+        deltaTracking = 1;
+        u = (u - vspMISRatio) / (1 - vspMISRatio);
+    } else {
+        u /= vspMISRatio;
+    }
+    int done = 0, count = 0, overTheEnd = 0;
+    const float ScatterEpsilon = 1e-5;
+    while (!done) {
+        majseg_t seg;
+        if (!majiter_next(&iter, &seg)) return T_maj;
+        if (seg.sigma_maj.c[ch] == 0 || overTheEnd) {
+            float dt = seg.tMax - seg.tMin;
+            if (isinf(dt)) dt = FLT_MAX;
+            T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -dt)));
+            continue;
+        }
+        float tMin = seg.tMin;
+        spec normalizedMaj = s_divf(seg.sigma_maj, seg.sigma_maj.c[ch]);
+
+        if (remainingDist > 0) {
+            tMin += remainingDist / seg.sigma_maj.c[ch];
+            if (tMin > seg.tMax + ScatterEpsilon) {
+                float dist = (seg.tMax - seg.tMin) * seg.sigma_maj.c[ch];
+                t_v_current -= dist;
+                t_n_current -= dist;
+                remainingDist -= dist;
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -(seg.tMax - seg.tMin))));
+                continue;
+            }
+            t_v_current -= remainingDist;
+            t_n_current -= remainingDist;
+            remainingDist = 0;
+            T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -(tMin - seg.tMin))));
+            v3 p = v_add(ro, v_scale(rd, tMin));
+            medium_props_t mp = medium_sample_point(r, p);
+            for (int i = 0; i < 3; ++i)
+                r_u_factor->c[i] = vspMISRatio / tpScaleFactor.c[i] + (1 - vspMISRatio);
+            if (!cb(cbctx, p, &mp, seg.sigma_maj, T_maj, 1)) break;
+            T_maj = S1(1.f);
+        }
+
+        while (1) {
+            count++;
+            float dist = FLT_MAX;
+            spec tpStep;
+            if (NDS) {
+                for (int i = 0; i < 3; ++i)
+                    tpStep.c[i] = 1.0f - oracle_fast_exp(-t_n_current * normalizedMaj.c[i]);
+                if (!deltaTracking) dist = (float)(-log(1.0 - (double)(u * tpStep.c[ch])));
+            } else {
+                for (int i = 0; i < 3; ++i)
+                    tpStep.c[i] = (1.0f - oracle_fast_exp(-t_v_current * normalizedMaj.c[i])) / vsp;
+                if (!deltaTracking) {
+                    if (u < vsp) dist = (float)(-log(1.0 - (double)(u * tpStep.c[ch])));
+                }
+            }
+            if (deltaTracking) dist = (float)(-log(1.0 - (double)u));
+
+            int passThrough = (t_v_current - dist < ScatterEpsilon) || dist == 0;
+            if (NDS || !passThrough) tpScaleFactor = s_mul(tpScaleFactor, tpStep);
+
+            if (passThrough) {
+                if (NDS) {
+                    tpScaleFactor = s_divf(tpScaleFactor, 1.0f - oracle_fast_exp(-t_n + t_v));
+                } else {
+                    spec e;
+                    for (int i = 0; i < 3; ++i)
+                        e.c[i] = oracle_fast_exp(-t_v_current * normalizedMaj.c[i]) / (1 - vsp);
+                    tpScaleFactor = s_mul(tpScaleFactor, e);
+                }
+                for (int i = 0; i < 3; ++i)
+                    r_u_factor->c[i] = vspMISRatio / tpScaleFactor.c[i] + (1 - vspMISRatio);
+                overTheEnd = 1;
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -(seg.tMax - tMin))));
+                break;
+            }
+
+            float t = tMin + dist / seg.sigma_maj.c[ch];
+            u = rng_float(rng);
+            if (t <= seg.tMax + ScatterEpsilon) {
+                if (count > 10000) break;
+                t_v_current -= dist;
+                t_n_current -= dist;
+                remainingDist = 0;
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -(t - tMin))));
+                v3 p = v_add(ro, v_scale(rd, t));
+                medium_props_t mp = medium_sample_point(r, p);
+                for (int i = 0; i < 3; ++i)
+                    r_u_factor->c[i] = vspMISRatio / tpScaleFactor.c[i] + (1 - vspMISRatio);
+                if (!cb(cbctx, p, &mp, seg.sigma_maj, T_maj, 1)) {
+                    done = 1;
+                    break;
+                }
+                T_maj = S1(1.f);
+                tMin = t;
+            } else {
+                float dt = seg.tMax - tMin;
+                if (isinf(dt)) dt = FLT_MAX;
+                T_maj = s_mul(T_maj, s_fast_exp(s_scale(seg.sigma_maj, -dt)));
+                float distWithinThisSeg = dt * seg.sigma_maj.c[ch];
+                remainingDist = dist - distWithinThisSeg;
+                t_v_current -= distWithinThisSeg;
+                t_n_current -= distWithinThisSeg;
+                break;
+            }
+        }
+    }
+    return S1(1.f);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* surface scattering: DiffuseBxDF behind BSDF (bxdfs.h:31-80, bsdf.h:20-88)              */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    frame_t frame; /* Frame::FromXZ(Normalize(dpdus), ns) (vecmath.h:1862) */
+    spec R;
+    int has_lobes;
+} bsdf_t;
+
+static bsdf_t bsdf_make(const rquad_t *q) {
+    bsdf_t b;
+    b.frame.x = q->dpdu_n;
+    b.frame.z = q->n;
+    b.frame.y = v_cross(q->n, q->dpdu_n);
+    b.R = q->Kd;
+    b.has_lobes = q->has_bsdf_lobes;
+    return b;
+}
+static spec bsdf_f(const bsdf_t *b, v3 woR, v3 wiR) {
+    v3 wi = frame_to_local(&b->frame, wiR), wo = frame_to_local(&b->frame, woR);
+    if (wo.z == 0) return S1(0.f);
+    if (!(wi.z * wo.z > 0)) return S1(0.f); /* SameHemisphere */
+    return s_scale(b->R, INV_PI_F);
+}
+static float bsdf_pdf(const bsdf_t *b, v3 woR, v3 wiR) {
+    v3 wo = frame_to_local(&b->frame, woR), wi = frame_to_local(&b->frame, wiR);
+    if (wo.z == 0) return 0;
+    if (!b->has_lobes) return 0;
+    if (!(wi.z * wo.z > 0)) return 0;
+    return fabsf(wi.z) * INV_PI_F; /* CosineHemispherePDF(AbsCosTheta) */
+}
+/* returns 0 if no sample */
+static int bsdf_sample_f(const bsdf_t *b, v3 woR, float uc, float u0, float u1, spec *f, v3 *wiR,
+                         float *pdf) {
+    (void)uc;
+    v3 wo = frame_to_local(&b->frame, woR);
+    if (wo.z == 0 || !b->has_lobes) return 0;
+    v3 wi = sample_cosine_hemisphere(u0, u1);
+    if (wo.z < 0) wi.z *= -1;
+    *pdf = fabsf(wi.z) * INV_PI_F;
+    *f = s_scale(b->R, INV_PI_F);
+    if (!s_nonzero(*f) || *pdf == 0 || wi.z == 0) return 0;
+    *wiR = frame_from_local(&b->frame, wi);
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* lights: DiffuseAreaLight on a rectangle, sampled uniformly by area                     */
+/* (lights.cpp:796-820; shapes.cpp:1155-1212 + area->solid-angle branch :1267-1283)       */
+/* ------------------------------------------------------------------------------------ */
+static spec light_L(const rquad_t *q, v3 n, v3 w) { /* lights.h:492-511 */
+    if (!q->two_sided && v_dot(n, w) < 0) return S1(0.f);
+    return q->Le;
+}
+typedef struct { spec L; v3 wi; float pdf; p3i pLight; v3 nLight; } lightli_t;
+
+static int light_sample_li(const rquad_t *q, v3 ctxp, float u0, float u1, lightli_t *ls) {
+    /* BilinearPatch::Sample(u), rectangle branch: uv = u */
+    v3 pu0 = v_lerp(u1, q->p00, q->p01), pu1 = v_lerp(u1, q->p10, q->p11);
+    v3 p = v_lerp(u0, pu0, pu1);
+    v3 dpdu = v_sub(pu1, pu0);
+    v3 dpdv = v_sub(v_lerp(u0, q->p01, q->p11), v_lerp(u0, q->p00, q->p10));
+    if (v_len2(dpdu) == 0 || v_len2(dpdv) == 0) return 0;
+    v3 c = v_cross(dpdu, dpdv);
+    v3 n = v_normalize(c);
+    if (v_dot(n, q->n) < 0) n = v_neg(n); /* reverseOrientation flip */
+    float pdf = 1 / v_len(c);
+    p3i pint = p3i_from_err(p, q->perr); /* Interaction(Point3fi(p, pError), n, st) */
+    p = p3i_mid(pint);                   /* ss->intr.p() */
+    /* area -> solid angle (shapes.cpp:1271-1281) */
+    v3 wi = v_sub(p, ctxp);
+    if (v_len2(wi) == 0) return 0;
+    wi = v_normalize(wi);
+    v3 d = v_sub(ctxp, p);
+    pdf /= v_absdot(n, v_neg(wi)) / v_len2(d);
+    if (isinf(pdf)) return 0;
+    /* DiffuseAreaLight::SampleLi */
+    if (pdf == 0) return 0;
+    spec Le = light_L(q, n, v_neg(wi));
+    if (!s_nonzero(Le)) return 0;
+    ls->L = Le; ls->wi = wi; ls->pdf = pdf; ls->pLight = pint; ls->nLight = n;
+    return 1;
+}
+/* DiffuseAreaLight::PDF_Li -> BilinearPatch::PDF(ctx, wi), area branch (shapes.cpp:1329-1352) */
+static float light_pdf_li(const rquad_t *q, const lsctx_t *ctx, v3 wi) {
+    v3 o = offset_ray_origin(ctx->pi, ctx->n, wi);
+    float t;
+    v3 p;
+    if (!quad_intersect(q, o, wi, INFINITY, &t, &p)) return 0;
+    p = p3i_mid(p3i_from_err(p, q->perr));
+    v3 d = v_sub(p3i_mid(ctx->pi), p);
+    float pdf = (1 / q->area) * (v_len2(d) / v_absdot(q->n, v_neg(wi)));
+    return isinf(pdf) ? 0 : pdf;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a15: SampleLd (guidedvolpathvspgintegrator.cpp:1136-1252), guiding distributions        */
+/* inactive (field untrained => GuidedBSDF/GuidedPhaseFunction fall through to the plain   */
+/* BSDF / phase function, guiding.h:115-118,271-289,400-402,542-558)                       */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    const OracleRenderer *r;
+    int ch;
+    spec T_ray, r_l, r_u;
+    rng_t *rng;
+} shadow_cb_ctx_t;
+
+static int shadow_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, spec T_maj, int nds) {
+    (void)p; (void)nds;
+    shadow_cb_ctx_t *c = (shadow_cb_ctx_t *)vctx;
+    spec sigma_n = s_clamp_zero(s_sub(s_sub(sigma_maj, mp->sigma_a), mp->sigma_s));
+    float pdf = T_maj.c[c->ch] * sigma_maj.c[c->ch];
+    c->T_ray = s_mul(c->T_ray, s_divf(s_mul(T_maj, sigma_n), pdf));
+    c->r_l = s_mul(c->r_l, s_divf(s_mul(T_maj, sigma_maj), pdf));
+    c->r_u = s_mul(c->r_u, s_divf(s_mul(T_maj, sigma_n), pdf));
+    spec Tr = s_divf(c->T_ray, s_avg(s_add(c->r_l, c->r_u)));
+    if (s_max(Tr) < 0.05f) {
+        float q = 0.75f;
+        if (rng_float(c->rng) < q)
+            c->T_ray = S1(0.f);
+        else
+            c->T_ray = s_divf(c->T_ray, 1 - q);
+    }
+    if (!s_nonzero(c->T_ray)) return 0;
+    return 1;
+}
+
+typedef struct {
+    int is_surface;
+    p3i pi;        /* interaction point with error bounds (exact for medium interactions) */
+    v3 n;          /* geometric normal (0 for medium) */
+    v3 wo;
+    const bsdf_t *bsdf; /* surface */
+    float g;            /* medium: HG */
+} intr_t;
+
+static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, int ch, sampler_t *sampler,
+                      spec r_p, path_counters_t *pc) {
+    /* LightSampleContext */
+    v3 ctxp = p3i_mid(intr->pi);
+    if (intr->is_surface) {
+        /* reflective-only BSDF: ctx.pi = intr.OffsetRayOrigin(intr.wo) (:1147-1149) */
+        if (intr->bsdf->has_lobes) ctxp = offset_ray_origin(intr->pi, intr->n, intr->wo);
+    }
+    float u = sampler_get1d(sampler);
+    /* UniformLightSampler::Sample (lightsamplers.h:33-38) */
+    int have_light = r->n_lights > 0;
+    int lightIndex = 0;
+    float lightPmf = 0;
+    if (have_light) {
+        int li = (int)(u * (float)r->n_lights);
+        lightIndex = li < r->n_lights - 1 ? li : r->n_lights - 1;
+        lightPmf = 1.f / (float)r->n_lights;
+    }
+    float ul0 = sampler_get1d(sampler), ul1 = sampler_get1d(sampler);
+    if (!have_light) return S1(0.f);
+    const rquad_t *lq = &r->quads[r->light_quads[lightIndex]];
+    lightli_t ls;
+    if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return S1(0.f);
+    float p_l = lightPmf * ls.pdf;
+
+    float scatterPDF;
+    spec f_hat;
+    v3 wo = intr->wo, wi = ls.wi;
+    if (intr->is_surface) {
+        f_hat = s_scale(bsdf_f(intr->bsdf, wo, wi), v_absdot(wi, intr->n));
+        scatterPDF = 1.0f * bsdf_pdf(intr->bsdf, wo, wi);
+    } else {
+        f_hat = S1(oracle_henyey_greenstein(v_dot(wo, wi), intr->g));
+        scatterPDF = 1.0f * oracle_henyey_greenstein(v_dot(wo, wi), intr->g);
+    }
+    if (!s_nonzero(f_hat)) return S1(0.f);
+
+    /* lightRay = intr.SpawnRayTo(ls->pLight) (interaction.h:111-115, ray.h:103-108) */
+    v3 pf = offset_ray_origin(intr->pi, intr->n, v_sub(p3i_mid(ls.pLight), p3i_mid(intr->pi)));
+    v3 pt = offset_ray_origin(ls.pLight, ls.nLight, v_sub(pf, p3i_mid(ls.pLight)));
+    v3 lo = pf, ld = v_sub(pt, pf);
+    spec T_ray = S1(1.f), r_l = S1(1.f), r_u = S1(1.f);
+    rng_t rng;
+    rng_set_sequence2(&rng, oracle_hash_point3(lo.x, lo.y, lo.z), oracle_hash_point3(ld.x, ld.y, ld.z));
+    if (pc) pc->shadow_rays++;
+    if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
+        /* every surface in this scene has a material: any hit is an opaque blocker (:1197-1200) */
+        if (scene_intersect_any(r, lo, ld, 1 - SHADOW_EPS)) return S1(0.f);
+        if (r->scene.medium.type != VSPG_MEDIUM_NONE) {
+            float tMax = 1 - SHADOW_EPS;
+            float us = rng_float(&rng);
+            shadow_cb_ctx_t c;
+            c.r = r; c.ch = ch; c.T_ray = T_ray; c.r_l = r_l; c.r_u = r_u; c.rng = &rng;
+            spec T_maj = sample_T_maj(r, lo, ld, tMax, us, &rng, ch, shadow_cb, &c);
+            T_ray = c.T_ray; r_l = c.r_l; r_u = c.r_u;
+            T_ray = s_mul(T_ray, s_divf(T_maj, T_maj.c[ch]));
+            r_l = s_mul(r_l, s_divf(T_maj, T_maj.c[ch]));
+            r_u = s_mul(r_u, s_divf(T_maj, T_maj.c[ch]));
+        }
+        if (!s_nonzero(T_ray)) return S1(0.f);
+    }
+    r_l = s_mul(r_l, s_scale(r_p, p_l));
+    r_u = s_mul(r_u, s_scale(r_p, scatterPDF));
+    /* area light is not a delta light */
+    return s_divf(s_mul(s_mul(f_hat, T_ray), ls.L), s_avg(s_add(r_l, r_u)));
+}
+
+/* StandardThroughputBasedRussianRoulette lives in OpenPGL (absent; SURVEY.md App. A.5
+ * "[unverified]"): restated as pbrt's own rule q = max(0, 1 - maxComponent)
+ * (cf. the commented-out rrBeta code at guidedvolpathvspgintegrator.cpp:594-596). UNPINNED. */
+static float standard_throughput_rr(spec w) {
+    float m = s_max(w);
+    return fminf(1.f, fmaxf(0.f, m));
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a10-a13: SampleDistance (guidedvolpathvspgintegrator.cpp:637-1096)                     */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    const OracleRenderer *r;
+    int ch;
+    sampler_t *sampler;
+    rng_t *rng;
+    /* path state by reference */
+    v3 *ray_o, *ray_d;
+    int *depth;
+    spec *L, *beta, *r_u, *r_l;
+    int *specularBounce, *anyNonSpecularBounces, *lastVertexVolume;
+    lsctx_t *prevIntrCtx;
+    int scattered, terminated;
+    float rr_correction; /* by value */
+    spec beta_factor, r_u_factor;
+    isg_sample_t *isg;
+    path_counters_t *pc;
+} sd_ctx_t;
+
+/* volume-scatter tail shared by both branches (:804-875 == :988-1058) */
+static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
+    const OracleRenderer *r = c->r;
+    if (s_nonzero(*c->beta) && s_nonzero(*c->r_u)) {
+        intr_t intr;
+        memset(&intr, 0, sizeof intr);
+        intr.is_surface = 0;
+        intr.pi = p3i_exact(p);
+        intr.wo = v_neg(*c->ray_d);
+        intr.g = mp->g;
+        float v = sampler_get1d(c->sampler); /* gphase.init: cache untrained -> no guiding */
+        (void)v;
+        float survivalProb = 1.0f;
+        if (*c->depth > r->prm.minrrdepth) {
+            spec rrw = s_scale(s_divf(*c->beta, s_avg(*c->r_u)), c->rr_correction);
+            survivalProb = *c->specularBounce ? 0.95f : standard_throughput_rr(rrw);
+        }
+        if (r->prm.usenee) {
+            spec Ld = sample_Ld(r, &intr, c->ch, c->sampler, *c->r_u, c->pc);
+            *c->L = s_add(*c->L, s_mul(*c->beta, Ld));
+        }
+        if (survivalProb < 1 && *c->depth > r->prm.minrrdepth) {
+            float q = fmaxf(0.f, 1 - survivalProb);
+            if (sampler_get1d(c->sampler) < q) {
+                c->terminated = 1;
+                return;
+            }
+            *c->beta = s_divf(*c->beta, 1 - q);
+        }
+        float u0 = sampler_get1d(c->sampler), u1 = sampler_get1d(c->sampler);
+        float pdf;
+        v3 wi = sample_henyey_greenstein(v_neg(*c->ray_d), mp->g, u0, u1, &pdf);
+        if (pdf == 0) {
+            c->terminated = 1;
+        } else {
+            float phaseFunctionWeight = pdf / pdf; /* ps->p / ps->pdf, p == pdf for HG */
+            *c->beta = s_scale(*c->beta, phaseFunctionWeight);
+            *c->r_l = s_divf(*c->r_u, pdf);
+            memset(c->prevIntrCtx, 0, sizeof *c->prevIntrCtx);
+            c->prevIntrCtx->pi = p3i_exact(p);
+            c->scattered = 1;
+            *c->ray_o = p;
+            *c->ray_d = wi;
+            *c->specularBounce = 0;
+            *c->anyNonSpecularBounces = 1;
+            *c->lastVertexVolume = 1;
+        }
+    }
+}
+
+/* delta-tracking callback (:885-1078) */
+static int delta_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, spec T_maj, int activateNDS) {
+    (void)activateNDS;
+    sd_ctx_t *c = (sd_ctx_t *)vctx;
+    const OracleRenderer *r = c->r;
+    int ch = c->ch;
+    c->pc->density_queries++;
+    if (!s_nonzero(*c->beta)) {
+        c->terminated = 1;
+        return 0;
+    }
+    if (*c->depth < r->prm.maxdepth && s_nonzero(mp->Le)) {
+        float pdf = sigma_maj.c[ch] * T_maj.c[ch];
+        spec betap = s_divf(s_mul(*c->beta, T_maj), pdf);
+        spec r_e = s_divf(s_mul(s_mul(*c->r_u, sigma_maj), T_maj), pdf);
+        if (s_nonzero(r_e))
+            *c->L = s_add(*c->L, s_divf(s_mul(s_mul(betap, mp->sigma_a), mp->Le), s_avg(r_e)));
+    }
+    spec sigma_t = s_add(mp->sigma_s, mp->sigma_a);
+    float pScatter = sigma_t.c[ch] / sigma_maj.c[ch];
+    float pNull = fmaxf(0.f, 1 - pScatter);
+    float um = rng_float(c->rng);
+    int mode = oracle_sample_discrete2(pScatter, pNull, um);
+    if (mode == 0) {
+        if (*c->depth == 0) {
+            c->isg->valid = 1;
+            c->isg->surface_event = 0;
+        }
+        if ((*c->depth)++ >= r->prm.maxdepth) {
+            c->terminated = 1;
+            return 0;
+        }
+        c->pc->volume_scatters++;
+        float pdf = T_maj.c[ch] * sigma_t.c[ch];
+        *c->beta = s_mul(*c->beta, s_divf(s_mul(T_maj, mp->sigma_s), pdf));
+        *c->r_u = s_mul(*c->r_u, s_divf(s_mul(T_maj, sigma_t), pdf));
+        *c->beta = s_mul(*c->beta, c->beta_factor);
+        *c->r_u = s_mul(*c->r_u, c->r_u_factor);
+        scatter_tail(c, p, mp);
+        return 0;
+    } else {
+        spec sigma_n = s_clamp_zero(s_sub(s_sub(sigma_maj, mp->sigma_a), mp->sigma_s));
+        float pdf = T_maj.c[ch] * sigma_n.c[ch];
+        *c->beta = s_mul(*c->beta, s_divf(s_mul(T_maj, sigma_n), pdf));
+        if (pdf == 0) *c->beta = S1(0.f);
+        *c->r_u = s_mul(*c->r_u, s_divf(s_mul(T_maj, sigma_n), pdf));
+        *c->r_l = s_mul(*c->r_l, s_divf(s_mul(T_maj, sigma_maj), pdf));
+        return s_nonzero(*c->beta) && s_nonzero(*c->r_u);
+    }
+}
+
+/* resampling callback state (:684-719) */
+typedef struct {
+    sd_ctx_t *sd;
+    float weightSum;
+    spec trRatioEst, beta_rs, r_u_rs;
+    /* CandidateData (integrators.h:526-543) */
+    int have_sel;
+    v3 sel_p;
+    medium_props_t sel_mp;
+    float sel_wi, sel_sigmaTTr;
+    spec sel_num, sel_den;
+} rs_ctx_t;
+
+static int resampling_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, spec T_maj, int nds) {
+    (void)nds;
+    rs_ctx_t *c = (rs_ctx_t *)vctx;
+    int ch = c->sd->ch;
+    c->sd->pc->density_queries++;
+    spec sigma_t = s_add(mp->sigma_s, mp->sigma_a);
+    spec sigma_n = s_clamp_zero(s_sub(sigma_maj, sigma_t));
+    float wi = s_mul(s_div(sigma_t, sigma_maj), c->trRatioEst).c[ch];
+    float sigmaTTrEstScalar = wi;
+    if (wi > 0) {
+        c->weightSum += wi;
+        if (sampler_get1d(c->sd->sampler) < wi / c->weightSum) {
+            float pdf = T_maj.c[ch] * sigma_t.c[ch];
+            c->sel_num = s_divf(s_mul(s_mul(c->beta_rs, T_maj), mp->sigma_s), pdf);
+            c->sel_den = s_divf(s_mul(s_mul(c->r_u_rs, T_maj), sigma_t), pdf);
+            c->sel_p = p; c->sel_mp = *mp; c->sel_wi = wi; c->sel_sigmaTTr = sigmaTTrEstScalar;
+            c->have_sel = 1;
+        }
+    }
+    float pdf = T_maj.c[ch] * sigma_n.c[ch];
+    c->beta_rs = s_mul(c->beta_rs, s_divf(s_mul(T_maj, sigma_n), pdf));
+    c->r_u_rs = s_mul(c->r_u_rs, s_divf(s_mul(T_maj, sigma_n), pdf));
+    c->trRatioEst = s_mul(c->trRatioEst, s_div(sigma_n, sigma_maj));
+    return 1;
+}
+
+/* VSP fetch (:654-671, :1098-1134).  Secondary-ray VSP comes from the guiding cache, which is
+ * never trained in the configurations this oracle covers -> GuidedBSDF/GuidedPhaseFunction
+ * ::VolumeScatterProbability return -1 (guiding.h:295-298, 564-567). */
+static float fetch_vsp(const OracleRenderer *r, int px, int py, int depth, int *guide) {
+    float vsp = -1.f;
+    *guide = 0;
+    if (depth == 0) {
+        if (r->prm.vspguiding && r->prm.vspprimaryguiding) {
+            if (r->vsp_ready) vsp = r->vsp[(size_t)py * r->cfg.xres + px];
+            else vsp = 0.5f;
+            *guide = !(isnan(vsp) || vsp < 0.f || vsp > 1.f);
+        }
+    } else {
+        if (r->prm.vspguiding && r->prm.vspsecondaryguiding) {
+            vsp = -1.f;
+            *guide = !(isnan(vsp) || vsp < 0.f || vsp > 1.f);
+        }
+    }
+    if (*guide) vsp = fmaxf(fminf(vsp, 0.999f), 0.001f);
+    return vsp;
+}
+
+static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
+    const OracleRenderer *r = c->r;
+    int ch = c->ch;
+    int guide;
+    float vsp = fetch_vsp(r, px, py, *c->depth, &guide);
+    if (*c->depth == 0) c->isg->vsp_used = guide ? vsp : -1.f;
+
+    int use_resampling = r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && !medium_is_homogeneous(r);
+    if (use_resampling) {
+        rs_ctx_t rc;
+        memset(&rc, 0, sizeof rc);
+        rc.sd = c;
+        rc.weightSum = 0;
+        rc.trRatioEst = S1(1.f); rc.beta_rs = S1(1.f); rc.r_u_rs = S1(1.f);
+        float vrc = 0, majorantScale = 1;
+        float u = sampler_get1d(c->sampler);
+        spec T_maj = sample_T_maj_resampling(r, *c->ray_o, *c->ray_d, tMax, u, c->rng, ch, guide, vsp,
+                                             &vrc, &majorantScale, resampling_cb, &rc);
+        rc.beta_rs = s_mul(rc.beta_rs, s_divf(T_maj, T_maj.c[ch]));
+        rc.r_u_rs = s_mul(rc.r_u_rs, s_divf(T_maj, T_maj.c[ch]));
+        float trScalar = rc.trRatioEst.c[ch];
+        /* surfaceCandidate */
+        float surf_wi = trScalar, surf_sigmaTTr = trScalar;
+        spec surf_num = rc.beta_rs, surf_den = rc.r_u_rs;
+        if (guide && trScalar < 1 && trScalar > 0 && rc.weightSum > 0) {
+            float trEstForScale = trScalar;
+            float volRatio = vrc * r->prm.vspmisratio + (1 - trEstForScale) * (1 - r->prm.vspmisratio);
+            float surfRatio = 1 - volRatio;
+            surf_wi = surfRatio / volRatio * rc.weightSum;
+        }
+        rc.weightSum += surf_wi;
+        int selectSurface = 0;
+        if (rc.weightSum == 0) {
+            return;
+        } else if (sampler_get1d(c->sampler) < surf_wi / rc.weightSum) {
+            rc.sel_wi = surf_wi; rc.sel_sigmaTTr = surf_sigmaTTr; rc.sel_num = surf_num; rc.sel_den = surf_den;
+            selectSurface = 1;
+        }
+        float resamplingFactorScalar = rc.weightSum * rc.sel_sigmaTTr / rc.sel_wi;
+        if (selectSurface) {
+            *c->beta = s_mul(*c->beta, s_scale(rc.sel_num, resamplingFactorScalar));
+            *c->r_u = s_mul(*c->r_u, rc.sel_den);
+            if (s_has_nan(*c->beta) || s_has_nan(*c->r_u) || s_has_inf(*c->beta) || s_has_inf(*c->r_u)) {
+                c->terminated = 1;
+                return;
+            }
+        } else {
+            v3 p = rc.sel_p;
+            medium_props_t mp = rc.sel_mp;
+            if (*c->depth == 0) {
+                c->isg->valid = 1;
+                c->isg->surface_event = 0;
+            }
+            if ((*c->depth)++ >= r->prm.maxdepth) {
+                c->terminated = 1;
+                return;
+            }
+            c->pc->volume_scatters++;
+            *c->beta = s_mul(*c->beta, s_scale(rc.sel_num, resamplingFactorScalar));
+            *c->r_u = s_mul(*c->r_u, rc.sel_den);
+            if (s_has_nan(*c->beta) || s_has_nan(*c->r_u) || s_has_inf(*c->beta) || s_has_inf(*c->r_u)) {
+                c->terminated = 1;
+                return;
+            }
+            scatter_tail(c, p, &mp);
+        }
+    } else {
+        c->beta_factor = S1(1.f);
+        c->r_u_factor = S1(1.f);
+        float u = sampler_get1d(c->sampler);
+        spec T_maj = sample_T_maj_ods(r, *c->ray_o, *c->ray_d, tMax, u, c->rng, ch, guide, vsp,
+                                      r->prm.vspmisratio, r->prm.vspsamplingmethod == VSPG_VSP_NDS,
+                                      &c->beta_factor, &c->r_u_factor, delta_cb, c);
+        int multiply_T_maj = !(c->scattered || c->terminated || !s_nonzero(*c->beta) || !s_nonzero(*c->r_u));
+        if (multiply_T_maj) {
+            *c->beta = s_mul(*c->beta, s_divf(T_maj, T_maj.c[ch]));
+            *c->r_u = s_mul(*c->r_u, s_divf(T_maj, T_maj.c[ch]));
+            *c->r_l = s_mul(*c->r_l, s_divf(T_maj, T_maj.c[ch]));
+            *c->beta = s_mul(*c->beta, c->beta_factor);
+            *c->r_u = s_mul(*c->r_u, c->r_u_factor);
+            *c->r_l = s_mul(*c->r_l, c->r_u_factor);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a16: Li (guidedvolpathvspgintegrator.cpp:262-635)                                      */
+/* ------------------------------------------------------------------------------------ */
+static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sampler_t *sampler,
+               isg_sample_t *isg, path_counters_t *pc) {
+    float rr_correction = 1.0f;
+    spec L = S1(0.f), beta = S1(1.f), r_u = S1(1.f), r_l = S1(1.f);
+    int specularBounce = 0, anyNonSpecularBounces = 0;
+    int depth = 0;
+    float etaScale = 1;
+    int lastVertexVolume = 0;
+    lsctx_t prevIntrCtx;
+    memset(&prevIntrCtx, 0, sizeof prevIntrCtx);
+    isg->valid = 0; isg->surface_event = 0; isg->vsp_used = -1.f;
+
+    while (1) {
+        pc->segments++;
+        isect_t si = scene_intersect(r, ro, rd, INFINITY);
+        float tMax = si.hit ? si.t : INFINITY;
+        if (r->scene.medium.type != VSPG_MEDIUM_NONE && !isinf(tMax)) {
+            rng_t rng;
+            uint64_t hash0 = oracle_hash_float(sampler_get1d(sampler));
+            uint64_t hash1 = oracle_hash_float(sampler_get1d(sampler));
+            rng_set_sequence2(&rng, hash0, hash1);
+            sd_ctx_t c;
+            memset(&c, 0, sizeof c);
+            c.r = r; c.ch = ch; c.sampler = sampler; c.rng = &rng;
+            c.ray_o = &ro; c.ray_d = &rd; c.depth = &depth;
+            c.L = &L; c.beta = &beta; c.r_u = &r_u; c.r_l = &r_l;
+            c.specularBounce = &specularBounce; c.anyNonSpecularBounces = &anyNonSpecularBounces;
+            c.lastVertexVolume = &lastVertexVolume; c.prevIntrCtx = &prevIntrCtx;
+            c.rr_correction = rr_correction;
+            c.isg = isg; c.pc = pc;
+            sample_distance(&c, px, py, tMax);
+            if (c.terminated || !s_nonzero(beta) || !s_nonzero(r_u)) break;
+            if (c.scattered) continue;
+        }
+        if (!si.hit) break; /* no infinite lights in scope (:353-374) */
+
+        const rquad_t *q = &r->quads[si.quad];
+        /* isect.Le(-ray.d) (:377-397) */
+        spec Le = q->is_light ? light_L(q, si.n, v_neg(rd)) : S1(0.f);
+        if (s_nonzero(Le)) {
+            if (depth == 0 || specularBounce) {
+                L = s_add(L, s_divf(s_mul(beta, Le), s_avg(r_u)));
+            } else {
+                float lightPDF = (1.f / (float)r->n_lights) * light_pdf_li(q, &prevIntrCtx, rd);
+                r_l = s_scale(r_l, lightPDF);
+                float w_l = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.0f;
+                L = s_add(L, s_mul(s_scale(beta, w_l), Le));
+            }
+        }
+        bsdf_t bsdf = bsdf_make(q);
+        if (depth == 0) {
+            isg->valid = 1;
+            isg->surface_event = 1;
+        }
+        if (depth++ >= r->prm.maxdepth) break;
+        pc->surface_hits++;
+
+        float v = sampler_get1d(sampler); /* gbsdf.init (cache untrained) */
+        (void)v;
+        float survivalProb = 1.f;
+        intr_t intr;
+        memset(&intr, 0, sizeof intr);
+        intr.is_surface = 1;
+        p3i pi = p3i_from_err(si.p, q->perr); /* SurfaceInteraction pi (shapes.h InteractionFromIntersection) */
+        intr.pi = pi; intr.n = si.n;
+        intr.wo = v_normalize(v_neg(rd)); /* Interaction ctor normalises wo (interaction.h:31-32) */
+        intr.bsdf = &bsdf;
+        if (r->prm.usenee && bsdf.has_lobes) { /* IsNonSpecular(bsdf.Flags()) */
+            spec Ld = sample_Ld(r, &intr, ch, sampler, r_u, pc);
+            L = s_add(L, s_mul(beta, Ld));
+        }
+        prevIntrCtx.pi = pi; prevIntrCtx.n = si.n; prevIntrCtx.ns = si.n;
+
+        v3 wo = v_neg(rd);
+        float u = sampler_get1d(sampler);
+        float u20 = sampler_get1d(sampler), u21 = sampler_get1d(sampler);
+        spec f;
+        v3 wi;
+        float pdf;
+        if (!bsdf_sample_f(&bsdf, wo, u, u20, u21, &f, &wi, &pdf)) break;
+        lastVertexVolume = 0;
+        rr_correction *= pdf / pdf; /* bs->pdf / bs->bsdfPdf */
+        spec bsdfWeight = s_divf(s_scale(f, v_absdot(wi, si.n)), pdf);
+        beta = s_mul(beta, bsdfWeight);
+        r_l = s_divf(r_u, pdf); /* misPdf == pdf */
+        specularBounce = 0;
+        anyNonSpecularBounces = 1;
+        ro = offset_ray_origin(pi, si.n, wi); /* SpawnRay (interaction.h:99-101) */
+        rd = wi;
+
+        if (!s_nonzero(beta)) break;
+        if (depth > r->prm.minrrdepth) {
+            spec rrw = s_scale(s_scale(s_divf(beta, s_avg(r_u)), rr_correction), etaScale);
+            survivalProb = specularBounce ? 0.95f : standard_throughput_rr(rrw);
+        }
+        if (survivalProb < 1 && depth > r->prm.minrrdepth) {
+            float qq = fmaxf(0.f, 1 - survivalProb);
+            if (sampler_get1d(sampler) < qq) break;
+            beta = s_divf(beta, 1 - qq);
+        }
+    }
+    return L;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* EvaluatePixelSample (src/pbrt/cpu/integrators.cpp:272-334) + film + ISG sample          */
+/* ------------------------------------------------------------------------------------ */
+static void camera_ray(const VspgCamera *cam, float fx, float fy, v3 *o, v3 *d) {
+    v3 pc = V3(cam->sx * fx + cam->ox, cam->sy * fy + cam->oy, 1.f);
+    v3 dir = v_normalize(pc);
+    frame_t f;
+    f.x = v3_from(cam->right); f.y = v3_from(cam->up); f.z = v3_from(cam->fwd);
+    *o = v3_from(cam->origin);
+    *d = frame_from_local(&f, dir);
+}
+
+static spec evaluate_pixel_sample(const OracleRenderer *r, int px, int py, int sampleIndex,
+                                  isg_sample_t *isg, path_counters_t *pc, float *filterWeight) {
+    sampler_t sampler;
+    sampler_start_pixel_sample(&sampler, px, py, r->cfg.seed, sampleIndex, 0);
+    float lu = sampler_get1d(&sampler);
+    int ch = (int)floorf(lu * 3); /* SampledWavelengths::SampleVisible, spectrum.h:380-384 */
+    if (ch > 2) ch = 2;
+    /* GetCameraSample (samplers.h:796-815) with BoxFilter radius 0.5 (filters.h:67-69) */
+    float f0 = sampler_get1d(&sampler), f1 = sampler_get1d(&sampler);
+    float fpx = (1 - f0) * -0.5f + f0 * 0.5f;
+    float fpy = (1 - f1) * -0.5f + f1 * 0.5f;
+    float pfx = ((float)px + fpx) + 0.5f, pfy = ((float)py + fpy) + 0.5f;
+    (void)sampler_get1d(&sampler); /* time */
+    (void)sampler_get1d(&sampler); (void)sampler_get1d(&sampler); /* pLens */
+    *filterWeight = 1.f;
+    v3 o, d;
+    camera_ray(&r->scene.camera, pfx, pfy, &o, &d);
+    spec L = Li(r, px, py, o, d, ch, &sampler, isg, pc);
+    /* L = cameraRay->weight * L with weight 1; NaN / Inf -> black (:308-318) */
+    if (s_has_nan(L)) L = S1(0.f);
+    else if (s_has_inf(L)) L = S1(0.f);
+    return L;
+}
+
+/* image-space VSP statistics: own design standing in for ImageSpaceGuidingBuffer::AddSample
+ * (guidedvolpathvspgintegrator.cpp:613-622).  PARITY UNPINNED (OpenPGL absent).
+ * stats[0]=n  [1]=sum c*[vol]  [2]=sum c*[surf]  [3]=sum c^2*q*[vol]  [4]=sum c^2*(1-q)*[surf]
+ * [5]=n_vol  [6],[7] reserved; c = average of the RGB contribution, q = VSP used (0.5 if unguided) */
+static void isg_add_sample(float *st, spec L, const isg_sample_t *isg) {
+    if (!isg->valid) return;
+    float c = s_avg(L);
+    float q = isg->vsp_used >= 0.f ? isg->vsp_used : 0.5f;
+    st[0] += 1.f;
+    if (isg->surface_event) {
+        st[2] += c;
+        st[4] += c * c * (1 - q);
+    } else {
+        st[1] += c;
+        st[3] += c * c * q;
+        st[5] += 1.f;
+    }
+}
+
+static void film_add_sample(double *px, spec L, float weight) { /* film.h:251-267 */
+    /* sensor->ToSensorRGB: imagingRatio 1; maxComponentValue = Infinity */
+    for (int c = 0; c < 3; ++c) px[c] += (double)(weight * L.c[c]);
+    px[3] += (double)weight;
+}
+
+static void counters_merge(VspgCounters *dst, const path_counters_t *pc, uint64_t paths) {
+    dst->paths += paths;
+    dst->segments += pc->segments;
+    dst->volume_scatters += pc->volume_scatters;
+    dst->surface_hits += pc->surface_hits;
+    dst->density_queries += pc->density_queries;
+    dst->shadow_rays += pc->shadow_rays;
+}
+
+int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int wave_start,
+                         int wave_end, int nthreads) {
+    if (!r || wave_end < wave_start) return VSPG_EINVAL;
+    int W = r->cfg.xres;
+    int ntx = (x1 - x0 + 15) / 16, nty = (y1 - y0 + 15) / 16;
+    int ntiles = ntx * nty;
+    VspgCounters total;
+    memset(&total, 0, sizeof total);
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads)
+    {
+        path_counters_t pc;
+        memset(&pc, 0, sizeof pc);
+        uint64_t paths = 0;
+#pragma omp for schedule(dynamic, 1)
+        for (int tile = 0; tile < ntiles; ++tile) {
+            int tx = tile % ntx, ty = tile / ntx;
+            int xa = x0 + tx * 16, ya = y0 + ty * 16;
+            int xb = xa + 16 < x1 ? xa + 16 : x1, yb = ya + 16 < y1 ? ya + 16 : y1;
+            for (int py = ya; py < yb; ++py)
+                for (int px = xa; px < xb; ++px)
+                    for (int s = wave_start; s < wave_end; ++s) {
+                        if (r->cfg.shard_count > 1 && (s % r->cfg.shard_count) != r->cfg.shard_index) continue;
+                        isg_sample_t isg;
+                        float w;
+                        spec L = evaluate_pixel_sample(r, px, py, s, &isg, &pc, &w);
+                        size_t idx = (size_t)py * W + px;
+                        film_add_sample(&r->film[idx * 4], L, w);
+                        isg_add_sample(&r->isg_stats[idx * VSPG_ISG_STATS], L, &isg);
+                        paths++;
+                    }
+        }
+#pragma omp critical
+        counters_merge(&total, &pc, paths);
+    }
+    counters_merge(&r->counters, &(path_counters_t){total.segments, total.volume_scatters, total.surface_hits,
+                                                    total.density_queries, total.shadow_rays},
+                   total.paths);
+    return 0;
+}
+
+int oracle_render_wave(OracleRenderer *r, int wave_start, int wave_end, int nthreads) {
+    return oracle_render_window(r, 0, 0, r->cfg.xres, r->cfg.yres, wave_start, wave_end, nthreads);
+}
+
+/* PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260): the guiding-field update is absent
+ * (guideTraining false in covered configs); VSP buffer update at waveCounter == 2^bufferWave.
+ * Update() = 5x5 box filter over the sufficient statistics, then the criterion (own design). */
+#define ISG_FILTER_RADIUS 2
+int oracle_post_process_wave(OracleRenderer *r) {
+    r->wave_counter++;
+    if ((double)r->wave_counter == pow(2.0, (double)r->buffer_wave)) {
+        int W = r->cfg.xres, H = r->cfg.yres;
+        if (r->prm.vspguiding && r->prm.vspprimaryguiding) {
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    float a[5] = {0, 0, 0, 0, 0};
+                    for (int dy = -ISG_FILTER_RADIUS; dy <= ISG_FILTER_RADIUS; ++dy)
+                        for (int dx = -ISG_FILTER_RADIUS; dx <= ISG_FILTER_RADIUS; ++dx) {
+                            int xx = x + dx, yy = y + dy;
+                            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+                            const float *st = &r->isg_stats[((size_t)yy * W + xx) * VSPG_ISG_STATS];
+                            for (int k = 0; k < 5; ++k) a[k] += st[k];
+                        }
+                    float vsp = -1.f;
+                    if (a[0] > 0) {
+                        float v, s;
+                        if (r->prm.vspcriterion == VSPG_VSP_VARIANCE) {
+                            v = sqrtf(a[3] / a[0]);
+                            s = sqrtf(a[4] / a[0]);
+                        } else {
+                            v = a[1] / a[0];
+                            s = a[2] / a[0];
+                        }
+                        if (v + s > 0) vsp = v / (v + s);
+                    }
+                    r->vsp[(size_t)y * W + x] = vsp;
+                }
+            r->vsp_ready = 1;
+        }
+        r->buffer_wave++;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* life cycle + accessors                                                                 */
+/* ------------------------------------------------------------------------------------ */
+static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p, const VspgRenderConfig *cfg) {
+    if (!scene || !p || !cfg) return VSPG_EINVAL;
+    if (cfg->xres <= 0 || cfg->yres <= 0) return VSPG_EINVAL;
+    if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return VSPG_EINVAL;
+    if (p->collisionProbabilityBias || p->rrguiding) return VSPG_ESCOPE;
+    if (p->surfaceguiding || p->volumeguiding || (p->vspguiding && p->vspsecondaryguiding)) return VSPG_ESCOPE;
+    return 0;
+}
+
+int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *params,
+                           const VspgRenderConfig *cfg, OracleRenderer **out) {
+    int rc = validate_params(scene, params, cfg);
+    if (rc) return rc;
+    OracleRenderer *r = (OracleRenderer *)calloc(1, sizeof *r);
+    r->scene = *scene;
+    r->prm = *params;
+    r->cfg = *cfg;
+    if (r->cfg.shard_count < 1) { r->cfg.shard_count = 1; r->cfg.shard_index = 0; }
+    r->n_quads = scene->n_quads;
+    for (int i = 0; i < r->n_quads; ++i) {
+        quad_init(&r->quads[i], &scene->quads[i]);
+        if (r->quads[i].is_light) r->light_quads[r->n_lights++] = i;
+    }
+    size_t npix = (size_t)cfg->xres * cfg->yres;
+    r->film = (double *)calloc(npix * 4, sizeof(double));
+    r->isg_stats = (float *)calloc(npix * VSPG_ISG_STATS, sizeof(float));
+    r->vsp = (float *)calloc(npix, sizeof(float));
+    *out = r;
+    return 0;
+}
+void oracle_renderer_destroy(OracleRenderer *r) {
+    if (!r) return;
+    free(r->film); free(r->isg_stats); free(r->vsp); free(r);
+}
+void oracle_film_read(OracleRenderer *r, float *rgbw) {
+    size_t n = (size_t)r->cfg.xres * r->cfg.yres * 4;
+    for (size_t i = 0; i < n; ++i) rgbw[i] = (float)r->film[i];
+}
+void oracle_film_read_f64(OracleRenderer *r, double *rgbw) {
+    memcpy(rgbw, r->film, (size_t)r->cfg.xres * r->cfg.yres * 4 * sizeof(double));
+}
+void oracle_film_clear(OracleRenderer *r) { memset(r->film, 0, (size_t)r->cfg.xres * r->cfg.yres * 4 * sizeof(double)); }
+void oracle_vsp_buffer_read(OracleRenderer *r, float *vsp, int *is_ready) {
+    memcpy(vsp, r->vsp, (size_t)r->cfg.xres * r->cfg.yres * sizeof(float));
+    if (is_ready) *is_ready = r->vsp_ready;
+}
+void oracle_vsp_buffer_write(OracleRenderer *r, const float *vsp, int is_ready) {
+    memcpy(r->vsp, vsp, (size_t)r->cfg.xres * r->cfg.yres * sizeof(float));
+    r->vsp_ready = is_ready;
+}
+void oracle_isg_stats_read(OracleRenderer *r, float *stats) {
+    memcpy(stats, r->isg_stats, (size_t)r->cfg.xres * r->cfg.yres * VSPG_ISG_STATS * sizeof(float));
+}
+void oracle_get_counters(OracleRenderer *r, VspgCounters *out) { *out = r->counters; }
+void oracle_reset_counters(OracleRenderer *r) { memset(&r->counters, 0, sizeof r->counters); }
+
+int oracle_trace_paths(OracleRenderer *r, int n, const int32_t *pixel_xy, const int32_t *sample_index,
+                       float *out_L, int32_t *out_segments) {
+    for (int i = 0; i < n; ++i) {
+        path_counters_t pc;
+        memset(&pc, 0, sizeof pc);
+        isg_sample_t isg;
+        float w;
+        spec L = evaluate_pixel_sample(r, pixel_xy[2 * i], pixel_xy[2 * i + 1], sample_index[i], &isg, &pc, &w);
+        out_L[3 * i] = L.c[0]; out_L[3 * i + 1] = L.c[1]; out_L[3 * i + 2] = L.c[2];
+        if (out_segments) out_segments[i] = (int32_t)pc.segments;
+    }
+    return 0;
+}
+
+/* recording callback for the free-flight batch driver */
+typedef struct {
+    int ch, stop_after;
+    VspgTmajResult *res;
+    v3 ro, rd_n;
+} rec_ctx_t;
+static int rec_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, spec T_maj, int nds) {
+    (void)T_maj; (void)nds;
+    rec_ctx_t *c = (rec_ctx_t *)vctx;
+    VspgTmajResult *o = c->res;
+    o->n_callbacks++;
+    o->last_p[0] = p.x; o->last_p[1] = p.y; o->last_p[2] = p.z;
+    o->last_t = v_dot(v_sub(p, c->ro), c->rd_n);
+    spec sigma_t = s_add(mp->sigma_s, mp->sigma_a);
+    o->sum_sigt_over_maj += sigma_t.c[c->ch] / sigma_maj.c[c->ch];
+    if (c->stop_after > 0 && o->n_callbacks >= c->stop_after) return 0;
+    return 1;
+}
+int oracle_sample_tmaj_batch(OracleRenderer *r, int variant, int n, const VspgTmajQuery *q,
+                             VspgTmajResult *out) {
+    for (int i = 0; i < n; ++i) {
+        VspgTmajResult *o = &out[i];
+        memset(o, 0, sizeof *o);
+        o->last_t = -1.f;
+        for (int k = 0; k < 3; ++k) o->r_u_factor[k] = 1.f;
+        o->majorant_scale = 1.f;
+        rng_t rng;
+        rng_set_sequence2(&rng, oracle_hash_float(q[i].rng_a), oracle_hash_float(q[i].rng_b));
+        rec_ctx_t c;
+        c.ch = q[i].channel; c.stop_after = q[i].stop_after; c.res = o;
+        c.ro = v3_from(q[i].o); c.rd_n = v_normalize(v3_from(q[i].d));
+        int guide = q[i].vsp >= 0.f;
+        float vsp = guide ? fmaxf(fminf(q[i].vsp, 0.999f), 0.001f) : q[i].vsp;
+        spec T, bf = S1(1.f), rf = S1(1.f);
+        if (variant == VSPG_TMAJ_PLAIN) {
+            T = sample_T_maj(r, c.ro, v3_from(q[i].d), q[i].tMax, q[i].u, &rng, c.ch, rec_cb, &c);
+        } else if (variant == VSPG_TMAJ_OPTICAL_DEPTH) {
+            T = sample_T_maj_ods(r, c.ro, v3_from(q[i].d), q[i].tMax, q[i].u, &rng, c.ch, guide, vsp,
+                                 r->prm.vspmisratio, r->prm.vspsamplingmethod == VSPG_VSP_NDS, &bf, &rf, rec_cb, &c);
+        } else if (variant == VSPG_TMAJ_RESAMPLING) {
+            float vrc = vsp, ms = 1.f;
+            T = sample_T_maj_resampling(r, c.ro, v3_from(q[i].d), q[i].tMax, q[i].u, &rng, c.ch, guide, vsp,
+                                        &vrc, &ms, rec_cb, &c);
+            o->vrc = vrc; o->majorant_scale = ms;
+        } else {
+            return VSPG_EINVAL;
+        }
+        for (int k = 0; k < 3; ++k) { o->T_maj[k] = T.c[k]; o->r_u_factor[k] = rf.c[k]; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* scene helpers                                                                          */
+/* ------------------------------------------------------------------------------------ */
+void oracle_integrator_params_default(VspgIntegratorParams *p) {
+    /* guidedvolpathvspgintegrator.cpp:1263-1319 */
+    memset(p, 0, sizeof *p);
+    p->maxdepth = 5; p->minrrdepth = 1; p->usenee = 1;
+    p->surfaceguiding = 1; p->volumeguiding = 1;
+    p->surfaceguidingtype = VSPG_GUIDE_RIS; p->volumeguidingtype = VSPG_GUIDE_MIS;
+    p->vspguiding = 1; p->vspprimaryguiding = 1; p->vspsecondaryguiding = 1;
+    p->vspmisratio = 0.5f;
+    p->vspcriterion = VSPG_VSP_VARIANCE;
+    p->vspsamplingmethod = VSPG_VSP_RESAMPLING;
+    p->collisionProbabilityBias = 0; p->rrguiding = 0;
+    p->lightsampler = VSPG_LIGHTSAMPLER_BVH; p->regularize = 0;
+    p->guide_num_training_waves = 128;
+}
+
+int oracle_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3], const float up[3],
+                          float fov_degrees, int xres, int yres) {
+    double e[3] = {eye[0], eye[1], eye[2]}, l[3] = {look[0], look[1], look[2]}, u[3] = {up[0], up[1], up[2]};
+    double f[3] = {l[0] - e[0], l[1] - e[1], l[2] - e[2]};
+    double fl = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    if (fl == 0) return VSPG_EINVAL;
+    for (int i = 0; i < 3; ++i) f[i] /= fl;
+    /* pbrt LookAt (util/transform.cpp): right = Normalize(Cross(Normalize(up), dir)) */
+    double ul = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    for (int i = 0; i < 3; ++i) u[i] /= ul;
+    double rt[3] = {u[1] * f[2] - u[2] * f[1], u[2] * f[0] - u[0] * f[2], u[0] * f[1] - u[1] * f[0]};
+    double rl = sqrt(rt[0] * rt[0] + rt[1] * rt[1] + rt[2] * rt[2]);
+    if (rl == 0) return VSPG_EINVAL;
+    for (int i = 0; i < 3; ++i) rt[i] /= rl;
+    double nu[3] = {f[1] * rt[2] - f[2] * rt[1], f[2] * rt[0] - f[0] * rt[2], f[0] * rt[1] - f[1] * rt[0]};
+    for (int i = 0; i < 3; ++i) {
+        cam->origin[i] = (float)e[i]; cam->right[i] = (float)rt[i]; cam->up[i] = (float)nu[i]; cam->fwd[i] = (float)f[i];
+    }
+    /* screen window [-a,a]x[-1,1] (a = aspect if >1) scaled by tan(fov/2) on the shorter axis
+     * (cameras.cpp:474-489); raster y grows downwards (cameras.h:268-274) */
+    double aspect = (double)xres / (double)yres;
+    double sxw = aspect > 1 ? aspect : 1.0, syw = aspect > 1 ? 1.0 : 1.0 / aspect;
+    double th = tan(fov_degrees * 3.14159265358979323846 / 360.0);
+    cam->sx = (float)(2.0 * sxw * th / xres);
+    cam->ox = (float)(-sxw * th);
+    cam->sy = (float)(-2.0 * syw * th / yres);
+    cam->oy = (float)(syw * th);
+    return 0;
+}
+
+static void set_quad(VspgQuad *q, float px, float py, float pz, float ax, float ay, float az, float bx,
+                     float by, float bz, float kd, float ler, float leg, float leb) {
+    memset(q, 0, sizeof *q);
+    q->p00[0] = px; q->p00[1] = py; q->p00[2] = pz;
+    q->e1[0] = ax; q->e1[1] = ay; q->e1[2] = az;
+    q->e2[0] = bx; q->e2[1] = by; q->e2[2] = bz;
+    q->Kd[0] = q->Kd[1] = q->Kd[2] = kd;
+    q->Le[0] = ler; q->Le[1] = leg; q->Le[2] = leb;
+}
+
+/* SURVEY.md App. F.  Quad normals (e1 x e2) point into the box. */
+int oracle_scene_fog_box(VspgScene *s, int xres, int yres) {
+    memset(s, 0, sizeof *s);
+    const float k = 0.73f;
+    s->n_quads = 7;
+    set_quad(&s->quads[0], -1, -1, -1, 0, 0, 2, 2, 0, 0, k, 0, 0, 0);  /* floor   y=-1, n=+y */
+    set_quad(&s->quads[1], -1, 1, -1, 2, 0, 0, 0, 0, 2, k, 0, 0, 0);   /* ceiling y=+1, n=-y */
+    set_quad(&s->quads[2], -1, -1, 1, 0, 2, 0, 2, 0, 0, k, 0, 0, 0);   /* back    z=+1, n=-z */
+    set_quad(&s->quads[3], -1, -1, -1, 2, 0, 0, 0, 2, 0, k, 0, 0, 0);  /* front   z=-1, n=+z */
+    set_quad(&s->quads[4], -1, -1, -1, 0, 2, 0, 0, 0, 2, k, 0, 0, 0);  /* left    x=-1, n=+x */
+    set_quad(&s->quads[5], 1, -1, -1, 0, 0, 2, 0, 2, 0, k, 0, 0, 0);   /* right   x=+1, n=-x */
+    set_quad(&s->quads[6], -0.25f, 0.999f, -0.25f, 0.5f, 0, 0, 0, 0, 0.5f, 0, 17, 12, 4); /* light, n=-y */
+    float eye[3] = {0, 0, -0.95f}, look[3] = {0, 0, 0}, up[3] = {0, 1, 0};
+    int rc = oracle_camera_look_at(&s->camera, eye, look, up, 60.f, xres, yres);
+    if (rc) return rc;
+    s->medium.type = VSPG_MEDIUM_HOMOGENEOUS;
+    for (int i = 0; i < 3; ++i) { s->medium.sigma_a[i] = 0.05f; s->medium.sigma_s[i] = 0.45f; s->medium.Le[i] = 0; }
+    s->medium.g = 0.f;
+    return 0;
+}

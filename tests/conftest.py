@@ -1,0 +1,48 @@
+"""pytest configuration: registers the `gpu` marker and provides the package / oracle loaders.
+
+  -m "not gpu": oracle vs golden vectors, host logic, C-ABI symbol export (no compute calls).
+  -m gpu      : parity tests proper -- HIP path through the C-ABI vs the oracle.
+"""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+
+
+def load_package():
+    """Import the hyphen-named package directory as module `vspg_pbrt_v4_amd`."""
+    name = "vspg_pbrt_v4_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    path = os.path.join(ROOT, "vspg-pbrt-v4_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_pkg(pkg):
+    """The package with the HIP library loaded; fails loudly if the extension is missing."""
+    pkg.load()
+    return pkg

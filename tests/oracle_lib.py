@@ -1,0 +1,166 @@
+"""ctypes loader for oracle/liboracle.so (the CPU checker).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from conftest import ROOT, load_package
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    src = os.path.join(ROOT, "oracle", "vspg_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    P = load_package()
+    lib = C.CDLL(so)
+    p, vp, f3 = C.POINTER, C.c_void_p, P.f3
+    sig = {
+        "oracle_murmur64a": (C.c_uint64, [C.c_char_p, C.c_size_t, C.c_uint64]),
+        "oracle_mix_bits": (C.c_uint64, [C.c_uint64]),
+        "oracle_hash_float": (C.c_uint64, [C.c_float]),
+        "oracle_hash_pixel_seed": (C.c_uint64, [C.c_int32, C.c_int32, C.c_int32]),
+        "oracle_hash_point3": (C.c_uint64, [C.c_float, C.c_float, C.c_float]),
+        "oracle_rng_seq": (None, [C.c_uint64, C.c_uint64, C.c_int, C.c_int64, C.c_int, p(C.c_uint32), p(C.c_float)]),
+        "oracle_fast_exp": (C.c_float, [C.c_float]),
+        "oracle_sample_exponential": (C.c_float, [C.c_float, C.c_float]),
+        "oracle_sample_discrete2": (C.c_int, [C.c_float, C.c_float, C.c_float]),
+        "oracle_henyey_greenstein": (C.c_float, [C.c_float, C.c_float]),
+        "oracle_sample_henyey_greenstein": (None, [f3, C.c_float, C.c_float, C.c_float, f3, p(C.c_float)]),
+        "oracle_sample_uniform_sphere": (None, [C.c_float, C.c_float, f3]),
+        "oracle_sample_cosine_hemisphere": (None, [C.c_float, C.c_float, f3]),
+        "oracle_coordinate_system": (None, [f3, f3, f3]),
+        "oracle_offset_ray_origin": (None, [f3, f3, f3, f3, f3]),
+        "oracle_independent_sampler": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, p(C.c_float)]),
+        "oracle_renderer_create": (C.c_int, [p(P.VspgScene), p(P.VspgIntegratorParams), p(P.VspgRenderConfig), p(vp)]),
+        "oracle_renderer_destroy": (None, [vp]),
+        "oracle_render_wave": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "oracle_render_window": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "oracle_post_process_wave": (C.c_int, [vp]),
+        "oracle_film_read": (None, [vp, p(C.c_float)]),
+        "oracle_film_read_f64": (None, [vp, p(C.c_double)]),
+        "oracle_film_clear": (None, [vp]),
+        "oracle_vsp_buffer_read": (None, [vp, p(C.c_float), p(C.c_int)]),
+        "oracle_vsp_buffer_write": (None, [vp, p(C.c_float), C.c_int]),
+        "oracle_isg_stats_read": (None, [vp, p(C.c_float)]),
+        "oracle_get_counters": (None, [vp, p(P.VspgCounters)]),
+        "oracle_reset_counters": (None, [vp]),
+        "oracle_trace_paths": (C.c_int, [vp, C.c_int, p(C.c_int32), p(C.c_int32), p(C.c_float), p(C.c_int32)]),
+        "oracle_sample_tmaj_batch": (C.c_int, [vp, C.c_int, C.c_int, p(P.VspgTmajQuery), p(P.VspgTmajResult)]),
+        "oracle_integrator_params_default": (None, [p(P.VspgIntegratorParams)]),
+        "oracle_camera_look_at": (C.c_int, [p(P.VspgCamera), f3, f3, f3, C.c_float, C.c_int, C.c_int]),
+        "oracle_scene_fog_box": (C.c_int, [p(P.VspgScene), C.c_int, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def default_params():
+    P = load_package()
+    prm = P.VspgIntegratorParams()
+    load().oracle_integrator_params_default(C.byref(prm))
+    return prm
+
+
+def app_f_params():
+    prm = default_params()
+    prm.surfaceguiding = 0
+    prm.volumeguiding = 0
+    prm.vspsecondaryguiding = 0
+    return prm
+
+
+def fog_box_scene(xres, yres):
+    P = load_package()
+    s = P.VspgScene()
+    rc = load().oracle_scene_fog_box(C.byref(s), xres, yres)
+    assert rc == 0
+    return s
+
+
+class OracleRenderer:
+    def __init__(self, scene, params, xres, yres, spp=1, seed=0, shard_index=0, shard_count=1):
+        P = load_package()
+        self.lib = load()
+        self.cfg = P.VspgRenderConfig(xres, yres, spp, seed, shard_index, shard_count, 0)
+        self.h = C.c_void_p()
+        rc = self.lib.oracle_renderer_create(C.byref(scene), C.byref(params), C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("oracle_renderer_create failed: %d" % rc)
+        self.xres, self.yres = xres, yres
+        self.P = P
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.oracle_renderer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def render_wave(self, w0, w1, nthreads=0):
+        assert self.lib.oracle_render_wave(self.h, w0, w1, nthreads) == 0
+
+    def render_window(self, x0, y0, x1, y1, w0, w1, nthreads=0):
+        assert self.lib.oracle_render_window(self.h, x0, y0, x1, y1, w0, w1, nthreads) == 0
+
+    def post_process_wave(self):
+        assert self.lib.oracle_post_process_wave(self.h) == 0
+
+    def film(self):
+        out = np.empty((self.yres, self.xres, 4), dtype=np.float32)
+        self.lib.oracle_film_read(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def film_f64(self):
+        out = np.empty((self.yres, self.xres, 4), dtype=np.float64)
+        self.lib.oracle_film_read_f64(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def vsp_buffer(self):
+        out = np.empty((self.yres, self.xres), dtype=np.float32)
+        ready = C.c_int()
+        self.lib.oracle_vsp_buffer_read(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ready))
+        return out, bool(ready.value)
+
+    def set_vsp_buffer(self, vsp, ready=True):
+        v = np.ascontiguousarray(vsp, dtype=np.float32)
+        self.lib.oracle_vsp_buffer_write(self.h, v.ctypes.data_as(C.POINTER(C.c_float)), int(ready))
+
+    def isg_stats(self):
+        out = np.empty((self.yres, self.xres, self.P.VSPG_ISG_STATS), dtype=np.float32)
+        self.lib.oracle_isg_stats_read(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def counters(self):
+        c = self.P.VspgCounters()
+        self.lib.oracle_get_counters(self.h, C.byref(c))
+        return c.as_dict()
+
+    def trace_paths(self, pixel_xy, sample_index):
+        pix = np.ascontiguousarray(pixel_xy, dtype=np.int32).reshape(-1, 2)
+        si = np.ascontiguousarray(sample_index, dtype=np.int32).reshape(-1)
+        n = si.shape[0]
+        L = np.empty((n, 3), dtype=np.float32)
+        seg = np.empty(n, dtype=np.int32)
+        rc = self.lib.oracle_trace_paths(self.h, n, pix.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         si.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         L.ctypes.data_as(C.POINTER(C.c_float)),
+                                         seg.ctypes.data_as(C.POINTER(C.c_int32)))
+        assert rc == 0
+        return L, seg
+
+    def sample_tmaj_batch(self, variant, queries):
+        n = len(queries)
+        q = (self.P.VspgTmajQuery * n)(*queries)
+        out = (self.P.VspgTmajResult * n)()
+        assert self.lib.oracle_sample_tmaj_batch(self.h, variant, n, q, out) == 0
+        return list(out)

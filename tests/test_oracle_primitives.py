@@ -1,0 +1,176 @@
+"""Oracle (CPU restatement) vs the committed golden vectors generated from the reference's own
+headers (tests/golden/primitives.json, made by oracle/make_golden.py) and vs the known-answer
+fixtures of the reference's unit tests.  Integer work is bit-exact; float results are bit-exact
+too where they depend only on IEEE ops (FastExp, HG, CoordinateSystem, OffsetRayOrigin), and
+exact on the generating host for libm-dependent ones (logf / sinf / cosf)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+G = json.load(open(os.path.join(ROOT, "tests", "golden", "primitives.json")))
+fh = float.fromhex
+
+
+def f3(P, v):
+    return P.f3(*v)
+
+
+def bits(x):
+    return np.float32(x).view(np.uint32)
+
+
+def same(a, b):
+    return bits(a) == bits(b)
+
+
+def test_hash_float(oracle):
+    for f, h in G["hash_float"]:
+        assert oracle.oracle_hash_float(fh(f)) == int(h, 16)
+    # SURVEY.md App. D.3 known answer
+    assert oracle.oracle_hash_float(0.25) == 0x3EB9F34EC52A56A0
+
+
+def test_hash_pixel_seed_point3_mixbits(oracle):
+    for x, y, s, h in G["hash_pixel_seed"]:
+        assert oracle.oracle_hash_pixel_seed(x, y, s) == int(h, 16)
+    for x, y, z, h in G["hash_point3"]:
+        assert oracle.oracle_hash_point3(fh(x), fh(y), fh(z)) == int(h, 16)
+    for v, m in G["mix_bits"]:
+        assert oracle.oracle_mix_bits(int(v, 16)) == int(m, 16)
+
+
+def test_murmur_reference_unit_test_properties(oracle):
+    # src/pbrt/util/hash_test.cpp:13-55: distinct inputs hash differently, buffers hash by content
+    buf = bytes(range(64))
+    hs = {oracle.oracle_murmur64a(buf[:n], n, 0) for n in range(1, 65)}
+    assert len(hs) == 64
+    assert oracle.oracle_murmur64a(b"", 0, 0) == 0  # seed ^ (0*m) mixed: h=0 stays 0
+
+
+def test_rng(oracle):
+    for c in G["rng"]:
+        n = len(c["u32"])
+        u = (C.c_uint32 * n)()
+        f = (C.c_float * n)()
+        oracle.oracle_rng_seq(int(c["seq"], 16), int(c["seed"], 16), c["has_seed"], c["advance"], n, u, f)
+        assert list(u) == c["u32"]
+        assert all(same(a, fh(b)) for a, b in zip(f, c["f"]))
+    # D.3: RNG(Hash(0.25f),Hash(0.75f)).Uniform<float>() = 0x1.62bf6p-2
+    u = (C.c_uint32 * 1)()
+    f = (C.c_float * 1)()
+    oracle.oracle_rng_seq(oracle.oracle_hash_float(0.25), oracle.oracle_hash_float(0.75), 1, 0, 1, u, f)
+    assert f[0] == fh("0x1.62bf6p-2")
+
+
+def test_rng_reference_unit_test_fixtures(oracle):
+    # src/pbrt/util/rng_test.cpp: Advance(n) equals n draws; Advance(-n) rewinds (:16-60)
+    n = 24
+    a = (C.c_uint32 * n)()
+    oracle.oracle_rng_seq(1234, 6502, 1, 0, n, a, None)
+    for k in (1, 5, 17):
+        b = (C.c_uint32 * (n - k))()
+        oracle.oracle_rng_seq(1234, 6502, 1, k, n - k, b, None)
+        assert list(b) == list(a)[k:]
+    # floats in [0,1)
+    f = (C.c_float * 1000)()
+    oracle.oracle_rng_seq(9, 9, 1, 0, 1000, None, f)
+    arr = np.array(f)
+    assert arr.min() >= 0 and arr.max() < 1
+
+
+def test_independent_sampler(oracle):
+    for c in G["independent_sampler"]:
+        n = len(c["f"])
+        out = (C.c_float * n)()
+        oracle.oracle_independent_sampler(c["px"], c["py"], c["seed"], c["sample"], n, out)
+        assert all(same(a, fh(b)) for a, b in zip(out, c["f"]))
+
+
+def test_fast_exp(oracle):
+    for x, y in G["fast_exp"]:
+        assert same(oracle.oracle_fast_exp(fh(x)), fh(y)), (x, y)
+    assert oracle.oracle_fast_exp(-1.5) == fh("0x1.c90078p-3")  # D.3
+    # src/pbrt/util/math_test.cpp:365-376: rel. error <= 3e-4 on [-20,20]
+    xs = np.linspace(-20, 20, 100, dtype=np.float32)
+    for x in xs:
+        e = oracle.oracle_fast_exp(float(x))
+        assert abs(e - np.exp(np.float64(x))) / np.exp(np.float64(x)) < 3e-4
+
+
+def test_sample_exponential_discrete(oracle):
+    for u, a, t in G["sample_exponential"]:
+        assert same(oracle.oracle_sample_exponential(fh(u), fh(a)), fh(t))
+    assert oracle.oracle_sample_exponential(0.3, 2.0) == fh("0x1.6d3c34p-3")  # D.3
+    for w0, w1, u, k in G["sample_discrete2"]:
+        assert oracle.oracle_sample_discrete2(fh(w0), fh(w1), fh(u)) == k
+    assert oracle.oracle_sample_discrete2(0.3, 0.7, 0.5) == 1  # D.3
+
+
+def test_henyey_greenstein(oracle, pkg):
+    for c, g, p in G["henyey_greenstein"]:
+        assert same(oracle.oracle_henyey_greenstein(fh(c), fh(g)), fh(p))
+    for row in G["sample_henyey_greenstein"]:
+        wo, g, u0, u1, wi, pdf = [fh(v) for v in row[0:3]], fh(row[3]), fh(row[4]), fh(row[5]), [fh(v) for v in row[6:9]], fh(row[9])
+        out = pkg.f3()
+        opdf = C.c_float()
+        oracle.oracle_sample_henyey_greenstein(f3(pkg, wo), g, u0, u1, out, C.byref(opdf))
+        assert all(same(a, b) for a, b in zip(out, wi)) and same(opdf.value, pdf)
+
+
+def test_hg_reference_unit_test_properties(oracle, pkg):
+    # src/pbrt/media_test.cpp:15-98: sampling pdf == p(); normalisation; mean cosine == g
+    rng = np.random.default_rng(5)
+    for g in (-0.75, -0.3, 0.0, 0.25, 0.8):
+        us = rng.random((4000, 2)).astype(np.float32)
+        cos_sum = 0.0
+        wo = (0.0, 0.0, 1.0)
+        for u0, u1 in us:
+            out = pkg.f3()
+            pdf = C.c_float()
+            oracle.oracle_sample_henyey_greenstein(f3(pkg, wo), g, float(u0), float(u1), out, C.byref(pdf))
+            c = out[2]  # dot(wo, wi)
+            assert abs(pdf.value - oracle.oracle_henyey_greenstein(c, g)) <= 1e-4 * max(1.0, pdf.value)
+            cos_sum += c
+        # pbrt convention: wo and wi both point away, so E[dot(wo,wi)] = -g
+        assert abs(cos_sum / len(us) + g) < 0.03
+        # normalisation by quadrature over cos(theta)
+        cs = np.linspace(-1, 1, 8001)
+        ps = np.array([oracle.oracle_henyey_greenstein(float(c), g) for c in cs])
+        integ = np.trapezoid(ps, cs) * 2 * np.pi
+        assert abs(integ - 1) < 2e-3
+
+
+def test_direction_sampling(oracle, pkg):
+    for u0, u1, x, y, z in G["sample_uniform_sphere"]:
+        out = pkg.f3()
+        oracle.oracle_sample_uniform_sphere(fh(u0), fh(u1), out)
+        assert all(same(a, fh(b)) for a, b in zip(out, (x, y, z)))
+    for u0, u1, x, y, z in G["sample_cosine_hemisphere"]:
+        out = pkg.f3()
+        oracle.oracle_sample_cosine_hemisphere(fh(u0), fh(u1), out)
+        assert all(same(a, fh(b)) for a, b in zip(out, (x, y, z)))
+    for row in G["coordinate_system"]:
+        v = [fh(t) for t in row]
+        a, b = pkg.f3(), pkg.f3()
+        oracle.oracle_coordinate_system(f3(pkg, v[0:3]), a, b)
+        assert all(same(p, q) for p, q in zip(list(a) + list(b), v[3:9]))
+
+
+def test_offset_ray_origin(oracle, pkg):
+    for row in G["offset_ray_origin"]:
+        v = [fh(t) for t in row]
+        out = pkg.f3()
+        oracle.oracle_offset_ray_origin(f3(pkg, v[0:3]), f3(pkg, v[3:6]), f3(pkg, v[6:9]), f3(pkg, v[9:12]), out)
+        assert all(same(a, b) for a, b in zip(out, v[12:15])), row
+
+
+def test_channel_idx():
+    # spectrum.h:380-384: channelIdx = min(floor(3u), 2); the oracle inlines it in
+    # evaluate_pixel_sample -- check the formula against the reference's outputs
+    for u, ch in G["channel_idx"]:
+        assert min(int(np.floor(np.float32(fh(u)) * np.float32(3))), 2) == ch

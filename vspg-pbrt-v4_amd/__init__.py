@@ -1,0 +1,271 @@
+"""vspg-pbrt-v4_amd -- Python plumbing over the C-ABI of the MI355X-native VSPG hot path.
+
+The product is `csrc/libvspg_hip.so` (hand-written HIP kernels for gfx950 + the C-ABI declared
+in include/vspg.h) and the C++ host adapter in `host/`.  This module is only a ctypes binding
+used by tests/ and bench.py; it contains no algorithm and NO CPU fallback: if the shared
+library is missing, `load()` raises.
+
+The directory name carries a hyphen (it is the repo's package directory, not a Python
+identifier); import it with `importlib` under the name `vspg_pbrt_v4_amd`
+(see tests/conftest.py / bench.py: `load_package()`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvspg_hip.so")
+
+VSPG_MAX_QUADS = 16
+VSPG_ISG_STATS = 8
+
+MEDIUM_NONE, MEDIUM_HOMOGENEOUS, MEDIUM_GRID = 0, 1, 2
+GUIDE_MIS, GUIDE_RIS = 0, 1
+VSP_CONTRIBUTION, VSP_VARIANCE = 0, 1
+VSP_RESAMPLING, VSP_NDS = 0, 1
+LIGHTSAMPLER_UNIFORM, LIGHTSAMPLER_POWER, LIGHTSAMPLER_BVH = 0, 1, 2
+TMAJ_PLAIN, TMAJ_OPTICAL_DEPTH, TMAJ_RESAMPLING = 0, 1, 2
+
+VSPG_OK, VSPG_EINVAL, VSPG_ENODEVICE, VSPG_EHIP, VSPG_ESCOPE = 0, -1, -2, -3, -4
+
+f3 = C.c_float * 3
+
+
+class VspgQuad(C.Structure):
+    _fields_ = [("p00", f3), ("e1", f3), ("e2", f3), ("Kd", f3), ("Le", f3),
+                ("two_sided", C.c_int32), ("reverse_orientation", C.c_int32)]
+
+
+class VspgCamera(C.Structure):
+    _fields_ = [("origin", f3), ("right", f3), ("up", f3), ("fwd", f3),
+                ("sx", C.c_float), ("ox", C.c_float), ("sy", C.c_float), ("oy", C.c_float)]
+
+
+class VspgMedium(C.Structure):
+    _fields_ = [("type", C.c_int32), ("sigma_a", f3), ("sigma_s", f3), ("g", C.c_float),
+                ("Le", f3), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("bounds_min", f3), ("bounds_max", f3), ("density", C.POINTER(C.c_float))]
+
+
+class VspgScene(C.Structure):
+    _fields_ = [("n_quads", C.c_int32), ("quads", VspgQuad * VSPG_MAX_QUADS),
+                ("camera", VspgCamera), ("medium", VspgMedium)]
+
+
+class VspgIntegratorParams(C.Structure):
+    _fields_ = [("maxdepth", C.c_int32), ("minrrdepth", C.c_int32), ("usenee", C.c_int32),
+                ("surfaceguiding", C.c_int32), ("volumeguiding", C.c_int32),
+                ("surfaceguidingtype", C.c_int32), ("volumeguidingtype", C.c_int32),
+                ("vspguiding", C.c_int32), ("vspprimaryguiding", C.c_int32),
+                ("vspsecondaryguiding", C.c_int32), ("vspmisratio", C.c_float),
+                ("vspcriterion", C.c_int32), ("vspsamplingmethod", C.c_int32),
+                ("collisionProbabilityBias", C.c_int32), ("rrguiding", C.c_int32),
+                ("lightsampler", C.c_int32), ("regularize", C.c_int32),
+                ("guide_num_training_waves", C.c_int32)]
+
+
+class VspgRenderConfig(C.Structure):
+    _fields_ = [("xres", C.c_int32), ("yres", C.c_int32), ("spp", C.c_int32), ("seed", C.c_int32),
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("device", C.c_int32)]
+
+
+class VspgCounters(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("volume_scatters", C.c_uint64),
+                ("surface_hits", C.c_uint64), ("density_queries", C.c_uint64),
+                ("shadow_rays", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class VspgTmajQuery(C.Structure):
+    _fields_ = [("o", f3), ("d", f3), ("tMax", C.c_float), ("u", C.c_float),
+                ("rng_a", C.c_float), ("rng_b", C.c_float), ("vsp", C.c_float),
+                ("channel", C.c_int32), ("stop_after", C.c_int32)]
+
+
+class VspgTmajResult(C.Structure):
+    _fields_ = [("T_maj", f3), ("r_u_factor", f3), ("last_t", C.c_float), ("last_p", f3),
+                ("n_callbacks", C.c_int32), ("sum_sigt_over_maj", C.c_float),
+                ("vrc", C.c_float), ("majorant_scale", C.c_float)]
+
+
+# every symbol include/vspg.h declares: (name, restype, argtypes)
+_P = C.POINTER
+_vp = C.c_void_p
+SYMBOLS = [
+    ("vspg_abi_version", C.c_int, []),
+    ("vspg_last_error", C.c_char_p, []),
+    ("vspg_integrator_params_default", None, [_P(VspgIntegratorParams)]),
+    ("vspg_camera_look_at", C.c_int, [_P(VspgCamera), f3, f3, f3, C.c_float, C.c_int, C.c_int]),
+    ("vspg_scene_fog_box", C.c_int, [_P(VspgScene), C.c_int, C.c_int]),
+    ("vspg_renderer_create", C.c_int, [_P(VspgScene), _P(VspgIntegratorParams), _P(VspgRenderConfig), _P(_vp)]),
+    ("vspg_renderer_destroy", C.c_int, [_vp]),
+    ("vspg_render_wave", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    ("vspg_post_process_wave", C.c_int, [_vp, _vp]),
+    ("vspg_film_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
+    ("vspg_film_read", C.c_int, [_vp, _P(C.c_float), _vp]),
+    ("vspg_film_clear", C.c_int, [_vp, _vp]),
+    ("vspg_vsp_buffer_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
+    ("vspg_vsp_buffer_read", C.c_int, [_vp, _P(C.c_float), _P(C.c_int), _vp]),
+    ("vspg_isg_stats_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
+    ("vspg_get_counters", C.c_int, [_vp, _P(VspgCounters), _vp]),
+    ("vspg_reset_counters", C.c_int, [_vp, _vp]),
+    ("vspg_trace_paths", C.c_int, [_vp, C.c_int, _P(C.c_int32), _P(C.c_int32), _P(C.c_float), _P(C.c_int32), _vp]),
+    ("vspg_sample_tmaj_batch", C.c_int, [_vp, C.c_int, C.c_int, _P(VspgTmajQuery), _P(VspgTmajResult), _vp]),
+    ("vspg_primitives_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_uint64), _P(C.c_uint32), _P(C.c_float), _vp]),
+]
+
+_lib = None
+
+
+class VspgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vspg error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load csrc/libvspg_hip.so (built by __graft_entry__.build()).  Raises if it is missing:
+    there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                           % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise VspgError(rc, (lib.vspg_last_error() or b"").decode())
+
+
+def default_params():
+    lib = load()
+    p = VspgIntegratorParams()
+    lib.vspg_integrator_params_default(C.byref(p))
+    return p
+
+
+def fog_box_scene(xres, yres):
+    lib = load()
+    s = VspgScene()
+    _check(lib, lib.vspg_scene_fog_box(C.byref(s), xres, yres))
+    return s
+
+
+def app_f_params():
+    """SURVEY.md App. F integrator line: primary-ray VSP guiding only."""
+    p = default_params()
+    p.surfaceguiding = 0
+    p.volumeguiding = 0
+    p.vspsecondaryguiding = 0
+    return p
+
+
+class Renderer:
+    """Thin RAII wrapper over the vspg_renderer_* entry points."""
+
+    def __init__(self, scene, params, xres, yres, spp=1, seed=0, shard_index=0, shard_count=1, device=0):
+        self.lib = load()
+        self.cfg = VspgRenderConfig(xres, yres, spp, seed, shard_index, shard_count, device)
+        self.scene, self.params = scene, params
+        self.h = _vp()
+        _check(self.lib, self.lib.vspg_renderer_create(C.byref(scene), C.byref(params), C.byref(self.cfg),
+                                                       C.byref(self.h)))
+        self.xres, self.yres = xres, yres
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vspg_renderer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def render_wave(self, w0, w1, stream=None):
+        _check(self.lib, self.lib.vspg_render_wave(self.h, w0, w1, _vp(stream or 0)))
+
+    def post_process_wave(self, stream=None):
+        _check(self.lib, self.lib.vspg_post_process_wave(self.h, _vp(stream or 0)))
+
+    def film_ptr(self):
+        p, n = _vp(), C.c_size_t()
+        _check(self.lib, self.lib.vspg_film_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def isg_stats_ptr(self):
+        p, n = _vp(), C.c_size_t()
+        _check(self.lib, self.lib.vspg_isg_stats_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def vsp_ptr(self):
+        p, n = _vp(), C.c_size_t()
+        _check(self.lib, self.lib.vspg_vsp_buffer_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def film(self, stream=None):
+        import numpy as np
+        out = np.empty((self.yres, self.xres, 4), dtype=np.float32)
+        _check(self.lib, self.lib.vspg_film_read(self.h, out.ctypes.data_as(_P(C.c_float)), _vp(stream or 0)))
+        return out
+
+    def film_clear(self, stream=None):
+        _check(self.lib, self.lib.vspg_film_clear(self.h, _vp(stream or 0)))
+
+    def vsp_buffer(self, stream=None):
+        import numpy as np
+        out = np.empty((self.yres, self.xres), dtype=np.float32)
+        ready = C.c_int()
+        _check(self.lib, self.lib.vspg_vsp_buffer_read(self.h, out.ctypes.data_as(_P(C.c_float)), C.byref(ready),
+                                                      _vp(stream or 0)))
+        return out, bool(ready.value)
+
+    def counters(self, stream=None):
+        c = VspgCounters()
+        _check(self.lib, self.lib.vspg_get_counters(self.h, C.byref(c), _vp(stream or 0)))
+        return c.as_dict()
+
+    def reset_counters(self, stream=None):
+        _check(self.lib, self.lib.vspg_reset_counters(self.h, _vp(stream or 0)))
+
+    def trace_paths(self, pixel_xy, sample_index):
+        import numpy as np
+        pix = np.ascontiguousarray(pixel_xy, dtype=np.int32).reshape(-1, 2)
+        si = np.ascontiguousarray(sample_index, dtype=np.int32).reshape(-1)
+        n = si.shape[0]
+        L = np.empty((n, 3), dtype=np.float32)
+        seg = np.empty(n, dtype=np.int32)
+        _check(self.lib, self.lib.vspg_trace_paths(self.h, n, pix.ctypes.data_as(_P(C.c_int32)),
+                                                   si.ctypes.data_as(_P(C.c_int32)),
+                                                   L.ctypes.data_as(_P(C.c_float)),
+                                                   seg.ctypes.data_as(_P(C.c_int32)), _vp(0)))
+        return L, seg
+
+    def sample_tmaj_batch(self, variant, queries):
+        n = len(queries)
+        q = (VspgTmajQuery * n)(*queries)
+        out = (VspgTmajResult * n)()
+        _check(self.lib, self.lib.vspg_sample_tmaj_batch(self.h, variant, n, q, out, _vp(0)))
+        return list(out)
+
+    def primitives_batch(self, f, g):
+        import numpy as np
+        f = np.ascontiguousarray(f, dtype=np.float32)
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        n = f.shape[0]
+        h = np.empty(n, dtype=np.uint64)
+        r = np.empty(n, dtype=np.uint32)
+        e = np.empty(n, dtype=np.float32)
+        _check(self.lib, self.lib.vspg_primitives_batch(self.h, n, f.ctypes.data_as(_P(C.c_float)),
+                                                        g.ctypes.data_as(_P(C.c_float)),
+                                                        h.ctypes.data_as(_P(C.c_uint64)),
+                                                        r.ctypes.data_as(_P(C.c_uint32)),
+                                                        e.ctypes.data_as(_P(C.c_float)), _vp(0)))
+        return h, r, e
