@@ -247,6 +247,12 @@ int vspg_sample_tmaj_batch(VspgRenderer *r, int variant, int n, const VspgTmajQu
 int vspg_primitives_batch(VspgRenderer *r, int n, const float *f, const float *g,
                           uint64_t *hash, uint32_t *rng_u32, float *fastexp, void *stream);
 
+/* Device float libm batch: logf(x), sinf(x), cosf(x) as the kernels evaluate them; they must
+ * equal the host libm the CPU reference run uses (std::log/std::sin/std::cos of float,
+ * src/pbrt/util/sampling.h:222-225, 325-341, src/pbrt/util/vecmath.h:1666-1672). */
+int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, float *sinf_out,
+                    float *cosf_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

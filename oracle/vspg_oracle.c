@@ -499,6 +499,9 @@ typedef struct {
     float vsp_used;   /* clamped primary VSP used on the first segment, -1 if unguided */
 } isg_sample_t;
 
+static _Thread_local uint32_t g_dbg_flags;
+#define DBG(f) (g_dbg_flags |= (f))
+
 /* closest hit over all quads (stands in for Integrator::Intersect, integrators.cpp:341-349) */
 static isect_t scene_intersect(const OracleRenderer *r, v3 o, v3 d, float tMax) {
     isect_t best;
@@ -695,8 +698,6 @@ static spec sample_T_maj_ods(const OracleRenderer *r, v3 ro, v3 rd, float tMax, 
     (void)beta_factor; /* never written by the reference */
     if (!guide || vspMISRatio == 0.f) return sample_T_maj(r, ro, rd, tMax, u, rng, ch, cb, cbctx);
 
-    v3 ro0 = ro, rd0 = rd;
-    float tMax0 = tMax;
     tMax *= v_len(rd);
     rd = v_normalize(rd);
     majiter_t iter = medium_sample_ray(r, ro, rd, tMax);
@@ -705,7 +706,7 @@ static spec sample_T_maj_ods(const OracleRenderer *r, v3 ro, v3 rd, float tMax, 
     while (1) {
         majseg_t seg;
         if (!majiter_next(&pre, &seg)) break;
-        if (isinf(seg.tMax)) return sample_T_maj(r, ro0, rd0, tMax0, u, rng, ch, cb, cbctx);
+        if (isinf(seg.tMax)) return sample_T_maj(r, ro, rd, tMax, u, rng, ch, cb, cbctx); /* normalised ray, scaled tMax (:307) */
         if (seg.sigma_maj.c[ch] == 0) continue;
         t_v += seg.sigma_maj.c[ch] * (seg.tMax - seg.tMin);
     }
@@ -715,7 +716,7 @@ static spec sample_T_maj_ods(const OracleRenderer *r, v3 ro, v3 rd, float tMax, 
     float t_n = -1.f, t_n_current = -1.f;
     if (NDS) {
         if (vsp < 1 - oracle_fast_exp(-t_v))
-            return sample_T_maj(r, ro0, rd0, tMax0, u, rng, ch, cb, cbctx);
+            return sample_T_maj(r, ro, rd, tMax, u, rng, ch, cb, cbctx); /* (:327) */
         else {
             t_n = (float)(-log(1.0 - (double)(OneMinusENegTv / vsp)));
             t_n_current = t_n;
@@ -1036,6 +1037,7 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, int ch, sampl
     r_l = s_mul(r_l, s_scale(r_p, p_l));
     r_u = s_mul(r_u, s_scale(r_p, scatterPDF));
     /* area light is not a delta light */
+    DBG(intr->is_surface ? 32 : 64);
     return s_divf(s_mul(s_mul(f_hat, T_ray), ls.L), s_avg(s_add(r_l, r_u)));
 }
 
@@ -1092,6 +1094,7 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
         if (survivalProb < 1 && *c->depth > r->prm.minrrdepth) {
             float q = fmaxf(0.f, 1 - survivalProb);
             if (sampler_get1d(c->sampler) < q) {
+                DBG(16);
                 c->terminated = 1;
                 return;
             }
@@ -1359,8 +1362,10 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         spec Le = q->is_light ? light_L(q, si.n, v_neg(rd)) : S1(0.f);
         if (s_nonzero(Le)) {
             if (depth == 0 || specularBounce) {
+                DBG(1);
                 L = s_add(L, s_divf(s_mul(beta, Le), s_avg(r_u)));
             } else {
+                DBG(lastVertexVolume ? 2 : 4);
                 float lightPDF = (1.f / (float)r->n_lights) * light_pdf_li(q, &prevIntrCtx, rd);
                 r_l = s_scale(r_l, lightPDF);
                 float w_l = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.0f;
@@ -1415,7 +1420,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         }
         if (survivalProb < 1 && depth > r->prm.minrrdepth) {
             float qq = fmaxf(0.f, 1 - survivalProb);
-            if (sampler_get1d(sampler) < qq) break;
+            if (sampler_get1d(sampler) < qq) { DBG(8); break; }
             beta = s_divf(beta, 1 - qq);
         }
     }
@@ -1643,6 +1648,7 @@ void oracle_reset_counters(OracleRenderer *r) { memset(&r->counters, 0, sizeof r
 int oracle_trace_paths(OracleRenderer *r, int n, const int32_t *pixel_xy, const int32_t *sample_index,
                        float *out_L, int32_t *out_segments) {
     for (int i = 0; i < n; ++i) {
+        g_dbg_flags = 0;
         path_counters_t pc;
         memset(&pc, 0, sizeof pc);
         isg_sample_t isg;

@@ -46,3 +46,26 @@ def gpu_pkg(pkg):
     """The package with the HIP library loaded; fails loudly if the extension is missing."""
     pkg.load()
     return pkg
+
+
+@pytest.fixture(scope="session")
+def libm_shim():
+    """tests/libm_model_shim.cpp built for the host: the product's vspg_libm.h functions next to
+    the running libm's logf/sinf/cosf."""
+    import ctypes as C
+    import subprocess
+
+    src = os.path.join(ROOT, "tests", "libm_model_shim.cpp")
+    out = os.path.join(ROOT, "tests", "_build", "libm_model_shim.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    hdr = os.path.join(ROOT, "vspg-pbrt-v4_amd", "csrc", "vspg_libm.h")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        flags = ["-O2", "-ffp-contract=off", "-fno-builtin", "-shared", "-fPIC"]
+        if " fma " in open("/proc/cpuinfo").read():
+            flags.append("-mfma")
+        subprocess.check_call(["g++"] + flags + ["-o", out, src, "-lm"])
+    lib = C.CDLL(out)
+    fp = C.POINTER(C.c_float)
+    for n in ("model_logf", "model_sinf", "model_cosf", "libm_logf", "libm_sinf", "libm_cosf"):
+        getattr(lib, n).argtypes = [C.c_int, fp, fp]
+    return lib

@@ -1,0 +1,15 @@
+// Test shim: exposes the product's host-exact float functions (vspg_libm.h, the same header the
+// HIP kernels use) and the running libm's logf/sinf/cosf side by side, for bitwise comparison.
+#include <math.h>
+#include <stdint.h>
+
+#include "../vspg-pbrt-v4_amd/csrc/vspg_libm.h"
+
+extern "C" {
+void model_logf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::logf_host_exact(x[i]); }
+void model_sinf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::sinf_host_exact(x[i]); }
+void model_cosf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::cosf_host_exact(x[i]); }
+void libm_logf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = logf(x[i]); }
+void libm_sinf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = sinf(x[i]); }
+void libm_cosf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = cosf(x[i]); }
+}

@@ -1,0 +1,59 @@
+"""The device's logf/sinf/cosf (csrc/vspg_libm.h) must equal the HOST libm bit for bit, because
+the CPU reference path calls the host libm and a single ulp re-seeds the shadow-ray RNG.  Here
+the same header is compiled for the host and compared with the running libm on >10^7 arguments
+drawn from the ranges the path produces.  (GPU build of the same header: test_gpu_parity.py.)"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def shim(libm_shim):
+    return libm_shim
+
+
+def run(lib, name, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    fp = C.POINTER(C.c_float)
+    getattr(lib, name)(x.shape[0], x.ctypes.data_as(fp), y.ctypes.data_as(fp))
+    return y
+
+
+def check(lib, fn, x):
+    a, b = run(lib, "model_" + fn, x), run(lib, "libm_" + fn, x)
+    bad = np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]
+    assert bad.size == 0, "%s: %d mismatches, e.g. x=%r model=%r libm=%r" % (
+        fn, bad.size, x[bad[:3]], a[bad[:3]], b[bad[:3]])
+
+
+def test_logf_equals_host_libm(shim):
+    rng = np.random.default_rng(0)
+    # SampleExponential: log(1-u), u = k*2^-32 rounded to float; resampling: log(1-vsp)
+    u = np.minimum((rng.integers(0, 2 ** 32, 6_000_000, dtype=np.uint64).astype(np.float32) * np.float32(2.0 ** -32)),
+                   np.float32(float.fromhex('0x1.fffffep-1')))
+    check(shim, "logf", np.float32(1) - u)
+    check(shim, "logf", rng.uniform(1e-3, 1.0, 2_000_000).astype(np.float32))
+    check(shim, "logf", np.exp(rng.uniform(-80, 80, 2_000_000)).astype(np.float32))
+    # every float in a few binades around 1 where the table index changes
+    bits = np.arange(0x3f000000, 0x3f000000 + 3_000_000, dtype=np.uint32)
+    check(shim, "logf", bits.view(np.float32))
+    check(shim, "logf", np.array([1.0, 0.5, 2.0, 2.0 ** -126, 3.4e38, float.fromhex('0x1.fffffep-1')], dtype=np.float32))
+
+
+@pytest.mark.parametrize("fn", ["sinf", "cosf"])
+def test_sincos_equal_host_libm(shim, fn):
+    rng = np.random.default_rng(1)
+    two_pi = np.float32(2) * np.float32(np.pi)
+    # phi = 2*Pi*u (HG / sphere sampling), theta in [-pi/4, 3pi/4] (concentric disk)
+    check(shim, fn, two_pi * rng.random(6_000_000, dtype=np.float32))
+    check(shim, fn, rng.uniform(-np.pi / 4, 3 * np.pi / 4, 4_000_000).astype(np.float32))
+    check(shim, fn, rng.uniform(-119.9, 119.9, 2_000_000).astype(np.float32))
+    check(shim, fn, (10.0 ** rng.uniform(-8, 0, 1_000_000)).astype(np.float32))
+    edge = np.array([0.0, -0.0, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, 2.0 ** -12, float.fromhex('0x1.fffffep-13'), 119.99], dtype=np.float32)
+    check(shim, fn, np.concatenate([edge, -edge, np.nextafter(edge, np.float32(10)), np.nextafter(edge, np.float32(-10))]))

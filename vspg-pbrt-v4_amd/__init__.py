@@ -113,6 +113,7 @@ SYMBOLS = [
     ("vspg_trace_paths", C.c_int, [_vp, C.c_int, _P(C.c_int32), _P(C.c_int32), _P(C.c_float), _P(C.c_int32), _vp]),
     ("vspg_sample_tmaj_batch", C.c_int, [_vp, C.c_int, C.c_int, _P(VspgTmajQuery), _P(VspgTmajResult), _vp]),
     ("vspg_primitives_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_uint64), _P(C.c_uint32), _P(C.c_float), _vp]),
+    ("vspg_libm_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
 ]
 
 _lib = None
@@ -269,3 +270,13 @@ class Renderer:
                                                         r.ctypes.data_as(_P(C.c_uint32)),
                                                         e.ctypes.data_as(_P(C.c_float)), _vp(0)))
         return h, r, e
+
+    def libm_batch(self, x):
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        lo, so, co = (np.empty(n, dtype=np.float32) for _ in range(3))
+        fp = _P(C.c_float)
+        _check(self.lib, self.lib.vspg_libm_batch(self.h, n, x.ctypes.data_as(fp), lo.ctypes.data_as(fp),
+                                                  so.ctypes.data_as(fp), co.ctypes.data_as(fp), _vp(0)))
+        return lo, so, co

@@ -1,0 +1,678 @@
+// vspg_capi.hip -- HIP kernels (gfx950) + the C-ABI declared in include/vspg.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
+// No CPU fallback lives here: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vspg_path.h"
+
+using namespace vspg;
+
+// =======================================================================================
+// kernels
+// =======================================================================================
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kNumCounters = 6;  // paths, segments, volume_scatters, surface_hits, density_queries, shadow_rays
+
+__device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t paths, unsigned long long *g) {
+    __shared__ unsigned int s[kNumCounters];
+    if (threadIdx.x < kNumCounters) s[threadIdx.x] = 0;
+    __syncthreads();
+    atomicAdd(&s[0], paths);
+    atomicAdd(&s[1], pc.segments);
+    atomicAdd(&s[2], pc.volume_scatters);
+    atomicAdd(&s[3], pc.surface_hits);
+    atomicAdd(&s[4], pc.density_queries);
+    atomicAdd(&s[5], pc.shadow_rays);
+    __syncthreads();
+    if (threadIdx.x < kNumCounters) atomicAdd(&g[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+
+// One lane owns one pixel and runs its samples [wave_start, wave_end) to termination, path state
+// in registers (no HBM round trip between segments); film and ISG statistics are read-modify-
+// written once per launch by the owning lane (no atomics: one owner per pixel per launch).
+// Lanes of a wavefront cover an 8x8 pixel tile so primary rays are coherent.
+template <class Medium>
+__global__ __launch_bounds__(kBlock) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
+                                                        float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
+                                                        int vsp_ready, int wave_start, int wave_end,
+                                                        unsigned long long *__restrict__ counters) {
+    const DScene &S = *Sp;
+    const int W = S.xres, H = S.yres;
+    const int tilesX = (W + 7) >> 3;
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int tile = gid >> 6, lane = gid & 63;
+    const int px = (tile % tilesX) * 8 + (lane & 7);
+    const int py = (tile / tilesX) * 8 + (lane >> 3);
+    const bool active = px < W && py < H;
+    PathCounters pc = {0, 0, 0, 0, 0};
+    uint32_t paths = 0;
+    if (active) {
+        const Medium medium = make_homogeneous(S);
+        const size_t idx = (size_t)py * W + px;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float st8[VSPG_ISG_STATS];
+        const float4 *sp4 = reinterpret_cast<const float4 *>(isg_stats + idx * VSPG_ISG_STATS);
+        float4 s0 = sp4[0], s1 = sp4[1];
+        st8[0] = s0.x; st8[1] = s0.y; st8[2] = s0.z; st8[3] = s0.w;
+        st8[4] = s1.x; st8[5] = s1.y; st8[6] = s1.z; st8[7] = s1.w;
+        for (int s = wave_start; s < wave_end; ++s) {
+            if (S.shard_count > 1 && (s % S.shard_count) != S.shard_index) continue;
+            Sampler sampler;
+            PathState st;
+            IsgSample isg;
+            int ch;
+            start_path(S, px, py, s, sampler, st, &ch, isg);
+            while (li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc)) {
+            }
+            Spec L = finish_radiance(st.L);
+            // RGBFilm::AddSample (film.h:251-267), weight 1, imagingRatio 1, no clamp
+            acc.x += L.r; acc.y += L.g; acc.z += L.b; acc.w += 1.f;
+            isg_add_sample(st8, L, isg);
+            paths++;
+        }
+        float4 f = film[idx];
+        f.x += acc.x; f.y += acc.y; f.z += acc.z; f.w += acc.w;
+        film[idx] = f;
+        float4 *so = reinterpret_cast<float4 *>(isg_stats + idx * VSPG_ISG_STATS);
+        so[0] = make_float4(st8[0], st8[1], st8[2], st8[3]);
+        so[1] = make_float4(st8[4], st8[5], st8[6], st8[7]);
+    }
+    flush_counters(pc, paths, counters);
+}
+
+template <class Medium>
+__global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict__ Sp, const float *__restrict__ vsp_buf,
+                                                        int vsp_ready, int n, const int32_t *__restrict__ pixel_xy,
+                                                        const int32_t *__restrict__ sample_index, float *__restrict__ out_L,
+                                                        int32_t *__restrict__ out_seg) {
+    const DScene &S = *Sp;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Medium medium = make_homogeneous(S);
+    int px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
+    PathCounters pc = {0, 0, 0, 0, 0};
+    Sampler sampler;
+    PathState st;
+    IsgSample isg;
+    int ch;
+    start_path(S, px, py, sample_index[i], sampler, st, &ch, isg);
+    while (li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc)) {
+    }
+    Spec L = finish_radiance(st.L);
+    out_L[3 * i] = L.r; out_L[3 * i + 1] = L.g; out_L[3 * i + 2] = L.b;
+    if (out_seg) out_seg[i] = (int32_t)pc.segments;
+}
+
+template <class Medium>
+__global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict__ Sp, int variant, int n,
+                                                       const VspgTmajQuery *__restrict__ q, VspgTmajResult *__restrict__ out) {
+    const DScene &S = *Sp;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Medium medium = make_homogeneous(S);
+    VspgTmajQuery Q = q[i];
+    VspgTmajResult R;
+    memset(&R, 0, sizeof R);
+    R.last_t = -1.f;
+    R.majorant_scale = 1.f;
+    Rng rng;
+    rng.set_sequence(hash_float(Q.rng_a), hash_float(Q.rng_b));
+    const int ch = Q.channel;
+    V3 ro = ld3(Q.o), rd = ld3(Q.d), rdn = normalize(rd);
+    bool guide = Q.vsp >= 0.f;
+    float vsp = guide ? fmax_(fmin_(Q.vsp, 0.999f), 0.001f) : Q.vsp;
+    int ncb = 0;
+    float sum = 0, last_t = -1.f;
+    V3 lastp = mk(0, 0, 0);
+    auto rec = [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec, bool) {
+        ncb++;
+        lastp = p;
+        last_t = dot(p - ro, rdn);
+        Spec sigma_t = mp.sigma_s + mp.sigma_a;
+        sum += ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
+        if (Q.stop_after > 0 && ncb >= Q.stop_after) return false;
+        return true;
+    };
+    Spec T = sp(1.f), rf = sp(1.f);
+    if (variant == VSPG_TMAJ_PLAIN) {
+        T = sample_T_maj(medium, ro, rd, Q.tMax, Q.u, rng, ch, rec);
+    } else if (variant == VSPG_TMAJ_OPTICAL_DEPTH) {
+        T = sample_T_maj_ods(medium, ro, rd, Q.tMax, Q.u, rng, ch, guide, vsp, S.prm.vspmisratio,
+                             S.prm.vspsamplingmethod == VSPG_VSP_NDS, &rf, rec);
+    } else {
+        float vrc = vsp, ms = 1.f;
+        T = sample_T_maj_resampling(medium, ro, rd, Q.tMax, Q.u, rng, ch, guide, vsp, &vrc, &ms, rec);
+        R.vrc = vrc;
+        R.majorant_scale = ms;
+    }
+    R.T_maj[0] = T.r; R.T_maj[1] = T.g; R.T_maj[2] = T.b;
+    R.r_u_factor[0] = rf.r; R.r_u_factor[1] = rf.g; R.r_u_factor[2] = rf.b;
+    R.last_t = last_t;
+    R.last_p[0] = lastp.x; R.last_p[1] = lastp.y; R.last_p[2] = lastp.z;
+    R.n_callbacks = ncb;
+    R.sum_sigt_over_maj = sum;
+    out[i] = R;
+}
+
+__global__ __launch_bounds__(kBlock) void k_primitives(int n, const float *__restrict__ f, const float *__restrict__ g,
+                                                       uint64_t *__restrict__ hash, uint32_t *__restrict__ rng_u32,
+                                                       float *__restrict__ fexp) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    hash[i] = hash_float(f[i]);
+    Rng r;
+    r.set_sequence(hash_float(f[i]), hash_float(g[i]));
+    rng_u32[i] = r.u32();
+    fexp[i] = fast_exp(f[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_libm(int n, const float *__restrict__ x, float *__restrict__ lo,
+                                                 float *__restrict__ so, float *__restrict__ co) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    lo[i] = logf_(x[i]);
+    so[i] = sinf_(x[i]);
+    co[i] = cosf_(x[i]);
+}
+
+// ImageSpaceGuidingBuffer::Update stand-in: 5x5 box filter over the sufficient statistics,
+// then the contribution / variance criterion (own design, unpinned).
+constexpr int kIsgRadius = 2;
+__global__ __launch_bounds__(kBlock) void k_isg_update(int W, int H, int criterion, const float *__restrict__ stats,
+                                                       float *__restrict__ vsp) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= W * H) return;
+    int x = i % W, y = i / W;
+    float a[5] = {0, 0, 0, 0, 0};
+    for (int dy = -kIsgRadius; dy <= kIsgRadius; ++dy)
+        for (int dx = -kIsgRadius; dx <= kIsgRadius; ++dx) {
+            int xx = x + dx, yy = y + dy;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const float *st = stats + ((size_t)yy * W + xx) * VSPG_ISG_STATS;
+            float4 s0 = *reinterpret_cast<const float4 *>(st);
+            float s4 = st[4];
+            a[0] += s0.x; a[1] += s0.y; a[2] += s0.z; a[3] += s0.w; a[4] += s4;
+        }
+    float r = -1.f;
+    if (a[0] > 0) {
+        float v, s;
+        if (criterion == VSPG_VSP_VARIANCE) {
+            v = __builtin_sqrtf(a[3] / a[0]);
+            s = __builtin_sqrtf(a[4] / a[0]);
+        } else {
+            v = a[1] / a[0];
+            s = a[2] / a[0];
+        }
+        if (v + s > 0) r = v / (v + s);
+    }
+    vsp[i] = r;
+}
+
+}  // namespace
+
+// =======================================================================================
+// host side
+// =======================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(VSPG_EHIP, std::string(#expr) + ": " + hipGetErrorName(e_) + " (" + hipGetErrorString(e_) + ")"); \
+    } while (0)
+
+struct VspgRenderer {
+    VspgScene scene;
+    VspgIntegratorParams prm;
+    VspgRenderConfig cfg;
+    DScene hscene;
+    DScene *dscene = nullptr;
+    float4 *film = nullptr;
+    float *isg_stats = nullptr;
+    float *vsp = nullptr;
+    unsigned long long *counters = nullptr;
+    int vsp_ready = 0;
+    int wave_counter = 0, buffer_wave = 0;
+    size_t npix = 0;
+};
+
+// ---- host float helpers for scene preprocessing (same formulas as the kernels use) ----
+namespace hostmath {
+struct H3 { float x, y, z; };
+static H3 ld(const float *p) { return H3{p[0], p[1], p[2]}; }
+static void stv(float *d, H3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+static H3 add(H3 a, H3 b) { return H3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static H3 absv(H3 a) { return H3{std::fabs(a.x), std::fabs(a.y), std::fabs(a.z)}; }
+static float dop(float a, float b, float c, float d) {
+    float cd = c * d;
+    float r = std::fmaf(a, b, -cd);
+    float e = std::fmaf(-c, d, cd);
+    return r + e;
+}
+static H3 crossv(H3 v, H3 w) { return H3{dop(v.y, w.z, v.z, w.y), dop(v.z, w.x, v.x, w.z), dop(v.x, w.y, v.y, w.x)}; }
+static float len2v(H3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+static H3 normv(H3 a) { float l = std::sqrt(len2v(a)); return H3{a.x / l, a.y / l, a.z / l}; }
+}  // namespace hostmath
+
+static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, const VspgRenderConfig &cfg, DScene *D) {
+    using namespace hostmath;
+    memset(D, 0, sizeof *D);
+    D->n_quads = sc.n_quads;
+    for (int i = 0; i < sc.n_quads; ++i) {
+        const VspgQuad &in = sc.quads[i];
+        DQuad &q = D->quads[i];
+        H3 p00 = ld(in.p00), e1 = ld(in.e1), e2 = ld(in.e2);
+        H3 p10 = add(p00, e1), p01 = add(p00, e2), p11 = add(p10, e2);
+        stv(q.p00, p00); stv(q.p10, p10); stv(q.p01, p01); stv(q.p11, p11); stv(q.e1, e1); stv(q.e2, e2);
+        H3 c = crossv(e1, e2);
+        q.area = std::sqrt(len2v(c));
+        H3 n = normv(c);
+        if (in.reverse_orientation) n = H3{-n.x, -n.y, -n.z};
+        stv(q.n, n);
+        stv(q.dpdu_n, normv(e1));
+        const float eps = 0x1p-24f;
+        float g6 = (6 * eps) / (1 - 6 * eps);  // gamma(6) (util/float.h:195)
+        H3 s = add(add(absv(p00), absv(p01)), add(absv(p10), absv(p11)));
+        stv(q.perr, H3{s.x * g6, s.y * g6, s.z * g6});
+        q.inv_l1 = 1.f / len2v(e1);
+        q.inv_l2 = 1.f / len2v(e2);
+        bool lobes = false, light = false;
+        for (int k = 0; k < 3; ++k) {
+            float kd = in.Kd[k];
+            kd = kd < 0 ? 0 : (kd > 1 ? 1 : kd);  // DiffuseMaterial clamps reflectance to [0,1]
+            q.Kd[k] = kd;
+            q.Le[k] = in.Le[k];
+            lobes = lobes || kd != 0;
+            light = light || in.Le[k] != 0;
+        }
+        q.two_sided = in.two_sided;
+        q.is_light = light;
+        q.has_lobes = lobes;
+        if (light) D->light_quads[D->n_lights++] = i;
+    }
+    D->cam = sc.camera;
+    D->medium_type = sc.medium.type;
+    for (int k = 0; k < 3; ++k) {
+        D->sigma_a[k] = sc.medium.sigma_a[k];
+        D->sigma_s[k] = sc.medium.sigma_s[k];
+        D->Le[k] = sc.medium.Le[k];
+    }
+    D->g = sc.medium.g;
+    D->prm = prm;
+    D->xres = cfg.xres;
+    D->yres = cfg.yres;
+    D->seed = cfg.seed;
+    D->shard_index = cfg.shard_index;
+    D->shard_count = cfg.shard_count < 1 ? 1 : cfg.shard_count;
+}
+
+static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const VspgRenderConfig *cfg) {
+    if (!scene || !p || !cfg) return fail(VSPG_EINVAL, "null argument");
+    if (cfg->xres <= 0 || cfg->yres <= 0) return fail(VSPG_EINVAL, "film resolution must be positive");
+    if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return fail(VSPG_EINVAL, "n_quads out of range");
+    if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count))
+        return fail(VSPG_EINVAL, "shard_index out of range");
+    if (p->maxdepth < 0) return fail(VSPG_EINVAL, "maxdepth must be >= 0");
+    if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
+    if (p->collisionProbabilityBias) return fail(VSPG_ESCOPE, "collisionProbabilityBias (NDS+ / TrBuffer) is outside the hot-path scope");
+    if (p->rrguiding) return fail(VSPG_ESCOPE, "rrguiding (guided Russian roulette) is outside the hot-path scope");
+    if (p->surfaceguiding || p->volumeguiding || (p->vspguiding && p->vspsecondaryguiding))
+        return fail(VSPG_ESCOPE,
+                    "directional guiding / secondary-ray VSP need the OpenPGL-style guiding cache, which this build does "
+                    "not provide yet: set surfaceguiding, volumeguiding and vspsecondaryguiding to false");
+    if (scene->medium.type == VSPG_MEDIUM_GRID) return fail(VSPG_ESCOPE, "grid media are not built yet in this round");
+    if (scene->medium.type != VSPG_MEDIUM_NONE && scene->medium.type != VSPG_MEDIUM_HOMOGENEOUS)
+        return fail(VSPG_EINVAL, "unknown medium type");
+    int nl = 0;
+    for (int i = 0; i < scene->n_quads; ++i)
+        if (scene->quads[i].Le[0] != 0 || scene->quads[i].Le[1] != 0 || scene->quads[i].Le[2] != 0) nl++;
+    if (p->lightsampler == VSPG_LIGHTSAMPLER_BVH && nl > 1)
+        return fail(VSPG_ESCOPE, "lightsampler \"bvh\" with more than one light is outside scope: use \"uniform\"");
+    if (p->lightsampler == VSPG_LIGHTSAMPLER_POWER && nl > 1)
+        return fail(VSPG_ESCOPE, "lightsampler \"power\" with more than one light is outside scope: use \"uniform\"");
+    return 0;
+}
+
+extern "C" {
+
+int vspg_abi_version(void) { return VSPG_ABI_VERSION; }
+const char *vspg_last_error(void) { return g_err.c_str(); }
+
+void vspg_integrator_params_default(VspgIntegratorParams *p) {
+    // GuidedVolPathVSPGIntegrator::Create defaults (guidedvolpathvspgintegrator.cpp:1263-1319)
+    memset(p, 0, sizeof *p);
+    p->maxdepth = 5;
+    p->minrrdepth = 1;
+    p->usenee = 1;
+    p->surfaceguiding = 1;
+    p->volumeguiding = 1;
+    p->surfaceguidingtype = VSPG_GUIDE_RIS;
+    p->volumeguidingtype = VSPG_GUIDE_MIS;
+    p->vspguiding = 1;
+    p->vspprimaryguiding = 1;
+    p->vspsecondaryguiding = 1;
+    p->vspmisratio = 0.5f;
+    p->vspcriterion = VSPG_VSP_VARIANCE;
+    p->vspsamplingmethod = VSPG_VSP_RESAMPLING;
+    p->lightsampler = VSPG_LIGHTSAMPLER_BVH;
+    p->guide_num_training_waves = 128;
+}
+
+int vspg_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3], const float up[3], float fov_degrees,
+                        int xres, int yres) {
+    if (!cam || xres <= 0 || yres <= 0) return fail(VSPG_EINVAL, "bad camera arguments");
+    double e[3], f[3], u[3];
+    for (int i = 0; i < 3; ++i) { e[i] = eye[i]; f[i] = (double)look[i] - eye[i]; u[i] = up[i]; }
+    double fl = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (fl == 0 || ul == 0) return fail(VSPG_EINVAL, "degenerate LookAt");
+    for (int i = 0; i < 3; ++i) { f[i] /= fl; u[i] /= ul; }
+    // pbrt LookAt: right = Normalize(Cross(Normalize(up), dir)); newUp = Cross(dir, right)
+    double r[3] = {u[1] * f[2] - u[2] * f[1], u[2] * f[0] - u[0] * f[2], u[0] * f[1] - u[1] * f[0]};
+    double rl = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (rl == 0) return fail(VSPG_EINVAL, "up vector parallel to view direction");
+    for (int i = 0; i < 3; ++i) r[i] /= rl;
+    double nu[3] = {f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0]};
+    for (int i = 0; i < 3; ++i) {
+        cam->origin[i] = (float)e[i];
+        cam->right[i] = (float)r[i];
+        cam->up[i] = (float)nu[i];
+        cam->fwd[i] = (float)f[i];
+    }
+    // screen window spans [-1,1] on the shorter axis (cameras.cpp:474-489); raster y points down
+    double aspect = (double)xres / (double)yres;
+    double wx = aspect > 1 ? aspect : 1.0, wy = aspect > 1 ? 1.0 : 1.0 / aspect;
+    double th = std::tan(fov_degrees * 3.14159265358979323846 / 360.0);
+    cam->sx = (float)(2.0 * wx * th / xres);
+    cam->ox = (float)(-wx * th);
+    cam->sy = (float)(-2.0 * wy * th / yres);
+    cam->oy = (float)(wy * th);
+    return 0;
+}
+
+static void quad(VspgQuad *q, float px, float py, float pz, float ax, float ay, float az, float bx, float by, float bz,
+                 float kd, float lr, float lg, float lb) {
+    memset(q, 0, sizeof *q);
+    q->p00[0] = px; q->p00[1] = py; q->p00[2] = pz;
+    q->e1[0] = ax; q->e1[1] = ay; q->e1[2] = az;
+    q->e2[0] = bx; q->e2[1] = by; q->e2[2] = bz;
+    q->Kd[0] = q->Kd[1] = q->Kd[2] = kd;
+    q->Le[0] = lr; q->Le[1] = lg; q->Le[2] = lb;
+}
+
+int vspg_scene_fog_box(VspgScene *s, int xres, int yres) {
+    if (!s) return fail(VSPG_EINVAL, "null scene");
+    memset(s, 0, sizeof *s);
+    const float k = 0.73f;
+    s->n_quads = 7;  // normals e1 x e2 face into the box
+    quad(&s->quads[0], -1, -1, -1, 0, 0, 2, 2, 0, 0, k, 0, 0, 0);   // floor
+    quad(&s->quads[1], -1, 1, -1, 2, 0, 0, 0, 0, 2, k, 0, 0, 0);    // ceiling
+    quad(&s->quads[2], -1, -1, 1, 0, 2, 0, 2, 0, 0, k, 0, 0, 0);    // back  z=+1
+    quad(&s->quads[3], -1, -1, -1, 2, 0, 0, 0, 2, 0, k, 0, 0, 0);   // front z=-1
+    quad(&s->quads[4], -1, -1, -1, 0, 2, 0, 0, 0, 2, k, 0, 0, 0);   // left
+    quad(&s->quads[5], 1, -1, -1, 0, 0, 2, 0, 2, 0, k, 0, 0, 0);    // right
+    quad(&s->quads[6], -0.25f, 0.999f, -0.25f, 0.5f, 0, 0, 0, 0, 0.5f, 0, 17, 12, 4);  // ceiling light, faces -y
+    const float eye[3] = {0, 0, -0.95f}, look[3] = {0, 0, 0}, up[3] = {0, 1, 0};
+    int rc = vspg_camera_look_at(&s->camera, eye, look, up, 60.f, xres, yres);
+    if (rc) return rc;
+    s->medium.type = VSPG_MEDIUM_HOMOGENEOUS;
+    for (int i = 0; i < 3; ++i) { s->medium.sigma_a[i] = 0.05f; s->medium.sigma_s[i] = 0.45f; }
+    s->medium.g = 0.f;
+    return 0;
+}
+
+int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *params, const VspgRenderConfig *cfg,
+                         VspgRenderer **out) {
+    if (!out) return fail(VSPG_EINVAL, "null out pointer");
+    *out = nullptr;
+    int rc = validate(scene, params, cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(VSPG_ENODEVICE, std::string("no HIP device available (") + hipGetErrorName(e) + "); this library has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(VSPG_EINVAL, "device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+    VspgRenderer *r = new VspgRenderer();
+    r->scene = *scene;
+    r->prm = *params;
+    r->cfg = *cfg;
+    if (r->cfg.shard_count < 1) { r->cfg.shard_count = 1; r->cfg.shard_index = 0; }
+    build_dscene(r->scene, r->prm, r->cfg, &r->hscene);
+    r->npix = (size_t)cfg->xres * cfg->yres;
+#define CK(expr)                                                                                                  \
+    do {                                                                                                          \
+        hipError_t e2 = (expr);                                                                                   \
+        if (e2 != hipSuccess) {                                                                                   \
+            vspg_renderer_destroy(r);                                                                             \
+            return fail(VSPG_EHIP, std::string(#expr) + ": " + hipGetErrorName(e2));                              \
+        }                                                                                                         \
+    } while (0)
+    CK(hipMalloc(&r->dscene, sizeof(DScene)));
+    CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
+    CK(hipMalloc(&r->film, r->npix * sizeof(float4)));
+    CK(hipMemset(r->film, 0, r->npix * sizeof(float4)));
+    CK(hipMalloc(&r->isg_stats, r->npix * VSPG_ISG_STATS * sizeof(float)));
+    CK(hipMemset(r->isg_stats, 0, r->npix * VSPG_ISG_STATS * sizeof(float)));
+    CK(hipMalloc(&r->vsp, r->npix * sizeof(float)));
+    CK(hipMemset(r->vsp, 0, r->npix * sizeof(float)));
+    CK(hipMalloc(&r->counters, kNumCounters * sizeof(unsigned long long)));
+    CK(hipMemset(r->counters, 0, kNumCounters * sizeof(unsigned long long)));
+#undef CK
+    *out = r;
+    return 0;
+}
+
+int vspg_renderer_destroy(VspgRenderer *r) {
+    if (!r) return 0;
+    (void)hipSetDevice(r->cfg.device);
+    if (r->dscene) (void)hipFree(r->dscene);
+    if (r->film) (void)hipFree(r->film);
+    if (r->isg_stats) (void)hipFree(r->isg_stats);
+    if (r->vsp) (void)hipFree(r->vsp);
+    if (r->counters) (void)hipFree(r->counters);
+    delete r;
+    return 0;
+}
+
+int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream) {
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    if (wave_end < wave_start || wave_start < 0) return fail(VSPG_EINVAL, "bad wave range");
+    if (wave_end == wave_start) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
+    const long long threads = (long long)tilesX * tilesY * 64;
+    const int blocks = (int)((threads + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_render_wave<HomogeneousMedium>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, r->counters);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int vspg_post_process_wave(VspgRenderer *r, void *stream) {
+    // PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260)
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    r->wave_counter++;
+    if ((double)r->wave_counter == std::pow(2.0, (double)r->buffer_wave)) {
+        if (r->prm.vspguiding && r->prm.vspprimaryguiding) {
+            HIPCHK(hipSetDevice(r->cfg.device));
+            int blocks = (int)((r->npix + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(k_isg_update, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, r->cfg.xres, r->cfg.yres,
+                               r->prm.vspcriterion, r->isg_stats, r->vsp);
+            HIPCHK(hipGetLastError());
+            r->vsp_ready = 1;
+        }
+        r->buffer_wave++;
+    }
+    return 0;
+}
+
+int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
+    if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
+    *dev_ptr = reinterpret_cast<float *>(r->film);
+    *n_floats = r->npix * 4;
+    return 0;
+}
+int vspg_film_read(VspgRenderer *r, float *host, void *stream) {
+    if (!r || !host) return fail(VSPG_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    HIPCHK(hipMemcpyAsync(host, r->film, r->npix * sizeof(float4), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int vspg_film_clear(VspgRenderer *r, void *stream) {
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    HIPCHK(hipMemsetAsync(r->film, 0, r->npix * sizeof(float4), (hipStream_t)stream));
+    return 0;
+}
+int vspg_vsp_buffer_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
+    if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
+    *dev_ptr = r->vsp;
+    *n_floats = r->npix;
+    return 0;
+}
+int vspg_vsp_buffer_read(VspgRenderer *r, float *host, int *is_ready, void *stream) {
+    if (!r || !host) return fail(VSPG_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    HIPCHK(hipMemcpyAsync(host, r->vsp, r->npix * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (is_ready) *is_ready = r->vsp_ready;
+    return 0;
+}
+int vspg_isg_stats_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
+    if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
+    *dev_ptr = r->isg_stats;
+    *n_floats = r->npix * VSPG_ISG_STATS;
+    return 0;
+}
+int vspg_get_counters(VspgRenderer *r, VspgCounters *out, void *stream) {
+    if (!r || !out) return fail(VSPG_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    unsigned long long h[kNumCounters];
+    HIPCHK(hipMemcpyAsync(h, r->counters, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    out->paths = h[0]; out->segments = h[1]; out->volume_scatters = h[2];
+    out->surface_hits = h[3]; out->density_queries = h[4]; out->shadow_rays = h[5];
+    return 0;
+}
+int vspg_reset_counters(VspgRenderer *r, void *stream) {
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    HIPCHK(hipMemsetAsync(r->counters, 0, kNumCounters * sizeof(unsigned long long), (hipStream_t)stream));
+    return 0;
+}
+
+// scoped device scratch for the batch entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy, const int32_t *sample_index, float *out_L,
+                     int32_t *out_segments, void *stream) {
+    if (!r || n < 0 || (n > 0 && (!pixel_xy || !sample_index || !out_L))) return fail(VSPG_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    for (int i = 0; i < n; ++i)
+        if (pixel_xy[2 * i] < 0 || pixel_xy[2 * i] >= r->cfg.xres || pixel_xy[2 * i + 1] < 0 || pixel_xy[2 * i + 1] >= r->cfg.yres)
+            return fail(VSPG_EINVAL, "pixel outside the film");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dp, ds, dl, dg;
+    HIPCHK(hipMalloc(&dp.p, (size_t)n * 2 * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&ds.p, (size_t)n * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&dl.p, (size_t)n * 3 * sizeof(float)));
+    HIPCHK(hipMalloc(&dg.p, (size_t)n * sizeof(int32_t)));
+    HIPCHK(hipMemcpyAsync(dp.p, pixel_xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(ds.p, sample_index, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_trace_paths<HomogeneousMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp,
+                       r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_L, dl.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out_segments) HIPCHK(hipMemcpyAsync(out_segments, dg.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_sample_tmaj_batch(VspgRenderer *r, int variant, int n, const VspgTmajQuery *q, VspgTmajResult *out, void *stream) {
+    if (!r || n < 0 || (n > 0 && (!q || !out))) return fail(VSPG_EINVAL, "bad arguments");
+    if (variant < VSPG_TMAJ_PLAIN || variant > VSPG_TMAJ_RESAMPLING) return fail(VSPG_EINVAL, "unknown variant");
+    if (n == 0) return 0;
+    for (int i = 0; i < n; ++i)
+        if (q[i].channel < 0 || q[i].channel > 2) return fail(VSPG_EINVAL, "channel must be 0..2");
+    if (r->scene.medium.type == VSPG_MEDIUM_NONE) return fail(VSPG_EINVAL, "renderer has no medium");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dq, dr;
+    HIPCHK(hipMalloc(&dq.p, (size_t)n * sizeof(VspgTmajQuery)));
+    HIPCHK(hipMalloc(&dr.p, (size_t)n * sizeof(VspgTmajResult)));
+    HIPCHK(hipMemcpyAsync(dq.p, q, (size_t)n * sizeof(VspgTmajQuery), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_tmaj_batch<HomogeneousMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, variant, n,
+                       (const VspgTmajQuery *)dq.p, (VspgTmajResult *)dr.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dr.p, (size_t)n * sizeof(VspgTmajResult), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_primitives_batch(VspgRenderer *r, int n, const float *f, const float *g, uint64_t *hash, uint32_t *rng_u32,
+                          float *fastexp, void *stream) {
+    if (!r || n < 0 || (n > 0 && (!f || !g || !hash || !rng_u32 || !fastexp))) return fail(VSPG_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf df, dg, dh, du, de;
+    HIPCHK(hipMalloc(&df.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dg.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dh.p, (size_t)n * 8));
+    HIPCHK(hipMalloc(&du.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&de.p, (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(df.p, f, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dg.p, g, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_primitives, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, (const float *)df.p, (const float *)dg.p,
+                       (uint64_t *)dh.p, (uint32_t *)du.p, (float *)de.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hash, dh.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(rng_u32, du.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(fastexp, de.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, float *sinf_out, float *cosf_out,
+                    void *stream) {
+    if (!r || n < 0 || (n > 0 && (!x || !logf_out || !sinf_out || !cosf_out))) return fail(VSPG_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dx, dl, ds, dc;
+    HIPCHK(hipMalloc(&dx.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dl.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&ds.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dc.p, (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_libm, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, (const float *)dx.p, (float *)dl.p,
+                       (float *)ds.p, (float *)dc.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(logf_out, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(sinf_out, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(cosf_out, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,724 @@
+// vspg_device.h -- device-side building blocks of the MI355X-native VSPG hot path (gfx950).
+//
+// Written from the reference's text (file:line cited per function, paths relative to the
+// reference root), independently of oracle/.  Float evaluation order follows the reference
+// expression by expression so that identical RNG seeds give identical paths; the TU is built
+// with -ffp-contract=off, explicit FMA() in the reference == __builtin_fmaf here.
+//
+// libm policy: the reference calls glibc's logf/sinf/cosf and a double-precision std::log.  The
+// float functions are reproduced bit for bit on device (vspg_libm.h); double log is ocml's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vspg.h"
+#include "vspg_libm.h"
+
+#define VDEV __device__ __forceinline__
+
+namespace vspg {
+
+// ---------------------------------------------------------------------------------------
+// constants (src/pbrt/util/math.h:30-60, util/float.h:27)
+// ---------------------------------------------------------------------------------------
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kInv4Pi = 0.07957747154594766788f;
+constexpr float kPiOver2 = 1.57079632679489661923f;
+constexpr float kPiOver4 = 0.78539816339744830961f;
+constexpr float kOneMinusEps = 0x1.fffffep-1f;
+constexpr float kMachineEps = 0x1p-24f;
+constexpr float kShadowEps = 0.0001f;
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr float kInf = __builtin_huge_valf();
+
+// ---------------------------------------------------------------------------------------
+// vectors / RGB spectra
+// ---------------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+VDEV V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+VDEV V3 ld3(const float *p) { return V3{p[0], p[1], p[2]}; }
+VDEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+VDEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+VDEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+VDEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+VDEV V3 operator*(float s, V3 a) { return V3{a.x * s, a.y * s, a.z * s}; }
+VDEV V3 vabs(V3 a) { return V3{__builtin_fabsf(a.x), __builtin_fabsf(a.y), __builtin_fabsf(a.z)}; }
+VDEV float sqr(float x) { return x * x; }
+VDEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vecmath.h:964
+VDEV float absdot(V3 a, V3 b) { return __builtin_fabsf(dot(a, b)); }
+VDEV float len2(V3 a) { return sqr(a.x) + sqr(a.y) + sqr(a.z); }           // vecmath.h:948
+VDEV float len(V3 a) { return __builtin_sqrtf(len2(a)); }
+VDEV V3 normalize(V3 a) {  // vecmath.h:959: v / Length(v), one division per component
+    float l = len(a);
+    return V3{a.x / l, a.y / l, a.z / l};
+}
+VDEV float diff_of_products(float a, float b, float c, float d) {  // math.h:569-574
+    float cd = c * d;
+    float dop = __builtin_fmaf(a, b, -cd);
+    float err = __builtin_fmaf(-c, d, cd);
+    return dop + err;
+}
+VDEV V3 cross(V3 v, V3 w) {  // vecmath.h:999-1004
+    return V3{diff_of_products(v.y, w.z, v.z, w.y), diff_of_products(v.z, w.x, v.x, w.z),
+              diff_of_products(v.x, w.y, v.y, w.x)};
+}
+VDEV V3 lerp(float t, V3 a, V3 b) { return a * (1 - t) + b * t; }  // math.h:210 on tuples
+VDEV float fmax_(float a, float b) { return a < b ? b : a; }       // std::max semantics
+VDEV float fmin_(float a, float b) { return b < a ? b : a; }       // std::min semantics
+VDEV float safe_sqrt(float x) { return __builtin_sqrtf(fmax_(0.f, x)); }
+VDEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+VDEV bool isinf_(float x) { return __builtin_isinf(x); }
+VDEV bool isnan_(float x) { return x != x; }
+
+struct Spec {
+    float r, g, b;
+};
+VDEV Spec sp(float v) { return Spec{v, v, v}; }
+VDEV Spec lds(const float *p) { return Spec{p[0], p[1], p[2]}; }
+// runtime channel select without runtime-indexed arrays (they would go to scratch)
+VDEV float ch_of(Spec s, int ch) { return ch == 0 ? s.r : (ch == 1 ? s.g : s.b); }
+VDEV Spec operator+(Spec a, Spec b) { return Spec{a.r + b.r, a.g + b.g, a.b + b.b}; }
+VDEV Spec operator-(Spec a, Spec b) { return Spec{a.r - b.r, a.g - b.g, a.b - b.b}; }
+VDEV Spec operator*(Spec a, Spec b) { return Spec{a.r * b.r, a.g * b.g, a.b * b.b}; }
+VDEV Spec operator/(Spec a, Spec b) { return Spec{a.r / b.r, a.g / b.g, a.b / b.b}; }
+VDEV Spec operator*(Spec a, float f) { return Spec{a.r * f, a.g * f, a.b * f}; }
+VDEV Spec operator/(Spec a, float f) { return Spec{a.r / f, a.g / f, a.b / f}; }
+VDEV bool nonzero(Spec a) { return a.r != 0 || a.g != 0 || a.b != 0; }  // spectrum.h:263-268
+VDEV float avg(Spec a) {  // spectrum.h:288-294
+    float s = a.r;
+    s += a.g;
+    s += a.b;
+    return s / 3;
+}
+VDEV float maxc(Spec a) { return fmax_(fmax_(a.r, a.g), a.b); }
+VDEV Spec clamp_zero(Spec a) { return Spec{fmax_(0.f, a.r), fmax_(0.f, a.g), fmax_(0.f, a.b)}; }
+VDEV bool has_nan(Spec a) { return isnan_(a.r) || isnan_(a.g) || isnan_(a.b); }
+VDEV bool has_inf(Spec a) { return isinf_(a.r) || isinf_(a.g) || isinf_(a.b); }
+
+// ---------------------------------------------------------------------------------------
+// float <-> bits, NextFloatUp/Down (util/float.h:164-193)
+// ---------------------------------------------------------------------------------------
+VDEV uint32_t f2b(float f) { return __float_as_uint(f); }
+VDEV float b2f(uint32_t u) { return __uint_as_float(u); }
+VDEV float next_float_up(float v) {
+    if (isinf_(v) && v > 0.f) return v;
+    if (v == -0.f) v = 0.f;
+    uint32_t ui = f2b(v);
+    if (v >= 0) ++ui; else --ui;
+    return b2f(ui);
+}
+VDEV float next_float_down(float v) {
+    if (isinf_(v) && v < 0.f) return v;
+    if (v == 0.f) v = -0.f;
+    uint32_t ui = f2b(v);
+    if (v > 0) --ui; else ++ui;
+    return b2f(ui);
+}
+
+// ---------------------------------------------------------------------------------------
+// a2: MurmurHash64A specialised to the key sizes the path uses (util/hash.h:19-63, 96-103)
+// ---------------------------------------------------------------------------------------
+constexpr uint64_t kMurmurM = 0xc6a4a7935bd1e995ull;
+VDEV uint64_t murmur_finish(uint64_t h) {
+    h ^= h >> 47;
+    h *= kMurmurM;
+    h ^= h >> 47;
+    return h;
+}
+// Hash(float): len 4 -> no 8-byte block, tail case 4..1 then h *= m
+VDEV uint64_t hash_u32(uint32_t w) {
+    uint64_t h = 0 ^ (4ull * kMurmurM);
+    h ^= (uint64_t)w;
+    h *= kMurmurM;
+    return murmur_finish(h);
+}
+VDEV uint64_t hash_float(float f) { return hash_u32(f2b(f)); }
+// 12-byte keys: Hash(Point3f), Hash(Point2i, int): one 8-byte block + 4-byte tail
+VDEV uint64_t hash_3u32(uint32_t w0, uint32_t w1, uint32_t w2) {
+    uint64_t h = 0 ^ (12ull * kMurmurM);
+    uint64_t k = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    k *= kMurmurM;
+    k ^= k >> 47;
+    k *= kMurmurM;
+    h ^= k;
+    h *= kMurmurM;
+    h ^= (uint64_t)w2;
+    h *= kMurmurM;
+    return murmur_finish(h);
+}
+VDEV uint64_t hash_v3(V3 p) { return hash_3u32(f2b(p.x), f2b(p.y), f2b(p.z)); }
+VDEV uint64_t mix_bits(uint64_t v) {  // hash.h:70-77
+    v ^= (v >> 31);
+    v *= 0x7fb5d329728ea185ull;
+    v ^= (v >> 27);
+    v *= 0x81dadef4bc2dd44dull;
+    v ^= (v >> 33);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// a1: PCG32 (util/rng.h:30-150)
+// ---------------------------------------------------------------------------------------
+constexpr uint64_t kPcgMult = 0x5851f42d4c957f2dULL;
+struct Rng {
+    uint64_t state, inc;
+    VDEV uint32_t u32() {  // rng.h:82-88
+        uint64_t old = state;
+        state = old * kPcgMult + inc;
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((~rot + 1u) & 31));
+    }
+    VDEV float uniform() {  // rng.h:128-130
+        float f = (float)u32() * 0x1p-32f;
+        return fmin_(kOneMinusEps, f);
+    }
+    VDEV void set_sequence(uint64_t seq, uint64_t seed) {  // rng.h:119-125
+        state = 0u;
+        inc = (seq << 1u) | 1u;
+        u32();
+        state += seed;
+        u32();
+    }
+    VDEV void set_sequence(uint64_t seq) { set_sequence(seq, mix_bits(seq)); }  // rng.h:43-45
+    VDEV void advance(uint64_t delta) {  // rng.h:137-150
+        uint64_t curMult = kPcgMult, curPlus = inc, accMult = 1u, accPlus = 0u;
+        while (delta > 0) {
+            if (delta & 1) {
+                accMult *= curMult;
+                accPlus = accPlus * curMult + curPlus;
+            }
+            curPlus = (curMult + 1) * curPlus;
+            curMult *= curMult;
+            delta /= 2;
+        }
+        state = accMult * state + accPlus;
+    }
+};
+
+// IndependentSampler (src/pbrt/samplers.h:442-476)
+struct Sampler {
+    Rng rng;
+    VDEV void start_pixel_sample(int px, int py, int seed, int sampleIndex) {
+        rng.set_sequence(hash_3u32((uint32_t)px, (uint32_t)py, (uint32_t)seed));
+        rng.advance((uint64_t)sampleIndex * 65536ull);
+    }
+    VDEV float get1d() { return rng.uniform(); }
+};
+
+// ---------------------------------------------------------------------------------------
+// libm: float functions reproduce the host glibc bit for bit (vspg_libm.h); the reference's
+// `std::log(1.0 - x)` in media_sampleTMaj.h is DOUBLE precision -> ocml double log, rounded once
+// ---------------------------------------------------------------------------------------
+VDEV float logf_(float x) { return vspg_libm::logf_host_exact(x); }
+VDEV float sinf_(float x) { return vspg_libm::sinf_host_exact(x); }
+VDEV float cosf_(float x) { return vspg_libm::cosf_host_exact(x); }
+VDEV float neg_log1m_d(float x) { return (float)(-log(1.0 - (double)x)); }  // -std::log(1.0 - x)
+
+// ---------------------------------------------------------------------------------------
+// a3: FastExp / SampleExponential / SampleDiscrete
+// ---------------------------------------------------------------------------------------
+VDEV float fast_exp(float x) {  // util/math.h:450-474 (CPU branch; NOT __expf)
+    float xp = x * 1.442695041f;
+    float fxp = __builtin_floorf(xp), f = xp - fxp;
+    int i = (int)fxp;
+    float twoToF = __builtin_fmaf(f, __builtin_fmaf(f, __builtin_fmaf(f, 0.0781455737f, 0.226173572f), 0.695556856f), 1.f);
+    int exponent = (int)((f2b(twoToF) >> 23) & 0xff) - 127 + i;
+    if (exponent < -126) return 0;
+    if (exponent > 127) return kInf;
+    uint32_t bits = f2b(twoToF);
+    bits &= 0x807fffffu;
+    bits |= (uint32_t)(exponent + 127) << 23;
+    return b2f(bits);
+}
+VDEV Spec fast_exp(Spec a) { return Spec{fast_exp(a.r), fast_exp(a.g), fast_exp(a.b)}; }
+VDEV float sample_exponential(float u, float a) { return -logf_(1 - u) / a; }  // sampling.h:222
+VDEV int sample_discrete2(float w0, float w1, float u) {  // sampling.h:79-113, two weights
+    float sumWeights = 0;
+    sumWeights += w0;
+    sumWeights += w1;
+    float up = u * sumWeights;
+    if (up == sumWeights) up = next_float_down(up);
+    // while (sum + weights[offset] <= up) sum += weights[offset++];
+    if (!(0.f + w0 <= up)) return 0;
+    return 1;  // the reference would index past two weights only if w0+w1 <= up, which
+               // cannot happen after the up == sumWeights fix-up (DCHECK_LT in the reference)
+}
+
+// ---------------------------------------------------------------------------------------
+// a4: Henyey-Greenstein, frames, direction sampling
+// ---------------------------------------------------------------------------------------
+VDEV float henyey_greenstein(float cosTheta, float g) {  // scattering.h:50-59
+    g = clampf(g, (float)-.99, (float).99);
+    float denom = 1 + sqr(g) + 2 * g * cosTheta;
+    return kInv4Pi * (1 - sqr(g)) / (denom * safe_sqrt(denom));
+}
+VDEV void coordinate_system(V3 v1, V3 *v2, V3 *v3) {  // vecmath.h:1007-1013
+    float sign = __builtin_copysignf(1.f, v1.z);
+    float a = -1 / (sign + v1.z);
+    float b = v1.x * v1.y * a;
+    *v2 = V3{1 + sign * sqr(v1.x) * a, sign * b, -sign * v1.x};
+    *v3 = V3{b, sign + sqr(v1.y) * a, -v1.y};
+}
+struct Frame {
+    V3 x, y, z;
+    VDEV V3 from_local(V3 v) const { return v.x * x + v.y * y + v.z * z; }  // vecmath.h:1914
+    VDEV V3 to_local(V3 v) const { return V3{dot(v, x), dot(v, y), dot(v, z)}; }
+};
+VDEV V3 sample_henyey_greenstein(V3 wo, float g, float u0, float u1, float *pdf) {  // sampling.cpp:348-374
+    g = clampf(g, (float)-.99, (float).99);
+    float cosTheta;
+    if (__builtin_fabsf(g) < 1e-3f)
+        cosTheta = 1 - 2 * u0;
+    else
+        cosTheta = -1 / (2 * g) * (1 + sqr(g) - sqr((1 - sqr(g)) / (1 + g - 2 * g * u0)));
+    float sinTheta = safe_sqrt(1 - sqr(cosTheta));
+    float phi = 2 * kPi * u1;
+    Frame f;
+    f.z = wo;
+    coordinate_system(wo, &f.x, &f.y);
+    float sp_ = sinf_(phi), cp_ = cosf_(phi);
+    // SphericalDirection (vecmath.h:1666-1672)
+    V3 local = V3{clampf(sinTheta, -1, 1) * cp_, clampf(sinTheta, -1, 1) * sp_, clampf(cosTheta, -1, 1)};
+    *pdf = henyey_greenstein(cosTheta, g);
+    return f.from_local(local);
+}
+VDEV V3 sample_cosine_hemisphere(float u0, float u1) {  // sampling.h:325-341, 409-413
+    float ox = 2 * u0 - 1, oy = 2 * u1 - 1;
+    float dx, dy;
+    if (ox == 0 && oy == 0) {
+        dx = 0;
+        dy = 0;
+    } else {
+        float theta, r;
+        if (__builtin_fabsf(ox) > __builtin_fabsf(oy)) {
+            r = ox;
+            theta = kPiOver4 * (oy / ox);
+        } else {
+            r = oy;
+            theta = kPiOver2 - kPiOver4 * (ox / oy);
+        }
+        dx = r * cosf_(theta);
+        dy = r * sinf_(theta);
+    }
+    float z = safe_sqrt(1 - sqr(dx) - sqr(dy));
+    return V3{dx, dy, z};
+}
+
+// ---------------------------------------------------------------------------------------
+// Point3fi (vecmath.h:737-760; Interval math.h:815-862) and ray spawning (ray.h:75-108)
+// ---------------------------------------------------------------------------------------
+struct P3i {
+    V3 lo, hi;
+    VDEV V3 mid() const { return V3{(lo.x + hi.x) / 2, (lo.y + hi.y) / 2, (lo.z + hi.z) / 2}; }
+    VDEV V3 err() const { return V3{(hi.x - lo.x) / 2, (hi.y - lo.y) / 2, (hi.z - lo.z) / 2}; }
+};
+VDEV P3i p3i_exact(V3 p) { return P3i{p, p}; }
+VDEV void interval_ve(float v, float e, float *lo, float *hi) {
+    if (e == 0) {
+        *lo = *hi = v;
+    } else {
+        *lo = next_float_down(v - e);
+        *hi = next_float_up(v + e);
+    }
+}
+VDEV P3i p3i_from_err(V3 p, V3 e) {
+    P3i r;
+    interval_ve(p.x, e.x, &r.lo.x, &r.hi.x);
+    interval_ve(p.y, e.y, &r.lo.y, &r.hi.y);
+    interval_ve(p.z, e.z, &r.lo.z, &r.hi.z);
+    return r;
+}
+VDEV float offset_axis(float po, float off) {
+    if (off > 0) return next_float_up(po);
+    if (off < 0) return next_float_down(po);
+    return po;
+}
+VDEV V3 offset_ray_origin(P3i pi, V3 n, V3 w) {
+    float d = dot(vabs(n), pi.err());
+    V3 offset = n * d;
+    if (dot(w, n) < 0) offset = -offset;
+    V3 po = pi.mid() + offset;
+    return V3{offset_axis(po.x, offset.x), offset_axis(po.y, offset.y), offset_axis(po.z, offset.z)};
+}
+
+// ---------------------------------------------------------------------------------------
+// device-resident scene (uploaded once; uniform accesses become scalar loads)
+// ---------------------------------------------------------------------------------------
+struct DQuad {
+    float p00[3], p10[3], p01[3], p11[3], e1[3], e2[3];
+    float n[3], dpdu_n[3], perr[3];
+    float inv_l1, inv_l2, area;
+    float Kd[3], Le[3];
+    int32_t two_sided, is_light, has_lobes, pad;
+};
+struct DScene {
+    int32_t n_quads, n_lights;
+    int32_t light_quads[VSPG_MAX_QUADS];
+    DQuad quads[VSPG_MAX_QUADS];
+    VspgCamera cam;
+    // medium
+    int32_t medium_type;
+    float sigma_a[3], sigma_s[3], Le[3], g;
+    // integrator parameters
+    VspgIntegratorParams prm;
+    // render config
+    int32_t xres, yres, seed, shard_index, shard_count;
+};
+
+struct Isect {
+    bool hit;
+    float t;
+    int quad;
+    V3 p, n;
+};
+
+// ray / rectangle (own geometry stand-in; same formulas as the scene contract in DESIGN.md)
+VDEV bool quad_intersect(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, V3 *pHit) {
+    V3 n = ld3(q.n), p00 = ld3(q.p00), e1 = ld3(q.e1), e2 = ld3(q.e2);
+    float denom = dot(n, d);
+    if (denom == 0) return false;
+    float t = dot(n, p00 - o) / denom;
+    if (!(t > 0) || !(t < tMax)) return false;
+    V3 p = o + d * t;
+    V3 rel = p - p00;
+    float u = dot(rel, e1) * q.inv_l1;
+    float v = dot(rel, e2) * q.inv_l2;
+    if (u < 0 || u > 1 || v < 0 || v > 1) return false;
+    *tHit = t;
+    *pHit = p00 + (e1 * u + e2 * v);
+    return true;
+}
+VDEV Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
+    Isect best;
+    best.hit = false;
+    best.t = tMax;
+    best.quad = 0;
+    best.p = mk(0, 0, 0);
+    best.n = mk(0, 0, 0);
+    for (int i = 0; i < S.n_quads; ++i) {
+        float t;
+        V3 p;
+        if (quad_intersect(S.quads[i], o, d, best.t, &t, &p)) {
+            best.hit = true;
+            best.t = t;
+            best.quad = i;
+            best.p = p;
+            best.n = ld3(S.quads[i].n);
+        }
+    }
+    return best;
+}
+VDEV bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
+    bool any = false;
+    for (int i = 0; i < S.n_quads; ++i) {
+        float t;
+        V3 p;
+        any = any || quad_intersect(S.quads[i], o, d, tMax, &t, &p);
+    }
+    return any;
+}
+
+// ---------------------------------------------------------------------------------------
+// a5: media.  MediumProperties (media.h:77-82) and majorant iterators.
+// ---------------------------------------------------------------------------------------
+struct MediumProps {
+    Spec sigma_a, sigma_s, Le;
+    float g;
+};
+struct MajSeg {
+    float tMin, tMax;
+    Spec sigma_maj;
+};
+// HomogeneousMedium (media.h:221-283): one segment [0,tMax], sigma_maj = sigma_a + sigma_s
+struct HomogeneousMedium {
+    Spec sigma_a, sigma_s, Le;
+    float g;
+    struct Iter {  // HomogeneousMajorantIterator (media.h:84-106)
+        MajSeg seg;
+        bool called;
+        VDEV bool next(MajSeg *s) {
+            if (called) return false;
+            called = true;
+            *s = seg;
+            return true;
+        }
+    };
+    VDEV Iter sample_ray(V3, V3, float tMax) const { return Iter{MajSeg{0, tMax, sigma_a + sigma_s}, false}; }
+    VDEV MediumProps sample_point(V3) const { return MediumProps{sigma_a, sigma_s, Le, g}; }
+    VDEV bool is_homogeneous() const { return true; }
+};
+VDEV HomogeneousMedium make_homogeneous(const DScene &S) {
+    return HomogeneousMedium{lds(S.sigma_a), lds(S.sigma_s), lds(S.Le), S.g};
+}
+
+// ---------------------------------------------------------------------------------------
+// a7: SampleT_maj (src/pbrt/media_sampleTMaj.h:49-117)
+//   callback: bool cb(V3 p, const MediumProps&, Spec sigma_maj, Spec T_maj, bool activateNDS)
+// ---------------------------------------------------------------------------------------
+template <class Medium, class F>
+VDEV Spec sample_T_maj(const Medium &medium, V3 ro, V3 rd, float tMax, float u, Rng &rng, int ch, F &&cb) {
+    tMax *= len(rd);
+    rd = normalize(rd);
+    auto iter = medium.sample_ray(ro, rd, tMax);
+    Spec T_maj = sp(1.f);
+    bool done = false;
+    while (!done) {
+        MajSeg seg;
+        if (!iter.next(&seg)) return T_maj;
+        float smaj = ch_of(seg.sigma_maj, ch);
+        if (smaj == 0) {
+            float dt = seg.tMax - seg.tMin;
+            if (isinf_(dt)) dt = kFltMax;
+            T_maj = T_maj * fast_exp(seg.sigma_maj * -dt);
+            continue;
+        }
+        float tMin = seg.tMin;
+        while (true) {
+            float t = tMin + sample_exponential(u, smaj);
+            u = rng.uniform();
+            if (t < seg.tMax) {
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -(t - tMin));
+                V3 p = ro + rd * t;
+                MediumProps mp = medium.sample_point(p);
+                if (!cb(p, mp, seg.sigma_maj, T_maj, false)) {
+                    done = true;
+                    break;
+                }
+                T_maj = sp(1.f);
+                tMin = t;
+            } else {
+                float dt = seg.tMax - tMin;
+                if (isinf_(dt)) dt = kFltMax;
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -dt);
+                break;
+            }
+        }
+    }
+    return sp(1.f);
+}
+
+// ---------------------------------------------------------------------------------------
+// a9: SampleT_maj_Resampling (media_sampleTMaj.h:136-248)
+// ---------------------------------------------------------------------------------------
+template <class Medium, class F>
+VDEV Spec sample_T_maj_resampling(const Medium &medium, V3 ro, V3 rd, float tMax, float u, Rng &rng, int ch,
+                                  bool guide, float vsp, float *vrc, float *majorantScale, F &&cb) {
+    tMax *= len(rd);
+    rd = normalize(rd);
+    auto iter = medium.sample_ray(ro, rd, tMax);
+    auto pre = iter;
+    float totalLength = 0.f;
+    while (true) {
+        MajSeg seg;
+        if (!pre.next(&seg)) break;
+        float smaj = ch_of(seg.sigma_maj, ch);
+        if (smaj == 0) continue;
+        totalLength += smaj * (seg.tMax - seg.tMin);
+    }
+    if (totalLength == 0.f) return sp(1.f);
+    *majorantScale = 1.0f;
+    *vrc = vsp;
+    if (guide) {
+        float minTotalLength = -logf_(1 - vsp);
+        if (minTotalLength > totalLength) {
+            *majorantScale = minTotalLength / totalLength;
+            totalLength = minTotalLength;
+        }
+        float expNegTotalLength = fast_exp(-totalLength);
+        *vrc = vsp / (1 - expNegTotalLength);
+    }
+    Spec T_maj = sp(1.f);
+    bool done = false;
+    int count = 0;
+    while (!done) {
+        MajSeg seg;
+        if (!iter.next(&seg)) return T_maj;
+        seg.sigma_maj = seg.sigma_maj * *majorantScale;
+        float smaj = ch_of(seg.sigma_maj, ch);
+        if (smaj == 0) {
+            float dt = seg.tMax - seg.tMin;
+            if (isinf_(dt)) dt = kFltMax;
+            T_maj = T_maj * fast_exp(seg.sigma_maj * -dt);
+            continue;
+        }
+        float tMin = seg.tMin;
+        while (true) {
+            count++;
+            float t = tMin + sample_exponential(u, smaj);
+            u = rng.uniform();
+            if (t < seg.tMax) {
+                if (count > 10000) break;
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -(t - tMin));
+                V3 p = ro + rd * t;
+                MediumProps mp = medium.sample_point(p);
+                if (!cb(p, mp, seg.sigma_maj, T_maj, false)) {
+                    done = true;
+                    break;
+                }
+                T_maj = sp(1.f);
+                tMin = t;
+            } else {
+                float dt = seg.tMax - tMin;
+                if (isinf_(dt)) dt = kFltMax;
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -dt);
+                break;
+            }
+        }
+    }
+    return sp(1.f);
+}
+
+// ---------------------------------------------------------------------------------------
+// a8: SampleT_maj_OpticalDepthSpace (media_sampleTMaj.h:269-491)
+// ---------------------------------------------------------------------------------------
+VDEV Spec ruf_from(float alpha, Spec tp) {  // SampledSpectrum(a)/tp + SampledSpectrum(1-a)
+    return Spec{alpha / tp.r + (1 - alpha), alpha / tp.g + (1 - alpha), alpha / tp.b + (1 - alpha)};
+}
+template <class Medium, class F>
+VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float u, Rng &rng, int ch,
+                           bool guide, float vsp, float alpha, bool NDS, Spec *r_u_factor, F &&cb) {
+    if (!guide || alpha == 0.f) return sample_T_maj(medium, ro, rd, tMax, u, rng, ch, cb);
+    tMax *= len(rd);
+    rd = normalize(rd);
+    auto iter = medium.sample_ray(ro, rd, tMax);
+    auto pre = iter;
+    float t_v = 0.f;
+    bool inf_seg = false;
+    while (true) {
+        MajSeg seg;
+        if (!pre.next(&seg)) break;
+        if (isinf_(seg.tMax)) {
+            inf_seg = true;
+            break;
+        }
+        float smaj = ch_of(seg.sigma_maj, ch);
+        if (smaj == 0) continue;
+        t_v += smaj * (seg.tMax - seg.tMin);
+    }
+    if (inf_seg) return sample_T_maj(medium, ro, rd, tMax, u, rng, ch, cb);  // normalised ray, scaled tMax (:307)
+    if (t_v == 0.f) return sp(1.f);
+
+    float OneMinusENegTv = 1.f - fast_exp(-t_v);
+    float t_n = -1.f, t_n_current = -1.f;
+    if (NDS) {
+        if (vsp < 1 - fast_exp(-t_v))
+            return sample_T_maj(medium, ro, rd, tMax, u, rng, ch, cb);  // (:327)
+        else {
+            t_n = neg_log1m_d(OneMinusENegTv / vsp);
+            t_n_current = t_n;
+        }
+    }
+    Spec T_maj = sp(1.f), tpScale = sp(1.f);
+    float t_v_current = t_v;
+    float remainingDist = 0;
+    bool deltaTracking = false;
+    if (u > alpha) {
+        deltaTracking = true;
+        u = (u - alpha) / (1 - alpha);
+    } else {
+        u /= alpha;
+    }
+    bool done = false, overTheEnd = false;
+    int count = 0;
+    const float ScatterEpsilon = 1e-5;
+    while (!done) {
+        MajSeg seg;
+        if (!iter.next(&seg)) return T_maj;
+        float smaj = ch_of(seg.sigma_maj, ch);
+        if (smaj == 0 || overTheEnd) {
+            float dt = seg.tMax - seg.tMin;
+            if (isinf_(dt)) dt = kFltMax;
+            T_maj = T_maj * fast_exp(seg.sigma_maj * -dt);
+            continue;
+        }
+        float tMin = seg.tMin;
+        Spec nMaj = seg.sigma_maj / smaj;
+        if (remainingDist > 0) {
+            tMin += remainingDist / smaj;
+            if (tMin > seg.tMax + ScatterEpsilon) {
+                float dist = (seg.tMax - seg.tMin) * smaj;
+                t_v_current -= dist;
+                t_n_current -= dist;
+                remainingDist -= dist;
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -(seg.tMax - seg.tMin));
+                continue;
+            }
+            t_v_current -= remainingDist;
+            t_n_current -= remainingDist;
+            remainingDist = 0;
+            T_maj = T_maj * fast_exp(seg.sigma_maj * -(tMin - seg.tMin));
+            V3 p = ro + rd * tMin;
+            MediumProps mp = medium.sample_point(p);
+            *r_u_factor = ruf_from(alpha, tpScale);
+            if (!cb(p, mp, seg.sigma_maj, T_maj, true)) break;
+            T_maj = sp(1.f);
+        }
+        while (true) {
+            count++;
+            float dist = kFltMax;
+            Spec tpStep;
+            if (NDS) {
+                tpStep = Spec{1.0f - fast_exp(-t_n_current * nMaj.r), 1.0f - fast_exp(-t_n_current * nMaj.g),
+                              1.0f - fast_exp(-t_n_current * nMaj.b)};
+                if (!deltaTracking) dist = neg_log1m_d(u * ch_of(tpStep, ch));
+            } else {
+                tpStep = Spec{(1.0f - fast_exp(-t_v_current * nMaj.r)) / vsp, (1.0f - fast_exp(-t_v_current * nMaj.g)) / vsp,
+                              (1.0f - fast_exp(-t_v_current * nMaj.b)) / vsp};
+                if (!deltaTracking) {
+                    if (u < vsp) dist = neg_log1m_d(u * ch_of(tpStep, ch));
+                }
+            }
+            if (deltaTracking) dist = neg_log1m_d(u);
+
+            bool passThrough = (t_v_current - dist < ScatterEpsilon) || dist == 0;
+            if (NDS || !passThrough) tpScale = tpScale * tpStep;
+            if (passThrough) {
+                if (NDS) {
+                    tpScale = tpScale / (1.0f - fast_exp(-t_n + t_v));
+                } else {
+                    Spec e = Spec{fast_exp(-t_v_current * nMaj.r) / (1 - vsp), fast_exp(-t_v_current * nMaj.g) / (1 - vsp),
+                                  fast_exp(-t_v_current * nMaj.b) / (1 - vsp)};
+                    tpScale = tpScale * e;
+                }
+                *r_u_factor = ruf_from(alpha, tpScale);
+                overTheEnd = true;
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -(seg.tMax - tMin));
+                break;
+            }
+            float t = tMin + dist / smaj;
+            u = rng.uniform();
+            if (t <= seg.tMax + ScatterEpsilon) {
+                if (count > 10000) break;
+                t_v_current -= dist;
+                t_n_current -= dist;
+                remainingDist = 0;
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -(t - tMin));
+                V3 p = ro + rd * t;
+                MediumProps mp = medium.sample_point(p);
+                *r_u_factor = ruf_from(alpha, tpScale);
+                if (!cb(p, mp, seg.sigma_maj, T_maj, true)) {
+                    done = true;
+                    break;
+                }
+                T_maj = sp(1.f);
+                tMin = t;
+            } else {
+                float dt = seg.tMax - tMin;
+                if (isinf_(dt)) dt = kFltMax;
+                T_maj = T_maj * fast_exp(seg.sigma_maj * -dt);
+                float distWithinThisSeg = dt * smaj;
+                remainingDist = dist - distWithinThisSeg;
+                t_v_current -= distWithinThisSeg;
+                t_n_current -= distWithinThisSeg;
+                break;
+            }
+        }
+    }
+    return sp(1.f);
+}
+
+}  // namespace vspg

@@ -1,0 +1,590 @@
+// vspg_path.h -- device-side path logic: SampleLd, SampleDistance, Li, EvaluatePixelSample.
+// (reference: src/pbrt/cpu/guidedvolpathvspgintegrator.cpp; citations per function)
+#pragma once
+#include "vspg_device.h"
+
+namespace vspg {
+
+// ---------------------------------------------------------------------------------------
+// DiffuseBxDF behind BSDF (src/pbrt/bxdfs.h:31-80, src/pbrt/bsdf.h:20-88)
+// ---------------------------------------------------------------------------------------
+struct Bsdf {
+    Frame frame;  // Frame::FromXZ(Normalize(dpdus), ns) (vecmath.h:1862)
+    Spec R;
+    bool has_lobes;
+};
+VDEV Bsdf bsdf_make(const DQuad &q) {
+    Bsdf b;
+    b.frame.x = ld3(q.dpdu_n);
+    b.frame.z = ld3(q.n);
+    b.frame.y = cross(b.frame.z, b.frame.x);
+    b.R = lds(q.Kd);
+    b.has_lobes = q.has_lobes != 0;
+    return b;
+}
+VDEV Spec bsdf_f(const Bsdf &b, V3 woR, V3 wiR) {
+    V3 wi = b.frame.to_local(wiR), wo = b.frame.to_local(woR);
+    if (wo.z == 0) return sp(0.f);
+    if (!(wi.z * wo.z > 0)) return sp(0.f);  // SameHemisphere
+    return b.R * kInvPi;
+}
+VDEV float bsdf_pdf(const Bsdf &b, V3 woR, V3 wiR) {
+    V3 wo = b.frame.to_local(woR), wi = b.frame.to_local(wiR);
+    if (wo.z == 0) return 0;
+    if (!b.has_lobes) return 0;
+    if (!(wi.z * wo.z > 0)) return 0;
+    return __builtin_fabsf(wi.z) * kInvPi;  // CosineHemispherePDF(AbsCosTheta(wi))
+}
+VDEV bool bsdf_sample_f(const Bsdf &b, V3 woR, float u0, float u1, Spec *f, V3 *wiR, float *pdf) {
+    V3 wo = b.frame.to_local(woR);
+    if (wo.z == 0 || !b.has_lobes) return false;
+    V3 wi = sample_cosine_hemisphere(u0, u1);
+    if (wo.z < 0) wi.z *= -1;
+    *pdf = __builtin_fabsf(wi.z) * kInvPi;
+    *f = b.R * kInvPi;
+    if (!nonzero(*f) || *pdf == 0 || wi.z == 0) return false;
+    *wiR = b.frame.from_local(wi);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// DiffuseAreaLight on a rectangle, uniform-area sampling
+// (src/pbrt/lights.cpp:796-820, lights.h:492-511, src/pbrt/shapes.cpp:1155-1212, 1267-1283)
+// ---------------------------------------------------------------------------------------
+VDEV Spec light_L(const DQuad &q, V3 n, V3 w) {
+    if (!q.two_sided && dot(n, w) < 0) return sp(0.f);
+    return lds(q.Le);
+}
+struct LightLi {
+    Spec L;
+    V3 wi;
+    float pdf;
+    P3i pLight;
+    V3 nLight;
+};
+VDEV bool light_sample_li(const DQuad &q, V3 ctxp, float u0, float u1, LightLi *ls) {
+    V3 p00 = ld3(q.p00), p10 = ld3(q.p10), p01 = ld3(q.p01), p11 = ld3(q.p11);
+    V3 pu0 = lerp(u1, p00, p01), pu1 = lerp(u1, p10, p11);
+    V3 p = lerp(u0, pu0, pu1);
+    V3 dpdu = pu1 - pu0;
+    V3 dpdv = lerp(u0, p01, p11) - lerp(u0, p00, p10);
+    if (len2(dpdu) == 0 || len2(dpdv) == 0) return false;
+    V3 c = cross(dpdu, dpdv);
+    V3 n = normalize(c);
+    if (dot(n, ld3(q.n)) < 0) n = -n;  // reverseOrientation
+    float pdf = 1 / len(c);
+    P3i pint = p3i_from_err(p, ld3(q.perr));
+    p = pint.mid();
+    V3 wi = p - ctxp;
+    if (len2(wi) == 0) return false;
+    wi = normalize(wi);
+    V3 d = ctxp - p;
+    pdf /= absdot(n, -wi) / len2(d);
+    if (isinf_(pdf)) return false;
+    if (pdf == 0) return false;
+    Spec Le = light_L(q, n, -wi);
+    if (!nonzero(Le)) return false;
+    ls->L = Le;
+    ls->wi = wi;
+    ls->pdf = pdf;
+    ls->pLight = pint;
+    ls->nLight = n;
+    return true;
+}
+struct LsCtx {  // LightSampleContext
+    P3i pi;
+    V3 n;
+};
+VDEV float light_pdf_li(const DQuad &q, const LsCtx &ctx, V3 wi) {  // shapes.cpp:1329-1352, area branch
+    V3 o = offset_ray_origin(ctx.pi, ctx.n, wi);
+    float t;
+    V3 p;
+    if (!quad_intersect(q, o, wi, kInf, &t, &p)) return 0;
+    p = p3i_from_err(p, ld3(q.perr)).mid();
+    V3 d = ctx.pi.mid() - p;
+    float pdf = (1 / q.area) * (len2(d) / absdot(ld3(q.n), -wi));
+    return isinf_(pdf) ? 0 : pdf;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-lane counters (reduced per workgroup at kernel end)
+// ---------------------------------------------------------------------------------------
+struct PathCounters {
+    uint32_t segments, volume_scatters, surface_hits, density_queries, shadow_rays;
+};
+
+struct IsgSample {
+    bool valid, surface_event;
+    float vsp_used;
+};
+
+// StandardThroughputBasedRussianRoulette is OpenPGL code (absent from the reference tree):
+// pbrt's own rule, survival = clamp(maxComponent, 0, 1).  Unpinned, see DESIGN.md.
+VDEV float standard_throughput_rr(Spec w) { return fmin_(1.f, fmax_(0.f, maxc(w))); }
+
+// ---------------------------------------------------------------------------------------
+// a15: SampleLd (guidedvolpathvspgintegrator.cpp:1136-1252); guiding distributions inactive
+// ---------------------------------------------------------------------------------------
+struct Intr {
+    bool is_surface;
+    P3i pi;
+    V3 n;
+    V3 wo;
+    float g;
+};
+template <class Medium>
+VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, const Bsdf *bsdf, int ch,
+                    Sampler &sampler, Spec r_p, PathCounters &pc) {
+    V3 ctxp = intr.pi.mid();
+    if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
+    float u = sampler.get1d();
+    // UniformLightSampler::Sample (lightsamplers.h:33-38)
+    bool have_light = S.n_lights > 0;
+    int lightIndex = 0;
+    float lightPmf = 0;
+    if (have_light) {
+        int li = (int)(u * (float)S.n_lights);
+        lightIndex = li < S.n_lights - 1 ? li : S.n_lights - 1;
+        lightPmf = 1.f / (float)S.n_lights;
+    }
+    float ul0 = sampler.get1d(), ul1 = sampler.get1d();
+    if (!have_light) return sp(0.f);
+    const DQuad &lq = S.quads[S.light_quads[lightIndex]];
+    LightLi ls;
+    if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return sp(0.f);
+    float p_l = lightPmf * ls.pdf;
+
+    float scatterPDF;
+    Spec f_hat;
+    V3 wo = intr.wo, wi = ls.wi;
+    if (intr.is_surface) {
+        f_hat = bsdf_f(*bsdf, wo, wi) * absdot(wi, intr.n);
+        scatterPDF = 1.0f * bsdf_pdf(*bsdf, wo, wi);
+    } else {
+        float p = henyey_greenstein(dot(wo, wi), intr.g);
+        f_hat = sp(p);
+        scatterPDF = 1.0f * p;
+    }
+    if (!nonzero(f_hat)) return sp(0.f);
+
+    // lightRay = intr.SpawnRayTo(ls->pLight) (interaction.h:111-115, ray.h:103-108)
+    V3 pf = offset_ray_origin(intr.pi, intr.n, ls.pLight.mid() - intr.pi.mid());
+    V3 pt = offset_ray_origin(ls.pLight, ls.nLight, pf - ls.pLight.mid());
+    V3 lo = pf, ld = pt - pf;
+    Spec T_ray = sp(1.f), r_l = sp(1.f), r_u = sp(1.f);
+    Rng rng;
+    rng.set_sequence(hash_v3(lo), hash_v3(ld));  // :1193
+    pc.shadow_rays++;
+    if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
+        // every surface here carries a material: any hit is an opaque blocker (:1197-1200)
+        if (scene_intersect_any(S, lo, ld, 1 - kShadowEps)) return sp(0.f);
+        if (S.medium_type != VSPG_MEDIUM_NONE) {
+            float tMax = 1 - kShadowEps;
+            float us = rng.uniform();
+            Spec T_maj = sample_T_maj(medium, lo, ld, tMax, us, rng, ch,
+                                      [&](V3, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+                                          // ratio tracking (:1207-1232)
+                                          Spec sigma_n = clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s);
+                                          float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
+                                          T_ray = T_ray * (T_maj * sigma_n / pdf);
+                                          r_l = r_l * (T_maj * sigma_maj / pdf);
+                                          r_u = r_u * (T_maj * sigma_n / pdf);
+                                          Spec Tr = T_ray / avg(r_l + r_u);
+                                          if (maxc(Tr) < 0.05f) {
+                                              float q = 0.75f;
+                                              if (rng.uniform() < q)
+                                                  T_ray = sp(0.f);
+                                              else
+                                                  T_ray = T_ray / (1 - q);
+                                          }
+                                          if (!nonzero(T_ray)) return false;
+                                          return true;
+                                      });
+            float tm = ch_of(T_maj, ch);
+            T_ray = T_ray * (T_maj / tm);
+            r_l = r_l * (T_maj / tm);
+            r_u = r_u * (T_maj / tm);
+        }
+        if (!nonzero(T_ray)) return sp(0.f);
+    }
+    r_l = r_l * (r_p * p_l);
+    r_u = r_u * (r_p * scatterPDF);
+    return f_hat * T_ray * ls.L / avg(r_l + r_u);  // area light: not a delta light (:1248-1251)
+}
+
+// ---------------------------------------------------------------------------------------
+// path state carried across the Li loop (:294-307)
+// ---------------------------------------------------------------------------------------
+struct PathState {
+    V3 ro, rd;
+    Spec L, beta, r_u, r_l;
+    LsCtx prevCtx;
+    int depth;
+    bool specularBounce, anyNonSpecularBounces, lastVertexVolume;
+    float rr_correction, etaScale;
+};
+
+// VSP fetch (:654-671, :1098-1134).  Secondary-ray VSP comes from the guiding cache, which is
+// untrained in the configurations this build accepts -> VolumeScatterProbability() == -1
+// (guiding.h:295-298, 564-567).
+VDEV float fetch_vsp(const DScene &S, const float *vsp_buf, int vsp_ready, int px, int py, int depth, bool *guide) {
+    float vsp = -1.f;
+    *guide = false;
+    if (depth == 0) {
+        if (S.prm.vspguiding && S.prm.vspprimaryguiding) {
+            vsp = vsp_ready ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
+            *guide = !(isnan_(vsp) || vsp < 0.f || vsp > 1.f);
+        }
+    }
+    if (*guide) vsp = fmax_(fmin_(vsp, 0.999f), 0.001f);
+    return vsp;
+}
+
+// volume-scatter tail shared by both SampleDistance branches (:804-875 == :988-1058)
+// returns false when the path terminates
+template <class Medium>
+VDEV void scatter_tail(const DScene &S, const Medium &medium, PathState &st, V3 p, const MediumProps &mp, int ch,
+                       Sampler &sampler, float rr_correction, bool *scattered, bool *terminated, PathCounters &pc) {
+    if (nonzero(st.beta) && nonzero(st.r_u)) {
+        Intr intr;
+        intr.is_surface = false;
+        intr.pi = p3i_exact(p);
+        intr.n = mk(0, 0, 0);
+        intr.wo = -st.rd;
+        intr.g = mp.g;
+        (void)sampler.get1d();  // v: gphase.init with an untrained field
+        float survivalProb = 1.0f;
+        if (st.depth > S.prm.minrrdepth) {
+            Spec rrw = (st.beta / avg(st.r_u)) * rr_correction;
+            survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+        }
+        if (S.prm.usenee) {
+            Spec Ld = sample_Ld(S, medium, intr, (const Bsdf *)nullptr, ch, sampler, st.r_u, pc);
+            st.L = st.L + st.beta * Ld;
+        }
+        if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
+            float q = fmax_(0.f, 1 - survivalProb);
+            if (sampler.get1d() < q) {
+                *terminated = true;
+                return;
+            }
+            st.beta = st.beta / (1 - q);
+        }
+        float u0 = sampler.get1d(), u1 = sampler.get1d();
+        float pdf;
+        V3 wi = sample_henyey_greenstein(-st.rd, mp.g, u0, u1, &pdf);
+        if (pdf == 0) {
+            *terminated = true;
+        } else {
+            float w = pdf / pdf;  // ps->p / ps->pdf
+            st.beta = st.beta * w;
+            st.r_l = st.r_u / pdf;
+            st.prevCtx.pi = p3i_exact(p);
+            st.prevCtx.n = mk(0, 0, 0);
+            *scattered = true;
+            st.ro = p;
+            st.rd = wi;
+            st.specularBounce = false;
+            st.anyNonSpecularBounces = true;
+            st.lastVertexVolume = true;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a10-a13: SampleDistance (:637-1096)
+// ---------------------------------------------------------------------------------------
+template <class Medium>
+VDEV void sample_distance(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
+                          PathState &st, float tMax, int ch, Sampler &sampler, Rng &rng, bool *scattered,
+                          bool *terminated, IsgSample &isg, PathCounters &pc) {
+    bool guide;
+    float vsp = fetch_vsp(S, vsp_buf, vsp_ready, px, py, st.depth, &guide);
+    if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
+    const float rr_correction = st.rr_correction;  // passed by value (:647)
+
+    bool use_resampling = S.prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && !medium.is_homogeneous();
+    if (use_resampling) {
+        float weightSum = 0;
+        Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f);
+        // CandidateData (integrators.h:526-543)
+        V3 sel_p = mk(0, 0, 0);
+        MediumProps sel_mp = MediumProps{sp(0), sp(0), sp(0), 0};
+        float sel_wi = 0, sel_sTTr = 0;
+        Spec sel_num = sp(0), sel_den = sp(0);
+        float vrc = 0, majorantScale = 1;
+        float u = sampler.get1d();
+        Spec T_maj = sample_T_maj_resampling(
+            medium, st.ro, st.rd, tMax, u, rng, ch, guide, vsp, &vrc, &majorantScale,
+            [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+                pc.density_queries++;
+                Spec sigma_t = mp.sigma_s + mp.sigma_a;
+                Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
+                float wi = ch_of(sigma_t / sigma_maj * trRatioEst, ch);
+                if (wi > 0) {
+                    weightSum += wi;
+                    if (sampler.get1d() < wi / weightSum) {
+                        float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
+                        sel_num = beta_rs * T_maj * mp.sigma_s / pdf;
+                        sel_den = r_u_rs * T_maj * sigma_t / pdf;
+                        sel_p = p;
+                        sel_mp = mp;
+                        sel_wi = wi;
+                        sel_sTTr = wi;
+                    }
+                }
+                float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
+                beta_rs = beta_rs * (T_maj * sigma_n / pdf);
+                r_u_rs = r_u_rs * (T_maj * sigma_n / pdf);
+                trRatioEst = trRatioEst * (sigma_n / sigma_maj);
+                return true;
+            });
+        float tm = ch_of(T_maj, ch);
+        beta_rs = beta_rs * (T_maj / tm);
+        r_u_rs = r_u_rs * (T_maj / tm);
+        float trScalar = ch_of(trRatioEst, ch);
+        float surf_wi = trScalar;
+        if (guide && trScalar < 1 && trScalar > 0 && weightSum > 0) {
+            float volRatio = vrc * S.prm.vspmisratio + (1 - trScalar) * (1 - S.prm.vspmisratio);
+            float surfRatio = 1 - volRatio;
+            surf_wi = surfRatio / volRatio * weightSum;
+        }
+        weightSum += surf_wi;
+        bool selectSurface = false;
+        if (weightSum == 0) return;
+        if (sampler.get1d() < surf_wi / weightSum) {
+            sel_wi = surf_wi;
+            sel_sTTr = trScalar;
+            sel_num = beta_rs;
+            sel_den = r_u_rs;
+            selectSurface = true;
+        }
+        float factor = weightSum * sel_sTTr / sel_wi;
+        if (!selectSurface) {
+            if (st.depth == 0) {
+                isg.valid = true;
+                isg.surface_event = false;
+            }
+            if (st.depth++ >= S.prm.maxdepth) {
+                *terminated = true;
+                return;
+            }
+            pc.volume_scatters++;
+        }
+        st.beta = st.beta * (sel_num * factor);
+        st.r_u = st.r_u * sel_den;
+        if (has_nan(st.beta) || has_nan(st.r_u) || has_inf(st.beta) || has_inf(st.r_u)) {
+            *terminated = true;
+            return;
+        }
+        if (!selectSurface) scatter_tail(S, medium, st, sel_p, sel_mp, ch, sampler, rr_correction, scattered, terminated, pc);
+    } else {
+        Spec r_u_factor = sp(1.f);  // beta_factor is never written by the reference (always 1)
+        float u = sampler.get1d();
+        Spec T_maj = sample_T_maj_ods(
+            medium, st.ro, st.rd, tMax, u, rng, ch, guide, vsp, S.prm.vspmisratio, S.prm.vspsamplingmethod == VSPG_VSP_NDS,
+            &r_u_factor, [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+                pc.density_queries++;
+                if (!nonzero(st.beta)) {
+                    *terminated = true;
+                    return false;
+                }
+                if (st.depth < S.prm.maxdepth && nonzero(mp.Le)) {  // :895-906
+                    float pdf = ch_of(sigma_maj, ch) * ch_of(T_maj, ch);
+                    Spec betap = st.beta * T_maj / pdf;
+                    Spec r_e = st.r_u * sigma_maj * T_maj / pdf;
+                    if (nonzero(r_e)) st.L = st.L + betap * mp.sigma_a * mp.Le / avg(r_e);
+                }
+                Spec sigma_t = mp.sigma_s + mp.sigma_a;
+                float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
+                float pNull = fmax_(0.f, 1 - pScatter);
+                float um = rng.uniform();
+                int mode = sample_discrete2(pScatter, pNull, um);
+                if (mode == 0) {
+                    if (st.depth == 0) {
+                        isg.valid = true;
+                        isg.surface_event = false;
+                    }
+                    if (st.depth++ >= S.prm.maxdepth) {
+                        *terminated = true;
+                        return false;
+                    }
+                    pc.volume_scatters++;
+                    float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
+                    st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
+                    st.r_u = st.r_u * (T_maj * sigma_t / pdf);
+                    st.r_u = st.r_u * r_u_factor;
+                    scatter_tail(S, medium, st, p, mp, ch, sampler, rr_correction, scattered, terminated, pc);
+                    return false;
+                } else {
+                    Spec sigma_n = clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s);
+                    float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
+                    st.beta = st.beta * (T_maj * sigma_n / pdf);
+                    if (pdf == 0) st.beta = sp(0.f);
+                    st.r_u = st.r_u * (T_maj * sigma_n / pdf);
+                    st.r_l = st.r_l * (T_maj * sigma_maj / pdf);
+                    return nonzero(st.beta) && nonzero(st.r_u);
+                }
+            });
+        bool multiply_T_maj = !(*scattered || *terminated || !nonzero(st.beta) || !nonzero(st.r_u));
+        if (multiply_T_maj) {
+            float tm = ch_of(T_maj, ch);
+            st.beta = st.beta * (T_maj / tm);
+            st.r_u = st.r_u * (T_maj / tm);
+            st.r_l = st.r_l * (T_maj / tm);
+            st.r_u = st.r_u * r_u_factor;
+            st.r_l = st.r_l * r_u_factor;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// one iteration of the Li path loop (:309-609): returns false when the path ends
+// ---------------------------------------------------------------------------------------
+template <class Medium>
+VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
+                     PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc) {
+    pc.segments++;
+    Isect si = scene_intersect(S, st.ro, st.rd, kInf);
+    float tMax = si.hit ? si.t : kInf;
+    if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
+        bool scattered = false, terminated = false;
+        uint64_t hash0 = hash_float(sampler.get1d());
+        uint64_t hash1 = hash_float(sampler.get1d());
+        Rng rng;
+        rng.set_sequence(hash0, hash1);
+        sample_distance(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, &scattered, &terminated, isg, pc);
+        if (terminated || !nonzero(st.beta) || !nonzero(st.r_u)) return false;
+        if (scattered) return true;
+    }
+    if (!si.hit) return false;  // no infinite lights in scope (:353-374)
+
+    const DQuad &q = S.quads[si.quad];
+    Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
+    if (nonzero(Le)) {
+        if (st.depth == 0 || st.specularBounce) {
+            st.L = st.L + st.beta * Le / avg(st.r_u);
+        } else {
+            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx, st.rd);
+            st.r_l = st.r_l * lightPDF;
+            float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
+            st.L = st.L + st.beta * w_l * Le;
+        }
+    }
+    Bsdf bsdf = bsdf_make(q);
+    if (st.depth == 0) {
+        isg.valid = true;
+        isg.surface_event = true;
+    }
+    if (st.depth++ >= S.prm.maxdepth) return false;
+    pc.surface_hits++;
+
+    (void)sampler.get1d();  // v: gbsdf.init with an untrained field (:457-458)
+    float survivalProb = 1.f;
+    P3i pi = p3i_from_err(si.p, ld3(q.perr));
+    Intr intr;
+    intr.is_surface = true;
+    intr.pi = pi;
+    intr.n = si.n;
+    intr.wo = normalize(-st.rd);  // Interaction ctor normalises wo (interaction.h:31-32)
+    intr.g = 0;
+    if (S.prm.usenee && bsdf.has_lobes) {  // IsNonSpecular(bsdf.Flags())
+        Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc);
+        st.L = st.L + st.beta * Ld;
+    }
+    st.prevCtx.pi = pi;
+    st.prevCtx.n = si.n;
+
+    V3 wo = -st.rd;
+    (void)sampler.get1d();  // u (unused by DiffuseBxDF)
+    float u20 = sampler.get1d(), u21 = sampler.get1d();
+    Spec f;
+    V3 wi;
+    float pdf;
+    if (!bsdf_sample_f(bsdf, wo, u20, u21, &f, &wi, &pdf)) return false;
+    st.lastVertexVolume = false;
+    st.rr_correction *= pdf / pdf;  // bs->pdf / bs->bsdfPdf
+    Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
+    st.beta = st.beta * bsdfWeight;
+    st.r_l = st.r_u / pdf;  // misPdf == pdf without guiding
+    st.specularBounce = false;
+    st.anyNonSpecularBounces = true;
+    st.ro = offset_ray_origin(pi, si.n, wi);  // SpawnRay (interaction.h:99-101)
+    st.rd = wi;
+
+    if (!nonzero(st.beta)) return false;
+    if (st.depth > S.prm.minrrdepth) {
+        Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;
+        survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+    }
+    if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
+        float qq = fmax_(0.f, 1 - survivalProb);
+        if (sampler.get1d() < qq) return false;
+        st.beta = st.beta / (1 - qq);
+    }
+    return true;
+}
+
+// EvaluatePixelSample up to the camera ray (src/pbrt/cpu/integrators.cpp:272-304)
+VDEV void start_path(const DScene &S, int px, int py, int sampleIndex, Sampler &sampler, PathState &st, int *ch,
+                     IsgSample &isg) {
+    sampler.start_pixel_sample(px, py, S.seed, sampleIndex);
+    float lu = sampler.get1d();
+    int c = (int)__builtin_floorf(lu * 3);  // SampledWavelengths::SampleVisible (spectrum.h:380-384)
+    *ch = c > 2 ? 2 : c;
+    // GetCameraSample (samplers.h:796-815), BoxFilter radius .5 (filters.h:67-69)
+    float f0 = sampler.get1d(), f1 = sampler.get1d();
+    float fpx = (1 - f0) * -0.5f + f0 * 0.5f;
+    float fpy = (1 - f1) * -0.5f + f1 * 0.5f;
+    float pfx = ((float)px + fpx) + 0.5f, pfy = ((float)py + fpy) + 0.5f;
+    (void)sampler.get1d();  // time
+    (void)sampler.get1d();  // pLens
+    (void)sampler.get1d();
+    V3 pc_ = mk(S.cam.sx * pfx + S.cam.ox, S.cam.sy * pfy + S.cam.oy, 1.f);
+    V3 dir = normalize(pc_);
+    Frame f{ld3(S.cam.right), ld3(S.cam.up), ld3(S.cam.fwd)};
+    st.ro = ld3(S.cam.origin);
+    st.rd = f.from_local(dir);
+    st.L = sp(0.f);
+    st.beta = sp(1.f);
+    st.r_u = sp(1.f);
+    st.r_l = sp(1.f);
+    st.prevCtx.pi = p3i_exact(mk(0, 0, 0));
+    st.prevCtx.n = mk(0, 0, 0);
+    st.depth = 0;
+    st.specularBounce = false;
+    st.anyNonSpecularBounces = false;
+    st.lastVertexVolume = false;
+    st.rr_correction = 1.0f;
+    st.etaScale = 1;
+    isg.valid = false;
+    isg.surface_event = false;
+    isg.vsp_used = -1.f;
+}
+
+// NaN / Inf radiance -> black (integrators.cpp:308-318)
+VDEV Spec finish_radiance(Spec L) {
+    if (has_nan(L)) return sp(0.f);
+    if (has_inf(L)) return sp(0.f);
+    return L;
+}
+
+// image-space VSP statistics (own design standing in for ImageSpaceGuidingBuffer::AddSample,
+// guidedvolpathvspgintegrator.cpp:613-622; OpenPGL absent -> unpinned)
+//   st[0]=n [1]=sum c[vol] [2]=sum c[surf] [3]=sum c^2 q [vol] [4]=sum c^2 (1-q) [surf] [5]=n_vol
+VDEV void isg_add_sample(float *st, Spec L, const IsgSample &isg) {
+    if (!isg.valid) return;
+    float c = avg(L);
+    float q = isg.vsp_used >= 0.f ? isg.vsp_used : 0.5f;
+    st[0] += 1.f;
+    if (isg.surface_event) {
+        st[2] += c;
+        st[4] += c * c * (1 - q);
+    } else {
+        st[1] += c;
+        st[3] += c * c * q;
+        st[5] += 1.f;
+    }
+}
+
+}  // namespace vspg
