@@ -21,6 +21,7 @@ using namespace vspg;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kBlocksPerCU = 8;  // persistent blocks per CU (upper bound on residency; extra blocks just queue)
 constexpr int kNumCounters = 6;  // paths, segments, volume_scatters, surface_hits, density_queries, shadow_rays
 
 __device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t paths, unsigned long long *g) {
@@ -37,55 +38,95 @@ __device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t 
     if (threadIdx.x < kNumCounters) atomicAdd(&g[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
-// One lane owns one pixel and runs its samples [wave_start, wave_end) to termination, path state
-// in registers (no HBM round trip between segments); film and ISG statistics are read-modify-
-// written once per launch by the owning lane (no atomics: one owner per pixel per launch).
-// Lanes of a wavefront cover an 8x8 pixel tile so primary rays are coherent.
+// Persistent wavefront kernel with path regeneration.
+//   work item  = one pixel (all its samples [wave_start, wave_end) run in order by the lane that
+//                claims it, so film / ISG statistics are read-modify-written by exactly one lane
+//                per launch: no atomics, deterministic summation order);
+//   claiming   = lanes whose path has ended are compacted with a wave ballot + prefix count and
+//                served by ONE atomicAdd per wavefront on the global work head (stochastic path
+//                termination -- Russian roulette, absorption at maxdepth -- leaves holes in the
+//                wave; regeneration refills them instead of idling until the longest path ends);
+//   path state = registers for the whole life of a path (no HBM round trip per segment);
+//   items are tile-ordered (8x8 pixels per 64 items) so a fresh wavefront starts on one coherent
+//   tile of primary rays.
 template <class Medium>
-__global__ __launch_bounds__(kBlock) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
+__global__ __launch_bounds__(kBlock, 2) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
                                                         float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
                                                         int vsp_ready, int wave_start, int wave_end,
+                                                        unsigned int *__restrict__ work_head,
                                                         unsigned long long *__restrict__ counters) {
     const DScene &S = *Sp;
     const int W = S.xres, H = S.yres;
-    const int tilesX = (W + 7) >> 3;
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
-    const int tile = gid >> 6, lane = gid & 63;
-    const int px = (tile % tilesX) * 8 + (lane & 7);
-    const int py = (tile / tilesX) * 8 + (lane >> 3);
-    const bool active = px < W && py < H;
+    const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
+    const unsigned total_items = (unsigned)(tilesX * tilesY) * 64u;
+    const int lane = threadIdx.x & 63;
+    const Medium medium = make_homogeneous(S);
     PathCounters pc = {0, 0, 0, 0, 0};
     uint32_t paths = 0;
-    if (active) {
-        const Medium medium = make_homogeneous(S);
-        const size_t idx = (size_t)py * W + px;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float st8[VSPG_ISG_STATS];
-        const float4 *sp4 = reinterpret_cast<const float4 *>(isg_stats + idx * VSPG_ISG_STATS);
-        float4 s0 = sp4[0], s1 = sp4[1];
-        st8[0] = s0.x; st8[1] = s0.y; st8[2] = s0.z; st8[3] = s0.w;
-        st8[4] = s1.x; st8[5] = s1.y; st8[6] = s1.z; st8[7] = s1.w;
-        for (int s = wave_start; s < wave_end; ++s) {
-            if (S.shard_count > 1 && (s % S.shard_count) != S.shard_index) continue;
-            Sampler sampler;
-            PathState st;
-            IsgSample isg;
-            int ch;
-            start_path(S, px, py, s, sampler, st, &ch, isg);
-            while (li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc)) {
+
+    bool has = false;        // this lane carries a live path
+    bool exhausted = false;  // wave-uniform: the work head ran past the last item
+    int px = 0, py = 0, s = 0, ch = 0;
+    Sampler sampler;
+    PathState st;
+    IsgSample isg;
+
+    while (true) {
+        // ---- regeneration: ballot the empty lanes, one atomic per wavefront -------------------
+        unsigned long long need = __ballot(!has);
+        if (need != 0ull && !exhausted) {
+            const int cnt = __popcll(need);
+            unsigned base = 0;
+            if (lane == (int)(__ffsll((long long)need) - 1)) base = atomicAdd(work_head, (unsigned)cnt);
+            base = __shfl(base, (int)(__ffsll((long long)need) - 1));
+            const unsigned rank = (unsigned)__popcll(need & ((1ull << lane) - 1ull));
+            if (!has) {
+                const unsigned item = base + rank;
+                if (item < total_items) {
+                    const unsigned tile = item >> 6, l = item & 63u;
+                    px = (int)(tile % (unsigned)tilesX) * 8 + (int)(l & 7u);
+                    py = (int)(tile / (unsigned)tilesX) * 8 + (int)(l >> 3);
+                    s = wave_start;
+                    if (S.shard_count > 1) {  // first sample index of this shard in the range
+                        int r = s % S.shard_count;
+                        s += (S.shard_index - r + S.shard_count) % S.shard_count;
+                    }
+                    if (px < W && py < H && s < wave_end) {
+                        start_path(S, px, py, s, sampler, st, &ch, isg);
+                        has = true;
+                    }
+                }
             }
-            Spec L = finish_radiance(st.L);
-            // RGBFilm::AddSample (film.h:251-267), weight 1, imagingRatio 1, no clamp
-            acc.x += L.r; acc.y += L.g; acc.z += L.b; acc.w += 1.f;
-            isg_add_sample(st8, L, isg);
-            paths++;
+            if (base + (unsigned)cnt >= total_items) exhausted = true;
         }
-        float4 f = film[idx];
-        f.x += acc.x; f.y += acc.y; f.z += acc.z; f.w += acc.w;
-        film[idx] = f;
-        float4 *so = reinterpret_cast<float4 *>(isg_stats + idx * VSPG_ISG_STATS);
-        so[0] = make_float4(st8[0], st8[1], st8[2], st8[3]);
-        so[1] = make_float4(st8[4], st8[5], st8[6], st8[7]);
+        if (__ballot(has) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- one path segment for every live lane ----------------------------------------------
+        if (has) {
+            const bool alive = li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc);
+            if (!alive) {
+                const Spec L = finish_radiance(st.L);
+                const size_t idx = (size_t)py * W + px;
+                // RGBFilm::AddSample (film.h:251-267): weight 1, imagingRatio 1, no clamp
+                float4 f = film[idx];
+                f.x += L.r; f.y += L.g; f.z += L.b; f.w += 1.f;
+                film[idx] = f;
+                float4 *sp4 = reinterpret_cast<float4 *>(isg_stats + idx * VSPG_ISG_STATS);
+                float4 s0 = sp4[0], s1 = sp4[1];
+                float st8[VSPG_ISG_STATS] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                isg_add_sample(st8, L, isg);
+                sp4[0] = make_float4(st8[0], st8[1], st8[2], st8[3]);
+                sp4[1] = make_float4(st8[4], st8[5], st8[6], st8[7]);
+                paths++;
+                s += S.shard_count > 1 ? S.shard_count : 1;
+                if (s < wave_end)
+                    start_path(S, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
+                else
+                    has = false;
+            }
+        }
     }
     flush_counters(pc, paths, counters);
 }
@@ -245,6 +286,8 @@ struct VspgRenderer {
     float *isg_stats = nullptr;
     float *vsp = nullptr;
     unsigned long long *counters = nullptr;
+    unsigned int *work_head = nullptr;
+    int num_cus = 0;
     int vsp_ready = 0;
     int wave_counter = 0, buffer_wave = 0;
     size_t npix = 0;
@@ -472,6 +515,12 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     CK(hipMemset(r->vsp, 0, r->npix * sizeof(float)));
     CK(hipMalloc(&r->counters, kNumCounters * sizeof(unsigned long long)));
     CK(hipMemset(r->counters, 0, kNumCounters * sizeof(unsigned long long)));
+    CK(hipMalloc(&r->work_head, sizeof(unsigned int)));
+    {
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, cfg->device));
+        r->num_cus = prop.multiProcessorCount;
+    }
 #undef CK
     *out = r;
     return 0;
@@ -485,6 +534,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->isg_stats) (void)hipFree(r->isg_stats);
     if (r->vsp) (void)hipFree(r->vsp);
     if (r->counters) (void)hipFree(r->counters);
+    if (r->work_head) (void)hipFree(r->work_head);
     delete r;
     return 0;
 }
@@ -495,10 +545,14 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     if (wave_end == wave_start) return 0;
     HIPCHK(hipSetDevice(r->cfg.device));
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
-    const long long threads = (long long)tilesX * tilesY * 64;
-    const int blocks = (int)((threads + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_render_wave<HomogeneousMedium>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,
-                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, r->counters);
+    const long long items = (long long)tilesX * tilesY * 64;
+    // persistent grid: enough resident wavefronts to fill the chip, never more blocks than work
+    long long blocks = (long long)r->num_cus * kBlocksPerCU;
+    const long long max_blocks = (items + kBlock - 1) / kBlock;
+    if (blocks > max_blocks) blocks = max_blocks;
+    HIPCHK(hipMemsetAsync(r->work_head, 0, sizeof(unsigned int), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_render_wave<HomogeneousMedium>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, r->work_head, r->counters);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -376,20 +376,34 @@ struct Isect {
     V3 p, n;
 };
 
-// ray / rectangle (own geometry stand-in; same formulas as the scene contract in DESIGN.md)
-VDEV bool quad_intersect(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, V3 *pHit) {
-    V3 n = ld3(q.n), p00 = ld3(q.p00), e1 = ld3(q.e1), e2 = ld3(q.e2);
+// ray / rectangle (own geometry stand-in, contract in DESIGN.md): plane hit t = n.(p00-o)/n.d,
+// accepted when 0 < t < tMax and the parametric (u,v) of o+t*d lie in [0,1]^2; the reported point
+// is re-projected onto the rectangle, p00 + (u*e1 + v*e2).
+// The sign pre-test only skips work whose outcome is already decided: t = num/denom can be > 0
+// only when num and denom are non-zero with equal signs.
+VDEV bool quad_hit_uv(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, float *uHit, float *vHit) {
+    V3 n = ld3(q.n), p00 = ld3(q.p00);
     float denom = dot(n, d);
-    if (denom == 0) return false;
-    float t = dot(n, p00 - o) / denom;
+    float num = dot(n, p00 - o);
+    bool cand = (num > 0 && denom > 0) || (num < 0 && denom < 0);
+    if (!cand) return false;
+    float t = num / denom;
     if (!(t > 0) || !(t < tMax)) return false;
     V3 p = o + d * t;
     V3 rel = p - p00;
-    float u = dot(rel, e1) * q.inv_l1;
-    float v = dot(rel, e2) * q.inv_l2;
+    float u = dot(rel, ld3(q.e1)) * q.inv_l1;
+    float v = dot(rel, ld3(q.e2)) * q.inv_l2;
     if (u < 0 || u > 1 || v < 0 || v > 1) return false;
     *tHit = t;
-    *pHit = p00 + (e1 * u + e2 * v);
+    *uHit = u;
+    *vHit = v;
+    return true;
+}
+VDEV V3 quad_point(const DQuad &q, float u, float v) { return ld3(q.p00) + (ld3(q.e1) * u + ld3(q.e2) * v); }
+VDEV bool quad_intersect(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, V3 *pHit) {
+    float u, v;
+    if (!quad_hit_uv(q, o, d, tMax, tHit, &u, &v)) return false;
+    *pHit = quad_point(q, u, v);
     return true;
 }
 VDEV Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
@@ -397,27 +411,27 @@ VDEV Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     best.hit = false;
     best.t = tMax;
     best.quad = 0;
-    best.p = mk(0, 0, 0);
-    best.n = mk(0, 0, 0);
+    float bu = 0, bv = 0;
     for (int i = 0; i < S.n_quads; ++i) {
-        float t;
-        V3 p;
-        if (quad_intersect(S.quads[i], o, d, best.t, &t, &p)) {
+        float t, u, v;
+        if (quad_hit_uv(S.quads[i], o, d, best.t, &t, &u, &v)) {
             best.hit = true;
             best.t = t;
             best.quad = i;
-            best.p = p;
-            best.n = ld3(S.quads[i].n);
+            bu = u;
+            bv = v;
         }
     }
+    const DQuad &q = S.quads[best.quad];  // per-lane index: vector loads, once per segment
+    best.p = quad_point(q, bu, bv);
+    best.n = ld3(q.n);
     return best;
 }
 VDEV bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
     bool any = false;
     for (int i = 0; i < S.n_quads; ++i) {
-        float t;
-        V3 p;
-        any = any || quad_intersect(S.quads[i], o, d, tMax, &t, &p);
+        float t, u, v;
+        any = any || quad_hit_uv(S.quads[i], o, d, tMax, &t, &u, &v);
     }
     return any;
 }

@@ -240,68 +240,33 @@ VDEV float fetch_vsp(const DScene &S, const float *vsp_buf, int vsp_ready, int p
     return vsp;
 }
 
-// volume-scatter tail shared by both SampleDistance branches (:804-875 == :988-1058)
-// returns false when the path terminates
-template <class Medium>
-VDEV void scatter_tail(const DScene &S, const Medium &medium, PathState &st, V3 p, const MediumProps &mp, int ch,
-                       Sampler &sampler, float rr_correction, bool *scattered, bool *terminated, PathCounters &pc) {
-    if (nonzero(st.beta) && nonzero(st.r_u)) {
-        Intr intr;
-        intr.is_surface = false;
-        intr.pi = p3i_exact(p);
-        intr.n = mk(0, 0, 0);
-        intr.wo = -st.rd;
-        intr.g = mp.g;
-        (void)sampler.get1d();  // v: gphase.init with an untrained field
-        float survivalProb = 1.0f;
-        if (st.depth > S.prm.minrrdepth) {
-            Spec rrw = (st.beta / avg(st.r_u)) * rr_correction;
-            survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
-        }
-        if (S.prm.usenee) {
-            Spec Ld = sample_Ld(S, medium, intr, (const Bsdf *)nullptr, ch, sampler, st.r_u, pc);
-            st.L = st.L + st.beta * Ld;
-        }
-        if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
-            float q = fmax_(0.f, 1 - survivalProb);
-            if (sampler.get1d() < q) {
-                *terminated = true;
-                return;
-            }
-            st.beta = st.beta / (1 - q);
-        }
-        float u0 = sampler.get1d(), u1 = sampler.get1d();
-        float pdf;
-        V3 wi = sample_henyey_greenstein(-st.rd, mp.g, u0, u1, &pdf);
-        if (pdf == 0) {
-            *terminated = true;
-        } else {
-            float w = pdf / pdf;  // ps->p / ps->pdf
-            st.beta = st.beta * w;
-            st.r_l = st.r_u / pdf;
-            st.prevCtx.pi = p3i_exact(p);
-            st.prevCtx.n = mk(0, 0, 0);
-            *scattered = true;
-            st.ro = p;
-            st.rd = wi;
-            st.specularBounce = false;
-            st.anyNonSpecularBounces = true;
-            st.lastVertexVolume = true;
-        }
-    }
-}
+// ---------------------------------------------------------------------------------------
+// a10-a13: SampleDistance (:637-1096), restructured around an EVENT: the traversal callbacks only
+// do the cheap bookkeeping the reference does at a collision; when a real scattering event is
+// chosen the callback records where (p, phase g) and stops the traversal, and the volume-scatter
+// tail (:804-875 == :988-1058: cache init, NEE, RR, phase sampling) runs ONCE afterwards in
+// li_segment, merged with the surface-vertex code.  The reference runs the tail inside the
+// callback and then returns false, so nothing else happens in between: same operations, same
+// random-number order, one copy of the expensive code instead of one per callback site.
+// ---------------------------------------------------------------------------------------
+enum { EV_PASS = 0, EV_SCATTER = 1, EV_TERMINATE = 2 };
+struct DistEvent {
+    int kind;
+    V3 p;     // scattering position
+    float g;  // HG asymmetry of the phase function at p
+};
 
-// ---------------------------------------------------------------------------------------
-// a10-a13: SampleDistance (:637-1096)
-// ---------------------------------------------------------------------------------------
 template <class Medium>
-VDEV void sample_distance(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
-                          PathState &st, float tMax, int ch, Sampler &sampler, Rng &rng, bool *scattered,
-                          bool *terminated, IsgSample &isg, PathCounters &pc) {
+VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
+                               PathState &st, float tMax, int ch, Sampler &sampler, Rng &rng, IsgSample &isg,
+                               PathCounters &pc) {
+    DistEvent ev;
+    ev.kind = EV_PASS;
+    ev.p = mk(0, 0, 0);
+    ev.g = 0;
     bool guide;
     float vsp = fetch_vsp(S, vsp_buf, vsp_ready, px, py, st.depth, &guide);
     if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
-    const float rr_correction = st.rr_correction;  // passed by value (:647)
 
     bool use_resampling = S.prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && !medium.is_homogeneous();
     if (use_resampling) {
@@ -309,7 +274,7 @@ VDEV void sample_distance(const DScene &S, const Medium &medium, const float *vs
         Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f);
         // CandidateData (integrators.h:526-543)
         V3 sel_p = mk(0, 0, 0);
-        MediumProps sel_mp = MediumProps{sp(0), sp(0), sp(0), 0};
+        float sel_g = 0;
         float sel_wi = 0, sel_sTTr = 0;
         Spec sel_num = sp(0), sel_den = sp(0);
         float vrc = 0, majorantScale = 1;
@@ -328,7 +293,7 @@ VDEV void sample_distance(const DScene &S, const Medium &medium, const float *vs
                         sel_num = beta_rs * T_maj * mp.sigma_s / pdf;
                         sel_den = r_u_rs * T_maj * sigma_t / pdf;
                         sel_p = p;
-                        sel_mp = mp;
+                        sel_g = mp.g;
                         sel_wi = wi;
                         sel_sTTr = wi;
                     }
@@ -351,7 +316,7 @@ VDEV void sample_distance(const DScene &S, const Medium &medium, const float *vs
         }
         weightSum += surf_wi;
         bool selectSurface = false;
-        if (weightSum == 0) return;
+        if (weightSum == 0) return ev;
         if (sampler.get1d() < surf_wi / weightSum) {
             sel_wi = surf_wi;
             sel_sTTr = trScalar;
@@ -366,80 +331,92 @@ VDEV void sample_distance(const DScene &S, const Medium &medium, const float *vs
                 isg.surface_event = false;
             }
             if (st.depth++ >= S.prm.maxdepth) {
-                *terminated = true;
-                return;
+                ev.kind = EV_TERMINATE;
+                return ev;
             }
             pc.volume_scatters++;
         }
         st.beta = st.beta * (sel_num * factor);
         st.r_u = st.r_u * sel_den;
         if (has_nan(st.beta) || has_nan(st.r_u) || has_inf(st.beta) || has_inf(st.r_u)) {
-            *terminated = true;
-            return;
+            ev.kind = EV_TERMINATE;
+            return ev;
         }
-        if (!selectSurface) scatter_tail(S, medium, st, sel_p, sel_mp, ch, sampler, rr_correction, scattered, terminated, pc);
-    } else {
-        Spec r_u_factor = sp(1.f);  // beta_factor is never written by the reference (always 1)
-        float u = sampler.get1d();
-        Spec T_maj = sample_T_maj_ods(
-            medium, st.ro, st.rd, tMax, u, rng, ch, guide, vsp, S.prm.vspmisratio, S.prm.vspsamplingmethod == VSPG_VSP_NDS,
-            &r_u_factor, [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
-                pc.density_queries++;
-                if (!nonzero(st.beta)) {
-                    *terminated = true;
-                    return false;
-                }
-                if (st.depth < S.prm.maxdepth && nonzero(mp.Le)) {  // :895-906
-                    float pdf = ch_of(sigma_maj, ch) * ch_of(T_maj, ch);
-                    Spec betap = st.beta * T_maj / pdf;
-                    Spec r_e = st.r_u * sigma_maj * T_maj / pdf;
-                    if (nonzero(r_e)) st.L = st.L + betap * mp.sigma_a * mp.Le / avg(r_e);
-                }
-                Spec sigma_t = mp.sigma_s + mp.sigma_a;
-                float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
-                float pNull = fmax_(0.f, 1 - pScatter);
-                float um = rng.uniform();
-                int mode = sample_discrete2(pScatter, pNull, um);
-                if (mode == 0) {
-                    if (st.depth == 0) {
-                        isg.valid = true;
-                        isg.surface_event = false;
-                    }
-                    if (st.depth++ >= S.prm.maxdepth) {
-                        *terminated = true;
-                        return false;
-                    }
-                    pc.volume_scatters++;
-                    float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
-                    st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
-                    st.r_u = st.r_u * (T_maj * sigma_t / pdf);
-                    st.r_u = st.r_u * r_u_factor;
-                    scatter_tail(S, medium, st, p, mp, ch, sampler, rr_correction, scattered, terminated, pc);
-                    return false;
-                } else {
-                    Spec sigma_n = clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s);
-                    float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
-                    st.beta = st.beta * (T_maj * sigma_n / pdf);
-                    if (pdf == 0) st.beta = sp(0.f);
-                    st.r_u = st.r_u * (T_maj * sigma_n / pdf);
-                    st.r_l = st.r_l * (T_maj * sigma_maj / pdf);
-                    return nonzero(st.beta) && nonzero(st.r_u);
-                }
-            });
-        bool multiply_T_maj = !(*scattered || *terminated || !nonzero(st.beta) || !nonzero(st.r_u));
-        if (multiply_T_maj) {
-            float tm = ch_of(T_maj, ch);
-            st.beta = st.beta * (T_maj / tm);
-            st.r_u = st.r_u * (T_maj / tm);
-            st.r_l = st.r_l * (T_maj / tm);
-            st.r_u = st.r_u * r_u_factor;
-            st.r_l = st.r_l * r_u_factor;
+        if (!selectSurface) {
+            ev.kind = EV_SCATTER;
+            ev.p = sel_p;
+            ev.g = sel_g;
         }
+        return ev;
     }
+
+    // the delta-tracking routine (:878-1094)
+    Spec r_u_factor = sp(1.f);  // beta_factor is never written by the reference (always 1)
+    float u = sampler.get1d();
+    Spec T_maj = sample_T_maj_ods(
+        medium, st.ro, st.rd, tMax, u, rng, ch, guide, vsp, S.prm.vspmisratio, S.prm.vspsamplingmethod == VSPG_VSP_NDS,
+        &r_u_factor, [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+            pc.density_queries++;
+            if (!nonzero(st.beta)) {
+                ev.kind = EV_TERMINATE;
+                return false;
+            }
+            if (st.depth < S.prm.maxdepth && nonzero(mp.Le)) {  // :895-906
+                float pdf = ch_of(sigma_maj, ch) * ch_of(T_maj, ch);
+                Spec betap = st.beta * T_maj / pdf;
+                Spec r_e = st.r_u * sigma_maj * T_maj / pdf;
+                if (nonzero(r_e)) st.L = st.L + betap * mp.sigma_a * mp.Le / avg(r_e);
+            }
+            Spec sigma_t = mp.sigma_s + mp.sigma_a;
+            float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
+            float pNull = fmax_(0.f, 1 - pScatter);
+            float um = rng.uniform();
+            int mode = sample_discrete2(pScatter, pNull, um);
+            if (mode == 0) {
+                if (st.depth == 0) {
+                    isg.valid = true;
+                    isg.surface_event = false;
+                }
+                if (st.depth++ >= S.prm.maxdepth) {
+                    ev.kind = EV_TERMINATE;
+                    return false;
+                }
+                pc.volume_scatters++;
+                float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
+                st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
+                st.r_u = st.r_u * (T_maj * sigma_t / pdf);
+                st.r_u = st.r_u * r_u_factor;
+                ev.kind = EV_SCATTER;
+                ev.p = p;
+                ev.g = mp.g;
+                return false;
+            } else {
+                Spec sigma_n = clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s);
+                float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
+                st.beta = st.beta * (T_maj * sigma_n / pdf);
+                if (pdf == 0) st.beta = sp(0.f);
+                st.r_u = st.r_u * (T_maj * sigma_n / pdf);
+                st.r_l = st.r_l * (T_maj * sigma_maj / pdf);
+                return nonzero(st.beta) && nonzero(st.r_u);
+            }
+        });
+    // :1080-1091 -- after a scatter event the reference never multiplies T_maj in (scattered or
+    // terminated is set by the tail, or beta / r_u is zero)
+    bool multiply_T_maj = ev.kind == EV_PASS && nonzero(st.beta) && nonzero(st.r_u);
+    if (multiply_T_maj) {
+        float tm = ch_of(T_maj, ch);
+        st.beta = st.beta * (T_maj / tm);
+        st.r_u = st.r_u * (T_maj / tm);
+        st.r_l = st.r_l * (T_maj / tm);
+        st.r_u = st.r_u * r_u_factor;
+        st.r_l = st.r_l * r_u_factor;
+    }
+    return ev;
 }
 
 // ---------------------------------------------------------------------------------------
-// one iteration of the Li path loop (:309-609): returns false when the path ends
+// one iteration of the Li path loop (:309-609): returns false when the path ends.
+// Surface vertices (:376-608) and volume vertices (the scatter tail) share the NEE code.
 // ---------------------------------------------------------------------------------------
 template <class Medium>
 VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
@@ -447,54 +424,97 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
     pc.segments++;
     Isect si = scene_intersect(S, st.ro, st.rd, kInf);
     float tMax = si.hit ? si.t : kInf;
+    bool volume_vertex = false;
+    V3 vp = mk(0, 0, 0);
+    float vg = 0;
     if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
-        bool scattered = false, terminated = false;
         uint64_t hash0 = hash_float(sampler.get1d());
         uint64_t hash1 = hash_float(sampler.get1d());
         Rng rng;
         rng.set_sequence(hash0, hash1);
-        sample_distance(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, &scattered, &terminated, isg, pc);
-        if (terminated || !nonzero(st.beta) || !nonzero(st.r_u)) return false;
-        if (scattered) return true;
-    }
-    if (!si.hit) return false;  // no infinite lights in scope (:353-374)
-
-    const DQuad &q = S.quads[si.quad];
-    Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
-    if (nonzero(Le)) {
-        if (st.depth == 0 || st.specularBounce) {
-            st.L = st.L + st.beta * Le / avg(st.r_u);
-        } else {
-            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx, st.rd);
-            st.r_l = st.r_l * lightPDF;
-            float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
-            st.L = st.L + st.beta * w_l * Le;
+        DistEvent ev = sample_distance(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
+        if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return false;  // :343-344
+        if (ev.kind == EV_SCATTER) {
+            volume_vertex = true;
+            vp = ev.p;
+            vg = ev.g;
         }
     }
-    Bsdf bsdf = bsdf_make(q);
-    if (st.depth == 0) {
-        isg.valid = true;
-        isg.surface_event = true;
-    }
-    if (st.depth++ >= S.prm.maxdepth) return false;
-    pc.surface_hits++;
 
-    (void)sampler.get1d();  // v: gbsdf.init with an untrained field (:457-458)
-    float survivalProb = 1.f;
-    P3i pi = p3i_from_err(si.p, ld3(q.perr));
     Intr intr;
-    intr.is_surface = true;
-    intr.pi = pi;
-    intr.n = si.n;
-    intr.wo = normalize(-st.rd);  // Interaction ctor normalises wo (interaction.h:31-32)
-    intr.g = 0;
-    if (S.prm.usenee && bsdf.has_lobes) {  // IsNonSpecular(bsdf.Flags())
+    Bsdf bsdf;
+    float survivalProb = 1.f;
+    if (volume_vertex) {
+        // MediumInteraction intr(p, -ray.d, ...) (:806 / :990)
+        intr.is_surface = false;
+        intr.pi = p3i_exact(vp);
+        intr.n = mk(0, 0, 0);
+        intr.wo = -st.rd;
+        intr.g = vg;
+        bsdf.has_lobes = false;
+    } else {
+        if (!si.hit) return false;  // no infinite lights in scope (:353-374)
+        const DQuad &q = S.quads[si.quad];
+        Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
+        if (nonzero(Le)) {
+            if (st.depth == 0 || st.specularBounce) {
+                st.L = st.L + st.beta * Le / avg(st.r_u);
+            } else {
+                float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx, st.rd);
+                st.r_l = st.r_l * lightPDF;
+                float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
+                st.L = st.L + st.beta * w_l * Le;
+            }
+        }
+        bsdf = bsdf_make(q);
+        if (st.depth == 0) {
+            isg.valid = true;
+            isg.surface_event = true;
+        }
+        if (st.depth++ >= S.prm.maxdepth) return false;
+        pc.surface_hits++;
+        intr.is_surface = true;
+        intr.pi = p3i_from_err(si.p, ld3(q.perr));
+        intr.n = si.n;
+        intr.wo = normalize(-st.rd);  // Interaction ctor normalises wo (interaction.h:31-32)
+        intr.g = 0;
+    }
+
+    (void)sampler.get1d();  // v: gbsdf.init / gphase.init with an untrained field (:457-458, :809-810)
+    if (volume_vertex && st.depth > S.prm.minrrdepth) {  // :817-830: survival probability BEFORE the NEE
+        Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction;
+        survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+    }
+    if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {  // :479 IsNonSpecular(bsdf.Flags()) / :833
         Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc);
         st.L = st.L + st.beta * Ld;
     }
-    st.prevCtx.pi = pi;
-    st.prevCtx.n = si.n;
 
+    if (volume_vertex) {
+        if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {  // :842-849
+            float q = fmax_(0.f, 1 - survivalProb);
+            if (sampler.get1d() < q) return false;
+            st.beta = st.beta / (1 - q);
+        }
+        float u0 = sampler.get1d(), u1 = sampler.get1d();
+        float pdf;
+        V3 wi = sample_henyey_greenstein(-st.rd, vg, u0, u1, &pdf);  // gphase.Sample_p(-ray.d, u)
+        if (pdf == 0) return false;
+        float w = pdf / pdf;  // ps->p / ps->pdf
+        st.beta = st.beta * w;
+        st.r_l = st.r_u / pdf;
+        st.prevCtx.pi = p3i_exact(vp);
+        st.prevCtx.n = mk(0, 0, 0);
+        st.ro = vp;
+        st.rd = wi;
+        st.specularBounce = false;
+        st.anyNonSpecularBounces = true;
+        st.lastVertexVolume = true;
+        return true;
+    }
+
+    st.prevCtx.pi = intr.pi;  // :487
+    st.prevCtx.n = si.n;
     V3 wo = -st.rd;
     (void)sampler.get1d();  // u (unused by DiffuseBxDF)
     float u20 = sampler.get1d(), u21 = sampler.get1d();
@@ -509,7 +529,7 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
     st.r_l = st.r_u / pdf;  // misPdf == pdf without guiding
     st.specularBounce = false;
     st.anyNonSpecularBounces = true;
-    st.ro = offset_ray_origin(pi, si.n, wi);  // SpawnRay (interaction.h:99-101)
+    st.ro = offset_ray_origin(intr.pi, si.n, wi);  // SpawnRay (interaction.h:99-101)
     st.rd = wi;
 
     if (!nonzero(st.beta)) return false;
