@@ -42,14 +42,27 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": (n_floats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+def host_threads():
+    """CPU threads this process may actually use: cgroup quota, else affinity (the GPU box exposes
+    every core of the host in os.cpu_count() but grants a 1-GPU job a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("VSPG_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(pkg, scene, prm, W, H, budget_s=15.0):
     """Oracle timed on the host cores over a bounded sample of the same workload."""
     import oracle_lib
 
     cpu = oracle_lib.OracleRenderer(scene, prm, W, H)
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     t0 = time.perf_counter()
-    cpu.render_wave(0, 1, 0)
+    cpu.render_wave(0, 1, cores)
     cpu.post_process_wave()
     t1 = time.perf_counter() - t0
     waves = 1
@@ -57,7 +70,7 @@ def cpu_baseline(pkg, scene, prm, W, H, budget_s=15.0):
     if extra > 0:
         t0 = time.perf_counter()
         for w in range(1, 1 + extra):
-            cpu.render_wave(w, w + 1, 0)
+            cpu.render_wave(w, w + 1, cores)
             cpu.post_process_wave()
         t1 += time.perf_counter() - t0
         waves += extra
@@ -95,6 +108,10 @@ def main():
 
     pkg = load_package()
     pkg.load()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vspg_sharding", os.path.join(ROOT, "vspg-pbrt-v4_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
     W, H = args.xres, args.yres
     scene = pkg.fog_box_scene(W, H)
     prm = pkg.app_f_params()
@@ -106,7 +123,8 @@ def main():
 
     def step(i):
         # global waves [i*world, (i+1)*world): this rank runs exactly the one with w % world == rank
-        r.render_wave(i * world, (i + 1) * world, stream)
+        w0, w1 = sh.step_wave_range(i, world)
+        r.render_wave(w0, w1, stream)
         r.post_process_wave(stream)
 
     for i in range(args.warmup):
@@ -123,31 +141,23 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        r.render_wave((args.warmup + i) * world, (args.warmup + i + 1) * world, stream)
+        w0, w1 = sh.step_wave_range(args.warmup + i, world)
+        r.render_wave(w0, w1, stream)
         ev[i][1].record()
         r.post_process_wave(stream)
-    if world > 1:
-        dist.all_reduce(film, op=dist.ReduceOp.SUM)  # frame-end film all-reduce over RCCL / xGMI
+    sh.frame_end_allreduce(dist, film, world)  # frame-end film all-reduce over RCCL / xGMI
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sh.max_over_ranks(dist, elapsed, world, "cuda")
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     cnt = r.counters()
     paths_rank = cnt["paths"]
     segs_rank = cnt["segments"]
-    if world > 1:
-        t = torch.tensor([paths_rank, segs_rank], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        paths_total, segs_total = float(t[0].item()), float(t[1].item())
-    else:
-        paths_total, segs_total = float(paths_rank), float(segs_rank)
+    paths_total, segs_total = sh.sum_over_ranks(dist, [paths_rank, segs_rank], world, "cuda")
 
     if rank == 0:
         kbar = segs_rank / max(1, paths_rank)

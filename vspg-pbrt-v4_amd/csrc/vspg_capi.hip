@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_render_wave(const DScene *__restr
         if (has) {
             const bool alive = li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc);
             if (!alive) {
+                VSPG_PROF(PS_FINISH);
                 const Spec L = finish_radiance(st.L);
                 const size_t idx = (size_t)py * W + px;
                 // RGBFilm::AddSample (film.h:251-267): weight 1, imagingRatio 1, no clamp
@@ -728,5 +729,18 @@ int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, flo
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
+
+#ifdef VSPG_PROFILE
+// diagnostic build only: dump and clear the per-section counters
+int vspg_prof_read(unsigned long long *out /* PS_COUNT*3 */, int *n_sections) {
+    unsigned long long h[PS_COUNT][3];
+    HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof h));
+    memcpy(out, h, sizeof h);
+    memset(h, 0, sizeof h);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof h));
+    *n_sections = PS_COUNT;
+    return 0;
+}
+#endif
 
 }  // extern "C"

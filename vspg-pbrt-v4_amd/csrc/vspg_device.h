@@ -19,6 +19,33 @@
 namespace vspg {
 
 // ---------------------------------------------------------------------------------------
+// diagnostic build only (-DVSPG_PROFILE, csrc/Makefile target `prof`): per-section wave time,
+// active-lane count and execution count.  The shipped library contains none of this.
+// ---------------------------------------------------------------------------------------
+#ifdef VSPG_PROFILE
+enum { PS_INTERSECT = 0, PS_HASHRNG, PS_DIST_GUIDED, PS_DIST_PLAIN, PS_SURF_PRE, PS_NEE, PS_NEE_TR, PS_VOL_SAMPLE,
+       PS_SURF_SAMPLE, PS_FINISH, PS_START, PS_REFILL, PS_SEGMENT, PS_COUNT };
+__device__ unsigned long long g_prof[PS_COUNT][3];
+struct ProfScope {
+    int sec;
+    unsigned long long t0;
+    __device__ __forceinline__ ProfScope(int s) : sec(s) { t0 = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ ~ProfScope() {
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        unsigned long long m = __ballot(1);
+        if ((int)(threadIdx.x & 63) == (int)(__ffsll((long long)m) - 1)) {
+            atomicAdd(&g_prof[sec][0], t1 - t0);
+            atomicAdd(&g_prof[sec][1], (unsigned long long)__popcll(m));
+            atomicAdd(&g_prof[sec][2], 1ull);
+        }
+    }
+};
+#define VSPG_PROF(sec) ProfScope prof_scope_##sec(sec)
+#else
+#define VSPG_PROF(sec)
+#endif
+
+// ---------------------------------------------------------------------------------------
 // constants (src/pbrt/util/math.h:30-60, util/float.h:27)
 // ---------------------------------------------------------------------------------------
 constexpr float kPi = 3.14159265358979323846f;

@@ -179,6 +179,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
         // every surface here carries a material: any hit is an opaque blocker (:1197-1200)
         if (scene_intersect_any(S, lo, ld, 1 - kShadowEps)) return sp(0.f);
         if (S.medium_type != VSPG_MEDIUM_NONE) {
+            VSPG_PROF(PS_NEE_TR);
             float tMax = 1 - kShadowEps;
             float us = rng.uniform();
             Spec T_maj = sample_T_maj(medium, lo, ld, tMax, us, rng, ch,
@@ -351,6 +352,9 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
     }
 
     // the delta-tracking routine (:878-1094)
+#ifdef VSPG_PROFILE
+    ProfScope prof_dist(guide ? PS_DIST_GUIDED : PS_DIST_PLAIN);
+#endif
     Spec r_u_factor = sp(1.f);  // beta_factor is never written by the reference (always 1)
     float u = sampler.get1d();
     Spec T_maj = sample_T_maj_ods(
@@ -421,17 +425,25 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
 template <class Medium>
 VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
                      PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc) {
+    VSPG_PROF(PS_SEGMENT);
     pc.segments++;
-    Isect si = scene_intersect(S, st.ro, st.rd, kInf);
+    Isect si;
+    {
+        VSPG_PROF(PS_INTERSECT);
+        si = scene_intersect(S, st.ro, st.rd, kInf);
+    }
     float tMax = si.hit ? si.t : kInf;
     bool volume_vertex = false;
     V3 vp = mk(0, 0, 0);
     float vg = 0;
     if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
-        uint64_t hash0 = hash_float(sampler.get1d());
-        uint64_t hash1 = hash_float(sampler.get1d());
         Rng rng;
-        rng.set_sequence(hash0, hash1);
+        {
+            VSPG_PROF(PS_HASHRNG);
+            uint64_t hash0 = hash_float(sampler.get1d());
+            uint64_t hash1 = hash_float(sampler.get1d());
+            rng.set_sequence(hash0, hash1);
+        }
         DistEvent ev = sample_distance(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
         if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return false;  // :343-344
         if (ev.kind == EV_SCATTER) {
@@ -453,6 +465,7 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         intr.g = vg;
         bsdf.has_lobes = false;
     } else {
+        VSPG_PROF(PS_SURF_PRE);
         if (!si.hit) return false;  // no infinite lights in scope (:353-374)
         const DQuad &q = S.quads[si.quad];
         Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
@@ -486,11 +499,13 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
     }
     if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {  // :479 IsNonSpecular(bsdf.Flags()) / :833
+        VSPG_PROF(PS_NEE);
         Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc);
         st.L = st.L + st.beta * Ld;
     }
 
     if (volume_vertex) {
+        VSPG_PROF(PS_VOL_SAMPLE);
         if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {  // :842-849
             float q = fmax_(0.f, 1 - survivalProb);
             if (sampler.get1d() < q) return false;
@@ -513,6 +528,7 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         return true;
     }
 
+    VSPG_PROF(PS_SURF_SAMPLE);
     st.prevCtx.pi = intr.pi;  // :487
     st.prevCtx.n = si.n;
     V3 wo = -st.rd;

@@ -1,0 +1,106 @@
+// vspg_host.h -- C++ host adapter: the reference's Integrator / Medium plugin surface for the
+// GuidedVolPathVSPG path, implemented on top of the C-ABI (include/vspg.h).
+//
+// Mirrors (names, argument meaning, defaults, error behaviour):
+//   ParameterDictionary::GetOne*/ReportUnused     src/pbrt/paramdict.h, paramdict.cpp:642-664
+//   Integrator::Create(name, params, ...)          src/pbrt/cpu/integrators.cpp:3711-3768
+//   GuidedVolPathVSPGIntegrator::Create / Render / PostProcessWave / ToString
+//                                                  src/pbrt/cpu/guidedvolpathvspgintegrator.cpp:1260-1322, 230-260
+//   ImageTileIntegrator::Render wave loop          src/pbrt/cpu/integrators.cpp:75-269 (1-spp waves :239)
+//   HomogeneousMedium::Create / Medium::Create     src/pbrt/media.cpp:167-206, 816-841
+// The reference aborts the process on fatal errors (ErrorExit); this adapter throws
+// vspg::Error with the same trigger conditions so an embedding application can decide.
+#pragma once
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vspg.h"
+
+namespace vspg {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// A small typed parameter dictionary: the subset of pbrt's ParameterDictionary the path reads.
+class ParameterDictionary {
+  public:
+    ParameterDictionary &Int(const std::string &n, int v);
+    ParameterDictionary &Float(const std::string &n, float v);
+    ParameterDictionary &Bool(const std::string &n, bool v);
+    ParameterDictionary &String(const std::string &n, const std::string &v);
+    ParameterDictionary &RGB(const std::string &n, float r, float g, float b);
+
+    int GetOneInt(const std::string &n, int def) const;
+    float GetOneFloat(const std::string &n, float def) const;
+    bool GetOneBool(const std::string &n, bool def) const;
+    std::string GetOneString(const std::string &n, const std::string &def) const;
+    // returns false if absent
+    bool GetOneRGB(const std::string &n, float rgb[3]) const;
+    // paramdict.cpp:642-664: any parameter that was never looked up is a fatal error
+    void ReportUnused() const;
+
+  private:
+    struct Value {
+        char type;  // i f b s c
+        int i = 0;
+        float f[3] = {0, 0, 0};
+        std::string s;
+        mutable bool lookedUp = false;
+    };
+    const Value *find(const std::string &n, char type) const;
+    std::map<std::string, Value> values;
+};
+
+// Medium::Create("homogeneous", ...) (media.cpp:816-841; other names -> Error: outside scope)
+VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &parameters);
+
+struct Film {
+    int xres = 0, yres = 0;
+    std::vector<float> rgbw;  // W*H*4: sum w*r, sum w*g, sum w*b, sum w
+    // RGBFilm::GetPixelRGB (film.h:269-287) without the output colour transform
+    void GetPixelRGB(int x, int y, float rgb[3]) const;
+    void WritePFM(const std::string &filename) const;
+};
+
+class Integrator {
+  public:
+    virtual ~Integrator() = default;
+    virtual void Render() = 0;
+    virtual std::string ToString() const = 0;
+    // Integrator::Create: "guidedvolpathvspg"; "guidedvolpath" is accepted as an alias ONLY when
+    // the dictionary carries "vspguiding" (the option BASELINE.json names), see SURVEY.md 0.1
+    static std::unique_ptr<Integrator> Create(const std::string &name, const ParameterDictionary &parameters,
+                                              const VspgScene &scene, int xres, int yres, int pixelSamples,
+                                              int seed = 0, int device = 0);
+};
+
+class GuidedVolPathVSPGIntegrator : public Integrator {
+  public:
+    static std::unique_ptr<GuidedVolPathVSPGIntegrator> Create(const ParameterDictionary &parameters,
+                                                               const VspgScene &scene, int xres, int yres,
+                                                               int pixelSamples, int seed, int device);
+    GuidedVolPathVSPGIntegrator(const VspgIntegratorParams &p, const VspgScene &scene, int xres, int yres,
+                                int pixelSamples, int seed, int device);
+    ~GuidedVolPathVSPGIntegrator() override;
+    void Render() override;       // wave loop: 1 spp per wave, PostProcessWave after each
+    void PostProcessWave();       // guidedvolpathvspgintegrator.cpp:230-260
+    std::string ToString() const override;
+    Film GetFilm();
+    VspgCounters Counters();
+    const VspgIntegratorParams &Params() const { return params; }
+
+  private:
+    VspgIntegratorParams params;
+    VspgRenderConfig cfg;
+    VspgRenderer *renderer = nullptr;
+    int spp;
+};
+
+// parameter parsing only (no device): used by Create and by the CPU self test
+VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters);
+
+}  // namespace vspg
