@@ -21,7 +21,8 @@ using namespace vspg;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kBlocksPerCU = 8;  // persistent blocks per CU (upper bound on residency; extra blocks just queue)
+constexpr int kBlocksPerCU = 2;  // persistent blocks per CU = resident blocks at 2 waves/SIMD (256 VGPRs)
+constexpr int kChunk = 64;        // dynamic work items a wavefront claims per atomic (one 8x8 pixel tile)
 constexpr int kNumCounters = 6;  // paths, segments, volume_scatters, surface_hits, density_queries, shadow_rays
 
 __device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t paths, unsigned long long *g) {
@@ -53,8 +54,13 @@ template <class Medium>
 __global__ __launch_bounds__(kBlock, 2) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
                                                         float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
                                                         int vsp_ready, int wave_start, int wave_end,
+                                                        int first_sample, int single_sample, PcgJump jump,
+                                                        unsigned static_per_wave, unsigned dyn_base,
                                                         unsigned int *__restrict__ work_head,
                                                         unsigned long long *__restrict__ counters) {
+    // first_sample: first sample index of this shard in [wave_start, wave_end); single_sample: the
+    // launch covers exactly one sample per pixel (the reference's 1-spp waves) and `jump` is the
+    // PCG skip-ahead for first_sample*65536
     const DScene &S = *Sp;
     const int W = S.xres, H = S.yres;
     const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
@@ -65,42 +71,54 @@ __global__ __launch_bounds__(kBlock, 2) void k_render_wave(const DScene *__restr
     uint32_t paths = 0;
 
     bool has = false;        // this lane carries a live path
-    bool exhausted = false;  // wave-uniform: the work head ran past the last item
+    bool exhausted = false;  // wave-uniform: the global work head ran past the last item
+    // wave-local slice [local_next, local_end) of the item space.  Every wavefront starts with a
+    // STATIC slice (static_per_wave items, ~3/4 of its fair share, no atomics at all); the remaining
+    // items [dyn_base, total) are handed out dynamically in chunks of kChunk through one returning
+    // atomic per chunk, which evens out the tail.  (One atomic per refill on a single hot counter
+    // saturates at ~10^2 dequeues/us on this chip and capped the kernel at the atomic rate.)
+    const unsigned wave_id = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    unsigned local_next = wave_id * static_per_wave, local_end = local_next + static_per_wave;
     int px = 0, py = 0, s = 0, ch = 0;
     Sampler sampler;
     PathState st;
     IsgSample isg;
 
     while (true) {
-        // ---- regeneration: ballot the empty lanes, one atomic per wavefront -------------------
+        // ---- regeneration: ballot the empty lanes, prefix-count them, hand out items -----------
         unsigned long long need = __ballot(!has);
-        if (need != 0ull && !exhausted) {
-            const int cnt = __popcll(need);
-            unsigned base = 0;
-            if (lane == (int)(__ffsll((long long)need) - 1)) base = atomicAdd(work_head, (unsigned)cnt);
-            base = __shfl(base, (int)(__ffsll((long long)need) - 1));
+        if (need != 0ull && !(exhausted && local_next >= local_end)) {
+            if (local_next >= local_end && !exhausted) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(work_head, (unsigned)kChunk);
+                base = __builtin_amdgcn_readfirstlane(base) + dyn_base;
+                local_next = base;
+                local_end = base + (unsigned)kChunk < total_items ? base + (unsigned)kChunk : total_items;
+                if (base + (unsigned)kChunk >= total_items) exhausted = true;
+                if (base >= total_items) local_next = local_end = 0;
+            }
             const unsigned rank = (unsigned)__popcll(need & ((1ull << lane) - 1ull));
-            if (!has) {
-                const unsigned item = base + rank;
-                if (item < total_items) {
-                    const unsigned tile = item >> 6, l = item & 63u;
-                    px = (int)(tile % (unsigned)tilesX) * 8 + (int)(l & 7u);
-                    py = (int)(tile / (unsigned)tilesX) * 8 + (int)(l >> 3);
-                    s = wave_start;
-                    if (S.shard_count > 1) {  // first sample index of this shard in the range
-                        int r = s % S.shard_count;
-                        s += (S.shard_index - r + S.shard_count) % S.shard_count;
-                    }
-                    if (px < W && py < H && s < wave_end) {
+            const unsigned avail = local_end - local_next;  // lanes beyond `avail` wait for the next chunk
+            if (!has && rank < avail) {
+                VSPG_PROF(PS_START);
+                const unsigned item = local_next + rank;
+                const unsigned tile = item >> 6, l = item & 63u;
+                px = (int)(tile % (unsigned)tilesX) * 8 + (int)(l & 7u);
+                py = (int)(tile / (unsigned)tilesX) * 8 + (int)(l >> 3);
+                s = first_sample;
+                if (px < W && py < H && s < wave_end) {
+                    if (single_sample)
+                        start_path(S, px, py, jump, sampler, st, &ch, isg);
+                    else
                         start_path(S, px, py, s, sampler, st, &ch, isg);
-                        has = true;
-                    }
+                    has = true;
                 }
             }
-            if (base + (unsigned)cnt >= total_items) exhausted = true;
+            const unsigned cnt = (unsigned)__popcll(need);
+            local_next += cnt < avail ? cnt : avail;
         }
         if (__ballot(has) == 0ull) {
-            if (exhausted) break;
+            if (exhausted && local_next >= local_end) break;
             continue;
         }
         // ---- one path segment for every live lane ----------------------------------------------
@@ -312,6 +330,21 @@ static float len2v(H3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
 static H3 normv(H3 a) { float l = std::sqrt(len2v(a)); return H3{a.x / l, a.y / l, a.z / l}; }
 }  // namespace hostmath
 
+// (accMult, G) of RNG::Advance(delta) (src/pbrt/util/rng.h:137-150), see PcgJump
+static PcgJump pcg_jump(unsigned long long delta) {
+    unsigned long long curMult = 0x5851f42d4c957f2dULL, curPlus = 1u, accMult = 1u, accPlus = 0u;
+    while (delta > 0) {
+        if (delta & 1) {
+            accMult *= curMult;
+            accPlus = accPlus * curMult + curPlus;
+        }
+        curPlus = (curMult + 1) * curPlus;
+        curMult *= curMult;
+        delta /= 2;
+    }
+    return PcgJump{accMult, accPlus};
+}
+
 static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, const VspgRenderConfig &cfg, DScene *D) {
     using namespace hostmath;
     memset(D, 0, sizeof *D);
@@ -346,6 +379,19 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
         q.two_sided = in.two_sided;
         q.is_light = light;
         q.has_lobes = lobes;
+        // axis-aligned fast path: n, e1, e2 each have exactly one non-zero component
+        auto single_axis = [](const float *v) {
+            int nz = 0, ax = -1;
+            for (int k = 0; k < 3; ++k)
+                if (v[k] != 0) { nz++; ax = k; }
+            return nz == 1 ? ax : -1;
+        };
+        int an = single_axis(q.n), a1 = single_axis(q.e1), a2 = single_axis(q.e2);
+        q.axis = -1;
+        if (an >= 0 && a1 >= 0 && a2 >= 0 && an != a1 && an != a2 && a1 != a2 && std::fabs(q.n[an]) == 1.0f) {
+            q.axis = an; q.uaxis = a1; q.vaxis = a2;
+            q.nsign = q.n[an]; q.l1 = q.e1[a1]; q.l2 = q.e2[a2];
+        }
         if (light) D->light_quads[D->n_lights++] = i;
     }
     D->cam = sc.camera;
@@ -547,13 +593,25 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     HIPCHK(hipSetDevice(r->cfg.device));
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
     const long long items = (long long)tilesX * tilesY * 64;
-    // persistent grid: enough resident wavefronts to fill the chip, never more blocks than work
+    // persistent grid: exactly the resident wavefronts (never more blocks than tiles of work)
     long long blocks = (long long)r->num_cus * kBlocksPerCU;
     const long long max_blocks = (items + kBlock - 1) / kBlock;
     if (blocks > max_blocks) blocks = max_blocks;
+    const long long n_waves = blocks * (kBlock / 64);
+    // static slice per wavefront: 3/4 of the fair share, whole tiles
+    const unsigned static_per_wave = (unsigned)((items * 3 / 4 / n_waves) / 64 * 64);
+    const unsigned dyn_base = (unsigned)(static_per_wave * n_waves);
+    // first sample index of this shard in the range, and how many it has
+    const int sc = r->cfg.shard_count, si = r->cfg.shard_index;
+    int first = wave_start;
+    if (sc > 1) first += ((si - wave_start % sc) % sc + sc) % sc;
+    if (first >= wave_end) return 0;  // nothing for this shard in the range
+    const int n_samples = (wave_end - 1 - first) / sc + 1;
+    const PcgJump jump = pcg_jump((unsigned long long)first * 65536ull);
     HIPCHK(hipMemsetAsync(r->work_head, 0, sizeof(unsigned int), (hipStream_t)stream));
     hipLaunchKernelGGL(k_render_wave<HomogeneousMedium>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,
-                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, r->work_head, r->counters);
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first, n_samples == 1 ? 1 : 0, jump,
+                       static_per_wave, dyn_base, r->work_head, r->counters);
     HIPCHK(hipGetLastError());
     return 0;
 }

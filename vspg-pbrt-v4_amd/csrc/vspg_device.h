@@ -110,9 +110,27 @@ VDEV float ch_of(Spec s, int ch) { return ch == 0 ? s.r : (ch == 1 ? s.g : s.b);
 VDEV Spec operator+(Spec a, Spec b) { return Spec{a.r + b.r, a.g + b.g, a.b + b.b}; }
 VDEV Spec operator-(Spec a, Spec b) { return Spec{a.r - b.r, a.g - b.g, a.b - b.b}; }
 VDEV Spec operator*(Spec a, Spec b) { return Spec{a.r * b.r, a.g * b.g, a.b * b.b}; }
-VDEV Spec operator/(Spec a, Spec b) { return Spec{a.r / b.r, a.g / b.g, a.b / b.b}; }
+// IEEE division is a ~10-instruction sequence on gfx950 and the path divides spectra all the time.
+// When every lane of the wavefront holds a GREY spectrum (r == g == b bitwise-equal values, the
+// usual case for fog / white walls: beta, r_u, r_l, T_maj, sigma_*), one channel is computed and
+// copied: identical results, a third of the work.  The test is wave-uniform (__all), so it is a
+// scalar branch, never divergence.
+VDEV bool grey(Spec a) { return a.r == a.g && a.g == a.b; }
+VDEV Spec operator/(Spec a, Spec b) {
+    if (__all(grey(a) && grey(b))) {
+        float q = a.r / b.r;
+        return Spec{q, q, q};
+    }
+    return Spec{a.r / b.r, a.g / b.g, a.b / b.b};
+}
 VDEV Spec operator*(Spec a, float f) { return Spec{a.r * f, a.g * f, a.b * f}; }
-VDEV Spec operator/(Spec a, float f) { return Spec{a.r / f, a.g / f, a.b / f}; }
+VDEV Spec operator/(Spec a, float f) {
+    if (__all(grey(a))) {
+        float q = a.r / f;
+        return Spec{q, q, q};
+    }
+    return Spec{a.r / f, a.g / f, a.b / f};
+}
 VDEV bool nonzero(Spec a) { return a.r != 0 || a.g != 0 || a.b != 0; }  // spectrum.h:263-268
 VDEV float avg(Spec a) {  // spectrum.h:288-294
     float s = a.r;
@@ -226,12 +244,24 @@ struct Rng {
     }
 };
 
+// RNG::Advance(delta) maps state -> accMult*state + accPlus, and accPlus is linear in `inc`
+// (every curPlus in rng.h:137-150 is a multiple of inc), so accPlus == inc * G(delta) mod 2^64 with
+// G(delta) the same recurrence started from curPlus = 1.  (accMult, G) depend on delta only: the
+// host computes them once per launch and every lane applies them with two 64-bit multiplies instead
+// of running the ~24-iteration skip-ahead loop per path.  Exact (integer arithmetic mod 2^64).
+struct PcgJump {
+    uint64_t mult, g;
+};
 // IndependentSampler (src/pbrt/samplers.h:442-476)
 struct Sampler {
     Rng rng;
     VDEV void start_pixel_sample(int px, int py, int seed, int sampleIndex) {
         rng.set_sequence(hash_3u32((uint32_t)px, (uint32_t)py, (uint32_t)seed));
         rng.advance((uint64_t)sampleIndex * 65536ull);
+    }
+    VDEV void start_pixel_sample(int px, int py, int seed, PcgJump j) {  // j = jump for sampleIndex*65536
+        rng.set_sequence(hash_3u32((uint32_t)px, (uint32_t)py, (uint32_t)seed));
+        rng.state = j.mult * rng.state + rng.inc * j.g;
     }
     VDEV float get1d() { return rng.uniform(); }
 };
@@ -261,7 +291,13 @@ VDEV float fast_exp(float x) {  // util/math.h:450-474 (CPU branch; NOT __expf)
     bits |= (uint32_t)(exponent + 127) << 23;
     return b2f(bits);
 }
-VDEV Spec fast_exp(Spec a) { return Spec{fast_exp(a.r), fast_exp(a.g), fast_exp(a.b)}; }
+VDEV Spec fast_exp(Spec a) {
+    if (__all(grey(a))) {  // wave-uniform grey fast path, see operator/
+        float e = fast_exp(a.r);
+        return Spec{e, e, e};
+    }
+    return Spec{fast_exp(a.r), fast_exp(a.g), fast_exp(a.b)};
+}
 VDEV float sample_exponential(float u, float a) { return -logf_(1 - u) / a; }  // sampling.h:222
 VDEV int sample_discrete2(float w0, float w1, float u) {  // sampling.h:79-113, two weights
     float sumWeights = 0;
@@ -295,44 +331,60 @@ struct Frame {
     VDEV V3 from_local(V3 v) const { return v.x * x + v.y * y + v.z * z; }  // vecmath.h:1914
     VDEV V3 to_local(V3 v) const { return V3{dot(v, x), dot(v, y), dot(v, z)}; }
 };
-VDEV V3 sample_henyey_greenstein(V3 wo, float g, float u0, float u1, float *pdf) {  // sampling.cpp:348-374
+// SampleHenyeyGreenstein (sampling.cpp:348-374) split around its sin/cos so that the kernel can
+// evaluate sinf/cosf once for phase-function and BSDF lanes together (same operations, same order
+// per lane): hg_pre returns phi, hg_post finishes with sin(phi), cos(phi).
+VDEV float hg_pre(float g, float u0, float u1, float *sinTheta, float *cosTheta) {
     g = clampf(g, (float)-.99, (float).99);
-    float cosTheta;
+    float ct;
     if (__builtin_fabsf(g) < 1e-3f)
-        cosTheta = 1 - 2 * u0;
+        ct = 1 - 2 * u0;
     else
-        cosTheta = -1 / (2 * g) * (1 + sqr(g) - sqr((1 - sqr(g)) / (1 + g - 2 * g * u0)));
-    float sinTheta = safe_sqrt(1 - sqr(cosTheta));
-    float phi = 2 * kPi * u1;
+        ct = -1 / (2 * g) * (1 + sqr(g) - sqr((1 - sqr(g)) / (1 + g - 2 * g * u0)));
+    *cosTheta = ct;
+    *sinTheta = safe_sqrt(1 - sqr(ct));
+    return 2 * kPi * u1;
+}
+VDEV V3 hg_post(V3 wo, float g, float sinTheta, float cosTheta, float sinPhi, float cosPhi, float *pdf) {
+    g = clampf(g, (float)-.99, (float).99);
     Frame f;
     f.z = wo;
     coordinate_system(wo, &f.x, &f.y);
-    float sp_ = sinf_(phi), cp_ = cosf_(phi);
     // SphericalDirection (vecmath.h:1666-1672)
-    V3 local = V3{clampf(sinTheta, -1, 1) * cp_, clampf(sinTheta, -1, 1) * sp_, clampf(cosTheta, -1, 1)};
+    V3 local = V3{clampf(sinTheta, -1, 1) * cosPhi, clampf(sinTheta, -1, 1) * sinPhi, clampf(cosTheta, -1, 1)};
     *pdf = henyey_greenstein(cosTheta, g);
     return f.from_local(local);
 }
-VDEV V3 sample_cosine_hemisphere(float u0, float u1) {  // sampling.h:325-341, 409-413
+VDEV V3 sample_henyey_greenstein(V3 wo, float g, float u0, float u1, float *pdf) {
+    float st, ct;
+    float phi = hg_pre(g, u0, u1, &st, &ct);
+    return hg_post(wo, g, st, ct, sinf_(phi), cosf_(phi), pdf);
+}
+// SampleCosineHemisphere / SampleUniformDiskConcentric (sampling.h:325-341, 409-413), split the same way
+VDEV float cos_hemi_pre(float u0, float u1, float *r, bool *degenerate) {
     float ox = 2 * u0 - 1, oy = 2 * u1 - 1;
-    float dx, dy;
-    if (ox == 0 && oy == 0) {
-        dx = 0;
-        dy = 0;
+    *degenerate = (ox == 0 && oy == 0);
+    float theta;
+    if (__builtin_fabsf(ox) > __builtin_fabsf(oy)) {
+        *r = ox;
+        theta = kPiOver4 * (oy / ox);
     } else {
-        float theta, r;
-        if (__builtin_fabsf(ox) > __builtin_fabsf(oy)) {
-            r = ox;
-            theta = kPiOver4 * (oy / ox);
-        } else {
-            r = oy;
-            theta = kPiOver2 - kPiOver4 * (ox / oy);
-        }
-        dx = r * cosf_(theta);
-        dy = r * sinf_(theta);
+        *r = oy;
+        theta = kPiOver2 - kPiOver4 * (ox / oy);
     }
+    return theta;
+}
+VDEV V3 cos_hemi_post(float r, bool degenerate, float sinT, float cosT) {
+    float dx = degenerate ? 0.f : r * cosT;
+    float dy = degenerate ? 0.f : r * sinT;
     float z = safe_sqrt(1 - sqr(dx) - sqr(dy));
     return V3{dx, dy, z};
+}
+VDEV V3 sample_cosine_hemisphere(float u0, float u1) {
+    float r;
+    bool deg;
+    float theta = cos_hemi_pre(u0, u1, &r, &deg);
+    return cos_hemi_post(r, deg, sinf_(theta), cosf_(theta));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -380,7 +432,13 @@ struct DQuad {
     float n[3], dpdu_n[3], perr[3];
     float inv_l1, inv_l2, area;
     float Kd[3], Le[3];
-    int32_t two_sided, is_light, has_lobes, pad;
+    int32_t two_sided, is_light, has_lobes;
+    // axis-aligned rectangles (n = +-unit axis `axis`, e1 and e2 each along one other axis): the
+    // generic dot products reduce to single products because every other term is an exact zero;
+    // axis = -1 selects the generic code.  uaxis / vaxis: axes of e1 / e2; nsign, l1, l2: the only
+    // non-zero components of n, e1, e2.
+    int32_t axis, uaxis, vaxis;
+    float nsign, l1, l2;
 };
 struct DScene {
     int32_t n_quads, n_lights;
@@ -408,7 +466,28 @@ struct Isect {
 // is re-projected onto the rectangle, p00 + (u*e1 + v*e2).
 // The sign pre-test only skips work whose outcome is already decided: t = num/denom can be > 0
 // only when num and denom are non-zero with equal signs.
+VDEV float comp(V3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }  // axis is wave-uniform
 VDEV bool quad_hit_uv(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, float *uHit, float *vHit) {
+    if (q.axis >= 0) {
+        // axis-aligned rectangle: n.d == nsign*d[a] and n.(p00-o) == nsign*(p00[a]-o[a]) exactly (the other
+        // products are +-0), so t == (p00[a]-o[a])/d[a] exactly; likewise (p-p00).e1 == rel[uaxis]*l1.
+        const int a = q.axis;
+        float denom = q.nsign * comp(d, a);
+        float num = q.nsign * (q.p00[a] - comp(o, a));
+        bool cand = (num > 0 && denom > 0) || (num < 0 && denom < 0);
+        if (!cand) return false;
+        float t = num / denom;
+        if (!(t > 0) || !(t < tMax)) return false;
+        const int ua = q.uaxis, va = q.vaxis;
+        float pu = comp(o, ua) + comp(d, ua) * t, pv = comp(o, va) + comp(d, va) * t;
+        float u = ((pu - q.p00[ua]) * q.l1) * q.inv_l1;
+        float v = ((pv - q.p00[va]) * q.l2) * q.inv_l2;
+        if (u < 0 || u > 1 || v < 0 || v > 1) return false;
+        *tHit = t;
+        *uHit = u;
+        *vHit = v;
+        return true;
+    }
     V3 n = ld3(q.n), p00 = ld3(q.p00);
     float denom = dot(n, d);
     float num = dot(n, p00 - o);
@@ -617,7 +696,7 @@ VDEV Spec sample_T_maj_resampling(const Medium &medium, V3 ro, V3 rd, float tMax
 // a8: SampleT_maj_OpticalDepthSpace (media_sampleTMaj.h:269-491)
 // ---------------------------------------------------------------------------------------
 VDEV Spec ruf_from(float alpha, Spec tp) {  // SampledSpectrum(a)/tp + SampledSpectrum(1-a)
-    return Spec{alpha / tp.r + (1 - alpha), alpha / tp.g + (1 - alpha), alpha / tp.b + (1 - alpha)};
+    return sp(alpha) / tp + sp(1 - alpha);
 }
 template <class Medium, class F>
 VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float u, Rng &rng, int ch,
@@ -702,18 +781,15 @@ VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float
             count++;
             float dist = kFltMax;
             Spec tpStep;
-            if (NDS) {
-                tpStep = Spec{1.0f - fast_exp(-t_n_current * nMaj.r), 1.0f - fast_exp(-t_n_current * nMaj.g),
-                              1.0f - fast_exp(-t_n_current * nMaj.b)};
-                if (!deltaTracking) dist = neg_log1m_d(u * ch_of(tpStep, ch));
-            } else {
-                tpStep = Spec{(1.0f - fast_exp(-t_v_current * nMaj.r)) / vsp, (1.0f - fast_exp(-t_v_current * nMaj.g)) / vsp,
-                              (1.0f - fast_exp(-t_v_current * nMaj.b)) / vsp};
-                if (!deltaTracking) {
-                    if (u < vsp) dist = neg_log1m_d(u * ch_of(tpStep, ch));
-                }
-            }
-            if (deltaTracking) dist = neg_log1m_d(u);
+            // (1 - FastExp(-t * normalizedMaj)) [/ vsp]: Float * SampledSpectrum products, then the
+            // grey-aware fast_exp / division
+            if (NDS)
+                tpStep = sp(1.0f) - fast_exp(nMaj * -t_n_current);
+            else
+                tpStep = (sp(1.0f) - fast_exp(nMaj * -t_v_current)) / vsp;
+            // one -std::log(1.0 - x) per step: x = u (delta tracking) or u * tpStep[ch] (guided)
+            bool want_log = deltaTracking || NDS || u < vsp;
+            if (want_log) dist = neg_log1m_d(deltaTracking ? u : u * ch_of(tpStep, ch));
 
             bool passThrough = (t_v_current - dist < ScatterEpsilon) || dist == 0;
             if (NDS || !passThrough) tpScale = tpScale * tpStep;
@@ -721,9 +797,7 @@ VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float
                 if (NDS) {
                     tpScale = tpScale / (1.0f - fast_exp(-t_n + t_v));
                 } else {
-                    Spec e = Spec{fast_exp(-t_v_current * nMaj.r) / (1 - vsp), fast_exp(-t_v_current * nMaj.g) / (1 - vsp),
-                                  fast_exp(-t_v_current * nMaj.b) / (1 - vsp)};
-                    tpScale = tpScale * e;
+                    tpScale = tpScale * (fast_exp(nMaj * -t_v_current) / (1 - vsp));
                 }
                 *r_u_factor = ruf_from(alpha, tpScale);
                 overTheEnd = true;

@@ -14,16 +14,26 @@
 // libm on >10^7 arguments; tests/test_gpu_parity.py checks the device build the same way.
 //
 // Scope: the argument ranges the path produces (logf: positive normal floats; sinf/cosf:
-// |x| < 120).  Outside them the functions fall back to a double evaluation rounded once.
+// |x| < 120).  Outside them the host build falls back to a double evaluation rounded once; the
+// DEVICE build returns NaN (the path cannot produce such arguments, and the fallbacks would pull
+// ocml's Payne-Hanek double sin/cos and double log into every call site: ~10x the code size
+// and register pressure of the functions themselves).
 #pragma once
 #include <stdint.h>
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define VSPG_HD __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VSPG_LIBM_OUT_OF_SCOPE(expr) __builtin_nanf("")
+#endif
 #else
 #include <math.h>
 #include <string.h>
 #define VSPG_HD static inline
+#endif
+
+#ifndef VSPG_LIBM_OUT_OF_SCOPE
+#define VSPG_LIBM_OUT_OF_SCOPE(expr) (expr)
 #endif
 
 namespace vspg_libm {
@@ -62,7 +72,7 @@ VSPG_HD float logf_host_exact(float x) {
     const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
     uint32_t ix = asuint(x);
     if (ix == 0x3f800000u) return 0.f;
-    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return (float)log((double)x);  // out of scope: subnormal, <=0, inf, nan
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return VSPG_LIBM_OUT_OF_SCOPE((float)log((double)x));  // subnormal, <=0, inf, nan
     uint32_t tmp = ix - 0x3f330000u;
     int i = (int)((tmp >> 19) & 15u);
     int k = (int32_t)tmp >> 23;
@@ -126,7 +136,7 @@ VSPG_HD float sinf_host_exact(float y) {
         double s = sincosf_sign(n & 3);
         return sincosf_poly(x * s, x * x, (n & 2) != 0, n);
     }
-    return (float)sin((double)y);  // out of scope (|y| >= 120, inf, nan)
+    return VSPG_LIBM_OUT_OF_SCOPE((float)sin((double)y));  // |y| >= 120, inf, nan
 }
 VSPG_HD float cosf_host_exact(float y) {
     double x = (double)y;
@@ -141,7 +151,7 @@ VSPG_HD float cosf_host_exact(float y) {
         double s = sincosf_sign(n & 3);
         return sincosf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
     }
-    return (float)cos((double)y);
+    return VSPG_LIBM_OUT_OF_SCOPE((float)cos((double)y));
 }
 
 }  // namespace vspg_libm

@@ -504,6 +504,12 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         st.L = st.L + st.beta * Ld;
     }
 
+    // ---- new direction.  Phase-function lanes (HG, :842-874) and BSDF lanes (cosine hemisphere,
+    // :487-519) both need sinf/cosf of one angle: each side prepares its angle, the sin/cos are
+    // evaluated once for all lanes, each side finishes.  Per lane the operations and the sampler
+    // order are the reference's.
+    float ang = 0, a0 = 0, a1 = 0;
+    bool degenerate = false;
     if (volume_vertex) {
         VSPG_PROF(PS_VOL_SAMPLE);
         if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {  // :842-849
@@ -512,8 +518,24 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
             st.beta = st.beta / (1 - q);
         }
         float u0 = sampler.get1d(), u1 = sampler.get1d();
+        ang = hg_pre(vg, u0, u1, &a0, &a1);  // a0 = sinTheta, a1 = cosTheta
+    } else {
+        VSPG_PROF(PS_SURF_SAMPLE);
+        st.prevCtx.pi = intr.pi;  // :487
+        st.prevCtx.n = si.n;
+        (void)sampler.get1d();  // u (unused by DiffuseBxDF)
+        float u20 = sampler.get1d(), u21 = sampler.get1d();
+        // BSDF::Sample_f / DiffuseBxDF::Sample_f (bsdf.h:58-78, bxdfs.h:47-58)
+        a1 = bsdf.frame.to_local(-st.rd).z;  // wo.z in the shading frame
+        if (a1 == 0 || !bsdf.has_lobes) return false;
+        ang = cos_hemi_pre(u20, u21, &a0, &degenerate);  // a0 = r
+    }
+    const float sinA = sinf_(ang), cosA = cosf_(ang);
+
+    if (volume_vertex) {
+        VSPG_PROF(PS_VOL_SAMPLE);
         float pdf;
-        V3 wi = sample_henyey_greenstein(-st.rd, vg, u0, u1, &pdf);  // gphase.Sample_p(-ray.d, u)
+        V3 wi = hg_post(-st.rd, vg, a0, a1, sinA, cosA, &pdf);  // gphase.Sample_p(-ray.d, u)
         if (pdf == 0) return false;
         float w = pdf / pdf;  // ps->p / ps->pdf
         st.beta = st.beta * w;
@@ -529,15 +551,12 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
     }
 
     VSPG_PROF(PS_SURF_SAMPLE);
-    st.prevCtx.pi = intr.pi;  // :487
-    st.prevCtx.n = si.n;
-    V3 wo = -st.rd;
-    (void)sampler.get1d();  // u (unused by DiffuseBxDF)
-    float u20 = sampler.get1d(), u21 = sampler.get1d();
-    Spec f;
-    V3 wi;
-    float pdf;
-    if (!bsdf_sample_f(bsdf, wo, u20, u21, &f, &wi, &pdf)) return false;
+    V3 wl = cos_hemi_post(a0, degenerate, sinA, cosA);
+    if (a1 < 0) wl.z *= -1;
+    float pdf = __builtin_fabsf(wl.z) * kInvPi;
+    Spec f = bsdf.R * kInvPi;
+    if (!nonzero(f) || pdf == 0 || wl.z == 0) return false;
+    V3 wi = bsdf.frame.from_local(wl);
     st.lastVertexVolume = false;
     st.rr_correction *= pdf / pdf;  // bs->pdf / bs->bsdfPdf
     Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
@@ -562,9 +581,18 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
 }
 
 // EvaluatePixelSample up to the camera ray (src/pbrt/cpu/integrators.cpp:272-304)
+VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, PathState &st, int *ch, IsgSample &isg);
 VDEV void start_path(const DScene &S, int px, int py, int sampleIndex, Sampler &sampler, PathState &st, int *ch,
                      IsgSample &isg) {
     sampler.start_pixel_sample(px, py, S.seed, sampleIndex);
+    start_path_common(S, px, py, sampler, st, ch, isg);
+}
+VDEV void start_path(const DScene &S, int px, int py, PcgJump jump, Sampler &sampler, PathState &st, int *ch,
+                     IsgSample &isg) {
+    sampler.start_pixel_sample(px, py, S.seed, jump);
+    start_path_common(S, px, py, sampler, st, ch, isg);
+}
+VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, PathState &st, int *ch, IsgSample &isg) {
     float lu = sampler.get1d();
     int c = (int)__builtin_floorf(lu * 3);  // SampledWavelengths::SampleVisible (spectrum.h:380-384)
     *ch = c > 2 ? 2 : c;
