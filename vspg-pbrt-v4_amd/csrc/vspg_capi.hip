@@ -21,7 +21,11 @@ using namespace vspg;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kBlocksPerCU = 2;  // persistent blocks per CU = resident blocks at 2 waves/SIMD (256 VGPRs)
+#ifndef VSPG_WAVES_PER_SIMD
+#define VSPG_WAVES_PER_SIMD 2
+#endif
+constexpr int kWavesPerSimd = VSPG_WAVES_PER_SIMD;  // register budget of k_render_wave: 512 / kWavesPerSimd VGPRs
+constexpr int kBlocksPerCU = kWavesPerSimd;         // persistent 256-thread blocks per CU == resident blocks
 constexpr int kChunk = 64;        // dynamic work items a wavefront claims per atomic (one 8x8 pixel tile)
 constexpr int kNumCounters = 6;  // paths, segments, volume_scatters, surface_hits, density_queries, shadow_rays
 
@@ -51,7 +55,7 @@ __device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t 
 //   items are tile-ordered (8x8 pixels per 64 items) so a fresh wavefront starts on one coherent
 //   tile of primary rays.
 template <class Medium>
-__global__ __launch_bounds__(kBlock, 2) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
                                                         float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
                                                         int vsp_ready, int wave_start, int wave_end,
                                                         int first_sample, int single_sample, PcgJump jump,

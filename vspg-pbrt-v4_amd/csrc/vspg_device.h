@@ -15,6 +15,15 @@
 #include "vspg_libm.h"
 
 #define VDEV __device__ __forceinline__
+// leaf functions with small interfaces.  Measured on MI355X (round 1): as real calls
+// (-DVSPG_NOINLINE_LEAVES) k_render_wave drops from 248 to 220 VGPRs but runs 8 % slower at the same
+// 2 waves/SIMD, and the 168-VGPR build (3 waves/SIMD) still spills 101 registers and is 17 % slower,
+// so they are inlined.
+#ifdef VSPG_NOINLINE_LEAVES
+#define VLEAF __device__ __attribute__((noinline))
+#else
+#define VLEAF __device__ __forceinline__
+#endif
 
 namespace vspg {
 
@@ -270,10 +279,10 @@ struct Sampler {
 // libm: float functions reproduce the host glibc bit for bit (vspg_libm.h); the reference's
 // `std::log(1.0 - x)` in media_sampleTMaj.h is DOUBLE precision -> ocml double log, rounded once
 // ---------------------------------------------------------------------------------------
-VDEV float logf_(float x) { return vspg_libm::logf_host_exact(x); }
-VDEV float sinf_(float x) { return vspg_libm::sinf_host_exact(x); }
-VDEV float cosf_(float x) { return vspg_libm::cosf_host_exact(x); }
-VDEV float neg_log1m_d(float x) { return (float)(-log(1.0 - (double)x)); }  // -std::log(1.0 - x)
+VLEAF float logf_(float x) { return vspg_libm::logf_host_exact(x); }
+VLEAF float sinf_(float x) { return vspg_libm::sinf_host_exact(x); }
+VLEAF float cosf_(float x) { return vspg_libm::cosf_host_exact(x); }
+VLEAF float neg_log1m_d(float x) { return (float)(-log(1.0 - (double)x)); }  // -std::log(1.0 - x)
 
 // ---------------------------------------------------------------------------------------
 // a3: FastExp / SampleExponential / SampleDiscrete
@@ -512,7 +521,7 @@ VDEV bool quad_intersect(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, V3
     *pHit = quad_point(q, u, v);
     return true;
 }
-VDEV Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
+VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     Isect best;
     best.hit = false;
     best.t = tMax;
@@ -533,7 +542,7 @@ VDEV Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     best.n = ld3(q.n);
     return best;
 }
-VDEV bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
+VLEAF bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
     bool any = false;
     for (int i = 0; i < S.n_quads; ++i) {
         float t, u, v;
