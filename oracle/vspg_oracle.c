@@ -474,6 +474,9 @@ struct OracleRenderer {
     rquad_t quads[VSPG_MAX_QUADS];
     int n_lights;
     int light_quads[VSPG_MAX_QUADS];
+    /* GridMedium: density samples (copied) and the 16^3 majorant grid (media.cpp:252-269) */
+    float *density;
+    float *majorant;
     /* film: RGBFilm::Pixel (film.h:314-318) */
     double *film; /* W*H*4 */
     /* image-space VSP buffer (own design; OpenPGL absent) */
@@ -533,7 +536,15 @@ typedef struct {
     int type;
     int called;   /* HomogeneousMajorantIterator (media.h:84-106) */
     majseg_t seg;
+    /* DDAMajorantIterator (media.h:140-218) */
+    spec sigma_t;
+    float tMin, tMax;
+    const float *maj; /* MajorantGrid voxels, res 16^3 */
+    float nextCrossingT[3], deltaT[3];
+    int step[3], voxelLimit[3], voxel[3];
 } majiter_t;
+
+#define MAJ_RES 16 /* GridMedium majorant grid resolution (media.cpp:252) */
 
 static int majiter_next(majiter_t *it, majseg_t *seg) {
     if (it->type == VSPG_MEDIUM_HOMOGENEOUS) {
@@ -542,34 +553,171 @@ static int majiter_next(majiter_t *it, majseg_t *seg) {
         *seg = it->seg;
         return 1;
     }
+    if (it->type == VSPG_MEDIUM_GRID) { /* DDAMajorantIterator::Next (media.h:178-207) */
+        if (it->tMin >= it->tMax) return 0;
+        int bits = ((it->nextCrossingT[0] < it->nextCrossingT[1]) << 2) +
+                   ((it->nextCrossingT[0] < it->nextCrossingT[2]) << 1) +
+                   ((it->nextCrossingT[1] < it->nextCrossingT[2]));
+        const int cmpToAxis[8] = {2, 1, 2, 1, 2, 2, 0, 0};
+        int stepAxis = cmpToAxis[bits];
+        float tVoxelExit = it->nextCrossingT[stepAxis] < it->tMax ? it->nextCrossingT[stepAxis] : it->tMax; /* std::min(tMax, next) */
+        float md = it->maj[it->voxel[0] + MAJ_RES * (it->voxel[1] + MAJ_RES * it->voxel[2])];
+        seg->tMin = it->tMin;
+        seg->tMax = tVoxelExit;
+        seg->sigma_maj = s_scale(it->sigma_t, md);
+        it->tMin = tVoxelExit;
+        if (it->nextCrossingT[stepAxis] > it->tMax) it->tMin = it->tMax;
+        it->voxel[stepAxis] += it->step[stepAxis];
+        if (it->voxel[stepAxis] == it->voxelLimit[stepAxis]) it->tMin = it->tMax;
+        it->nextCrossingT[stepAxis] += it->deltaT[stepAxis];
+        return 1;
+    }
     return 0;
 }
-/* Medium::SampleRay: HomogeneousMedium (media.h:263-269) */
+/* Bounds3::Offset (vecmath.h:1323-1332) */
+static v3 bounds_offset(const VspgMedium *m, v3 p) {
+    v3 o = V3(p.x - m->bounds_min[0], p.y - m->bounds_min[1], p.z - m->bounds_min[2]);
+    if (m->bounds_max[0] > m->bounds_min[0]) o.x /= m->bounds_max[0] - m->bounds_min[0];
+    if (m->bounds_max[1] > m->bounds_min[1]) o.y /= m->bounds_max[1] - m->bounds_min[1];
+    if (m->bounds_max[2] > m->bounds_min[2]) o.z /= m->bounds_max[2] - m->bounds_min[2];
+    return o;
+}
+/* SampledGrid<Float>::Lookup(Point3i) (containers.h:830-835) */
+static float grid_at(const OracleRenderer *r, int x, int y, int z) {
+    const VspgMedium *m = &r->scene.medium;
+    if (x < 0 || y < 0 || z < 0 || x >= m->nx || y >= m->ny || z >= m->nz) return 0.f;
+    return r->density[((size_t)z * m->ny + y) * m->nx + x];
+}
+/* SampledGrid<Float>::Lookup(Point3f) trilinear (containers.h:804-819) */
+static float grid_lookup(const OracleRenderer *r, v3 p) {
+    const VspgMedium *m = &r->scene.medium;
+    float sx = p.x * m->nx - .5f, sy = p.y * m->ny - .5f, sz = p.z * m->nz - .5f;
+    int ix = (int)floorf(sx), iy = (int)floorf(sy), iz = (int)floorf(sz);
+    float dx = sx - (float)ix, dy = sy - (float)iy, dz = sz - (float)iz;
+#define LERPF(t, a, b) ((1 - (t)) * (a) + (t) * (b))
+    float d00 = LERPF(dx, grid_at(r, ix, iy, iz), grid_at(r, ix + 1, iy, iz));
+    float d10 = LERPF(dx, grid_at(r, ix, iy + 1, iz), grid_at(r, ix + 1, iy + 1, iz));
+    float d01 = LERPF(dx, grid_at(r, ix, iy, iz + 1), grid_at(r, ix + 1, iy, iz + 1));
+    float d11 = LERPF(dx, grid_at(r, ix, iy + 1, iz + 1), grid_at(r, ix + 1, iy + 1, iz + 1));
+    float a = LERPF(dy, d00, d10), b = LERPF(dy, d01, d11);
+    return LERPF(dz, a, b);
+#undef LERPF
+}
+/* majorant grid construction: SampledGrid::MaxValue over each voxel's bounds
+ * (media.cpp:262-269, containers.h:838-854) */
+static void build_majorant_grid(OracleRenderer *r) {
+    const VspgMedium *m = &r->scene.medium;
+    for (int z = 0; z < MAJ_RES; ++z)
+        for (int y = 0; y < MAJ_RES; ++y)
+            for (int x = 0; x < MAJ_RES; ++x) {
+                float b0[3] = {(float)x / MAJ_RES, (float)y / MAJ_RES, (float)z / MAJ_RES};
+                float b1[3] = {(float)(x + 1) / MAJ_RES, (float)(y + 1) / MAJ_RES, (float)(z + 1) / MAJ_RES};
+                int n[3] = {m->nx, m->ny, m->nz}, lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    int a = (int)floorf(b0[k] * n[k] - .5f);
+                    int b = (int)floorf(b1[k] * n[k] - .5f) + 1;
+                    lo[k] = a > 0 ? a : 0;
+                    hi[k] = b < n[k] - 1 ? b : n[k] - 1;
+                }
+                float mx = grid_at(r, lo[0], lo[1], lo[2]);
+                for (int zz = lo[2]; zz <= hi[2]; ++zz)
+                    for (int yy = lo[1]; yy <= hi[1]; ++yy)
+                        for (int xx = lo[0]; xx <= hi[0]; ++xx) {
+                            float v = grid_at(r, xx, yy, zz);
+                            mx = mx < v ? v : mx; /* std::max(maxValue, v) */
+                        }
+                r->majorant[x + MAJ_RES * (y + MAJ_RES * z)] = mx;
+            }
+}
+
+/* Medium::SampleRay: HomogeneousMedium (media.h:263-269), GridMedium (media.h:347-362) */
 static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tMax) {
     majiter_t it;
     memset(&it, 0, sizeof it);
     const VspgMedium *m = &r->scene.medium;
     it.type = m->type;
-    (void)o; (void)d;
     if (m->type == VSPG_MEDIUM_HOMOGENEOUS) {
         it.called = 0;
         it.seg.tMin = 0;
         it.seg.tMax = tMax;
         it.seg.sigma_maj = s_add(s_from(m->sigma_a), s_from(m->sigma_s));
+    } else if (m->type == VSPG_MEDIUM_GRID) {
+        it.tMin = INFINITY; it.tMax = -INFINITY; /* default-constructed iterator: Next() returns nothing */
+        /* ray = renderFromMedium.ApplyInverse(ray, &raytMax) with an identity transform
+         * (transform.h:416-429, transform.cpp:263-303): the origin picks up the conservative
+         * error bound gamma(3)*|o| and is pushed along d by dt */
+        const float g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS);
+        v3 oerr = V3(g3 * (fabsf(o.x) + 0.f + 0.f), g3 * (0.f + fabsf(o.y) + 0.f), g3 * (0.f + 0.f + fabsf(o.z)));
+        p3i oi = p3i_from_err(o, oerr);
+        float lengthSquared = v_len2(d);
+        if (lengthSquared > 0) {
+            v3 oe = p3i_err(oi);
+            float dt = v_dot(v_abs(d), oe) / lengthSquared;
+            v3 sh = v_scale(d, dt);
+            /* Interval + Float: {AddRoundDown(low, f), AddRoundUp(high, f)} (math.h:873-875) */
+            oi.lo = V3(next_float_down(oi.lo.x + sh.x), next_float_down(oi.lo.y + sh.y), next_float_down(oi.lo.z + sh.z));
+            oi.hi = V3(next_float_up(oi.hi.x + sh.x), next_float_up(oi.hi.y + sh.y), next_float_up(oi.hi.z + sh.z));
+            tMax -= dt;
+        }
+        v3 ro = p3i_mid(oi);
+        /* bounds.IntersectP(ray.o, ray.d, raytMax, &tMin, &tMax) (vecmath.h:1547-1571) */
+        float t0 = 0, t1 = tMax;
+        const float *oo = &ro.x, *dd = &d.x;
+        for (int i = 0; i < 3; ++i) {
+            float invRayDir = 1 / dd[i];
+            float tNear = (m->bounds_min[i] - oo[i]) * invRayDir;
+            float tFar = (m->bounds_max[i] - oo[i]) * invRayDir;
+            if (tNear > tFar) { float t = tNear; tNear = tFar; tFar = t; }
+            tFar *= 1 + 2 * g3;
+            t0 = tNear > t0 ? tNear : t0;
+            t1 = tFar < t1 ? tFar : t1;
+            if (t0 > t1) return it;
+        }
+        /* DDAMajorantIterator ctor (media.h:145-176) */
+        it.tMin = t0; it.tMax = t1;
+        it.maj = r->majorant;
+        it.sigma_t = s_add(s_from(m->sigma_a), s_from(m->sigma_s));
+        v3 diag = V3(m->bounds_max[0] - m->bounds_min[0], m->bounds_max[1] - m->bounds_min[1], m->bounds_max[2] - m->bounds_min[2]);
+        v3 go = bounds_offset(m, ro);
+        float gd[3] = {d.x / diag.x, d.y / diag.y, d.z / diag.z};
+        float gi[3] = {go.x + gd[0] * t0, go.y + gd[1] * t0, go.z + gd[2] * t0};
+        for (int axis = 0; axis < 3; ++axis) {
+            float v = gi[axis] * MAJ_RES; /* Clamp(float, 0, res-1) -> float, then converted to int */
+            it.voxel[axis] = (int)(v < 0 ? 0.f : (v > (float)(MAJ_RES - 1) ? (float)(MAJ_RES - 1) : v));
+            it.deltaT[axis] = 1 / (fabsf(gd[axis]) * MAJ_RES);
+            if (gd[axis] == -0.f) gd[axis] = 0.f;
+            if (gd[axis] >= 0) {
+                float nextVoxelPos = (float)(it.voxel[axis] + 1) / MAJ_RES;
+                it.nextCrossingT[axis] = t0 + (nextVoxelPos - gi[axis]) / gd[axis];
+                it.step[axis] = 1;
+                it.voxelLimit[axis] = MAJ_RES;
+            } else {
+                float nextVoxelPos = (float)(it.voxel[axis]) / MAJ_RES;
+                it.nextCrossingT[axis] = t0 + (nextVoxelPos - gi[axis]) / gd[axis];
+                it.step[axis] = -1;
+                it.voxelLimit[axis] = -1;
+            }
+        }
     } else {
         it.called = 1;
     }
     return it;
 }
-/* Medium::SamplePoint: HomogeneousMedium (media.h:256-261) */
+/* Medium::SamplePoint: HomogeneousMedium (media.h:256-261), GridMedium (media.h:316-345) */
 static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
     medium_props_t mp;
     const VspgMedium *m = &r->scene.medium;
-    (void)p;
     mp.sigma_a = s_from(m->sigma_a);
     mp.sigma_s = s_from(m->sigma_s);
     mp.Le = s_from(m->Le);
     mp.g = m->g;
+    if (m->type == VSPG_MEDIUM_GRID) {
+        /* identity renderFromMedium: ApplyInverse(Point3f) returns p unchanged */
+        float d = grid_lookup(r, bounds_offset(m, p));
+        mp.sigma_a = s_scale(mp.sigma_a, d);
+        mp.sigma_s = s_scale(mp.sigma_s, d);
+        mp.Le = S1(0.f); /* emissive grids (Le / temperature) are outside this build's scope */
+    }
     return mp;
 }
 static int medium_is_homogeneous(const OracleRenderer *r) { return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS; }
@@ -1595,6 +1743,11 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return VSPG_EINVAL;
     if (p->collisionProbabilityBias || p->rrguiding) return VSPG_ESCOPE;
     if (p->surfaceguiding || p->volumeguiding || (p->vspguiding && p->vspsecondaryguiding)) return VSPG_ESCOPE;
+    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+        const VspgMedium *m = &scene->medium;
+        if (m->nx <= 0 || m->ny <= 0 || m->nz <= 0 || !m->density) return VSPG_EINVAL;
+        if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) return VSPG_ESCOPE;
+    }
     return 0;
 }
 
@@ -1612,6 +1765,15 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
         quad_init(&r->quads[i], &scene->quads[i]);
         if (r->quads[i].is_light) r->light_quads[r->n_lights++] = i;
     }
+    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+        const VspgMedium *m = &scene->medium;
+        size_t n = (size_t)m->nx * m->ny * m->nz;
+        r->density = (float *)malloc(n * sizeof(float));
+        memcpy(r->density, m->density, n * sizeof(float));
+        r->scene.medium.density = r->density;
+        r->majorant = (float *)calloc(MAJ_RES * MAJ_RES * MAJ_RES, sizeof(float));
+        build_majorant_grid(r);
+    }
     size_t npix = (size_t)cfg->xres * cfg->yres;
     r->film = (double *)calloc(npix * 4, sizeof(double));
     r->isg_stats = (float *)calloc(npix * VSPG_ISG_STATS, sizeof(float));
@@ -1621,7 +1783,7 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
 }
 void oracle_renderer_destroy(OracleRenderer *r) {
     if (!r) return;
-    free(r->film); free(r->isg_stats); free(r->vsp); free(r);
+    free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {
     size_t n = (size_t)r->cfg.xres * r->cfg.yres * 4;

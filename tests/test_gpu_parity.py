@@ -274,3 +274,89 @@ def test_sharded_waves_sum_to_unsharded(gpu_pkg):
     assert np.array_equal(acc[..., 3], ref[..., 3])
     assert np.allclose(acc, ref, rtol=1e-6, atol=1e-7)
     full.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# heterogeneous medium (GridMedium: DDA majorants, trilinear density, SampleT_maj_Resampling)
+# ---------------------------------------------------------------------------------------------
+def test_grid_known_answers_on_device(gpu_pkg):
+    from scenes import d3_density, grid_scene
+    P = gpu_pkg
+    dens = d3_density()
+    scene = grid_scene(dens, (8, 8, 8), 0.5, 4.5)
+    g = P.Renderer(scene, P.app_f_params(), 16, 16)
+    q = P.VspgTmajQuery(P.f3(0.1, 0.2, -0.5), P.f3(0.3, 0.2, 1.0), 2.0, 0.37, 0.25, 0.75, 0.6, 1, 0)
+    o = g.sample_tmaj_batch(P.TMAJ_RESAMPLING, [q])[0]
+    # SURVEY.md App. D.3 (reference's own output)
+    assert o.n_callbacks == 8 and o.sum_sigt_over_maj == fh("0x1.dd496p+1")
+    assert o.T_maj[1] == fh("0x1.8f239ep-2") and o.vrc == fh("0x1.356952p-1") and o.majorant_scale == 1.0
+    q3 = P.VspgTmajQuery(P.f3(0.1, 0.2, -0.5), P.f3(0.3, 0.2, 1.0), 2.0, 0.37, 0.25, 0.75, -1.0, 1, 3)
+    o = g.sample_tmaj_batch(P.TMAJ_PLAIN, [q3])[0]
+    assert o.n_callbacks == 3 and o.last_p[2] == fh("0x1.717118p-2") and list(o.T_maj) == [1.0, 1.0, 1.0]
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def cloud_pair(gpu_pkg):
+    from scenes import cloud_density, grid_scene
+    P = gpu_pkg
+    W, H = 64, 48
+    dens = cloud_density(24)
+    scene = grid_scene(dens, (24, 24, 24), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    prm = P.app_f_params()
+    g = P.Renderer(scene, prm, W, H, seed=3)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
+    yield P, g, c
+    g.close()
+    c.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_grid_free_flight_vs_oracle(cloud_pair, variant):
+    P, g, c = cloud_pair
+    rng = np.random.default_rng(40 + variant)
+    qs = []
+    for i in range(20000):
+        d = rng.normal(size=3)
+        d = d / np.linalg.norm(d) * rng.uniform(0.5, 2.0)
+        stop = int(rng.integers(0, 4))
+        qs.append(P.VspgTmajQuery(P.f3(*rng.uniform(-1, 1, 3)), P.f3(*d), float(rng.uniform(0.0, 3.0)), float(rng.random()),
+                                  float(rng.random()), float(rng.random()), float(rng.random()) if i % 5 else -1.0,
+                                  int(rng.integers(0, 3)), stop))
+    go, co = g.sample_tmaj_batch(variant, qs), c.sample_tmaj_batch(variant, qs)
+    exact = 0
+    for a, b in zip(go, co):
+        assert a.n_callbacks == b.n_callbacks
+        same = (list(a.T_maj) == list(b.T_maj) and list(a.r_u_factor) == list(b.r_u_factor) and a.last_t == b.last_t
+                and a.sum_sigt_over_maj == b.sum_sigt_over_maj and a.vrc == b.vrc and a.majorant_scale == b.majorant_scale)
+        exact += same
+        assert np.allclose(list(a.T_maj), list(b.T_maj), rtol=1e-5, atol=1e-30)
+    print("grid variant", variant, "bit-identical fraction", exact / len(qs))
+    assert exact / len(qs) >= 0.999
+
+
+def test_grid_paths_and_film_vs_oracle(cloud_pair):
+    P, g, c = cloud_pair
+    rng = np.random.default_rng(9)
+    n = 20000
+    pix = np.stack([rng.integers(0, g.xres, n), rng.integers(0, g.yres, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    exact = np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)
+    ok = np.all(np.abs(Lg - Lc) <= 1e-4 * np.abs(Lc) + 1e-6, axis=1)
+    print("cloud paths: same segments %.5f within tol %.5f bit-identical %.5f" % (np.mean(sg == sc), ok.mean(), exact.mean()))
+    assert np.mean(sg == sc) >= 0.998 and ok.mean() >= 0.998
+    for w in range(5):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fg, fc = g.film(), c.film()
+    assert np.array_equal(fg[..., 3], fc[..., 3])
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    relmse = np.mean((ig - ic) ** 2 / (ic ** 2 + 1e-4))
+    print("cloud film relMSE %.3e" % relmse)
+    assert relmse <= 1e-4
+    cg, cc = g.counters(), c.counters()
+    assert cg["density_queries"] > cg["volume_scatters"]
+    for k in cg:
+        assert abs(cg[k] - cc[k]) <= 2e-3 * cc[k] + 5, (k, cg[k], cc[k])

@@ -1,0 +1,115 @@
+"""Oracle GridMedium layer (DDA majorant iterator, trilinear density lookup, majorant grid,
+SampleT_maj / SampleT_maj_Resampling over it) vs the known answers the survey recorded from the
+reference's own code (GridMedium case) and structural properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import load_package
+
+fh = float.fromhex
+
+
+from scenes import d3_density, grid_scene as _grid_scene
+
+
+def grid_scene(P, density, n, sigma_a, sigma_s, **kw):
+    return _grid_scene(density, n, sigma_a, sigma_s, **kw)
+
+
+@pytest.fixture(scope="module")
+def d3():
+    P = load_package()
+    dens = d3_density()
+    scene = grid_scene(P, dens, (8, 8, 8), 0.5, 4.5)
+    r = oracle_lib.OracleRenderer(scene, oracle_lib.app_f_params(), 16, 16)
+    r._keep = dens
+    yield P, r
+    r.close()
+
+
+def q(P, **kw):
+    d = dict(o=(0.1, 0.2, -0.5), d=(0.3, 0.2, 1.0), tMax=2.0, u=0.37, rng_a=0.25, rng_b=0.75, vsp=0.6, channel=1, stop_after=0)
+    d.update(kw)
+    return P.VspgTmajQuery(P.f3(*d["o"]), P.f3(*d["d"]), d["tMax"], d["u"], d["rng_a"], d["rng_b"], d["vsp"], d["channel"], d["stop_after"])
+
+
+def test_d3_grid_resampling_known_answer(d3):
+    P, r = d3
+    # SampleT_maj_Resampling(guide, vsp=0.6) => 8 callbacks, sum(sigma_t/sigma_maj)[1] = 0x1.dd496p+1,
+    # T[1] = 0x1.8f239ep-2, vrc = 0x1.356952p-1, majorantScale = 1
+    o = r.sample_tmaj_batch(P.TMAJ_RESAMPLING, [q(P)])[0]
+    assert o.n_callbacks == 8
+    assert o.sum_sigt_over_maj == fh("0x1.dd496p+1")
+    assert o.T_maj[1] == fh("0x1.8f239ep-2")
+    assert o.vrc == fh("0x1.356952p-1")
+    assert o.majorant_scale == 1.0
+
+
+def test_d3_grid_plain_known_answer(d3):
+    P, r = d3
+    # plain SampleT_maj stopping at the 3rd callback => last z = 0x1.717118p-2, returns 1
+    o = r.sample_tmaj_batch(P.TMAJ_PLAIN, [q(P, vsp=-1.0, stop_after=3)])[0]
+    assert o.n_callbacks == 3
+    assert o.last_p[2] == fh("0x1.717118p-2")
+    assert list(o.T_maj) == [1.0, 1.0, 1.0]
+
+
+def test_grid_matches_homogeneous_when_density_is_one():
+    # a constant-density grid over a box covering the ray: the majorant equals sigma_t everywhere,
+    # no null collisions, and delta tracking statistics equal the homogeneous medium's
+    P = load_package()
+    dens = np.ones(4 * 4 * 4, dtype=np.float32)
+    scene = grid_scene(P, dens, (4, 4, 4), 0.05, 0.45, bmin=(-2, -2, -2), bmax=(2, 2, 2))
+    r = oracle_lib.OracleRenderer(scene, oracle_lib.app_f_params(), 16, 16)
+    rng = np.random.default_rng(0)
+    n = 40000
+    qs = [q(P, o=(0, 0, 0), d=(0, 0, 1), tMax=1.5, u=float(rng.random()), rng_a=float(rng.random()), vsp=-1.0, channel=0, stop_after=1)
+          for _ in range(n)]
+    out = r.sample_tmaj_batch(P.TMAJ_PLAIN, qs)
+    frac = np.mean([o.n_callbacks for o in out])
+    assert abs(frac - (1 - np.exp(-0.75))) < 6e-3
+    assert all(abs(o.sum_sigt_over_maj - 1.0) < 1e-6 for o in out if o.n_callbacks)
+    r.close()
+
+
+def test_grid_ray_missing_bounds_and_zero_density():
+    P = load_package()
+    dens = np.zeros(8, dtype=np.float32)
+    scene = grid_scene(P, dens, (2, 2, 2), 1.0, 1.0)
+    r = oracle_lib.OracleRenderer(scene, oracle_lib.app_f_params(), 16, 16)
+    for variant in (P.TMAJ_PLAIN, P.TMAJ_OPTICAL_DEPTH, P.TMAJ_RESAMPLING):
+        # misses the [0,1]^3 bounds entirely
+        o = r.sample_tmaj_batch(variant, [q(P, o=(5, 5, 5), d=(0, 0, 1), tMax=3.0)])[0]
+        assert o.n_callbacks == 0 and list(o.T_maj) == [1.0, 1.0, 1.0]
+        # crosses the bounds but the medium is empty: majorant 0 everywhere
+        o = r.sample_tmaj_batch(variant, [q(P, o=(0.5, 0.5, -1), d=(0, 0, 1), tMax=3.0)])[0]
+        assert o.n_callbacks == 0 and list(o.T_maj) == [1.0, 1.0, 1.0]
+    r.close()
+
+
+def test_grid_render_is_unbiased_wrt_vsp_guiding():
+    # heterogeneous medium: the resampling estimator (VSP-guided) and plain delta tracking
+    # (vspguiding off) must converge to the same image mean
+    P = load_package()
+    rng = np.random.default_rng(5)
+    n = 12
+    dens = np.clip(rng.random(n ** 3).astype(np.float32) * 1.6 - 0.3, 0, None).astype(np.float32)
+    W, H = 48, 36
+    means = []
+    for guided in (1, 0):
+        scene = grid_scene(P, dens, (n, n, n), 0.1, 2.4, g=0.3, bmin=(-0.8, -0.8, -0.6), bmax=(0.8, 0.6, 0.9), W=W, H=H)
+        prm = oracle_lib.app_f_params()
+        prm.vspguiding = guided
+        r = oracle_lib.OracleRenderer(scene, prm, W, H)
+        for w in range(96):
+            r.render_wave(w, w + 1)
+            r.post_process_wave()
+        f = r.film_f64()
+        means.append((f[..., :3] / f[..., 3:4]).reshape(-1, 3).mean(0))
+        c = r.counters()
+        assert c["density_queries"] > c["volume_scatters"]  # null collisions happen
+        r.close()
+    assert np.allclose(means[0], means[1], rtol=0.02), means

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "vspg_path.h"
@@ -70,7 +71,18 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
     const unsigned total_items = (unsigned)(tilesX * tilesY) * 64u;
     const int lane = threadIdx.x & 63;
-    const Medium medium = make_homogeneous(S);
+    // heterogeneous media: the 16^3 majorant grid (16 KB) is staged into LDS once per workgroup with
+    // coalesced 16-B loads; every DDA step then reads LDS instead of HBM/L2
+    const float *maj_ptr = nullptr;
+    if constexpr (!std::is_same<Medium, HomogeneousMedium>::value) {
+        __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
+        const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
+        float4 *dst = reinterpret_cast<float4 *>(s_maj);
+        for (int i = threadIdx.x; i < kMajRes * kMajRes * kMajRes / 4; i += kBlock) dst[i] = src[i];
+        __syncthreads();
+        maj_ptr = s_maj;
+    }
+    const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
     PathCounters pc = {0, 0, 0, 0, 0};
     uint32_t paths = 0;
 
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict
     const DScene &S = *Sp;
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const Medium medium = make_homogeneous(S);
+    const Medium medium = MediumMaker<Medium>::make(S, S.majorant);
     int px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
     PathCounters pc = {0, 0, 0, 0, 0};
     Sampler sampler;
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict_
     const DScene &S = *Sp;
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const Medium medium = make_homogeneous(S);
+    const Medium medium = MediumMaker<Medium>::make(S, S.majorant);
     VspgTmajQuery Q = q[i];
     VspgTmajResult R;
     memset(&R, 0, sizeof R);
@@ -310,6 +322,8 @@ struct VspgRenderer {
     float *vsp = nullptr;
     unsigned long long *counters = nullptr;
     unsigned int *work_head = nullptr;
+    float *density = nullptr;   // GridMedium density samples
+    float *majorant = nullptr;  // 16^3 majorant grid
     int num_cus = 0;
     int vsp_ready = 0;
     int wave_counter = 0, buffer_wave = 0;
@@ -406,12 +420,49 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
         D->Le[k] = sc.medium.Le[k];
     }
     D->g = sc.medium.g;
+    D->nx = sc.medium.nx;
+    D->ny = sc.medium.ny;
+    D->nz = sc.medium.nz;
+    for (int k = 0; k < 3; ++k) {
+        D->bounds_min[k] = sc.medium.bounds_min[k];
+        D->bounds_max[k] = sc.medium.bounds_max[k];
+    }
     D->prm = prm;
     D->xres = cfg.xres;
     D->yres = cfg.yres;
     D->seed = cfg.seed;
     D->shard_index = cfg.shard_index;
     D->shard_count = cfg.shard_count < 1 ? 1 : cfg.shard_count;
+}
+
+// GridMedium constructor: majorantGrid.Set(x,y,z, densityGrid.MaxValue(VoxelBounds(x,y,z)))
+// (src/pbrt/media.cpp:262-269; SampledGrid::MaxValue src/pbrt/util/containers.h:838-854)
+static std::vector<float> build_majorant_grid(const VspgMedium &m) {
+    const int R = 16;
+    std::vector<float> maj((size_t)R * R * R);
+    const int n[3] = {m.nx, m.ny, m.nz};
+    auto at = [&](int x, int y, int z) -> float {
+        if (x < 0 || y < 0 || z < 0 || x >= m.nx || y >= m.ny || z >= m.nz) return 0.f;
+        return m.density[((size_t)z * m.ny + y) * m.nx + x];
+    };
+    for (int z = 0; z < R; ++z)
+        for (int y = 0; y < R; ++y)
+            for (int x = 0; x < R; ++x) {
+                const int c[3] = {x, y, z};
+                int lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    float p0 = (float)c[k] / R, p1 = (float)(c[k] + 1) / R;
+                    int a = (int)std::floor(p0 * n[k] - .5f), b = (int)std::floor(p1 * n[k] - .5f) + 1;
+                    lo[k] = std::max(a, 0);
+                    hi[k] = std::min(b, n[k] - 1);
+                }
+                float mx = at(lo[0], lo[1], lo[2]);
+                for (int zz = lo[2]; zz <= hi[2]; ++zz)
+                    for (int yy = lo[1]; yy <= hi[1]; ++yy)
+                        for (int xx = lo[0]; xx <= hi[0]; ++xx) mx = std::max(mx, at(xx, yy, zz));
+                maj[x + R * (y + R * z)] = mx;
+            }
+    return maj;
 }
 
 static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const VspgRenderConfig *cfg) {
@@ -428,8 +479,15 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         return fail(VSPG_ESCOPE,
                     "directional guiding / secondary-ray VSP need the OpenPGL-style guiding cache, which this build does "
                     "not provide yet: set surfaceguiding, volumeguiding and vspsecondaryguiding to false");
-    if (scene->medium.type == VSPG_MEDIUM_GRID) return fail(VSPG_ESCOPE, "grid media are not built yet in this round");
-    if (scene->medium.type != VSPG_MEDIUM_NONE && scene->medium.type != VSPG_MEDIUM_HOMOGENEOUS)
+    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+        const VspgMedium &m = scene->medium;
+        if (m.nx <= 0 || m.ny <= 0 || m.nz <= 0 || !m.density) return fail(VSPG_EINVAL, "grid medium needs nx,ny,nz > 0 and a density array");
+        if ((long long)m.nx * m.ny * m.nz > (1ll << 31)) return fail(VSPG_EINVAL, "density grid too large");
+        for (int k = 0; k < 3; ++k)
+            if (!(m.bounds_max[k] > m.bounds_min[k])) return fail(VSPG_EINVAL, "grid medium bounds must have positive extent");
+        if (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0)
+            return fail(VSPG_ESCOPE, "emissive grid media (Le / temperature grids) are outside this build's scope");
+    } else if (scene->medium.type != VSPG_MEDIUM_NONE && scene->medium.type != VSPG_MEDIUM_HOMOGENEOUS)
         return fail(VSPG_EINVAL, "unknown medium type");
     int nl = 0;
     for (int i = 0; i < scene->n_quads; ++i)
@@ -556,6 +614,17 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             return fail(VSPG_EHIP, std::string(#expr) + ": " + hipGetErrorName(e2));                              \
         }                                                                                                         \
     } while (0)
+    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+        const size_t n = (size_t)scene->medium.nx * scene->medium.ny * scene->medium.nz;
+        std::vector<float> maj = build_majorant_grid(scene->medium);
+        CK(hipMalloc(&r->density, n * sizeof(float)));
+        CK(hipMemcpy(r->density, scene->medium.density, n * sizeof(float), hipMemcpyHostToDevice));
+        CK(hipMalloc(&r->majorant, maj.size() * sizeof(float)));
+        CK(hipMemcpy(r->majorant, maj.data(), maj.size() * sizeof(float), hipMemcpyHostToDevice));
+        r->hscene.density = r->density;
+        r->hscene.majorant = r->majorant;
+        r->scene.medium.density = nullptr;  // the host array belongs to the caller
+    }
     CK(hipMalloc(&r->dscene, sizeof(DScene)));
     CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
     CK(hipMalloc(&r->film, r->npix * sizeof(float4)));
@@ -586,6 +655,8 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->vsp) (void)hipFree(r->vsp);
     if (r->counters) (void)hipFree(r->counters);
     if (r->work_head) (void)hipFree(r->work_head);
+    if (r->density) (void)hipFree(r->density);
+    if (r->majorant) (void)hipFree(r->majorant);
     delete r;
     return 0;
 }
@@ -613,9 +684,14 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const int n_samples = (wave_end - 1 - first) / sc + 1;
     const PcgJump jump = pcg_jump((unsigned long long)first * 65536ull);
     HIPCHK(hipMemsetAsync(r->work_head, 0, sizeof(unsigned int), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_render_wave<HomogeneousMedium>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,
-                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first, n_samples == 1 ? 1 : 0, jump,
-                       static_per_wave, dyn_base, r->work_head, r->counters);
+    if (r->scene.medium.type == VSPG_MEDIUM_GRID)
+        hipLaunchKernelGGL(k_render_wave<GridMedium>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,
+                           r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first, n_samples == 1 ? 1 : 0,
+                           jump, static_per_wave, dyn_base, r->work_head, r->counters);
+    else
+        hipLaunchKernelGGL(k_render_wave<HomogeneousMedium>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first,
+                           n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, r->work_head, r->counters);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -716,8 +792,12 @@ int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy, const int3
     HIPCHK(hipMalloc(&dg.p, (size_t)n * sizeof(int32_t)));
     HIPCHK(hipMemcpyAsync(dp.p, pixel_xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ds.p, sample_index, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_trace_paths<HomogeneousMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp,
-                       r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p);
+    if (r->scene.medium.type == VSPG_MEDIUM_GRID)
+        hipLaunchKernelGGL(k_trace_paths<GridMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp,
+                           r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p);
+    else
+        hipLaunchKernelGGL(k_trace_paths<HomogeneousMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp,
+                           r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_L, dl.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (out_segments) HIPCHK(hipMemcpyAsync(out_segments, dg.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -738,8 +818,12 @@ int vspg_sample_tmaj_batch(VspgRenderer *r, int variant, int n, const VspgTmajQu
     HIPCHK(hipMalloc(&dq.p, (size_t)n * sizeof(VspgTmajQuery)));
     HIPCHK(hipMalloc(&dr.p, (size_t)n * sizeof(VspgTmajResult)));
     HIPCHK(hipMemcpyAsync(dq.p, q, (size_t)n * sizeof(VspgTmajQuery), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_tmaj_batch<HomogeneousMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, variant, n,
-                       (const VspgTmajQuery *)dq.p, (VspgTmajResult *)dr.p);
+    if (r->scene.medium.type == VSPG_MEDIUM_GRID)
+        hipLaunchKernelGGL(k_tmaj_batch<GridMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, variant, n,
+                           (const VspgTmajQuery *)dq.p, (VspgTmajResult *)dr.p);
+    else
+        hipLaunchKernelGGL(k_tmaj_batch<HomogeneousMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, variant, n,
+                           (const VspgTmajQuery *)dq.p, (VspgTmajResult *)dr.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dr.p, (size_t)n * sizeof(VspgTmajResult), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -457,6 +457,12 @@ struct DScene {
     // medium
     int32_t medium_type;
     float sigma_a[3], sigma_s[3], Le[3], g;
+    // grid medium (GridMedium, media.h:284-390): density samples nx*ny*nz (x fastest) and the 16^3
+    // majorant grid (media.cpp:252-269), both in HBM
+    int32_t nx, ny, nz;
+    float bounds_min[3], bounds_max[3];
+    const float *density;
+    const float *majorant;
     // integrator parameters
     VspgIntegratorParams prm;
     // render config
@@ -583,6 +589,167 @@ struct HomogeneousMedium {
 VDEV HomogeneousMedium make_homogeneous(const DScene &S) {
     return HomogeneousMedium{lds(S.sigma_a), lds(S.sigma_s), lds(S.Le), S.g};
 }
+
+// ---------------------------------------------------------------------------------------
+// a6: GridMedium (media.h:284-390) with the 3-D DDA majorant iterator (media.h:140-218),
+// identity renderFromMedium.  Per-axis DDA state is kept in named registers and selected with
+// compares (runtime-indexed private arrays would live in scratch).
+// ---------------------------------------------------------------------------------------
+constexpr int kMajRes = 16;  // media.cpp:252
+VDEV float sel3(float a0, float a1, float a2, int axis) { return axis == 0 ? a0 : (axis == 1 ? a1 : a2); }
+VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis == 1 ? a1 : a2); }
+struct GridMedium {
+    Spec sigma_a, sigma_s;
+    float g;
+    int nx, ny, nz;
+    V3 bmin, bmax;
+    const float *density;
+    const float *majorant;  // HBM or the block's LDS copy
+
+    struct Iter {  // DDAMajorantIterator
+        Spec sigma_t;
+        float tMin, tMax;
+        const float *maj;
+        float ncx, ncy, ncz;  // nextCrossingT
+        float dtx, dty, dtz;  // deltaT
+        int vx, vy, vz;       // voxel
+        int neg;              // bit a set: step[a] == -1 (voxelLimit -1), else +1 (voxelLimit res)
+        VDEV bool next(MajSeg *s) {  // media.h:178-207
+            if (tMin >= tMax) return false;
+            int bits = ((ncx < ncy) << 2) + ((ncx < ncz) << 1) + ((ncy < ncz));
+            int stepAxis = (0xA66 >> (2 * bits)) & 3;  // cmpToAxis[8] = {2,1,2,1,2,2,0,0}
+            float nc = sel3(ncx, ncy, ncz, stepAxis);
+            float tVoxelExit = fmin_(tMax, nc);
+            float md = maj[vx + kMajRes * (vy + kMajRes * vz)];
+            s->tMin = tMin;
+            s->tMax = tVoxelExit;
+            s->sigma_maj = sigma_t * md;
+            tMin = tVoxelExit;
+            if (nc > tMax) tMin = tMax;
+            int st = ((neg >> stepAxis) & 1) ? -1 : 1;
+            int lim = ((neg >> stepAxis) & 1) ? -1 : kMajRes;
+            int v = sel3i(vx, vy, vz, stepAxis) + st;
+            if (v == lim) tMin = tMax;
+            float ncn = nc + sel3(dtx, dty, dtz, stepAxis);
+            if (stepAxis == 0) { vx = v; ncx = ncn; }
+            else if (stepAxis == 1) { vy = v; ncy = ncn; }
+            else { vz = v; ncz = ncn; }
+            return true;
+        }
+    };
+
+    VDEV V3 offset(V3 p) const {  // Bounds3::Offset (vecmath.h:1323-1332)
+        V3 o = p - bmin;
+        if (bmax.x > bmin.x) o.x /= bmax.x - bmin.x;
+        if (bmax.y > bmin.y) o.y /= bmax.y - bmin.y;
+        if (bmax.z > bmin.z) o.z /= bmax.z - bmin.z;
+        return o;
+    }
+    VDEV float at(int x, int y, int z) const {  // SampledGrid::Lookup(Point3i) (containers.h:830-835)
+        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
+        return density[((size_t)z * ny + y) * nx + x];
+    }
+    VDEV float lookup(V3 p) const {  // SampledGrid::Lookup(Point3f) (containers.h:804-819)
+        float sx = p.x * nx - .5f, sy = p.y * ny - .5f, sz = p.z * nz - .5f;
+        float fx = __builtin_floorf(sx), fy = __builtin_floorf(sy), fz = __builtin_floorf(sz);
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        float dx = sx - (float)ix, dy = sy - (float)iy, dz = sz - (float)iz;
+        // issue the 8 voxel loads together, then interpolate
+        float v000 = at(ix, iy, iz), v100 = at(ix + 1, iy, iz), v010 = at(ix, iy + 1, iz), v110 = at(ix + 1, iy + 1, iz);
+        float v001 = at(ix, iy, iz + 1), v101 = at(ix + 1, iy, iz + 1), v011 = at(ix, iy + 1, iz + 1), v111 = at(ix + 1, iy + 1, iz + 1);
+        float d00 = (1 - dx) * v000 + dx * v100;
+        float d10 = (1 - dx) * v010 + dx * v110;
+        float d01 = (1 - dx) * v001 + dx * v101;
+        float d11 = (1 - dx) * v011 + dx * v111;
+        float a = (1 - dy) * d00 + dy * d10, b = (1 - dy) * d01 + dy * d11;
+        return (1 - dz) * a + dz * b;
+    }
+    VDEV Iter sample_ray(V3 o, V3 d, float raytMax) const {  // media.h:347-362
+        Iter it;
+        it.sigma_t = sigma_a + sigma_s;
+        it.tMin = kInf;
+        it.tMax = -kInf;  // default-constructed iterator: next() yields nothing
+        it.maj = majorant;
+        it.ncx = it.ncy = it.ncz = 0;
+        it.dtx = it.dty = it.dtz = 0;
+        it.vx = it.vy = it.vz = 0;
+        it.neg = 0;
+        // Transform::ApplyInverse(ray, &tMax), identity matrix (transform.h:416-429, transform.cpp:263-303):
+        // the origin carries the error bound gamma(3)*|o| and is pushed along d by dt
+        const float g3 = (3 * kMachineEps) / (1 - 3 * kMachineEps);
+        V3 oerr = V3{g3 * (__builtin_fabsf(o.x) + 0.f + 0.f), g3 * (0.f + __builtin_fabsf(o.y) + 0.f),
+                     g3 * (0.f + 0.f + __builtin_fabsf(o.z))};
+        P3i oi = p3i_from_err(o, oerr);
+        float lengthSquared = len2(d);
+        if (lengthSquared > 0) {
+            V3 oe = oi.err();
+            float dt = dot(vabs(d), oe) / lengthSquared;
+            V3 sh = d * dt;
+            oi.lo = V3{next_float_down(oi.lo.x + sh.x), next_float_down(oi.lo.y + sh.y), next_float_down(oi.lo.z + sh.z)};
+            oi.hi = V3{next_float_up(oi.hi.x + sh.x), next_float_up(oi.hi.y + sh.y), next_float_up(oi.hi.z + sh.z)};
+            raytMax -= dt;
+        }
+        V3 ro = oi.mid();
+        // Bounds3::IntersectP (vecmath.h:1547-1571)
+        float t0 = 0, t1 = raytMax;
+        {
+            const float k = 1 + 2 * g3;
+            float inv = 1 / d.x, tn = (bmin.x - ro.x) * inv, tf = (bmax.x - ro.x) * inv;
+            if (tn > tf) { float t = tn; tn = tf; tf = t; }
+            tf *= k; t0 = tn > t0 ? tn : t0; t1 = tf < t1 ? tf : t1;
+            if (t0 > t1) return it;
+            inv = 1 / d.y; tn = (bmin.y - ro.y) * inv; tf = (bmax.y - ro.y) * inv;
+            if (tn > tf) { float t = tn; tn = tf; tf = t; }
+            tf *= k; t0 = tn > t0 ? tn : t0; t1 = tf < t1 ? tf : t1;
+            if (t0 > t1) return it;
+            inv = 1 / d.z; tn = (bmin.z - ro.z) * inv; tf = (bmax.z - ro.z) * inv;
+            if (tn > tf) { float t = tn; tn = tf; tf = t; }
+            tf *= k; t0 = tn > t0 ? tn : t0; t1 = tf < t1 ? tf : t1;
+            if (t0 > t1) return it;
+        }
+        // DDAMajorantIterator ctor (media.h:145-176)
+        it.tMin = t0;
+        it.tMax = t1;
+        V3 diag = bmax - bmin;
+        V3 go = offset(ro);
+        V3 gd = V3{d.x / diag.x, d.y / diag.y, d.z / diag.z};
+        V3 gi = go + gd * t0;
+        auto axis_setup = [&](float gia, float gda, int bit, int *voxel, float *deltaT, float *nextT) {
+            float v = gia * kMajRes;
+            *voxel = (int)(v < 0 ? 0.f : (v > (float)(kMajRes - 1) ? (float)(kMajRes - 1) : v));
+            *deltaT = 1 / (__builtin_fabsf(gda) * kMajRes);
+            if (gda == -0.f) gda = 0.f;
+            if (gda >= 0) {
+                float nextVoxelPos = (float)(*voxel + 1) / kMajRes;
+                *nextT = t0 + (nextVoxelPos - gia) / gda;
+            } else {
+                float nextVoxelPos = (float)(*voxel) / kMajRes;
+                *nextT = t0 + (nextVoxelPos - gia) / gda;
+                it.neg |= bit;
+            }
+        };
+        axis_setup(gi.x, gd.x, 1, &it.vx, &it.dtx, &it.ncx);
+        axis_setup(gi.y, gd.y, 2, &it.vy, &it.dty, &it.ncy);
+        axis_setup(gi.z, gd.z, 4, &it.vz, &it.dtz, &it.ncz);
+        return it;
+    }
+    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 (no emission grids in scope)
+        float d = lookup(offset(p));
+        return MediumProps{sigma_a * d, sigma_s * d, sp(0.f), g};
+    }
+    VDEV bool is_homogeneous() const { return false; }
+};
+VDEV GridMedium make_grid(const DScene &S, const float *majorant) {
+    return GridMedium{lds(S.sigma_a), lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
+                      majorant};
+}
+template <class M> struct MediumMaker;
+template <> struct MediumMaker<HomogeneousMedium> {
+    static VDEV HomogeneousMedium make(const DScene &S, const float *) { return make_homogeneous(S); }
+};
+template <> struct MediumMaker<GridMedium> {
+    static VDEV GridMedium make(const DScene &S, const float *majorant) { return make_grid(S, majorant); }
+};
 
 // ---------------------------------------------------------------------------------------
 // a7: SampleT_maj (src/pbrt/media_sampleTMaj.h:49-117)
