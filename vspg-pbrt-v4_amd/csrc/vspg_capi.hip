@@ -124,9 +124,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
                 s = first_sample;
                 if (px < W && py < H && s < wave_end) {
                     if (single_sample)
-                        start_path(S, px, py, jump, sampler, st, &ch, isg);
+                        start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
                     else
-                        start_path(S, px, py, s, sampler, st, &ch, isg);
+                        start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);
                     has = true;
                 }
             }
@@ -144,20 +144,12 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
                 VSPG_PROF(PS_FINISH);
                 const Spec L = finish_radiance(st.L);
                 const size_t idx = (size_t)py * W + px;
-                // RGBFilm::AddSample (film.h:251-267): weight 1, imagingRatio 1, no clamp
-                float4 f = film[idx];
-                f.x += L.r; f.y += L.g; f.z += L.b; f.w += 1.f;
-                film[idx] = f;
-                float4 *sp4 = reinterpret_cast<float4 *>(isg_stats + idx * VSPG_ISG_STATS);
-                float4 s0 = sp4[0], s1 = sp4[1];
-                float st8[VSPG_ISG_STATS] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                isg_add_sample(st8, L, isg);
-                sp4[0] = make_float4(st8[0], st8[1], st8[2], st8[3]);
-                sp4[1] = make_float4(st8[4], st8[5], st8[6], st8[7]);
+                film_add_sample(film + idx, L);
+                isg_add_sample_atomic(isg_stats + idx * VSPG_ISG_STATS, L, isg);
                 paths++;
                 s += S.shard_count > 1 ? S.shard_count : 1;
                 if (s < wave_end)
-                    start_path(S, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
+                    start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
                 else
                     has = false;
             }
@@ -181,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict
     PathState st;
     IsgSample isg;
     int ch;
-    start_path(S, px, py, sample_index[i], sampler, st, &ch, isg);
+    start_path(S, vsp_buf, vsp_ready, px, py, sample_index[i], sampler, st, &ch, isg);
     while (li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc)) {
     }
     Spec L = finish_radiance(st.L);
@@ -405,10 +397,17 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
             return nz == 1 ? ax : -1;
         };
         int an = single_axis(q.n), a1 = single_axis(q.e1), a2 = single_axis(q.e2);
-        q.axis = -1;
+        IsectRec &rec = D->irec[i];
+        memset(&rec, 0, sizeof rec);
         if (an >= 0 && a1 >= 0 && a2 >= 0 && an != a1 && an != a2 && a1 != a2 && std::fabs(q.n[an]) == 1.0f) {
-            q.axis = an; q.uaxis = a1; q.vaxis = a2;
-            q.nsign = q.n[an]; q.l1 = q.e1[a1]; q.l2 = q.e2[a2];
+            rec.kind = 1;
+            rec.axes = an | (a1 << 2) | (a2 << 4);
+            rec.f[0] = q.n[an]; rec.f[1] = q.p00[an]; rec.f[2] = q.p00[a1]; rec.f[3] = q.p00[a2];
+            rec.f[4] = q.e1[a1]; rec.f[5] = q.e2[a2]; rec.f[6] = q.inv_l1; rec.f[7] = q.inv_l2;
+        } else {
+            rec.kind = 0;
+            for (int k = 0; k < 3; ++k) { rec.f[k] = q.n[k]; rec.f[3 + k] = q.p00[k]; rec.f[6 + k] = q.e1[k]; rec.f[9 + k] = q.e2[k]; }
+            rec.f[12] = q.inv_l1; rec.f[13] = q.inv_l2;
         }
         if (light) D->light_quads[D->n_lights++] = i;
     }

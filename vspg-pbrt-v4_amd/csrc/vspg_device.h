@@ -442,15 +442,19 @@ struct DQuad {
     float inv_l1, inv_l2, area;
     float Kd[3], Le[3];
     int32_t two_sided, is_light, has_lobes;
-    // axis-aligned rectangles (n = +-unit axis `axis`, e1 and e2 each along one other axis): the
-    // generic dot products reduce to single products because every other term is an exact zero;
-    // axis = -1 selects the generic code.  uaxis / vaxis: axes of e1 / e2; nsign, l1, l2: the only
-    // non-zero components of n, e1, e2.
-    int32_t axis, uaxis, vaxis;
-    float nsign, l1, l2;
+    int32_t pad;
+};
+// Packed per-rectangle intersection record: ONE 64-byte scalar load per test (s_load_dwordx16) with
+// no dependent address arithmetic.  kind 0: generic {n, p00, e1, e2, inv_l1, inv_l2}; kind 1: axis
+// aligned {nsign, pa = p00[axis], pu = p00[uaxis], pv = p00[vaxis], l1, l2, inv_l1, inv_l2}.
+struct IsectRec {
+    float f[14];
+    int32_t kind;   // 0 generic, 1 axis-aligned
+    int32_t axes;   // axis | uaxis << 2 | vaxis << 4
 };
 struct DScene {
     int32_t n_quads, n_lights;
+    IsectRec irec[VSPG_MAX_QUADS];
     int32_t light_quads[VSPG_MAX_QUADS];
     DQuad quads[VSPG_MAX_QUADS];
     VspgCamera cam;
@@ -481,28 +485,51 @@ struct Isect {
 // is re-projected onto the rectangle, p00 + (u*e1 + v*e2).
 // The sign pre-test only skips work whose outcome is already decided: t = num/denom can be > 0
 // only when num and denom are non-zero with equal signs.
+// Conservative range pre-test: with num, denom of equal sign, |num| > tMax*|denom|*(1+2^-20) implies
+// the correctly rounded quotient num/denom is >= tMax, so the exact test `t < tMax` below would
+// fail anyway; the IEEE division (~10 instructions) and the (u,v) work are skipped.  The margin
+// covers the rounding of the product and of the division (each <= 2^-24 relative).
+VDEV bool beyond(float num, float denom, float tMax) {
+    return __builtin_fabsf(num) > tMax * __builtin_fabsf(denom) * 1.000001f;
+}
 VDEV float comp(V3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }  // axis is wave-uniform
-VDEV bool quad_hit_uv(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, float *uHit, float *vHit) {
-    if (q.axis >= 0) {
+VDEV bool rect_hit_uv(const IsectRec &r, V3 o, V3 d, float tMax, float *tHit, float *uHit, float *vHit) {
+    float num, denom, u, v, t;
+    if (r.kind == 1) {
         // axis-aligned rectangle: n.d == nsign*d[a] and n.(p00-o) == nsign*(p00[a]-o[a]) exactly (the other
         // products are +-0), so t == (p00[a]-o[a])/d[a] exactly; likewise (p-p00).e1 == rel[uaxis]*l1.
-        const int a = q.axis;
-        float denom = q.nsign * comp(d, a);
-        float num = q.nsign * (q.p00[a] - comp(o, a));
+        const int a = r.axes & 3, ua = (r.axes >> 2) & 3, va = (r.axes >> 4) & 3;
+        denom = r.f[0] * comp(d, a);
+        num = r.f[0] * (r.f[1] - comp(o, a));
         bool cand = (num > 0 && denom > 0) || (num < 0 && denom < 0);
         if (!cand) return false;
-        float t = num / denom;
+        if (beyond(num, denom, tMax)) return false;
+        t = num / denom;
         if (!(t > 0) || !(t < tMax)) return false;
-        const int ua = q.uaxis, va = q.vaxis;
         float pu = comp(o, ua) + comp(d, ua) * t, pv = comp(o, va) + comp(d, va) * t;
-        float u = ((pu - q.p00[ua]) * q.l1) * q.inv_l1;
-        float v = ((pv - q.p00[va]) * q.l2) * q.inv_l2;
-        if (u < 0 || u > 1 || v < 0 || v > 1) return false;
-        *tHit = t;
-        *uHit = u;
-        *vHit = v;
-        return true;
+        u = ((pu - r.f[2]) * r.f[4]) * r.f[6];
+        v = ((pv - r.f[3]) * r.f[5]) * r.f[7];
+    } else {
+        V3 n = V3{r.f[0], r.f[1], r.f[2]}, p00 = V3{r.f[3], r.f[4], r.f[5]};
+        denom = dot(n, d);
+        num = dot(n, p00 - o);
+        bool cand = (num > 0 && denom > 0) || (num < 0 && denom < 0);
+        if (!cand) return false;
+        if (beyond(num, denom, tMax)) return false;
+        t = num / denom;
+        if (!(t > 0) || !(t < tMax)) return false;
+        V3 p = o + d * t;
+        V3 rel = p - p00;
+        u = dot(rel, V3{r.f[6], r.f[7], r.f[8]}) * r.f[12];
+        v = dot(rel, V3{r.f[9], r.f[10], r.f[11]}) * r.f[13];
     }
+    if (u < 0 || u > 1 || v < 0 || v > 1) return false;
+    *tHit = t;
+    *uHit = u;
+    *vHit = v;
+    return true;
+}
+VDEV bool quad_hit_uv(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, float *uHit, float *vHit) {
     V3 n = ld3(q.n), p00 = ld3(q.p00);
     float denom = dot(n, d);
     float num = dot(n, p00 - o);
@@ -535,7 +562,7 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     float bu = 0, bv = 0;
     for (int i = 0; i < S.n_quads; ++i) {
         float t, u, v;
-        if (quad_hit_uv(S.quads[i], o, d, best.t, &t, &u, &v)) {
+        if (rect_hit_uv(S.irec[i], o, d, best.t, &t, &u, &v)) {
             best.hit = true;
             best.t = t;
             best.quad = i;
@@ -552,7 +579,7 @@ VLEAF bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
     bool any = false;
     for (int i = 0; i < S.n_quads; ++i) {
         float t, u, v;
-        any = any || quad_hit_uv(S.quads[i], o, d, tMax, &t, &u, &v);
+        any = any || rect_hit_uv(S.irec[i], o, d, tMax, &t, &u, &v);
     }
     return any;
 }

@@ -223,17 +223,18 @@ struct PathState {
     int depth;
     bool specularBounce, anyNonSpecularBounces, lastVertexVolume;
     float rr_correction, etaScale;
+    float vsp0;  // primary-ray VSP of this pixel, loaded when the path starts (hides the HBM latency)
 };
 
 // VSP fetch (:654-671, :1098-1134).  Secondary-ray VSP comes from the guiding cache, which is
 // untrained in the configurations this build accepts -> VolumeScatterProbability() == -1
 // (guiding.h:295-298, 564-567).
-VDEV float fetch_vsp(const DScene &S, const float *vsp_buf, int vsp_ready, int px, int py, int depth, bool *guide) {
+VDEV float fetch_vsp(const DScene &S, float vsp0, int depth, bool *guide) {
     float vsp = -1.f;
     *guide = false;
     if (depth == 0) {
         if (S.prm.vspguiding && S.prm.vspprimaryguiding) {
-            vsp = vsp_ready ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
+            vsp = vsp0;  // imageSpaceGuidingBuffer estimate, or 0.5 before the first update (:1101-1105)
             *guide = !(isnan_(vsp) || vsp < 0.f || vsp > 1.f);
         }
     }
@@ -266,7 +267,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
     ev.p = mk(0, 0, 0);
     ev.g = 0;
     bool guide;
-    float vsp = fetch_vsp(S, vsp_buf, vsp_ready, px, py, st.depth, &guide);
+    float vsp = fetch_vsp(S, st.vsp0, st.depth, &guide);
     if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
 
     bool use_resampling = S.prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && !medium.is_homogeneous();
@@ -582,13 +583,15 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
 
 // EvaluatePixelSample up to the camera ray (src/pbrt/cpu/integrators.cpp:272-304)
 VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, PathState &st, int *ch, IsgSample &isg);
-VDEV void start_path(const DScene &S, int px, int py, int sampleIndex, Sampler &sampler, PathState &st, int *ch,
-                     IsgSample &isg) {
+VDEV void start_path(const DScene &S, const float *vsp_buf, int vsp_ready, int px, int py, int sampleIndex, Sampler &sampler,
+                     PathState &st, int *ch, IsgSample &isg) {
+    st.vsp0 = vsp_ready ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
     sampler.start_pixel_sample(px, py, S.seed, sampleIndex);
     start_path_common(S, px, py, sampler, st, ch, isg);
 }
-VDEV void start_path(const DScene &S, int px, int py, PcgJump jump, Sampler &sampler, PathState &st, int *ch,
-                     IsgSample &isg) {
+VDEV void start_path(const DScene &S, const float *vsp_buf, int vsp_ready, int px, int py, PcgJump jump, Sampler &sampler,
+                     PathState &st, int *ch, IsgSample &isg) {
+    st.vsp0 = vsp_ready ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
     sampler.start_pixel_sample(px, py, S.seed, jump);
     start_path_common(S, px, py, sampler, st, ch, isg);
 }
@@ -636,6 +639,32 @@ VDEV Spec finish_radiance(Spec L) {
 // image-space VSP statistics (own design standing in for ImageSpaceGuidingBuffer::AddSample,
 // guidedvolpathvspgintegrator.cpp:613-622; OpenPGL absent -> unpinned)
 //   st[0]=n [1]=sum c[vol] [2]=sum c[surf] [3]=sum c^2 q [vol] [4]=sum c^2 (1-q) [surf] [5]=n_vol
+// Fire-and-forget accumulation: the lane that owns the pixel is the only writer during a launch, so
+// a no-return float atomic add gives the same single IEEE addition as load + add + store, but the
+// wave never waits for the HBM round trip (a finished path would otherwise stall its whole
+// wavefront for ~1-2 us every loop iteration).
+VDEV void add_noret(float *p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+VDEV void film_add_sample(float4 *film_px, Spec L) {  // RGBFilm::AddSample (film.h:251-267): weight 1, no clamp
+    float *f = reinterpret_cast<float *>(film_px);
+    add_noret(f + 0, L.r);
+    add_noret(f + 1, L.g);
+    add_noret(f + 2, L.b);
+    add_noret(f + 3, 1.f);
+}
+VDEV void isg_add_sample_atomic(float *st, Spec L, const IsgSample &isg) {
+    if (!isg.valid) return;
+    float c = avg(L);
+    float q = isg.vsp_used >= 0.f ? isg.vsp_used : 0.5f;
+    add_noret(st + 0, 1.f);
+    if (isg.surface_event) {
+        add_noret(st + 2, c);
+        add_noret(st + 4, c * c * (1 - q));
+    } else {
+        add_noret(st + 1, c);
+        add_noret(st + 3, c * c * q);
+        add_noret(st + 5, 1.f);
+    }
+}
 VDEV void isg_add_sample(float *st, Spec L, const IsgSample &isg) {
     if (!isg.valid) return;
     float c = avg(L);
