@@ -144,6 +144,34 @@ typedef struct VspgCounters {
     uint64_t shadow_rays;
 } VspgCounters;
 
+/* ---- guiding field (spatial-directional cache) -------------------------------------------
+ * Stands in for an openpgl::cpp::Field after Field::Update / Field(file)
+ * (guidedvolpathvspgintegrator.cpp:111-128, 234-246).  OpenPGL is not part of the reference tree,
+ * so the layout and the mixture math are this build's own design: a kd-tree over
+ * positions whose leaves hold a parallax-aware von-Mises-Fisher mixture of the incident radiance
+ * plus a per-lobe volume-scatter-probability estimate.  Training on device (Field::Update, SURVEY
+ * 8a row a18) is not built yet: the caller supplies a trained field. */
+#define VSPG_FIELD_LOBES 8
+typedef struct VspgKdNode {
+    float split;      /* inner node: split plane position along `axis` */
+    uint32_t packed;  /* bits 0-1: axis 0..2, 3 = leaf; bits 2-31: left child index (right = left+1),
+                         or the region index for a leaf */
+} VspgKdNode;
+typedef struct VspgFieldRegion {
+    float pivot[3];                    /* reference point of the lobes' parallax distances */
+    int32_t n_lobes;                   /* 0 = region not trained: Init() fails there */
+    float weight[VSPG_FIELD_LOBES];    /* mixture weights, sum 1 */
+    float kappa[VSPG_FIELD_LOBES];     /* vMF concentrations */
+    float mu[3][VSPG_FIELD_LOBES];     /* vMF mean directions (unit), SoA */
+    float distance[VSPG_FIELD_LOBES];  /* distance of the lobe's source from the pivot; +inf = none */
+    float vsp[VSPG_FIELD_LOBES];       /* volume scatter probability along the lobe, in [0,1] */
+} VspgFieldRegion;
+typedef struct VspgField {
+    int32_t n_nodes, n_regions;
+    const VspgKdNode *nodes;           /* HOST pointers; node 0 is the root */
+    const VspgFieldRegion *regions;
+} VspgField;
+
 typedef struct VspgRenderer VspgRenderer; /* opaque */
 
 /* ---- helpers (host only, no device needed) ----------------------------------------- */
@@ -168,6 +196,14 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
                          const VspgRenderConfig *cfg, VspgRenderer **out);
 /* Replaces ~GuidedVolPathVSPGIntegrator (guidedvolpathvspgintegrator.cpp:200-228). */
 int vspg_renderer_destroy(VspgRenderer *r);
+
+/* Uploads trained guiding fields: surface_field feeds SurfaceSamplingDistribution::Init
+ * (guiding.h:90), volume_field feeds VolumeSamplingDistribution::Init (guiding.h:388); either may be
+ * NULL (= untrained, Init() returns false as OpenPGL does before the first Field::Update).  Until
+ * this is called a renderer created with surfaceguiding / volumeguiding / vspsecondaryguiding
+ * refuses to render (VSPG_ESCOPE): the reference would train the field itself. */
+int vspg_renderer_set_guiding_field(VspgRenderer *r, const VspgField *surface_field,
+                                    const VspgField *volume_field, void *stream);
 
 /* Replaces one wave of ImageTileIntegrator::Render -- the ParallelFor2D over all pixels
  * for sample indices [wave_start, wave_end) (src/pbrt/cpu/integrators.cpp:183-207),
@@ -246,6 +282,15 @@ int vspg_sample_tmaj_batch(VspgRenderer *r, int variant, int n, const VspgTmajQu
  */
 int vspg_primitives_batch(VspgRenderer *r, int n, const float *f, const float *g,
                           uint64_t *hash, uint32_t *rng_u32, float *fastexp, void *stream);
+
+/* Batch driver of the guiding-cache query (parity tests): for each i initialises the distribution
+ * at p[i] (surface: cosine product with n[i]; volume: HG product with wo = n[i], asymmetry g) and
+ * returns PDF(wi[i]), IncomingRadiancePDF(wi[i]), VolumeScatterProbability(wi[i]) and one sample
+ * SamplePDF(u[i]) -> (ws[i], pdf_s[i]).  out_ok[i] = Init() result.  HOST arrays. */
+int vspg_guiding_query_batch(VspgRenderer *r, int is_volume, float g, int n, const float *p /*3n*/,
+                             const float *n_or_wo /*3n*/, const float *wi /*3n*/, const float *u /*2n*/,
+                             int32_t *out_ok, float *out_pdf, float *out_incoming_pdf, float *out_vsp,
+                             float *out_ws /*3n*/, float *out_pdf_s, void *stream);
 
 /* Device float libm batch: logf(x), sinf(x), cosf(x) as the kernels evaluate them; they must
  * equal the host libm the CPU reference run uses (std::log/std::sin/std::cos of float,

@@ -474,6 +474,8 @@ struct OracleRenderer {
     rquad_t quads[VSPG_MAX_QUADS];
     int n_lights;
     int light_quads[VSPG_MAX_QUADS];
+    /* guiding fields (copies): [0] surface, [1] volume; nodes == NULL -> untrained */
+    struct { int n_nodes, n_regions; VspgKdNode *nodes; VspgFieldRegion *regions; } field[2];
     /* GridMedium: density samples (copied) and the 16^3 majorant grid (media.cpp:252-269) */
     float *density;
     float *majorant;
@@ -1080,6 +1082,210 @@ static float light_pdf_li(const rquad_t *q, const lsctx_t *ctx, v3 wi) {
     return isinf(pdf) ? 0 : pdf;
 }
 
+
+/* ------------------------------------------------------------------------------------ */
+/* a14: guiding-cache query.  The wrapper logic (GuidedBSDF / GuidedPhaseFunction: MIS and */
+/* RIS mixing, PDF, VolumeScatterProbability) restates src/pbrt/cpu/guiding.h:57-638.  What */
+/* sits behind the OpenPGL calls it makes (Init, ApplyCosineProduct,                       */
+/* ApplySingleLobeHenyeyGreensteinProduct, PDF, SamplePDF, IncomingRadiancePDF,            */
+/* VolumeScatterProbability) is OpenPGL code absent from the reference tree: own design,   */
+/* PARITY UNPINNED -- kd-tree leaf lookup, parallax-aware vMF mixture. */
+/* Only +,-,*,/,sqrt, FastExp and the libm float functions are used, in one fixed order,   */
+/* so the device build can reproduce it bit for bit.                                       */
+/* ------------------------------------------------------------------------------------ */
+#define GK VSPG_FIELD_LOBES
+#define TWO_PI_F 6.28318530717958647692f
+typedef struct {
+    int ok;            /* Init() succeeded */
+    int field, region; /* which field / leaf */
+    v3 p;              /* query position (parallax) */
+    int n;             /* lobes of the PRODUCT mixture */
+    float w[GK], kappa[GK];
+    v3 mu[GK];
+} gdist_t;
+
+static float vmf_norm(float kappa) { /* kappa / (2 pi (1 - e^{-2 kappa})) */
+    return kappa / (TWO_PI_F * (1 - oracle_fast_exp(-2 * kappa)));
+}
+static float vmf_eval(v3 mu, float kappa, v3 w) { return vmf_norm(kappa) * oracle_fast_exp(kappa * (v_dot(mu, w) - 1)); }
+static float kappa_clamp(float k) { return k < 1e-2f ? 1e-2f : (k > 1e4f ? 1e4f : k); }
+
+/* kd-tree descent to the leaf containing p */
+static int field_lookup(const OracleRenderer *r, int f, v3 p) {
+    if (!r->field[f].nodes || r->field[f].n_nodes <= 0) return -1;
+    uint32_t node = 0;
+    for (int depth = 0; depth < 64; ++depth) {
+        VspgKdNode nd = r->field[f].nodes[node];
+        uint32_t axis = nd.packed & 3u, idx = nd.packed >> 2;
+        if (axis == 3u) return (int)idx < r->field[f].n_regions ? (int)idx : -1;
+        float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+        node = idx + (c < nd.split ? 0u : 1u);
+        if ((int)node >= r->field[f].n_nodes) return -1;
+    }
+    return -1;
+}
+/* parallax-shifted incident-radiance lobe k of a region seen from p */
+static v3 lobe_dir(const VspgFieldRegion *R, int k, v3 p) {
+    v3 mu = V3(R->mu[0][k], R->mu[1][k], R->mu[2][k]);
+    float d = R->distance[k];
+    if (!(d > 0) || isinf(d)) return mu;
+    v3 src = v_add(v3_from(R->pivot), v_scale(mu, d));
+    v3 t = v_sub(src, p);
+    float l2 = v_len2(t);
+    if (!(l2 > 0)) return mu;
+    return v_normalize(t);
+}
+/* product of lobe (mu,kappa,w) with a vMF (m2,k2): closed form (App. E.2) */
+static void lobe_product(v3 mu, float kappa, float w, v3 m2, float k2, v3 *mo, float *ko, float *wo) {
+    v3 s = v_add(v_scale(mu, kappa), v_scale(m2, k2));
+    float kp = v_len(s);
+    if (!(kp > 1e-6f)) { /* lobes cancel: nearly uniform */
+        *mo = mu; *ko = 1e-2f; *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(1e-2f)) * oracle_fast_exp(1e-2f - kappa - k2);
+        return;
+    }
+    float kc = kappa_clamp(kp);
+    *mo = V3(s.x / kp, s.y / kp, s.z / kp);
+    *ko = kc;
+    *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(kc)) * oracle_fast_exp(kp - kappa - k2);
+}
+/* {Surface,Volume}SamplingDistribution::Init + Apply*Product */
+static gdist_t gdist_init(const OracleRenderer *r, int f, v3 p, int have_product, v3 m2, float k2) {
+    gdist_t d;
+    memset(&d, 0, sizeof d);
+    d.field = f; d.p = p;
+    d.region = field_lookup(r, f, p);
+    if (d.region < 0) return d;
+    const VspgFieldRegion *R = &r->field[f].regions[d.region];
+    if (R->n_lobes <= 0) return d;
+    d.ok = 1;
+    d.n = R->n_lobes < GK ? R->n_lobes : GK;
+    float sum = 0;
+    for (int k = 0; k < d.n; ++k) {
+        v3 mu = lobe_dir(R, k, p);
+        float kap = kappa_clamp(R->kappa[k]);
+        if (have_product) lobe_product(mu, kap, R->weight[k], m2, k2, &d.mu[k], &d.kappa[k], &d.w[k]);
+        else { d.mu[k] = mu; d.kappa[k] = kap; d.w[k] = R->weight[k]; }
+        sum += d.w[k];
+    }
+    if (sum > 0 && !isinf(sum)) {
+        for (int k = 0; k < d.n; ++k) d.w[k] = d.w[k] / sum;
+    } else { /* degenerate product: fall back to the incident-radiance mixture */
+        for (int k = 0; k < d.n; ++k) { d.mu[k] = lobe_dir(R, k, p); d.kappa[k] = kappa_clamp(R->kappa[k]); d.w[k] = R->weight[k]; }
+    }
+    return d;
+}
+#define COSINE_LOBE_KAPPA 2.18853f /* vMF fit of the clamped cosine (App. E.2) */
+static gdist_t gdist_init_surface(const OracleRenderer *r, v3 p, v3 n) { return gdist_init(r, 0, p, 1, n, COSINE_LOBE_KAPPA); }
+static gdist_t gdist_init_volume(const OracleRenderer *r, v3 p, v3 dir, float g) {
+    /* gphase.init(&phase, p, ray.d, v) hands the ray's PROPAGATION direction to
+     * ApplySingleLobeHenyeyGreensteinProduct(dir, meanCosine) (guiding.h:389-391): vMF with mean
+     * cosine |g| around the HG peak, +dir for forward scattering (g > 0); isotropic -> no product */
+    float ag = fabsf(g);
+    if (ag < 1e-3f) return gdist_init(r, 1, p, 0, V3(0, 0, 1), 0);
+    if (ag > 0.99f) ag = 0.99f;
+    float kg = ag * (3 - ag * ag) / (1 - ag * ag);
+    v3 axis = g > 0 ? dir : v_neg(dir);
+    return gdist_init(r, 1, p, 1, v_normalize(axis), kg);
+}
+static float gdist_pdf(const gdist_t *d, v3 w) {
+    float s = 0;
+    for (int k = 0; k < d->n; ++k) s += d->w[k] * vmf_eval(d->mu[k], d->kappa[k], w);
+    return s;
+}
+/* incident-radiance mixture (before the product) */
+static float gdist_incoming_pdf(const OracleRenderer *r, const gdist_t *d, v3 w) {
+    const VspgFieldRegion *R = &r->field[d->field].regions[d->region];
+    float s = 0;
+    for (int k = 0; k < d->n; ++k) s += R->weight[k] * vmf_eval(lobe_dir(R, k, d->p), kappa_clamp(R->kappa[k]), w);
+    return s;
+}
+/* VolumeScatterProbability(wi): responsibility-weighted per-lobe estimate */
+static float gdist_vsp(const OracleRenderer *r, int f, int region, v3 p, v3 w) {
+    const VspgFieldRegion *R = &r->field[f].regions[region];
+    int n = R->n_lobes < GK ? R->n_lobes : GK;
+    float num = 0, den = 0;
+    for (int k = 0; k < n; ++k) {
+        float e = R->weight[k] * vmf_eval(lobe_dir(R, k, p), kappa_clamp(R->kappa[k]), w);
+        num += e * R->vsp[k];
+        den += e;
+    }
+    if (!(den > 0)) return -1.f;
+    return num / den;
+}
+/* SamplePDF(u2, &wi) */
+static float gdist_sample(const gdist_t *d, float u0, float u1, v3 *wi) {
+    /* lobe selection by CDF walk over the weights, u0 rescaled inside the chosen lobe */
+    int k = 0;
+    float acc = 0;
+    for (; k < d->n - 1; ++k) {
+        if (u0 < acc + d->w[k]) break;
+        acc += d->w[k];
+    }
+    float uw = d->w[k] > 0 ? (u0 - acc) / d->w[k] : 0.f;
+    uw = uw < 0 ? 0 : (uw > ONE_MINUS_EPS ? ONE_MINUS_EPS : uw);
+    float kap = d->kappa[k];
+    float W = 1 + logf(uw + (1 - uw) * oracle_fast_exp(-2 * kap)) / kap;
+    W = clampf(W, -1, 1);
+    float sinT = safe_sqrt(1 - W * W);
+    float phi = TWO_PI_F * u1;
+    frame_t fr;
+    fr.z = d->mu[k];
+    coordinate_system(fr.z, &fr.x, &fr.y);
+    *wi = frame_from_local(&fr, V3(sinT * cosf(phi), sinT * sinf(phi), W));
+    return gdist_pdf(d, *wi);
+}
+
+static void free_field(OracleRenderer *r, int f) {
+    free(r->field[f].nodes); free(r->field[f].regions);
+    memset(&r->field[f], 0, sizeof r->field[f]);
+}
+static int copy_field(OracleRenderer *r, int f, const VspgField *src) {
+    free_field(r, f);
+    if (!src || src->n_nodes <= 0 || src->n_regions <= 0) return 0;
+    for (int i = 0; i < src->n_nodes; ++i) {
+        uint32_t axis = src->nodes[i].packed & 3u, idx = src->nodes[i].packed >> 2;
+        if (axis == 3u ? (int)idx >= src->n_regions : (int)idx + 1 >= src->n_nodes || (int)idx <= i) return VSPG_EINVAL;
+    }
+    r->field[f].n_nodes = src->n_nodes; r->field[f].n_regions = src->n_regions;
+    r->field[f].nodes = (VspgKdNode *)malloc(sizeof(VspgKdNode) * src->n_nodes);
+    r->field[f].regions = (VspgFieldRegion *)malloc(sizeof(VspgFieldRegion) * src->n_regions);
+    memcpy(r->field[f].nodes, src->nodes, sizeof(VspgKdNode) * src->n_nodes);
+    memcpy(r->field[f].regions, src->regions, sizeof(VspgFieldRegion) * src->n_regions);
+    return 0;
+}
+int oracle_renderer_set_guiding_field(OracleRenderer *r, const VspgField *surface_field, const VspgField *volume_field) {
+    int rc = copy_field(r, 0, surface_field);
+    if (rc) return rc;
+    return copy_field(r, 1, volume_field);
+}
+int oracle_guiding_query_batch(OracleRenderer *r, int is_volume, float g, int n, const float *p, const float *n_or_wo,
+                               const float *wi, const float *u, int32_t *out_ok, float *out_pdf, float *out_incoming_pdf,
+                               float *out_vsp, float *out_ws, float *out_pdf_s) {
+    for (int i = 0; i < n; ++i) {
+        v3 pp = v3_from(p + 3 * i), a = v3_from(n_or_wo + 3 * i), w = v3_from(wi + 3 * i);
+        gdist_t d = is_volume ? gdist_init_volume(r, pp, a, g) : gdist_init_surface(r, pp, a);
+        out_ok[i] = d.ok;
+        out_pdf[i] = out_incoming_pdf[i] = out_pdf_s[i] = 0; out_vsp[i] = -1;
+        out_ws[3 * i] = out_ws[3 * i + 1] = out_ws[3 * i + 2] = 0;
+        if (!d.ok) continue;
+        out_pdf[i] = gdist_pdf(&d, w);
+        out_incoming_pdf[i] = gdist_incoming_pdf(r, &d, w);
+        out_vsp[i] = gdist_vsp(r, d.field, d.region, d.p, w);
+        v3 ws;
+        out_pdf_s[i] = gdist_sample(&d, u[2 * i], u[2 * i + 1], &ws);
+        out_ws[3 * i] = ws.x; out_ws[3 * i + 1] = ws.y; out_ws[3 * i + 2] = ws.z;
+    }
+    return 0;
+}
+
+
+/* GuidedBSDF / GuidedPhaseFunction state that outlives a vertex (guiding.h:345-357, 625-637) */
+typedef struct {
+    gdist_t d;
+    int useGuiding, useScatterGuiding;
+} gwrap_t;
+#define GUIDING_PROBABILITY 0.5f /* guiding.h:348, 628 */
+
 /* ------------------------------------------------------------------------------------ */
 /* a15: SampleLd (guidedvolpathvspgintegrator.cpp:1136-1252), guiding distributions        */
 /* inactive (field untrained => GuidedBSDF/GuidedPhaseFunction fall through to the plain   */
@@ -1121,7 +1327,7 @@ typedef struct {
     float g;            /* medium: HG */
 } intr_t;
 
-static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, int ch, sampler_t *sampler,
+static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t *gw, int ch, sampler_t *sampler,
                       spec r_p, path_counters_t *pc) {
     /* LightSampleContext */
     v3 ctxp = p3i_mid(intr->pi);
@@ -1149,12 +1355,18 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, int ch, sampl
     float scatterPDF;
     spec f_hat;
     v3 wo = intr->wo, wi = ls.wi;
+    /* GuidedBSDF::PDF / GuidedPhaseFunction::PDF (guiding.h:271-289, 542-558): MIS and RIS types
+     * both give 0.5*scatterPDF + 0.5*guidedPDF for guidingProbability 0.5 */
     if (intr->is_surface) {
         f_hat = s_scale(bsdf_f(intr->bsdf, wo, wi), v_absdot(wi, intr->n));
-        scatterPDF = 1.0f * bsdf_pdf(intr->bsdf, wo, wi);
+        float bsdfPDF = bsdf_pdf(intr->bsdf, wo, wi);
+        if (gw && gw->useGuiding) bsdfPDF = ((1.0f - GUIDING_PROBABILITY) * bsdfPDF) + (GUIDING_PROBABILITY * gdist_pdf(&gw->d, wi));
+        scatterPDF = 1.0f * bsdfPDF;
     } else {
         f_hat = S1(oracle_henyey_greenstein(v_dot(wo, wi), intr->g));
-        scatterPDF = 1.0f * oracle_henyey_greenstein(v_dot(wo, wi), intr->g);
+        float phasePDF = oracle_henyey_greenstein(v_dot(wo, wi), intr->g);
+        if (gw && gw->useGuiding) phasePDF = ((1.0f - GUIDING_PROBABILITY) * phasePDF) + (GUIDING_PROBABILITY * gdist_pdf(&gw->d, wi));
+        scatterPDF = 1.0f * phasePDF;
     }
     if (!s_nonzero(f_hat)) return S1(0.f);
 
@@ -1216,6 +1428,7 @@ typedef struct {
     spec beta_factor, r_u_factor;
     isg_sample_t *isg;
     path_counters_t *pc;
+    gwrap_t *gbsdf, *gphase; /* persist across the path loop like the GuidedBSDF / GuidedPhaseFunction objects (:287-288) */
 } sd_ctx_t;
 
 /* volume-scatter tail shared by both branches (:804-875 == :988-1058) */
@@ -1228,15 +1441,19 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
         intr.pi = p3i_exact(p);
         intr.wo = v_neg(*c->ray_d);
         intr.g = mp->g;
-        float v = sampler_get1d(c->sampler); /* gphase.init: cache untrained -> no guiding */
+        float v = sampler_get1d(c->sampler);
         (void)v;
+        /* gphase.init(&intr.phase, p, ray.d, v) (guiding.h:383-398) */
+        c->gphase->d = gdist_init_volume(r, p, *c->ray_d, mp->g);
+        c->gphase->useGuiding = r->prm.volumeguiding ? c->gphase->d.ok : 0;
+        c->gphase->useScatterGuiding = r->prm.vspsecondaryguiding ? c->gphase->d.ok : 0;
         float survivalProb = 1.0f;
         if (*c->depth > r->prm.minrrdepth) {
             spec rrw = s_scale(s_divf(*c->beta, s_avg(*c->r_u)), c->rr_correction);
             survivalProb = *c->specularBounce ? 0.95f : standard_throughput_rr(rrw);
         }
         if (r->prm.usenee) {
-            spec Ld = sample_Ld(r, &intr, c->ch, c->sampler, *c->r_u, c->pc);
+            spec Ld = sample_Ld(r, &intr, c->gphase, c->ch, c->sampler, *c->r_u, c->pc);
             *c->L = s_add(*c->L, s_mul(*c->beta, Ld));
         }
         if (survivalProb < 1 && *c->depth > r->prm.minrrdepth) {
@@ -1249,14 +1466,80 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
             *c->beta = s_divf(*c->beta, 1 - q);
         }
         float u0 = sampler_get1d(c->sampler), u1 = sampler_get1d(c->sampler);
-        float pdf;
-        v3 wi = sample_henyey_greenstein(v_neg(*c->ray_d), mp->g, u0, u1, &pdf);
-        if (pdf == 0) {
+        /* gphase.Sample_p(-ray.d, u) (guiding.h:404-540) */
+        v3 wo = v_neg(*c->ray_d);
+        float ps_p = 0, ps_pdf = 0;
+        v3 wi = V3(0, 0, 0);
+        int have = 0;
+        const gwrap_t *gw = c->gphase;
+        if (!gw->useGuiding) {
+            wi = sample_henyey_greenstein(wo, mp->g, u0, u1, &ps_pdf);
+            ps_p = ps_pdf;
+            have = 1;
+        } else if (r->prm.volumeguidingtype == VSPG_GUIDE_MIS) { /* Sample_p_MIS :404-445 */
+            int samplePhase = 1;
+            if (GUIDING_PROBABILITY > u0) { u0 /= GUIDING_PROBABILITY; samplePhase = 0; }
+            else { u0 -= GUIDING_PROBABILITY; u0 /= (1.0f - GUIDING_PROBABILITY); }
+            if (samplePhase) {
+                wi = sample_henyey_greenstein(wo, mp->g, u0, u1, &ps_pdf);
+                ps_p = ps_pdf;
+                float guidedPDF = gdist_pdf(&gw->d, wi);
+                ps_pdf = ((1.0f - GUIDING_PROBABILITY) * ps_pdf) + (GUIDING_PROBABILITY * guidedPDF);
+                have = 1;
+            } else {
+                float guidedPDF = gdist_sample(&gw->d, u0, u1, &wi);
+                float pp = oracle_henyey_greenstein(v_dot(wo, wi), mp->g);
+                float phasePDF = pp;
+                if (phasePDF > 0.f) {
+                    ps_p = pp;
+                    ps_pdf = ((1.0f - GUIDING_PROBABILITY) * phasePDF) + (GUIDING_PROBABILITY * guidedPDF);
+                    have = 1;
+                }
+            }
+        } else { /* Sample_p_RIS :447-530 */
+            const float uniformIncomingRadiancePDF = (float)(1.0f / (4.0f * M_PI));
+            float rp[2] = {0, 0}, rphase[2] = {0, 0}, rguid[2] = {0, 0}, rmis[2] = {0, 0}, rinc[2] = {0, 0}, rw[2] = {0, 0};
+            v3 rwi[2];
+            rwi[0] = sample_henyey_greenstein(wo, mp->g, u0, u1, &rphase[0]);
+            rp[0] = rphase[0];
+            rguid[0] = gdist_pdf(&gw->d, rwi[0]);
+            rinc[0] = gdist_incoming_pdf(r, &gw->d, rwi[0]);
+            rmis[0] = 0.5f * (rphase[0] + rguid[0]);
+            float s0 = sampler_get1d(c->sampler), s1 = sampler_get1d(c->sampler);
+            rguid[1] = gdist_sample(&gw->d, s0, s1, &rwi[1]);
+            rinc[1] = gdist_incoming_pdf(r, &gw->d, rwi[1]);
+            rp[1] = oracle_henyey_greenstein(v_dot(wo, rwi[1]), mp->g);
+            rphase[1] = rp[1];
+            rmis[1] = 0.5f * (rphase[1] + rguid[1]);
+            float sumW = 0.f;
+            int nS = 0;
+            for (int i = 0; i < 2; ++i)
+                if (rphase[i] > 0.f) {
+                    rw[i] = (rphase[i] * ((1.0f - GUIDING_PROBABILITY) * uniformIncomingRadiancePDF + GUIDING_PROBABILITY * rinc[i]));
+                    rw[i] /= rmis[i];
+                    sumW += rw[i];
+                    nS++;
+                }
+            if (!(nS == 0 || sumW <= 0.f)) {
+                int idx = 0;
+                float sample1D = sumW * sampler_get1d(c->sampler);
+                float sumR = 0.f;
+                for (int i = 0; i < 2; ++i) {
+                    sumR += rw[i];
+                    if (sample1D <= sumR) { idx = i; break; }
+                }
+                ps_pdf = (rw[idx] * rmis[idx]) * ((float)2 / sumW);
+                ps_p = rp[idx];
+                wi = rwi[idx];
+                have = 1;
+            }
+        }
+        if (!have || ps_pdf == 0) {
             c->terminated = 1;
         } else {
-            float phaseFunctionWeight = pdf / pdf; /* ps->p / ps->pdf, p == pdf for HG */
+            float phaseFunctionWeight = ps_p / ps_pdf;
             *c->beta = s_scale(*c->beta, phaseFunctionWeight);
-            *c->r_l = s_divf(*c->r_u, pdf);
+            *c->r_l = s_divf(*c->r_u, ps_pdf);
             memset(c->prevIntrCtx, 0, sizeof *c->prevIntrCtx);
             c->prevIntrCtx->pi = p3i_exact(p);
             c->scattered = 1;
@@ -1362,7 +1645,8 @@ static int resampling_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_
 /* VSP fetch (:654-671, :1098-1134).  Secondary-ray VSP comes from the guiding cache, which is
  * never trained in the configurations this oracle covers -> GuidedBSDF/GuidedPhaseFunction
  * ::VolumeScatterProbability return -1 (guiding.h:295-298, 564-567). */
-static float fetch_vsp(const OracleRenderer *r, int px, int py, int depth, int *guide) {
+static float fetch_vsp(const OracleRenderer *r, int px, int py, int depth, int lastVertexVolume, const gwrap_t *gbsdf,
+                       const gwrap_t *gphase, v3 rayd, int *guide) {
     float vsp = -1.f;
     *guide = 0;
     if (depth == 0) {
@@ -1373,7 +1657,9 @@ static float fetch_vsp(const OracleRenderer *r, int px, int py, int depth, int *
         }
     } else {
         if (r->prm.vspguiding && r->prm.vspsecondaryguiding) {
-            vsp = -1.f;
+            /* g{phase,bsdf}.VolumeScatterProbability(ray.d) (:661-668, guiding.h:295-305, 564-574) */
+            const gwrap_t *gw = lastVertexVolume ? gphase : gbsdf;
+            vsp = gw->useScatterGuiding ? gdist_vsp(r, gw->d.field, gw->d.region, gw->d.p, rayd) : -1.f;
             *guide = !(isnan(vsp) || vsp < 0.f || vsp > 1.f);
         }
     }
@@ -1385,7 +1671,7 @@ static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
     const OracleRenderer *r = c->r;
     int ch = c->ch;
     int guide;
-    float vsp = fetch_vsp(r, px, py, *c->depth, &guide);
+    float vsp = fetch_vsp(r, px, py, *c->depth, *c->lastVertexVolume, c->gbsdf, c->gphase, *c->ray_d, &guide);
     if (*c->depth == 0) c->isg->vsp_used = guide ? vsp : -1.f;
 
     int use_resampling = r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && !medium_is_homogeneous(r);
@@ -1480,6 +1766,9 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
     lsctx_t prevIntrCtx;
     memset(&prevIntrCtx, 0, sizeof prevIntrCtx);
     isg->valid = 0; isg->surface_event = 0; isg->vsp_used = -1.f;
+    gwrap_t gbsdf, gphase; /* GuidedBSDF gbsdf / GuidedPhaseFunction gphase (:287-288) */
+    memset(&gbsdf, 0, sizeof gbsdf);
+    memset(&gphase, 0, sizeof gphase);
 
     while (1) {
         pc->segments++;
@@ -1499,6 +1788,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             c.lastVertexVolume = &lastVertexVolume; c.prevIntrCtx = &prevIntrCtx;
             c.rr_correction = rr_correction;
             c.isg = isg; c.pc = pc;
+            c.gbsdf = &gbsdf; c.gphase = &gphase;
             sample_distance(&c, px, py, tMax);
             if (c.terminated || !s_nonzero(beta) || !s_nonzero(r_u)) break;
             if (c.scattered) continue;
@@ -1528,7 +1818,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         if (depth++ >= r->prm.maxdepth) break;
         pc->surface_hits++;
 
-        float v = sampler_get1d(sampler); /* gbsdf.init (cache untrained) */
+        float v = sampler_get1d(sampler);
         (void)v;
         float survivalProb = 1.f;
         intr_t intr;
@@ -1538,8 +1828,19 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         intr.pi = pi; intr.n = si.n;
         intr.wo = v_normalize(v_neg(rd)); /* Interaction ctor normalises wo (interaction.h:31-32) */
         intr.bsdf = &bsdf;
+        /* gbsdf.init(&bsdf, ray, si, v) (guiding.h:83-109): p = ray.o + tHit*ray.d, cosine product
+         * with the shading normal flipped towards -ray.d; only for non-specular BSDFs */
+        memset(&gbsdf.d, 0, sizeof gbsdf.d);
+        if (bsdf.has_lobes) {
+            v3 pg = v_add(ro, v_scale(rd, si.t));
+            v3 ng = si.n;
+            if (v_dot(v_neg(rd), si.n) < 0.f) ng = v_neg(ng);
+            gbsdf.d = gdist_init_surface(r, pg, ng);
+        }
+        gbsdf.useGuiding = r->prm.surfaceguiding ? gbsdf.d.ok : 0;
+        gbsdf.useScatterGuiding = r->prm.vspsecondaryguiding ? gbsdf.d.ok : 0;
         if (r->prm.usenee && bsdf.has_lobes) { /* IsNonSpecular(bsdf.Flags()) */
-            spec Ld = sample_Ld(r, &intr, ch, sampler, r_u, pc);
+            spec Ld = sample_Ld(r, &intr, &gbsdf, ch, sampler, r_u, pc);
             L = s_add(L, s_mul(beta, Ld));
         }
         prevIntrCtx.pi = pi; prevIntrCtx.n = si.n; prevIntrCtx.ns = si.n;
@@ -1547,15 +1848,86 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         v3 wo = v_neg(rd);
         float u = sampler_get1d(sampler);
         float u20 = sampler_get1d(sampler), u21 = sampler_get1d(sampler);
-        spec f;
-        v3 wi;
-        float pdf;
-        if (!bsdf_sample_f(&bsdf, wo, u, u20, u21, &f, &wi, &pdf)) break;
+        /* gbsdf.Sample_f(wo, u, u2) (guiding.h:120-269) */
+        spec f = S1(0.f);
+        v3 wi = V3(0, 0, 0);
+        float pdf = 0, bsdfPdf = 0, misPdf = 0;
+        int have = 0;
+        if (!gbsdf.useGuiding) {
+            have = bsdf_sample_f(&bsdf, wo, u, u20, u21, &f, &wi, &pdf);
+            bsdfPdf = misPdf = pdf;
+        } else if (r->prm.surfaceguidingtype == VSPG_GUIDE_MIS) { /* Sample_f_MIS :120-167 */
+            int sampleBSDF = 1;
+            if (GUIDING_PROBABILITY > u) { u /= GUIDING_PROBABILITY; sampleBSDF = 0; }
+            else { u -= GUIDING_PROBABILITY; u /= (1.0f - GUIDING_PROBABILITY); }
+            if (sampleBSDF) {
+                have = bsdf_sample_f(&bsdf, wo, u, u20, u21, &f, &wi, &pdf);
+                if (have) {
+                    float guidedPDF = gdist_pdf(&gbsdf.d, wi);
+                    bsdfPdf = pdf;
+                    pdf = ((1.0f - GUIDING_PROBABILITY) * pdf) + (GUIDING_PROBABILITY * guidedPDF);
+                    misPdf = pdf;
+                }
+            } else {
+                float guidedPDF = gdist_sample(&gbsdf.d, u20, u21, &wi);
+                f = bsdf_f(&bsdf, wo, wi);
+                float bPDF = bsdf_pdf(&bsdf, wo, wi);
+                if (bPDF > 0.f) {
+                    pdf = ((1.0f - GUIDING_PROBABILITY) * bPDF) + (GUIDING_PROBABILITY * guidedPDF);
+                    bsdfPdf = bPDF;
+                    misPdf = pdf;
+                    have = 1;
+                }
+            }
+        } else { /* Sample_f_RIS :169-257 */
+            const float uniformIncomingRadiancePDF = (float)(1.0f / (4.0f * M_PI));
+            spec rf[2] = {S1(0.f), S1(0.f)};
+            float rb[2] = {0, 0}, rguid[2] = {0, 0}, rmis[2] = {0, 0}, rinc[2] = {0, 0}, rw[2] = {0, 0};
+            v3 rwi[2] = {V3(0, 0, 0), V3(0, 0, 0)};
+            float p0;
+            if (bsdf_sample_f(&bsdf, wo, u, u20, u21, &rf[0], &rwi[0], &p0)) {
+                rb[0] = p0;
+                rguid[0] = gdist_pdf(&gbsdf.d, rwi[0]);
+                rinc[0] = gdist_incoming_pdf(r, &gbsdf.d, rwi[0]);
+                rmis[0] = 0.5f * (rb[0] + rguid[0]);
+            }
+            float s0 = sampler_get1d(sampler), s1 = sampler_get1d(sampler);
+            rguid[1] = gdist_sample(&gbsdf.d, s0, s1, &rwi[1]);
+            rinc[1] = gdist_incoming_pdf(r, &gbsdf.d, rwi[1]);
+            rf[1] = bsdf_f(&bsdf, wo, rwi[1]);
+            rb[1] = bsdf_pdf(&bsdf, wo, rwi[1]);
+            rmis[1] = 0.5f * (rb[1] + rguid[1]);
+            float sumW = 0.f;
+            int nS = 0;
+            for (int i = 0; i < 2; ++i)
+                if (rb[i] > 0.f) {
+                    rw[i] = (rb[i] * ((1.0f - GUIDING_PROBABILITY) * uniformIncomingRadiancePDF + GUIDING_PROBABILITY * rinc[i]));
+                    rw[i] /= rmis[i];
+                    sumW += rw[i];
+                    nS++;
+                }
+            if (!(nS == 0 || sumW <= 0.f)) {
+                int idx = 0;
+                float sample1D = sumW * sampler_get1d(sampler);
+                float sumR = 0.f;
+                for (int i = 0; i < 2; ++i) {
+                    sumR += rw[i];
+                    if (sample1D <= sumR) { idx = i; break; }
+                }
+                pdf = (rw[idx] * rmis[idx]) * ((float)2 / sumW);
+                misPdf = rmis[idx];
+                bsdfPdf = rb[idx];
+                f = rf[idx];
+                wi = rwi[idx];
+                have = 1;
+            }
+        }
+        if (!have) break;
         lastVertexVolume = 0;
-        rr_correction *= pdf / pdf; /* bs->pdf / bs->bsdfPdf */
+        rr_correction *= pdf / bsdfPdf;
         spec bsdfWeight = s_divf(s_scale(f, v_absdot(wi, si.n)), pdf);
         beta = s_mul(beta, bsdfWeight);
-        r_l = s_divf(r_u, pdf); /* misPdf == pdf */
+        r_l = s_divf(r_u, misPdf);
         specularBounce = 0;
         anyNonSpecularBounces = 1;
         ro = offset_ray_origin(pi, si.n, wi); /* SpawnRay (interaction.h:99-101) */
@@ -1742,7 +2114,6 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
     if (cfg->xres <= 0 || cfg->yres <= 0) return VSPG_EINVAL;
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return VSPG_EINVAL;
     if (p->collisionProbabilityBias || p->rrguiding) return VSPG_ESCOPE;
-    if (p->surfaceguiding || p->volumeguiding || (p->vspguiding && p->vspsecondaryguiding)) return VSPG_ESCOPE;
     if (scene->medium.type == VSPG_MEDIUM_GRID) {
         const VspgMedium *m = &scene->medium;
         if (m->nx <= 0 || m->ny <= 0 || m->nz <= 0 || !m->density) return VSPG_EINVAL;
@@ -1783,6 +2154,7 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
 }
 void oracle_renderer_destroy(OracleRenderer *r) {
     if (!r) return;
+    free_field(r, 0); free_field(r, 1);
     free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {

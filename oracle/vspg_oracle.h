@@ -79,6 +79,13 @@ int oracle_trace_paths(OracleRenderer *r, int n, const int32_t *pixel_xy,
 int oracle_sample_tmaj_batch(OracleRenderer *r, int variant, int n, const VspgTmajQuery *q,
                              VspgTmajResult *out);
 
+int oracle_renderer_set_guiding_field(OracleRenderer *r, const VspgField *surface_field,
+                                      const VspgField *volume_field);
+int oracle_guiding_query_batch(OracleRenderer *r, int is_volume, float g, int n, const float *p,
+                               const float *n_or_wo, const float *wi, const float *u, int32_t *out_ok,
+                               float *out_pdf, float *out_incoming_pdf, float *out_vsp, float *out_ws,
+                               float *out_pdf_s);
+
 /* scene helpers restated independently of the product's (same formulas, separate code) */
 void oracle_integrator_params_default(VspgIntegratorParams *p);
 int oracle_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3],

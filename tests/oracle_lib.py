@@ -53,6 +53,10 @@ def load():
         "oracle_reset_counters": (None, [vp]),
         "oracle_trace_paths": (C.c_int, [vp, C.c_int, p(C.c_int32), p(C.c_int32), p(C.c_float), p(C.c_int32)]),
         "oracle_sample_tmaj_batch": (C.c_int, [vp, C.c_int, C.c_int, p(P.VspgTmajQuery), p(P.VspgTmajResult)]),
+        "oracle_renderer_set_guiding_field": (C.c_int, [vp, p(P.VspgField), p(P.VspgField)]),
+        "oracle_guiding_query_batch": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, p(C.c_float), p(C.c_float), p(C.c_float),
+                                                 p(C.c_float), p(C.c_int32), p(C.c_float), p(C.c_float), p(C.c_float),
+                                                 p(C.c_float), p(C.c_float)]),
         "oracle_integrator_params_default": (None, [p(P.VspgIntegratorParams)]),
         "oracle_camera_look_at": (C.c_int, [p(P.VspgCamera), f3, f3, f3, C.c_float, C.c_int, C.c_int]),
         "oracle_scene_fog_box": (C.c_int, [p(P.VspgScene), C.c_int, C.c_int]),
@@ -164,3 +168,28 @@ class OracleRenderer:
         out = (self.P.VspgTmajResult * n)()
         assert self.lib.oracle_sample_tmaj_batch(self.h, variant, n, q, out) == 0
         return list(out)
+
+    def set_guiding_field(self, surface, volume):
+        rc = self.lib.oracle_renderer_set_guiding_field(self.h, C.byref(surface.pod) if surface else None,
+                                                        C.byref(volume.pod) if volume else None)
+        assert rc == 0, rc
+
+    def guiding_query_batch(self, is_volume, g, p, n_or_wo, wi, u):
+        return guiding_query(self.lib.oracle_guiding_query_batch, self.h, is_volume, g, p, n_or_wo, wi, u, None)
+
+
+def guiding_query(fn, handle, is_volume, g, p, n_or_wo, wi, u, stream):
+    fp = C.POINTER(C.c_float)
+    p, a, wi, u = (np.ascontiguousarray(x, dtype=np.float32) for x in (p, n_or_wo, wi, u))
+    n = p.shape[0]
+    ok = np.zeros(n, dtype=np.int32)
+    pdf, inc, vsp, pdfs = (np.zeros(n, dtype=np.float32) for _ in range(4))
+    ws = np.zeros((n, 3), dtype=np.float32)
+    args = [handle, int(is_volume), float(g), n, p.ctypes.data_as(fp), a.ctypes.data_as(fp), wi.ctypes.data_as(fp),
+            u.ctypes.data_as(fp), ok.ctypes.data_as(C.POINTER(C.c_int32)), pdf.ctypes.data_as(fp), inc.ctypes.data_as(fp),
+            vsp.ctypes.data_as(fp), ws.ctypes.data_as(fp), pdfs.ctypes.data_as(fp)]
+    if stream is not None:
+        args.append(C.c_void_p(stream))
+    rc = fn(*args)
+    assert rc == 0, rc
+    return dict(ok=ok, pdf=pdf, incoming_pdf=inc, vsp=vsp, ws=ws, pdf_s=pdfs)

@@ -52,3 +52,66 @@ def cloud_density(n, seed=5):
     v = interp(interp(interp(coarse, 0), 1), 2)
     v = np.clip(v * 2.2 - 0.75, 0.0, None)
     return np.ascontiguousarray(v.transpose(2, 1, 0).reshape(-1).astype(np.float32))  # x fastest
+
+
+def light_field(P, n=4, bmin=(-1, -1, -1), bmax=(1, 1, 1), light=(0.0, 0.999, 0.0), vsp_lo=0.25, vsp_hi=0.8, seed=0):
+    """A hand-made guiding field for the fog box: balanced kd-tree with n^3 leaves; every region has
+    a sharp parallax-aware lobe towards the ceiling light, a broad lobe up and a near-uniform lobe.
+    Stands in for a trained OpenPGL field in the query-side tests."""
+    rng = np.random.default_rng(seed)
+    nodes, regions = [], []
+
+    def build(lo, hi, depth):
+        idx = len(nodes)
+        nodes.append(None)
+        if depth == 3 * int(np.log2(n)):
+            c = [(a + b) / 2 for a, b in zip(lo, hi)]
+            R = P.VspgFieldRegion()
+            R.pivot[:] = c
+            R.n_lobes = 3
+            d = np.array(light) - np.array(c)
+            dist = float(np.linalg.norm(d))
+            d = d / dist
+            lobes = [(0.55, 25.0 + 10 * rng.random(), d, dist, vsp_lo), (0.3, 1.5, np.array([0.0, 1.0, 0.0]), np.inf, 0.5),
+                     (0.15, 0.05, np.array([1.0, 0.0, 0.0]), np.inf, vsp_hi)]
+            for k, (w, kap, mu, dd, vsp) in enumerate(lobes):
+                R.weight[k] = w
+                R.kappa[k] = kap
+                for a in range(3):
+                    R.mu[a][k] = float(mu[a])
+                R.distance[k] = dd
+                R.vsp[k] = vsp
+            nodes[idx] = P.VspgKdNode(0.0, 3 | (len(regions) << 2))
+            regions.append(R)
+            return idx
+        axis = depth % 3
+        mid = (lo[axis] + hi[axis]) / 2
+        # children must be adjacent: reserve both slots, then fill
+        left = len(nodes)
+        nodes.append(None)
+        nodes.append(None)
+
+        def fill(slot, lo2, hi2):
+            sub_first = len(nodes)
+            sub = build(lo2, hi2, depth + 1)  # appended at the end
+            nodes[slot] = nodes[sub]
+            # the subtree root was appended at `sub`; move it into the reserved slot
+            nodes.pop(sub)
+            # fix child indices that pointed past the removed entry
+            for i in range(sub_first, len(nodes)):
+                nd = nodes[i]
+                if nd is not None and (nd.packed & 3) != 3 and (nd.packed >> 2) > sub:
+                    nodes[i] = P.VspgKdNode(nd.split, (nd.packed & 3) | (((nd.packed >> 2) - 1) << 2))
+            nd = nodes[slot]
+            if (nd.packed & 3) != 3 and (nd.packed >> 2) > sub:
+                nodes[slot] = P.VspgKdNode(nd.split, (nd.packed & 3) | (((nd.packed >> 2) - 1) << 2))
+
+        hi_l = list(hi); hi_l[axis] = mid
+        lo_r = list(lo); lo_r[axis] = mid
+        fill(left, list(lo), hi_l)
+        fill(left + 1, lo_r, list(hi))
+        nodes[idx] = P.VspgKdNode(float(mid), axis | (left << 2))
+        return idx
+
+    build(list(bmin), list(bmax), 0)
+    return P.Field(nodes, regions)

@@ -77,6 +77,24 @@ class VspgCounters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+VSPG_FIELD_LOBES = 8
+_fl = C.c_float * VSPG_FIELD_LOBES
+
+
+class VspgKdNode(C.Structure):
+    _fields_ = [("split", C.c_float), ("packed", C.c_uint32)]
+
+
+class VspgFieldRegion(C.Structure):
+    _fields_ = [("pivot", f3), ("n_lobes", C.c_int32), ("weight", _fl), ("kappa", _fl), ("mu", _fl * 3),
+                ("distance", _fl), ("vsp", _fl)]
+
+
+class VspgField(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_regions", C.c_int32), ("nodes", C.POINTER(VspgKdNode)),
+                ("regions", C.POINTER(VspgFieldRegion))]
+
+
 class VspgTmajQuery(C.Structure):
     _fields_ = [("o", f3), ("d", f3), ("tMax", C.c_float), ("u", C.c_float),
                 ("rng_a", C.c_float), ("rng_b", C.c_float), ("vsp", C.c_float),
@@ -114,6 +132,10 @@ SYMBOLS = [
     ("vspg_sample_tmaj_batch", C.c_int, [_vp, C.c_int, C.c_int, _P(VspgTmajQuery), _P(VspgTmajResult), _vp]),
     ("vspg_primitives_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_uint64), _P(C.c_uint32), _P(C.c_float), _vp]),
     ("vspg_libm_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
+    ("vspg_renderer_set_guiding_field", C.c_int, [_vp, _P(VspgField), _P(VspgField), _vp]),
+    ("vspg_guiding_query_batch", C.c_int, [_vp, C.c_int, C.c_float, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float),
+                                          _P(C.c_float), _P(C.c_int32), _P(C.c_float), _P(C.c_float), _P(C.c_float),
+                                          _P(C.c_float), _P(C.c_float), _vp]),
 ]
 
 _lib = None
@@ -280,3 +302,16 @@ class Renderer:
         _check(self.lib, self.lib.vspg_libm_batch(self.h, n, x.ctypes.data_as(fp), lo.ctypes.data_as(fp),
                                                   so.ctypes.data_as(fp), co.ctypes.data_as(fp), _vp(0)))
         return lo, so, co
+
+    def set_guiding_field(self, surface, volume, stream=None):
+        _check(self.lib, self.lib.vspg_renderer_set_guiding_field(self.h, C.byref(surface.pod) if surface else None,
+                                                                  C.byref(volume.pod) if volume else None, _vp(stream or 0)))
+
+
+class Field:
+    """Host-side container of a guiding field (kd-tree nodes + regions) keeping the arrays alive."""
+
+    def __init__(self, nodes, regions):
+        self.nodes = (VspgKdNode * len(nodes))(*nodes)
+        self.regions = (VspgFieldRegion * len(regions))(*regions)
+        self.pod = VspgField(len(nodes), len(regions), self.nodes, self.regions)
