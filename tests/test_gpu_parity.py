@@ -360,3 +360,83 @@ def test_grid_paths_and_film_vs_oracle(cloud_pair):
     assert cg["density_queries"] > cg["volume_scatters"]
     for k in cg:
         assert abs(cg[k] - cc[k]) <= 2e-3 * cc[k] + 5, (k, cg[k], cc[k])
+
+
+# ---------------------------------------------------------------------------------------------
+# guiding cache query (own design behind the restated GuidedBSDF / GuidedPhaseFunction logic)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def guided_pair(gpu_pkg):
+    import scenes
+    P = gpu_pkg
+    W, H = 64, 48
+    scene = P.fog_box_scene(W, H)
+    scene.medium.g = 0.4
+    prm = P.default_params()          # the reference's defaults: surface RIS, volume MIS, secondary VSP
+    field = scenes.light_field(P, n=4)
+    g = P.Renderer(scene, prm, W, H, seed=2)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=2)
+    # guiding requested but no field yet: the product refuses loudly instead of silently not guiding
+    with pytest.raises(P.VspgError) as e:
+        g.render_wave(0, 1)
+    assert e.value.code == P.VSPG_ESCOPE
+    g.set_guiding_field(field, field)
+    c.set_guiding_field(field, field)
+    yield P, g, c, field
+    g.close()
+    c.close()
+
+
+@pytest.mark.parametrize("is_volume,gg", [(0, 0.0), (1, 0.0), (1, 0.7), (1, -0.4)])
+def test_guiding_query_vs_oracle(guided_pair, is_volume, gg):
+    P, g, c, field = guided_pair
+    rng = np.random.default_rng(17 + is_volume)
+    n = 30000
+    p = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    a = rng.normal(size=(n, 3)); a = (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    wi = rng.normal(size=(n, 3)); wi = (wi / np.linalg.norm(wi, axis=1, keepdims=True)).astype(np.float32)
+    u = rng.random((n, 2)).astype(np.float32)
+    og = g.guiding_query_batch(is_volume, gg, p, a, wi, u)
+    oc = c.guiding_query_batch(is_volume, gg, p, a, wi, u)
+    assert np.array_equal(og["ok"], oc["ok"]) and og["ok"].all()
+    for k in ("pdf", "incoming_pdf", "vsp", "pdf_s", "ws"):
+        same = np.mean(og[k].view(np.uint32) == oc[k].view(np.uint32))
+        print(k, "bit-identical fraction %.5f" % same)
+        assert np.allclose(og[k], oc[k], rtol=1e-5, atol=1e-7)
+        assert same >= 0.999
+
+
+@pytest.mark.parametrize("stype,vtype", [(1, 0), (0, 1)])  # (ris, mis) = reference defaults; (mis, ris)
+def test_guided_paths_and_film_vs_oracle(gpu_pkg, stype, vtype):
+    import scenes
+    P = gpu_pkg
+    W, H = 64, 48
+    scene = P.fog_box_scene(W, H)
+    scene.medium.g = 0.4
+    prm = P.default_params()
+    prm.surfaceguidingtype, prm.volumeguidingtype = stype, vtype
+    field = scenes.light_field(P, n=4)
+    g = P.Renderer(scene, prm, W, H, seed=5)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=5)
+    g.set_guiding_field(field, field)
+    c.set_guiding_field(field, field)
+    rng = np.random.default_rng(23)
+    n = 30000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    exact = np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)
+    ok = np.all(np.abs(Lg - Lc) <= 1e-4 * np.abs(Lc) + 1e-6, axis=1)
+    print("guided paths (%d,%d): same segments %.5f within tol %.5f bit-identical %.5f" % (stype, vtype, np.mean(sg == sc), ok.mean(), exact.mean()))
+    assert np.mean(sg == sc) >= 0.998 and ok.mean() >= 0.998
+    for w in range(4):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fg, fc = g.film(), c.film()
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    relmse = np.mean((ig - ic) ** 2 / (ic ** 2 + 1e-4))
+    print("guided film relMSE %.3e" % relmse)
+    assert relmse <= 1e-4
+    g.close()
+    c.close()

@@ -308,6 +308,25 @@ class Renderer:
                                                                   C.byref(volume.pod) if volume else None, _vp(stream or 0)))
 
 
+def _guiding_query(self, is_volume, g, p, n_or_wo, wi, u):
+    import numpy as np
+    fp = _P(C.c_float)
+    p, a, wi, u = (np.ascontiguousarray(x, dtype=np.float32) for x in (p, n_or_wo, wi, u))
+    n = p.shape[0]
+    ok = np.zeros(n, dtype=np.int32)
+    pdf, inc, vsp, pdfs = (np.zeros(n, dtype=np.float32) for _ in range(4))
+    ws = np.zeros((n, 3), dtype=np.float32)
+    _check(self.lib, self.lib.vspg_guiding_query_batch(self.h, int(is_volume), float(g), n, p.ctypes.data_as(fp),
+                                                       a.ctypes.data_as(fp), wi.ctypes.data_as(fp), u.ctypes.data_as(fp),
+                                                       ok.ctypes.data_as(_P(C.c_int32)), pdf.ctypes.data_as(fp),
+                                                       inc.ctypes.data_as(fp), vsp.ctypes.data_as(fp), ws.ctypes.data_as(fp),
+                                                       pdfs.ctypes.data_as(fp), _vp(0)))
+    return dict(ok=ok, pdf=pdf, incoming_pdf=inc, vsp=vsp, ws=ws, pdf_s=pdfs)
+
+
+Renderer.guiding_query_batch = _guiding_query
+
+
 class Field:
     """Host-side container of a guiding field (kd-tree nodes + regions) keeping the arrays alive."""
 

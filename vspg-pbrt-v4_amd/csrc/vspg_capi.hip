@@ -55,7 +55,7 @@ __device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t 
 //   path state = registers for the whole life of a path (no HBM round trip per segment);
 //   items are tile-ordered (8x8 pixels per 64 items) so a fresh wavefront starts on one coherent
 //   tile of primary rays.
-template <class Medium>
+template <class Medium, bool GUIDED>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
                                                         float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
                                                         int vsp_ready, int wave_start, int wave_end,
@@ -83,6 +83,13 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
         maj_ptr = s_maj;
     }
     const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
+    // guided builds: the per-lane product mixture of the guiding cache (5 floats x 8 lobes) lives in
+    // LDS, element e of lane t at s_gmix[e * kBlock + t] (conflict-free)
+    float *glds = nullptr;
+    if constexpr (GUIDED) {
+        __shared__ float s_gmix[kBlock * 5 * GK];
+        glds = s_gmix + threadIdx.x;
+    }
     PathCounters pc = {0, 0, 0, 0, 0};
     uint32_t paths = 0;
 
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
         }
         // ---- one path segment for every live lane ----------------------------------------------
         if (has) {
-            const bool alive = li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc);
+            const bool alive = li_segment<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, glds, kBlock);
             if (!alive) {
                 VSPG_PROF(PS_FINISH);
                 const Spec L = finish_radiance(st.L);
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     flush_counters(pc, paths, counters);
 }
 
-template <class Medium>
+template <class Medium, bool GUIDED>
 __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict__ Sp, const float *__restrict__ vsp_buf,
                                                         int vsp_ready, int n, const int32_t *__restrict__ pixel_xy,
                                                         const int32_t *__restrict__ sample_index, float *__restrict__ out_L,
@@ -173,8 +180,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict
     PathState st;
     IsgSample isg;
     int ch;
+    float *glds = nullptr;
+    if constexpr (GUIDED) {
+        __shared__ float s_gmix[kBlock * 5 * GK];
+        glds = s_gmix + threadIdx.x;
+    }
     start_path(S, vsp_buf, vsp_ready, px, py, sample_index[i], sampler, st, &ch, isg);
-    while (li_segment(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc)) {
+    while (li_segment<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, glds, kBlock)) {
     }
     Spec L = finish_radiance(st.L);
     out_L[3 * i] = L.r; out_L[3 * i + 1] = L.g; out_L[3 * i + 2] = L.b;
@@ -242,6 +254,32 @@ __global__ __launch_bounds__(kBlock) void k_primitives(int n, const float *__res
     r.set_sequence(hash_float(f[i]), hash_float(g[i]));
     rng_u32[i] = r.u32();
     fexp[i] = fast_exp(f[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_guiding_query(const DScene *__restrict__ Sp, int is_volume, float g, int n,
+                                                          const float *__restrict__ p, const float *__restrict__ a,
+                                                          const float *__restrict__ wi, const float *__restrict__ u,
+                                                          int32_t *__restrict__ ok, float *__restrict__ pdf,
+                                                          float *__restrict__ inc, float *__restrict__ vsp,
+                                                          float *__restrict__ ws, float *__restrict__ pdfs) {
+    __shared__ float s_gmix[kBlock * 5 * GK];
+    const DScene &S = *Sp;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float *glds = s_gmix + threadIdx.x;
+    V3 pp = ld3(p + 3 * i), aa = ld3(a + 3 * i), w = ld3(wi + 3 * i);
+    GDist d = is_volume ? gdist_init_volume(S.field, pp, aa, g, glds, kBlock) : gdist_init_surface(S.field, pp, aa, glds, kBlock);
+    ok[i] = d.ok ? 1 : 0;
+    pdf[i] = inc[i] = pdfs[i] = 0;
+    vsp[i] = -1;
+    ws[3 * i] = ws[3 * i + 1] = ws[3 * i + 2] = 0;
+    if (!d.ok) return;
+    pdf[i] = gdist_pdf(d, w);
+    inc[i] = gdist_incoming_pdf(S.field, d, w);
+    vsp[i] = gdist_vsp(S.field, d.field, d.region, d.p, w);
+    V3 s;
+    pdfs[i] = gdist_sample(d, u[2 * i], u[2 * i + 1], &s);
+    ws[3 * i] = s.x; ws[3 * i + 1] = s.y; ws[3 * i + 2] = s.z;
 }
 
 __global__ __launch_bounds__(kBlock) void k_libm(int n, const float *__restrict__ x, float *__restrict__ lo,
@@ -314,6 +352,9 @@ struct VspgRenderer {
     float *vsp = nullptr;
     unsigned long long *counters = nullptr;
     unsigned int *work_head = nullptr;
+    VspgKdNode *fnodes[2] = {nullptr, nullptr};        // guiding fields (device copies)
+    VspgFieldRegion *fregions[2] = {nullptr, nullptr};
+    bool field_set = false;
     float *density = nullptr;   // GridMedium density samples
     float *majorant = nullptr;  // 16^3 majorant grid
     int num_cus = 0;
@@ -464,6 +505,10 @@ static std::vector<float> build_majorant_grid(const VspgMedium &m) {
     return maj;
 }
 
+static bool wants_guiding(const VspgIntegratorParams &p) {
+    return p.surfaceguiding || p.volumeguiding || (p.vspguiding && p.vspsecondaryguiding);
+}
+
 static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const VspgRenderConfig *cfg) {
     if (!scene || !p || !cfg) return fail(VSPG_EINVAL, "null argument");
     if (cfg->xres <= 0 || cfg->yres <= 0) return fail(VSPG_EINVAL, "film resolution must be positive");
@@ -474,10 +519,6 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
     if (p->collisionProbabilityBias) return fail(VSPG_ESCOPE, "collisionProbabilityBias (NDS+ / TrBuffer) is outside the hot-path scope");
     if (p->rrguiding) return fail(VSPG_ESCOPE, "rrguiding (guided Russian roulette) is outside the hot-path scope");
-    if (p->surfaceguiding || p->volumeguiding || (p->vspguiding && p->vspsecondaryguiding))
-        return fail(VSPG_ESCOPE,
-                    "directional guiding / secondary-ray VSP need the OpenPGL-style guiding cache, which this build does "
-                    "not provide yet: set surfaceguiding, volumeguiding and vspsecondaryguiding to false");
     if (scene->medium.type == VSPG_MEDIUM_GRID) {
         const VspgMedium &m = scene->medium;
         if (m.nx <= 0 || m.ny <= 0 || m.nz <= 0 || !m.density) return fail(VSPG_EINVAL, "grid medium needs nx,ny,nz > 0 and a density array");
@@ -654,6 +695,10 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->vsp) (void)hipFree(r->vsp);
     if (r->counters) (void)hipFree(r->counters);
     if (r->work_head) (void)hipFree(r->work_head);
+    for (int f = 0; f < 2; ++f) {
+        if (r->fnodes[f]) (void)hipFree(r->fnodes[f]);
+        if (r->fregions[f]) (void)hipFree(r->fregions[f]);
+    }
     if (r->density) (void)hipFree(r->density);
     if (r->majorant) (void)hipFree(r->majorant);
     delete r;
@@ -683,14 +728,21 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const int n_samples = (wave_end - 1 - first) / sc + 1;
     const PcgJump jump = pcg_jump((unsigned long long)first * 65536ull);
     HIPCHK(hipMemsetAsync(r->work_head, 0, sizeof(unsigned int), (hipStream_t)stream));
-    if (r->scene.medium.type == VSPG_MEDIUM_GRID)
-        hipLaunchKernelGGL(k_render_wave<GridMedium>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,
-                           r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first, n_samples == 1 ? 1 : 0,
-                           jump, static_per_wave, dyn_base, r->work_head, r->counters);
-    else
-        hipLaunchKernelGGL(k_render_wave<HomogeneousMedium>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
-                           r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first,
-                           n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, r->work_head, r->counters);
+    const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
+    const bool guided = wants_guiding(r->prm);
+    if (guided && !r->field_set)
+        return fail(VSPG_ESCOPE,
+                    "surfaceguiding / volumeguiding / vspsecondaryguiding are enabled but no guiding field was uploaded "
+                    "(vspg_renderer_set_guiding_field); on-device field training is not built yet");
+#define VSPG_LAUNCH_RENDER(M, G)                                                                                          \
+    hipLaunchKernelGGL((k_render_wave<M, G>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,    \
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first, n_samples == 1 ? 1 : 0, \
+                       jump, static_per_wave, dyn_base, r->work_head, r->counters)
+    if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
+    else if (grid) VSPG_LAUNCH_RENDER(GridMedium, false);
+    else if (guided) VSPG_LAUNCH_RENDER(HomogeneousMedium, true);
+    else VSPG_LAUNCH_RENDER(HomogeneousMedium, false);
+#undef VSPG_LAUNCH_RENDER
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -791,12 +843,17 @@ int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy, const int3
     HIPCHK(hipMalloc(&dg.p, (size_t)n * sizeof(int32_t)));
     HIPCHK(hipMemcpyAsync(dp.p, pixel_xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(ds.p, sample_index, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (r->scene.medium.type == VSPG_MEDIUM_GRID)
-        hipLaunchKernelGGL(k_trace_paths<GridMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp,
-                           r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p);
-    else
-        hipLaunchKernelGGL(k_trace_paths<HomogeneousMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp,
-                           r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p);
+    const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
+    const bool guided = wants_guiding(r->prm);
+    if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but no guiding field uploaded");
+#define VSPG_LAUNCH_TRACE(M, G)                                                                                       \
+    hipLaunchKernelGGL((k_trace_paths<M, G>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp, \
+                       r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p)
+    if (grid && guided) VSPG_LAUNCH_TRACE(GridMedium, true);
+    else if (grid) VSPG_LAUNCH_TRACE(GridMedium, false);
+    else if (guided) VSPG_LAUNCH_TRACE(HomogeneousMedium, true);
+    else VSPG_LAUNCH_TRACE(HomogeneousMedium, false);
+#undef VSPG_LAUNCH_TRACE
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_L, dl.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (out_segments) HIPCHK(hipMemcpyAsync(out_segments, dg.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -849,6 +906,75 @@ int vspg_primitives_batch(VspgRenderer *r, int n, const float *f, const float *g
     HIPCHK(hipMemcpyAsync(hash, dh.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(rng_u32, du.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(fastexp, de.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int upload_field(VspgRenderer *r, int f, const VspgField *src, hipStream_t s) {
+    if (r->fnodes[f]) { (void)hipFree(r->fnodes[f]); r->fnodes[f] = nullptr; }
+    if (r->fregions[f]) { (void)hipFree(r->fregions[f]); r->fregions[f] = nullptr; }
+    r->hscene.field[f] = DField{0, 0, nullptr, nullptr};
+    if (!src || src->n_nodes <= 0 || src->n_regions <= 0) return 0;
+    if (!src->nodes || !src->regions) return fail(VSPG_EINVAL, "guiding field without node / region arrays");
+    for (int i = 0; i < src->n_nodes; ++i) {  // structural check: children after their parent, leaves in range
+        uint32_t axis = src->nodes[i].packed & 3u, idx = src->nodes[i].packed >> 2;
+        if (axis == 3u ? (int)idx >= src->n_regions : ((int)idx + 1 >= src->n_nodes || (int)idx <= i))
+            return fail(VSPG_EINVAL, "malformed guiding-field kd-tree");
+    }
+    for (int i = 0; i < src->n_regions; ++i)
+        if (src->regions[i].n_lobes < 0 || src->regions[i].n_lobes > VSPG_FIELD_LOBES)
+            return fail(VSPG_EINVAL, "guiding-field region with an invalid lobe count");
+    HIPCHK(hipMalloc(&r->fnodes[f], sizeof(VspgKdNode) * src->n_nodes));
+    HIPCHK(hipMalloc(&r->fregions[f], sizeof(VspgFieldRegion) * src->n_regions));
+    HIPCHK(hipMemcpyAsync(r->fnodes[f], src->nodes, sizeof(VspgKdNode) * src->n_nodes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(r->fregions[f], src->regions, sizeof(VspgFieldRegion) * src->n_regions, hipMemcpyHostToDevice, s));
+    r->hscene.field[f] = DField{src->n_nodes, src->n_regions, r->fnodes[f], r->fregions[f]};
+    return 0;
+}
+
+int vspg_renderer_set_guiding_field(VspgRenderer *r, const VspgField *surface_field, const VspgField *volume_field,
+                                    void *stream) {
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipStreamSynchronize(s));  // no launch may still read the old field
+    int rc = upload_field(r, 0, surface_field, s);
+    if (rc) return rc;
+    rc = upload_field(r, 1, volume_field, s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    r->field_set = true;
+    return 0;
+}
+
+int vspg_guiding_query_batch(VspgRenderer *r, int is_volume, float g, int n, const float *p, const float *n_or_wo,
+                             const float *wi, const float *u, int32_t *out_ok, float *out_pdf, float *out_incoming_pdf,
+                             float *out_vsp, float *out_ws, float *out_pdf_s, void *stream) {
+    if (!r || n < 0 || (n > 0 && (!p || !n_or_wo || !wi || !u || !out_ok || !out_pdf || !out_incoming_pdf || !out_vsp || !out_ws || !out_pdf_s)))
+        return fail(VSPG_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dp, da, dw, du, dok, dpdf, dinc, dvsp, dws, dps;
+    const size_t n3 = (size_t)n * 3 * 4, n2 = (size_t)n * 2 * 4, n1 = (size_t)n * 4;
+    HIPCHK(hipMalloc(&dp.p, n3)); HIPCHK(hipMalloc(&da.p, n3)); HIPCHK(hipMalloc(&dw.p, n3)); HIPCHK(hipMalloc(&du.p, n2));
+    HIPCHK(hipMalloc(&dok.p, n1)); HIPCHK(hipMalloc(&dpdf.p, n1)); HIPCHK(hipMalloc(&dinc.p, n1)); HIPCHK(hipMalloc(&dvsp.p, n1));
+    HIPCHK(hipMalloc(&dws.p, n3)); HIPCHK(hipMalloc(&dps.p, n1));
+    HIPCHK(hipMemcpyAsync(dp.p, p, n3, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(da.p, n_or_wo, n3, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dw.p, wi, n3, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(du.p, u, n2, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_guiding_query, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, is_volume, g, n,
+                       (const float *)dp.p, (const float *)da.p, (const float *)dw.p, (const float *)du.p, (int32_t *)dok.p,
+                       (float *)dpdf.p, (float *)dinc.p, (float *)dvsp.p, (float *)dws.p, (float *)dps.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_ok, dok.p, n1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_pdf, dpdf.p, n1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_incoming_pdf, dinc.p, n1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_vsp, dvsp.p, n1, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_ws, dws.p, n3, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out_pdf_s, dps.p, n1, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }

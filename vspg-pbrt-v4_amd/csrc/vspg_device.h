@@ -452,8 +452,15 @@ struct IsectRec {
     int32_t kind;   // 0 generic, 1 axis-aligned
     int32_t axes;   // axis | uaxis << 2 | vaxis << 4
 };
+// guiding field in HBM (see vspg_guiding.h): [0] surface, [1] volume; nodes == nullptr -> untrained
+struct DField {
+    int32_t n_nodes, n_regions;
+    const VspgKdNode *nodes;
+    const VspgFieldRegion *regions;
+};
 struct DScene {
     int32_t n_quads, n_lights;
+    DField field[2];
     IsectRec irec[VSPG_MAX_QUADS];
     int32_t light_quads[VSPG_MAX_QUADS];
     DQuad quads[VSPG_MAX_QUADS];

@@ -1,0 +1,188 @@
+// vspg_guiding.h -- device-side guiding-cache query.
+//
+// The wrapper logic (GuidedBSDF / GuidedPhaseFunction: init, MIS / RIS sampling, PDF,
+// VolumeScatterProbability) follows src/pbrt/cpu/guiding.h:57-638 and lives in vspg_path.h.  This
+// file is what sits behind the OpenPGL calls those wrappers make -- OpenPGL is absent from the
+// reference tree, so it is this build's own design (parity unpinned):
+//   Init(field, p, rand)                  kd-tree descent to the leaf region containing p
+//   parallax-aware vMF mixture            lobe k re-aimed at pivot + distance_k * mu_k
+//   ApplyCosineProduct(n)                 closed-form product with a kappa = 2.18853 vMF around n
+//   ApplySingleLobeHenyeyGreensteinProduct closed-form product with a vMF of mean cosine |g|
+//   PDF / SamplePDF / IncomingRadiancePDF / VolumeScatterProbability
+// Layout: kd nodes (8 B) and regions (240 B) in HBM, read through L2; the per-lane PRODUCT mixture
+// (5 floats x 8 lobes) lives in LDS for the lifetime of a vertex, strided by the workgroup size so
+// that lanes hit distinct banks.  Arithmetic uses +,-,*,/,sqrt, FastExp and the host-exact
+// logf/sinf/cosf only, in the same order as the CPU checker, so results are bit-identical.
+#pragma once
+#include "vspg_device.h"
+
+namespace vspg {
+
+constexpr int GK = VSPG_FIELD_LOBES;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr float kCosineLobeKappa = 2.18853f;
+constexpr float kGuidingProbability = 0.5f;  // guiding.h:348, 628
+constexpr float kUniformIncomingRadiancePDF = (float)(1.0f / (4.0f * 3.14159265358979323846));  // guiding.h:179
+
+VDEV float vmf_norm(float kappa) { return kappa / (kTwoPi * (1 - fast_exp(-2 * kappa))); }
+VDEV float vmf_eval(V3 mu, float kappa, V3 w) { return vmf_norm(kappa) * fast_exp(kappa * (dot(mu, w) - 1)); }
+VDEV float kappa_clamp(float k) { return k < 1e-2f ? 1e-2f : (k > 1e4f ? 1e4f : k); }
+
+VDEV int field_lookup(const DField &F, V3 p) {
+    if (!F.nodes || F.n_nodes <= 0) return -1;
+    uint32_t node = 0;
+    for (int depth = 0; depth < 64; ++depth) {
+        VspgKdNode nd = F.nodes[node];
+        uint32_t axis = nd.packed & 3u, idx = nd.packed >> 2;
+        if (axis == 3u) return (int)idx < F.n_regions ? (int)idx : -1;
+        float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+        node = idx + (c < nd.split ? 0u : 1u);
+        if ((int)node >= F.n_nodes) return -1;
+    }
+    return -1;
+}
+VDEV V3 lobe_dir(const VspgFieldRegion &R, int k, V3 p) {
+    V3 mu = V3{R.mu[0][k], R.mu[1][k], R.mu[2][k]};
+    float d = R.distance[k];
+    if (!(d > 0) || isinf_(d)) return mu;
+    V3 src = ld3(R.pivot) + mu * d;
+    V3 t = src - p;
+    float l2 = len2(t);
+    if (!(l2 > 0)) return mu;
+    return normalize(t);
+}
+VDEV void lobe_product(V3 mu, float kappa, float w, V3 m2, float k2, V3 *mo, float *ko, float *wo) {
+    V3 s = mu * kappa + m2 * k2;
+    float kp = len(s);
+    if (!(kp > 1e-6f)) {
+        *mo = mu;
+        *ko = 1e-2f;
+        *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(1e-2f)) * fast_exp(1e-2f - kappa - k2);
+        return;
+    }
+    float kc = kappa_clamp(kp);
+    *mo = V3{s.x / kp, s.y / kp, s.z / kp};
+    *ko = kc;
+    *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(kc)) * fast_exp(kp - kappa - k2);
+}
+
+// per-lane product mixture in LDS: element e of lobe k at lds[(e * GK + k) * stride]
+struct GDist {
+    bool ok;
+    int field, region, n;
+    V3 p;
+    float *lds;
+    int stride;
+    VDEV float &w(int k) const { return lds[(0 * GK + k) * stride]; }
+    VDEV float &kappa(int k) const { return lds[(1 * GK + k) * stride]; }
+    VDEV V3 mu(int k) const { return V3{lds[(2 * GK + k) * stride], lds[(3 * GK + k) * stride], lds[(4 * GK + k) * stride]}; }
+    VDEV void set_mu(int k, V3 m) const {
+        lds[(2 * GK + k) * stride] = m.x;
+        lds[(3 * GK + k) * stride] = m.y;
+        lds[(4 * GK + k) * stride] = m.z;
+    }
+};
+
+VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m2, float k2, float *lds, int stride) {
+    GDist d;
+    d.ok = false;
+    d.field = f;
+    d.p = p;
+    d.n = 0;
+    d.lds = lds;
+    d.stride = stride;
+    d.region = field_lookup(fields[f], p);
+    if (d.region < 0) return d;
+    const VspgFieldRegion &R = fields[f].regions[d.region];
+    if (R.n_lobes <= 0) return d;
+    d.ok = true;
+    d.n = R.n_lobes < GK ? R.n_lobes : GK;
+    float sum = 0;
+    for (int k = 0; k < d.n; ++k) {
+        V3 mu = lobe_dir(R, k, p);
+        float kap = kappa_clamp(R.kappa[k]);
+        V3 mo = mu;
+        float ko = kap, wo = R.weight[k];
+        if (have_product) lobe_product(mu, kap, R.weight[k], m2, k2, &mo, &ko, &wo);
+        d.set_mu(k, mo);
+        d.kappa(k) = ko;
+        d.w(k) = wo;
+        sum += wo;
+    }
+    if (sum > 0 && !isinf_(sum)) {
+        for (int k = 0; k < d.n; ++k) d.w(k) = d.w(k) / sum;
+    } else {
+        for (int k = 0; k < d.n; ++k) {
+            d.set_mu(k, lobe_dir(R, k, p));
+            d.kappa(k) = kappa_clamp(R.kappa[k]);
+            d.w(k) = R.weight[k];
+        }
+    }
+    return d;
+}
+VDEV GDist gdist_init_surface(const DField *fields, V3 p, V3 n, float *lds, int stride) {
+    return gdist_init(fields, 0, p, true, n, kCosineLobeKappa, lds, stride);
+}
+VDEV GDist gdist_init_volume(const DField *fields, V3 p, V3 dir, float g, float *lds, int stride) {
+    float ag = __builtin_fabsf(g);
+    if (ag < 1e-3f) return gdist_init(fields, 1, p, false, mk(0, 0, 1), 0, lds, stride);
+    if (ag > 0.99f) ag = 0.99f;
+    float kg = ag * (3 - ag * ag) / (1 - ag * ag);
+    V3 axis = g > 0 ? dir : -dir;
+    return gdist_init(fields, 1, p, true, normalize(axis), kg, lds, stride);
+}
+VDEV float gdist_pdf(const GDist &d, V3 w) {
+    float s = 0;
+    for (int k = 0; k < d.n; ++k) s += d.w(k) * vmf_eval(d.mu(k), d.kappa(k), w);
+    return s;
+}
+VDEV float gdist_incoming_pdf(const DField *fields, const GDist &d, V3 w) {
+    const VspgFieldRegion &R = fields[d.field].regions[d.region];
+    float s = 0;
+    for (int k = 0; k < d.n; ++k) s += R.weight[k] * vmf_eval(lobe_dir(R, k, d.p), kappa_clamp(R.kappa[k]), w);
+    return s;
+}
+VDEV float gdist_vsp(const DField *fields, int f, int region, V3 p, V3 w) {
+    const VspgFieldRegion &R = fields[f].regions[region];
+    int n = R.n_lobes < GK ? R.n_lobes : GK;
+    float num = 0, den = 0;
+    for (int k = 0; k < n; ++k) {
+        float e = R.weight[k] * vmf_eval(lobe_dir(R, k, p), kappa_clamp(R.kappa[k]), w);
+        num += e * R.vsp[k];
+        den += e;
+    }
+    if (!(den > 0)) return -1.f;
+    return num / den;
+}
+VDEV float gdist_sample(const GDist &d, float u0, float u1, V3 *wi) {
+    int k = 0;
+    float acc = 0;
+    for (; k < d.n - 1; ++k) {
+        float wk = d.w(k);
+        if (u0 < acc + wk) break;
+        acc += wk;
+    }
+    float wk = d.w(k);
+    float uw = wk > 0 ? (u0 - acc) / wk : 0.f;
+    uw = uw < 0 ? 0 : (uw > kOneMinusEps ? kOneMinusEps : uw);
+    float kap = d.kappa(k);
+    float W = 1 + logf_(uw + (1 - uw) * fast_exp(-2 * kap)) / kap;
+    W = clampf(W, -1, 1);
+    float sinT = safe_sqrt(1 - W * W);
+    float phi = kTwoPi * u1;
+    Frame fr;
+    fr.z = d.mu(k);
+    coordinate_system(fr.z, &fr.x, &fr.y);
+    *wi = fr.from_local(V3{sinT * cosf_(phi), sinT * sinf_(phi), W});
+    return gdist_pdf(d, *wi);
+}
+
+// GuidedBSDF / GuidedPhaseFunction state that outlives the vertex: what the NEXT segment's
+// VolumeScatterProbability(ray.d) needs (guiding.h:295-305, 564-574)
+struct GuideState {
+    bool useScatterGuiding;
+    int field, region;
+    V3 p;
+};
+
+}  // namespace vspg

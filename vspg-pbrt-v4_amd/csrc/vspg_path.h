@@ -2,6 +2,7 @@
 // (reference: src/pbrt/cpu/guidedvolpathvspgintegrator.cpp; citations per function)
 #pragma once
 #include "vspg_device.h"
+#include "vspg_guiding.h"
 
 namespace vspg {
 
@@ -134,7 +135,7 @@ struct Intr {
 };
 template <class Medium>
 VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, const Bsdf *bsdf, int ch,
-                    Sampler &sampler, Spec r_p, PathCounters &pc) {
+                    Sampler &sampler, Spec r_p, PathCounters &pc, const GDist *gd = nullptr) {
     V3 ctxp = intr.pi.mid();
     if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
     float u = sampler.get1d();
@@ -157,13 +158,18 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     float scatterPDF;
     Spec f_hat;
     V3 wo = intr.wo, wi = ls.wi;
+    // GuidedBSDF::PDF / GuidedPhaseFunction::PDF (guiding.h:271-289, 542-558); gd != nullptr iff useGuiding
     if (intr.is_surface) {
         f_hat = bsdf_f(*bsdf, wo, wi) * absdot(wi, intr.n);
-        scatterPDF = 1.0f * bsdf_pdf(*bsdf, wo, wi);
+        float bsdfPDF = bsdf_pdf(*bsdf, wo, wi);
+        if (gd) bsdfPDF = ((1.0f - kGuidingProbability) * bsdfPDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        scatterPDF = 1.0f * bsdfPDF;
     } else {
         float p = henyey_greenstein(dot(wo, wi), intr.g);
         f_hat = sp(p);
-        scatterPDF = 1.0f * p;
+        float phasePDF = p;
+        if (gd) phasePDF = ((1.0f - kGuidingProbability) * phasePDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        scatterPDF = 1.0f * phasePDF;
     }
     if (!nonzero(f_hat)) return sp(0.f);
 
@@ -224,17 +230,25 @@ struct PathState {
     bool specularBounce, anyNonSpecularBounces, lastVertexVolume;
     float rr_correction, etaScale;
     float vsp0;  // primary-ray VSP of this pixel, loaded when the path starts (hides the HBM latency)
+    GuideState gs;  // guided builds only: the previous vertex's distribution for the secondary-ray VSP
 };
 
 // VSP fetch (:654-671, :1098-1134).  Secondary-ray VSP comes from the guiding cache, which is
 // untrained in the configurations this build accepts -> VolumeScatterProbability() == -1
 // (guiding.h:295-298, 564-567).
-VDEV float fetch_vsp(const DScene &S, float vsp0, int depth, bool *guide) {
+template <bool GUIDED>
+VDEV float fetch_vsp(const DScene &S, const PathState &st, bool *guide) {
     float vsp = -1.f;
     *guide = false;
-    if (depth == 0) {
+    if (st.depth == 0) {
         if (S.prm.vspguiding && S.prm.vspprimaryguiding) {
-            vsp = vsp0;  // imageSpaceGuidingBuffer estimate, or 0.5 before the first update (:1101-1105)
+            vsp = st.vsp0;  // imageSpaceGuidingBuffer estimate, or 0.5 before the first update (:1101-1105)
+            *guide = !(isnan_(vsp) || vsp < 0.f || vsp > 1.f);
+        }
+    } else if constexpr (GUIDED) {
+        if (S.prm.vspguiding && S.prm.vspsecondaryguiding) {
+            // g{phase,bsdf}.VolumeScatterProbability(ray.d) of the PREVIOUS vertex (:661-668)
+            vsp = st.gs.useScatterGuiding ? gdist_vsp(S.field, st.gs.field, st.gs.region, st.gs.p, st.rd) : -1.f;
             *guide = !(isnan_(vsp) || vsp < 0.f || vsp > 1.f);
         }
     }
@@ -258,7 +272,7 @@ struct DistEvent {
     float g;  // HG asymmetry of the phase function at p
 };
 
-template <class Medium>
+template <class Medium, bool GUIDED>
 VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
                                PathState &st, float tMax, int ch, Sampler &sampler, Rng &rng, IsgSample &isg,
                                PathCounters &pc) {
@@ -267,7 +281,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
     ev.p = mk(0, 0, 0);
     ev.g = 0;
     bool guide;
-    float vsp = fetch_vsp(S, st.vsp0, st.depth, &guide);
+    float vsp = fetch_vsp<GUIDED>(S, st, &guide);
     if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
 
     bool use_resampling = S.prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && !medium.is_homogeneous();
@@ -423,9 +437,14 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
 // one iteration of the Li path loop (:309-609): returns false when the path ends.
 // Surface vertices (:376-608) and volume vertices (the scatter tail) share the NEE code.
 // ---------------------------------------------------------------------------------------
-template <class Medium>
+template <class Medium, bool GUIDED>
+VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
+                           bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride);
+
+template <class Medium, bool GUIDED = false>
 VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
-                     PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc) {
+                     PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc, float *glds = nullptr,
+                     int gstride = 0) {
     VSPG_PROF(PS_SEGMENT);
     pc.segments++;
     Isect si;
@@ -445,7 +464,7 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
             uint64_t hash1 = hash_float(sampler.get1d());
             rng.set_sequence(hash0, hash1);
         }
-        DistEvent ev = sample_distance(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
+        DistEvent ev = sample_distance<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
         if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return false;  // :343-344
         if (ev.kind == EV_SCATTER) {
             volume_vertex = true;
@@ -493,6 +512,9 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         intr.wo = normalize(-st.rd);  // Interaction ctor normalises wo (interaction.h:31-32)
         intr.g = 0;
     }
+
+    if constexpr (GUIDED)
+        return li_vertex_guided<Medium, GUIDED>(S, medium, st, ch, sampler, pc, volume_vertex, vp, vg, si, intr, bsdf, glds, gstride);
 
     (void)sampler.get1d();  // v: gbsdf.init / gphase.init with an untrained field (:457-458, :809-810)
     if (volume_vertex && st.depth > S.prm.minrrdepth) {  // :817-830: survival probability BEFORE the NEE
@@ -581,6 +603,251 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
     return true;
 }
 
+// ---------------------------------------------------------------------------------------
+// vertex processing with the guiding cache active (guided kernel instantiations only):
+// gbsdf.init / gphase.init, NEE with the guided PDF, MIS / RIS sampling (guiding.h:83-109, 120-269,
+// 383-398, 404-540) -- same flow as the unguided tail of li_segment, written straight (no sin/cos
+// fusion) because the sampling branches differ per guiding type.
+// ---------------------------------------------------------------------------------------
+template <class Medium, bool GUIDED>
+VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
+                           bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride) {
+    (void)sampler.get1d();  // v (the stochastic-lookup sample of Init)
+    GDist gd;
+    bool useGuiding;
+    float survivalProb = 1.f;
+    if (volume_vertex) {
+        gd = gdist_init_volume(S.field, vp, st.rd, vg, glds, gstride);  // gphase.init(&phase, p, ray.d, v)
+        useGuiding = S.prm.volumeguiding ? gd.ok : false;
+        st.gs.useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
+        st.gs.field = 1;
+        st.gs.region = gd.region;
+        st.gs.p = vp;
+        if (st.depth > S.prm.minrrdepth) {
+            Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction;
+            survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+        }
+    } else {
+        gd.ok = false;
+        gd.region = -1;
+        V3 pg = st.ro + st.rd * si.t;  // p = ray.o + si->tHit * ray.d (guiding.h:85)
+        if (bsdf.has_lobes) {
+            V3 ng = si.n;
+            if (dot(-st.rd, si.n) < 0.f) ng = -ng;
+            gd = gdist_init_surface(S.field, pg, ng, glds, gstride);
+        }
+        useGuiding = S.prm.surfaceguiding ? gd.ok : false;
+        st.gs.useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
+        st.gs.field = 0;
+        st.gs.region = gd.region;
+        st.gs.p = pg;
+    }
+    if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {
+        Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, useGuiding ? &gd : nullptr);
+        st.L = st.L + st.beta * Ld;
+    }
+
+    if (volume_vertex) {
+        if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
+            float q = fmax_(0.f, 1 - survivalProb);
+            if (sampler.get1d() < q) return false;
+            st.beta = st.beta / (1 - q);
+        }
+        float u0 = sampler.get1d(), u1 = sampler.get1d();
+        V3 wo = -st.rd;
+        float ps_p = 0, ps_pdf = 0;
+        V3 wi = mk(0, 0, 0);
+        bool have = false;
+        if (!useGuiding) {
+            wi = sample_henyey_greenstein(wo, vg, u0, u1, &ps_pdf);
+            ps_p = ps_pdf;
+            have = true;
+        } else if (S.prm.volumeguidingtype == VSPG_GUIDE_MIS) {  // Sample_p_MIS (guiding.h:404-445)
+            bool samplePhase = true;
+            if (kGuidingProbability > u0) {
+                u0 /= kGuidingProbability;
+                samplePhase = false;
+            } else {
+                u0 -= kGuidingProbability;
+                u0 /= (1.0f - kGuidingProbability);
+            }
+            if (samplePhase) {
+                wi = sample_henyey_greenstein(wo, vg, u0, u1, &ps_pdf);
+                ps_p = ps_pdf;
+                float guidedPDF = gdist_pdf(gd, wi);
+                ps_pdf = ((1.0f - kGuidingProbability) * ps_pdf) + (kGuidingProbability * guidedPDF);
+                have = true;
+            } else {
+                float guidedPDF = gdist_sample(gd, u0, u1, &wi);
+                float pp = henyey_greenstein(dot(wo, wi), vg);
+                if (pp > 0.f) {
+                    ps_p = pp;
+                    ps_pdf = ((1.0f - kGuidingProbability) * pp) + (kGuidingProbability * guidedPDF);
+                    have = true;
+                }
+            }
+        } else {  // Sample_p_RIS (guiding.h:447-530)
+            float rphase0, rp1;
+            V3 w0 = sample_henyey_greenstein(wo, vg, u0, u1, &rphase0);
+            float rguid0 = gdist_pdf(gd, w0);
+            float rinc0 = gdist_incoming_pdf(S.field, gd, w0);
+            float rmis0 = 0.5f * (rphase0 + rguid0);
+            float s0 = sampler.get1d(), s1 = sampler.get1d();
+            V3 w1;
+            float rguid1 = gdist_sample(gd, s0, s1, &w1);
+            float rinc1 = gdist_incoming_pdf(S.field, gd, w1);
+            rp1 = henyey_greenstein(dot(wo, w1), vg);
+            float rmis1 = 0.5f * (rp1 + rguid1);
+            float sumW = 0.f, rw0 = 0.f, rw1 = 0.f;
+            int nS = 0;
+            if (rphase0 > 0.f) {
+                rw0 = (rphase0 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc0));
+                rw0 /= rmis0;
+                sumW += rw0;
+                nS++;
+            }
+            if (rp1 > 0.f) {
+                rw1 = (rp1 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc1));
+                rw1 /= rmis1;
+                sumW += rw1;
+                nS++;
+            }
+            if (!(nS == 0 || sumW <= 0.f)) {
+                float sample1D = sumW * sampler.get1d();
+                // for (i < 2) { sumRis += w_i; if (sample1D <= sumRis) { idx = i; break; } }  (idx defaults to 0)
+                float sumR = 0.f + rw0;
+                int idx = 0;
+                if (!(sample1D <= sumR)) {
+                    sumR += rw1;
+                    if (sample1D <= sumR) idx = 1;
+                }
+                float rw = idx ? rw1 : rw0, rmis = idx ? rmis1 : rmis0;
+                ps_pdf = (rw * rmis) * ((float)2 / sumW);
+                ps_p = idx ? rp1 : rphase0;
+                wi = idx ? w1 : w0;
+                have = true;
+            }
+        }
+        if (!have || ps_pdf == 0) return false;
+        float w = ps_p / ps_pdf;
+        st.beta = st.beta * w;
+        st.r_l = st.r_u / ps_pdf;
+        st.prevCtx.pi = p3i_exact(vp);
+        st.prevCtx.n = mk(0, 0, 0);
+        st.ro = vp;
+        st.rd = wi;
+        st.specularBounce = false;
+        st.anyNonSpecularBounces = true;
+        st.lastVertexVolume = true;
+        return true;
+    }
+
+    st.prevCtx.pi = intr.pi;
+    st.prevCtx.n = si.n;
+    V3 wo = -st.rd;
+    float u = sampler.get1d();
+    float u20 = sampler.get1d(), u21 = sampler.get1d();
+    Spec f = sp(0.f);
+    V3 wi = mk(0, 0, 0);
+    float pdf = 0, bsdfPdf = 0, misPdf = 0;
+    bool have = false;
+    if (!useGuiding) {
+        have = bsdf_sample_f(bsdf, wo, u20, u21, &f, &wi, &pdf);
+        bsdfPdf = misPdf = pdf;
+    } else if (S.prm.surfaceguidingtype == VSPG_GUIDE_MIS) {  // Sample_f_MIS (guiding.h:120-167)
+        bool sampleBSDF = true;
+        if (kGuidingProbability > u) {
+            sampleBSDF = false;
+        }
+        if (sampleBSDF) {
+            have = bsdf_sample_f(bsdf, wo, u20, u21, &f, &wi, &pdf);
+            if (have) {
+                float guidedPDF = gdist_pdf(gd, wi);
+                bsdfPdf = pdf;
+                pdf = ((1.0f - kGuidingProbability) * pdf) + (kGuidingProbability * guidedPDF);
+                misPdf = pdf;
+            }
+        } else {
+            float guidedPDF = gdist_sample(gd, u20, u21, &wi);
+            f = bsdf_f(bsdf, wo, wi);
+            float bPDF = bsdf_pdf(bsdf, wo, wi);
+            if (bPDF > 0.f) {
+                pdf = ((1.0f - kGuidingProbability) * bPDF) + (kGuidingProbability * guidedPDF);
+                bsdfPdf = bPDF;
+                misPdf = pdf;
+                have = true;
+            }
+        }
+    } else {  // Sample_f_RIS (guiding.h:169-257)
+        Spec rf0 = sp(0.f), rf1;
+        V3 w0 = mk(0, 0, 0), w1;
+        float rb0 = 0, rguid0 = 0, rmis0 = 0, rinc0 = 0, p0;
+        if (bsdf_sample_f(bsdf, wo, u20, u21, &rf0, &w0, &p0)) {
+            rb0 = p0;
+            rguid0 = gdist_pdf(gd, w0);
+            rinc0 = gdist_incoming_pdf(S.field, gd, w0);
+            rmis0 = 0.5f * (rb0 + rguid0);
+        }
+        float s0 = sampler.get1d(), s1 = sampler.get1d();
+        float rguid1 = gdist_sample(gd, s0, s1, &w1);
+        float rinc1 = gdist_incoming_pdf(S.field, gd, w1);
+        rf1 = bsdf_f(bsdf, wo, w1);
+        float rb1 = bsdf_pdf(bsdf, wo, w1);
+        float rmis1 = 0.5f * (rb1 + rguid1);
+        float sumW = 0.f, rw0 = 0.f, rw1 = 0.f;
+        int nS = 0;
+        if (rb0 > 0.f) {
+            rw0 = (rb0 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc0));
+            rw0 /= rmis0;
+            sumW += rw0;
+            nS++;
+        }
+        if (rb1 > 0.f) {
+            rw1 = (rb1 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc1));
+            rw1 /= rmis1;
+            sumW += rw1;
+            nS++;
+        }
+        if (!(nS == 0 || sumW <= 0.f)) {
+            float sample1D = sumW * sampler.get1d();
+            float sumR = 0.f + rw0;
+            int idx = 0;
+            if (!(sample1D <= sumR)) {
+                sumR += rw1;
+                if (sample1D <= sumR) idx = 1;
+            }
+            float rw = idx ? rw1 : rw0;
+            misPdf = idx ? rmis1 : rmis0;
+            pdf = (rw * misPdf) * ((float)2 / sumW);
+            bsdfPdf = idx ? rb1 : rb0;
+            f = idx ? rf1 : rf0;
+            wi = idx ? w1 : w0;
+            have = true;
+        }
+    }
+    if (!have) return false;
+    st.lastVertexVolume = false;
+    st.rr_correction *= pdf / bsdfPdf;
+    Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
+    st.beta = st.beta * bsdfWeight;
+    st.r_l = st.r_u / misPdf;
+    st.specularBounce = false;
+    st.anyNonSpecularBounces = true;
+    st.ro = offset_ray_origin(intr.pi, si.n, wi);
+    st.rd = wi;
+    if (!nonzero(st.beta)) return false;
+    if (st.depth > S.prm.minrrdepth) {
+        Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;
+        survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+    }
+    if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
+        float qq = fmax_(0.f, 1 - survivalProb);
+        if (sampler.get1d() < qq) return false;
+        st.beta = st.beta / (1 - qq);
+    }
+    return true;
+}
+
 // EvaluatePixelSample up to the camera ray (src/pbrt/cpu/integrators.cpp:272-304)
 VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, PathState &st, int *ch, IsgSample &isg);
 VDEV void start_path(const DScene &S, const float *vsp_buf, int vsp_ready, int px, int py, int sampleIndex, Sampler &sampler,
@@ -624,6 +891,10 @@ VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, P
     st.lastVertexVolume = false;
     st.rr_correction = 1.0f;
     st.etaScale = 1;
+    st.gs.useScatterGuiding = false;
+    st.gs.field = 0;
+    st.gs.region = 0;
+    st.gs.p = mk(0, 0, 0);
     isg.valid = false;
     isg.surface_event = false;
     isg.vsp_used = -1.f;
