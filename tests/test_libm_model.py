@@ -57,3 +57,19 @@ def test_sincos_equal_host_libm(shim, fn):
     check(shim, fn, (10.0 ** rng.uniform(-8, 0, 1_000_000)).astype(np.float32))
     edge = np.array([0.0, -0.0, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, 2.0 ** -12, float.fromhex('0x1.fffffep-13'), 119.99], dtype=np.float32)
     check(shim, fn, np.concatenate([edge, -edge, np.nextafter(edge, np.float32(10)), np.nextafter(edge, np.float32(-10))]))
+
+
+@pytest.mark.parametrize("fn", ["sinf", "cosf"])
+def test_sincos_exhaustive(shim, fn):
+    """every float in [2^-30, 8] and its negative (the path's angles lie in [-pi, 2 pi]); below 2^-30
+    sampled.  ~6e8 arguments per function, a few seconds each in C."""
+    lo, hi = np.float32(2.0 ** -30).view(np.uint32), np.float32(8.0).view(np.uint32)
+    step = 1 << 24
+    for start in range(int(lo), int(hi) + 1, step):
+        bits = np.arange(start, min(start + step, int(hi) + 1), dtype=np.uint32)
+        x = bits.view(np.float32)
+        check(shim, fn, x)
+        check(shim, fn, -x)
+    tiny = (2.0 ** np.random.default_rng(3).uniform(-126, -30, 2_000_000)).astype(np.float32)
+    check(shim, fn, tiny)
+    check(shim, fn, -tiny)

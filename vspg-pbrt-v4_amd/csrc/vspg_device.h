@@ -157,19 +157,19 @@ VDEV bool has_inf(Spec a) { return isinf_(a.r) || isinf_(a.g) || isinf_(a.b); }
 // ---------------------------------------------------------------------------------------
 VDEV uint32_t f2b(float f) { return __float_as_uint(f); }
 VDEV float b2f(uint32_t u) { return __uint_as_float(u); }
+// branch-free integer forms: identical results for every non-NaN input (the reference's branches
+// on +-inf and -0 become selects)
 VDEV float next_float_up(float v) {
-    if (isinf_(v) && v > 0.f) return v;
-    if (v == -0.f) v = 0.f;
     uint32_t ui = f2b(v);
-    if (v >= 0) ++ui; else --ui;
-    return b2f(ui);
+    ui = (ui == 0x80000000u) ? 0u : ui;                          // -0 -> +0
+    uint32_t r = ((int32_t)ui >= 0) ? ui + 1u : ui - 1u;         // v >= 0 ? ++ui : --ui
+    return b2f(ui == 0x7f800000u ? ui : r);                      // +inf stays
 }
 VDEV float next_float_down(float v) {
-    if (isinf_(v) && v < 0.f) return v;
-    if (v == 0.f) v = -0.f;
     uint32_t ui = f2b(v);
-    if (v > 0) --ui; else ++ui;
-    return b2f(ui);
+    ui = (ui == 0u) ? 0x80000000u : ui;                          // +0 -> -0
+    uint32_t r = ((int32_t)ui > 0) ? ui - 1u : ui + 1u;          // v > 0 ? --ui : ++ui
+    return b2f(ui == 0xff800000u ? ui : r);                      // -inf stays
 }
 
 // ---------------------------------------------------------------------------------------
@@ -293,12 +293,12 @@ VDEV float fast_exp(float x) {  // util/math.h:450-474 (CPU branch; NOT __expf)
     int i = (int)fxp;
     float twoToF = __builtin_fmaf(f, __builtin_fmaf(f, __builtin_fmaf(f, 0.0781455737f, 0.226173572f), 0.695556856f), 1.f);
     int exponent = (int)((f2b(twoToF) >> 23) & 0xff) - 127 + i;
-    if (exponent < -126) return 0;
-    if (exponent > 127) return kInf;
     uint32_t bits = f2b(twoToF);
     bits &= 0x807fffffu;
     bits |= (uint32_t)(exponent + 127) << 23;
-    return b2f(bits);
+    float r = b2f(bits);
+    r = exponent > 127 ? kInf : r;   // the reference's two early returns as selects
+    return exponent < -126 ? 0.f : r;
 }
 VDEV Spec fast_exp(Spec a) {
     if (__all(grey(a))) {  // wave-uniform grey fast path, see operator/
@@ -373,15 +373,12 @@ VDEV V3 sample_henyey_greenstein(V3 wo, float g, float u0, float u1, float *pdf)
 VDEV float cos_hemi_pre(float u0, float u1, float *r, bool *degenerate) {
     float ox = 2 * u0 - 1, oy = 2 * u1 - 1;
     *degenerate = (ox == 0 && oy == 0);
-    float theta;
-    if (__builtin_fabsf(ox) > __builtin_fabsf(oy)) {
-        *r = ox;
-        theta = kPiOver4 * (oy / ox);
-    } else {
-        *r = oy;
-        theta = kPiOver2 - kPiOver4 * (ox / oy);
-    }
-    return theta;
+    // both branches of the concentric map as one select (a single division)
+    const bool xmajor = __builtin_fabsf(ox) > __builtin_fabsf(oy);
+    const float q = (xmajor ? oy : ox) / (xmajor ? ox : oy);
+    *r = xmajor ? ox : oy;
+    const float t = kPiOver4 * q;
+    return xmajor ? t : kPiOver2 - t;
 }
 VDEV V3 cos_hemi_post(float r, bool degenerate, float sinT, float cosT) {
     float dx = degenerate ? 0.f : r * cosT;
@@ -406,12 +403,9 @@ struct P3i {
 };
 VDEV P3i p3i_exact(V3 p) { return P3i{p, p}; }
 VDEV void interval_ve(float v, float e, float *lo, float *hi) {
-    if (e == 0) {
-        *lo = *hi = v;
-    } else {
-        *lo = next_float_down(v - e);
-        *hi = next_float_up(v + e);
-    }
+    float l = next_float_down(v - e), h = next_float_up(v + e);
+    *lo = e == 0 ? v : l;
+    *hi = e == 0 ? v : h;
 }
 VDEV P3i p3i_from_err(V3 p, V3 e) {
     P3i r;
@@ -421,9 +415,8 @@ VDEV P3i p3i_from_err(V3 p, V3 e) {
     return r;
 }
 VDEV float offset_axis(float po, float off) {
-    if (off > 0) return next_float_up(po);
-    if (off < 0) return next_float_down(po);
-    return po;
+    float up = next_float_up(po), dn = next_float_down(po);
+    return off > 0 ? up : (off < 0 ? dn : po);
 }
 VDEV V3 offset_ray_origin(P3i pi, V3 n, V3 w) {
     float d = dot(vabs(n), pi.err());

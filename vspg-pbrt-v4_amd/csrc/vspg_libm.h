@@ -123,35 +123,27 @@ VSPG_HD double sincosf_reduce_fast(double x, int *np) {
 }
 VSPG_HD double sincosf_sign(int q) { return (q == 1 || q == 2) ? -1.0 : 1.0; }  // sign[4] = {1,-1,-1,1}
 
+// glibc's sinf/cosf take a short cut for |y| < pi/4 (no reduction) and return y / 1.0f for
+// |y| < 2^-12.  Both are special cases of the general path: for |y| < pi/4 the reduction yields n = 0
+// and x unchanged, and for |y| < 2^-12 the polynomial's correction is below half an ulp of the float
+// result, so one branch-free path reproduces all three (verified exhaustively over every float in
+// [0, 8] and its negative by tests/test_libm_model.py::test_sincos_exhaustive).
 VSPG_HD float sinf_host_exact(float y) {
-    double x = (double)y;
     uint32_t top = (asuint(y) >> 20) & 0x7ffu;
-    if (top <= 0x3f3u) {  // |y| < pi/4
-        double s = x * x;
-        if (top <= 0x397u) return y;  // |y| < 2^-12
-        return sincosf_poly(x, s, false, 0);
-    } else if (top <= 0x42eu) {  // |y| < 120
-        int n;
-        x = sincosf_reduce_fast(x, &n);
-        double s = sincosf_sign(n & 3);
-        return sincosf_poly(x * s, x * x, (n & 2) != 0, n);
-    }
-    return VSPG_LIBM_OUT_OF_SCOPE((float)sin((double)y));  // |y| >= 120, inf, nan
+    if (top > 0x42eu) return VSPG_LIBM_OUT_OF_SCOPE((float)sin((double)y));  // |y| >= 120, inf, nan
+    int n;
+    double x = sincosf_reduce_fast((double)y, &n);
+    double s = sincosf_sign(n & 3);
+    float r = sincosf_poly(x * s, x * x, (n & 2) != 0, n);
+    return y == 0.f ? y : r;  // sin(-0) = -0: the only input whose sign the polynomial loses
 }
 VSPG_HD float cosf_host_exact(float y) {
-    double x = (double)y;
     uint32_t top = (asuint(y) >> 20) & 0x7ffu;
-    if (top <= 0x3f3u) {
-        double x2 = x * x;
-        if (top <= 0x397u) return 1.0f;
-        return sincosf_poly(x, x2, false, 1);
-    } else if (top <= 0x42eu) {
-        int n;
-        x = sincosf_reduce_fast(x, &n);
-        double s = sincosf_sign(n & 3);
-        return sincosf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
-    }
-    return VSPG_LIBM_OUT_OF_SCOPE((float)cos((double)y));
+    if (top > 0x42eu) return VSPG_LIBM_OUT_OF_SCOPE((float)cos((double)y));
+    int n;
+    double x = sincosf_reduce_fast((double)y, &n);
+    double s = sincosf_sign(n & 3);
+    return sincosf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
 }
 
 }  // namespace vspg_libm

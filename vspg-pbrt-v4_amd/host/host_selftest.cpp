@@ -48,7 +48,8 @@ int main() {
     CHECK(throws([&] { Integrator::Create("path", ParameterDictionary(), scene, 16, 16, 1); }));
     CHECK(throws([&] { Integrator::Create("guidedvolpath", ParameterDictionary(), scene, 16, 16, 1); }));
     // out-of-scope options are refused loudly, before any device work
-    CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary(), scene, 16, 16, 1); }));  // needs the guiding cache
+    CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("rrguiding", true), scene, 16, 16, 1); }));
+    CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("collisionProbabilityBias", true), scene, 16, 16, 1); }));
     std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: ok\n", fails);
     return fails ? 1 : 0;
 }
