@@ -160,6 +160,18 @@ def main():
     paths_total, segs_total = sh.sum_over_ranks(dist, [paths_rank, segs_rank], world, "cuda")
 
     if rank == 0:
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same
+        # command (profiles/r01_pmc_k_render_wave.json; FETCH_SIZE and WRITE_SIZE are separate
+        # passes, KiB per launch).  Reads here are 4-B gathers and scalar loads, a width the
+        # microarch guide lists as uncalibrated (FETCH_SIZE may under-count by up to 2x); writes
+        # are float atomics, which WRITE_SIZE counts at 64 B per request.
+        traffic_gbs, traffic_bytes = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_render_wave.json")))
+            if W == 1920 and H == 1080:
+                traffic_bytes = (pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+        except Exception:
+            pass
         kbar = segs_rank / max(1, paths_rank)
         bytes_per_launch = (segs_rank * B_SEGMENT + paths_rank * B_PATH_FIXED) / max(1, args.steps)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -181,7 +193,9 @@ def main():
                        "paths_per_step_per_gpu": W * H, "mean_segments_per_path": kbar,
                        "parallelism": "sample-index sharding x%d, film all-reduce at frame end" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (traffic_bytes / (kern_ms * 1e-3) / 1e9) if traffic_bytes and kern_ms > 0 else None,
+                         "traffic_bytes_per_launch": traffic_bytes,
                          "kernel": "k_render_wave", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
