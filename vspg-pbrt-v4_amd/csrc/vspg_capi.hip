@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "vspg_path.h"
+#include "vspg_wg_kernel.h"
 
 using namespace vspg;
 
@@ -161,6 +162,236 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
                     has = false;
             }
         }
+    }
+    flush_counters(pc, paths, counters);
+}
+
+// Workgroup-level wavefront kernel (see vspg_wg_kernel.h for the design): a persistent 256-thread
+// workgroup advances a pool of NP paths parked in LDS, phase by phase, over compacted lists.
+//   counters in s_cnt (iteration k, parity par = k & 1):
+//     A0[par], A1[par]  entries of segment list k: new (depth-0) paths grow from the front of
+//                       s_listA[par], continuing paths from its back; CURA[par] = wave chunk cursor
+//     BV, BS, CURB      vertex list: volume vertices from the front of s_listB, surface from the back
+//     NFREE[par]        free slots (s_free[par]) waiting for a work item in R(k); slots freed during
+//                       iteration k collect in s_free[nxt];  NASSIGN / RNEXT / REND / EXH: refill state
+constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
+enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
+       C_EXH = 14, C_COUNT = 16 };
+
+template <class Medium, bool GUIDED, int NP>
+__global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
+    const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
+    int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int *__restrict__ work_head,
+    unsigned long long *__restrict__ counters) {
+    const DScene &S = *Sp;
+    const int W = S.xres, H = S.yres;
+    const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
+    const unsigned total_items = (unsigned)(tilesX * tilesY) * 64u;
+    const int lane = threadIdx.x & 63;
+    const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
+
+    constexpr int NF = GUIDED ? (int)PF_COUNT : (int)PF_GS;
+    __shared__ float s_pool[NF * NP];
+    __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
+    __shared__ unsigned int s_item[NP];
+    __shared__ unsigned int s_cnt[C_COUNT];
+    const Pool P{s_pool, NP};
+
+    const float *maj_ptr = nullptr;
+    if constexpr (!std::is_same<Medium, HomogeneousMedium>::value) {
+        __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
+        const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
+        float4 *dst = reinterpret_cast<float4 *>(s_maj);
+        for (int i = threadIdx.x; i < kMajRes * kMajRes * kMajRes / 4; i += kBlock) dst[i] = src[i];
+        maj_ptr = s_maj;
+    }
+    const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
+    float *glds = nullptr;
+    if constexpr (GUIDED) {
+        __shared__ float s_gmix[kBlock * 5 * GK];
+        glds = s_gmix + threadIdx.x;
+    }
+    PathCounters pc = {0, 0, 0, 0, 0};
+    uint32_t paths = 0;
+
+    if (threadIdx.x < C_COUNT) s_cnt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < NP; i += kBlock) s_free[0][i] = (unsigned short)i;
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt[C_NFREE] = NP;
+    __syncthreads();
+
+    // a finished path: splat, then either start the pixel's next sample in the same slot (multi-sample
+    // launches keep one pixel's samples in order in one slot) or hand the slot back
+    auto finish = [&](int slot, int par, PathState &st, Sampler &sampler, IsgSample &isg, bool *restart, bool *freed) {
+        const Spec L = finish_radiance(st.L);
+        const int pidx = P.i(PF_PIXEL, slot);
+        film_add_sample(film + pidx, L);
+        isg_add_sample_atomic(isg_stats + (size_t)pidx * VSPG_ISG_STATS, L, isg);
+        paths++;
+        const int s = P.i(PF_SAMPLE, slot) + sample_step;
+        if (s < wave_end) {
+            int ch;
+            const int py = pidx / W, px = pidx - py * W;
+            start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);
+            P.i(PF_SAMPLE, slot) = s;
+            pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, -1, mk(0, 0, 0), FL_LIVE);
+            *restart = true;
+        } else {
+            *freed = true;
+        }
+        (void)par;
+    };
+
+    for (int k = 0;; ++k) {
+        const int par = k & 1, nxt = par ^ 1;
+        // ---- R: hand work items to the free slots ------------------------------------------------
+        if (threadIdx.x < 64) {  // wavefront 0: items for the first nFree entries of s_free
+            const unsigned n_free = s_cnt[C_NFREE + par];
+            unsigned rnext = s_cnt[C_RNEXT], rend = s_cnt[C_REND], exh = s_cnt[C_EXH];
+            unsigned filled = 0;
+            while (filled < n_free) {
+                if (rnext >= rend) {
+                    if (exh) break;
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(work_head, (unsigned)kWgChunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total_items) { exh = 1; break; }
+                    rnext = base;
+                    rend = base + (unsigned)kWgChunk < total_items ? base + (unsigned)kWgChunk : total_items;
+                }
+                const unsigned n = rend - rnext < n_free - filled ? rend - rnext : n_free - filled;
+                for (unsigned j = (unsigned)lane; j < n; j += 64u) s_item[filled + j] = rnext + j;
+                rnext += n;
+                filled += n;
+            }
+            if (lane == 0) {
+                s_cnt[C_RNEXT] = rnext; s_cnt[C_REND] = rend; s_cnt[C_EXH] = exh;
+                s_cnt[C_NASSIGN] = filled;
+                s_cnt[C_NFREE + par] = 0;
+                s_cnt[C_BV] = 0; s_cnt[C_BS] = 0; s_cnt[C_CURB] = 0;
+                s_cnt[C_A0 + nxt] = 0; s_cnt[C_A1 + nxt] = 0; s_cnt[C_CURA + nxt] = 0;
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned n_assign = s_cnt[C_NASSIGN];
+            for (unsigned j0 = 0; j0 < n_assign; j0 += kBlock) {
+                const unsigned j = j0 + threadIdx.x;
+                bool started = false, back = false;
+                int slot = 0;
+                if (j < n_assign) {
+                    slot = s_free[par][j];
+                    const unsigned item = s_item[j];
+                    const unsigned tile = item >> 6, l = item & 63u;
+                    const int px = (int)(tile % (unsigned)tilesX) * 8 + (int)(l & 7u);
+                    const int py = (int)(tile / (unsigned)tilesX) * 8 + (int)(l >> 3);
+                    if (px < W && py < H && first_sample < wave_end) {
+                        Sampler sampler;
+                        PathState st;
+                        IsgSample isg;
+                        int ch;
+                        if (single_sample)
+                            start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
+                        else
+                            start_path(S, vsp_buf, vsp_ready, px, py, first_sample, sampler, st, &ch, isg);
+                        P.i(PF_PIXEL, slot) = py * W + px;
+                        P.i(PF_SAMPLE, slot) = first_sample;
+                        pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, -1, mk(0, 0, 0), FL_LIVE);
+                        started = true;
+                    } else {
+                        back = true;  // tile padding: the slot waits for the next item
+                    }
+                }
+                list_push(started, slot, s_listA[par], &s_cnt[C_A0 + par]);
+                list_push(back, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
+            }
+        }
+        __syncthreads();
+        const unsigned nA0 = s_cnt[C_A0 + par], nA1 = s_cnt[C_A1 + par], nA = nA0 + nA1;
+        if (nA == 0 && s_cnt[C_EXH]) break;  // nothing in flight and nothing left to start
+
+        // ---- A: one segment (intersect + distance sampling) for every live path -------------------
+        while (true) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[C_CURA + par], 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= nA) break;
+            const unsigned i = base + (unsigned)lane;
+            bool toV = false, toS = false, restart = false, freed = false;
+            int slot = 0;
+            if (i < nA) {
+                slot = i < nA0 ? s_listA[par][i] : s_listA[par][NP - 1 - (int)(i - nA0)];
+                Sampler sampler;
+                PathState st;
+                IsgSample isg;
+                int ch;
+                const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
+                const int pidx = P.i(PF_PIXEL, slot);
+                const int py = pidx / W, px = pidx - py * W;
+                Vertex vx;
+                if (li_segment_a<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, vx)) {
+                    pool_store_a(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                    toV = vx.volume;
+                    toS = !vx.volume;
+                } else {
+                    finish(slot, par, st, sampler, isg, &restart, &freed);
+                }
+            }
+            list_push(toV, slot, s_listB, &s_cnt[C_BV]);
+            {   // surface vertices grow from the back
+                const unsigned long long m = __ballot(toS);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    unsigned b = 0;
+                    if (lane == leader) b = atomicAdd(&s_cnt[C_BS], (unsigned)__popcll(m));
+                    b = __shfl(b, leader);
+                    if (toS) s_listB[NP - 1 - (int)(b + (unsigned)__popcll(m & ((1ull << lane) - 1ull)))] = (unsigned short)slot;
+                }
+            }
+            list_push(restart, slot, s_listA[nxt], &s_cnt[C_A0 + nxt]);
+            list_push(freed, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
+        }
+        __syncthreads();
+
+        // ---- B: vertex processing (NEE, Russian roulette, new direction) --------------------------
+        const unsigned nBV = s_cnt[C_BV], nB = nBV + s_cnt[C_BS];
+        while (true) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[C_CURB], 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= nB) break;
+            const unsigned i = base + (unsigned)lane;
+            bool cont = false, restart = false, freed = false;
+            int slot = 0;
+            if (i < nB) {
+                slot = i < nBV ? s_listB[i] : s_listB[NP - 1 - (int)(i - nBV)];
+                Sampler sampler;
+                PathState st;
+                IsgSample isg;
+                int ch;
+                const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
+                const Vertex vx = pool_load_vertex(P, slot, fl);
+                if (li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kBlock)) {
+                    pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, vx.volume ? -1 : vx.quad, vx.p, FL_LIVE);
+                    cont = true;
+                } else {
+                    finish(slot, par, st, sampler, isg, &restart, &freed);
+                }
+            }
+            {   // continuing paths grow from the back of the next segment list
+                const unsigned long long m = __ballot(cont);
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    unsigned b = 0;
+                    if (lane == leader) b = atomicAdd(&s_cnt[C_A1 + nxt], (unsigned)__popcll(m));
+                    b = __shfl(b, leader);
+                    if (cont) s_listA[nxt][NP - 1 - (int)(b + (unsigned)__popcll(m & ((1ull << lane) - 1ull)))] = (unsigned short)slot;
+                }
+            }
+            list_push(restart, slot, s_listA[nxt], &s_cnt[C_A0 + nxt]);
+            list_push(freed, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
+        }
+        __syncthreads();
     }
     flush_counters(pc, paths, counters);
 }
@@ -738,7 +969,22 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     hipLaunchKernelGGL((k_render_wave<M, G>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,    \
                        r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first, n_samples == 1 ? 1 : 0, \
                        jump, static_per_wave, dyn_base, r->work_head, r->counters)
-    if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
+    // scheduler: "wg" = workgroup-level wavefront kernel (unguided builds), "lane" = per-lane persistent kernel
+    const char *kenv = getenv("VSPG_KERNEL");
+    const bool use_wg = !guided && !(kenv && strcmp(kenv, "lane") == 0);
+    if (use_wg) {
+        long long wblocks = (long long)r->num_cus * kBlocksPerCU;
+        const long long wmax = (items + kWgChunk - 1) / kWgChunk;
+        if (wblocks > wmax) wblocks = wmax;
+        if (grid)
+            hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, 384>), dim3((unsigned)wblocks), dim3(kBlock), 0,
+                               (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first,
+                               n_samples == 1 ? 1 : 0, jump, r->work_head, r->counters);
+        else
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, 512>), dim3((unsigned)wblocks), dim3(kBlock), 0,
+                               (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first,
+                               n_samples == 1 ? 1 : 0, jump, r->work_head, r->counters);
+    } else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
     else if (grid) VSPG_LAUNCH_RENDER(GridMedium, false);
     else if (guided) VSPG_LAUNCH_RENDER(HomogeneousMedium, true);
     else VSPG_LAUNCH_RENDER(HomogeneousMedium, false);

@@ -437,14 +437,22 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
 // one iteration of the Li path loop (:309-609): returns false when the path ends.
 // Surface vertices (:376-608) and volume vertices (the scatter tail) share the NEE code.
 // ---------------------------------------------------------------------------------------
-template <class Medium, bool GUIDED>
-VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
-                           bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride);
+// The path-loop iteration is split at the vertex: li_segment_a runs up to the point where the path
+// either ended or stands at a vertex (volume: scatter position + phase g; surface: rectangle + hit
+// point), li_segment_b processes that vertex (NEE, RR, new direction).  The workgroup-level wavefront
+// kernel runs the two halves in separate phases with the path state parked in LDS in between; the
+// per-lane kernels simply call one after the other.  Same operations, same order per path.
+struct Vertex {
+    bool volume;
+    V3 p;      // volume: scatter position; surface: re-projected hit point (si.p)
+    float g;   // volume: HG asymmetry
+    int quad;  // surface: rectangle index
+    float t;   // surface: tHit (only the guided build needs it, for p = ray.o + tHit * ray.d)
+};
 
 template <class Medium, bool GUIDED = false>
-VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
-                     PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc, float *glds = nullptr,
-                     int gstride = 0) {
+VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
+                       PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc, Vertex &vx) {
     VSPG_PROF(PS_SEGMENT);
     pc.segments++;
     Isect si;
@@ -453,9 +461,11 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         si = scene_intersect(S, st.ro, st.rd, kInf);
     }
     float tMax = si.hit ? si.t : kInf;
-    bool volume_vertex = false;
-    V3 vp = mk(0, 0, 0);
-    float vg = 0;
+    vx.volume = false;
+    vx.p = si.p;
+    vx.g = 0;
+    vx.quad = si.quad;
+    vx.t = si.t;
     if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
         Rng rng;
         {
@@ -467,12 +477,51 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         DistEvent ev = sample_distance<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
         if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return false;  // :343-344
         if (ev.kind == EV_SCATTER) {
-            volume_vertex = true;
-            vp = ev.p;
-            vg = ev.g;
+            vx.volume = true;
+            vx.p = ev.p;
+            vx.g = ev.g;
+            return true;
         }
     }
+    VSPG_PROF(PS_SURF_PRE);
+    if (!si.hit) return false;  // no infinite lights in scope (:353-374)
+    const DQuad &q = S.quads[si.quad];
+    Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
+    if (nonzero(Le)) {
+        if (st.depth == 0 || st.specularBounce) {
+            st.L = st.L + st.beta * Le / avg(st.r_u);
+        } else {
+            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx, st.rd);
+            st.r_l = st.r_l * lightPDF;
+            float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
+            st.L = st.L + st.beta * w_l * Le;
+        }
+    }
+    if (st.depth == 0) {
+        isg.valid = true;
+        isg.surface_event = true;
+    }
+    if (st.depth++ >= S.prm.maxdepth) return false;
+    pc.surface_hits++;
+    return true;
+}
 
+template <class Medium, bool GUIDED>
+VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
+                           bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride);
+
+template <class Medium, bool GUIDED = false>
+VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
+                       const Vertex &vx, float *glds = nullptr, int gstride = 0) {
+    const bool volume_vertex = vx.volume;
+    const V3 vp = vx.p;
+    const float vg = vx.g;
+    Isect si;
+    si.hit = !vx.volume;
+    si.t = vx.t;
+    si.quad = vx.quad;
+    si.p = vx.p;
+    si.n = mk(0, 0, 0);
     Intr intr;
     Bsdf bsdf;
     float survivalProb = 1.f;
@@ -485,27 +534,9 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         intr.g = vg;
         bsdf.has_lobes = false;
     } else {
-        VSPG_PROF(PS_SURF_PRE);
-        if (!si.hit) return false;  // no infinite lights in scope (:353-374)
-        const DQuad &q = S.quads[si.quad];
-        Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
-        if (nonzero(Le)) {
-            if (st.depth == 0 || st.specularBounce) {
-                st.L = st.L + st.beta * Le / avg(st.r_u);
-            } else {
-                float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx, st.rd);
-                st.r_l = st.r_l * lightPDF;
-                float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
-                st.L = st.L + st.beta * w_l * Le;
-            }
-        }
+        const DQuad &q = S.quads[vx.quad];
+        si.n = ld3(q.n);
         bsdf = bsdf_make(q);
-        if (st.depth == 0) {
-            isg.valid = true;
-            isg.surface_event = true;
-        }
-        if (st.depth++ >= S.prm.maxdepth) return false;
-        pc.surface_hits++;
         intr.is_surface = true;
         intr.pi = p3i_from_err(si.p, ld3(q.perr));
         intr.n = si.n;
@@ -601,6 +632,15 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
         st.beta = st.beta / (1 - qq);
     }
     return true;
+}
+
+template <class Medium, bool GUIDED = false>
+VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
+                     PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc, float *glds = nullptr,
+                     int gstride = 0) {
+    Vertex vx;
+    if (!li_segment_a<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, vx)) return false;
+    return li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, gstride);
 }
 
 // ---------------------------------------------------------------------------------------
