@@ -83,6 +83,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
         __syncthreads();
         maj_ptr = s_maj;
     }
+    stage_scene_lds(S);
+    __syncthreads();
     const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
     // guided builds: the per-lane product mixture of the guiding cache (5 floats x 8 lobes) lives in
     // LDS, element e of lane t at s_gmix[e * kBlock + t] (conflict-free)
@@ -174,12 +176,22 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
 //     BV, BS, CURB      vertex list: volume vertices from the front of s_listB, surface from the back
 //     NFREE[par]        free slots (s_free[par]) waiting for a work item in R(k); slots freed during
 //                       iteration k collect in s_free[nxt];  NASSIGN / RNEXT / REND / EXH: refill state
+#ifndef VSPG_WG_WAVES
+#define VSPG_WG_WAVES 2
+#endif
+#ifndef VSPG_WG_NP
+#define VSPG_WG_NP 480
+#endif
+#ifndef VSPG_WG_NP_GRID
+#define VSPG_WG_NP_GRID 384
+#endif
+constexpr int kWgWavesPerSimd = VSPG_WG_WAVES;
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_COUNT = 16 };
 
 template <class Medium, bool GUIDED, int NP>
-__global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
+__global__ __launch_bounds__(kBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
     int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int *__restrict__ work_head,
     unsigned long long *__restrict__ counters) {
@@ -214,6 +226,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
     PathCounters pc = {0, 0, 0, 0, 0};
     uint32_t paths = 0;
 
+    stage_scene_lds(S);
     if (threadIdx.x < C_COUNT) s_cnt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < NP; i += kBlock) s_free[0][i] = (unsigned short)i;
     __syncthreads();
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
         (void)par;
     };
 
+    VSPG_PROF(PS_WG_TOTAL);
     for (int k = 0;; ++k) {
         const int par = k & 1, nxt = par ^ 1;
         // ---- R: hand work items to the free slots ------------------------------------------------
@@ -272,8 +286,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
                 s_cnt[C_A0 + nxt] = 0; s_cnt[C_A1 + nxt] = 0; s_cnt[C_CURA + nxt] = 0;
             }
         }
-        __syncthreads();
+        { VSPG_PROF(PS_WG_BAR_R); __syncthreads(); }
         {
+            VSPG_PROF(PS_WG_R);
             const unsigned n_assign = s_cnt[C_NASSIGN];
             for (unsigned j0 = 0; j0 < n_assign; j0 += kBlock) {
                 const unsigned j = j0 + threadIdx.x;
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
                 list_push(back, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
             }
         }
-        __syncthreads();
+        { VSPG_PROF(PS_WG_BAR_R); __syncthreads(); }
         const unsigned nA0 = s_cnt[C_A0 + par], nA1 = s_cnt[C_A1 + par], nA = nA0 + nA1;
         if (nA == 0 && s_cnt[C_EXH]) break;  // nothing in flight and nothing left to start
 
@@ -316,6 +331,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
             if (lane == 0) base = atomicAdd(&s_cnt[C_CURA + par], 64u);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= nA) break;
+            VSPG_PROF(PS_WG_A);
             const unsigned i = base + (unsigned)lane;
             bool toV = false, toS = false, restart = false, freed = false;
             int slot = 0;
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
             list_push(restart, slot, s_listA[nxt], &s_cnt[C_A0 + nxt]);
             list_push(freed, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
         }
-        __syncthreads();
+        { VSPG_PROF(PS_WG_BAR_A); __syncthreads(); }
 
         // ---- B: vertex processing (NEE, Russian roulette, new direction) --------------------------
         const unsigned nBV = s_cnt[C_BV], nB = nBV + s_cnt[C_BS];
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
             if (lane == 0) base = atomicAdd(&s_cnt[C_CURB], 64u);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= nB) break;
+            VSPG_PROF(PS_WG_B);
             const unsigned i = base + (unsigned)lane;
             bool cont = false, restart = false, freed = false;
             int slot = 0;
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave_wg(
             list_push(restart, slot, s_listA[nxt], &s_cnt[C_A0 + nxt]);
             list_push(freed, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
         }
-        __syncthreads();
+        { VSPG_PROF(PS_WG_BAR_B); __syncthreads(); }
     }
     flush_counters(pc, paths, counters);
 }
@@ -402,6 +419,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict
                                                         const int32_t *__restrict__ sample_index, float *__restrict__ out_L,
                                                         int32_t *__restrict__ out_seg) {
     const DScene &S = *Sp;
+    stage_scene_lds(S);
+    __syncthreads();
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const Medium medium = MediumMaker<Medium>::make(S, S.majorant);
@@ -429,6 +448,8 @@ __global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict_
                                                        const VspgTmajQuery *__restrict__ q, VspgTmajResult *__restrict__ out) {
     const DScene &S = *Sp;
     int i = blockIdx.x * kBlock + threadIdx.x;
+    vspg_libm::stage_logf_tab_lds();
+    __syncthreads();
     if (i >= n) return;
     const Medium medium = MediumMaker<Medium>::make(S, S.majorant);
     VspgTmajQuery Q = q[i];
@@ -496,6 +517,8 @@ __global__ __launch_bounds__(kBlock) void k_guiding_query(const DScene *__restri
     __shared__ float s_gmix[kBlock * 5 * GK];
     const DScene &S = *Sp;
     int i = blockIdx.x * kBlock + threadIdx.x;
+    vspg_libm::stage_logf_tab_lds();
+    __syncthreads();
     if (i >= n) return;
     float *glds = s_gmix + threadIdx.x;
     V3 pp = ld3(p + 3 * i), aa = ld3(a + 3 * i), w = ld3(wi + 3 * i);
@@ -516,6 +539,8 @@ __global__ __launch_bounds__(kBlock) void k_guiding_query(const DScene *__restri
 __global__ __launch_bounds__(kBlock) void k_libm(int n, const float *__restrict__ x, float *__restrict__ lo,
                                                  float *__restrict__ so, float *__restrict__ co) {
     int i = blockIdx.x * kBlock + threadIdx.x;
+    vspg_libm::stage_logf_tab_lds();
+    __syncthreads();
     if (i >= n) return;
     lo[i] = logf_(x[i]);
     so[i] = sinf_(x[i]);
@@ -973,15 +998,15 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const char *kenv = getenv("VSPG_KERNEL");
     const bool use_wg = !guided && !(kenv && strcmp(kenv, "lane") == 0);
     if (use_wg) {
-        long long wblocks = (long long)r->num_cus * kBlocksPerCU;
+        long long wblocks = (long long)r->num_cus * kWgWavesPerSimd;
         const long long wmax = (items + kWgChunk - 1) / kWgChunk;
         if (wblocks > wmax) wblocks = wmax;
         if (grid)
-            hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, 384>), dim3((unsigned)wblocks), dim3(kBlock), 0,
+            hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, VSPG_WG_NP_GRID>), dim3((unsigned)wblocks), dim3(kBlock), 0,
                                (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first,
                                n_samples == 1 ? 1 : 0, jump, r->work_head, r->counters);
         else
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, 512>), dim3((unsigned)wblocks), dim3(kBlock), 0,
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, VSPG_WG_NP>), dim3((unsigned)wblocks), dim3(kBlock), 0,
                                (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first,
                                n_samples == 1 ? 1 : 0, jump, r->work_head, r->counters);
     } else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);

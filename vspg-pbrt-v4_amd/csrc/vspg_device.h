@@ -33,7 +33,8 @@ namespace vspg {
 // ---------------------------------------------------------------------------------------
 #ifdef VSPG_PROFILE
 enum { PS_INTERSECT = 0, PS_HASHRNG, PS_DIST_GUIDED, PS_DIST_PLAIN, PS_SURF_PRE, PS_NEE, PS_NEE_TR, PS_VOL_SAMPLE,
-       PS_SURF_SAMPLE, PS_FINISH, PS_START, PS_REFILL, PS_SEGMENT, PS_COUNT };
+       PS_SURF_SAMPLE, PS_FINISH, PS_START, PS_REFILL, PS_SEGMENT, PS_WG_R, PS_WG_A, PS_WG_B, PS_WG_BAR_R, PS_WG_BAR_A,
+       PS_WG_BAR_B, PS_WG_VERTEX, PS_WG_TOTAL, PS_COUNT };
 __device__ unsigned long long g_prof[PS_COUNT][3];
 struct ProfScope {
     int sec;
@@ -473,6 +474,26 @@ struct DScene {
     int32_t xres, yres, seed, shard_index, shard_count;
 };
 
+// Rectangle records that are indexed PER LANE (the rectangle a lane hit, the light it sampled) are
+// read from an LDS copy: through the DScene in HBM each such access is a vector load with a full
+// L2 round trip (~1 us, and the light lookup is two dependent ones) that two waves per SIMD cannot
+// hide; measured, those loads were the largest single wait of the path kernels.  Wave-uniform
+// accesses (S.irec[i], camera, medium, parameters) stay scalar loads from the constant cache.
+// Every kernel that runs path code calls stage_scene_lds() + __syncthreads() first (it also stages
+// the logf table of vspg_libm.h).
+__shared__ DQuad s_scene_quads[VSPG_MAX_QUADS];
+__shared__ int32_t s_scene_light_quads[VSPG_MAX_QUADS];
+VDEV void stage_scene_lds(const DScene &S) {
+    vspg_libm::stage_logf_tab_lds();
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(S.quads);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(s_scene_quads);
+    const int n = S.n_quads * (int)(sizeof(DQuad) / 4);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < VSPG_MAX_QUADS) s_scene_light_quads[threadIdx.x] = S.light_quads[threadIdx.x];
+}
+VDEV const DQuad &quad_at(int i) { return s_scene_quads[i]; }
+VDEV const DQuad &light_quad_at(int lightIndex) { return s_scene_quads[s_scene_light_quads[lightIndex]]; }
+
 struct Isect {
     bool hit;
     float t;
@@ -570,7 +591,7 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
             bv = v;
         }
     }
-    const DQuad &q = S.quads[best.quad];  // per-lane index: vector loads, once per segment
+    const DQuad &q = quad_at(best.quad);  // per-lane index: LDS copy
     best.p = quad_point(q, bu, bv);
     best.n = ld3(q.n);
     return best;
@@ -612,6 +633,7 @@ struct HomogeneousMedium {
     VDEV Iter sample_ray(V3, V3, float tMax) const { return Iter{MajSeg{0, tMax, sigma_a + sigma_s}, false}; }
     VDEV MediumProps sample_point(V3) const { return MediumProps{sigma_a, sigma_s, Le, g}; }
     VDEV bool is_homogeneous() const { return true; }
+    static constexpr bool kSingleSegment = true;
 };
 VDEV HomogeneousMedium make_homogeneous(const DScene &S) {
     return HomogeneousMedium{lds(S.sigma_a), lds(S.sigma_s), lds(S.Le), S.g};
@@ -765,6 +787,7 @@ struct GridMedium {
         return MediumProps{sigma_a * d, sigma_s * d, sp(0.f), g};
     }
     VDEV bool is_homogeneous() const { return false; }
+    static constexpr bool kSingleSegment = false;
 };
 VDEV GridMedium make_grid(const DScene &S, const float *majorant) {
     return GridMedium{lds(S.sigma_a), lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
@@ -904,37 +927,47 @@ VDEV Spec ruf_from(float alpha, Spec tp) {  // SampledSpectrum(a)/tp + SampledSp
 template <class Medium, class F>
 VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float u, Rng &rng, int ch,
                            bool guide, float vsp, float alpha, bool NDS, Spec *r_u_factor, F &&cb) {
-    if (!guide || alpha == 0.f) return sample_T_maj(medium, ro, rd, tMax, u, rng, ch, cb);
-    tMax *= len(rd);
-    rd = normalize(rd);
-    auto iter = medium.sample_ray(ro, rd, tMax);
-    auto pre = iter;
-    float t_v = 0.f;
-    bool inf_seg = false;
-    while (true) {
-        MajSeg seg;
-        if (!pre.next(&seg)) break;
-        if (isinf_(seg.tMax)) {
-            inf_seg = true;
-            break;
+    // The reference falls back to SampleT_maj at three places (:279 unguided, :307 infinite segment,
+    // :327 NDS with vsp below the volume's own scatter probability); they are folded into ONE call
+    // site here (one inlined copy of the tracking loop + callback instead of three).  The first
+    // fallback passes the ray as given, the other two the normalised ray and scaled tMax -- as there.
+    bool fallback = !guide || alpha == 0.f;
+    float t_v = 0.f, t_n = -1.f, t_n_current = -1.f;
+    decltype(medium.sample_ray(ro, rd, tMax)) iter;
+    if (!fallback) {
+        tMax *= len(rd);
+        rd = normalize(rd);
+        iter = medium.sample_ray(ro, rd, tMax);
+        auto pre = iter;
+        bool inf_seg = false;
+        while (true) {
+            MajSeg seg;
+            if (!pre.next(&seg)) break;
+            if (isinf_(seg.tMax)) {
+                inf_seg = true;
+                break;
+            }
+            float smaj = ch_of(seg.sigma_maj, ch);
+            if (smaj == 0) continue;
+            t_v += smaj * (seg.tMax - seg.tMin);
         }
-        float smaj = ch_of(seg.sigma_maj, ch);
-        if (smaj == 0) continue;
-        t_v += smaj * (seg.tMax - seg.tMin);
+        if (inf_seg) {
+            fallback = true;
+        } else {
+            if (t_v == 0.f) return sp(1.f);
+            if (NDS) {
+                float OneMinusENegTv = 1.f - fast_exp(-t_v);
+                if (vsp < 1 - fast_exp(-t_v)) {
+                    fallback = true;
+                } else {
+                    t_n = neg_log1m_d(OneMinusENegTv / vsp);
+                    t_n_current = t_n;
+                }
+            }
+        }
     }
-    if (inf_seg) return sample_T_maj(medium, ro, rd, tMax, u, rng, ch, cb);  // normalised ray, scaled tMax (:307)
-    if (t_v == 0.f) return sp(1.f);
+    if (fallback) return sample_T_maj(medium, ro, rd, tMax, u, rng, ch, cb);
 
-    float OneMinusENegTv = 1.f - fast_exp(-t_v);
-    float t_n = -1.f, t_n_current = -1.f;
-    if (NDS) {
-        if (vsp < 1 - fast_exp(-t_v))
-            return sample_T_maj(medium, ro, rd, tMax, u, rng, ch, cb);  // (:327)
-        else {
-            t_n = neg_log1m_d(OneMinusENegTv / vsp);
-            t_n_current = t_n;
-        }
-    }
     Spec T_maj = sp(1.f), tpScale = sp(1.f);
     float t_v_current = t_v;
     float remainingDist = 0;
@@ -960,7 +993,9 @@ VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float
         }
         float tMin = seg.tMin;
         Spec nMaj = seg.sigma_maj / smaj;
-        if (remainingDist > 0) {
+        // a medium with ONE majorant segment never carries a remaining optical distance into a next
+        // segment: the block below is dead for it and the loop body runs once
+        if (!Medium::kSingleSegment && remainingDist > 0) {
             tMin += remainingDist / smaj;
             if (tMin > seg.tMax + ScatterEpsilon) {
                 float dist = (seg.tMax - seg.tMin) * smaj;
@@ -1035,6 +1070,7 @@ VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float
                 break;
             }
         }
+        if (Medium::kSingleSegment) return done ? sp(1.f) : T_maj;  // the next iter.next() would fail (:350)
     }
     return sp(1.f);
 }

@@ -51,20 +51,36 @@ VSPG_HD float asfloat(uint32_t u) {
 
 // ---- logf ---------------------------------------------------------------------------------
 // __logf_data (glibc 2.35 sysdeps/ieee754/flt-32/e_logf_data.c): {invc, logc} x 16
+VSPG_HD double logf_tab_entry(int j) {  // flat view: entry i = {T[2i], T[2i+1]}
+    static const double T[32] = {
+        0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2, 0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2,
+        0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2,  0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3,
+        0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3, 0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3,
+        0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4, 0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4,
+        0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5, 0x1p+0, 0x0p+0,
+        0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5,  0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4,
+        0x1.b2036576afce6p-1, 0x1.526e57720db08p-3,  0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3,
+        0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2};
+    return T[j];
+}
+#if defined(__HIPCC__)
+// Device: the table is looked up per lane, and from its home in constant memory that is a vector load
+// with a full cache round trip (hundreds of cycles, waited for at once: every free-flight step calls
+// logf).  Kernels copy it into LDS first (stage_logf_tab_lds() + __syncthreads()); the lookup is then
+// one ds_read_b128.
+__shared__ double s_logf_tab[32];
+__device__ __forceinline__ void stage_logf_tab_lds() {
+    if (threadIdx.x < 32) s_logf_tab[threadIdx.x] = logf_tab_entry((int)threadIdx.x);
+}
+#endif
 VSPG_HD void logf_tab(int i, double *invc, double *logc) {
-    // a switch keeps the table in the instruction stream / scalar constants on device
-    // (no runtime-indexed private array)
-    static const double T[16][2] = {
-        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
-        {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
-        {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
-        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
-        {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
-        {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
-        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
-        {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
-    *invc = T[i][0];
-    *logc = T[i][1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    *invc = s_logf_tab[2 * i];
+    *logc = s_logf_tab[2 * i + 1];
+#else
+    *invc = logf_tab_entry(2 * i);
+    *logc = logf_tab_entry(2 * i + 1);
+#endif
 }
 
 VSPG_HD float logf_host_exact(float x) {

@@ -150,7 +150,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     }
     float ul0 = sampler.get1d(), ul1 = sampler.get1d();
     if (!have_light) return sp(0.f);
-    const DQuad &lq = S.quads[S.light_quads[lightIndex]];
+    const DQuad &lq = light_quad_at(lightIndex);
     LightLi ls;
     if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return sp(0.f);
     float p_l = lightPmf * ls.pdf;
@@ -272,7 +272,16 @@ struct DistEvent {
     float g;  // HG asymmetry of the phase function at p
 };
 
-template <class Medium, bool GUIDED>
+// SEG tells the compiler which segment of a path the caller is at, when the caller knows (the
+// workgroup-level kernel runs primary and later segments in different phases):
+//   SEG_PRIMARY    depth == 0: the camera segment, the only one whose VSP comes from the image-space buffer;
+//   SEG_SECONDARY  depth  > 0: without the guiding cache no VSP exists there, SampleT_maj_OpticalDepthSpace
+//                  returns SampleT_maj(...) at its first line (media_sampleTMaj.h:279) -- the call is made
+//                  directly and the optical-depth-space code (the register-hungriest part of the path
+//                  loop) is not instantiated in that phase;
+//   SEG_ANY        decided at run time (per-lane kernels).
+enum { SEG_ANY = 0, SEG_PRIMARY = 1, SEG_SECONDARY = 2 };
+template <class Medium, bool GUIDED, int SEG = SEG_ANY>
 VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
                                PathState &st, float tMax, int ch, Sampler &sampler, Rng &rng, IsgSample &isg,
                                PathCounters &pc) {
@@ -280,8 +289,12 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
     ev.kind = EV_PASS;
     ev.p = mk(0, 0, 0);
     ev.g = 0;
-    bool guide;
-    float vsp = fetch_vsp<GUIDED>(S, st, &guide);
+    constexpr bool kPlainOnly = SEG == SEG_SECONDARY && !GUIDED;
+    if constexpr (SEG == SEG_PRIMARY) __builtin_assume(st.depth == 0);
+    if constexpr (SEG == SEG_SECONDARY) __builtin_assume(st.depth > 0);
+    bool guide = false;
+    float vsp = -1.f;
+    if constexpr (!kPlainOnly) vsp = fetch_vsp<GUIDED>(S, st, &guide);
     if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
 
     bool use_resampling = S.prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && !medium.is_homogeneous();
@@ -372,9 +385,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
 #endif
     Spec r_u_factor = sp(1.f);  // beta_factor is never written by the reference (always 1)
     float u = sampler.get1d();
-    Spec T_maj = sample_T_maj_ods(
-        medium, st.ro, st.rd, tMax, u, rng, ch, guide, vsp, S.prm.vspmisratio, S.prm.vspsamplingmethod == VSPG_VSP_NDS,
-        &r_u_factor, [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+    auto on_collision = [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
             pc.density_queries++;
             if (!nonzero(st.beta)) {
                 ev.kind = EV_TERMINATE;
@@ -418,7 +429,13 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 st.r_l = st.r_l * (T_maj * sigma_maj / pdf);
                 return nonzero(st.beta) && nonzero(st.r_u);
             }
-        });
+        };
+    Spec T_maj;
+    if constexpr (kPlainOnly)
+        T_maj = sample_T_maj(medium, st.ro, st.rd, tMax, u, rng, ch, on_collision);
+    else
+        T_maj = sample_T_maj_ods(medium, st.ro, st.rd, tMax, u, rng, ch, guide, vsp, S.prm.vspmisratio,
+                                 S.prm.vspsamplingmethod == VSPG_VSP_NDS, &r_u_factor, on_collision);
     // :1080-1091 -- after a scatter event the reference never multiplies T_maj in (scattered or
     // terminated is set by the tail, or beta / r_u is zero)
     bool multiply_T_maj = ev.kind == EV_PASS && nonzero(st.beta) && nonzero(st.r_u);
@@ -450,7 +467,7 @@ struct Vertex {
     float t;   // surface: tHit (only the guided build needs it, for p = ray.o + tHit * ray.d)
 };
 
-template <class Medium, bool GUIDED = false>
+template <class Medium, bool GUIDED = false, int SEG = SEG_ANY>
 VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
                        PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc, Vertex &vx) {
     VSPG_PROF(PS_SEGMENT);
@@ -474,7 +491,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
             uint64_t hash1 = hash_float(sampler.get1d());
             rng.set_sequence(hash0, hash1);
         }
-        DistEvent ev = sample_distance<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
+        DistEvent ev = sample_distance<Medium, GUIDED, SEG>(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
         if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return false;  // :343-344
         if (ev.kind == EV_SCATTER) {
             vx.volume = true;
@@ -485,7 +502,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
     }
     VSPG_PROF(PS_SURF_PRE);
     if (!si.hit) return false;  // no infinite lights in scope (:353-374)
-    const DQuad &q = S.quads[si.quad];
+    const DQuad &q = quad_at(si.quad);
     Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
     if (nonzero(Le)) {
         if (st.depth == 0 || st.specularBounce) {
@@ -534,7 +551,7 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
         intr.g = vg;
         bsdf.has_lobes = false;
     } else {
-        const DQuad &q = S.quads[vx.quad];
+        const DQuad &q = quad_at(vx.quad);
         si.n = ld3(q.n);
         bsdf = bsdf_make(q);
         intr.is_surface = true;
@@ -954,7 +971,11 @@ VDEV Spec finish_radiance(Spec L) {
 // a no-return float atomic add gives the same single IEEE addition as load + add + store, but the
 // wave never waits for the HBM round trip (a finished path would otherwise stall its whole
 // wavefront for ~1-2 us every loop iteration).
+#ifdef VSPG_EXP_NOFILM  // timing experiment only: results are wrong
+VDEV void add_noret(float *p, float v) { (void)p; (void)v; }
+#else
 VDEV void add_noret(float *p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 VDEV void film_add_sample(float4 *film_px, Spec L) {  // RGBFilm::AddSample (film.h:251-267): weight 1, no clamp
     float *f = reinterpret_cast<float *>(film_px);
     add_noret(f + 0, L.r);

@@ -151,7 +151,7 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     const int pcq = P.i(PF_PCQ, slot);
     const V3 pcp = P.v3(PF_PCP, slot);
     if (pcq >= 0) {  // surface vertex: LightSampleContext(isect) = {Point3fi(p, pError), n}
-        const DQuad &q = S.quads[pcq];
+        const DQuad &q = quad_at(pcq);
         st.prevCtx.pi = p3i_from_err(pcp, ld3(q.perr));
         st.prevCtx.n = ld3(q.n);
     } else {
