@@ -297,6 +297,9 @@ int vspg_guiding_query_batch(VspgRenderer *r, int is_volume, float g, int n, con
  * src/pbrt/util/sampling.h:222-225, 325-341, src/pbrt/util/vecmath.h:1666-1672). */
 int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, float *sinf_out,
                     float *cosf_out, void *stream);
+/* out[i] = (float)(-log(1.0 - (double)x[i])) as the kernels evaluate it: the DOUBLE-precision
+ * std::log of the optical-depth-space distance sampling (src/pbrt/media_sampleTMaj.h:379-404). */
+int vspg_libm_log1m_batch(VspgRenderer *r, int n, const float *x, float *out, void *stream);
 
 #ifdef __cplusplus
 }

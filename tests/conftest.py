@@ -68,4 +68,8 @@ def libm_shim():
     fp = C.POINTER(C.c_float)
     for n in ("model_logf", "model_sinf", "model_cosf", "libm_logf", "libm_sinf", "libm_cosf"):
         getattr(lib, n).argtypes = [C.c_int, fp, fp]
+    dp = C.POINTER(C.c_double)
+    for n in ("model_log", "libm_log"):
+        getattr(lib, n).argtypes = [C.c_int, dp, dp]
+    lib.libm_neg_log1m.argtypes = [C.c_int, fp, fp]
     return lib

@@ -1,5 +1,5 @@
 // Test shim: exposes the product's host-exact float functions (vspg_libm.h, the same header the
-// HIP kernels use) and the running libm's logf/sinf/cosf side by side, for bitwise comparison.
+// HIP kernels use) and the running libm's logf/sinf/cosf/log side by side, for bitwise comparison.
 #include <math.h>
 #include <stdint.h>
 
@@ -12,4 +12,8 @@ void model_cosf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y
 void libm_logf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = logf(x[i]); }
 void libm_sinf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = sinf(x[i]); }
 void libm_cosf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = cosf(x[i]); }
+// double log (the -std::log(1.0 - x) of the optical-depth-space sampling)
+void model_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::log_host_exact(x[i]); }
+void libm_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = log(x[i]); }
+void libm_neg_log1m(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = (float)(-log(1.0 - (double)x[i])); }
 }

@@ -2,6 +2,7 @@
 seeded inputs.  Bars: bit-exact for integer work (RNG, hashes) and for FastExp; for path radiance
 the tolerance is stated per test (libm differences: glibc logf/sinf/cosf on the host vs
 double-evaluated-and-rounded on device can differ in the last ulp)."""
+import ctypes as C
 import json
 import os
 
@@ -75,6 +76,23 @@ def test_device_libm_equals_host_libm(pair, libm_shim):
             diff &= x > 0  # the path only takes logs of positive normal floats
         bad = np.nonzero(diff)[0]
         assert bad.size == 0, (name, bad.size, x[bad[:3]], dev[bad[:3]], ref[bad[:3]])
+
+
+def test_device_double_log_matches_host_libm(pair, libm_shim):
+    """-std::log(1.0 - x) in double, rounded to float (media_sampleTMaj.h:379-404): device == host libm."""
+    P, g, c = pair
+    rng = np.random.default_rng(11)
+    u = np.minimum(rng.integers(0, 2 ** 32, 1_000_000, dtype=np.uint64).astype(np.float32) * np.float32(2.0 ** -32),
+                   np.float32(float.fromhex("0x1.fffffep-1")))
+    x = np.concatenate([u, u * rng.random(u.shape[0], dtype=np.float32),
+                        np.ldexp(rng.random(500_000), rng.integers(-24, 0, 500_000)).astype(np.float32),
+                        np.array([0.0, 0.0625, 0.5, float.fromhex("0x1.fffffep-1")], dtype=np.float32)])
+    dev = g.libm_log1m_batch(x)
+    ref = np.empty_like(x)
+    fp = C.POINTER(C.c_float)
+    libm_shim.libm_neg_log1m(x.shape[0], x.ctypes.data_as(fp), ref.ctypes.data_as(fp))
+    bad = np.nonzero(dev.view(np.uint32) != ref.view(np.uint32))[0]
+    assert bad.size == 0, (bad.size, x[bad[:3]], dev[bad[:3]], ref[bad[:3]])
 
 
 def _queries(P, n, seed, vsp=None):

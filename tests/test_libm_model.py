@@ -46,6 +46,38 @@ def test_logf_equals_host_libm(shim):
     check(shim, "logf", np.array([1.0, 0.5, 2.0, 2.0 ** -126, 3.4e38, float.fromhex('0x1.fffffep-1')], dtype=np.float32))
 
 
+def test_double_log_equals_host_libm(shim):
+    """log_host_exact (double) vs the running libm's log: the arguments the path produces are
+    1.0 - (double)u with u a float in [0, 1); plus both branches of the algorithm on wide ranges."""
+    rng = np.random.default_rng(3)
+    dp = C.POINTER(C.c_double)
+
+    def check_d(x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        a, b = np.empty_like(x), np.empty_like(x)
+        shim.model_log(x.shape[0], x.ctypes.data_as(dp), a.ctypes.data_as(dp))
+        shim.libm_log(x.shape[0], x.ctypes.data_as(dp), b.ctypes.data_as(dp))
+        bad = np.nonzero(a.view(np.uint64) != b.view(np.uint64))[0]
+        assert bad.size == 0, "log: %d mismatches, e.g. x=%r model=%r libm=%r" % (bad.size, x[bad[:3]], a[bad[:3]], b[bad[:3]])
+
+    u = np.minimum(rng.integers(0, 2 ** 32, 4_000_000, dtype=np.uint64).astype(np.float32) * np.float32(2.0 ** -32),
+                   np.float32(float.fromhex('0x1.fffffep-1')))
+    check_d(1.0 - u.astype(np.float64))
+    # u * tpStep products: small arguments -> the near-1 branch
+    check_d(1.0 - (u * rng.random(u.shape[0], dtype=np.float32)).astype(np.float64))
+    check_d(1.0 - np.ldexp(rng.random(1_000_000), rng.integers(-24, 0, 1_000_000)).astype(np.float32).astype(np.float64))
+    # every float u in [0, 2^-10) step 7, and the floats just below 1
+    bits = np.arange(0, 0x3a800000, 7 * 4093, dtype=np.uint32)
+    check_d(1.0 - bits.view(np.float32).astype(np.float64))
+    bits = np.arange(0x3f7fffff - 2_000_000, 0x3f800000, dtype=np.uint32)
+    check_d(1.0 - bits.view(np.float32).astype(np.float64))
+    # generic positive normal doubles, both branches and the branch boundaries
+    check_d(np.exp(rng.uniform(-700, 700, 2_000_000)))
+    check_d(rng.uniform(0.9, 1.1, 2_000_000))
+    check_d(np.array([1.0, 1.0 - 2.0 ** -4, np.nextafter(1.0 - 2.0 ** -4, 0), 1.0 + float.fromhex('0x1.09p-4'),
+                      np.nextafter(1.0 + float.fromhex('0x1.09p-4'), 0), 2.0 ** -24, 2.0 ** -1022, 1.7e308, 0.5, 2.0]))
+
+
 @pytest.mark.parametrize("fn", ["sinf", "cosf"])
 def test_sincos_equal_host_libm(shim, fn):
     rng = np.random.default_rng(1)

@@ -132,6 +132,7 @@ SYMBOLS = [
     ("vspg_sample_tmaj_batch", C.c_int, [_vp, C.c_int, C.c_int, _P(VspgTmajQuery), _P(VspgTmajResult), _vp]),
     ("vspg_primitives_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_uint64), _P(C.c_uint32), _P(C.c_float), _vp]),
     ("vspg_libm_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
+    ("vspg_libm_log1m_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _vp]),
     ("vspg_renderer_set_guiding_field", C.c_int, [_vp, _P(VspgField), _P(VspgField), _vp]),
     ("vspg_guiding_query_batch", C.c_int, [_vp, C.c_int, C.c_float, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                           _P(C.c_float), _P(C.c_int32), _P(C.c_float), _P(C.c_float), _P(C.c_float),
@@ -302,6 +303,14 @@ class Renderer:
         _check(self.lib, self.lib.vspg_libm_batch(self.h, n, x.ctypes.data_as(fp), lo.ctypes.data_as(fp),
                                                   so.ctypes.data_as(fp), co.ctypes.data_as(fp), _vp(0)))
         return lo, so, co
+
+    def libm_log1m_batch(self, x):
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        fp = _P(C.c_float)
+        _check(self.lib, self.lib.vspg_libm_log1m_batch(self.h, x.shape[0], x.ctypes.data_as(fp), out.ctypes.data_as(fp), _vp(0)))
+        return out
 
     def set_guiding_field(self, surface, volume, stream=None):
         _check(self.lib, self.lib.vspg_renderer_set_guiding_field(self.h, C.byref(surface.pod) if surface else None,

@@ -168,30 +168,44 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     flush_counters(pc, paths, counters);
 }
 
-// Workgroup-level wavefront kernel (see vspg_wg_kernel.h for the design): a persistent 256-thread
-// workgroup advances a pool of NP paths parked in LDS, phase by phase, over compacted lists.
-//   counters in s_cnt (iteration k, parity par = k & 1):
-//     A0[par], A1[par]  entries of segment list k: new (depth-0) paths grow from the front of
-//                       s_listA[par], continuing paths from its back; CURA[par] = wave chunk cursor
-//     BV, BS, CURB      vertex list: volume vertices from the front of s_listB, surface from the back
-//     NFREE[par]        free slots (s_free[par]) waiting for a work item in R(k); slots freed during
-//                       iteration k collect in s_free[nxt];  NASSIGN / RNEXT / REND / EXH: refill state
+// Workgroup-level wavefront kernel (see vspg_wg_kernel.h for the design): a persistent workgroup
+// advances a pool of NP paths parked in LDS, phase by phase, over compacted lists.  Iteration k
+// (parity par = k & 1, nxt = par ^ 1):
+//   assign  wavefront 0 maps the free slots of s_free[par] to work items (s_item), claiming chunks of
+//           kWgChunk items from the global head;
+//   S       "segment" phase over one dense index space
+//             [0, nAssign)           fresh slots: camera ray + PRIMARY segment (VSP-guided distance sampling)
+//             [.., + A0[par])        slots whose pixel starts its next sample (multi-sample launches): same
+//             [.., + A1[par])        continuing paths: one SECONDARY segment (plain delta tracking)
+//           survivors go to the vertex list (volume vertices from the front of s_listB, surface vertices
+//           from the back), finished paths are splatted and their slot goes to s_free[nxt] or, when the
+//           pixel has samples left, to the front of s_listA[nxt];
+//   V       vertex phase over s_listB: NEE, Russian roulette, new direction; survivors go to the back of
+//           s_listA[nxt].
+// Fusing the camera ray with the primary segment keeps the heaviest code (optical-depth-space sampling)
+// where the path state is still compile-time constant (beta = r_u = r_l = 1, L = 0), and keeping it out
+// of the secondary phase is what lets the whole kernel fit the 128-VGPR budget of 4 waves per SIMD.
+// Launch shapes.  Homogeneous media: the segment code has no loops left (see HomogeneousMedium::
+// kAlwaysRealCollision) and the kernel fits 128 VGPRs: 512-thread workgroups, 4 waves per SIMD, two
+// workgroups per CU, 480 paths each.  Grid media keep the DDA / null-collision loops (about 250 live
+// VGPRs): 256-thread workgroups at 2 waves per SIMD, 368 paths beside the 16 KB majorant grid in LDS.
 #ifndef VSPG_WG_WAVES
-#define VSPG_WG_WAVES 2
+#define VSPG_WG_WAVES 4
+#endif
+#ifndef VSPG_WG_BLOCK
+#define VSPG_WG_BLOCK 512
 #endif
 #ifndef VSPG_WG_NP
 #define VSPG_WG_NP 480
 #endif
-#ifndef VSPG_WG_NP_GRID
-#define VSPG_WG_NP_GRID 384
-#endif
-constexpr int kWgWavesPerSimd = VSPG_WG_WAVES;
+constexpr int kWgWavesHomog = VSPG_WG_WAVES, kWgBlockHomog = VSPG_WG_BLOCK, kWgPoolHomog = VSPG_WG_NP;
+constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 368;
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_COUNT = 16 };
 
-template <class Medium, bool GUIDED, int NP>
-__global__ __launch_bounds__(kBlock, kWgWavesPerSimd) void k_render_wave_wg(
+template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd>
+__global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
     int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int *__restrict__ work_head,
     unsigned long long *__restrict__ counters) {
@@ -214,13 +228,13 @@ __global__ __launch_bounds__(kBlock, kWgWavesPerSimd) void k_render_wave_wg(
         __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
         const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
         float4 *dst = reinterpret_cast<float4 *>(s_maj);
-        for (int i = threadIdx.x; i < kMajRes * kMajRes * kMajRes / 4; i += kBlock) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kMajRes * kMajRes * kMajRes / 4; i += kWgBlock) dst[i] = src[i];
         maj_ptr = s_maj;
     }
     const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
     float *glds = nullptr;
     if constexpr (GUIDED) {
-        __shared__ float s_gmix[kBlock * 5 * GK];
+        __shared__ float s_gmix[kWgBlock * 5 * GK];
         glds = s_gmix + threadIdx.x;
     }
     PathCounters pc = {0, 0, 0, 0, 0};
@@ -228,38 +242,16 @@ __global__ __launch_bounds__(kBlock, kWgWavesPerSimd) void k_render_wave_wg(
 
     stage_scene_lds(S);
     if (threadIdx.x < C_COUNT) s_cnt[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < NP; i += kBlock) s_free[0][i] = (unsigned short)i;
+    for (int i = threadIdx.x; i < NP; i += kWgBlock) s_free[0][i] = (unsigned short)i;
     __syncthreads();
     if (threadIdx.x == 0) s_cnt[C_NFREE] = NP;
     __syncthreads();
 
-    // a finished path: splat, then either start the pixel's next sample in the same slot (multi-sample
-    // launches keep one pixel's samples in order in one slot) or hand the slot back
-    auto finish = [&](int slot, int par, PathState &st, Sampler &sampler, IsgSample &isg, bool *restart, bool *freed) {
-        const Spec L = finish_radiance(st.L);
-        const int pidx = P.i(PF_PIXEL, slot);
-        film_add_sample(film + pidx, L);
-        isg_add_sample_atomic(isg_stats + (size_t)pidx * VSPG_ISG_STATS, L, isg);
-        paths++;
-        const int s = P.i(PF_SAMPLE, slot) + sample_step;
-        if (s < wave_end) {
-            int ch;
-            const int py = pidx / W, px = pidx - py * W;
-            start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);
-            P.i(PF_SAMPLE, slot) = s;
-            pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, -1, mk(0, 0, 0), FL_LIVE);
-            *restart = true;
-        } else {
-            *freed = true;
-        }
-        (void)par;
-    };
-
     VSPG_PROF(PS_WG_TOTAL);
     for (int k = 0;; ++k) {
         const int par = k & 1, nxt = par ^ 1;
-        // ---- R: hand work items to the free slots ------------------------------------------------
-        if (threadIdx.x < 64) {  // wavefront 0: items for the first nFree entries of s_free
+        // ---- assign: work items for the free slots ---------------------------------------------------
+        if (threadIdx.x < 64) {
             const unsigned n_free = s_cnt[C_NFREE + par];
             unsigned rnext = s_cnt[C_RNEXT], rend = s_cnt[C_REND], exh = s_cnt[C_EXH];
             unsigned filled = 0;
@@ -280,52 +272,18 @@ __global__ __launch_bounds__(kBlock, kWgWavesPerSimd) void k_render_wave_wg(
             }
             if (lane == 0) {
                 s_cnt[C_RNEXT] = rnext; s_cnt[C_REND] = rend; s_cnt[C_EXH] = exh;
-                s_cnt[C_NASSIGN] = filled;
+                s_cnt[C_NASSIGN] = filled;  // free slots beyond `filled` stay empty: the work has run out
                 s_cnt[C_NFREE + par] = 0;
                 s_cnt[C_BV] = 0; s_cnt[C_BS] = 0; s_cnt[C_CURB] = 0;
                 s_cnt[C_A0 + nxt] = 0; s_cnt[C_A1 + nxt] = 0; s_cnt[C_CURA + nxt] = 0;
             }
         }
         { VSPG_PROF(PS_WG_BAR_R); __syncthreads(); }
-        {
-            VSPG_PROF(PS_WG_R);
-            const unsigned n_assign = s_cnt[C_NASSIGN];
-            for (unsigned j0 = 0; j0 < n_assign; j0 += kBlock) {
-                const unsigned j = j0 + threadIdx.x;
-                bool started = false, back = false;
-                int slot = 0;
-                if (j < n_assign) {
-                    slot = s_free[par][j];
-                    const unsigned item = s_item[j];
-                    const unsigned tile = item >> 6, l = item & 63u;
-                    const int px = (int)(tile % (unsigned)tilesX) * 8 + (int)(l & 7u);
-                    const int py = (int)(tile / (unsigned)tilesX) * 8 + (int)(l >> 3);
-                    if (px < W && py < H && first_sample < wave_end) {
-                        Sampler sampler;
-                        PathState st;
-                        IsgSample isg;
-                        int ch;
-                        if (single_sample)
-                            start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
-                        else
-                            start_path(S, vsp_buf, vsp_ready, px, py, first_sample, sampler, st, &ch, isg);
-                        P.i(PF_PIXEL, slot) = py * W + px;
-                        P.i(PF_SAMPLE, slot) = first_sample;
-                        pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, -1, mk(0, 0, 0), FL_LIVE);
-                        started = true;
-                    } else {
-                        back = true;  // tile padding: the slot waits for the next item
-                    }
-                }
-                list_push(started, slot, s_listA[par], &s_cnt[C_A0 + par]);
-                list_push(back, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
-            }
-        }
-        { VSPG_PROF(PS_WG_BAR_R); __syncthreads(); }
-        const unsigned nA0 = s_cnt[C_A0 + par], nA1 = s_cnt[C_A1 + par], nA = nA0 + nA1;
+        const unsigned nFresh = s_cnt[C_NASSIGN], nA0 = s_cnt[C_A0 + par], nA1 = s_cnt[C_A1 + par];
+        const unsigned nPrim = nFresh + nA0, nA = nPrim + nA1;
         if (nA == 0 && s_cnt[C_EXH]) break;  // nothing in flight and nothing left to start
 
-        // ---- A: one segment (intersect + distance sampling) for every live path -------------------
+        // ---- S: camera ray + primary segment for new paths, one secondary segment for the others ------
         while (true) {
             unsigned base = 0;
             if (lane == 0) base = atomicAdd(&s_cnt[C_CURA + par], 64u);
@@ -336,40 +294,78 @@ __global__ __launch_bounds__(kBlock, kWgWavesPerSimd) void k_render_wave_wg(
             bool toV = false, toS = false, restart = false, freed = false;
             int slot = 0;
             if (i < nA) {
-                slot = i < nA0 ? s_listA[par][i] : s_listA[par][NP - 1 - (int)(i - nA0)];
                 Sampler sampler;
                 PathState st;
                 IsgSample isg;
-                int ch;
-                const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
-                const int pidx = P.i(PF_PIXEL, slot);
-                const int py = pidx / W, px = pidx - py * W;
+                int ch = 0, pidx = 0;
                 Vertex vx;
-                if (li_segment_a<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, vx)) {
-                    pool_store_a(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                bool alive = false, valid = true;
+                if (i < nPrim) {
+                    int px, py, smp;
+                    if (i < nFresh) {
+                        slot = s_free[par][i];
+                        const unsigned item = s_item[i];
+                        const unsigned tile = item >> 6, l = item & 63u;
+                        px = (int)(tile % (unsigned)tilesX) * 8 + (int)(l & 7u);
+                        py = (int)(tile / (unsigned)tilesX) * 8 + (int)(l >> 3);
+                        smp = first_sample;
+                        valid = px < W && py < H && first_sample < wave_end;  // tile padding: the slot stays free
+                        pidx = py * W + px;
+                    } else {
+                        slot = s_listA[par][i - nFresh];
+                        pidx = P.i(PF_PIXEL, slot);
+                        smp = P.i(PF_SAMPLE, slot);
+                        py = pidx / W;
+                        px = pidx - py * W;
+                    }
+                    if (valid) {
+                        if (single_sample)
+                            start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
+                        else
+                            start_path(S, vsp_buf, vsp_ready, px, py, smp, sampler, st, &ch, isg);
+                        P.i(PF_PIXEL, slot) = pidx;
+                        P.i(PF_SAMPLE, slot) = smp;
+                        alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
+                                                                          isg, pc, vx);
+                        if (alive) {
+                            pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, -1, mk(0, 0, 0),
+                                                    FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
+                            pool_store_vertex(P, slot, vx);
+                        }
+                    } else {
+                        freed = true;
+                    }
+                } else {
+                    slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
+                    const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
+                    pidx = P.i(PF_PIXEL, slot);
+                    const int py = pidx / W, px = pidx - py * W;
+                    alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
+                                                                        isg, pc, vx);
+                    if (alive) pool_store_a(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                }
+                if (alive) {
                     toV = vx.volume;
                     toS = !vx.volume;
-                } else {
-                    finish(slot, par, st, sampler, isg, &restart, &freed);
+                } else if (valid) {
+                    const Spec L = finish_radiance(st.L);
+                    film_add_sample(film + pidx, L);
+                    isg_add_sample_atomic(isg_stats + (size_t)pidx * VSPG_ISG_STATS, L, isg);
+                    paths++;
+                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
+                    P.i(PF_SAMPLE, slot) = s2;
+                    restart = s2 < wave_end;
+                    freed = !restart;
                 }
             }
             list_push(toV, slot, s_listB, &s_cnt[C_BV]);
-            {   // surface vertices grow from the back
-                const unsigned long long m = __ballot(toS);
-                if (m) {
-                    const int leader = __ffsll((long long)m) - 1;
-                    unsigned b = 0;
-                    if (lane == leader) b = atomicAdd(&s_cnt[C_BS], (unsigned)__popcll(m));
-                    b = __shfl(b, leader);
-                    if (toS) s_listB[NP - 1 - (int)(b + (unsigned)__popcll(m & ((1ull << lane) - 1ull)))] = (unsigned short)slot;
-                }
-            }
+            list_push_back(toS, slot, s_listB + NP - 1, &s_cnt[C_BS]);
             list_push(restart, slot, s_listA[nxt], &s_cnt[C_A0 + nxt]);
             list_push(freed, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
         }
         { VSPG_PROF(PS_WG_BAR_A); __syncthreads(); }
 
-        // ---- B: vertex processing (NEE, Russian roulette, new direction) --------------------------
+        // ---- V: vertex processing (NEE, Russian roulette, new direction) ----------------------------
         const unsigned nBV = s_cnt[C_BV], nB = nBV + s_cnt[C_BS];
         while (true) {
             unsigned base = 0;
@@ -388,23 +384,22 @@ __global__ __launch_bounds__(kBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 int ch;
                 const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
                 const Vertex vx = pool_load_vertex(P, slot, fl);
-                if (li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kBlock)) {
+                if (li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock)) {
                     pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, vx.volume ? -1 : vx.quad, vx.p, FL_LIVE);
                     cont = true;
                 } else {
-                    finish(slot, par, st, sampler, isg, &restart, &freed);
+                    const int pidx = P.i(PF_PIXEL, slot);
+                    const Spec L = finish_radiance(st.L);
+                    film_add_sample(film + pidx, L);
+                    isg_add_sample_atomic(isg_stats + (size_t)pidx * VSPG_ISG_STATS, L, isg);
+                    paths++;
+                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
+                    P.i(PF_SAMPLE, slot) = s2;
+                    restart = s2 < wave_end;
+                    freed = !restart;
                 }
             }
-            {   // continuing paths grow from the back of the next segment list
-                const unsigned long long m = __ballot(cont);
-                if (m) {
-                    const int leader = __ffsll((long long)m) - 1;
-                    unsigned b = 0;
-                    if (lane == leader) b = atomicAdd(&s_cnt[C_A1 + nxt], (unsigned)__popcll(m));
-                    b = __shfl(b, leader);
-                    if (cont) s_listA[nxt][NP - 1 - (int)(b + (unsigned)__popcll(m & ((1ull << lane) - 1ull)))] = (unsigned short)slot;
-                }
-            }
+            list_push_back(cont, slot, s_listA[nxt] + NP - 1, &s_cnt[C_A1 + nxt]);
             list_push(restart, slot, s_listA[nxt], &s_cnt[C_A0 + nxt]);
             list_push(freed, slot, s_free[nxt], &s_cnt[C_NFREE + nxt]);
         }
@@ -449,6 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict_
     const DScene &S = *Sp;
     int i = blockIdx.x * kBlock + threadIdx.x;
     vspg_libm::stage_logf_tab_lds();
+    vspg_libm::stage_log_tab_lds();
     __syncthreads();
     if (i >= n) return;
     const Medium medium = MediumMaker<Medium>::make(S, S.majorant);
@@ -545,6 +541,13 @@ __global__ __launch_bounds__(kBlock) void k_libm(int n, const float *__restrict_
     lo[i] = logf_(x[i]);
     so[i] = sinf_(x[i]);
     co[i] = cosf_(x[i]);
+}
+__global__ __launch_bounds__(kBlock) void k_libm_log1m(int n, const float *__restrict__ x, float *__restrict__ out) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    vspg_libm::stage_log_tab_lds();
+    __syncthreads();
+    if (i >= n) return;
+    out[i] = neg_log1m_d(x[i]);
 }
 
 // ImageSpaceGuidingBuffer::Update stand-in: 5x5 box filter over the sufficient statistics,
@@ -998,17 +1001,20 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const char *kenv = getenv("VSPG_KERNEL");
     const bool use_wg = !guided && !(kenv && strcmp(kenv, "lane") == 0);
     if (use_wg) {
-        long long wblocks = (long long)r->num_cus * kWgWavesPerSimd;
+        const int wwaves = grid ? kWgWavesGrid : kWgWavesHomog, wblock = grid ? kWgBlockGrid : kWgBlockHomog;
+        long long wblocks = (long long)r->num_cus * (wwaves * 4 / (wblock / 64));
         const long long wmax = (items + kWgChunk - 1) / kWgChunk;
         if (wblocks > wmax) wblocks = wmax;
         if (grid)
-            hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, VSPG_WG_NP_GRID>), dim3((unsigned)wblocks), dim3(kBlock), 0,
-                               (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first,
-                               n_samples == 1 ? 1 : 0, jump, r->work_head, r->counters);
+            hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
+                               dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, r->work_head,
+                               r->counters);
         else
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, VSPG_WG_NP>), dim3((unsigned)wblocks), dim3(kBlock), 0,
-                               (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first,
-                               n_samples == 1 ? 1 : 0, jump, r->work_head, r->counters);
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, r->work_head,
+                               r->counters);
     } else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
     else if (grid) VSPG_LAUNCH_RENDER(GridMedium, false);
     else if (guided) VSPG_LAUNCH_RENDER(HomogeneousMedium, true);
@@ -1268,6 +1274,22 @@ int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, flo
     HIPCHK(hipMemcpyAsync(logf_out, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(sinf_out, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(cosf_out, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_libm_log1m_batch(VspgRenderer *r, int n, const float *x, float *out, void *stream) {
+    if (!r || !x || !out || n < 0) return fail(VSPG_EINVAL, "bad argument");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dx, dout;
+    HIPCHK(hipMalloc(&dx.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dout.p, (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_libm_log1m, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, (const float *)dx.p, (float *)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }

@@ -278,12 +278,12 @@ struct Sampler {
 
 // ---------------------------------------------------------------------------------------
 // libm: float functions reproduce the host glibc bit for bit (vspg_libm.h); the reference's
-// `std::log(1.0 - x)` in media_sampleTMaj.h is DOUBLE precision -> ocml double log, rounded once
+// `std::log(1.0 - x)` in media_sampleTMaj.h is DOUBLE precision -> the double log of vspg_libm.h, rounded once
 // ---------------------------------------------------------------------------------------
 VLEAF float logf_(float x) { return vspg_libm::logf_host_exact(x); }
 VLEAF float sinf_(float x) { return vspg_libm::sinf_host_exact(x); }
 VLEAF float cosf_(float x) { return vspg_libm::cosf_host_exact(x); }
-VLEAF float neg_log1m_d(float x) { return (float)(-log(1.0 - (double)x)); }  // -std::log(1.0 - x)
+VLEAF float neg_log1m_d(float x) { return (float)(-vspg_libm::log_host_exact(1.0 - (double)x)); }  // -std::log(1.0 - x)
 
 // ---------------------------------------------------------------------------------------
 // a3: FastExp / SampleExponential / SampleDiscrete
@@ -485,6 +485,7 @@ __shared__ DQuad s_scene_quads[VSPG_MAX_QUADS];
 __shared__ int32_t s_scene_light_quads[VSPG_MAX_QUADS];
 VDEV void stage_scene_lds(const DScene &S) {
     vspg_libm::stage_logf_tab_lds();
+    vspg_libm::stage_log_tab_lds();
     const uint32_t *src = reinterpret_cast<const uint32_t *>(S.quads);
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_scene_quads);
     const int n = S.n_quads * (int)(sizeof(DQuad) / 4);
@@ -634,6 +635,11 @@ struct HomogeneousMedium {
     VDEV MediumProps sample_point(V3) const { return MediumProps{sigma_a, sigma_s, Le, g}; }
     VDEV bool is_homogeneous() const { return true; }
     static constexpr bool kSingleSegment = true;
+    // sigma_t = sigma_s + sigma_a at the collision and sigma_maj = sigma_a + sigma_s of the segment are
+    // the same float sum, so pScatter = sigma_t/sigma_maj == 1 and pNull == 0 exactly:
+    // SampleDiscrete({1, 0}, u) returns 0 for every u in [0, 1) -- the first collision of the
+    // distance-sampling walk is always a real one (no null collisions in a homogeneous medium).
+    static constexpr bool kAlwaysRealCollision = true;
 };
 VDEV HomogeneousMedium make_homogeneous(const DScene &S) {
     return HomogeneousMedium{lds(S.sigma_a), lds(S.sigma_s), lds(S.Le), S.g};
@@ -788,6 +794,7 @@ struct GridMedium {
     }
     VDEV bool is_homogeneous() const { return false; }
     static constexpr bool kSingleSegment = false;
+    static constexpr bool kAlwaysRealCollision = false;
 };
 VDEV GridMedium make_grid(const DScene &S, const float *majorant) {
     return GridMedium{lds(S.sigma_a), lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,

@@ -289,7 +289,11 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
     ev.kind = EV_PASS;
     ev.p = mk(0, 0, 0);
     ev.g = 0;
+#ifdef VSPG_EXP_NOODS  // timing experiment only (primary rays lose their VSP guiding)
+    constexpr bool kPlainOnly = !GUIDED;
+#else
     constexpr bool kPlainOnly = SEG == SEG_SECONDARY && !GUIDED;
+#endif
     if constexpr (SEG == SEG_PRIMARY) __builtin_assume(st.depth == 0);
     if constexpr (SEG == SEG_SECONDARY) __builtin_assume(st.depth > 0);
     bool guide = false;
@@ -401,7 +405,9 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
             float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
             float pNull = fmax_(0.f, 1 - pScatter);
             float um = rng.uniform();
-            int mode = sample_discrete2(pScatter, pNull, um);
+            // Medium::kAlwaysRealCollision: the draw cannot change the outcome (see HomogeneousMedium), and
+            // with it the walk's private RNG -- seeded by two 64-bit hashes per segment -- is dead code
+            const int mode = Medium::kAlwaysRealCollision ? 0 : sample_discrete2(pScatter, pNull, um);
             if (mode == 0) {
                 if (st.depth == 0) {
                     isg.valid = true;

@@ -9,11 +9,10 @@
 // path), and advances all of them phase by phase.  Between phases the live paths are compacted into
 // index lists with wave ballots + one LDS atomic per wavefront, so every phase runs over a dense
 // list of paths that all need the SAME code:
-//     R   refill free slots with new camera paths (work items claimed per workgroup)
-//     A0  first segment of new paths: intersect + VSP-guided distance sampling (coherent)
-//     A1  later segments: intersect + plain delta tracking
-//     V   volume vertices: NEE, Russian roulette, phase-function sampling
-//     S   surface vertices: NEE, BSDF sampling, Russian roulette
+//     new paths         camera ray + primary segment: intersect + VSP-guided distance sampling (coherent)
+//     continuing paths  one secondary segment: intersect + plain delta tracking
+//     volume vertices   NEE, Russian roulette, phase-function sampling
+//     surface vertices  NEE, BSDF sampling, Russian roulette
 // A path's registers exist only inside a phase; the SoA record of SURVEY 8d is what crosses phase
 // boundaries -- through LDS instead of HBM.  Per path the operations and their order are exactly
 // those of li_segment_a / li_segment_b, so results are bit-identical to the per-lane kernel.
@@ -113,6 +112,11 @@ VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sa
     P.f(PF_VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
 }
 
+VDEV void pool_store_vertex(const Pool &P, int slot, const Vertex &vx) {
+    P.set3(PF_VXP, slot, vx.p);
+    if (vx.volume) P.f(PF_VXG, slot) = vx.g; else P.i(PF_VXG, slot) = vx.quad;
+    P.f(PF_VXT, slot) = vx.t;
+}
 // after li_segment_a: only what that half changes (L, beta, r_u, r_l, sampler, depth / ISG flags) plus
 // the vertex it stopped at; ray, previous context, rr_correction and guiding state are untouched
 VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
@@ -126,9 +130,7 @@ VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampl
     if (vx.volume) fl |= FL_VX_VOLUME;
     P.u(PF_FLAGS, slot) = fl;
     P.f(PF_VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
-    P.set3(PF_VXP, slot, vx.p);
-    if (vx.volume) P.f(PF_VXG, slot) = vx.g; else P.i(PF_VXG, slot) = vx.quad;
-    P.f(PF_VXT, slot) = vx.t;
+    pool_store_vertex(P, slot, vx);
 }
 VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
     Vertex vx;
@@ -197,6 +199,18 @@ VDEV void list_push(bool pred, int slot, unsigned short *list, unsigned int *cou
     if (lane == leader) base = atomicAdd(count, (unsigned int)__popcll(m));
     base = __shfl(base, leader);
     if (pred) list[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)slot;
+}
+
+// same, growing downwards from `last` (the two-ended lists keep both kinds dense in one array)
+VDEV void list_push_back(bool pred, int slot, unsigned short *last, unsigned int *count) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    if (pred) *(last - (int)(base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull)))) = (unsigned short)slot;
 }
 
 }  // namespace vspg
