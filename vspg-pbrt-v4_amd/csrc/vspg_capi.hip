@@ -202,13 +202,15 @@ constexpr int kWgWavesHomog = VSPG_WG_WAVES, kWgBlockHomog = VSPG_WG_BLOCK, kWgP
 constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 368;
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
-       C_EXH = 14, C_COUNT = 16 };
+       C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
 
 template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd>
 __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
-    int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int *__restrict__ work_head,
-    unsigned long long *__restrict__ counters) {
+    int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int tiles_magic,
+    unsigned int *__restrict__ work_head, unsigned long long *__restrict__ counters) {
+    // tiles_magic = ceil(2^32 / tilesX): the one integer division of the kernel (tile index -> tile row, once
+    // per claimed chunk) is a multiply-high by it plus a fix-up; pixels travel as packed (x | y << 16)
     const DScene &S = *Sp;
     const int W = S.xres, H = S.yres;
     const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
@@ -237,10 +239,16 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
         __shared__ float s_gmix[kWgBlock * 5 * GK];
         glds = s_gmix + threadIdx.x;
     }
-    PathCounters pc = {0, 0, 0, 0, 0};
-    uint32_t paths = 0;
+    __shared__ unsigned int s_counters[CNT_COUNT];
+#ifdef VSPG_WG_WAVE_COUNTERS  // alternative sink: no per-lane registers, ~2 % slower (measured)
+    const WaveCounters pc{s_counters};
+#else
+    struct LaneCounters : PathCounters { uint32_t paths; VDEV void path() { paths++; } } pc;
+    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = pc.paths = 0;
+#endif
 
     stage_scene_lds(S);
+    if (threadIdx.x < CNT_COUNT) s_counters[threadIdx.x] = 0;
     if (threadIdx.x < C_COUNT) s_cnt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < NP; i += kWgBlock) s_free[0][i] = (unsigned short)i;
     __syncthreads();
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
         if (threadIdx.x < 64) {
             const unsigned n_free = s_cnt[C_NFREE + par];
             unsigned rnext = s_cnt[C_RNEXT], rend = s_cnt[C_REND], exh = s_cnt[C_EXH];
+            unsigned rtx = s_cnt[C_RTX], rty = s_cnt[C_RTY];  // tile column / row of item rnext
             unsigned filled = 0;
             while (filled < n_free) {
                 if (rnext >= rend) {
@@ -264,14 +273,25 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                     if (base >= total_items) { exh = 1; break; }
                     rnext = base;
                     rend = base + (unsigned)kWgChunk < total_items ? base + (unsigned)kWgChunk : total_items;
+                    const unsigned tile = base >> 6;
+                    rty = tilesX == 1 ? tile : __umulhi(tile, tiles_magic);
+                    rtx = tile - rty * (unsigned)tilesX;
+                    while (rtx >= (unsigned)tilesX) { rtx -= (unsigned)tilesX; rty++; }
                 }
                 const unsigned n = rend - rnext < n_free - filled ? rend - rnext : n_free - filled;
-                for (unsigned j = (unsigned)lane; j < n; j += 64u) s_item[filled + j] = rnext + j;
+                for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+                    const unsigned it = (rnext & 63u) + j;
+                    unsigned tx = rtx + (it >> 6), ty = rty;
+                    while (tx >= (unsigned)tilesX) { tx -= (unsigned)tilesX; ty++; }
+                    s_item[filled + j] = (tx * 8u + (it & 7u)) | ((ty * 8u + ((it >> 3) & 7u)) << 16);
+                }
+                rtx += ((rnext & 63u) + n) >> 6;
+                while (rtx >= (unsigned)tilesX) { rtx -= (unsigned)tilesX; rty++; }
                 rnext += n;
                 filled += n;
             }
             if (lane == 0) {
-                s_cnt[C_RNEXT] = rnext; s_cnt[C_REND] = rend; s_cnt[C_EXH] = exh;
+                s_cnt[C_RNEXT] = rnext; s_cnt[C_REND] = rend; s_cnt[C_EXH] = exh; s_cnt[C_RTX] = rtx; s_cnt[C_RTY] = rty;
                 s_cnt[C_NASSIGN] = filled;  // free slots beyond `filled` stay empty: the work has run out
                 s_cnt[C_NFREE + par] = 0;
                 s_cnt[C_BV] = 0; s_cnt[C_BS] = 0; s_cnt[C_CURB] = 0;
@@ -297,39 +317,34 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 Sampler sampler;
                 PathState st;
                 IsgSample isg;
-                int ch = 0, pidx = 0;
+                int ch = 0, pxy = 0;
                 Vertex vx;
                 bool alive = false, valid = true;
                 if (i < nPrim) {
                     int px, py, smp;
                     if (i < nFresh) {
                         slot = s_free[par][i];
-                        const unsigned item = s_item[i];
-                        const unsigned tile = item >> 6, l = item & 63u;
-                        px = (int)(tile % (unsigned)tilesX) * 8 + (int)(l & 7u);
-                        py = (int)(tile / (unsigned)tilesX) * 8 + (int)(l >> 3);
+                        pxy = (int)s_item[i];
                         smp = first_sample;
-                        valid = px < W && py < H && first_sample < wave_end;  // tile padding: the slot stays free
-                        pidx = py * W + px;
                     } else {
                         slot = s_listA[par][i - nFresh];
-                        pidx = P.i(PF_PIXEL, slot);
+                        pxy = P.i(PF_PIXEL, slot);
                         smp = P.i(PF_SAMPLE, slot);
-                        py = pidx / W;
-                        px = pidx - py * W;
                     }
+                    px = pxy & 0xffff;
+                    py = (int)((unsigned)pxy >> 16);
+                    valid = px < W && py < H && smp < wave_end;  // tile padding: the slot stays free
                     if (valid) {
                         if (single_sample)
                             start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
                         else
                             start_path(S, vsp_buf, vsp_ready, px, py, smp, sampler, st, &ch, isg);
-                        P.i(PF_PIXEL, slot) = pidx;
+                        P.i(PF_PIXEL, slot) = pxy;
                         P.i(PF_SAMPLE, slot) = smp;
                         alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                           isg, pc, vx);
                         if (alive) {
-                            pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, -1, mk(0, 0, 0),
-                                                    FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
+                            pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
                             pool_store_vertex(P, slot, vx);
                         }
                     } else {
@@ -338,8 +353,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 } else {
                     slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
                     const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
-                    pidx = P.i(PF_PIXEL, slot);
-                    const int py = pidx / W, px = pidx - py * W;
+                    pxy = P.i(PF_PIXEL, slot);
+                    const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
                     alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                         isg, pc, vx);
                     if (alive) pool_store_a(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
@@ -349,9 +364,10 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                     toS = !vx.volume;
                 } else if (valid) {
                     const Spec L = finish_radiance(st.L);
+                    const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
                     film_add_sample(film + pidx, L);
-                    isg_add_sample_atomic(isg_stats + (size_t)pidx * VSPG_ISG_STATS, L, isg);
-                    paths++;
+                    isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+                    pc.path();
                     const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
                     P.i(PF_SAMPLE, slot) = s2;
                     restart = s2 < wave_end;
@@ -385,14 +401,15 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
                 const Vertex vx = pool_load_vertex(P, slot, fl);
                 if (li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock)) {
-                    pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, vx.volume ? -1 : vx.quad, vx.p, FL_LIVE);
+                    pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, FL_LIVE);
                     cont = true;
                 } else {
-                    const int pidx = P.i(PF_PIXEL, slot);
+                    const int pxy = P.i(PF_PIXEL, slot);
+                    const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
                     const Spec L = finish_radiance(st.L);
                     film_add_sample(film + pidx, L);
-                    isg_add_sample_atomic(isg_stats + (size_t)pidx * VSPG_ISG_STATS, L, isg);
-                    paths++;
+                    isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+                    pc.path();
                     const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
                     P.i(PF_SAMPLE, slot) = s2;
                     restart = s2 < wave_end;
@@ -405,7 +422,14 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
         }
         { VSPG_PROF(PS_WG_BAR_B); __syncthreads(); }
     }
-    flush_counters(pc, paths, counters);
+    static_assert(CNT_COUNT == kNumCounters, "counter layout");
+#ifndef VSPG_WG_WAVE_COUNTERS
+    atomicAdd(&s_counters[CNT_PATHS], pc.paths); atomicAdd(&s_counters[CNT_SEGMENTS], pc.segments);
+    atomicAdd(&s_counters[CNT_VOLUME_SCATTERS], pc.volume_scatters); atomicAdd(&s_counters[CNT_SURFACE_HITS], pc.surface_hits);
+    atomicAdd(&s_counters[CNT_DENSITY_QUERIES], pc.density_queries); atomicAdd(&s_counters[CNT_SHADOW_RAYS], pc.shadow_rays);
+    __syncthreads();
+#endif
+    if (threadIdx.x < CNT_COUNT) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_counters[threadIdx.x]);
 }
 
 template <class Medium, bool GUIDED>
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict_
         ncb++;
         lastp = p;
         last_t = dot(p - ro, rdn);
-        Spec sigma_t = mp.sigma_s + mp.sigma_a;
+        Spec sigma_t = mp.sigma_t;
         sum += ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
         if (Q.stop_after > 0 && ncb >= Q.stop_after) return false;
         return true;
@@ -716,6 +740,13 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
     for (int k = 0; k < 3; ++k) {
         D->sigma_a[k] = sc.medium.sigma_a[k];
         D->sigma_s[k] = sc.medium.sigma_s[k];
+        {
+            volatile float st = D->sigma_s[k] + D->sigma_a[k];  // volatile: one rounding per operation, no contraction
+            volatile float sn = st - D->sigma_a[k];
+            sn = sn - D->sigma_s[k];
+            D->sigma_t[k] = st;
+            D->sigma_n_raw[k] = sn;
+        }
         D->Le[k] = sc.medium.Le[k];
     }
     D->g = sc.medium.g;
@@ -771,6 +802,7 @@ static bool wants_guiding(const VspgIntegratorParams &p) {
 static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const VspgRenderConfig *cfg) {
     if (!scene || !p || !cfg) return fail(VSPG_EINVAL, "null argument");
     if (cfg->xres <= 0 || cfg->yres <= 0) return fail(VSPG_EINVAL, "film resolution must be positive");
+    if (cfg->xres > 32768 || cfg->yres > 32768) return fail(VSPG_EINVAL, "film resolution above 32768 (pixels travel as packed 16-bit pairs)");
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return fail(VSPG_EINVAL, "n_quads out of range");
     if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count))
         return fail(VSPG_EINVAL, "shard_index out of range");
@@ -1001,6 +1033,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const char *kenv = getenv("VSPG_KERNEL");
     const bool use_wg = !guided && !(kenv && strcmp(kenv, "lane") == 0);
     if (use_wg) {
+        const unsigned tiles_magic = tilesX > 1 ? (unsigned)((0x100000000ull + (unsigned)tilesX - 1) / (unsigned)tilesX) : 0u;
         const int wwaves = grid ? kWgWavesGrid : kWgWavesHomog, wblock = grid ? kWgBlockGrid : kWgBlockHomog;
         long long wblocks = (long long)r->num_cus * (wwaves * 4 / (wblock / 64));
         const long long wmax = (items + kWgChunk - 1) / kWgChunk;
@@ -1008,13 +1041,13 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         if (grid)
             hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, r->work_head,
-                               r->counters);
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
+                               r->work_head, r->counters);
         else
             hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, r->work_head,
-                               r->counters);
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
+                               r->work_head, r->counters);
     } else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
     else if (grid) VSPG_LAUNCH_RENDER(GridMedium, false);
     else if (guided) VSPG_LAUNCH_RENDER(HomogeneousMedium, true);

@@ -462,6 +462,11 @@ struct DScene {
     // medium
     int32_t medium_type;
     float sigma_a[3], sigma_s[3], Le[3], g;
+    // homogeneous medium: sigma_s + sigma_a and (sigma_t - sigma_a) - sigma_s, formed on the host with the
+    // same IEEE float operations the kernels would use.  They are wave-uniform; the vector ALU is the
+    // only float adder on this chip, so computing them in the kernel parks the results in VGPRs for
+    // the whole persistent loop -- as scalar loads they stay in SGPRs.
+    float sigma_t[3], sigma_n_raw[3];
     // grid medium (GridMedium, media.h:284-390): density samples nx*ny*nz (x fastest) and the 16^3
     // majorant grid (media.cpp:252-269), both in HBM
     int32_t nx, ny, nz;
@@ -612,6 +617,7 @@ VLEAF bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
 struct MediumProps {
     Spec sigma_a, sigma_s, Le;
     float g;
+    Spec sigma_t;  // sigma_s + sigma_a
 };
 struct MajSeg {
     float tMin, tMax;
@@ -621,6 +627,7 @@ struct MajSeg {
 struct HomogeneousMedium {
     Spec sigma_a, sigma_s, Le;
     float g;
+    Spec sigma_t, sigma_n_raw;  // host-precomputed (DScene)
     struct Iter {  // HomogeneousMajorantIterator (media.h:84-106)
         MajSeg seg;
         bool called;
@@ -631,8 +638,10 @@ struct HomogeneousMedium {
             return true;
         }
     };
-    VDEV Iter sample_ray(V3, V3, float tMax) const { return Iter{MajSeg{0, tMax, sigma_a + sigma_s}, false}; }
-    VDEV MediumProps sample_point(V3) const { return MediumProps{sigma_a, sigma_s, Le, g}; }
+    VDEV Iter sample_ray(V3, V3, float tMax) const { return Iter{MajSeg{0, tMax, sigma_t}, false}; }  // sigma_a + sigma_s
+    VDEV MediumProps sample_point(V3) const { return MediumProps{sigma_a, sigma_s, Le, g, sigma_t}; }
+    // null-collision coefficient ClampZero(sigma_maj - sigma_a - sigma_s) for this medium's own majorant
+    VDEV Spec sigma_n(const MediumProps &, Spec) const { return clamp_zero(sigma_n_raw); }
     VDEV bool is_homogeneous() const { return true; }
     static constexpr bool kSingleSegment = true;
     // sigma_t = sigma_s + sigma_a at the collision and sigma_maj = sigma_a + sigma_s of the segment are
@@ -642,7 +651,7 @@ struct HomogeneousMedium {
     static constexpr bool kAlwaysRealCollision = true;
 };
 VDEV HomogeneousMedium make_homogeneous(const DScene &S) {
-    return HomogeneousMedium{lds(S.sigma_a), lds(S.sigma_s), lds(S.Le), S.g};
+    return HomogeneousMedium{lds(S.sigma_a), lds(S.sigma_s), lds(S.Le), S.g, lds(S.sigma_t), lds(S.sigma_n_raw)};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -790,8 +799,10 @@ struct GridMedium {
     }
     VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 (no emission grids in scope)
         float d = lookup(offset(p));
-        return MediumProps{sigma_a * d, sigma_s * d, sp(0.f), g};
+        Spec sa = sigma_a * d, ss = sigma_s * d;
+        return MediumProps{sa, ss, sp(0.f), g, ss + sa};
     }
+    VDEV Spec sigma_n(const MediumProps &mp, Spec sigma_maj) const { return clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s); }
     VDEV bool is_homogeneous() const { return false; }
     static constexpr bool kSingleSegment = false;
     static constexpr bool kAlwaysRealCollision = false;

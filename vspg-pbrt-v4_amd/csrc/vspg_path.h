@@ -96,6 +96,26 @@ struct LsCtx {  // LightSampleContext
     P3i pi;
     V3 n;
 };
+// The previous vertex's LightSampleContext, carried across a path segment in compressed form: a
+// surface vertex is {re-projected hit point, rectangle} and LightSampleContext(isect) =
+// {Point3fi(p, pError), n} is a pure function of the two; a medium vertex (quad < 0) is the exact
+// point with n = 0.  Expanded only where it is read (emitter hit by a non-specular path).
+struct PrevCtx {
+    V3 p;
+    int quad;
+    VDEV LsCtx expand() const {
+        LsCtx c;
+        if (quad >= 0) {
+            const DQuad &q = quad_at(quad);
+            c.pi = p3i_from_err(p, ld3(q.perr));
+            c.n = ld3(q.n);
+        } else {
+            c.pi = p3i_exact(p);
+            c.n = mk(0, 0, 0);
+        }
+        return c;
+    }
+};
 VDEV float light_pdf_li(const DQuad &q, const LsCtx &ctx, V3 wi) {  // shapes.cpp:1329-1352, area branch
     V3 o = offset_ray_origin(ctx.pi, ctx.n, wi);
     float t;
@@ -110,8 +130,31 @@ VDEV float light_pdf_li(const DQuad &q, const LsCtx &ctx, V3 wi) {  // shapes.cp
 // ---------------------------------------------------------------------------------------
 // per-lane counters (reduced per workgroup at kernel end)
 // ---------------------------------------------------------------------------------------
+// Two interchangeable counter sinks (the path functions take either, `class PC`):
+//   PathCounters  one set per lane in registers (per-lane kernels; k_trace_paths reports segments per path);
+//   WaveCounters  one set per workgroup in LDS: the active lanes of a wavefront are counted with a
+//                 ballot and one lane adds the total -- no per-lane registers, ~10 instructions per count.
+enum { CNT_PATHS = 0, CNT_SEGMENTS, CNT_VOLUME_SCATTERS, CNT_SURFACE_HITS, CNT_DENSITY_QUERIES, CNT_SHADOW_RAYS, CNT_COUNT };
 struct PathCounters {
     uint32_t segments, volume_scatters, surface_hits, density_queries, shadow_rays;
+    VDEV void segment() { segments++; }
+    VDEV void volume_scatter() { volume_scatters++; }
+    VDEV void surface_hit() { surface_hits++; }
+    VDEV void density_query() { density_queries++; }
+    VDEV void shadow_ray() { shadow_rays++; }
+};
+struct WaveCounters {
+    unsigned int *c;  // LDS, CNT_COUNT entries
+    VDEV void add(int k) const {
+        const unsigned long long m = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(c + k, (unsigned int)__popcll(m));
+    }
+    VDEV void path() const { add(CNT_PATHS); }
+    VDEV void segment() const { add(CNT_SEGMENTS); }
+    VDEV void volume_scatter() const { add(CNT_VOLUME_SCATTERS); }
+    VDEV void surface_hit() const { add(CNT_SURFACE_HITS); }
+    VDEV void density_query() const { add(CNT_DENSITY_QUERIES); }
+    VDEV void shadow_ray() const { add(CNT_SHADOW_RAYS); }
 };
 
 struct IsgSample {
@@ -133,9 +176,9 @@ struct Intr {
     V3 wo;
     float g;
 };
-template <class Medium>
+template <class Medium, class PC>
 VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, const Bsdf *bsdf, int ch,
-                    Sampler &sampler, Spec r_p, PathCounters &pc, const GDist *gd = nullptr) {
+                    Sampler &sampler, Spec r_p, PC &pc, const GDist *gd = nullptr) {
     V3 ctxp = intr.pi.mid();
     if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
     float u = sampler.get1d();
@@ -180,7 +223,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     Spec T_ray = sp(1.f), r_l = sp(1.f), r_u = sp(1.f);
     Rng rng;
     rng.set_sequence(hash_v3(lo), hash_v3(ld));  // :1193
-    pc.shadow_rays++;
+    pc.shadow_ray();
     if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
         // every surface here carries a material: any hit is an opaque blocker (:1197-1200)
         if (scene_intersect_any(S, lo, ld, 1 - kShadowEps)) return sp(0.f);
@@ -191,7 +234,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
             Spec T_maj = sample_T_maj(medium, lo, ld, tMax, us, rng, ch,
                                       [&](V3, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
                                           // ratio tracking (:1207-1232)
-                                          Spec sigma_n = clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s);
+                                          Spec sigma_n = medium.sigma_n(mp, sigma_maj);
                                           float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
                                           T_ray = T_ray * (T_maj * sigma_n / pdf);
                                           r_l = r_l * (T_maj * sigma_maj / pdf);
@@ -225,7 +268,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
 struct PathState {
     V3 ro, rd;
     Spec L, beta, r_u, r_l;
-    LsCtx prevCtx;
+    PrevCtx prevCtx;
     int depth;
     bool specularBounce, anyNonSpecularBounces, lastVertexVolume;
     float rr_correction, etaScale;
@@ -281,10 +324,10 @@ struct DistEvent {
 //                  loop) is not instantiated in that phase;
 //   SEG_ANY        decided at run time (per-lane kernels).
 enum { SEG_ANY = 0, SEG_PRIMARY = 1, SEG_SECONDARY = 2 };
-template <class Medium, bool GUIDED, int SEG = SEG_ANY>
+template <class Medium, bool GUIDED, int SEG = SEG_ANY, class PC>
 VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
                                PathState &st, float tMax, int ch, Sampler &sampler, Rng &rng, IsgSample &isg,
-                               PathCounters &pc) {
+                               PC &pc) {
     DistEvent ev;
     ev.kind = EV_PASS;
     ev.p = mk(0, 0, 0);
@@ -315,8 +358,8 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
         Spec T_maj = sample_T_maj_resampling(
             medium, st.ro, st.rd, tMax, u, rng, ch, guide, vsp, &vrc, &majorantScale,
             [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
-                pc.density_queries++;
-                Spec sigma_t = mp.sigma_s + mp.sigma_a;
+                pc.density_query();
+                Spec sigma_t = mp.sigma_t;
                 Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
                 float wi = ch_of(sigma_t / sigma_maj * trRatioEst, ch);
                 if (wi > 0) {
@@ -367,7 +410,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 ev.kind = EV_TERMINATE;
                 return ev;
             }
-            pc.volume_scatters++;
+            pc.volume_scatter();
         }
         st.beta = st.beta * (sel_num * factor);
         st.r_u = st.r_u * sel_den;
@@ -390,7 +433,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
     Spec r_u_factor = sp(1.f);  // beta_factor is never written by the reference (always 1)
     float u = sampler.get1d();
     auto on_collision = [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
-            pc.density_queries++;
+            pc.density_query();
             if (!nonzero(st.beta)) {
                 ev.kind = EV_TERMINATE;
                 return false;
@@ -401,7 +444,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 Spec r_e = st.r_u * sigma_maj * T_maj / pdf;
                 if (nonzero(r_e)) st.L = st.L + betap * mp.sigma_a * mp.Le / avg(r_e);
             }
-            Spec sigma_t = mp.sigma_s + mp.sigma_a;
+            Spec sigma_t = mp.sigma_t;
             float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
             float pNull = fmax_(0.f, 1 - pScatter);
             float um = rng.uniform();
@@ -417,7 +460,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                     ev.kind = EV_TERMINATE;
                     return false;
                 }
-                pc.volume_scatters++;
+                pc.volume_scatter();
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
                 st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
                 st.r_u = st.r_u * (T_maj * sigma_t / pdf);
@@ -427,7 +470,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 ev.g = mp.g;
                 return false;
             } else {
-                Spec sigma_n = clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s);
+                Spec sigma_n = medium.sigma_n(mp, sigma_maj);
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
                 st.beta = st.beta * (T_maj * sigma_n / pdf);
                 if (pdf == 0) st.beta = sp(0.f);
@@ -473,11 +516,11 @@ struct Vertex {
     float t;   // surface: tHit (only the guided build needs it, for p = ray.o + tHit * ray.d)
 };
 
-template <class Medium, bool GUIDED = false, int SEG = SEG_ANY>
+template <class Medium, bool GUIDED = false, int SEG = SEG_ANY, class PC>
 VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
-                       PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc, Vertex &vx) {
+                       PathState &st, int ch, Sampler &sampler, IsgSample &isg, PC &pc, Vertex &vx) {
     VSPG_PROF(PS_SEGMENT);
-    pc.segments++;
+    pc.segment();
     Isect si;
     {
         VSPG_PROF(PS_INTERSECT);
@@ -514,7 +557,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
         if (st.depth == 0 || st.specularBounce) {
             st.L = st.L + st.beta * Le / avg(st.r_u);
         } else {
-            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx, st.rd);
+            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx.expand(), st.rd);
             st.r_l = st.r_l * lightPDF;
             float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
             st.L = st.L + st.beta * w_l * Le;
@@ -525,16 +568,16 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
         isg.surface_event = true;
     }
     if (st.depth++ >= S.prm.maxdepth) return false;
-    pc.surface_hits++;
+    pc.surface_hit();
     return true;
 }
 
-template <class Medium, bool GUIDED>
-VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
+template <class Medium, bool GUIDED, class PC>
+VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                            bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride);
 
-template <class Medium, bool GUIDED = false>
-VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
+template <class Medium, bool GUIDED = false, class PC>
+VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                        const Vertex &vx, float *glds = nullptr, int gstride = 0) {
     const bool volume_vertex = vx.volume;
     const V3 vp = vx.p;
@@ -598,8 +641,8 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
         ang = hg_pre(vg, u0, u1, &a0, &a1);  // a0 = sinTheta, a1 = cosTheta
     } else {
         VSPG_PROF(PS_SURF_SAMPLE);
-        st.prevCtx.pi = intr.pi;  // :487
-        st.prevCtx.n = si.n;
+        st.prevCtx.p = si.p;  // :487 LightSampleContext(isect)
+        st.prevCtx.quad = vx.quad;
         (void)sampler.get1d();  // u (unused by DiffuseBxDF)
         float u20 = sampler.get1d(), u21 = sampler.get1d();
         // BSDF::Sample_f / DiffuseBxDF::Sample_f (bsdf.h:58-78, bxdfs.h:47-58)
@@ -617,8 +660,8 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
         float w = pdf / pdf;  // ps->p / ps->pdf
         st.beta = st.beta * w;
         st.r_l = st.r_u / pdf;
-        st.prevCtx.pi = p3i_exact(vp);
-        st.prevCtx.n = mk(0, 0, 0);
+        st.prevCtx.p = vp;
+        st.prevCtx.quad = -1;
         st.ro = vp;
         st.rd = wi;
         st.specularBounce = false;
@@ -657,9 +700,9 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
     return true;
 }
 
-template <class Medium, bool GUIDED = false>
+template <class Medium, bool GUIDED = false, class PC>
 VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
-                     PathState &st, int ch, Sampler &sampler, IsgSample &isg, PathCounters &pc, float *glds = nullptr,
+                     PathState &st, int ch, Sampler &sampler, IsgSample &isg, PC &pc, float *glds = nullptr,
                      int gstride = 0) {
     Vertex vx;
     if (!li_segment_a<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, vx)) return false;
@@ -672,8 +715,8 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
 // 383-398, 404-540) -- same flow as the unguided tail of li_segment, written straight (no sin/cos
 // fusion) because the sampling branches differ per guiding type.
 // ---------------------------------------------------------------------------------------
-template <class Medium, bool GUIDED>
-VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PathCounters &pc,
+template <class Medium, bool GUIDED, class PC>
+VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                            bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride) {
     (void)sampler.get1d();  // v (the stochastic-lookup sample of Init)
     GDist gd;
@@ -795,8 +838,8 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         float w = ps_p / ps_pdf;
         st.beta = st.beta * w;
         st.r_l = st.r_u / ps_pdf;
-        st.prevCtx.pi = p3i_exact(vp);
-        st.prevCtx.n = mk(0, 0, 0);
+        st.prevCtx.p = vp;
+        st.prevCtx.quad = -1;
         st.ro = vp;
         st.rd = wi;
         st.specularBounce = false;
@@ -805,8 +848,8 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         return true;
     }
 
-    st.prevCtx.pi = intr.pi;
-    st.prevCtx.n = si.n;
+    st.prevCtx.p = si.p;
+    st.prevCtx.quad = si.quad;
     V3 wo = -st.rd;
     float u = sampler.get1d();
     float u20 = sampler.get1d(), u21 = sampler.get1d();
@@ -946,8 +989,8 @@ VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, P
     st.beta = sp(1.f);
     st.r_u = sp(1.f);
     st.r_l = sp(1.f);
-    st.prevCtx.pi = p3i_exact(mk(0, 0, 0));
-    st.prevCtx.n = mk(0, 0, 0);
+    st.prevCtx.p = mk(0, 0, 0);
+    st.prevCtx.quad = -1;
     st.depth = 0;
     st.specularBounce = false;
     st.anyNonSpecularBounces = false;

@@ -84,21 +84,18 @@ VDEV void pool_store_rng(const Pool &P, int slot, const Sampler &sampler) {
     P.u(PF_RNG + 3, slot) = (uint32_t)(sampler.rng.inc >> 32);
 }
 
-// everything a path carries into its next segment (after start_path and after a vertex).  The
-// previous light-sample context is kept compressed: {raw point, rectangle} reproduces
-// LightSampleContext(isect) exactly (p3i_from_err is a pure function of both), a medium vertex is the
-// exact point with n = 0.
+// everything a path carries into its next segment (after the primary segment and after a vertex)
 template <bool GUIDED>
 VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
-                          int pc_quad, V3 pc_p, uint32_t keep_flags) {
+                          uint32_t keep_flags) {
     P.set3(PF_RO, slot, st.ro);
     P.set3(PF_RD, slot, st.rd);
     P.sets(PF_L, slot, st.L);
     P.sets(PF_BETA, slot, st.beta);
     P.sets(PF_RU, slot, st.r_u);
     P.sets(PF_RL, slot, st.r_l);
-    P.set3(PF_PCP, slot, pc_p);
-    P.i(PF_PCQ, slot) = pc_quad;
+    P.set3(PF_PCP, slot, st.prevCtx.p);
+    P.i(PF_PCQ, slot) = st.prevCtx.quad;
     pool_store_rng(P, slot, sampler);
     uint32_t fl = pool_pack_flags(st, ch, isg, keep_flags);
     if constexpr (GUIDED) {
@@ -150,16 +147,8 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     st.beta = P.sp3(PF_BETA, slot);
     st.r_u = P.sp3(PF_RU, slot);
     st.r_l = P.sp3(PF_RL, slot);
-    const int pcq = P.i(PF_PCQ, slot);
-    const V3 pcp = P.v3(PF_PCP, slot);
-    if (pcq >= 0) {  // surface vertex: LightSampleContext(isect) = {Point3fi(p, pError), n}
-        const DQuad &q = quad_at(pcq);
-        st.prevCtx.pi = p3i_from_err(pcp, ld3(q.perr));
-        st.prevCtx.n = ld3(q.n);
-    } else {
-        st.prevCtx.pi = p3i_exact(pcp);
-        st.prevCtx.n = mk(0, 0, 0);
-    }
+    st.prevCtx.p = P.v3(PF_PCP, slot);
+    st.prevCtx.quad = P.i(PF_PCQ, slot);
     sampler.rng.state = (uint64_t)P.u(PF_RNG + 0, slot) | ((uint64_t)P.u(PF_RNG + 1, slot) << 32);
     sampler.rng.inc = (uint64_t)P.u(PF_RNG + 2, slot) | ((uint64_t)P.u(PF_RNG + 3, slot) << 32);
     const uint32_t fl = P.u(PF_FLAGS, slot);
