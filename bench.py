@@ -13,7 +13,7 @@ end, inside the timed region.  Inputs (scene, film, VSP buffer) are resident in 
 timed region starts.
 
 The JSON line carries
-  roofline     : dominant kernel (k_render_wave) -- algorithmic bytes per launch (SURVEY.md 8d:
+  roofline     : dominant kernel (k_render_wave_wg) -- algorithmic bytes per launch (SURVEY.md 8d:
                  256 B per path segment + 76 B per path) / mean launch duration measured with
                  HIP events on the launch stream, against the 8 TB/s HBM peak.
   cpu_baseline : the CPU oracle (a port of the reference path; the reference itself cannot be
@@ -33,6 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 B_SEGMENT = 256                # 2 x 128 B SoA path state per segment
 B_PATH_FIXED = 32 + 4 + 40     # film RMW + primary-VSP read + ISG sample write
+PMC_PROFILE = "r01_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
 
 
 class DevArray:
@@ -161,13 +162,13 @@ def main():
 
     if rank == 0:
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same
-        # command (profiles/r01_pmc_k_render_wave.json; FETCH_SIZE and WRITE_SIZE are separate
+        # command (profiles/<PMC_PROFILE>; FETCH_SIZE and WRITE_SIZE are separate
         # passes, KiB per launch).  Reads here are 4-B gathers and scalar loads, a width the
         # microarch guide lists as uncalibrated (FETCH_SIZE may under-count by up to 2x); writes
         # are float atomics, which WRITE_SIZE counts at 64 B per request.
         traffic_gbs, traffic_bytes = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_k_render_wave.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
             if W == 1920 and H == 1080:
                 traffic_bytes = (pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
         except Exception:
@@ -196,7 +197,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic_bytes / (kern_ms * 1e-3) / 1e9) if traffic_bytes and kern_ms > 0 else None,
                          "traffic_bytes_per_launch": traffic_bytes,
-                         "kernel": "k_render_wave", "kernel_ms": kern_ms,
+                         "kernel": "k_render_wave_wg", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:
