@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
 // of the secondary phase is what lets the whole kernel fit the 128-VGPR budget of 4 waves per SIMD.
 // Launch shapes.  Homogeneous media: the segment code has no loops left (see HomogeneousMedium::
 // kAlwaysRealCollision) and the kernel fits 128 VGPRs: 512-thread workgroups, 4 waves per SIMD, two
-// workgroups per CU, 480 paths each.  Grid media keep the DDA / null-collision loops (about 250 live
+// workgroups per CU, 512 paths each.  Grid media keep the DDA / null-collision loops (about 250 live
 // VGPRs): 256-thread workgroups at 2 waves per SIMD, 368 paths beside the 16 KB majorant grid in LDS.
 #ifndef VSPG_WG_WAVES
 #define VSPG_WG_WAVES 4
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
 #define VSPG_WG_BLOCK 512
 #endif
 #ifndef VSPG_WG_NP
-#define VSPG_WG_NP 480
+#define VSPG_WG_NP 512
 #endif
 constexpr int kWgWavesHomog = VSPG_WG_WAVES, kWgBlockHomog = VSPG_WG_BLOCK, kWgPoolHomog = VSPG_WG_NP;
 constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 368;
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const int lane = threadIdx.x & 63;
     const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
 
+    static_assert(!GUIDED, "PF_VXP aliases PF_RO: the guided vertex code reads the old ray origin");
     constexpr int NF = GUIDED ? (int)PF_COUNT : (int)PF_GS;
     __shared__ float s_pool[NF * NP];
     __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
@@ -467,8 +468,7 @@ __global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict_
                                                        const VspgTmajQuery *__restrict__ q, VspgTmajResult *__restrict__ out) {
     const DScene &S = *Sp;
     int i = blockIdx.x * kBlock + threadIdx.x;
-    vspg_libm::stage_logf_tab_lds();
-    vspg_libm::stage_log_tab_lds();
+    stage_scene_lds(S);
     __syncthreads();
     if (i >= n) return;
     const Medium medium = MediumMaker<Medium>::make(S, S.majorant);

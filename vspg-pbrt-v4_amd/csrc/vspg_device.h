@@ -488,6 +488,12 @@ struct DScene {
 // the logf table of vspg_libm.h).
 __shared__ DQuad s_scene_quads[VSPG_MAX_QUADS];
 __shared__ int32_t s_scene_light_quads[VSPG_MAX_QUADS];
+// Homogeneous-medium constants {sigma_a[3], sigma_s[3], Le[3], g, sigma_t[3], sigma_n_raw[3]}: as one
+// 16-dword scalar load they stayed live over the whole persistent loop, and the register allocator
+// spilled and restored the 16-SGPR tuple as a unit (16 v_readlane + hazard nops at each of 32 use
+// sites -- 7 % of the kernel's vector instructions).  From LDS each site reads the 1-3 floats it needs.
+enum { MED_SIGMA_A = 0, MED_SIGMA_S = 3, MED_LE = 6, MED_G = 9, MED_SIGMA_T = 10, MED_SIGMA_N_RAW = 13, MED_COUNT = 16 };
+__shared__ float s_scene_medium[MED_COUNT];
 VDEV void stage_scene_lds(const DScene &S) {
     vspg_libm::stage_logf_tab_lds();
     vspg_libm::stage_log_tab_lds();
@@ -496,6 +502,11 @@ VDEV void stage_scene_lds(const DScene &S) {
     const int n = S.n_quads * (int)(sizeof(DQuad) / 4);
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
     if (threadIdx.x < VSPG_MAX_QUADS) s_scene_light_quads[threadIdx.x] = S.light_quads[threadIdx.x];
+    if (threadIdx.x < MED_COUNT) {
+        const int k = threadIdx.x;
+        s_scene_medium[k] = k < 3 ? S.sigma_a[k] : k < 6 ? S.sigma_s[k - 3] : k < 9 ? S.Le[k - 6] : k == 9 ? S.g
+                            : k < 13 ? S.sigma_t[k - 10] : S.sigma_n_raw[k - 13];
+    }
 }
 VDEV const DQuad &quad_at(int i) { return s_scene_quads[i]; }
 VDEV const DQuad &light_quad_at(int lightIndex) { return s_scene_quads[s_scene_light_quads[lightIndex]]; }
@@ -625,9 +636,8 @@ struct MajSeg {
 };
 // HomogeneousMedium (media.h:221-283): one segment [0,tMax], sigma_maj = sigma_a + sigma_s
 struct HomogeneousMedium {
-    Spec sigma_a, sigma_s, Le;
-    float g;
-    Spec sigma_t, sigma_n_raw;  // host-precomputed (DScene)
+    // constants live in the workgroup's LDS copy (s_scene_medium, staged by stage_scene_lds)
+    static VDEV Spec m3(int o) { return Spec{s_scene_medium[o], s_scene_medium[o + 1], s_scene_medium[o + 2]}; }
     struct Iter {  // HomogeneousMajorantIterator (media.h:84-106)
         MajSeg seg;
         bool called;
@@ -638,10 +648,12 @@ struct HomogeneousMedium {
             return true;
         }
     };
-    VDEV Iter sample_ray(V3, V3, float tMax) const { return Iter{MajSeg{0, tMax, sigma_t}, false}; }  // sigma_a + sigma_s
-    VDEV MediumProps sample_point(V3) const { return MediumProps{sigma_a, sigma_s, Le, g, sigma_t}; }
+    VDEV Iter sample_ray(V3, V3, float tMax) const { return Iter{MajSeg{0, tMax, m3(MED_SIGMA_T)}, false}; }  // sigma_a + sigma_s
+    VDEV MediumProps sample_point(V3) const {
+        return MediumProps{m3(MED_SIGMA_A), m3(MED_SIGMA_S), m3(MED_LE), s_scene_medium[MED_G], m3(MED_SIGMA_T)};
+    }
     // null-collision coefficient ClampZero(sigma_maj - sigma_a - sigma_s) for this medium's own majorant
-    VDEV Spec sigma_n(const MediumProps &, Spec) const { return clamp_zero(sigma_n_raw); }
+    VDEV Spec sigma_n(const MediumProps &, Spec) const { return clamp_zero(m3(MED_SIGMA_N_RAW)); }
     VDEV bool is_homogeneous() const { return true; }
     static constexpr bool kSingleSegment = true;
     // sigma_t = sigma_s + sigma_a at the collision and sigma_maj = sigma_a + sigma_s of the segment are
@@ -650,9 +662,7 @@ struct HomogeneousMedium {
     // distance-sampling walk is always a real one (no null collisions in a homogeneous medium).
     static constexpr bool kAlwaysRealCollision = true;
 };
-VDEV HomogeneousMedium make_homogeneous(const DScene &S) {
-    return HomogeneousMedium{lds(S.sigma_a), lds(S.sigma_s), lds(S.Le), S.g, lds(S.sigma_t), lds(S.sigma_n_raw)};
-}
+VDEV HomogeneousMedium make_homogeneous(const DScene &) { return HomogeneousMedium{}; }
 
 // ---------------------------------------------------------------------------------------
 // a6: GridMedium (media.h:284-390) with the 3-D DDA majorant iterator (media.h:140-218),

@@ -226,7 +226,9 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     pc.shadow_ray();
     if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
         // every surface here carries a material: any hit is an opaque blocker (:1197-1200)
+#ifndef VSPG_EXP_NOANYHIT
         if (scene_intersect_any(S, lo, ld, 1 - kShadowEps)) return sp(0.f);
+#endif
         if (S.medium_type != VSPG_MEDIUM_NONE) {
             VSPG_PROF(PS_NEE_TR);
             float tMax = 1 - kShadowEps;

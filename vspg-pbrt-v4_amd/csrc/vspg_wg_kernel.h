@@ -36,12 +36,15 @@ enum {
     PF_RRC = 27,      // 1  rr_correction
     PF_PIXEL = 28,    // 1  pixel index (int)
     PF_SAMPLE = 29,   // 1  sample index (int)
-    PF_VSP = 30,      // 1  vsp0 while depth == 0, then isg.vsp_used
-    PF_VXP = 31,      // 3  vertex position
-    PF_VXG = 34,      // 1  volume: g; surface: rectangle index (int)
-    PF_VXT = 35,      // 1  surface tHit
-    PF_GS = 36,       // 4  guided builds: gs.region (int), gs.p
-    PF_COUNT = 40
+    PF_VSP = 30,      // 1  isg.vsp_used (the primary VSP itself never leaves the primary phase)
+    PF_VXG = 31,      // 1  vertex: volume: g; surface: rectangle index (int)
+    PF_VXT = 32,      // 1  vertex: surface tHit
+    PF_GS = 33,       // 4  guided builds: gs.region (int), gs.p
+    PF_COUNT = 37,
+    // The vertex position lives only from the segment phase to the vertex phase, the ray origin only
+    // from the vertex phase to the next segment phase (the unguided vertex code never reads the old
+    // origin): they share three dwords.  480 -> 512 paths fit the 80 KB a workgroup may use.
+    PF_VXP = PF_RO
 };
 enum {
     FL_DEPTH_MASK = 0xff,
