@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
 #define VSPG_WG_NP 512
 #endif
 constexpr int kWgWavesHomog = VSPG_WG_WAVES, kWgBlockHomog = VSPG_WG_BLOCK, kWgPoolHomog = VSPG_WG_NP;
-constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 368;
+constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 384;
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
