@@ -172,6 +172,30 @@ typedef struct VspgField {
     const VspgFieldRegion *regions;
 } VspgField;
 
+/* ---- guiding-cache training -------------------------------------------
+ * With surfaceguiding / volumeguiding / vspsecondaryguiding set and no field uploaded, the renderer
+ * trains the field itself, like the reference (guideTraining, guidedvolpathvspgintegrator.cpp:109,
+ * 230-248): every path records its vertices (guiding.h:682-832), turns them into radiance samples when
+ * it ends (PathSegmentStorage::PropagateSamples, :627) and vspg_post_process_wave refits the field
+ * (Field::Update, :239) while fewer than guide_num_training_waves updates have run. */
+typedef struct VspgTrainSample {
+    float p[3];       /* vertex position */
+    float dir[3];     /* sampled direction at the vertex (direction the radiance arrives from) */
+    float weight;     /* incident radiance estimate / pdf */
+    float pdf;        /* pdf the direction was sampled with */
+    float distance;   /* distance to the next vertex along dir */
+    uint32_t flags;   /* VSPG_SAMPLE_* */
+} VspgTrainSample;
+#define VSPG_SAMPLE_VOLUME 1u       /* vertex lies in the medium -> volume field */
+#define VSPG_SAMPLE_NEXT_VOLUME 2u  /* the next event along dir was a volume scatter (VSP statistics) */
+typedef struct VspgTrainStats {
+    int32_t training;      /* 1 while the field is still being trained */
+    int32_t iteration;     /* Field::GetIteration(): number of updates done */
+    uint64_t n_samples;    /* radiance samples recorded since the last update */
+    uint64_t n_zero;       /* zero-valued samples dropped since the last update */
+    int32_t n_nodes[2], n_regions[2];  /* [0] surface field, [1] volume field */
+} VspgTrainStats;
+
 typedef struct VspgRenderer VspgRenderer; /* opaque */
 
 /* ---- helpers (host only, no device needed) ----------------------------------------- */
@@ -295,6 +319,15 @@ int vspg_guiding_query_batch(VspgRenderer *r, int is_volume, float g, int n, con
 /* Device float libm batch: logf(x), sinf(x), cosf(x) as the kernels evaluate them; they must
  * equal the host libm the CPU reference run uses (std::log/std::sin/std::cos of float,
  * src/pbrt/util/sampling.h:222-225, 325-341, src/pbrt/util/vecmath.h:1666-1672). */
+/* Training state / radiance samples recorded since the last update (test + diagnostics; order is
+ * unspecified) / the field as it stands (Field::Store counterpart: pass NULL arrays to get the sizes). */
+int vspg_renderer_training_stats(VspgRenderer *r, VspgTrainStats *out, void *stream);
+int vspg_train_samples_read(VspgRenderer *r, VspgTrainSample *out, size_t max_samples, size_t *n_out,
+                            void *stream);
+int vspg_renderer_get_guiding_field(VspgRenderer *r, int volume_field, VspgKdNode *nodes,
+                                    VspgFieldRegion *regions, int32_t *n_nodes, int32_t *n_regions,
+                                    void *stream);
+
 int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, float *sinf_out,
                     float *cosf_out, void *stream);
 /* out[i] = (float)(-log(1.0 - (double)x[i])) as the kernels evaluate it: the DOUBLE-precision

@@ -487,6 +487,13 @@ struct OracleRenderer {
     int vsp_ready;
     int wave_counter, buffer_wave;
     VspgCounters counters;
+    /* a18: guiding-cache training (see "training" section below) */
+    int training, field_iteration, field_uploaded;
+    VspgTrainSample *samples;
+    size_t n_samples, cap_samples;
+    uint64_t n_zero_samples;
+    struct region_stats *rstats[2];
+    int cap_nodes[2], cap_regions[2];
 };
 
 typedef struct { /* LightSampleContext (base/light.h) */
@@ -1236,7 +1243,8 @@ static float gdist_sample(const gdist_t *d, float u0, float u1, v3 *wi) {
 }
 
 static void free_field(OracleRenderer *r, int f) {
-    free(r->field[f].nodes); free(r->field[f].regions);
+    free(r->field[f].nodes); free(r->field[f].regions); free(r->rstats[f]);
+    r->rstats[f] = NULL;
     memset(&r->field[f], 0, sizeof r->field[f]);
 }
 static int copy_field(OracleRenderer *r, int f, const VspgField *src) {
@@ -1254,6 +1262,8 @@ static int copy_field(OracleRenderer *r, int f, const VspgField *src) {
     return 0;
 }
 int oracle_renderer_set_guiding_field(OracleRenderer *r, const VspgField *surface_field, const VspgField *volume_field) {
+    r->training = 0; /* a loaded cache is not trained further (:117-122) */
+    r->field_uploaded = 1;
     int rc = copy_field(r, 0, surface_field);
     if (rc) return rc;
     return copy_field(r, 1, volume_field);
@@ -1412,11 +1422,62 @@ static float standard_throughput_rr(spec w) {
 /* ------------------------------------------------------------------------------------ */
 /* a10-a13: SampleDistance (guidedvolpathvspgintegrator.cpp:637-1096)                     */
 /* ------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------ */
+/* a18: path-segment recording -- the guiding_* hooks of src/pbrt/cpu/guiding.h:682-832.   */
+/* A segment is openpgl::cpp::PathSegment reduced to what PropagateSamples reads.          */
+/* ------------------------------------------------------------------------------------ */
+#define TRAIN_MAX_SEG 32
+typedef struct {
+    v3 p, wi;
+    int has_wi, volume, is_delta;
+    float pdf, mi_weight, rr;
+    spec scattering_weight, transmittance_weight, direct, scattered;
+} pathseg_t;
+typedef struct {
+    int n, cur; /* cur: the reference's pathSegmentData pointer, -1 = nullptr */
+    pathseg_t seg[TRAIN_MAX_SEG];
+} pathrec_t;
+static spec s_max0(spec a) { return s_clamp_zero(a); } /* std::max(0.f, .) per component */
+/* guiding_newSurfacePathSegment / guiding_newVolumePathSegment (:682-732) */
+static void rec_new_segment(pathrec_t *rec, v3 p, int volume) {
+    if (!rec) return;
+    if (rec->n >= TRAIN_MAX_SEG) { rec->cur = -1; return; } /* NextSegment() == nullptr */
+    pathseg_t *g = &rec->seg[rec->n];
+    memset(g, 0, sizeof *g);
+    g->p = p; g->volume = volume;
+    g->scattered = S1(0.f); g->direct = S1(0.f); g->transmittance_weight = S1(1.f);
+    g->scattering_weight = S1(0.f); g->mi_weight = 1.f; g->rr = 1.f;
+    rec->cur = rec->n++;
+}
+static void rec_add_transmittance_weight(pathrec_t *rec, spec T) { /* :754-764 */
+    if (rec && rec->cur >= 0) rec->seg[rec->cur].transmittance_weight = s_max0(T);
+}
+static void rec_add_surface_emission(pathrec_t *rec, spec Le, float w) { /* :744-752 */
+    if (rec && rec->cur >= 0) { rec->seg[rec->cur].direct = s_max0(Le); rec->seg[rec->cur].mi_weight = w; }
+}
+static void rec_add_scattered_direct_light(pathrec_t *rec, spec Ld) { /* :734-742 */
+    if (rec && rec->cur >= 0) rec->seg[rec->cur].scattered = s_add(rec->seg[rec->cur].scattered, s_max0(Ld));
+}
+/* guiding_addSurfaceData / guiding_addVolumeData (:791-832) */
+static void rec_add_scatter_data(pathrec_t *rec, int volume, spec weight, v3 wi, float pdf, float roughness, float survivalProb) {
+    if (!rec || rec->cur < 0) return;
+    pathseg_t *g = &rec->seg[rec->cur];
+    g->transmittance_weight = S1(1.f);
+    g->volume = volume;
+    g->wi = wi; g->has_wi = 1;
+    g->pdf = pdf;
+    g->scattering_weight = s_max0(weight);
+    g->is_delta = roughness < 0.001f;
+    g->rr = survivalProb;
+}
+
 typedef struct {
     const OracleRenderer *r;
     int ch;
     sampler_t *sampler;
     rng_t *rng;
+    pathrec_t *rec;              /* a18 recorder, NULL when not training */
+    spec *transmittanceWeight;   /* :317, reset per path-loop iteration */
     /* path state by reference */
     v3 *ray_o, *ray_d;
     int *depth;
@@ -1455,6 +1516,7 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
         if (r->prm.usenee) {
             spec Ld = sample_Ld(r, &intr, c->gphase, c->ch, c->sampler, *c->r_u, c->pc);
             *c->L = s_add(*c->L, s_mul(*c->beta, Ld));
+            rec_add_scattered_direct_light(c->rec, Ld); /* :838 */
         }
         if (survivalProb < 1 && *c->depth > r->prm.minrrdepth) {
             float q = fmaxf(0.f, 1 - survivalProb);
@@ -1547,6 +1609,8 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
             *c->ray_d = wi;
             *c->specularBounce = 0;
             *c->anyNonSpecularBounces = 1;
+            /* guiding_addVolumeData(..., phaseFunctionWeight, ps->wi, ps->pdf, ps->meanCosine, survivalProb) (:871) */
+            rec_add_scatter_data(c->rec, 1, S1(phaseFunctionWeight), wi, ps_pdf, 1.0f - fabsf(mp->g), survivalProb);
             *c->lastVertexVolume = 1;
         }
     }
@@ -1590,13 +1654,24 @@ static int delta_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, 
         *c->r_u = s_mul(*c->r_u, s_divf(s_mul(T_maj, sigma_t), pdf));
         *c->beta = s_mul(*c->beta, c->beta_factor);
         *c->r_u = s_mul(*c->r_u, c->r_u_factor);
+        if (c->rec) { /* :978-986 */
+            spec tw = s_mul(*c->transmittanceWeight, s_divf(s_mul(T_maj, mp->sigma_s), pdf));
+            tw = s_mul(tw, s_divf(c->beta_factor, c->r_u_factor.c[ch]));
+            rec_add_transmittance_weight(c->rec, tw);
+            rec_new_segment(c->rec, p, 1);
+            *c->transmittanceWeight = S1(1.f);
+        }
         scatter_tail(c, p, mp);
         return 0;
     } else {
         spec sigma_n = s_clamp_zero(s_sub(s_sub(sigma_maj, mp->sigma_a), mp->sigma_s));
         float pdf = T_maj.c[ch] * sigma_n.c[ch];
         *c->beta = s_mul(*c->beta, s_divf(s_mul(T_maj, sigma_n), pdf));
-        if (pdf == 0) *c->beta = S1(0.f);
+        if (c->rec) *c->transmittanceWeight = s_mul(*c->transmittanceWeight, s_divf(s_mul(T_maj, sigma_n), pdf)); /* :1067 */
+        if (pdf == 0) {
+            *c->beta = S1(0.f);
+            if (c->rec) *c->transmittanceWeight = S1(0.f);
+        }
         *c->r_u = s_mul(*c->r_u, s_divf(s_mul(T_maj, sigma_n), pdf));
         *c->r_l = s_mul(*c->r_l, s_divf(s_mul(T_maj, sigma_maj), pdf));
         return s_nonzero(*c->beta) && s_nonzero(*c->r_u);
@@ -1731,6 +1806,12 @@ static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
                 c->terminated = 1;
                 return;
             }
+            if (c->rec) { /* :798-802 */
+                spec tw = s_mul(*c->transmittanceWeight, s_div(s_scale(rc.sel_num, resamplingFactorScalar), rc.sel_den));
+                rec_add_transmittance_weight(c->rec, tw);
+                rec_new_segment(c->rec, p, 1);
+                *c->transmittanceWeight = S1(1.f);
+            }
             scatter_tail(c, p, &mp);
         }
     } else {
@@ -1748,6 +1829,10 @@ static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
             *c->beta = s_mul(*c->beta, c->beta_factor);
             *c->r_u = s_mul(*c->r_u, c->r_u_factor);
             *c->r_l = s_mul(*c->r_l, c->r_u_factor);
+            if (c->rec) { /* :1085, :1090 */
+                spec tw = s_mul(*c->transmittanceWeight, s_divf(T_maj, T_maj.c[ch]));
+                *c->transmittanceWeight = s_mul(tw, s_divf(c->beta_factor, c->r_u_factor.c[ch]));
+            }
         }
     }
 }
@@ -1756,7 +1841,7 @@ static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
 /* a16: Li (guidedvolpathvspgintegrator.cpp:262-635)                                      */
 /* ------------------------------------------------------------------------------------ */
 static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sampler_t *sampler,
-               isg_sample_t *isg, path_counters_t *pc) {
+               isg_sample_t *isg, path_counters_t *pc, pathrec_t *rec) {
     float rr_correction = 1.0f;
     spec L = S1(0.f), beta = S1(1.f), r_u = S1(1.f), r_l = S1(1.f);
     int specularBounce = 0, anyNonSpecularBounces = 0;
@@ -1774,6 +1859,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         pc->segments++;
         isect_t si = scene_intersect(r, ro, rd, INFINITY);
         float tMax = si.hit ? si.t : INFINITY;
+        spec transmittanceWeight = S1(1.0f); /* :317 */
         if (r->scene.medium.type != VSPG_MEDIUM_NONE && !isinf(tMax)) {
             rng_t rng;
             uint64_t hash0 = oracle_hash_float(sampler_get1d(sampler));
@@ -1789,28 +1875,37 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             c.rr_correction = rr_correction;
             c.isg = isg; c.pc = pc;
             c.gbsdf = &gbsdf; c.gphase = &gphase;
+            c.rec = rec; c.transmittanceWeight = &transmittanceWeight;
             sample_distance(&c, px, py, tMax);
             if (c.terminated || !s_nonzero(beta) || !s_nonzero(r_u)) break;
             if (c.scattered) continue;
         }
+        rec_add_transmittance_weight(rec, transmittanceWeight); /* :350 */
         if (!si.hit) break; /* no infinite lights in scope (:353-374) */
 
         const rquad_t *q = &r->quads[si.quad];
         /* isect.Le(-ray.d) (:377-397) */
         spec Le = q->is_light ? light_L(q, si.n, v_neg(rd)) : S1(0.f);
+        int add_direct_contribution = 0;
+        float w_direct = 0.f;
         if (s_nonzero(Le)) {
+            add_direct_contribution = 1;
             if (depth == 0 || specularBounce) {
                 DBG(1);
                 L = s_add(L, s_divf(s_mul(beta, Le), s_avg(r_u)));
+                w_direct = 1.0f;
             } else {
                 DBG(lastVertexVolume ? 2 : 4);
                 float lightPDF = (1.f / (float)r->n_lights) * light_pdf_li(q, &prevIntrCtx, rd);
                 r_l = s_scale(r_l, lightPDF);
                 float w_l = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.0f;
                 L = s_add(L, s_mul(s_scale(beta, w_l), Le));
+                w_direct = w_l;
             }
         }
         bsdf_t bsdf = bsdf_make(q);
+        rec_new_segment(rec, v_add(ro, v_scale(rd, si.t)), 0); /* guiding_newSurfacePathSegment (:406) */
+        if (add_direct_contribution) rec_add_surface_emission(rec, Le, w_direct); /* :409-412 */
         if (depth == 0) {
             isg->valid = 1;
             isg->surface_event = 1;
@@ -1842,6 +1937,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         if (r->prm.usenee && bsdf.has_lobes) { /* IsNonSpecular(bsdf.Flags()) */
             spec Ld = sample_Ld(r, &intr, &gbsdf, ch, sampler, r_u, pc);
             L = s_add(L, s_mul(beta, Ld));
+            rec_add_scattered_direct_light(rec, Ld); /* :485 */
         }
         prevIntrCtx.pi = pi; prevIntrCtx.n = si.n; prevIntrCtx.ns = si.n;
 
@@ -1943,8 +2039,304 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             if (sampler_get1d(sampler) < qq) { DBG(8); break; }
             beta = s_divf(beta, 1 - qq);
         }
+        /* guiding_addSurfaceData(..., bsdfWeight, bs->wi, bs->eta, bs->sampledRoughness, bs->pdf, survivalProb) (:608);
+         * DiffuseBxDF: sampledRoughness 1 */
+        rec_add_scatter_data(rec, 0, bsdfWeight, wi, pdf, 1.0f, survivalProb);
     }
     return L;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* a18: training.  PathSegmentStorage::PropagateSamples and Field::Update are OpenPGL code   */
+/* (absent from the reference tree): OWN DESIGN, PARITY UNPINNED.  The product (HIP) follows  */
+/* the same definitions; radiance samples are compared bit for bit, the fitted field within   */
+/* a tolerance (the device sums with float atomics, this file with doubles).                 */
+/* ------------------------------------------------------------------------------------ */
+/* Incident-radiance samples from one finished path, walked from the last vertex to the first:
+ *   Lin(i)  = T(i) * Lout(i+1)                     radiance arriving at vertex i along wi(i)
+ *   Lout(i) = mi(i)*direct(i) + scattered(i) + scatteringWeight(i) * Lin(i) / rr(i)
+ * (direct = emission seen at the vertex with its MIS weight, scattered = NEE estimate, T = the
+ * transmittance weight of the segment leaving i).  Vertex i yields a sample when it has a sampled,
+ * non-delta direction and a next vertex; weight = average(Lin)/pdf; zero-valued samples are counted
+ * and dropped. */
+static void propagate_samples(OracleRenderer *r, const pathrec_t *rec) {
+    VspgTrainSample out[TRAIN_MAX_SEG];
+    int n_out = 0, n_zero = 0;
+    spec Lout_next = S1(0.f);
+    v3 p_next = V3(0, 0, 0);
+    int have_next = 0, next_volume = 0;
+    for (int i = rec->n - 1; i >= 0; --i) {
+        const pathseg_t *g = &rec->seg[i];
+        spec Lin = have_next ? s_mul(g->transmittance_weight, Lout_next) : S1(0.f);
+        if (g->has_wi && !g->is_delta && have_next && g->pdf > 0) {
+            float w = s_avg(Lin) / g->pdf;
+            if (w > 0 && !isinf(w)) {
+                VspgTrainSample *o = &out[n_out++];
+                o->p[0] = g->p.x; o->p[1] = g->p.y; o->p[2] = g->p.z;
+                o->dir[0] = g->wi.x; o->dir[1] = g->wi.y; o->dir[2] = g->wi.z;
+                o->weight = w; o->pdf = g->pdf;
+                o->distance = v_len(v_sub(p_next, g->p));
+                o->flags = (g->volume ? VSPG_SAMPLE_VOLUME : 0u) | (next_volume ? VSPG_SAMPLE_NEXT_VOLUME : 0u);
+            } else {
+                n_zero++;
+            }
+        }
+        spec Lout = s_add(s_scale(g->direct, g->mi_weight), g->scattered);
+        if (g->has_wi) Lout = s_add(Lout, s_divf(s_mul(g->scattering_weight, Lin), g->rr));
+        Lout_next = Lout; p_next = g->p; have_next = 1; next_volume = g->volume;
+    }
+    if (n_out == 0 && n_zero == 0) return;
+#pragma omp critical(vspg_samples)
+    {
+        if (r->n_samples + (size_t)n_out > r->cap_samples) {
+            size_t nc = r->cap_samples ? r->cap_samples * 2 : 65536;
+            while (nc < r->n_samples + (size_t)n_out) nc *= 2;
+            r->samples = (VspgTrainSample *)realloc(r->samples, nc * sizeof(VspgTrainSample));
+            r->cap_samples = nc;
+        }
+        memcpy(r->samples + r->n_samples, out, (size_t)n_out * sizeof(VspgTrainSample));
+        r->n_samples += (size_t)n_out;
+        r->n_zero_samples += (uint64_t)n_zero;
+    }
+}
+
+/* ---- Field::Update ------------------------------------------------------------------------
+ * field = kd-tree over positions, leaf -> region = parallax-aware vMF mixture (VspgFieldRegion) plus
+ * decayed sufficient statistics (region_stats).  One update = decay, spatial refinement (a leaf that
+ * has seen more than TRAIN_SPLIT_COUNT samples splits at the mean position along its axis of largest
+ * variance; both children inherit the mixture and half the statistics), then ONE weighted EM step of
+ * every region over the samples that fall into it:
+ *   E: gamma_k ~ weight_k vMF(omega' | mu_k, kappa_k), omega' = the sample direction re-aimed at the
+ *      region's pivot through the sample's hit distance (parallax compensation);
+ *   statistics per lobe: S += w gamma, R += w gamma omega', D += w gamma / distance,
+ *      V += w gamma [next event is a volume scatter], Qv / Qs += gamma w^2 [volume / surface next event];
+ *   M: weight = S / sum S (floored), mu = R/|R|, kappa from the mean resultant length
+ *      rbar(3 - rbar^2)/(1 - rbar^2), distance = S / D, vsp = V/S (contribution criterion) or
+ *      sqrt(Qv)/(sqrt(Qv)+sqrt(Qs)) (variance criterion).
+ * w is the sample weight clamped to TRAIN_WEIGHT_CLAMP times the batch mean weight. */
+#define TRAIN_SPLIT_COUNT 4096.0f
+#define TRAIN_DECAY 0.75f
+#define TRAIN_MAX_DEPTH 24
+#define TRAIN_WEIGHT_CLAMP 32.0f
+#define TRAIN_KAPPA_INIT 2.0f
+#define TRAIN_MIN_UPDATE_SAMPLES 128 /* guidedvolpathvspgintegrator.cpp:238 */
+struct region_stats {
+    float n;             /* decayed sample count */
+    float sum_p[3], sum_p2[3];
+    float S[VSPG_FIELD_LOBES], R[3][VSPG_FIELD_LOBES], D[VSPG_FIELD_LOBES], V[VSPG_FIELD_LOBES],
+        Qv[VSPG_FIELD_LOBES], Qs[VSPG_FIELD_LOBES];
+    int32_t depth;
+};
+#define TRAIN_STAT_FLOATS (7 + 8 * VSPG_FIELD_LOBES) /* every float member of region_stats, in order */
+typedef struct { /* double-precision accumulators of one update (the device uses float atomics) */
+    double n, sum_p[3], sum_p2[3];
+    double S[VSPG_FIELD_LOBES], R[3][VSPG_FIELD_LOBES], D[VSPG_FIELD_LOBES], V[VSPG_FIELD_LOBES],
+        Qv[VSPG_FIELD_LOBES], Qs[VSPG_FIELD_LOBES];
+} region_acc_t;
+
+static void region_init_lobes(VspgFieldRegion *R) {
+    /* 8 lobes on the cube diagonals, kappa 2, equal weights, no parallax, vsp 0.5 */
+    const float c = 0.57735026918962576451f;
+    R->n_lobes = VSPG_FIELD_LOBES;
+    for (int k = 0; k < VSPG_FIELD_LOBES; ++k) {
+        R->weight[k] = 1.0f / VSPG_FIELD_LOBES;
+        R->kappa[k] = TRAIN_KAPPA_INIT;
+        R->mu[0][k] = (k & 1) ? -c : c;
+        R->mu[1][k] = (k & 2) ? -c : c;
+        R->mu[2][k] = (k & 4) ? -c : c;
+        R->distance[k] = INFINITY;
+        R->vsp[k] = 0.5f;
+    }
+}
+static int field_alloc(OracleRenderer *r, int f) {
+    if (r->field[f].nodes) return 0;
+    r->cap_nodes[f] = 8192; r->cap_regions[f] = 4097;
+    r->field[f].nodes = (VspgKdNode *)calloc((size_t)r->cap_nodes[f], sizeof(VspgKdNode));
+    r->field[f].regions = (VspgFieldRegion *)calloc((size_t)r->cap_regions[f], sizeof(VspgFieldRegion));
+    r->rstats[f] = (struct region_stats *)calloc((size_t)r->cap_regions[f], sizeof(struct region_stats));
+    r->field[f].n_nodes = 1; r->field[f].n_regions = 1;
+    r->field[f].nodes[0].split = 0; r->field[f].nodes[0].packed = 3u; /* leaf -> region 0, untrained */
+    return 0;
+}
+static v3 reaim(const VspgFieldRegion *R, v3 p, v3 w, float dist) {
+    if (!(dist > 0) || isinf(dist)) return w;
+    v3 t = v_add(v_sub(p, v3_from(R->pivot)), v_scale(w, dist));
+    float l2 = v_len2(t);
+    if (!(l2 > 0)) return w;
+    return v_normalize(t);
+}
+static void field_update_one(OracleRenderer *r, int f, float mean_w) {
+    int want_vol = f == 1;
+    VspgKdNode *nodes = r->field[f].nodes;
+    VspgFieldRegion *regs = r->field[f].regions;
+    struct region_stats *st = r->rstats[f];
+    /* 1. decay */
+    for (int i = 0; i < r->field[f].n_regions; ++i) {
+        float *v = &st[i].n;
+        for (int k = 0; k < TRAIN_STAT_FLOATS; ++k) v[k] *= TRAIN_DECAY;
+    }
+    /* 2. position statistics of the new samples */
+    region_acc_t *acc = (region_acc_t *)calloc((size_t)r->cap_regions[f], sizeof(region_acc_t));
+    for (size_t i = 0; i < r->n_samples; ++i) {
+        const VspgTrainSample *sm = &r->samples[i];
+        if (((sm->flags & VSPG_SAMPLE_VOLUME) != 0) != want_vol) continue;
+        int reg = field_lookup(r, f, v3_from(sm->p));
+        if (reg < 0) continue;
+        acc[reg].n += 1;
+        for (int a = 0; a < 3; ++a) { acc[reg].sum_p[a] += sm->p[a]; acc[reg].sum_p2[a] += (double)sm->p[a] * sm->p[a]; }
+    }
+    int n_reg0 = r->field[f].n_regions;
+    for (int i = 0; i < n_reg0; ++i) {
+        st[i].n += (float)acc[i].n;
+        for (int a = 0; a < 3; ++a) { st[i].sum_p[a] += (float)acc[i].sum_p[a]; st[i].sum_p2[a] += (float)acc[i].sum_p2[a]; }
+    }
+    /* 3. spatial refinement: one split level per update */
+    int n_nodes0 = r->field[f].n_nodes;
+    for (int nd = 0; nd < n_nodes0; ++nd) {
+        if ((nodes[nd].packed & 3u) != 3u) continue;
+        int reg = (int)(nodes[nd].packed >> 2);
+        struct region_stats *s0 = &st[reg];
+        if (!(s0->n > TRAIN_SPLIT_COUNT) || s0->depth >= TRAIN_MAX_DEPTH) continue;
+        if (r->field[f].n_nodes + 2 > r->cap_nodes[f] || r->field[f].n_regions + 1 > r->cap_regions[f]) continue;
+        float mean[3], var[3];
+        for (int a = 0; a < 3; ++a) {
+            mean[a] = s0->sum_p[a] / s0->n;
+            var[a] = s0->sum_p2[a] / s0->n - mean[a] * mean[a];
+        }
+        int axis = var[0] >= var[1] ? (var[0] >= var[2] ? 0 : 2) : (var[1] >= var[2] ? 1 : 2);
+        if (!(var[axis] > 0)) continue;
+        int left = r->field[f].n_nodes, newreg = r->field[f].n_regions;
+        r->field[f].n_nodes += 2; r->field[f].n_regions += 1;
+        /* halve the statistics, give both children the parent's mixture */
+        float *v = &s0->n;
+        for (int k = 0; k < TRAIN_STAT_FLOATS; ++k) v[k] *= 0.5f;
+        s0->depth += 1;
+        st[newreg] = *s0;
+        regs[newreg] = regs[reg];
+        nodes[left].split = 0; nodes[left].packed = ((uint32_t)reg << 2) | 3u;
+        nodes[left + 1].split = 0; nodes[left + 1].packed = ((uint32_t)newreg << 2) | 3u;
+        nodes[nd].split = mean[axis];
+        nodes[nd].packed = ((uint32_t)left << 2) | (uint32_t)axis;
+    }
+    /* 4. pivots / default lobes of regions that see their first samples, then the E step */
+    memset(acc, 0, (size_t)r->cap_regions[f] * sizeof(region_acc_t));
+    for (size_t i = 0; i < r->n_samples; ++i) {
+        const VspgTrainSample *sm = &r->samples[i];
+        if (((sm->flags & VSPG_SAMPLE_VOLUME) != 0) != want_vol) continue;
+        int reg = field_lookup(r, f, v3_from(sm->p));
+        if (reg < 0) continue;
+        acc[reg].n += 1;
+        for (int a = 0; a < 3; ++a) acc[reg].sum_p[a] += sm->p[a];
+    }
+    for (int i = 0; i < r->field[f].n_regions; ++i)
+        if (regs[i].n_lobes == 0 && acc[i].n > 0) {
+            for (int a = 0; a < 3; ++a) regs[i].pivot[a] = (float)(acc[i].sum_p[a] / acc[i].n);
+            region_init_lobes(&regs[i]);
+        }
+    memset(acc, 0, (size_t)r->cap_regions[f] * sizeof(region_acc_t));
+    const float wmax = TRAIN_WEIGHT_CLAMP * mean_w;
+    for (size_t i = 0; i < r->n_samples; ++i) {
+        const VspgTrainSample *sm = &r->samples[i];
+        if (((sm->flags & VSPG_SAMPLE_VOLUME) != 0) != want_vol) continue;
+        v3 p = v3_from(sm->p);
+        int reg = field_lookup(r, f, p);
+        if (reg < 0) continue;
+        const VspgFieldRegion *R = &regs[reg];
+        if (R->n_lobes <= 0) continue;
+        float w = sm->weight < wmax ? sm->weight : wmax;
+        v3 om = reaim(R, p, v3_from(sm->dir), sm->distance);
+        float g[VSPG_FIELD_LOBES], gs = 0;
+        for (int k = 0; k < R->n_lobes; ++k) {
+            g[k] = R->weight[k] * vmf_eval(V3(R->mu[0][k], R->mu[1][k], R->mu[2][k]), kappa_clamp(R->kappa[k]), om);
+            gs += g[k];
+        }
+        if (!(gs > 0) || isinf(gs)) continue;
+        int nextvol = (sm->flags & VSPG_SAMPLE_NEXT_VOLUME) != 0;
+        for (int k = 0; k < R->n_lobes; ++k) {
+            float wg = w * (g[k] / gs);
+            acc[reg].S[k] += wg;
+            acc[reg].R[0][k] += wg * om.x; acc[reg].R[1][k] += wg * om.y; acc[reg].R[2][k] += wg * om.z;
+            if (sm->distance > 0 && !isinf(sm->distance)) acc[reg].D[k] += wg / sm->distance;
+            if (nextvol) { acc[reg].V[k] += wg; acc[reg].Qv[k] += wg * w; } else acc[reg].Qs[k] += wg * w;
+        }
+    }
+    /* 5. M step */
+    for (int i = 0; i < r->field[f].n_regions; ++i) {
+        VspgFieldRegion *R = &regs[i];
+        if (R->n_lobes <= 0) continue;
+        struct region_stats *s1 = &st[i];
+        float Stot = 0;
+        for (int k = 0; k < R->n_lobes; ++k) {
+            s1->S[k] += (float)acc[i].S[k];
+            for (int a = 0; a < 3; ++a) s1->R[a][k] += (float)acc[i].R[a][k];
+            s1->D[k] += (float)acc[i].D[k]; s1->V[k] += (float)acc[i].V[k];
+            s1->Qv[k] += (float)acc[i].Qv[k]; s1->Qs[k] += (float)acc[i].Qs[k];
+            Stot += s1->S[k];
+        }
+        if (!(Stot > 0)) continue;
+        const float floorw = 1e-3f / VSPG_FIELD_LOBES;
+        float wsum = 0;
+        for (int k = 0; k < R->n_lobes; ++k) {
+            float wk = s1->S[k] / Stot;
+            wk = wk < floorw ? floorw : wk;
+            R->weight[k] = wk;
+            wsum += wk;
+            float rl = sqrtf(s1->R[0][k] * s1->R[0][k] + s1->R[1][k] * s1->R[1][k] + s1->R[2][k] * s1->R[2][k]);
+            if (s1->S[k] > 0 && rl > 0) {
+                R->mu[0][k] = s1->R[0][k] / rl; R->mu[1][k] = s1->R[1][k] / rl; R->mu[2][k] = s1->R[2][k] / rl;
+                float rbar = rl / s1->S[k];
+                rbar = rbar > 0.9999f ? 0.9999f : rbar;
+                R->kappa[k] = kappa_clamp(rbar * (3 - rbar * rbar) / (1 - rbar * rbar));
+                R->distance[k] = s1->D[k] > 0 ? s1->S[k] / s1->D[k] : INFINITY;
+                if (r->prm.vspcriterion == VSPG_VSP_VARIANCE) {
+                    float qv = sqrtf(s1->Qv[k]), qs = sqrtf(s1->Qs[k]);
+                    R->vsp[k] = qv + qs > 0 ? qv / (qv + qs) : 0.5f;
+                } else {
+                    R->vsp[k] = s1->V[k] / s1->S[k];
+                }
+            }
+        }
+        for (int k = 0; k < R->n_lobes; ++k) R->weight[k] = R->weight[k] / wsum;
+    }
+    free(acc);
+}
+/* PostProcessWave's training branch (:234-248) */
+static void field_update(OracleRenderer *r) {
+    if (r->n_samples > TRAIN_MIN_UPDATE_SAMPLES) {
+        double sw = 0;
+        for (size_t i = 0; i < r->n_samples; ++i) sw += r->samples[i].weight;
+        float mean_w = (float)(sw / (double)r->n_samples);
+        field_update_one(r, 0, mean_w);
+        field_update_one(r, 1, mean_w);
+        r->field_iteration++;
+        if (r->field_iteration >= r->prm.guide_num_training_waves) r->training = 0;
+    }
+    r->n_samples = 0;
+    r->n_zero_samples = 0;
+}
+int oracle_renderer_training_stats(OracleRenderer *r, VspgTrainStats *out) {
+    if (!r || !out) return VSPG_EINVAL;
+    memset(out, 0, sizeof *out);
+    out->training = r->training; out->iteration = r->field_iteration;
+    out->n_samples = r->n_samples; out->n_zero = r->n_zero_samples;
+    for (int f = 0; f < 2; ++f) { out->n_nodes[f] = r->field[f].n_nodes; out->n_regions[f] = r->field[f].n_regions; }
+    return 0;
+}
+int oracle_train_samples_read(OracleRenderer *r, VspgTrainSample *out, size_t max_samples, size_t *n_out) {
+    if (!r || !n_out) return VSPG_EINVAL;
+    size_t n = r->n_samples < max_samples ? r->n_samples : max_samples;
+    if (out && n) memcpy(out, r->samples, n * sizeof(VspgTrainSample));
+    *n_out = r->n_samples;
+    return 0;
+}
+int oracle_renderer_get_guiding_field(OracleRenderer *r, int volume_field, VspgKdNode *nodes, VspgFieldRegion *regions,
+                                      int32_t *n_nodes, int32_t *n_regions) {
+    if (!r || !n_nodes || !n_regions) return VSPG_EINVAL;
+    int f = volume_field ? 1 : 0;
+    *n_nodes = r->field[f].n_nodes; *n_regions = r->field[f].n_regions;
+    if (nodes && r->field[f].nodes) memcpy(nodes, r->field[f].nodes, sizeof(VspgKdNode) * (size_t)r->field[f].n_nodes);
+    if (regions && r->field[f].regions) memcpy(regions, r->field[f].regions, sizeof(VspgFieldRegion) * (size_t)r->field[f].n_regions);
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1960,7 +2352,7 @@ static void camera_ray(const VspgCamera *cam, float fx, float fy, v3 *o, v3 *d) 
 }
 
 static spec evaluate_pixel_sample(const OracleRenderer *r, int px, int py, int sampleIndex,
-                                  isg_sample_t *isg, path_counters_t *pc, float *filterWeight) {
+                                  isg_sample_t *isg, path_counters_t *pc, float *filterWeight, pathrec_t *rec) {
     sampler_t sampler;
     sampler_start_pixel_sample(&sampler, px, py, r->cfg.seed, sampleIndex, 0);
     float lu = sampler_get1d(&sampler);
@@ -1976,7 +2368,8 @@ static spec evaluate_pixel_sample(const OracleRenderer *r, int px, int py, int s
     *filterWeight = 1.f;
     v3 o, d;
     camera_ray(&r->scene.camera, pfx, pfy, &o, &d);
-    spec L = Li(r, px, py, o, d, ch, &sampler, isg, pc);
+    if (rec) { rec->n = 0; rec->cur = -1; }
+    spec L = Li(r, px, py, o, d, ch, &sampler, isg, pc, rec);
     /* L = cameraRay->weight * L with weight 1; NaN / Inf -> black (:308-318) */
     if (s_has_nan(L)) L = S1(0.f);
     else if (s_has_inf(L)) L = S1(0.f);
@@ -2035,6 +2428,8 @@ int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int 
         path_counters_t pc;
         memset(&pc, 0, sizeof pc);
         uint64_t paths = 0;
+        pathrec_t rec;
+        rec.n = 0; rec.cur = -1;
 #pragma omp for schedule(dynamic, 1)
         for (int tile = 0; tile < ntiles; ++tile) {
             int tx = tile % ntx, ty = tile / ntx;
@@ -2046,7 +2441,8 @@ int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int 
                         if (r->cfg.shard_count > 1 && (s % r->cfg.shard_count) != r->cfg.shard_index) continue;
                         isg_sample_t isg;
                         float w;
-                        spec L = evaluate_pixel_sample(r, px, py, s, &isg, &pc, &w);
+                        spec L = evaluate_pixel_sample(r, px, py, s, &isg, &pc, &w, r->training ? &rec : NULL);
+                        if (r->training) propagate_samples(r, &rec);
                         size_t idx = (size_t)py * W + px;
                         film_add_sample(&r->film[idx * 4], L, w);
                         isg_add_sample(&r->isg_stats[idx * VSPG_ISG_STATS], L, &isg);
@@ -2066,12 +2462,15 @@ int oracle_render_wave(OracleRenderer *r, int wave_start, int wave_end, int nthr
     return oracle_render_window(r, 0, 0, r->cfg.xres, r->cfg.yres, wave_start, wave_end, nthreads);
 }
 
-/* PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260): the guiding-field update is absent
- * (guideTraining false in covered configs); VSP buffer update at waveCounter == 2^bufferWave.
+/* PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260): the guiding-field update (its
+ * training branch: field_update above); VSP buffer update at waveCounter == 2^bufferWave.
  * Update() = 5x5 box filter over the sufficient statistics, then the criterion (own design). */
 #define ISG_FILTER_RADIUS 2
 int oracle_post_process_wave(OracleRenderer *r) {
     r->wave_counter++;
+    if (r->training) field_update(r); /* :234-246 */
+    r->n_samples = 0;                 /* guiding_sampleStorage->Clear() (:248) */
+    r->n_zero_samples = 0;
     if ((double)r->wave_counter == pow(2.0, (double)r->buffer_wave)) {
         int W = r->cfg.xres, H = r->cfg.yres;
         if (r->prm.vspguiding && r->prm.vspprimaryguiding) {
@@ -2149,12 +2548,21 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
     r->film = (double *)calloc(npix * 4, sizeof(double));
     r->isg_stats = (float *)calloc(npix * VSPG_ISG_STATS, sizeof(float));
     r->vsp = (float *)calloc(npix, sizeof(float));
+    /* guideTraining (:109).  The reference also trains when only the guided-RR flags are set (they default to
+     * true); this build trains iff the field will be queried. */
+    r->training = params->surfaceguiding || params->volumeguiding || params->vspsecondaryguiding;
+    if (r->training) {
+        if (params->maxdepth + 2 > TRAIN_MAX_SEG) { oracle_renderer_destroy(r); return VSPG_ESCOPE; }
+        field_alloc(r, 0);
+        field_alloc(r, 1);
+    }
     *out = r;
     return 0;
 }
 void oracle_renderer_destroy(OracleRenderer *r) {
     if (!r) return;
     free_field(r, 0); free_field(r, 1);
+    free(r->samples);
     free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {
@@ -2187,7 +2595,7 @@ int oracle_trace_paths(OracleRenderer *r, int n, const int32_t *pixel_xy, const 
         memset(&pc, 0, sizeof pc);
         isg_sample_t isg;
         float w;
-        spec L = evaluate_pixel_sample(r, pixel_xy[2 * i], pixel_xy[2 * i + 1], sample_index[i], &isg, &pc, &w);
+        spec L = evaluate_pixel_sample(r, pixel_xy[2 * i], pixel_xy[2 * i + 1], sample_index[i], &isg, &pc, &w, NULL);
         out_L[3 * i] = L.c[0]; out_L[3 * i + 1] = L.c[1]; out_L[3 * i + 2] = L.c[2];
         if (out_segments) out_segments[i] = (int32_t)pc.segments;
     }

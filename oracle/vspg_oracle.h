@@ -86,6 +86,13 @@ int oracle_guiding_query_batch(OracleRenderer *r, int is_volume, float g, int n,
                                float *out_pdf, float *out_incoming_pdf, float *out_vsp, float *out_ws,
                                float *out_pdf_s);
 
+/* guiding-cache training (a18; the OpenPGL side -- PropagateSamples, Field::Update -- is this build's
+ * own design, PARITY UNPINNED; the recording hooks follow src/pbrt/cpu/guiding.h:682-832) */
+int oracle_renderer_training_stats(OracleRenderer *r, VspgTrainStats *out);
+int oracle_train_samples_read(OracleRenderer *r, VspgTrainSample *out, size_t max_samples, size_t *n_out);
+int oracle_renderer_get_guiding_field(OracleRenderer *r, int volume_field, VspgKdNode *nodes,
+                                      VspgFieldRegion *regions, int32_t *n_nodes, int32_t *n_regions);
+
 /* scene helpers restated independently of the product's (same formulas, separate code) */
 void oracle_integrator_params_default(VspgIntegratorParams *p);
 int oracle_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3],

@@ -57,6 +57,10 @@ def load():
         "oracle_guiding_query_batch": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, p(C.c_float), p(C.c_float), p(C.c_float),
                                                  p(C.c_float), p(C.c_int32), p(C.c_float), p(C.c_float), p(C.c_float),
                                                  p(C.c_float), p(C.c_float)]),
+        "oracle_renderer_training_stats": (C.c_int, [vp, p(P.VspgTrainStats)]),
+        "oracle_train_samples_read": (C.c_int, [vp, p(P.VspgTrainSample), C.c_size_t, p(C.c_size_t)]),
+        "oracle_renderer_get_guiding_field": (C.c_int, [vp, C.c_int, p(P.VspgKdNode), p(P.VspgFieldRegion), p(C.c_int32),
+                                                        p(C.c_int32)]),
         "oracle_integrator_params_default": (None, [p(P.VspgIntegratorParams)]),
         "oracle_camera_look_at": (C.c_int, [p(P.VspgCamera), f3, f3, f3, C.c_float, C.c_int, C.c_int]),
         "oracle_scene_fog_box": (C.c_int, [p(P.VspgScene), C.c_int, C.c_int]),
@@ -168,6 +172,26 @@ class OracleRenderer:
         out = (self.P.VspgTmajResult * n)()
         assert self.lib.oracle_sample_tmaj_batch(self.h, variant, n, q, out) == 0
         return list(out)
+
+    def training_stats(self):
+        st = self.P.VspgTrainStats()
+        assert self.lib.oracle_renderer_training_stats(self.h, C.byref(st)) == 0
+        return st.as_dict()
+
+    def train_samples(self):
+        n = C.c_size_t(0)
+        assert self.lib.oracle_train_samples_read(self.h, None, 0, C.byref(n)) == 0
+        buf = (self.P.VspgTrainSample * max(1, n.value))()
+        assert self.lib.oracle_train_samples_read(self.h, buf, n.value, C.byref(n)) == 0
+        return np.frombuffer(buf, dtype=self.P.TRAIN_SAMPLE_DTYPE, count=n.value).copy()
+
+    def get_guiding_field(self, volume):
+        nn, nr = C.c_int32(0), C.c_int32(0)
+        assert self.lib.oracle_renderer_get_guiding_field(self.h, int(volume), None, None, C.byref(nn), C.byref(nr)) == 0
+        nodes = (self.P.VspgKdNode * max(1, nn.value))()
+        regs = (self.P.VspgFieldRegion * max(1, nr.value))()
+        assert self.lib.oracle_renderer_get_guiding_field(self.h, int(volume), nodes, regs, C.byref(nn), C.byref(nr)) == 0
+        return nodes, regs, nn.value, nr.value
 
     def set_guiding_field(self, surface, volume):
         rc = self.lib.oracle_renderer_set_guiding_field(self.h, C.byref(surface.pod) if surface else None,

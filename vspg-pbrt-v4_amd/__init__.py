@@ -77,6 +77,23 @@ class VspgCounters(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class VspgTrainSample(C.Structure):
+    _fields_ = [("p", C.c_float * 3), ("dir", C.c_float * 3), ("weight", C.c_float), ("pdf", C.c_float),
+                ("distance", C.c_float), ("flags", C.c_uint32)]
+
+
+class VspgTrainStats(C.Structure):
+    _fields_ = [("training", C.c_int32), ("iteration", C.c_int32), ("n_samples", C.c_uint64), ("n_zero", C.c_uint64),
+                ("n_nodes", C.c_int32 * 2), ("n_regions", C.c_int32 * 2)]
+
+    def as_dict(self):
+        return {"training": int(self.training), "iteration": int(self.iteration), "n_samples": int(self.n_samples),
+                "n_zero": int(self.n_zero), "n_nodes": list(self.n_nodes), "n_regions": list(self.n_regions)}
+
+
+TRAIN_SAMPLE_DTYPE = [("p", "<f4", 3), ("dir", "<f4", 3), ("weight", "<f4"), ("pdf", "<f4"), ("distance", "<f4"),
+                      ("flags", "<u4")]
+
 VSPG_FIELD_LOBES = 8
 _fl = C.c_float * VSPG_FIELD_LOBES
 
@@ -131,6 +148,10 @@ SYMBOLS = [
     ("vspg_trace_paths", C.c_int, [_vp, C.c_int, _P(C.c_int32), _P(C.c_int32), _P(C.c_float), _P(C.c_int32), _vp]),
     ("vspg_sample_tmaj_batch", C.c_int, [_vp, C.c_int, C.c_int, _P(VspgTmajQuery), _P(VspgTmajResult), _vp]),
     ("vspg_primitives_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_uint64), _P(C.c_uint32), _P(C.c_float), _vp]),
+    ("vspg_renderer_training_stats", C.c_int, [_vp, _P(VspgTrainStats), _vp]),
+    ("vspg_train_samples_read", C.c_int, [_vp, _P(VspgTrainSample), C.c_size_t, _P(C.c_size_t), _vp]),
+    ("vspg_renderer_get_guiding_field", C.c_int, [_vp, C.c_int, _P(VspgKdNode), _P(VspgFieldRegion), _P(C.c_int32),
+                                                  _P(C.c_int32), _vp]),
     ("vspg_libm_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
     ("vspg_libm_log1m_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _vp]),
     ("vspg_renderer_set_guiding_field", C.c_int, [_vp, _P(VspgField), _P(VspgField), _vp]),
@@ -303,6 +324,28 @@ class Renderer:
         _check(self.lib, self.lib.vspg_libm_batch(self.h, n, x.ctypes.data_as(fp), lo.ctypes.data_as(fp),
                                                   so.ctypes.data_as(fp), co.ctypes.data_as(fp), _vp(0)))
         return lo, so, co
+
+    # ---- guiding-cache training (a18)
+    def training_stats(self):
+        st = VspgTrainStats()
+        _check(self.lib, self.lib.vspg_renderer_training_stats(self.h, C.byref(st), _vp(0)))
+        return st.as_dict()
+
+    def train_samples(self):
+        import numpy as np
+        n = C.c_size_t(0)
+        _check(self.lib, self.lib.vspg_train_samples_read(self.h, None, 0, C.byref(n), _vp(0)))
+        buf = (VspgTrainSample * max(1, n.value))()
+        _check(self.lib, self.lib.vspg_train_samples_read(self.h, buf, n.value, C.byref(n), _vp(0)))
+        return np.frombuffer(buf, dtype=TRAIN_SAMPLE_DTYPE, count=n.value).copy()
+
+    def get_guiding_field(self, volume):
+        nn, nr = C.c_int32(0), C.c_int32(0)
+        _check(self.lib, self.lib.vspg_renderer_get_guiding_field(self.h, int(volume), None, None, C.byref(nn), C.byref(nr), _vp(0)))
+        nodes = (VspgKdNode * max(1, nn.value))()
+        regs = (VspgFieldRegion * max(1, nr.value))()
+        _check(self.lib, self.lib.vspg_renderer_get_guiding_field(self.h, int(volume), nodes, regs, C.byref(nn), C.byref(nr), _vp(0)))
+        return nodes, regs, nn.value, nr.value
 
     def libm_log1m_batch(self, x):
         import numpy as np

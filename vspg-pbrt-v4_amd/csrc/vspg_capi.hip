@@ -31,7 +31,8 @@ constexpr int kBlocksPerCU = kWavesPerSimd;         // persistent 256-thread blo
 constexpr int kChunk = 64;        // dynamic work items a wavefront claims per atomic (one 8x8 pixel tile)
 constexpr int kNumCounters = 6;  // paths, segments, volume_scatters, surface_hits, density_queries, shadow_rays
 
-__device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t paths, unsigned long long *g) {
+template <class PC>
+__device__ __forceinline__ void flush_counters(const PC &pc, uint32_t paths, unsigned long long *g) {
     __shared__ unsigned int s[kNumCounters];
     if (threadIdx.x < kNumCounters) s[threadIdx.x] = 0;
     __syncthreads();
@@ -56,14 +57,20 @@ __device__ __forceinline__ void flush_counters(const PathCounters &pc, uint32_t 
 //   path state = registers for the whole life of a path (no HBM round trip per segment);
 //   items are tile-ordered (8x8 pixels per 64 items) so a fresh wavefront starts on one coherent
 //   tile of primary rays.
-template <class Medium, bool GUIDED>
+struct TrainArgs {  // a18: where a training launch records (all null / 0 otherwise)
+    float *segbuf;                   // per-lane segment records, SoA over the launch's lanes
+    VspgTrainSample *samples;        // radiance samples of this wave
+    unsigned long long *counters;    // [0] samples appended, [1] zero-valued samples dropped
+    unsigned long long capacity;
+};
+template <class Medium, bool GUIDED, bool TRAIN = false>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
                                                         float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
                                                         int vsp_ready, int wave_start, int wave_end,
                                                         int first_sample, int single_sample, PcgJump jump,
                                                         unsigned static_per_wave, unsigned dyn_base,
                                                         unsigned int *__restrict__ work_head,
-                                                        unsigned long long *__restrict__ counters) {
+                                                        unsigned long long *__restrict__ counters, TrainArgs train) {
     // first_sample: first sample index of this shard in [wave_start, wave_end); single_sample: the
     // launch covers exactly one sample per pixel (the reference's 1-spp waves) and `jump` is the
     // PCG skip-ahead for first_sample*65536
@@ -93,7 +100,14 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
         __shared__ float s_gmix[kBlock * 5 * GK];
         glds = s_gmix + threadIdx.x;
     }
-    PathCounters pc = {0, 0, 0, 0, 0};
+    typename std::conditional<TRAIN, PathCountersT<PathRecorder>, PathCounters>::type pc;
+    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = 0;
+    if constexpr (TRAIN) {
+        pc.rec.base = train.segbuf + (size_t)blockIdx.x * kBlock + threadIdx.x;
+        pc.rec.stride = (int)(gridDim.x * kBlock);
+        pc.rec.max_seg = S.prm.maxdepth + 2;
+        pc.rec.reset();
+    }
     uint32_t paths = 0;
 
     bool has = false;        // this lane carries a live path
@@ -148,6 +162,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
             continue;
         }
         // ---- one path segment for every live lane ----------------------------------------------
+        bool finished = false;
         if (has) {
             const bool alive = li_segment<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, glds, kBlock);
             if (!alive) {
@@ -157,15 +172,211 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
                 film_add_sample(film + idx, L);
                 isg_add_sample_atomic(isg_stats + idx * VSPG_ISG_STATS, L, isg);
                 paths++;
-                s += S.shard_count > 1 ? S.shard_count : 1;
-                if (s < wave_end)
-                    start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
-                else
-                    has = false;
+                finished = true;
             }
+        }
+        if constexpr (TRAIN) {  // PropagateSamples (:627), in lock step across the wavefront
+            propagate_samples(pc.rec, finished, train.samples, train.counters, train.capacity);
+            if (finished) pc.rec.reset();
+        }
+        if (finished) {
+            s += S.shard_count > 1 ? S.shard_count : 1;
+            if (s < wave_end)
+                start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
+            else
+                has = false;
         }
     }
     flush_counters(pc, paths, counters);
+}
+
+// ---- a18: Field::Update stand-in (definitions in vspg_train.h / oracle "Field::Update") --------------
+// Every kernel sees the batch through (samples, n); `f` selects the surface (0) or volume (1) field.
+__device__ __forceinline__ bool train_sample_region(const DScene &S, int f, const VspgTrainSample &sm, int *region) {
+    if (((sm.flags & VSPG_SAMPLE_VOLUME) != 0) != (f == 1)) return false;
+    *region = field_lookup(S.field[f], ld3(sm.p));
+    return *region >= 0;
+}
+__global__ __launch_bounds__(kBlock) void k_train_sum_weight(const VspgTrainSample *__restrict__ samples, unsigned long long n,
+                                                             float *__restrict__ sumw) {
+    float x = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kBlock)
+        x += samples[i].weight;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    if ((threadIdx.x & 63) == 0 && x != 0.f) atomicAdd(sumw, x);
+}
+__global__ __launch_bounds__(kBlock) void k_train_decay(const DScene *__restrict__ Sp, int f, RegionStats *__restrict__ stats) {
+    const int n = Sp->field[f].n_regions * kStatFloats;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int r = i / kStatFloats, k = i - r * kStatFloats;
+        (&stats[r].n)[k] *= kTrainDecay;
+    }
+}
+// position statistics {n, sum p, [sum p^2]} of the batch per region -> acc
+template <bool WITH_P2>
+__global__ __launch_bounds__(kBlock) void k_train_pos(const DScene *__restrict__ Sp, int f, const VspgTrainSample *__restrict__ samples,
+                                                      unsigned long long n, float *__restrict__ acc) {
+    const DScene &S = *Sp;
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * kBlock; i0 < n; i0 += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long i = i0 + threadIdx.x;
+        int region = 0;
+        bool valid = false;
+        VspgTrainSample sm;
+        if (i < n) {
+            sm = samples[i];
+            valid = train_sample_region(S, f, sm, &region);
+        }
+        if (WITH_P2) {
+            float v[7] = {1.f, sm.p[0], sm.p[1], sm.p[2], sm.p[0] * sm.p[0], sm.p[1] * sm.p[1], sm.p[2] * sm.p[2]};
+            wave_accumulate(valid, region, v, acc, 0);
+        } else {
+            float v[4] = {1.f, sm.p[0], sm.p[1], sm.p[2]};
+            wave_accumulate(valid, region, v, acc, 0);
+        }
+    }
+}
+// spatial refinement, ONE thread: sequential like the CPU definition so node / region numbering is the same
+__global__ void k_train_split(DScene *Sp, int f, RegionStats *stats, const float *acc, VspgKdNode *nodes, VspgFieldRegion *regs) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    DField &F = Sp->field[f];
+    const int n_reg0 = F.n_regions;
+    for (int i = 0; i < n_reg0; ++i) {
+        const float *a = acc + (size_t)i * kStatFloats;
+        stats[i].n += a[0];
+        for (int k = 0; k < 3; ++k) { stats[i].sum_p[k] += a[1 + k]; stats[i].sum_p2[k] += a[4 + k]; }
+    }
+    const int n_nodes0 = F.n_nodes;
+    for (int nd = 0; nd < n_nodes0; ++nd) {
+        if ((nodes[nd].packed & 3u) != 3u) continue;
+        const int reg = (int)(nodes[nd].packed >> 2);
+        RegionStats &s0 = stats[reg];
+        if (!(s0.n > kTrainSplitCount) || s0.depth >= kTrainMaxDepth) continue;
+        if (F.n_nodes + 2 > kTrainCapNodes || F.n_regions + 1 > kTrainCapRegions) continue;
+        float mean[3], var[3];
+        for (int k = 0; k < 3; ++k) {
+            mean[k] = s0.sum_p[k] / s0.n;
+            var[k] = s0.sum_p2[k] / s0.n - mean[k] * mean[k];
+        }
+        const int axis = var[0] >= var[1] ? (var[0] >= var[2] ? 0 : 2) : (var[1] >= var[2] ? 1 : 2);
+        if (!(var[axis] > 0)) continue;
+        const int left = F.n_nodes, newreg = F.n_regions;
+        F.n_nodes += 2;
+        F.n_regions += 1;
+        float *v = &s0.n;
+        for (int k = 0; k < kStatFloats; ++k) v[k] *= 0.5f;
+        s0.depth += 1;
+        stats[newreg] = s0;
+        regs[newreg] = regs[reg];
+        nodes[left].split = 0; nodes[left].packed = ((uint32_t)reg << 2) | 3u;
+        nodes[left + 1].split = 0; nodes[left + 1].packed = ((uint32_t)newreg << 2) | 3u;
+        nodes[nd].split = mean[axis];
+        nodes[nd].packed = ((uint32_t)left << 2) | (uint32_t)axis;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_train_init_regions(const DScene *__restrict__ Sp, int f, const float *__restrict__ acc,
+                                                               VspgFieldRegion *__restrict__ regs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= Sp->field[f].n_regions) return;
+    const float *a = acc + (size_t)i * kStatFloats;
+    if (regs[i].n_lobes == 0 && a[0] > 0) {
+        for (int k = 0; k < 3; ++k) regs[i].pivot[k] = a[1 + k] / a[0];
+        region_init_lobes(regs[i]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_train_estep(const DScene *__restrict__ Sp, int f, const VspgTrainSample *__restrict__ samples,
+                                                        unsigned long long n, const float *__restrict__ sumw, float *__restrict__ acc) {
+    const DScene &S = *Sp;
+    vspg_libm::stage_logf_tab_lds();
+    __syncthreads();
+    const float wmax = kTrainWeightClamp * (*sumw / (float)n);
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * kBlock; i0 < n; i0 += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long i = i0 + threadIdx.x;
+        int region = 0;
+        bool valid = false;
+        float vS[GK], vR0[GK], vR1[GK], vR2[GK], vD[GK], vV[GK], vQv[GK], vQs[GK];
+        for (int k = 0; k < GK; ++k) vS[k] = vR0[k] = vR1[k] = vR2[k] = vD[k] = vV[k] = vQv[k] = vQs[k] = 0.f;
+        if (i < n) {
+            const VspgTrainSample sm = samples[i];
+            valid = train_sample_region(S, f, sm, &region);
+            if (valid) {
+                const VspgFieldRegion &R = S.field[f].regions[region];
+                const int nl = R.n_lobes < GK ? R.n_lobes : GK;
+                valid = nl > 0;
+                if (valid) {
+                    const float w = sm.weight < wmax ? sm.weight : wmax;
+                    const V3 om = train_reaim(R, ld3(sm.p), ld3(sm.dir), sm.distance);
+                    float g[GK], gs = 0;
+                    for (int k = 0; k < GK; ++k) {
+                        g[k] = k < nl ? R.weight[k] * vmf_eval(V3{R.mu[0][k], R.mu[1][k], R.mu[2][k]}, kappa_clamp(R.kappa[k]), om) : 0.f;
+                        gs += g[k];
+                    }
+                    valid = gs > 0 && !isinf_(gs);
+                    if (valid) {
+                        const bool nextvol = (sm.flags & VSPG_SAMPLE_NEXT_VOLUME) != 0;
+                        const bool hasd = sm.distance > 0 && !isinf_(sm.distance);
+                        for (int k = 0; k < GK; ++k) {
+                            const float wg = w * (g[k] / gs);
+                            vS[k] = wg;
+                            vR0[k] = wg * om.x; vR1[k] = wg * om.y; vR2[k] = wg * om.z;
+                            vD[k] = hasd ? wg / sm.distance : 0.f;
+                            vV[k] = nextvol ? wg : 0.f;
+                            vQv[k] = nextvol ? wg * w : 0.f;
+                            vQs[k] = nextvol ? 0.f : wg * w;
+                        }
+                    }
+                }
+            }
+        }
+        wave_accumulate(valid, region, vS, acc, 7 + 0 * GK);
+        wave_accumulate(valid, region, vR0, acc, 7 + 1 * GK);
+        wave_accumulate(valid, region, vR1, acc, 7 + 2 * GK);
+        wave_accumulate(valid, region, vR2, acc, 7 + 3 * GK);
+        wave_accumulate(valid, region, vD, acc, 7 + 4 * GK);
+        wave_accumulate(valid, region, vV, acc, 7 + 5 * GK);
+        wave_accumulate(valid, region, vQv, acc, 7 + 6 * GK);
+        wave_accumulate(valid, region, vQs, acc, 7 + 7 * GK);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_train_mstep(const DScene *__restrict__ Sp, int f, const float *__restrict__ acc,
+                                                        RegionStats *__restrict__ stats, VspgFieldRegion *__restrict__ regs) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= Sp->field[f].n_regions) return;
+    VspgFieldRegion &R = regs[i];
+    if (R.n_lobes <= 0) return;
+    const int nl = R.n_lobes < GK ? R.n_lobes : GK;
+    RegionStats &s1 = stats[i];
+    const float *a = acc + (size_t)i * kStatFloats + 7;
+    float Stot = 0;
+    for (int k = 0; k < nl; ++k) {
+        s1.S[k] += a[0 * GK + k];
+        s1.R[0][k] += a[1 * GK + k]; s1.R[1][k] += a[2 * GK + k]; s1.R[2][k] += a[3 * GK + k];
+        s1.D[k] += a[4 * GK + k]; s1.V[k] += a[5 * GK + k]; s1.Qv[k] += a[6 * GK + k]; s1.Qs[k] += a[7 * GK + k];
+        Stot += s1.S[k];
+    }
+    if (!(Stot > 0)) return;
+    const float floorw = 1e-3f / GK;
+    float wsum = 0;
+    for (int k = 0; k < nl; ++k) {
+        float wk = s1.S[k] / Stot;
+        wk = wk < floorw ? floorw : wk;
+        R.weight[k] = wk;
+        wsum += wk;
+        const float rl = sqrtf(s1.R[0][k] * s1.R[0][k] + s1.R[1][k] * s1.R[1][k] + s1.R[2][k] * s1.R[2][k]);
+        if (s1.S[k] > 0 && rl > 0) {
+            R.mu[0][k] = s1.R[0][k] / rl; R.mu[1][k] = s1.R[1][k] / rl; R.mu[2][k] = s1.R[2][k] / rl;
+            float rbar = rl / s1.S[k];
+            rbar = rbar > 0.9999f ? 0.9999f : rbar;
+            R.kappa[k] = kappa_clamp(rbar * (3 - rbar * rbar) / (1 - rbar * rbar));
+            R.distance[k] = s1.D[k] > 0 ? s1.S[k] / s1.D[k] : kInf;
+            if (Sp->prm.vspcriterion == VSPG_VSP_VARIANCE) {
+                const float qv = sqrtf(s1.Qv[k]), qs = sqrtf(s1.Qs[k]);
+                R.vsp[k] = qv + qs > 0 ? qv / (qv + qs) : 0.5f;
+            } else {
+                R.vsp[k] = s1.V[k] / s1.S[k];
+            }
+        }
+    }
+    for (int k = 0; k < nl; ++k) R.weight[k] = R.weight[k] / wsum;
 }
 
 // Workgroup-level wavefront kernel (see vspg_wg_kernel.h for the design): a persistent workgroup
@@ -638,6 +849,17 @@ struct VspgRenderer {
     VspgKdNode *fnodes[2] = {nullptr, nullptr};        // guiding fields (device copies)
     VspgFieldRegion *fregions[2] = {nullptr, nullptr};
     bool field_set = false;
+    // a18: on-device training of the guiding field
+    bool training = false;
+    int field_iteration = 0;
+    float *segbuf = nullptr;                  // per-lane segment records of the training launches
+    size_t segbuf_lanes = 0;
+    VspgTrainSample *samples = nullptr;
+    unsigned long long sample_capacity = 0;
+    unsigned long long *train_counters = nullptr;  // [0] samples, [1] zero-valued, [2..3] spare
+    RegionStats *rstats[2] = {nullptr, nullptr};
+    float *train_acc = nullptr;               // kTrainCapRegions x kStatFloats accumulators of one pass
+    float *train_sumw = nullptr;
     float *density = nullptr;   // GridMedium density samples
     float *majorant = nullptr;  // 16^3 majorant grid
     int num_cus = 0;
@@ -972,6 +1194,33 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         CK(hipGetDeviceProperties(&prop, cfg->device));
         r->num_cus = prop.multiProcessorCount;
     }
+    // guideTraining (guidedvolpathvspgintegrator.cpp:109).  The reference also trains when only the guided-RR
+    // flags are set (they default to true); this build trains iff the field will be queried.
+    if (wants_guiding(r->prm)) {
+        r->training = true;
+        r->field_set = true;
+        for (int f = 0; f < 2; ++f) {
+            CK(hipMalloc(&r->fnodes[f], sizeof(VspgKdNode) * kTrainCapNodes));
+            CK(hipMemset(r->fnodes[f], 0, sizeof(VspgKdNode) * kTrainCapNodes));
+            CK(hipMalloc(&r->fregions[f], sizeof(VspgFieldRegion) * kTrainCapRegions));
+            CK(hipMemset(r->fregions[f], 0, sizeof(VspgFieldRegion) * kTrainCapRegions));
+            CK(hipMalloc(&r->rstats[f], sizeof(RegionStats) * kTrainCapRegions));
+            CK(hipMemset(r->rstats[f], 0, sizeof(RegionStats) * kTrainCapRegions));
+            const VspgKdNode root = {0.f, 3u};  // one leaf -> region 0, untrained (n_lobes 0)
+            CK(hipMemcpy(r->fnodes[f], &root, sizeof root, hipMemcpyHostToDevice));
+            r->hscene.field[f] = DField{1, 1, r->fnodes[f], r->fregions[f]};
+        }
+        CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
+        r->segbuf_lanes = (size_t)r->num_cus * kBlocksPerCU * kBlock;
+        CK(hipMalloc(&r->segbuf, r->segbuf_lanes * (size_t)(r->prm.maxdepth + 2) * SG_FLOATS * sizeof(float)));
+        r->sample_capacity = (unsigned long long)r->npix * (unsigned long long)(r->prm.maxdepth + 1);
+        if (r->sample_capacity > (1ull << 26)) r->sample_capacity = 1ull << 26;
+        CK(hipMalloc(&r->samples, r->sample_capacity * sizeof(VspgTrainSample)));
+        CK(hipMalloc(&r->train_counters, 4 * sizeof(unsigned long long)));
+        CK(hipMemset(r->train_counters, 0, 4 * sizeof(unsigned long long)));
+        CK(hipMalloc(&r->train_acc, (size_t)kTrainCapRegions * kStatFloats * sizeof(float)));
+        CK(hipMalloc(&r->train_sumw, sizeof(float)));
+    }
 #undef CK
     *out = r;
     return 0;
@@ -990,6 +1239,13 @@ int vspg_renderer_destroy(VspgRenderer *r) {
         if (r->fnodes[f]) (void)hipFree(r->fnodes[f]);
         if (r->fregions[f]) (void)hipFree(r->fregions[f]);
     }
+    for (int f = 0; f < 2; ++f)
+        if (r->rstats[f]) (void)hipFree(r->rstats[f]);
+    if (r->segbuf) (void)hipFree(r->segbuf);
+    if (r->samples) (void)hipFree(r->samples);
+    if (r->train_counters) (void)hipFree(r->train_counters);
+    if (r->train_acc) (void)hipFree(r->train_acc);
+    if (r->train_sumw) (void)hipFree(r->train_sumw);
     if (r->density) (void)hipFree(r->density);
     if (r->majorant) (void)hipFree(r->majorant);
     delete r;
@@ -1021,14 +1277,22 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     HIPCHK(hipMemsetAsync(r->work_head, 0, sizeof(unsigned int), (hipStream_t)stream));
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
     const bool guided = wants_guiding(r->prm);
-    if (guided && !r->field_set)
-        return fail(VSPG_ESCOPE,
-                    "surfaceguiding / volumeguiding / vspsecondaryguiding are enabled but no guiding field was uploaded "
-                    "(vspg_renderer_set_guiding_field); on-device field training is not built yet");
+    if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but the renderer holds no guiding field");
+    // a18: while the field trains, the guided kernels record path segments and emit radiance samples
+    const bool train = guided && r->training;
+    TrainArgs targs = {nullptr, nullptr, nullptr, 0};
+    if (train) targs = TrainArgs{r->segbuf, r->samples, r->train_counters, r->sample_capacity};
 #define VSPG_LAUNCH_RENDER(M, G)                                                                                          \
-    hipLaunchKernelGGL((k_render_wave<M, G>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, r->dscene,    \
-                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first, n_samples == 1 ? 1 : 0, \
-                       jump, static_per_wave, dyn_base, r->work_head, r->counters)
+    do {                                                                                                                  \
+        if (G && train)                                                                                                   \
+            hipLaunchKernelGGL((k_render_wave<M, G, G>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,    \
+                               r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first,        \
+                               n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, r->work_head, r->counters, targs); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((k_render_wave<M, G, false>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, \
+                               r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first,        \
+                               n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, r->work_head, r->counters, targs); \
+    } while (0)
     // scheduler: "wg" = workgroup-level wavefront kernel (unguided builds), "lane" = per-lane persistent kernel
     const char *kenv = getenv("VSPG_KERNEL");
     const bool use_wg = !guided && !(kenv && strcmp(kenv, "lane") == 0);
@@ -1057,10 +1321,54 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     return 0;
 }
 
+// Field::Update (:239) on device; one host read of the sample count per training wave decides whether the
+// update runs (more than 128 valid samples, :238) and sizes the grids.
+static int train_update(VspgRenderer *r, hipStream_t s) {
+    unsigned long long cnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(cnt, r->train_counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const unsigned long long n = cnt[0] < r->sample_capacity ? cnt[0] : r->sample_capacity;
+    if (n > kTrainMinUpdateSamples) {
+        const size_t acc_bytes = (size_t)kTrainCapRegions * kStatFloats * sizeof(float);
+        unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+        if (grid > (unsigned)r->num_cus * 16u) grid = (unsigned)r->num_cus * 16u;
+        const unsigned rgrid = (kTrainCapRegions + kBlock - 1) / kBlock;
+        HIPCHK(hipMemsetAsync(r->train_sumw, 0, sizeof(float), s));
+        hipLaunchKernelGGL(k_train_sum_weight, dim3(grid), dim3(kBlock), 0, s, r->samples, n, r->train_sumw);
+        for (int f = 0; f < 2; ++f) {
+            hipLaunchKernelGGL(k_train_decay, dim3(rgrid * 8), dim3(kBlock), 0, s, r->dscene, f, r->rstats[f]);
+            HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
+            hipLaunchKernelGGL((k_train_pos<true>), dim3(grid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_acc);
+            hipLaunchKernelGGL(k_train_split, dim3(1), dim3(64), 0, s, r->dscene, f, r->rstats[f], r->train_acc, r->fnodes[f],
+                               r->fregions[f]);
+            HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
+            hipLaunchKernelGGL((k_train_pos<false>), dim3(grid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_acc);
+            hipLaunchKernelGGL(k_train_init_regions, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->fregions[f]);
+            HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
+            hipLaunchKernelGGL(k_train_estep, dim3(grid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_sumw,
+                               r->train_acc);
+            hipLaunchKernelGGL(k_train_mstep, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->rstats[f],
+                               r->fregions[f]);
+        }
+        HIPCHK(hipGetLastError());
+        r->field_iteration++;
+        if (r->field_iteration >= r->prm.guide_num_training_waves) r->training = false;
+    }
+    return 0;
+}
+
 int vspg_post_process_wave(VspgRenderer *r, void *stream) {
     // PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260)
     if (!r) return fail(VSPG_EINVAL, "null renderer");
     r->wave_counter++;
+    if (r->train_counters) {
+        HIPCHK(hipSetDevice(r->cfg.device));
+        if (r->training) {
+            int rc = train_update(r, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+        HIPCHK(hipMemsetAsync(r->train_counters, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));  // Clear() (:248)
+    }
     if ((double)r->wave_counter == std::pow(2.0, (double)r->buffer_wave)) {
         if (r->prm.vspguiding && r->prm.vspprimaryguiding) {
             HIPCHK(hipSetDevice(r->cfg.device));
@@ -1248,6 +1556,7 @@ int vspg_renderer_set_guiding_field(VspgRenderer *r, const VspgField *surface_fi
     HIPCHK(hipSetDevice(r->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipStreamSynchronize(s));  // no launch may still read the old field
+    r->training = false;                // a loaded cache is not trained further (:117-122)
     int rc = upload_field(r, 0, surface_field, s);
     if (rc) return rc;
     rc = upload_field(r, 1, volume_field, s);
@@ -1307,6 +1616,65 @@ int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, flo
     HIPCHK(hipMemcpyAsync(logf_out, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(sinf_out, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(cosf_out, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_renderer_training_stats(VspgRenderer *r, VspgTrainStats *out, void *stream) {
+    if (!r || !out) return fail(VSPG_EINVAL, "null argument");
+    memset(out, 0, sizeof *out);
+    out->training = r->training ? 1 : 0;
+    out->iteration = r->field_iteration;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    if (r->train_counters) {
+        unsigned long long cnt[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(cnt, r->train_counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        out->n_samples = cnt[0];
+        out->n_zero = cnt[1];
+        DScene h;
+        HIPCHK(hipMemcpyAsync(&h, r->dscene, sizeof h, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int f = 0; f < 2; ++f) { out->n_nodes[f] = h.field[f].n_nodes; out->n_regions[f] = h.field[f].n_regions; }
+    } else {
+        for (int f = 0; f < 2; ++f) { out->n_nodes[f] = r->hscene.field[f].n_nodes; out->n_regions[f] = r->hscene.field[f].n_regions; }
+    }
+    return 0;
+}
+int vspg_train_samples_read(VspgRenderer *r, VspgTrainSample *out, size_t max_samples, size_t *n_out, void *stream) {
+    if (!r || !n_out) return fail(VSPG_EINVAL, "null argument");
+    *n_out = 0;
+    if (!r->train_counters) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, r->train_counters, sizeof cnt, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (cnt > r->sample_capacity) cnt = r->sample_capacity;
+    *n_out = (size_t)cnt;
+    const size_t n = cnt < max_samples ? (size_t)cnt : max_samples;
+    if (out && n) {
+        HIPCHK(hipMemcpyAsync(out, r->samples, n * sizeof(VspgTrainSample), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+int vspg_renderer_get_guiding_field(VspgRenderer *r, int volume_field, VspgKdNode *nodes, VspgFieldRegion *regions,
+                                    int32_t *n_nodes, int32_t *n_regions, void *stream) {
+    if (!r || !n_nodes || !n_regions) return fail(VSPG_EINVAL, "null argument");
+    const int f = volume_field ? 1 : 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DScene h;
+    HIPCHK(hipMemcpyAsync(&h, r->dscene, sizeof h, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_nodes = h.field[f].n_nodes;
+    *n_regions = h.field[f].n_regions;
+    if (nodes && h.field[f].nodes && *n_nodes > 0)
+        HIPCHK(hipMemcpyAsync(nodes, h.field[f].nodes, sizeof(VspgKdNode) * (size_t)*n_nodes, hipMemcpyDeviceToHost, s));
+    if (regions && h.field[f].regions && *n_regions > 0)
+        HIPCHK(hipMemcpyAsync(regions, h.field[f].regions, sizeof(VspgFieldRegion) * (size_t)*n_regions, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include "vspg_device.h"
 #include "vspg_guiding.h"
+#include "vspg_train.h"
 
 namespace vspg {
 
@@ -135,16 +136,22 @@ VDEV float light_pdf_li(const DQuad &q, const LsCtx &ctx, V3 wi) {  // shapes.cp
 //   WaveCounters  one set per workgroup in LDS: the active lanes of a wavefront are counted with a
 //                 ballot and one lane adds the total -- no per-lane registers, ~10 instructions per count.
 enum { CNT_PATHS = 0, CNT_SEGMENTS, CNT_VOLUME_SCATTERS, CNT_SURFACE_HITS, CNT_DENSITY_QUERIES, CNT_SHADOW_RAYS, CNT_COUNT };
-struct PathCounters {
+// Either sink also carries the a18 recorder (`rec`): NullRecorder everywhere except the training
+// instantiations of the per-lane kernel (vspg_train.h).
+template <class REC>
+struct PathCountersT {
     uint32_t segments, volume_scatters, surface_hits, density_queries, shadow_rays;
+    REC rec;
     VDEV void segment() { segments++; }
     VDEV void volume_scatter() { volume_scatters++; }
     VDEV void surface_hit() { surface_hits++; }
     VDEV void density_query() { density_queries++; }
     VDEV void shadow_ray() { shadow_rays++; }
 };
+using PathCounters = PathCountersT<NullRecorder>;
 struct WaveCounters {
     unsigned int *c;  // LDS, CNT_COUNT entries
+    NullRecorder rec;
     VDEV void add(int k) const {
         const unsigned long long m = __ballot(1);
         if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(c + k, (unsigned int)__popcll(m));
@@ -329,7 +336,7 @@ enum { SEG_ANY = 0, SEG_PRIMARY = 1, SEG_SECONDARY = 2 };
 template <class Medium, bool GUIDED, int SEG = SEG_ANY, class PC>
 VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
                                PathState &st, float tMax, int ch, Sampler &sampler, Rng &rng, IsgSample &isg,
-                               PC &pc) {
+                               PC &pc, Spec &tw /* transmittanceWeight (:317), training builds only */) {
     DistEvent ev;
     ev.kind = EV_PASS;
     ev.p = mk(0, 0, 0);
@@ -337,6 +344,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
 #ifdef VSPG_EXP_NOODS  // timing experiment only (primary rays lose their VSP guiding)
     constexpr bool kPlainOnly = !GUIDED;
 #else
+    constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     constexpr bool kPlainOnly = SEG == SEG_SECONDARY && !GUIDED;
 #endif
     if constexpr (SEG == SEG_PRIMARY) __builtin_assume(st.depth == 0);
@@ -421,6 +429,12 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
             return ev;
         }
         if (!selectSurface) {
+            if constexpr (kRec) {  // :798-802
+                tw = tw * ((sel_num * factor) / sel_den);
+                pc.rec.add_transmittance_weight(tw);
+                pc.rec.new_segment(sel_p, true);
+                tw = sp(1.f);
+            }
             ev.kind = EV_SCATTER;
             ev.p = sel_p;
             ev.g = sel_g;
@@ -467,6 +481,13 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
                 st.r_u = st.r_u * (T_maj * sigma_t / pdf);
                 st.r_u = st.r_u * r_u_factor;
+                if constexpr (kRec) {  // :978-986 (beta_factor is 1)
+                    tw = tw * ((T_maj * mp.sigma_s) / pdf);
+                    tw = tw * (sp(1.f) / ch_of(r_u_factor, ch));
+                    pc.rec.add_transmittance_weight(tw);
+                    pc.rec.new_segment(p, true);
+                    tw = sp(1.f);
+                }
                 ev.kind = EV_SCATTER;
                 ev.p = p;
                 ev.g = mp.g;
@@ -475,7 +496,11 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 Spec sigma_n = medium.sigma_n(mp, sigma_maj);
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
                 st.beta = st.beta * (T_maj * sigma_n / pdf);
-                if (pdf == 0) st.beta = sp(0.f);
+                if constexpr (kRec) tw = tw * (T_maj * sigma_n / pdf);  // :1067
+                if (pdf == 0) {
+                    st.beta = sp(0.f);
+                    if constexpr (kRec) tw = sp(0.f);
+                }
                 st.r_u = st.r_u * (T_maj * sigma_n / pdf);
                 st.r_l = st.r_l * (T_maj * sigma_maj / pdf);
                 return nonzero(st.beta) && nonzero(st.r_u);
@@ -497,6 +522,10 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
         st.r_l = st.r_l * (T_maj / tm);
         st.r_u = st.r_u * r_u_factor;
         st.r_l = st.r_l * r_u_factor;
+        if constexpr (kRec) {  // :1085, :1090
+            tw = tw * (T_maj / tm);
+            tw = tw * (sp(1.f) / ch_of(r_u_factor, ch));
+        }
     }
     return ev;
 }
@@ -534,6 +563,8 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
     vx.g = 0;
     vx.quad = si.quad;
     vx.t = si.t;
+    constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
+    Spec tw = sp(1.f);  // transmittanceWeight (:317)
     if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
         Rng rng;
         {
@@ -542,7 +573,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
             uint64_t hash1 = hash_float(sampler.get1d());
             rng.set_sequence(hash0, hash1);
         }
-        DistEvent ev = sample_distance<Medium, GUIDED, SEG>(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc);
+        DistEvent ev = sample_distance<Medium, GUIDED, SEG>(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc, tw);
         if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return false;  // :343-344
         if (ev.kind == EV_SCATTER) {
             vx.volume = true;
@@ -552,18 +583,26 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
         }
     }
     VSPG_PROF(PS_SURF_PRE);
+    if constexpr (kRec) pc.rec.add_transmittance_weight(tw);  // :350
     if (!si.hit) return false;  // no infinite lights in scope (:353-374)
     const DQuad &q = quad_at(si.quad);
     Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
+    float w_direct = 0.f;
     if (nonzero(Le)) {
         if (st.depth == 0 || st.specularBounce) {
             st.L = st.L + st.beta * Le / avg(st.r_u);
+            w_direct = 1.0f;
         } else {
             float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx.expand(), st.rd);
             st.r_l = st.r_l * lightPDF;
             float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
             st.L = st.L + st.beta * w_l * Le;
+            w_direct = w_l;
         }
+    }
+    if constexpr (kRec) {
+        pc.rec.new_segment(st.ro + st.rd * si.t, false);                // guiding_newSurfacePathSegment (:406)
+        if (nonzero(Le)) pc.rec.add_surface_emission(Le, w_direct);      // :409-412
     }
     if (st.depth == 0) {
         isg.valid = true;
@@ -753,6 +792,7 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
     if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {
         Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, useGuiding ? &gd : nullptr);
         st.L = st.L + st.beta * Ld;
+        pc.rec.add_scattered_direct_light(Ld);  // :485 / :838
     }
 
     if (volume_vertex) {
@@ -846,6 +886,8 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         st.rd = wi;
         st.specularBounce = false;
         st.anyNonSpecularBounces = true;
+        // guiding_addVolumeData(..., phaseFunctionWeight, ps->wi, ps->pdf, ps->meanCosine, survivalProb) (:871)
+        pc.rec.add_scatter_data(true, sp(w), wi, ps_pdf, 1.0f - __builtin_fabsf(vg), survivalProb);
         st.lastVertexVolume = true;
         return true;
     }
@@ -953,6 +995,9 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         if (sampler.get1d() < qq) return false;
         st.beta = st.beta / (1 - qq);
     }
+    // guiding_addSurfaceData(..., bsdfWeight, bs->wi, bs->eta, bs->sampledRoughness, bs->pdf, survivalProb) (:608);
+    // DiffuseBxDF: sampledRoughness 1
+    pc.rec.add_scatter_data(false, bsdfWeight, wi, pdf, 1.0f, survivalProb);
     return true;
 }
 

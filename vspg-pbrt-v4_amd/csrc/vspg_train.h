@@ -1,0 +1,230 @@
+// vspg_train.h -- guiding-cache training on device.
+//
+// Recording follows the reference's hooks (src/pbrt/cpu/guiding.h:682-832 and their call sites in
+// guidedvolpathvspgintegrator.cpp): a path keeps one segment record per vertex.  What OpenPGL does
+// with them -- PathSegmentStorage::PropagateSamples and Field::Update -- is absent from the reference
+// tree and is this build's own design (parity unpinned); oracle/vspg_oracle.c states
+// the same definitions on the CPU.  Radiance samples are bit-identical to the oracle's; the fitted
+// field agrees within float-summation-order tolerance (float atomics here, doubles there).
+#pragma once
+#include "vspg_guiding.h"
+
+namespace vspg {
+
+// ---- segment records: per lane, SoA over lanes in HBM -----------------------------------------
+enum {
+    SG_P = 0,        // 3  vertex position
+    SG_WI = 3,       // 3  sampled direction
+    SG_PDF = 6,      // 1
+    SG_MI = 7,       // 1  MIS weight of the emission seen at the vertex
+    SG_RR = 8,       // 1  survival probability
+    SG_SW = 9,       // 3  scattering weight
+    SG_T = 12,       // 3  transmittance weight of the segment LEAVING the vertex
+    SG_DIRECT = 15,  // 3
+    SG_SCAT = 18,    // 3  NEE estimate at the vertex
+    SG_FLAGS = 21,   // 1  bit0 has_wi, bit1 volume, bit2 is_delta
+    SG_FLOATS = 22
+};
+
+struct NullRecorder {  // every hook compiles to nothing
+    static constexpr bool kActive = false;
+    VDEV void new_segment(V3, bool) const {}
+    VDEV void add_transmittance_weight(Spec) const {}
+    VDEV void add_surface_emission(Spec, float) const {}
+    VDEV void add_scattered_direct_light(Spec) const {}
+    VDEV void add_scatter_data(bool, Spec, V3, float, float, float) const {}
+};
+
+struct PathRecorder {
+    static constexpr bool kActive = true;
+    float *base;  // this lane's column: element (seg, field) at base[(seg * SG_FLOATS + field) * stride]
+    int stride, max_seg;
+    int n, cur;  // cur: the reference's pathSegmentData pointer, -1 = nullptr
+    VDEV float &at(int seg, int f) const { return base[(size_t)(seg * SG_FLOATS + f) * (size_t)stride]; }
+    VDEV uint32_t &flags(int seg) const { return reinterpret_cast<uint32_t &>(at(seg, SG_FLAGS)); }
+    VDEV void set3(int seg, int f, float x, float y, float z) const { at(seg, f) = x; at(seg, f + 1) = y; at(seg, f + 2) = z; }
+    VDEV void reset() { n = 0; cur = -1; }
+    // guiding_newSurfacePathSegment / guiding_newVolumePathSegment (:682-732)
+    VDEV void new_segment(V3 p, bool volume) {
+        if (n >= max_seg) { cur = -1; return; }  // NextSegment() == nullptr
+        const int s = n;
+        set3(s, SG_P, p.x, p.y, p.z);
+        set3(s, SG_WI, 0, 0, 0);
+        at(s, SG_PDF) = 0;
+        at(s, SG_MI) = 1.f;
+        at(s, SG_RR) = 1.f;
+        set3(s, SG_SW, 0, 0, 0);
+        set3(s, SG_T, 1.f, 1.f, 1.f);
+        set3(s, SG_DIRECT, 0, 0, 0);
+        set3(s, SG_SCAT, 0, 0, 0);
+        flags(s) = volume ? 2u : 0u;
+        cur = n++;
+    }
+    VDEV void add_transmittance_weight(Spec T) const {  // :754-764
+        if (cur < 0) return;
+        T = clamp_zero(T);
+        set3(cur, SG_T, T.r, T.g, T.b);
+    }
+    VDEV void add_surface_emission(Spec Le, float w) const {  // :744-752
+        if (cur < 0) return;
+        Le = clamp_zero(Le);
+        set3(cur, SG_DIRECT, Le.r, Le.g, Le.b);
+        at(cur, SG_MI) = w;
+    }
+    VDEV void add_scattered_direct_light(Spec Ld) const {  // :734-742
+        if (cur < 0) return;
+        Ld = clamp_zero(Ld);
+        at(cur, SG_SCAT) = at(cur, SG_SCAT) + Ld.r;
+        at(cur, SG_SCAT + 1) = at(cur, SG_SCAT + 1) + Ld.g;
+        at(cur, SG_SCAT + 2) = at(cur, SG_SCAT + 2) + Ld.b;
+    }
+    // guiding_addSurfaceData / guiding_addVolumeData (:791-832)
+    VDEV void add_scatter_data(bool volume, Spec weight, V3 wi, float pdf, float roughness, float survivalProb) const {
+        if (cur < 0) return;
+        weight = clamp_zero(weight);
+        set3(cur, SG_T, 1.f, 1.f, 1.f);
+        set3(cur, SG_WI, wi.x, wi.y, wi.z);
+        at(cur, SG_PDF) = pdf;
+        set3(cur, SG_SW, weight.r, weight.g, weight.b);
+        at(cur, SG_RR) = survivalProb;
+        flags(cur) = 1u | (volume ? 2u : 0u) | (roughness < 0.001f ? 4u : 0u);
+    }
+};
+
+// append to the sample buffer: one returning atomic per wavefront (ballot + prefix count)
+VDEV void sample_append(bool emit, const VspgTrainSample &smp, VspgTrainSample *__restrict__ samples,
+                        unsigned long long *__restrict__ counters /* [0] n_samples, [1] n_zero, [2] dropped */,
+                        unsigned long long capacity) {
+    const unsigned long long m = __ballot(emit);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    if (emit) {
+        const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (idx < capacity) samples[idx] = smp;
+    }
+}
+
+// PathSegmentStorage::PropagateSamples stand-in (see oracle/vspg_oracle.c:propagate_samples for the
+// definition): walk the path's records from the last vertex to the first, in lock step across the wave.
+VDEV void propagate_samples(const PathRecorder &rec, bool active, VspgTrainSample *__restrict__ samples,
+                            unsigned long long *__restrict__ counters, unsigned long long capacity) {
+    const int n = active ? rec.n : 0;
+    int nmax = n;
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(nmax, off);
+        nmax = o > nmax ? o : nmax;
+    }
+    Spec Lout_next = sp(0.f);
+    V3 p_next = mk(0, 0, 0);
+    bool have_next = false, next_volume = false;
+    unsigned int zero = 0;
+    for (int i = nmax - 1; i >= 0; --i) {
+        bool emit = false;
+        VspgTrainSample smp;
+        if (i < n) {
+            const uint32_t fl = rec.flags(i);
+            const bool has_wi = (fl & 1u) != 0, volume = (fl & 2u) != 0, is_delta = (fl & 4u) != 0;
+            const V3 p = V3{rec.at(i, SG_P), rec.at(i, SG_P + 1), rec.at(i, SG_P + 2)};
+            const Spec T = Spec{rec.at(i, SG_T), rec.at(i, SG_T + 1), rec.at(i, SG_T + 2)};
+            const float pdf = rec.at(i, SG_PDF);
+            const Spec Lin = have_next ? T * Lout_next : sp(0.f);
+            if (has_wi && !is_delta && have_next && pdf > 0) {
+                const float w = avg(Lin) / pdf;
+                if (w > 0 && !isinf_(w)) {
+                    emit = true;
+                    smp.p[0] = p.x; smp.p[1] = p.y; smp.p[2] = p.z;
+                    smp.dir[0] = rec.at(i, SG_WI); smp.dir[1] = rec.at(i, SG_WI + 1); smp.dir[2] = rec.at(i, SG_WI + 2);
+                    smp.weight = w;
+                    smp.pdf = pdf;
+                    smp.distance = len(p_next - p);
+                    smp.flags = (volume ? VSPG_SAMPLE_VOLUME : 0u) | (next_volume ? VSPG_SAMPLE_NEXT_VOLUME : 0u);
+                } else {
+                    zero++;
+                }
+            }
+            const Spec direct = Spec{rec.at(i, SG_DIRECT), rec.at(i, SG_DIRECT + 1), rec.at(i, SG_DIRECT + 2)};
+            const Spec scat = Spec{rec.at(i, SG_SCAT), rec.at(i, SG_SCAT + 1), rec.at(i, SG_SCAT + 2)};
+            Spec Lout = direct * rec.at(i, SG_MI) + scat;
+            if (has_wi) {
+                const Spec sw = Spec{rec.at(i, SG_SW), rec.at(i, SG_SW + 1), rec.at(i, SG_SW + 2)};
+                Lout = Lout + (sw * Lin) / rec.at(i, SG_RR);
+            }
+            Lout_next = Lout;
+            p_next = p;
+            have_next = true;
+            next_volume = volume;
+        }
+        sample_append(emit, smp, samples, counters, capacity);
+    }
+    if (zero) atomicAdd(&counters[1], (unsigned long long)zero);
+}
+
+// ---- Field::Update stand-in (definition: oracle/vspg_oracle.c "Field::Update") ------------------
+constexpr float kTrainSplitCount = 4096.0f;
+constexpr float kTrainDecay = 0.75f;
+constexpr int kTrainMaxDepth = 24;
+constexpr float kTrainWeightClamp = 32.0f;
+constexpr float kTrainKappaInit = 2.0f;
+constexpr unsigned long long kTrainMinUpdateSamples = 128;  // guidedvolpathvspgintegrator.cpp:238
+constexpr int kTrainCapNodes = 8192, kTrainCapRegions = 4097;
+
+struct RegionStats {  // decayed sufficient statistics of one region
+    float n;
+    float sum_p[3], sum_p2[3];
+    float S[GK], R[3][GK], D[GK], V[GK], Qv[GK], Qs[GK];
+    int32_t depth;
+};
+constexpr int kStatFloats = 7 + 8 * GK;  // every float member of RegionStats, in order
+static_assert(sizeof(RegionStats) == (kStatFloats + 1) * 4, "RegionStats layout");
+
+// Add `vals[NV]` of every lane with `valid` into dst[region * kStatFloats + first + v].  Lanes of a
+// wavefront that share a region are summed with a butterfly first, so a region that dominates the
+// batch costs one atomic per value per wavefront; once a wavefront holds more than 8 distinct regions
+// contention is low and the remaining lanes add directly.
+template <int NV>
+VDEV void wave_accumulate(bool valid, int region, const float (&vals)[NV], float *__restrict__ dst, int first) {
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    for (int round = 0; todo != 0ull && round < 8; ++round) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lreg = __shfl(region, leader);
+        const unsigned long long same = __ballot(valid && region == lreg) & todo;
+        const bool mine = (same >> lane) & 1ull;
+        for (int v = 0; v < NV; ++v) {
+            float x = mine ? vals[v] : 0.f;
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == leader && x != 0.f) atomicAdd(&dst[(size_t)lreg * kStatFloats + first + v], x);
+        }
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull)
+        for (int v = 0; v < NV; ++v)
+            if (vals[v] != 0.f) atomicAdd(&dst[(size_t)region * kStatFloats + first + v], vals[v]);
+}
+
+VDEV V3 train_reaim(const VspgFieldRegion &R, V3 p, V3 w, float dist) {
+    if (!(dist > 0) || isinf_(dist)) return w;
+    V3 t = (p - ld3(R.pivot)) + w * dist;
+    float l2 = len2(t);
+    if (!(l2 > 0)) return w;
+    return normalize(t);
+}
+VDEV void region_init_lobes(VspgFieldRegion &R) {
+    const float c = 0.57735026918962576451f;
+    R.n_lobes = GK;
+    for (int k = 0; k < GK; ++k) {
+        R.weight[k] = 1.0f / GK;
+        R.kappa[k] = kTrainKappaInit;
+        R.mu[0][k] = (k & 1) ? -c : c;
+        R.mu[1][k] = (k & 2) ? -c : c;
+        R.mu[2][k] = (k & 4) ? -c : c;
+        R.distance[k] = kInf;
+        R.vsp[k] = 0.5f;
+    }
+}
+
+}  // namespace vspg
