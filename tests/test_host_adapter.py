@@ -52,3 +52,43 @@ def test_example_render_matches_cabi(host_build, gpu_pkg, tmp_path):
     ref = f[..., :3] / f[..., 3:4]
     assert np.array_equal(img.view(np.uint32), ref.astype(np.float32).view(np.uint32))
     r.close()
+
+
+@pytest.mark.gpu
+def test_guiding_cache_store_and_load(host_build, gpu_pkg, tmp_path):
+    """cfg-5 style run through the plugin surface: train in-loop + storeGuidingCache, then a second
+    integrator with loadGuidingCache renders with that field (no training) -- and equals the raw C-ABI
+    render with the same field uploaded."""
+    import ctypes as C
+    W, H, spp = 64, 48, 8
+    cache = tmp_path / "field.vspgfld"
+    exe = os.path.join(host_build, "example_render")
+    a = subprocess.run([exe, str(W), str(H), str(spp), str(tmp_path / "a.pfm"), "train", str(cache)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout + a.stderr
+    assert "guiding: training 1 iterations 8" in a.stdout and cache.exists()
+    b = subprocess.run([exe, str(W), str(H), str(spp), str(tmp_path / "b.pfm"), "load", str(cache)], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert "guiding: training 0 iterations 0" in b.stdout
+    # parse the VSPGFLD1 file (format documented in host/vspg_host.h) and upload it through the C-ABI
+    P = gpu_pkg
+    raw = cache.read_bytes()
+    assert raw[:8] == b"VSPGFLD1"
+    lobes, _, nn0, nr0, nn1, nr1 = np.frombuffer(raw, dtype="<u4", count=6, offset=8)
+    assert lobes == P.VSPG_FIELD_LOBES
+    off = 32
+    fields = []
+    for nn, nr in ((nn0, nr0), (nn1, nr1)):
+        nodes = (P.VspgKdNode * int(nn)).from_buffer_copy(raw, off); off += C.sizeof(nodes)
+        regs = (P.VspgFieldRegion * int(nr)).from_buffer_copy(raw, off); off += C.sizeof(regs)
+        fields.append(P.Field(list(nodes), list(regs)))
+    assert off == len(raw)
+    r = P.Renderer(P.fog_box_scene(W, H), P.default_params(), W, H)
+    r.set_guiding_field(fields[0], fields[1])
+    for w in range(spp):
+        r.render_wave(w, w + 1)
+        r.post_process_wave()
+    f = r.film()
+    ref = f[..., :3] / f[..., 3:4]
+    img = read_pfm(str(tmp_path / "b.pfm"))
+    assert np.array_equal(img.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    r.close()

@@ -138,3 +138,83 @@ def test_guiding_towards_the_light_reduces_variance():
     print("variance unguided %.4g guided %.4g" % (var_u, var_g))
     assert np.allclose(imgs_u.mean(), imgs_g.mean(), rtol=0.06)
     assert var_g < 0.6 * var_u
+
+
+# ---------------------------------------------------------------------------------------------
+# a18: training (recording hooks restated from guiding.h:682-832; PropagateSamples / Field::Update own design)
+# ---------------------------------------------------------------------------------------------
+def test_training_records_samples_and_fits_the_field():
+    P = load_package()
+    W, H = 48, 36
+    scene = oracle_lib.fog_box_scene(W, H)
+    prm = oracle_lib.default_params()
+    prm.guide_num_training_waves = 4
+    r = oracle_lib.OracleRenderer(scene, prm, W, H, seed=4)
+    st = r.training_stats()
+    assert st["training"] == 1 and st["iteration"] == 0 and st["n_regions"] == [1, 1]
+    r.render_wave(0, 1)
+    smp = r.train_samples()
+    st = r.training_stats()
+    assert st["n_samples"] == len(smp) > 1000
+    assert np.allclose(np.linalg.norm(smp["dir"], axis=1), 1, atol=1e-5)
+    assert (smp["weight"] > 0).all() and np.isfinite(smp["weight"]).all() and (smp["pdf"] > 0).all() and (smp["distance"] > 0).all()
+    assert set(np.unique(smp["flags"])) <= {0, 1, 2, 3}
+    vol = (smp["flags"] & 1) != 0
+    assert vol.any() and (~vol).any()
+    assert (np.abs(smp["p"][vol]) <= 1.0 + 1e-4).all()                       # medium vertices lie inside the fog box
+    assert np.isclose(np.abs(smp["p"][~vol]).max(axis=1), 1.0, atol=2e-3).all()  # surface vertices on a wall
+    # the distance is the length of the next path segment: the next vertex is again in / on the box
+    nxt = smp["p"] + smp["dir"] * smp["distance"][:, None]
+    assert (np.abs(nxt) <= 1.0 + 1e-3).all()
+    for w in range(4):
+        if w:
+            r.render_wave(w, w + 1)
+        r.post_process_wave()
+    st = r.training_stats()
+    assert st["training"] == 0 and st["iteration"] == 4 and st["n_samples"] == 0
+    for volume in (0, 1):
+        nodes, regs, nn, nr = r.get_guiding_field(volume)
+        assert nn == 2 * nr - 1  # binary tree: every split adds two nodes and one region
+        for i in range(nr):
+            R = regs[i]
+            assert R.n_lobes == P.VSPG_FIELD_LOBES
+            w = np.array(list(R.weight)); k = np.array(list(R.kappa)); v = np.array(list(R.vsp))
+            mu = np.array([list(R.mu[a]) for a in range(3)])
+            assert abs(w.sum() - 1) < 1e-5 and (w > 0).all()
+            assert (k >= 1e-2).all() and (k <= 1e4).all()
+            assert np.allclose(np.linalg.norm(mu, axis=0), 1, atol=1e-4)
+            assert (v >= 0).all() and (v <= 1).all()
+    r.close()
+
+
+def test_in_loop_training_is_unbiased_and_uploading_a_field_stops_it():
+    W, H = 48, 36
+    scene = oracle_lib.fog_box_scene(W, H)
+
+    def mean(guided, waves=40):
+        prm = oracle_lib.default_params()
+        prm.guide_num_training_waves = 12
+        if not guided:
+            prm.surfaceguiding = prm.volumeguiding = prm.vspsecondaryguiding = 0
+        r = oracle_lib.OracleRenderer(scene, prm, W, H, seed=6)
+        for w in range(waves):
+            r.render_wave(w, w + 1)
+            r.post_process_wave()
+        f = r.film_f64()
+        st = r.training_stats()
+        r.close()
+        return (f[..., :3] / f[..., 3:4]).mean(), st
+
+    mu, _ = mean(False)
+    mg, st = mean(True)
+    assert st["iteration"] == 12 and st["training"] == 0
+    assert abs(mg - mu) <= 0.02 * mu, (mg, mu)
+    P = load_package()
+    r = oracle_lib.OracleRenderer(scene, oracle_lib.default_params(), W, H)
+    assert r.training_stats()["training"] == 1
+    field = scenes.light_field(P, n=2)
+    r.set_guiding_field(field, field)
+    assert r.training_stats()["training"] == 0
+    r.render_wave(0, 1)
+    assert r.training_stats()["n_samples"] == 0
+    r.close()

@@ -1,9 +1,12 @@
 // example_render.cpp -- the scene-file lines of SURVEY.md App. F expressed through the host adapter:
 //   Integrator "guidedvolpathvspg" "integer maxdepth" 5 "bool vspguiding" true "bool surfaceguiding" false ...
 //   MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.05 .05 .05] "rgb sigma_s" [.45 .45 .45] "float g" 0
-// usage: example_render [xres yres spp out.pfm]
+// usage: example_render [xres yres spp out.pfm [train|load cachefile]]
+//   train: the reference's default guiding options (cfg 5: the field trains in-loop) + "bool storeGuidingCache" true
+//   load:  the same options + "bool loadGuidingCache" true (no training, guidedvolpathvspgintegrator.cpp:117-122)
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "vspg_host.h"
 
@@ -19,14 +22,22 @@ int main(int argc, char **argv) {
                                                              .RGB("sigma_s", .45f, .45f, .45f)
                                                              .Float("g", 0.f));
         vspg::ParameterDictionary ip;
-        ip.Int("maxdepth", 5).Bool("vspguiding", true).Bool("surfaceguiding", false).Bool("volumeguiding", false)
-            .Bool("vspsecondaryguiding", false);
+        const std::string mode = argc > 6 ? argv[5] : "";
+        if (mode == "train" || mode == "load") {
+            ip.Int("maxdepth", 5).Bool("vspguiding", true);  // surface / volume / secondary-VSP guiding default to true
+            ip.Bool(mode == "train" ? "storeGuidingCache" : "loadGuidingCache", true).String("guidingCacheFileName", argv[6]);
+        } else {
+            ip.Int("maxdepth", 5).Bool("vspguiding", true).Bool("surfaceguiding", false).Bool("volumeguiding", false)
+                .Bool("vspsecondaryguiding", false);
+        }
         auto integrator = vspg::Integrator::Create("guidedvolpathvspg", ip, scene, xres, yres, spp);
         std::printf("%s\n", integrator->ToString().c_str());
         integrator->Render();
         auto *vi = static_cast<vspg::GuidedVolPathVSPGIntegrator *>(integrator.get());
         vspg::Film film = vi->GetFilm();
         film.WritePFM(out);
+        VspgTrainStats ts = vi->TrainingStats();
+        std::printf("guiding: training %d iterations %d regions %d/%d\n", ts.training, ts.iteration, ts.n_regions[0], ts.n_regions[1]);
         VspgCounters c = vi->Counters();
         float rgb[3];
         film.GetPixelRGB(xres / 2, yres / 2, rgb);

@@ -50,6 +50,36 @@ int main() {
     // out-of-scope options are refused loudly, before any device work
     CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("rrguiding", true), scene, 16, 16, 1); }));
     CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("collisionProbabilityBias", true), scene, 16, 16, 1); }));
+    // guiding-cache file round trip (Field::Store / Field(file)) and its parameters
+    {
+        GuidingCache gc;
+        for (int f = 0; f < 2; ++f) {
+            gc.nodes[f].resize(3);
+            gc.nodes[f][0] = VspgKdNode{0.25f, (1u << 2) | (uint32_t)f};
+            gc.nodes[f][1] = VspgKdNode{0.f, (0u << 2) | 3u};
+            gc.nodes[f][2] = VspgKdNode{0.f, (1u << 2) | 3u};
+            gc.regions[f].resize(2);
+            std::memset(gc.regions[f].data(), 0, 2 * sizeof(VspgFieldRegion));
+            gc.regions[f][1].n_lobes = 2;
+            gc.regions[f][1].weight[0] = 0.75f; gc.regions[f][1].weight[1] = 0.25f;
+            gc.regions[f][1].kappa[0] = 12.f + f;
+        }
+        const char *fn = "/tmp/vspg_host_selftest.vspgfld";
+        gc.Write(fn);
+        GuidingCache rd = GuidingCache::Read(fn);
+        for (int f = 0; f < 2; ++f) {
+            CHECK(rd.nodes[f].size() == 3 && rd.regions[f].size() == 2);
+            CHECK(std::memcmp(rd.nodes[f].data(), gc.nodes[f].data(), 3 * sizeof(VspgKdNode)) == 0);
+            CHECK(std::memcmp(rd.regions[f].data(), gc.regions[f].data(), 2 * sizeof(VspgFieldRegion)) == 0);
+        }
+        std::remove(fn);
+        CHECK(throws([&] { GuidingCache::Read("/tmp/vspg_no_such_cache"); }));
+        GuidingCacheSettings cs;
+        (void)ParseIntegratorParams(ParameterDictionary().Bool("storeGuidingCache", true).String("guidingCacheFileName", "x.fld"), &cs);
+        CHECK(cs.store && !cs.load && cs.fileName == "x.fld");
+        CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("loadGuidingCache", true)); }));  // no file name
+        CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("storeISGBuffer", true)); }));    // still out of scope
+    }
     std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: ok\n", fails);
     return fails ? 1 : 0;
 }

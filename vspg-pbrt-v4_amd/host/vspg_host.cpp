@@ -64,7 +64,7 @@ VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p) {
 }
 
 // ---------------------------------------------------------------------------------------
-VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters) {
+VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache) {
     // GuidedVolPathVSPGIntegrator::Create (guidedvolpathvspgintegrator.cpp:1260-1322)
     VspgIntegratorParams p;
     vspg_integrator_params_default(&p);
@@ -75,9 +75,11 @@ VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters
     p.volumeguiding = parameters.GetOneBool("volumeguiding", true);
     p.surfaceguidingtype = parameters.GetOneString("surfaceguidingtype", "ris") == "mis" ? VSPG_GUIDE_MIS : VSPG_GUIDE_RIS;
     p.volumeguidingtype = parameters.GetOneString("volumeguidingtype", "mis") == "mis" ? VSPG_GUIDE_MIS : VSPG_GUIDE_RIS;
-    bool storeCache = parameters.GetOneBool("storeGuidingCache", false);
-    bool loadCache = parameters.GetOneBool("loadGuidingCache", false);
-    (void)parameters.GetOneString("guidingCacheFileName", "");
+    GuidingCacheSettings cs;
+    cs.store = parameters.GetOneBool("storeGuidingCache", false);
+    cs.load = parameters.GetOneBool("loadGuidingCache", false);
+    cs.fileName = parameters.GetOneString("guidingCacheFileName", "");
+    if (cache) *cache = cs;
     p.vspguiding = parameters.GetOneBool("vspguiding", true);
     p.vspprimaryguiding = parameters.GetOneBool("vspprimaryguiding", true);
     p.vspsecondaryguiding = parameters.GetOneBool("vspsecondaryguiding", true);
@@ -104,8 +106,9 @@ VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters
     else if (ls == "bvh") p.lightsampler = VSPG_LIGHTSAMPLER_BVH;
     else throw Error("Light sample distribution type \"" + ls + "\" unknown.");
     p.regularize = parameters.GetOneBool("regularize", false);
-    if (storeCache || loadCache || storeISG || loadISG || storeTr || loadTr)
-        throw Error("guiding-cache / ISG-buffer / Tr-buffer persistence is outside this build's scope");
+    if (storeISG || loadISG || storeTr || loadTr)
+        throw Error("ISG-buffer / Tr-buffer persistence is outside this build's scope");
+    if ((cs.store || cs.load) && cs.fileName.empty()) throw Error("storeGuidingCache / loadGuidingCache need \"guidingCacheFileName\"");
     return p;
 }
 
@@ -132,20 +135,100 @@ std::unique_ptr<Integrator> Integrator::Create(const std::string &name, const Pa
 std::unique_ptr<GuidedVolPathVSPGIntegrator> GuidedVolPathVSPGIntegrator::Create(const ParameterDictionary &parameters,
                                                                                  const VspgScene &scene, int xres, int yres,
                                                                                  int pixelSamples, int seed, int device) {
-    VspgIntegratorParams p = ParseIntegratorParams(parameters);
-    return std::make_unique<GuidedVolPathVSPGIntegrator>(p, scene, xres, yres, pixelSamples, seed, device);
+    GuidingCacheSettings cache;
+    VspgIntegratorParams p = ParseIntegratorParams(parameters, &cache);
+    return std::make_unique<GuidedVolPathVSPGIntegrator>(p, scene, xres, yres, pixelSamples, seed, device, cache);
 }
 
 GuidedVolPathVSPGIntegrator::GuidedVolPathVSPGIntegrator(const VspgIntegratorParams &p, const VspgScene &scene, int xres,
-                                                         int yres, int pixelSamples, int seed, int device)
-    : params(p), spp(pixelSamples) {
+                                                         int yres, int pixelSamples, int seed, int device,
+                                                         const GuidingCacheSettings &cache)
+    : params(p), spp(pixelSamples), cacheSettings(cache) {
     std::memset(&cfg, 0, sizeof cfg);
     cfg.xres = xres; cfg.yres = yres; cfg.spp = pixelSamples; cfg.seed = seed;
     cfg.shard_index = 0; cfg.shard_count = 1; cfg.device = device;
     int rc = vspg_renderer_create(&scene, &params, &cfg, &renderer);
     if (rc != 0) throw Error(std::string("GuidedVolPathVSPGIntegrator: ") + vspg_last_error());
+    if (cacheSettings.load) {  // :117-122: a loaded cache is used as is, guideTraining = false
+        GuidingCache gc = GuidingCache::Read(cacheSettings.fileName);
+        VspgField f[2];
+        for (int i = 0; i < 2; ++i)
+            f[i] = VspgField{(int32_t)gc.nodes[i].size(), (int32_t)gc.regions[i].size(), gc.nodes[i].data(), gc.regions[i].data()};
+        if (vspg_renderer_set_guiding_field(renderer, &f[0], &f[1], nullptr) != 0) {
+            std::string msg = vspg_last_error();
+            vspg_renderer_destroy(renderer);
+            throw Error("GuidedVolPathVSPGIntegrator: loading \"" + cacheSettings.fileName + "\": " + msg);
+        }
+    }
 }
-GuidedVolPathVSPGIntegrator::~GuidedVolPathVSPGIntegrator() { vspg_renderer_destroy(renderer); }
+GuidedVolPathVSPGIntegrator::~GuidedVolPathVSPGIntegrator() {
+    if (cacheSettings.store) {  // :210-213
+        try {
+            GetGuidingCache().Write(cacheSettings.fileName);
+        } catch (const Error &e) {
+            std::fprintf(stderr, "GuidedVolPathVSPGIntegrator: storing the guiding cache failed: %s\n", e.what());
+        }
+    }
+    vspg_renderer_destroy(renderer);
+}
+VspgTrainStats GuidedVolPathVSPGIntegrator::TrainingStats() {
+    VspgTrainStats st;
+    if (vspg_renderer_training_stats(renderer, &st, nullptr) != 0) throw Error(vspg_last_error());
+    return st;
+}
+GuidingCache GuidedVolPathVSPGIntegrator::GetGuidingCache() {
+    GuidingCache gc;
+    for (int f = 0; f < 2; ++f) {
+        int32_t nn = 0, nr = 0;
+        if (vspg_renderer_get_guiding_field(renderer, f, nullptr, nullptr, &nn, &nr, nullptr) != 0) throw Error(vspg_last_error());
+        gc.nodes[f].resize((size_t)nn);
+        gc.regions[f].resize((size_t)nr);
+        if (vspg_renderer_get_guiding_field(renderer, f, gc.nodes[f].data(), gc.regions[f].data(), &nn, &nr, nullptr) != 0)
+            throw Error(vspg_last_error());
+    }
+    return gc;
+}
+
+void GuidingCache::Write(const std::string &filename) const {
+    std::ofstream f(filename, std::ios::binary);
+    if (!f) throw Error("cannot open \"" + filename + "\" for writing");
+    const char magic[8] = {'V', 'S', 'P', 'G', 'F', 'L', 'D', '1'};
+    const uint32_t head[2] = {VSPG_FIELD_LOBES, 0u};
+    f.write(magic, 8);
+    f.write(reinterpret_cast<const char *>(head), sizeof head);
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t n[2] = {(uint32_t)nodes[i].size(), (uint32_t)regions[i].size()};
+        f.write(reinterpret_cast<const char *>(n), sizeof n);
+    }
+    for (int i = 0; i < 2; ++i) {
+        f.write(reinterpret_cast<const char *>(nodes[i].data()), (std::streamsize)(nodes[i].size() * sizeof(VspgKdNode)));
+        f.write(reinterpret_cast<const char *>(regions[i].data()), (std::streamsize)(regions[i].size() * sizeof(VspgFieldRegion)));
+    }
+    if (!f) throw Error("short write to \"" + filename + "\"");
+}
+GuidingCache GuidingCache::Read(const std::string &filename) {
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) throw Error("cannot open guiding cache \"" + filename + "\"");
+    char magic[8];
+    uint32_t head[2], n[2][2];
+    f.read(magic, 8);
+    f.read(reinterpret_cast<char *>(head), sizeof head);
+    f.read(reinterpret_cast<char *>(n), sizeof n);
+    if (!f || std::memcmp(magic, "VSPGFLD1", 8) != 0) throw Error("\"" + filename + "\" is not a VSPGFLD1 guiding cache");
+    if (head[0] != VSPG_FIELD_LOBES) throw Error("guiding cache was written with a different lobe count");
+    GuidingCache gc;
+    for (int i = 0; i < 2; ++i) {
+        if (n[i][0] > (1u << 24) || n[i][1] > (1u << 24)) throw Error("guiding cache header is corrupt");
+        gc.nodes[i].resize(n[i][0]);
+        gc.regions[i].resize(n[i][1]);
+    }
+    for (int i = 0; i < 2; ++i) {
+        f.read(reinterpret_cast<char *>(gc.nodes[i].data()), (std::streamsize)(gc.nodes[i].size() * sizeof(VspgKdNode)));
+        f.read(reinterpret_cast<char *>(gc.regions[i].data()), (std::streamsize)(gc.regions[i].size() * sizeof(VspgFieldRegion)));
+    }
+    if (!f) throw Error("guiding cache \"" + filename + "\" is truncated");
+    return gc;
+}
 
 void GuidedVolPathVSPGIntegrator::Render() {
     // ImageTileIntegrator::Render (integrators.cpp:123-239): waves of 1 spp, PostProcessWave each

@@ -66,6 +66,23 @@ struct Film {
     void WritePFM(const std::string &filename) const;
 };
 
+// Guiding-cache file (openpgl::cpp::Field::Store / Field(device, file), guidedvolpathvspgintegrator.cpp:
+// 117-128, 210-213).  Format "VSPGFLD1", little endian:
+//   char magic[8] = "VSPGFLD1"; uint32 lobes (= VSPG_FIELD_LOBES); uint32 reserved;
+//   for field in {surface, volume}: uint32 n_nodes, n_regions;
+//   for field in {surface, volume}: VspgKdNode nodes[n_nodes]; VspgFieldRegion regions[n_regions];
+// (structs exactly as declared in include/vspg.h).
+struct GuidingCache {
+    std::vector<VspgKdNode> nodes[2];
+    std::vector<VspgFieldRegion> regions[2];
+    void Write(const std::string &filename) const;
+    static GuidingCache Read(const std::string &filename);
+};
+struct GuidingCacheSettings {  // "storeGuidingCache" / "loadGuidingCache" / "guidingCacheFileName"
+    bool store = false, load = false;
+    std::string fileName;
+};
+
 class Integrator {
   public:
     virtual ~Integrator() = default;
@@ -84,13 +101,15 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
                                                                const VspgScene &scene, int xres, int yres,
                                                                int pixelSamples, int seed, int device);
     GuidedVolPathVSPGIntegrator(const VspgIntegratorParams &p, const VspgScene &scene, int xres, int yres,
-                                int pixelSamples, int seed, int device);
+                                int pixelSamples, int seed, int device, const GuidingCacheSettings &cache = {});
     ~GuidedVolPathVSPGIntegrator() override;
     void Render() override;       // wave loop: 1 spp per wave, PostProcessWave after each
     void PostProcessWave();       // guidedvolpathvspgintegrator.cpp:230-260
     std::string ToString() const override;
     Film GetFilm();
     VspgCounters Counters();
+    VspgTrainStats TrainingStats();      // guideTraining / guiding_field->GetIteration()
+    GuidingCache GetGuidingCache();      // the field as it stands (trained in-loop or loaded)
     const VspgIntegratorParams &Params() const { return params; }
 
   private:
@@ -98,9 +117,10 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
     VspgRenderConfig cfg;
     VspgRenderer *renderer = nullptr;
     int spp;
+    GuidingCacheSettings cacheSettings;
 };
 
 // parameter parsing only (no device): used by Create and by the CPU self test
-VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters);
+VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache = nullptr);
 
 }  // namespace vspg
