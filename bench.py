@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--xres", type=int, default=1920)
     ap.add_argument("--yres", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["fog", "cloud"], default="fog",
+                    help="fog = BASELINE.json's metric workload (default); cloud = procedural heterogeneous grid (configs 3-4 stand-in)")
+    ap.add_argument("--grid", type=int, default=256, help="voxels per axis of the cloud workload's density grid")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +117,7 @@ def main():
     sh = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sh)
     W, H = args.xres, args.yres
-    scene = pkg.fog_box_scene(W, H)
+    scene = pkg.fog_box_scene(W, H) if args.workload == "fog" else pkg.cloud_box_scene(W, H, args.grid)
     prm = pkg.app_f_params()
     r = pkg.Renderer(scene, prm, W, H, spp=args.steps * world, seed=0, shard_index=rank, shard_count=world,
                      device=local_rank)
@@ -169,15 +172,18 @@ def main():
         traffic_gbs, traffic_bytes = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
-            if W == 1920 and H == 1080:
+            if W == 1920 and H == 1080 and args.workload == "fog":
                 traffic_bytes = (pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
         except Exception:
             pass
         kbar = segs_rank / max(1, paths_rank)
-        bytes_per_launch = (segs_rank * B_SEGMENT + paths_rank * B_PATH_FIXED) / max(1, args.steps)
+        # heterogeneous media add 36 B per density query (8 voxels + 1 majorant)
+        dq_rank = cnt["density_queries"] if args.workload == "cloud" else 0
+        bytes_per_launch = (segs_rank * B_SEGMENT + paths_rank * B_PATH_FIXED + dq_rank * 36) / max(1, args.steps)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": "Mpaths/sec on 1920x1080 homogeneous fog; relMSE vs CPU ref at equal spp",
+            "metric": "Mpaths/sec on 1920x1080 homogeneous fog; relMSE vs CPU ref at equal spp" if args.workload == "fog"
+                      else "Mpaths/sec on a procedural %d^3 cloud grid (not BASELINE.json's metric workload)" % args.grid,
             "value": paths_total / elapsed / 1e6,
             "unit": "Mpaths/s",
             "n_gpus": world,
@@ -189,15 +195,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "fog-box %dx%d, guidedvolpathvspg vspguiding=true (primary-ray VSP), 1 spp per step per GPU, "
-                                   "independent sampler seed 0, maxdepth 5" % (W, H),
+            "config": {"workload": ("fog-box %dx%d" % (W, H) if args.workload == "fog" else
+                                    "cloud-box %dx%d, GridMedium %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (W, H, args.grid)) +
+                                   ", guidedvolpathvspg vspguiding=true (primary-ray VSP), 1 spp per step per GPU, "
+                                   "independent sampler seed 0, maxdepth 5",
                        "paths_per_step_per_gpu": W * H, "mean_segments_per_path": kbar,
                        "parallelism": "sample-index sharding x%d, film all-reduce at frame end" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic_bytes / (kern_ms * 1e-3) / 1e9) if traffic_bytes and kern_ms > 0 else None,
                          "traffic_bytes_per_launch": traffic_bytes,
-                         "kernel": "k_render_wave_wg", "kernel_ms": kern_ms,
+                         "kernel": "k_render_wave_wg", "kernel_ms": kern_ms, "density_queries_per_path": dq_rank / max(1, paths_rank),
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:

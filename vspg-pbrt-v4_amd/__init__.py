@@ -206,6 +206,46 @@ def fog_box_scene(xres, yres):
     return s
 
 
+def procedural_cloud_density(n, seed=5):
+    """Seeded value noise, density in [0, ~1.3], ~25-30 % empty voxels, x fastest (the layout
+    cmd/nanovdb2pbrt.cpp dumps for GridMedium): the heterogeneous stand-in of SURVEY.md 8d until a
+    Disney-cloud asset is supplied."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    coarse = rng.random((n // 4 + 2,) * 3).astype(np.float32)
+    idx = (np.arange(n, dtype=np.float32) + 0.5) / 4.0
+    i0 = np.floor(idx).astype(int)
+    f = (idx - i0).astype(np.float32)
+
+    def interp(a, axis):
+        shape = [1, 1, 1]
+        shape[axis] = n
+        w = f.reshape(shape)
+        return np.take(a, i0, axis=axis) * (1 - w) + np.take(a, i0 + 1, axis=axis) * w
+
+    v = interp(interp(interp(coarse, 0), 1), 2)
+    v = np.clip(v * 2.2 - 0.75, 0.0, None)
+    return np.ascontiguousarray(v.transpose(2, 1, 0).reshape(-1).astype(np.float32))
+
+
+def cloud_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5):
+    """Fog-box geometry and light with the homogeneous fog replaced by a procedural n^3 GridMedium
+    (sigma_t scale 8, albedo 0.99, g 0.877 -- SURVEY.md 8d's cloud-like choice)."""
+    s = fog_box_scene(xres, yres)
+    dens = procedural_cloud_density(n, seed)
+    m = s.medium
+    m.type = MEDIUM_GRID
+    m.sigma_a[:] = (sigma_t * (1 - albedo),) * 3
+    m.sigma_s[:] = (sigma_t * albedo,) * 3
+    m.g = g
+    m.nx = m.ny = m.nz = n
+    m.bounds_min[:] = (-0.9, -0.9, -0.6)
+    m.bounds_max[:] = (0.9, 0.8, 0.9)
+    m.density = dens.ctypes.data_as(C.POINTER(C.c_float))
+    s._density_keepalive = dens
+    return s
+
+
 def app_f_params():
     """SURVEY.md App. F integrator line: primary-ray VSP guiding only."""
     p = default_params()
