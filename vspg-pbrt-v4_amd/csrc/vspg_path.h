@@ -547,6 +547,42 @@ struct Vertex {
     float t;   // surface: tHit (only the guided build needs it, for p = ray.o + tHit * ray.d)
 };
 
+// the part of the path-loop iteration between distance sampling and the vertex, for a path that reached
+// the surface (:350-412): emission with MIS, ISG bookkeeping, depth test
+template <class PC>
+VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, const Isect &si, Spec tw) {
+    constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
+    VSPG_PROF(PS_SURF_PRE);
+    if constexpr (kRec) pc.rec.add_transmittance_weight(tw);  // :350
+    if (!si.hit) return false;  // no infinite lights in scope (:353-374)
+    const DQuad &q = quad_at(si.quad);
+    Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
+    float w_direct = 0.f;
+    if (nonzero(Le)) {
+        if (st.depth == 0 || st.specularBounce) {
+            st.L = st.L + st.beta * Le / avg(st.r_u);
+            w_direct = 1.0f;
+        } else {
+            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx.expand(), st.rd);
+            st.r_l = st.r_l * lightPDF;
+            float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
+            st.L = st.L + st.beta * w_l * Le;
+            w_direct = w_l;
+        }
+    }
+    if constexpr (kRec) {
+        pc.rec.new_segment(st.ro + st.rd * si.t, false);                // guiding_newSurfacePathSegment (:406)
+        if (nonzero(Le)) pc.rec.add_surface_emission(Le, w_direct);      // :409-412
+    }
+    if (st.depth == 0) {
+        isg.valid = true;
+        isg.surface_event = true;
+    }
+    if (st.depth++ >= S.prm.maxdepth) return false;
+    pc.surface_hit();
+    return true;
+}
+
 template <class Medium, bool GUIDED = false, int SEG = SEG_ANY, class PC>
 VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
                        PathState &st, int ch, Sampler &sampler, IsgSample &isg, PC &pc, Vertex &vx) {
@@ -582,56 +618,35 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
             return true;
         }
     }
-    VSPG_PROF(PS_SURF_PRE);
-    if constexpr (kRec) pc.rec.add_transmittance_weight(tw);  // :350
-    if (!si.hit) return false;  // no infinite lights in scope (:353-374)
-    const DQuad &q = quad_at(si.quad);
-    Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
-    float w_direct = 0.f;
-    if (nonzero(Le)) {
-        if (st.depth == 0 || st.specularBounce) {
-            st.L = st.L + st.beta * Le / avg(st.r_u);
-            w_direct = 1.0f;
-        } else {
-            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx.expand(), st.rd);
-            st.r_l = st.r_l * lightPDF;
-            float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
-            st.L = st.L + st.beta * w_l * Le;
-            w_direct = w_l;
-        }
-    }
-    if constexpr (kRec) {
-        pc.rec.new_segment(st.ro + st.rd * si.t, false);                // guiding_newSurfacePathSegment (:406)
-        if (nonzero(Le)) pc.rec.add_surface_emission(Le, w_direct);      // :409-412
-    }
-    if (st.depth == 0) {
-        isg.valid = true;
-        isg.surface_event = true;
-    }
-    if (st.depth++ >= S.prm.maxdepth) return false;
-    pc.surface_hit();
-    return true;
+    return li_surface_pre(S, st, isg, pc, si, tw);
 }
 
 template <class Medium, bool GUIDED, class PC>
 VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                            bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride);
 
-template <class Medium, bool GUIDED = false, class PC>
-VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
-                       const Vertex &vx, float *glds = nullptr, int gstride = 0) {
+// li_segment_b in three pieces, so that a scheduler can park a path between them (the per-lane state
+// machine for grid media runs the NEE transmittance walk step by step in between):
+//   vertex_setup   Interaction / BSDF of the vertex (a pure function of the path state and the vertex)
+//   vertex_pre     the cache-init sampler dimension and the volume vertex's survival probability
+//   vertex_tail    Russian roulette + new direction
+struct VertexCtx {
+    Isect si;
+    Intr intr;
+    Bsdf bsdf;
+};
+VDEV void vertex_setup(const PathState &st, const Vertex &vx, VertexCtx &c) {
+    Isect &si = c.si;
+    Intr &intr = c.intr;
+    Bsdf &bsdf = c.bsdf;
     const bool volume_vertex = vx.volume;
     const V3 vp = vx.p;
     const float vg = vx.g;
-    Isect si;
     si.hit = !vx.volume;
     si.t = vx.t;
     si.quad = vx.quad;
     si.p = vx.p;
     si.n = mk(0, 0, 0);
-    Intr intr;
-    Bsdf bsdf;
-    float survivalProb = 1.f;
     if (volume_vertex) {
         // MediumInteraction intr(p, -ray.d, ...) (:806 / :990)
         intr.is_surface = false;
@@ -650,21 +665,23 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
         intr.wo = normalize(-st.rd);  // Interaction ctor normalises wo (interaction.h:31-32)
         intr.g = 0;
     }
-
-    if constexpr (GUIDED)
-        return li_vertex_guided<Medium, GUIDED>(S, medium, st, ch, sampler, pc, volume_vertex, vp, vg, si, intr, bsdf, glds, gstride);
-
+}
+VDEV float vertex_pre(const DScene &S, const PathState &st, Sampler &sampler, const Vertex &vx) {
+    float survivalProb = 1.f;
     (void)sampler.get1d();  // v: gbsdf.init / gphase.init with an untrained field (:457-458, :809-810)
-    if (volume_vertex && st.depth > S.prm.minrrdepth) {  // :817-830: survival probability BEFORE the NEE
+    if (vx.volume && st.depth > S.prm.minrrdepth) {  // :817-830: survival probability BEFORE the NEE
         Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction;
         survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
     }
-    if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {  // :479 IsNonSpecular(bsdf.Flags()) / :833
-        VSPG_PROF(PS_NEE);
-        Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc);
-        st.L = st.L + st.beta * Ld;
-    }
-
+    return survivalProb;
+}
+VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Vertex &vx, const VertexCtx &c, float survivalProb) {
+    const bool volume_vertex = vx.volume;
+    const V3 vp = vx.p;
+    const float vg = vx.g;
+    const Isect &si = c.si;
+    const Intr &intr = c.intr;
+    const Bsdf &bsdf = c.bsdf;
     // ---- new direction.  Phase-function lanes (HG, :842-874) and BSDF lanes (cosine hemisphere,
     // :487-519) both need sinf/cosf of one angle: each side prepares its angle, the sin/cos are
     // evaluated once for all lanes, each side finishes.  Per lane the operations and the sampler
@@ -739,6 +756,22 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
         st.beta = st.beta / (1 - qq);
     }
     return true;
+}
+
+template <class Medium, bool GUIDED = false, class PC>
+VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
+                       const Vertex &vx, float *glds = nullptr, int gstride = 0) {
+    VertexCtx c;
+    vertex_setup(st, vx, c);
+    if constexpr (GUIDED)
+        return li_vertex_guided<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, glds, gstride);
+    const float survivalProb = vertex_pre(S, st, sampler, vx);
+    if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 IsNonSpecular(bsdf.Flags()) / :833
+        VSPG_PROF(PS_NEE);
+        Spec Ld = sample_Ld(S, medium, c.intr, &c.bsdf, ch, sampler, st.r_u, pc);
+        st.L = st.L + st.beta * Ld;
+    }
+    return vertex_tail(S, st, sampler, vx, c, survivalProb);
 }
 
 template <class Medium, bool GUIDED = false, class PC>
