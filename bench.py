@@ -133,6 +133,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    # untimed: first use of the communicator at the film's size (RCCL sets up channels / buffers lazily)
+    sh.frame_end_allreduce(dist, film, world)
     torch.cuda.synchronize()
     r.film_clear(stream)
     r.reset_counters(stream)
