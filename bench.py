@@ -89,8 +89,9 @@ def main():
     ap.add_argument("--xres", type=int, default=1920)
     ap.add_argument("--yres", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fog", "cloud"], default="fog",
-                    help="fog = BASELINE.json's metric workload (default); cloud = procedural heterogeneous grid (configs 3-4 stand-in)")
+    ap.add_argument("--workload", choices=["fog", "cloud", "cloud-nvdb"], default="fog",
+                    help="fog = BASELINE.json's metric workload (default); cloud = procedural heterogeneous GridMedium (configs 3-4 stand-in); "
+                         "cloud-nvdb = the same grid with NanoVDBMedium semantics (64^3 majorants)")
     ap.add_argument("--grid", type=int, default=256, help="voxels per axis of the cloud workload's density grid")
     args = ap.parse_args()
 
@@ -117,7 +118,8 @@ def main():
     sh = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sh)
     W, H = args.xres, args.yres
-    scene = pkg.fog_box_scene(W, H) if args.workload == "fog" else pkg.cloud_box_scene(W, H, args.grid)
+    scene = (pkg.fog_box_scene(W, H) if args.workload == "fog" else pkg.cloud_box_scene(W, H, args.grid) if args.workload == "cloud"
+             else pkg.nanovdb_box_scene(W, H, args.grid))
     prm = pkg.app_f_params()
     r = pkg.Renderer(scene, prm, W, H, spp=args.steps * world, seed=0, shard_index=rank, shard_count=world,
                      device=local_rank)
@@ -180,7 +182,7 @@ def main():
             pass
         kbar = segs_rank / max(1, paths_rank)
         # heterogeneous media add 36 B per density query (8 voxels + 1 majorant)
-        dq_rank = cnt["density_queries"] if args.workload == "cloud" else 0
+        dq_rank = cnt["density_queries"] if args.workload != "fog" else 0
         bytes_per_launch = (segs_rank * B_SEGMENT + paths_rank * B_PATH_FIXED + dq_rank * 36) / max(1, args.steps)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
@@ -198,7 +200,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("fog-box %dx%d" % (W, H) if args.workload == "fog" else
-                                    "cloud-box %dx%d, GridMedium %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (W, H, args.grid)) +
+                                    "cloud-box %dx%d, %s %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
+                                        W, H, "GridMedium" if args.workload == "cloud" else "NanoVDBMedium (dense copy, 64^3 majorants)", args.grid)) +
                                    ", guidedvolpathvspg vspguiding=true (primary-ray VSP), 1 spp per step per GPU, "
                                    "independent sampler seed 0, maxdepth 5",
                        "paths_per_step_per_gpu": W * H, "mean_segments_per_path": kbar,

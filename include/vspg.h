@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSPG_ABI_VERSION 1
+#define VSPG_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define VSPG_OK 0
@@ -66,7 +66,7 @@ typedef struct VspgCamera {
     float sx, ox, sy, oy;
 } VspgCamera;
 
-enum { VSPG_MEDIUM_NONE = 0, VSPG_MEDIUM_HOMOGENEOUS = 1, VSPG_MEDIUM_GRID = 2 };
+enum { VSPG_MEDIUM_NONE = 0, VSPG_MEDIUM_HOMOGENEOUS = 1, VSPG_MEDIUM_GRID = 2, VSPG_MEDIUM_NANOVDB = 3 };
 
 /* The single medium filling the scene (ray.medium for every ray).
  * HOMOGENEOUS mirrors HomogeneousMedium (src/pbrt/media.h:221-283; parameters
@@ -86,6 +86,16 @@ typedef struct VspgMedium {
     int32_t nx, ny, nz;
     float bounds_min[3], bounds_max[3];
     const float *density; /* HOST pointer, nx*ny*nz floats; copied at create time */
+    /* VSPG_MEDIUM_NANOVDB only -- NanoVDBMedium (src/pbrt/media.h:657-753, media.cpp:549-675) over a DENSE copy
+     * of the density grid (what cmd/nanovdb2pbrt.cpp:97-126 dumps): voxel (i,j,k) of the array is index
+     * (index_min + (i,j,k)); values outside the index bounding box are the background 0.
+     * worldToIndexF(p) = (p - grid_origin) / voxel_size; `bounds` is the grid's world bounding box;
+     * majorants live on a 64^3 grid (media.cpp:574); "densityoffset" / "majorantscale" as in the RGB-mode ctor. */
+    int32_t index_min[3];
+    float voxel_size[3];
+    float grid_origin[3];
+    float density_offset;
+    float majorant_scale;
 } VspgMedium;
 
 typedef struct VspgScene {

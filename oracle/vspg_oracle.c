@@ -553,7 +553,10 @@ typedef struct {
     int step[3], voxelLimit[3], voxel[3];
 } majiter_t;
 
-#define MAJ_RES 16 /* GridMedium majorant grid resolution (media.cpp:252) */
+#define MAJ_RES 16      /* GridMedium majorant grid resolution (media.cpp:252) */
+#define MAJ_RES_NVDB 64 /* NanoVDBMedium majorant grid resolution (media.cpp:574) */
+static int medium_is_grid_like(int type) { return type == VSPG_MEDIUM_GRID || type == VSPG_MEDIUM_NANOVDB; }
+static int medium_maj_res(int type) { return type == VSPG_MEDIUM_NANOVDB ? MAJ_RES_NVDB : MAJ_RES; }
 
 static int majiter_next(majiter_t *it, majseg_t *seg) {
     if (it->type == VSPG_MEDIUM_HOMOGENEOUS) {
@@ -562,7 +565,8 @@ static int majiter_next(majiter_t *it, majseg_t *seg) {
         *seg = it->seg;
         return 1;
     }
-    if (it->type == VSPG_MEDIUM_GRID) { /* DDAMajorantIterator::Next (media.h:178-207) */
+    if (medium_is_grid_like(it->type)) { /* DDAMajorantIterator::Next (media.h:178-207) */
+        const int MR = medium_maj_res(it->type);
         if (it->tMin >= it->tMax) return 0;
         int bits = ((it->nextCrossingT[0] < it->nextCrossingT[1]) << 2) +
                    ((it->nextCrossingT[0] < it->nextCrossingT[2]) << 1) +
@@ -570,7 +574,7 @@ static int majiter_next(majiter_t *it, majseg_t *seg) {
         const int cmpToAxis[8] = {2, 1, 2, 1, 2, 2, 0, 0};
         int stepAxis = cmpToAxis[bits];
         float tVoxelExit = it->nextCrossingT[stepAxis] < it->tMax ? it->nextCrossingT[stepAxis] : it->tMax; /* std::min(tMax, next) */
-        float md = it->maj[it->voxel[0] + MAJ_RES * (it->voxel[1] + MAJ_RES * it->voxel[2])];
+        float md = it->maj[it->voxel[0] + MR * (it->voxel[1] + MR * it->voxel[2])];
         seg->tMin = it->tMin;
         seg->tMax = tVoxelExit;
         seg->sigma_maj = s_scale(it->sigma_t, md);
@@ -650,7 +654,8 @@ static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tM
         it.seg.tMin = 0;
         it.seg.tMax = tMax;
         it.seg.sigma_maj = s_add(s_from(m->sigma_a), s_from(m->sigma_s));
-    } else if (m->type == VSPG_MEDIUM_GRID) {
+    } else if (medium_is_grid_like(m->type)) { /* GridMedium::SampleRay (media.h:347-362) == NanoVDBMedium::SampleRay (:705-719) */
+        const int MR = medium_maj_res(m->type);
         it.tMin = INFINITY; it.tMax = -INFINITY; /* default-constructed iterator: Next() returns nothing */
         /* ray = renderFromMedium.ApplyInverse(ray, &raytMax) with an identity transform
          * (transform.h:416-429, transform.cpp:263-303): the origin picks up the conservative
@@ -691,17 +696,17 @@ static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tM
         float gd[3] = {d.x / diag.x, d.y / diag.y, d.z / diag.z};
         float gi[3] = {go.x + gd[0] * t0, go.y + gd[1] * t0, go.z + gd[2] * t0};
         for (int axis = 0; axis < 3; ++axis) {
-            float v = gi[axis] * MAJ_RES; /* Clamp(float, 0, res-1) -> float, then converted to int */
-            it.voxel[axis] = (int)(v < 0 ? 0.f : (v > (float)(MAJ_RES - 1) ? (float)(MAJ_RES - 1) : v));
-            it.deltaT[axis] = 1 / (fabsf(gd[axis]) * MAJ_RES);
+            float v = gi[axis] * MR; /* Clamp(float, 0, res-1) -> float, then converted to int */
+            it.voxel[axis] = (int)(v < 0 ? 0.f : (v > (float)(MR - 1) ? (float)(MR - 1) : v));
+            it.deltaT[axis] = 1 / (fabsf(gd[axis]) * MR);
             if (gd[axis] == -0.f) gd[axis] = 0.f;
             if (gd[axis] >= 0) {
-                float nextVoxelPos = (float)(it.voxel[axis] + 1) / MAJ_RES;
+                float nextVoxelPos = (float)(it.voxel[axis] + 1) / MR;
                 it.nextCrossingT[axis] = t0 + (nextVoxelPos - gi[axis]) / gd[axis];
                 it.step[axis] = 1;
-                it.voxelLimit[axis] = MAJ_RES;
+                it.voxelLimit[axis] = MR;
             } else {
-                float nextVoxelPos = (float)(it.voxel[axis]) / MAJ_RES;
+                float nextVoxelPos = (float)(it.voxel[axis]) / MR;
                 it.nextCrossingT[axis] = t0 + (nextVoxelPos - gi[axis]) / gd[axis];
                 it.step[axis] = -1;
                 it.voxelLimit[axis] = -1;
@@ -713,6 +718,63 @@ static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tM
     return it;
 }
 /* Medium::SamplePoint: HomogeneousMedium (media.h:256-261), GridMedium (media.h:316-345) */
+/* NanoVDBMedium over a dense copy of the grid.  worldToIndexF(p) = (p - grid_origin) * (1 / voxel_size);
+ * nanovdb::SampleFromVoxels<Tree, 1, false>: ijk = floor(x), uvw = x - ijk, the 8 corner values (background 0
+ * outside the index bounding box), lerp(a, b, w) = a + w (b - a) along z, then y, then x.  NanoVDB itself is
+ * absent from the reference tree (submodule not vendored): PARITY UNPINNED for this fetch. */
+static float nvdb_value(const OracleRenderer *r, int i, int j, int k) {
+    const VspgMedium *m = &r->scene.medium;
+    int x = i - m->index_min[0], y = j - m->index_min[1], z = k - m->index_min[2];
+    if (x < 0 || y < 0 || z < 0 || x >= m->nx || y >= m->ny || z >= m->nz) return 0.f;
+    return r->density[((size_t)z * m->ny + y) * m->nx + x];
+}
+static float nvdb_sample(const OracleRenderer *r, v3 p) {
+    const VspgMedium *m = &r->scene.medium;
+    float inv[3] = {1.0f / m->voxel_size[0], 1.0f / m->voxel_size[1], 1.0f / m->voxel_size[2]};
+    float x = (p.x - m->grid_origin[0]) * inv[0], y = (p.y - m->grid_origin[1]) * inv[1], z = (p.z - m->grid_origin[2]) * inv[2];
+    float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float u = x - fx, v = y - fy, w = z - fz;
+#define NLERP(a, b, t) ((a) + (t) * ((b) - (a)))
+    float a00 = NLERP(nvdb_value(r, i, j, k), nvdb_value(r, i, j, k + 1), w);
+    float a01 = NLERP(nvdb_value(r, i, j + 1, k), nvdb_value(r, i, j + 1, k + 1), w);
+    float a10 = NLERP(nvdb_value(r, i + 1, j, k), nvdb_value(r, i + 1, j, k + 1), w);
+    float a11 = NLERP(nvdb_value(r, i + 1, j + 1, k), nvdb_value(r, i + 1, j + 1, k + 1), w);
+    float b0 = NLERP(a00, a01, v), b1 = NLERP(a10, a11, v);
+    return NLERP(b0, b1, u);
+#undef NLERP
+}
+/* NanoVDBMedium ctor, "Initialize majorantGrid" (media.cpp:600-671) */
+static void build_majorant_grid_nvdb(OracleRenderer *r) {
+    const VspgMedium *m = &r->scene.medium;
+    const int R = MAJ_RES_NVDB;
+    int imin[3] = {m->index_min[0], m->index_min[1], m->index_min[2]};
+    int imax[3] = {m->index_min[0] + m->nx - 1, m->index_min[1] + m->ny - 1, m->index_min[2] + m->nz - 1};
+    for (int z = 0; z < R; ++z)
+        for (int y = 0; y < R; ++y)
+            for (int x = 0; x < R; ++x) {
+                int c[3] = {x, y, z}, lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    float t0 = (float)c[k] / R, t1 = (float)(c[k] + 1) / R;
+                    float w0 = (1 - t0) * m->bounds_min[k] + t0 * m->bounds_max[k]; /* bounds.Lerp */
+                    float w1 = (1 - t1) * m->bounds_min[k] + t1 * m->bounds_max[k];
+                    double i0 = ((double)w0 - (double)m->grid_origin[k]) / (double)m->voxel_size[k]; /* worldToIndexF(Vec3R) */
+                    double i1 = ((double)w1 - (double)m->grid_origin[k]) / (double)m->voxel_size[k];
+                    float delta = 1.f; /* filter slop */
+                    int a = (int)(i0 - delta), b = (int)(i1 + delta);
+                    lo[k] = a > imin[k] ? a : imin[k];
+                    hi[k] = b < imax[k] ? b : imax[k];
+                }
+                float mx = 0;
+                for (int kk = lo[2]; kk <= hi[2]; ++kk)
+                    for (int jj = lo[1]; jj <= hi[1]; ++jj)
+                        for (int ii = lo[0]; ii <= hi[0]; ++ii) {
+                            float v = nvdb_value(r, ii, jj, kk);
+                            mx = mx < v ? v : mx;
+                        }
+                r->majorant[x + R * (y + R * z)] = (mx + m->density_offset) * m->majorant_scale;
+            }
+}
 static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
     medium_props_t mp;
     const VspgMedium *m = &r->scene.medium;
@@ -720,9 +782,15 @@ static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
     mp.sigma_s = s_from(m->sigma_s);
     mp.Le = s_from(m->Le);
     mp.g = m->g;
-    if (m->type == VSPG_MEDIUM_GRID) {
+    if (medium_is_grid_like(m->type)) {
         /* identity renderFromMedium: ApplyInverse(Point3f) returns p unchanged */
-        float d = grid_lookup(r, bounds_offset(m, p));
+        float d;
+        if (m->type == VSPG_MEDIUM_NANOVDB) { /* media.h:686-703 */
+            d = nvdb_sample(r, p);
+            d += m->density_offset;
+        } else {
+            d = grid_lookup(r, bounds_offset(m, p));
+        }
         mp.sigma_a = s_scale(mp.sigma_a, d);
         mp.sigma_s = s_scale(mp.sigma_s, d);
         mp.Le = S1(0.f); /* emissive grids (Le / temperature) are outside this build's scope */
@@ -2513,9 +2581,11 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
     if (cfg->xres <= 0 || cfg->yres <= 0) return VSPG_EINVAL;
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return VSPG_EINVAL;
     if (p->collisionProbabilityBias || p->rrguiding) return VSPG_ESCOPE;
-    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+    if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;
         if (m->nx <= 0 || m->ny <= 0 || m->nz <= 0 || !m->density) return VSPG_EINVAL;
+        if (m->type == VSPG_MEDIUM_NANOVDB && !(m->voxel_size[0] > 0 && m->voxel_size[1] > 0 && m->voxel_size[2] > 0 && m->majorant_scale > 0))
+            return VSPG_EINVAL;
         if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) return VSPG_ESCOPE;
     }
     return 0;
@@ -2535,14 +2605,16 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
         quad_init(&r->quads[i], &scene->quads[i]);
         if (r->quads[i].is_light) r->light_quads[r->n_lights++] = i;
     }
-    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+    if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;
         size_t n = (size_t)m->nx * m->ny * m->nz;
         r->density = (float *)malloc(n * sizeof(float));
         memcpy(r->density, m->density, n * sizeof(float));
         r->scene.medium.density = r->density;
-        r->majorant = (float *)calloc(MAJ_RES * MAJ_RES * MAJ_RES, sizeof(float));
-        build_majorant_grid(r);
+        const int MR = medium_maj_res(m->type);
+        r->majorant = (float *)calloc((size_t)MR * MR * MR, sizeof(float));
+        if (m->type == VSPG_MEDIUM_NANOVDB) build_majorant_grid_nvdb(r);
+        else build_majorant_grid(r);
     }
     size_t npix = (size_t)cfg->xres * cfg->yres;
     r->film = (double *)calloc(npix * 4, sizeof(double));

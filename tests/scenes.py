@@ -115,3 +115,21 @@ def light_field(P, n=4, bmin=(-1, -1, -1), bmax=(1, 1, 1), light=(0.0, 0.999, 0.
 
     build(list(bmin), list(bmax), 0)
     return P.Field(nodes, regions)
+
+
+def nvdb_scene(density, n, sigma_a, sigma_s, g=0.0, index_min=(0, 0, 0), voxel=(0.1, 0.1, 0.1), origin=(-0.8, -0.8, -0.5),
+               density_offset=0.0, majorant_scale=1.0, W=16, H=16):
+    """fog-box geometry with a NanoVDBMedium over a dense copy of the grid (index space = origin + index * voxel;
+    the world bounding box covers index_min .. index_min + n, i.e. the voxel extents)."""
+    P = load_package()
+    bmin = tuple(origin[k] + index_min[k] * voxel[k] for k in range(3))
+    bmax = tuple(origin[k] + (index_min[k] + n[k]) * voxel[k] for k in range(3))
+    s = grid_scene(density, n, sigma_a, sigma_s, g=g, bmin=bmin, bmax=bmax, W=W, H=H)
+    m = s.medium
+    m.type = P.MEDIUM_NANOVDB
+    m.index_min[:] = index_min
+    m.voxel_size[:] = voxel
+    m.grid_origin[:] = origin
+    m.density_offset = density_offset
+    m.majorant_scale = majorant_scale
+    return s

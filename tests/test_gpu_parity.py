@@ -437,6 +437,73 @@ def test_grid_paths_and_film_vs_oracle(cloud_pair):
 
 
 # ---------------------------------------------------------------------------------------------
+# NanoVDBMedium semantics over a dense copy of the grid: 64^3 majorants in HBM, index-space trilinear
+# fetch with zero background, densityoffset / majorantscale
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def nvdb_pair(gpu_pkg):
+    from scenes import cloud_density, nvdb_scene
+    P = gpu_pkg
+    W, H = 64, 48
+    dens = cloud_density(24)
+    scene = nvdb_scene(dens, (24, 24, 24), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5, index_min=(-3, 2, 0), voxel=(0.066, 0.0625, 0.058),
+                       origin=(-0.6, -0.93, -0.5), density_offset=0.02, majorant_scale=1.25, W=W, H=H)
+    prm = P.app_f_params()
+    g = P.Renderer(scene, prm, W, H, seed=3)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
+    yield P, g, c
+    g.close()
+    c.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_nvdb_free_flight_vs_oracle(nvdb_pair, variant):
+    P, g, c = nvdb_pair
+    rng = np.random.default_rng(70 + variant)
+    qs = []
+    for i in range(20000):
+        d = rng.normal(size=3)
+        d = d / np.linalg.norm(d) * rng.uniform(0.5, 2.0)
+        qs.append(P.VspgTmajQuery(P.f3(*rng.uniform(-1, 1, 3)), P.f3(*d), float(rng.uniform(0.0, 3.0)), float(rng.random()),
+                                  float(rng.random()), float(rng.random()), float(rng.random()) if i % 5 else -1.0,
+                                  int(rng.integers(0, 3)), int(rng.integers(0, 4))))
+    go, co = g.sample_tmaj_batch(variant, qs), c.sample_tmaj_batch(variant, qs)
+    ncb = 0
+    for a, b in zip(go, co):
+        assert a.n_callbacks == b.n_callbacks
+        assert list(a.T_maj) == list(b.T_maj) and list(a.r_u_factor) == list(b.r_u_factor) and a.last_t == b.last_t
+        assert a.sum_sigt_over_maj == b.sum_sigt_over_maj and a.vrc == b.vrc and a.majorant_scale == b.majorant_scale
+        ncb += a.n_callbacks
+    assert ncb > 10000
+
+
+def test_nvdb_paths_and_film_vs_oracle(nvdb_pair):
+    P, g, c = nvdb_pair
+    rng = np.random.default_rng(19)
+    n = 20000
+    pix = np.stack([rng.integers(0, g.xres, n), rng.integers(0, g.yres, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    exact = np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)
+    print("nvdb paths: same segments %.5f bit-identical %.5f" % (np.mean(sg == sc), exact.mean()))
+    assert np.mean(sg == sc) == 1.0 and exact.mean() == 1.0
+    for w in range(4):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fg, fc = g.film(), c.film()
+    assert np.array_equal(fg[..., 3], fc[..., 3])
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    relmse = np.mean((ig - ic) ** 2 / (ic ** 2 + 1e-4))
+    print("nvdb film relMSE %.3e" % relmse)
+    assert relmse <= 1e-4
+    cg, cc = g.counters(), c.counters()
+    assert cg["density_queries"] > cg["volume_scatters"]
+    for k in cg:
+        assert abs(cg[k] - cc[k]) <= 2e-3 * cc[k] + 5, (k, cg[k], cc[k])
+
+
+# ---------------------------------------------------------------------------------------------
 # guiding cache query (own design behind the restated GuidedBSDF / GuidedPhaseFunction logic)
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")

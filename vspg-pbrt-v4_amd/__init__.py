@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvspg_hip.so")
 VSPG_MAX_QUADS = 16
 VSPG_ISG_STATS = 8
 
-MEDIUM_NONE, MEDIUM_HOMOGENEOUS, MEDIUM_GRID = 0, 1, 2
+MEDIUM_NONE, MEDIUM_HOMOGENEOUS, MEDIUM_GRID, MEDIUM_NANOVDB = 0, 1, 2, 3
 GUIDE_MIS, GUIDE_RIS = 0, 1
 VSP_CONTRIBUTION, VSP_VARIANCE = 0, 1
 VSP_RESAMPLING, VSP_NDS = 0, 1
@@ -43,7 +43,9 @@ class VspgCamera(C.Structure):
 class VspgMedium(C.Structure):
     _fields_ = [("type", C.c_int32), ("sigma_a", f3), ("sigma_s", f3), ("g", C.c_float),
                 ("Le", f3), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
-                ("bounds_min", f3), ("bounds_max", f3), ("density", C.POINTER(C.c_float))]
+                ("bounds_min", f3), ("bounds_max", f3), ("density", C.POINTER(C.c_float)),
+                ("index_min", C.c_int32 * 3), ("voxel_size", f3), ("grid_origin", f3),
+                ("density_offset", C.c_float), ("majorant_scale", C.c_float)]
 
 
 class VspgScene(C.Structure):
@@ -243,6 +245,22 @@ def cloud_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5
     m.bounds_max[:] = (0.9, 0.8, 0.9)
     m.density = dens.ctypes.data_as(C.POINTER(C.c_float))
     s._density_keepalive = dens
+    return s
+
+
+def nanovdb_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5, density_offset=0.0, majorant_scale=1.0):
+    """Same cloud, handed over as a NanoVDBMedium (dense copy): index bbox [0, n-1]^3, cubic voxels, the world
+    bounding box covers the voxel extents (what cmd/nanovdb2pbrt.cpp reads from the grid); 64^3 majorants."""
+    s = cloud_box_scene(xres, yres, n, sigma_t, albedo, g, seed)
+    m = s.medium
+    m.type = MEDIUM_NANOVDB
+    ext = [m.bounds_max[k] - m.bounds_min[k] for k in range(3)]
+    for k in range(3):
+        m.index_min[k] = 0
+        m.voxel_size[k] = ext[k] / n
+        m.grid_origin[k] = m.bounds_min[k]
+    m.density_offset = density_offset
+    m.majorant_scale = majorant_scale
     return s
 
 

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     // heterogeneous media: the 16^3 majorant grid (16 KB) is staged into LDS once per workgroup with
     // coalesced 16-B loads; every DDA step then reads LDS instead of HBM/L2
     const float *maj_ptr = nullptr;
-    if constexpr (!std::is_same<Medium, HomogeneousMedium>::value) {
+    if constexpr (std::is_same<Medium, GridMedium>::value) {
         __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
         const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
         float4 *dst = reinterpret_cast<float4 *>(s_maj);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const Pool P{s_pool, NP};
 
     const float *maj_ptr = nullptr;
-    if constexpr (!std::is_same<Medium, HomogeneousMedium>::value) {
+    if constexpr (std::is_same<Medium, GridMedium>::value) {
         __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
         const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
         float4 *dst = reinterpret_cast<float4 *>(s_maj);
@@ -972,6 +972,12 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
         D->Le[k] = sc.medium.Le[k];
     }
     D->g = sc.medium.g;
+    for (int k = 0; k < 3; ++k) {
+        D->index_min[k] = sc.medium.index_min[k];
+        D->inv_voxel[k] = sc.medium.type == VSPG_MEDIUM_NANOVDB ? 1.0f / sc.medium.voxel_size[k] : 0.f;
+        D->grid_origin[k] = sc.medium.grid_origin[k];
+    }
+    D->density_offset = sc.medium.density_offset;
     D->nx = sc.medium.nx;
     D->ny = sc.medium.ny;
     D->nz = sc.medium.nz;
@@ -1021,6 +1027,42 @@ static bool wants_guiding(const VspgIntegratorParams &p) {
     return p.surfaceguiding || p.volumeguiding || (p.vspguiding && p.vspsecondaryguiding);
 }
 
+// NanoVDBMedium constructor, "Initialize majorantGrid" (media.cpp:600-671) over the dense copy: 64^3 cells; a
+// cell's majorant is the largest voxel value in the cell's index-space footprint widened by one voxel (the
+// trilinear filter slop), clipped to the index bounding box, then (max + densityOffset) * majorantScale.
+static std::vector<float> build_majorant_grid_nvdb(const VspgMedium &m) {
+    const int R = kMajResNvdb;
+    std::vector<float> maj((size_t)R * R * R);
+    const int imin[3] = {m.index_min[0], m.index_min[1], m.index_min[2]};
+    const int imax[3] = {m.index_min[0] + m.nx - 1, m.index_min[1] + m.ny - 1, m.index_min[2] + m.nz - 1};
+    auto value = [&](int i, int j, int k) -> float {  // accessor.getValue: background outside the tree
+        const int x = i - imin[0], y = j - imin[1], z = k - imin[2];
+        if (x < 0 || y < 0 || z < 0 || x >= m.nx || y >= m.ny || z >= m.nz) return 0.f;
+        return m.density[((size_t)z * m.ny + y) * m.nx + x];
+    };
+    auto lerp = [](float t, float a, float b) { return (1 - t) * a + t * b; };  // pbrt::Lerp (math.h)
+    for (int z = 0; z < R; ++z)
+        for (int y = 0; y < R; ++y)
+            for (int x = 0; x < R; ++x) {
+                const int c[3] = {x, y, z};
+                int lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    const float w0 = lerp((float)c[k] / R, m.bounds_min[k], m.bounds_max[k]);
+                    const float w1 = lerp((float)(c[k] + 1) / R, m.bounds_min[k], m.bounds_max[k]);
+                    const double i0 = ((double)w0 - (double)m.grid_origin[k]) / (double)m.voxel_size[k];  // worldToIndexF(Vec3R)
+                    const double i1 = ((double)w1 - (double)m.grid_origin[k]) / (double)m.voxel_size[k];
+                    const float delta = 1.f;
+                    lo[k] = std::max((int)(i0 - delta), imin[k]);
+                    hi[k] = std::min((int)(i1 + delta), imax[k]);
+                }
+                float mx = 0;
+                for (int kk = lo[2]; kk <= hi[2]; ++kk)
+                    for (int jj = lo[1]; jj <= hi[1]; ++jj)
+                        for (int ii = lo[0]; ii <= hi[0]; ++ii) mx = std::max(mx, value(ii, jj, kk));
+                maj[x + R * (y + R * z)] = (mx + m.density_offset) * m.majorant_scale;
+            }
+    return maj;
+}
 static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const VspgRenderConfig *cfg) {
     if (!scene || !p || !cfg) return fail(VSPG_EINVAL, "null argument");
     if (cfg->xres <= 0 || cfg->yres <= 0) return fail(VSPG_EINVAL, "film resolution must be positive");
@@ -1032,9 +1074,14 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
     if (p->collisionProbabilityBias) return fail(VSPG_ESCOPE, "collisionProbabilityBias (NDS+ / TrBuffer) is outside the hot-path scope");
     if (p->rrguiding) return fail(VSPG_ESCOPE, "rrguiding (guided Russian roulette) is outside the hot-path scope");
-    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+    if (scene->medium.type == VSPG_MEDIUM_GRID || scene->medium.type == VSPG_MEDIUM_NANOVDB) {
         const VspgMedium &m = scene->medium;
         if (m.nx <= 0 || m.ny <= 0 || m.nz <= 0 || !m.density) return fail(VSPG_EINVAL, "grid medium needs nx,ny,nz > 0 and a density array");
+        if (m.type == VSPG_MEDIUM_NANOVDB) {
+            for (int k = 0; k < 3; ++k)
+                if (!(m.voxel_size[k] > 0)) return fail(VSPG_EINVAL, "nanovdb medium needs a positive voxel_size");
+            if (!(m.majorant_scale > 0)) return fail(VSPG_EINVAL, "nanovdb medium needs majorant_scale > 0 (reference default 1)");
+        }
         if ((long long)m.nx * m.ny * m.nz > (1ll << 31)) return fail(VSPG_EINVAL, "density grid too large");
         for (int k = 0; k < 3; ++k)
             if (!(m.bounds_max[k] > m.bounds_min[k])) return fail(VSPG_EINVAL, "grid medium bounds must have positive extent");
@@ -1167,9 +1214,10 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             return fail(VSPG_EHIP, std::string(#expr) + ": " + hipGetErrorName(e2));                              \
         }                                                                                                         \
     } while (0)
-    if (scene->medium.type == VSPG_MEDIUM_GRID) {
+    if (scene->medium.type == VSPG_MEDIUM_GRID || scene->medium.type == VSPG_MEDIUM_NANOVDB) {
         const size_t n = (size_t)scene->medium.nx * scene->medium.ny * scene->medium.nz;
-        std::vector<float> maj = build_majorant_grid(scene->medium);
+        std::vector<float> maj = scene->medium.type == VSPG_MEDIUM_GRID ? build_majorant_grid(scene->medium)
+                                                                        : build_majorant_grid_nvdb(scene->medium);
         CK(hipMalloc(&r->density, n * sizeof(float)));
         CK(hipMemcpy(r->density, scene->medium.density, n * sizeof(float), hipMemcpyHostToDevice));
         CK(hipMalloc(&r->majorant, maj.size() * sizeof(float)));
@@ -1276,6 +1324,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const PcgJump jump = pcg_jump((unsigned long long)first * 65536ull);
     HIPCHK(hipMemsetAsync(r->work_head, 0, sizeof(unsigned int), (hipStream_t)stream));
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
+    const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but the renderer holds no guiding field");
     // a18: while the field trains, the guided kernels record path segments and emit radiance samples
@@ -1300,7 +1349,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     // -- and for guided builds.  VSPG_KERNEL=wg|lane overrides (unguided builds only).
     const char *kenv = getenv("VSPG_KERNEL");
     const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
-    const bool use_wg = !guided && want_wg && !(kenv && strcmp(kenv, "lane") == 0);
+    const bool use_wg = !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0);
     if (use_wg) {
         const unsigned tiles_magic = tilesX > 1 ? (unsigned)((0x100000000ull + (unsigned)tilesX - 1) / (unsigned)tilesX) : 0u;
         const int wwaves = grid ? kWgWavesGrid : kWgWavesHomog, wblock = grid ? kWgBlockGrid : kWgBlockHomog;
@@ -1317,7 +1366,9 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
                                r->work_head, r->counters);
-    } else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
+    } else if (nvdb && guided) VSPG_LAUNCH_RENDER(NanoDenseMedium, true);
+    else if (nvdb) VSPG_LAUNCH_RENDER(NanoDenseMedium, false);
+    else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
     else if (grid) VSPG_LAUNCH_RENDER(GridMedium, false);
     else if (guided) VSPG_LAUNCH_RENDER(HomogeneousMedium, true);
     else VSPG_LAUNCH_RENDER(HomogeneousMedium, false);
@@ -1472,7 +1523,10 @@ int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy, const int3
 #define VSPG_LAUNCH_TRACE(M, G)                                                                                       \
     hipLaunchKernelGGL((k_trace_paths<M, G>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp, \
                        r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p)
-    if (grid && guided) VSPG_LAUNCH_TRACE(GridMedium, true);
+    const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
+    if (nvdb && guided) VSPG_LAUNCH_TRACE(NanoDenseMedium, true);
+    else if (nvdb) VSPG_LAUNCH_TRACE(NanoDenseMedium, false);
+    else if (grid && guided) VSPG_LAUNCH_TRACE(GridMedium, true);
     else if (grid) VSPG_LAUNCH_TRACE(GridMedium, false);
     else if (guided) VSPG_LAUNCH_TRACE(HomogeneousMedium, true);
     else VSPG_LAUNCH_TRACE(HomogeneousMedium, false);
@@ -1497,7 +1551,10 @@ int vspg_sample_tmaj_batch(VspgRenderer *r, int variant, int n, const VspgTmajQu
     HIPCHK(hipMalloc(&dq.p, (size_t)n * sizeof(VspgTmajQuery)));
     HIPCHK(hipMalloc(&dr.p, (size_t)n * sizeof(VspgTmajResult)));
     HIPCHK(hipMemcpyAsync(dq.p, q, (size_t)n * sizeof(VspgTmajQuery), hipMemcpyHostToDevice, s));
-    if (r->scene.medium.type == VSPG_MEDIUM_GRID)
+    if (r->scene.medium.type == VSPG_MEDIUM_NANOVDB)
+        hipLaunchKernelGGL(k_tmaj_batch<NanoDenseMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, variant, n,
+                           (const VspgTmajQuery *)dq.p, (VspgTmajResult *)dr.p);
+    else if (r->scene.medium.type == VSPG_MEDIUM_GRID)
         hipLaunchKernelGGL(k_tmaj_batch<GridMedium>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, variant, n,
                            (const VspgTmajQuery *)dq.p, (VspgTmajResult *)dr.p);
     else

@@ -473,6 +473,9 @@ struct DScene {
     float bounds_min[3], bounds_max[3];
     const float *density;
     const float *majorant;
+    // NanoVDB-semantics dense medium: index bbox min, 1 / voxel_size, world position of index (0,0,0), density offset
+    int32_t index_min[3];
+    float inv_voxel[3], grid_origin[3], density_offset;
     // integrator parameters
     VspgIntegratorParams prm;
     // render config
@@ -669,16 +672,26 @@ VDEV HomogeneousMedium make_homogeneous(const DScene &) { return HomogeneousMedi
 // identity renderFromMedium.  Per-axis DDA state is kept in named registers and selected with
 // compares (runtime-indexed private arrays would live in scratch).
 // ---------------------------------------------------------------------------------------
-constexpr int kMajRes = 16;  // media.cpp:252
+constexpr int kMajRes = 16;      // GridMedium majorant grid (media.cpp:252)
+constexpr int kMajResNvdb = 64;  // NanoVDBMedium majorant grid (media.cpp:574)
 VDEV float sel3(float a0, float a1, float a2, int axis) { return axis == 0 ? a0 : (axis == 1 ? a1 : a2); }
 VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis == 1 ? a1 : a2); }
-struct GridMedium {
+// NVDB = false: GridMedium ("uniformgrid").  NVDB = true: NanoVDBMedium semantics over a dense copy of the
+// grid (media.h:686-719): index-space trilinear sampling a + w (b - a) with background 0 outside the index
+// bounding box, "densityoffset", 64^3 majorants read from HBM / L2 (1 MB: too large for LDS).  The sparse
+// NanoVDB tree and its sampler are absent from the reference tree: parity unpinned for the fetch itself.
+template <bool NVDB>
+struct GridMediumT {
+    static constexpr int kRes = NVDB ? kMajResNvdb : kMajRes;
     Spec sigma_a, sigma_s;
     float g;
     int nx, ny, nz;
     V3 bmin, bmax;
     const float *density;
     const float *majorant;  // HBM or the block's LDS copy
+    int imx, imy, imz;      // NVDB: index bbox min
+    V3 inv_voxel, origin;   // NVDB: worldToIndexF(p) = (p - origin) * inv_voxel
+    float density_offset;   // NVDB
 
     struct Iter {  // DDAMajorantIterator
         Spec sigma_t;
@@ -694,14 +707,14 @@ struct GridMedium {
             int stepAxis = (0xA66 >> (2 * bits)) & 3;  // cmpToAxis[8] = {2,1,2,1,2,2,0,0}
             float nc = sel3(ncx, ncy, ncz, stepAxis);
             float tVoxelExit = fmin_(tMax, nc);
-            float md = maj[vx + kMajRes * (vy + kMajRes * vz)];
+            float md = maj[vx + kRes * (vy + kRes * vz)];
             s->tMin = tMin;
             s->tMax = tVoxelExit;
             s->sigma_maj = sigma_t * md;
             tMin = tVoxelExit;
             if (nc > tMax) tMin = tMax;
             int st = ((neg >> stepAxis) & 1) ? -1 : 1;
-            int lim = ((neg >> stepAxis) & 1) ? -1 : kMajRes;
+            int lim = ((neg >> stepAxis) & 1) ? -1 : kRes;
             int v = sel3i(vx, vy, vz, stepAxis) + st;
             if (v == lim) tMin = tMax;
             float ncn = nc + sel3(dtx, dty, dtz, stepAxis);
@@ -789,15 +802,15 @@ struct GridMedium {
         V3 gd = V3{d.x / diag.x, d.y / diag.y, d.z / diag.z};
         V3 gi = go + gd * t0;
         auto axis_setup = [&](float gia, float gda, int bit, int *voxel, float *deltaT, float *nextT) {
-            float v = gia * kMajRes;
-            *voxel = (int)(v < 0 ? 0.f : (v > (float)(kMajRes - 1) ? (float)(kMajRes - 1) : v));
-            *deltaT = 1 / (__builtin_fabsf(gda) * kMajRes);
+            float v = gia * kRes;
+            *voxel = (int)(v < 0 ? 0.f : (v > (float)(kRes - 1) ? (float)(kRes - 1) : v));
+            *deltaT = 1 / (__builtin_fabsf(gda) * kRes);
             if (gda == -0.f) gda = 0.f;
             if (gda >= 0) {
-                float nextVoxelPos = (float)(*voxel + 1) / kMajRes;
+                float nextVoxelPos = (float)(*voxel + 1) / kRes;
                 *nextT = t0 + (nextVoxelPos - gia) / gda;
             } else {
-                float nextVoxelPos = (float)(*voxel) / kMajRes;
+                float nextVoxelPos = (float)(*voxel) / kRes;
                 *nextT = t0 + (nextVoxelPos - gia) / gda;
                 it.neg |= bit;
             }
@@ -807,8 +820,34 @@ struct GridMedium {
         axis_setup(gi.z, gd.z, 4, &it.vz, &it.dtz, &it.ncz);
         return it;
     }
-    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 (no emission grids in scope)
-        float d = lookup(offset(p));
+    // nanovdb::SampleFromVoxels<Tree, 1, false> over the dense copy: ijk = floor(x), uvw = x - ijk, corner values
+    // with background 0, lerp(a, b, w) = a + w (b - a) along z, then y, then x
+    VDEV float at_index(int i, int j, int k) const {
+        const int x = i - imx, y = j - imy, z = k - imz;
+        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
+        return density[((size_t)z * ny + y) * nx + x];
+    }
+    VDEV float lookup_index(V3 x) const {
+        const float fx = __builtin_floorf(x.x), fy = __builtin_floorf(x.y), fz = __builtin_floorf(x.z);
+        const int i = (int)fx, j = (int)fy, k = (int)fz;
+        const float u = x.x - fx, v = x.y - fy, w = x.z - fz;
+        const float v000 = at_index(i, j, k), v001 = at_index(i, j, k + 1), v010 = at_index(i, j + 1, k), v011 = at_index(i, j + 1, k + 1);
+        const float v100 = at_index(i + 1, j, k), v101 = at_index(i + 1, j, k + 1), v110 = at_index(i + 1, j + 1, k),
+                    v111 = at_index(i + 1, j + 1, k + 1);
+        const float a00 = v000 + w * (v001 - v000), a01 = v010 + w * (v011 - v010);
+        const float a10 = v100 + w * (v101 - v100), a11 = v110 + w * (v111 - v110);
+        const float b0 = a00 + v * (a01 - a00), b1 = a10 + v * (a11 - a10);
+        return b0 + u * (b1 - b0);
+    }
+    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703 (no emission grids in scope)
+        float d;
+        if constexpr (NVDB) {
+            const V3 xi = V3{(p.x - origin.x) * inv_voxel.x, (p.y - origin.y) * inv_voxel.y, (p.z - origin.z) * inv_voxel.z};
+            d = lookup_index(xi);
+            d += density_offset;
+        } else {
+            d = lookup(offset(p));
+        }
         Spec sa = sigma_a * d, ss = sigma_s * d;
         return MediumProps{sa, ss, sp(0.f), g, ss + sa};
     }
@@ -817,16 +856,20 @@ struct GridMedium {
     static constexpr bool kSingleSegment = false;
     static constexpr bool kAlwaysRealCollision = false;
 };
-VDEV GridMedium make_grid(const DScene &S, const float *majorant) {
-    return GridMedium{lds(S.sigma_a), lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
-                      majorant};
+using GridMedium = GridMediumT<false>;
+using NanoDenseMedium = GridMediumT<true>;
+template <bool NVDB>
+VDEV GridMediumT<NVDB> make_grid(const DScene &S, const float *majorant) {
+    return GridMediumT<NVDB>{lds(S.sigma_a), lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
+                             majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
+                             S.density_offset};
 }
 template <class M> struct MediumMaker;
 template <> struct MediumMaker<HomogeneousMedium> {
     static VDEV HomogeneousMedium make(const DScene &S, const float *) { return make_homogeneous(S); }
 };
-template <> struct MediumMaker<GridMedium> {
-    static VDEV GridMedium make(const DScene &S, const float *majorant) { return make_grid(S, majorant); }
+template <bool NVDB> struct MediumMaker<GridMediumT<NVDB>> {
+    static VDEV GridMediumT<NVDB> make(const DScene &S, const float *majorant) { return make_grid<NVDB>(S, majorant ? majorant : S.majorant); }
 };
 
 // ---------------------------------------------------------------------------------------
