@@ -50,6 +50,27 @@ int main() {
     // out-of-scope options are refused loudly, before any device work
     CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("rrguiding", true), scene, 16, 16, 1); }));
     CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("collisionProbabilityBias", true), scene, 16, 16, 1); }));
+    // the reference's parameter-list text (what cmd/nanovdb2pbrt prints for a grid) -> GridMedium::Create
+    {
+        const char *txt = "  \"integer nx\" 2 \"integer ny\" [ 3 ] \"integer nz\" 1   # comment\n"
+                          "\"point3 p0\" [ -1 -0.5 0 ] \"point3 p1\" [ 1 0.5 2 ]\n"
+                          "\"rgb sigma_a\" [ .1 .2 .3 ] \"rgb sigma_s\" [ 1 2 3 ] \"float scale\" 2 \"float g\" [ 0.25 ]\n"
+                          "\"float density\" [ 0 0.5 1\n 1.5 2 2.5 ]";
+        std::vector<float> storage;
+        VspgMedium gm = CreateMedium("uniformgrid", ParameterDictionary::Parse(txt), &storage);
+        CHECK(gm.type == VSPG_MEDIUM_GRID && gm.nx == 2 && gm.ny == 3 && gm.nz == 1);
+        CHECK(gm.bounds_min[1] == -0.5f && gm.bounds_max[2] == 2.f && gm.g == 0.25f);
+        CHECK(gm.sigma_a[2] == 0.6f && gm.sigma_s[0] == 2.f);
+        CHECK(storage.size() == 6 && gm.density == storage.data() && storage[5] == 2.5f);
+        CHECK(throws([&] { std::vector<float> st; CreateMedium("uniformgrid", ParameterDictionary::Parse("\"integer nx\" 2 \"float density\" [1 2 3]"), &st); }));  // count mismatch
+        CHECK(throws([&] { std::vector<float> st; CreateMedium("uniformgrid", ParameterDictionary::Parse("\"integer nx\" 1"), &st); }));  // no density
+        CHECK(throws([&] { std::vector<float> st; CreateMedium("uniformgrid", ParameterDictionary::Parse("\"float density\" 1 \"float temperature\" 300"), &st); }));
+        CHECK(throws([] { ParameterDictionary::Parse("\"spectrum sigma_a\" \"metal-Au-eta\""); }));   // type outside scope
+        CHECK(throws([] { ParameterDictionary::Parse("\"float g\" [ 0.5"); }));                        // missing ]
+        ParameterDictionary pd = ParameterDictionary::Parse("\"bool usenee\" false \"string lightsampler\" \"uniform\" \"integer maxdepth\" 7");
+        VspgIntegratorParams ip = ParseIntegratorParams(pd);
+        CHECK(ip.usenee == 0 && ip.lightsampler == VSPG_LIGHTSAMPLER_UNIFORM && ip.maxdepth == 7);
+    }
     // guiding-cache file round trip (Field::Store / Field(file)) and its parameters
     {
         GuidingCache gc;

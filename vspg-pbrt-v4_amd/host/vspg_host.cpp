@@ -1,6 +1,8 @@
 #include "vspg_host.h"
 
+#include <cctype>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -13,6 +15,80 @@ ParameterDictionary &ParameterDictionary::Float(const std::string &n, float v) {
 ParameterDictionary &ParameterDictionary::Bool(const std::string &n, bool v) { Value x; x.type = 'b'; x.i = v; values[n] = x; return *this; }
 ParameterDictionary &ParameterDictionary::String(const std::string &n, const std::string &v) { Value x; x.type = 's'; x.s = v; values[n] = x; return *this; }
 ParameterDictionary &ParameterDictionary::RGB(const std::string &n, float r, float g, float b) { Value x; x.type = 'c'; x.f[0] = r; x.f[1] = g; x.f[2] = b; values[n] = x; return *this; }
+
+ParameterDictionary &ParameterDictionary::Point3(const std::string &n, float x, float y, float z) { Value v; v.type = 'p'; v.f[0] = x; v.f[1] = y; v.f[2] = z; values[n] = v; return *this; }
+ParameterDictionary &ParameterDictionary::FloatArray(const std::string &n, std::vector<float> a) { Value v; v.type = 'a'; v.arr = std::move(a); values[n] = v; return *this; }
+
+ParameterDictionary ParameterDictionary::Parse(const std::string &text) {
+    ParameterDictionary d;
+    size_t i = 0;
+    const size_t n = text.size();
+    auto skip = [&] {
+        while (i < n) {
+            if (std::isspace((unsigned char)text[i])) ++i;
+            else if (text[i] == '#') { while (i < n && text[i] != '\n') ++i; }
+            else break;
+        }
+    };
+    auto quoted = [&]() -> std::string {
+        if (i >= n || text[i] != '"') throw Error("parameter list: expected a quoted string at offset " + std::to_string(i));
+        size_t j = text.find('"', i + 1);
+        if (j == std::string::npos) throw Error("parameter list: unterminated string");
+        std::string r = text.substr(i + 1, j - i - 1);
+        i = j + 1;
+        return r;
+    };
+    for (skip(); i < n; skip()) {
+        const std::string decl = quoted();
+        const size_t sp = decl.find_first_of(" \t");
+        if (sp == std::string::npos) throw Error("parameter list: \"" + decl + "\" is not \"type name\"");
+        const std::string type = decl.substr(0, sp), name = decl.substr(decl.find_first_not_of(" \t", sp));
+        skip();
+        const bool bracket = i < n && text[i] == '[';
+        if (bracket) ++i;
+        std::vector<std::string> toks;
+        while (true) {
+            skip();
+            if (i >= n) { if (bracket) throw Error("parameter list: missing ]"); break; }
+            if (text[i] == ']') { if (!bracket) throw Error("parameter list: stray ]"); ++i; break; }
+            if (text[i] == '"') {
+                if (!bracket && !toks.empty()) break;  // next declaration
+                toks.push_back(quoted());
+            } else {
+                size_t j = i;
+                while (j < n && !std::isspace((unsigned char)text[j]) && text[j] != ']' && text[j] != '"') ++j;
+                toks.push_back(text.substr(i, j - i));
+                i = j;
+            }
+            if (!bracket) break;
+        }
+        if (toks.empty()) throw Error("parameter \"" + name + "\" has no value");
+        auto num = [&](const std::string &t) -> float {
+            char *end = nullptr;
+            float v = std::strtof(t.c_str(), &end);
+            if (end == t.c_str() || *end) throw Error("parameter \"" + name + "\": \"" + t + "\" is not a number");
+            return v;
+        };
+        if (type == "integer") {
+            if (toks.size() != 1) throw Error("parameter \"" + name + "\": integer arrays are outside this build's scope");
+            d.Int(name, (int)std::strtol(toks[0].c_str(), nullptr, 10));
+        } else if (type == "float") {
+            if (toks.size() == 1) d.Float(name, num(toks[0]));
+            else { std::vector<float> a; for (auto &t : toks) a.push_back(num(t)); d.FloatArray(name, std::move(a)); }
+        } else if (type == "bool") {
+            if (toks[0] != "true" && toks[0] != "false") throw Error("parameter \"" + name + "\": bool must be true or false");
+            d.Bool(name, toks[0] == "true");
+        } else if (type == "string") {
+            d.String(name, toks[0]);
+        } else if (type == "rgb" || type == "point3") {
+            if (toks.size() != 3) throw Error("parameter \"" + name + "\": " + type + " needs three values");
+            if (type == "rgb") d.RGB(name, num(toks[0]), num(toks[1]), num(toks[2]));
+            else d.Point3(name, num(toks[0]), num(toks[1]), num(toks[2]));
+        } else
+            throw Error("parameter \"" + name + "\": type \"" + type + "\" is outside this build's scope");
+    }
+    return d;
+}
 
 const ParameterDictionary::Value *ParameterDictionary::find(const std::string &n, char type) const {
     auto it = values.find(n);
@@ -32,17 +108,70 @@ bool ParameterDictionary::GetOneRGB(const std::string &n, float rgb[3]) const {
     rgb[0] = v->f[0]; rgb[1] = v->f[1]; rgb[2] = v->f[2];
     return true;
 }
+bool ParameterDictionary::GetOnePoint3(const std::string &n, float p[3]) const {
+    auto v = find(n, 'p');
+    if (!v) return false;
+    p[0] = v->f[0]; p[1] = v->f[1]; p[2] = v->f[2];
+    return true;
+}
+std::vector<float> ParameterDictionary::GetFloatArray(const std::string &n) const {
+    auto it = values.find(n);
+    if (it == values.end()) return {};
+    if (it->second.type == 'f') { it->second.lookedUp = true; return {it->second.f[0]}; }
+    auto v = find(n, 'a');
+    return v->arr;
+}
 void ParameterDictionary::ReportUnused() const {
     for (const auto &kv : values)
         if (!kv.second.lookedUp) throw Error("\"" + kv.first + "\": unused parameter.");
 }
 
 // ---------------------------------------------------------------------------------------
-VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p) {
+static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<float> *densityStorage) {
+    // GridMedium::Create (media.cpp:272-361)
     VspgMedium m;
     std::memset(&m, 0, sizeof m);
+    std::vector<float> density = p.GetFloatArray("density");
+    std::vector<float> temperature = p.GetFloatArray("temperature");
+    if (density.empty()) throw Error("No \"density\" value provided for grid medium.");
+    if (!temperature.empty()) throw Error("grid medium \"temperature\" (emissive grids) is outside this build's scope");
+    const int nx = p.GetOneInt("nx", 1), ny = p.GetOneInt("ny", 1), nz = p.GetOneInt("nz", 1);
+    if ((long long)density.size() != (long long)nx * ny * nz)
+        throw Error("Grid medium has " + std::to_string(density.size()) + " density values; expected nx*ny*nz = " +
+                    std::to_string((long long)nx * ny * nz));
+    float le[3];
+    if (p.GetOneRGB("Le", le) || !p.GetFloatArray("Lescale").empty()) throw Error("grid medium \"Le\" / \"Lescale\" are outside this build's scope");
+    float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {1.f, 1.f, 1.f};
+    p.GetOnePoint3("p0", p0);
+    p.GetOnePoint3("p1", p1);
+    const float g = p.GetOneFloat("g", 0.f);
+    if (!p.GetOneString("preset", "").empty()) throw Error("medium \"preset\" tables are outside this build's scope");
+    float sa[3] = {1.f, 1.f, 1.f}, ss[3] = {1.f, 1.f, 1.f};
+    p.GetOneRGB("sigma_a", sa);
+    p.GetOneRGB("sigma_s", ss);
+    const float sigmaScale = p.GetOneFloat("scale", 1.f);
+    p.ReportUnused();
+    if (!densityStorage) throw Error("CreateMedium(\"uniformgrid\") needs a densityStorage vector to own the grid");
+    *densityStorage = std::move(density);
+    m.type = VSPG_MEDIUM_GRID;
+    for (int i = 0; i < 3; ++i) {
+        m.sigma_a[i] = sa[i] * sigmaScale;
+        m.sigma_s[i] = ss[i] * sigmaScale;
+        m.bounds_min[i] = p0[i];
+        m.bounds_max[i] = p1[i];
+    }
+    m.g = g;
+    m.nx = nx; m.ny = ny; m.nz = nz;
+    m.density = densityStorage->data();
+    return m;
+}
+
+VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p, std::vector<float> *densityStorage) {
+    VspgMedium m;
+    std::memset(&m, 0, sizeof m);
+    if (name == "uniformgrid") return CreateGridMedium(p, densityStorage);
     if (name != "homogeneous")
-        throw Error("medium \"" + name + "\": only \"homogeneous\" is inside this build's scope");
+        throw Error("medium \"" + name + "\": only \"homogeneous\" and \"uniformgrid\" are inside this build's scope");
     // HomogeneousMedium::Create (media.cpp:167-206)
     if (!p.GetOneString("preset", "").empty()) throw Error("medium \"preset\" tables are outside this build's scope");
     float sa[3] = {1.f, 1.f, 1.f}, ss[3] = {1.f, 1.f, 1.f}, le[3] = {0, 0, 0};  // defaults: ConstantSpectrum(1)

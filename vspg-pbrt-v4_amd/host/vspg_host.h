@@ -33,6 +33,13 @@ class ParameterDictionary {
     ParameterDictionary &Bool(const std::string &n, bool v);
     ParameterDictionary &String(const std::string &n, const std::string &v);
     ParameterDictionary &RGB(const std::string &n, float r, float g, float b);
+    ParameterDictionary &Point3(const std::string &n, float x, float y, float z);
+    ParameterDictionary &FloatArray(const std::string &n, std::vector<float> v);
+    // The reference's scene-file parameter-list syntax ("type name" value | [ values ]), e.g. the block
+    // cmd/nanovdb2pbrt.cpp:97-126 prints for a grid:
+    //   "integer nx" 64 "integer ny" 64 "integer nz" 32 "point3 p0" [ -1 -1 0 ] "point3 p1" [ 1 1 1 ] "float density" [ ... ]
+    // Types: integer, float (one value -> Float, several -> FloatArray), bool, string, rgb, point3.
+    static ParameterDictionary Parse(const std::string &text);
 
     int GetOneInt(const std::string &n, int def) const;
     float GetOneFloat(const std::string &n, float def) const;
@@ -40,23 +47,29 @@ class ParameterDictionary {
     std::string GetOneString(const std::string &n, const std::string &def) const;
     // returns false if absent
     bool GetOneRGB(const std::string &n, float rgb[3]) const;
+    bool GetOnePoint3(const std::string &n, float p[3]) const;
+    std::vector<float> GetFloatArray(const std::string &n) const;  // a single "float" value is a 1-element array
     // paramdict.cpp:642-664: any parameter that was never looked up is a fatal error
     void ReportUnused() const;
 
   private:
     struct Value {
-        char type;  // i f b s c
+        char type;  // i f b s c p a(rray)
         int i = 0;
         float f[3] = {0, 0, 0};
         std::string s;
+        std::vector<float> arr;
         mutable bool lookedUp = false;
     };
     const Value *find(const std::string &n, char type) const;
     std::map<std::string, Value> values;
 };
 
-// Medium::Create("homogeneous", ...) (media.cpp:816-841; other names -> Error: outside scope)
-VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &parameters);
+// Medium::Create (media.cpp:816-841): "homogeneous" (HomogeneousMedium::Create :167-206) and "uniformgrid"
+// (GridMedium::Create :272-361; the density array is copied into *densityStorage, which must outlive the
+// renderer creation -- VspgMedium.density points into it); other names -> Error: outside scope
+VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &parameters,
+                        std::vector<float> *densityStorage = nullptr);
 
 struct Film {
     int xres = 0, yres = 0;
