@@ -270,6 +270,37 @@ def test_ragged_resolutions_film_equals_replayed_paths(gpu_pkg, W, H):
             os.environ.pop("VSPG_KERNEL", None)
 
 
+def test_grey_specialisations_are_bit_identical(gpu_pkg):
+    """The workgroup kernel has three instantiations for homogeneous media: generic, grey medium (medium spectra
+    built from one value) and grey scene (surface reflectances and the throughput too).  Same film, bit for bit --
+    also for a scene where only the medium is grey (one wall coloured), which must pick the middle one."""
+    P = gpu_pkg
+    W, H = 96, 64
+    films = []
+    for coloured_wall in (False, True):
+        scene = P.fog_box_scene(W, H)
+        if coloured_wall:
+            scene.quads[1].Kd[0], scene.quads[1].Kd[1], scene.quads[1].Kd[2] = 0.63, 0.065, 0.05
+        ref = None
+        for env in ({"VSPG_NO_GREY": "1"}, {"VSPG_NO_GREY_KD": "1"}, {}):
+            os.environ.update(env)
+            try:
+                r = P.Renderer(scene, P.app_f_params(), W, H, seed=5)
+                for w in range(3):
+                    r.render_wave(w, w + 1)
+                    r.post_process_wave()
+                f = r.film()
+                r.close()
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            if ref is None:
+                ref = f
+            assert np.array_equal(ref.view(np.uint32), f.view(np.uint32)), (coloured_wall, env)
+        films.append(ref)
+    assert not np.array_equal(films[0], films[1])
+
+
 def test_full_size_wave_properties(gpu_pkg):
     """BASELINE size (1920x1080): size-independent properties of one wave -- every pixel got exactly one
     sample, path / segment counters are consistent, 20 000 random pixels equal their replayed paths bit

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                         alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                           isg, pc, vx);
                         if (alive) {
-                            pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
+                            pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
                             pool_store_vertex(P, slot, vx);
                         }
                     } else {
@@ -564,12 +564,12 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                     }
                 } else {
                     slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
-                    const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
+                    const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
                     pxy = P.i(PF_PIXEL, slot);
                     const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
                     alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                         isg, pc, vx);
-                    if (alive) pool_store_a(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                    if (alive) pool_store_a<Medium::kGrey>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
                 }
                 if (alive) {
                     toV = vx.volume;
@@ -610,10 +610,10 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 PathState st;
                 IsgSample isg;
                 int ch;
-                const uint32_t fl = pool_load<GUIDED>(P, slot, S, st, sampler, &ch, isg);
+                const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
                 const Vertex vx = pool_load_vertex(P, slot, fl);
                 if (li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock)) {
-                    pool_store_full<GUIDED>(P, slot, st, sampler, ch, isg, FL_LIVE);
+                    pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE);
                     cont = true;
                 } else {
                     const int pxy = P.i(PF_PIXEL, slot);
@@ -849,6 +849,8 @@ struct VspgRenderer {
     VspgKdNode *fnodes[2] = {nullptr, nullptr};        // guiding fields (device copies)
     VspgFieldRegion *fregions[2] = {nullptr, nullptr};
     bool field_set = false;
+    bool medium_grey = false;   // homogeneous medium with bitwise-grey sigma_a, sigma_s, Le
+    bool surfaces_grey = false; // every rectangle's (clamped) Kd bitwise grey
     // a18: on-device training of the guiding field
     bool training = false;
     int field_iteration = 0;
@@ -1205,6 +1207,13 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     r->cfg = *cfg;
     if (r->cfg.shard_count < 1) { r->cfg.shard_count = 1; r->cfg.shard_index = 0; }
     build_dscene(r->scene, r->prm, r->cfg, &r->hscene);
+    {
+        auto same = [](const float *v) { return std::memcmp(&v[0], &v[1], 4) == 0 && std::memcmp(&v[1], &v[2], 4) == 0; };
+        const VspgMedium &m = r->scene.medium;
+        r->medium_grey = m.type == VSPG_MEDIUM_HOMOGENEOUS && same(m.sigma_a) && same(m.sigma_s) && same(m.Le) && !getenv("VSPG_NO_GREY");
+        r->surfaces_grey = !getenv("VSPG_NO_GREY_KD");
+        for (int i = 0; i < r->hscene.n_quads; ++i) r->surfaces_grey = r->surfaces_grey && same(r->hscene.quads[i].Kd);
+    }
     r->npix = (size_t)cfg->xres * cfg->yres;
 #define CK(expr)                                                                                                  \
     do {                                                                                                          \
@@ -1359,6 +1368,16 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         if (grid)
             hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
+                               r->work_head, r->counters);
+        else if (r->medium_grey && r->surfaces_grey)  // ... and every Kd bitwise grey: beta is grey by construction too
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreyScene, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
+                               r->work_head, r->counters);
+        else if (r->medium_grey)  // sigma_a, sigma_s, Le bitwise grey: the broadcast-spectrum instantiation
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGrey, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
                                r->work_head, r->counters);
         else

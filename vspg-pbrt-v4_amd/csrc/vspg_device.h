@@ -125,7 +125,9 @@ VDEV Spec operator*(Spec a, Spec b) { return Spec{a.r * b.r, a.g * b.g, a.b * b.
 // usual case for fog / white walls: beta, r_u, r_l, T_maj, sigma_*), one channel is computed and
 // copied: identical results, a third of the work.  The test is wave-uniform (__all), so it is a
 // scalar branch, never divergence.
-VDEV bool grey(Spec a) { return a.r == a.g && a.g == a.b; }
+// (bitwise equality: a spectrum built as {x, x, x} from ONE value is grey at compile time -- see
+// HomogeneousMediumT<true> -- and (0, -0, 0), whose channels would differ in sign after a division, is not.)
+VDEV bool grey(Spec a) { return __float_as_uint(a.r) == __float_as_uint(a.g) && __float_as_uint(a.g) == __float_as_uint(a.b); }
 VDEV Spec operator/(Spec a, Spec b) {
     if (__all(grey(a) && grey(b))) {
         float q = a.r / b.r;
@@ -638,9 +640,25 @@ struct MajSeg {
     Spec sigma_maj;
 };
 // HomogeneousMedium (media.h:221-283): one segment [0,tMax], sigma_maj = sigma_a + sigma_s
-struct HomogeneousMedium {
+// GREY = true is chosen by the host when sigma_a, sigma_s and Le are bitwise grey (fog): every medium
+// spectrum is then built as {x, x, x} from ONE loaded value, so the compiler sees the three channels of
+// sigma_maj, T_maj, sigma_n, r_u, r_l ... as the same value and all per-channel arithmetic on them -- IEEE
+// divisions and FastExp included -- collapses to one channel by common-subexpression elimination, without a
+// different spectrum type.  Same operations on the same bits per channel: results unchanged.
+// GREY = 2 additionally promises that every rectangle's Kd is bitwise grey: the BSDF's reflectance is built
+// the same way and the path throughput beta (only ever multiplied by grey medium terms, grey BSDF weights and
+// scalars) is grey by construction too.
+template <int GREY>
+struct HomogeneousMediumT {
+    static constexpr int kGrey = GREY;   // 0 none, 1 medium spectra, 2 medium spectra + surface reflectances
     // constants live in the workgroup's LDS copy (s_scene_medium, staged by stage_scene_lds)
-    static VDEV Spec m3(int o) { return Spec{s_scene_medium[o], s_scene_medium[o + 1], s_scene_medium[o + 2]}; }
+    static VDEV Spec m3(int o) {
+        if constexpr (GREY) {
+            const float x = s_scene_medium[o];
+            return Spec{x, x, x};
+        }
+        return Spec{s_scene_medium[o], s_scene_medium[o + 1], s_scene_medium[o + 2]};
+    }
     struct Iter {  // HomogeneousMajorantIterator (media.h:84-106)
         MajSeg seg;
         bool called;
@@ -665,7 +683,9 @@ struct HomogeneousMedium {
     // distance-sampling walk is always a real one (no null collisions in a homogeneous medium).
     static constexpr bool kAlwaysRealCollision = true;
 };
-VDEV HomogeneousMedium make_homogeneous(const DScene &) { return HomogeneousMedium{}; }
+using HomogeneousMedium = HomogeneousMediumT<0>;
+using HomogeneousMediumGrey = HomogeneousMediumT<1>;
+using HomogeneousMediumGreyScene = HomogeneousMediumT<2>;
 
 // ---------------------------------------------------------------------------------------
 // a6: GridMedium (media.h:284-390) with the 3-D DDA majorant iterator (media.h:140-218),
@@ -683,6 +703,7 @@ VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis
 template <bool NVDB>
 struct GridMediumT {
     static constexpr int kRes = NVDB ? kMajResNvdb : kMajRes;
+    static constexpr int kGrey = 0;
     Spec sigma_a, sigma_s;
     float g;
     int nx, ny, nz;
@@ -865,8 +886,8 @@ VDEV GridMediumT<NVDB> make_grid(const DScene &S, const float *majorant) {
                              S.density_offset};
 }
 template <class M> struct MediumMaker;
-template <> struct MediumMaker<HomogeneousMedium> {
-    static VDEV HomogeneousMedium make(const DScene &S, const float *) { return make_homogeneous(S); }
+template <int GREY> struct MediumMaker<HomogeneousMediumT<GREY>> {
+    static VDEV HomogeneousMediumT<GREY> make(const DScene &, const float *) { return HomogeneousMediumT<GREY>{}; }
 };
 template <bool NVDB> struct MediumMaker<GridMediumT<NVDB>> {
     static VDEV GridMediumT<NVDB> make(const DScene &S, const float *majorant) { return make_grid<NVDB>(S, majorant ? majorant : S.majorant); }

@@ -15,12 +15,13 @@ struct Bsdf {
     Spec R;
     bool has_lobes;
 };
+template <bool GREY_KD = false>
 VDEV Bsdf bsdf_make(const DQuad &q) {
     Bsdf b;
     b.frame.x = ld3(q.dpdu_n);
     b.frame.z = ld3(q.n);
     b.frame.y = cross(b.frame.z, b.frame.x);
-    b.R = lds(q.Kd);
+    b.R = GREY_KD ? sp(q.Kd[0]) : lds(q.Kd);
     b.has_lobes = q.has_lobes != 0;
     return b;
 }
@@ -635,6 +636,7 @@ struct VertexCtx {
     Intr intr;
     Bsdf bsdf;
 };
+template <bool GREY_KD = false>
 VDEV void vertex_setup(const PathState &st, const Vertex &vx, VertexCtx &c) {
     Isect &si = c.si;
     Intr &intr = c.intr;
@@ -658,7 +660,7 @@ VDEV void vertex_setup(const PathState &st, const Vertex &vx, VertexCtx &c) {
     } else {
         const DQuad &q = quad_at(vx.quad);
         si.n = ld3(q.n);
-        bsdf = bsdf_make(q);
+        bsdf = bsdf_make<GREY_KD>(q);
         intr.is_surface = true;
         intr.pi = p3i_from_err(si.p, ld3(q.perr));
         intr.n = si.n;
@@ -762,7 +764,7 @@ template <class Medium, bool GUIDED = false, class PC>
 VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                        const Vertex &vx, float *glds = nullptr, int gstride = 0) {
     VertexCtx c;
-    vertex_setup(st, vx, c);
+    vertex_setup<(Medium::kGrey >= 2)>(st, vx, c);
     if constexpr (GUIDED)
         return li_vertex_guided<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, glds, gstride);
     const float survivalProb = vertex_pre(S, st, sampler, vx);

@@ -88,15 +88,31 @@ VDEV void pool_store_rng(const Pool &P, int slot, const Sampler &sampler) {
 }
 
 // everything a path carries into its next segment (after the primary segment and after a vertex)
-template <bool GUIDED>
+// GREY (grey medium, see HomogeneousMediumT): r_u and r_l are grey by construction -- one channel is parked
+// and broadcast on load, which also tells the compiler that the three channels are one value
+template <int GREY>
+VDEV void pool_store_beta(const Pool &P, int slot, const PathState &st) {
+    if constexpr (GREY >= 2) P.f(PF_BETA, slot) = st.beta.r;
+    else P.sets(PF_BETA, slot, st.beta);
+}
+template <int GREY>
+VDEV void pool_store_ru_rl(const Pool &P, int slot, const PathState &st) {
+    if constexpr (GREY >= 1) {
+        P.f(PF_RU, slot) = st.r_u.r;
+        P.f(PF_RL, slot) = st.r_l.r;
+    } else {
+        P.sets(PF_RU, slot, st.r_u);
+        P.sets(PF_RL, slot, st.r_l);
+    }
+}
+template <bool GUIDED, int GREY = 0>
 VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                           uint32_t keep_flags) {
     P.set3(PF_RO, slot, st.ro);
     P.set3(PF_RD, slot, st.rd);
     P.sets(PF_L, slot, st.L);
-    P.sets(PF_BETA, slot, st.beta);
-    P.sets(PF_RU, slot, st.r_u);
-    P.sets(PF_RL, slot, st.r_l);
+    pool_store_beta<GREY>(P, slot, st);
+    pool_store_ru_rl<GREY>(P, slot, st);
     P.set3(PF_PCP, slot, st.prevCtx.p);
     P.i(PF_PCQ, slot) = st.prevCtx.quad;
     pool_store_rng(P, slot, sampler);
@@ -119,12 +135,12 @@ VDEV void pool_store_vertex(const Pool &P, int slot, const Vertex &vx) {
 }
 // after li_segment_a: only what that half changes (L, beta, r_u, r_l, sampler, depth / ISG flags) plus
 // the vertex it stopped at; ray, previous context, rr_correction and guiding state are untouched
+template <int GREY = 0>
 VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                        const Vertex &vx, uint32_t keep_flags) {
     P.sets(PF_L, slot, st.L);
-    P.sets(PF_BETA, slot, st.beta);
-    P.sets(PF_RU, slot, st.r_u);
-    P.sets(PF_RL, slot, st.r_l);
+    pool_store_beta<GREY>(P, slot, st);
+    pool_store_ru_rl<GREY>(P, slot, st);
     pool_store_rng(P, slot, sampler);
     uint32_t fl = pool_pack_flags(st, ch, isg, keep_flags);
     if (vx.volume) fl |= FL_VX_VOLUME;
@@ -142,14 +158,19 @@ VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
     return vx;
 }
 
-template <bool GUIDED>
+template <bool GUIDED, int GREY = 0>
 VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st, Sampler &sampler, int *ch, IsgSample &isg) {
     st.ro = P.v3(PF_RO, slot);
     st.rd = P.v3(PF_RD, slot);
     st.L = P.sp3(PF_L, slot);
-    st.beta = P.sp3(PF_BETA, slot);
-    st.r_u = P.sp3(PF_RU, slot);
-    st.r_l = P.sp3(PF_RL, slot);
+    st.beta = GREY >= 2 ? sp(P.f(PF_BETA, slot)) : P.sp3(PF_BETA, slot);
+    if constexpr (GREY >= 1) {
+        st.r_u = sp(P.f(PF_RU, slot));
+        st.r_l = sp(P.f(PF_RL, slot));
+    } else {
+        st.r_u = P.sp3(PF_RU, slot);
+        st.r_l = P.sp3(PF_RL, slot);
+    }
     st.prevCtx.p = P.v3(PF_PCP, slot);
     st.prevCtx.quad = P.i(PF_PCQ, slot);
     sampler.rng.state = (uint64_t)P.u(PF_RNG + 0, slot) | ((uint64_t)P.u(PF_RNG + 1, slot) << 32);
