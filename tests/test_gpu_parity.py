@@ -301,6 +301,32 @@ def test_grey_specialisations_are_bit_identical(gpu_pkg):
     assert not np.array_equal(films[0], films[1])
 
 
+def test_grey_grid_medium_film_equals_replayed_paths(gpu_pkg):
+    """A grid medium with grey sigma_a / sigma_s renders through the broadcast-spectrum instantiation of the
+    per-lane kernel; the path replay (k_trace_paths) uses the generic one: same pixels bit for bit, and the
+    same again with the specialisation switched off."""
+    from scenes import cloud_density, grid_scene
+    P = gpu_pkg
+    W, H = 48, 40
+    scene = grid_scene(cloud_density(16), (16, 16, 16), 0.08, 2.6, g=0.5, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    xy = np.stack(np.meshgrid(np.arange(W), np.arange(H)), -1).reshape(-1, 2).astype(np.int32)
+    films = []
+    for env in ({}, {"VSPG_NO_GREY": "1"}):
+        os.environ.update(env)
+        try:
+            r = P.Renderer(scene, P.app_f_params(), W, H, seed=2)
+            r.render_wave(0, 1)
+            film = r.film()
+            L, _ = r.trace_paths(xy, np.zeros(len(xy), dtype=np.int32))
+            r.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert np.array_equal(film[..., :3].reshape(-1, 3).view(np.uint32), L.astype(np.float32).view(np.uint32))
+        films.append(film)
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+
+
 def test_full_size_wave_properties(gpu_pkg):
     """BASELINE size (1920x1080): size-independent properties of one wave -- every pixel got exactly one
     sample, path / segment counters are consistent, 20 000 random pixels equal their replayed paths bit

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     // heterogeneous media: the 16^3 majorant grid (16 KB) is staged into LDS once per workgroup with
     // coalesced 16-B loads; every DDA step then reads LDS instead of HBM/L2
     const float *maj_ptr = nullptr;
-    if constexpr (std::is_same<Medium, GridMedium>::value) {
+    if constexpr (std::is_same<Medium, GridMedium>::value || std::is_same<Medium, GridMediumGrey>::value) {
         __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
         const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
         float4 *dst = reinterpret_cast<float4 *>(s_maj);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const Pool P{s_pool, NP};
 
     const float *maj_ptr = nullptr;
-    if constexpr (std::is_same<Medium, GridMedium>::value) {
+    if constexpr (std::is_same<Medium, GridMedium>::value || std::is_same<Medium, GridMediumGrey>::value) {
         __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
         const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
         float4 *dst = reinterpret_cast<float4 *>(s_maj);
@@ -1210,7 +1210,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     {
         auto same = [](const float *v) { return std::memcmp(&v[0], &v[1], 4) == 0 && std::memcmp(&v[1], &v[2], 4) == 0; };
         const VspgMedium &m = r->scene.medium;
-        r->medium_grey = m.type == VSPG_MEDIUM_HOMOGENEOUS && same(m.sigma_a) && same(m.sigma_s) && same(m.Le) && !getenv("VSPG_NO_GREY");
+        r->medium_grey = m.type != VSPG_MEDIUM_NONE && same(m.sigma_a) && same(m.sigma_s) && same(m.Le) && !getenv("VSPG_NO_GREY");
         r->surfaces_grey = !getenv("VSPG_NO_GREY_KD");
         for (int i = 0; i < r->hscene.n_quads; ++i) r->surfaces_grey = r->surfaces_grey && same(r->hscene.quads[i].Kd);
     }
@@ -1388,6 +1388,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     } else if (nvdb && guided) VSPG_LAUNCH_RENDER(NanoDenseMedium, true);
     else if (nvdb) VSPG_LAUNCH_RENDER(NanoDenseMedium, false);
     else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
+    else if (grid && r->medium_grey) VSPG_LAUNCH_RENDER(GridMediumGrey, false);
     else if (grid) VSPG_LAUNCH_RENDER(GridMedium, false);
     else if (guided) VSPG_LAUNCH_RENDER(HomogeneousMedium, true);
     else VSPG_LAUNCH_RENDER(HomogeneousMedium, false);

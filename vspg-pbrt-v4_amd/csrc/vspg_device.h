@@ -700,10 +700,10 @@ VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis
 // grid (media.h:686-719): index-space trilinear sampling a + w (b - a) with background 0 outside the index
 // bounding box, "densityoffset", 64^3 majorants read from HBM / L2 (1 MB: too large for LDS).  The sparse
 // NanoVDB tree and its sampler are absent from the reference tree: parity unpinned for the fetch itself.
-template <bool NVDB>
+template <bool NVDB, bool GREY = false>
 struct GridMediumT {
     static constexpr int kRes = NVDB ? kMajResNvdb : kMajRes;
-    static constexpr int kGrey = 0;
+    static constexpr int kGrey = GREY ? 1 : 0;  // sigma_a, sigma_s built from one value each (see HomogeneousMediumT)
     Spec sigma_a, sigma_s;
     float g;
     int nx, ny, nz;
@@ -878,10 +878,11 @@ struct GridMediumT {
     static constexpr bool kAlwaysRealCollision = false;
 };
 using GridMedium = GridMediumT<false>;
+using GridMediumGrey = GridMediumT<false, true>;
 using NanoDenseMedium = GridMediumT<true>;
-template <bool NVDB>
-VDEV GridMediumT<NVDB> make_grid(const DScene &S, const float *majorant) {
-    return GridMediumT<NVDB>{lds(S.sigma_a), lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
+template <bool NVDB, bool GREY>
+VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
+    return GridMediumT<NVDB, GREY>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
                              majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
                              S.density_offset};
 }
@@ -889,8 +890,10 @@ template <class M> struct MediumMaker;
 template <int GREY> struct MediumMaker<HomogeneousMediumT<GREY>> {
     static VDEV HomogeneousMediumT<GREY> make(const DScene &, const float *) { return HomogeneousMediumT<GREY>{}; }
 };
-template <bool NVDB> struct MediumMaker<GridMediumT<NVDB>> {
-    static VDEV GridMediumT<NVDB> make(const DScene &S, const float *majorant) { return make_grid<NVDB>(S, majorant ? majorant : S.majorant); }
+template <bool NVDB, bool GREY> struct MediumMaker<GridMediumT<NVDB, GREY>> {
+    static VDEV GridMediumT<NVDB, GREY> make(const DScene &S, const float *majorant) {
+        return make_grid<NVDB, GREY>(S, majorant ? majorant : S.majorant);
+    }
 };
 
 // ---------------------------------------------------------------------------------------
