@@ -212,46 +212,171 @@ __global__ __launch_bounds__(kBlock) void k_train_decay(const DScene *__restrict
         (&stats[r].n)[k] *= kTrainDecay;
     }
 }
-// position statistics {n, sum p, [sum p^2]} of the batch per region -> acc
-template <bool WITH_P2>
-__global__ __launch_bounds__(kBlock) void k_train_pos(const DScene *__restrict__ Sp, int f, const VspgTrainSample *__restrict__ samples,
-                                                      unsigned long long n, float *__restrict__ acc) {
+// ---- counting sort of the batch by region ----------------------------------------------------------------
+// Histograms are built per workgroup in LDS over a contiguous chunk of the batch and flushed with one global
+// atomic per non-empty bin: device-scope atomics on a handful of hot addresses (few regions in the first
+// iterations) cost ~300 ns each when issued per wavefront.
+__device__ __forceinline__ void train_chunk(unsigned long long n, unsigned long long *lo, unsigned long long *hi) {
+    unsigned long long per = (n + gridDim.x - 1) / gridDim.x;
+    per = (per + kBlock - 1) / kBlock * kBlock;
+    *lo = (unsigned long long)blockIdx.x * per < n ? (unsigned long long)blockIdx.x * per : n;
+    *hi = *lo + per < n ? *lo + per : n;
+}
+// s_bins[region] += 1 for every lane with region >= 0; returns the lane's rank within the bin before the add.
+// A few ballot rounds serve the popular bins with one LDS atomic each, the tail goes lane by lane.
+__device__ __forceinline__ unsigned int lds_bin_add(unsigned int *s_bins, int region) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(region >= 0);
+    unsigned int rank = 0;
+    for (int round = 0; todo != 0ull && round < 4; ++round) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lreg = __shfl(region, leader);
+        const unsigned long long same = __ballot(region == lreg) & todo;
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&s_bins[lreg], (unsigned int)__popcll(same));
+        base = __shfl(base, leader);
+        if ((same >> lane) & 1ull) rank = base + (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) rank = atomicAdd(&s_bins[region], 1u);
+    return rank;
+}
+// region of every sample of field f (-1: other field / outside) + histogram
+__global__ __launch_bounds__(kBlock) void k_train_lookup(const DScene *__restrict__ Sp, int f, const VspgTrainSample *__restrict__ samples,
+                                                         unsigned long long n, int *__restrict__ reg_of, unsigned int *__restrict__ hist) {
+    __shared__ unsigned int s_hist[kTrainCapRegions];
     const DScene &S = *Sp;
-    for (unsigned long long i0 = (unsigned long long)blockIdx.x * kBlock; i0 < n; i0 += (unsigned long long)gridDim.x * kBlock) {
+    const int nreg = S.field[f].n_regions;
+    for (int b = threadIdx.x; b < nreg; b += kBlock) s_hist[b] = 0;
+    __syncthreads();
+    unsigned long long lo, hi;
+    train_chunk(n, &lo, &hi);
+    for (unsigned long long i0 = lo; i0 < hi; i0 += kBlock) {
         const unsigned long long i = i0 + threadIdx.x;
-        int region = 0;
-        bool valid = false;
-        VspgTrainSample sm;
-        if (i < n) {
-            sm = samples[i];
-            valid = train_sample_region(S, f, sm, &region);
+        int region = -1;
+        if (i < hi) {
+            const VspgTrainSample sm = samples[i];
+            int rg;
+            if (train_sample_region(S, f, sm, &rg)) region = rg;
+            reg_of[i] = region;
         }
-        if (WITH_P2) {
-            float v[7] = {1.f, sm.p[0], sm.p[1], sm.p[2], sm.p[0] * sm.p[0], sm.p[1] * sm.p[1], sm.p[2] * sm.p[2]};
-            wave_accumulate(valid, region, v, acc, 0);
-        } else {
-            float v[4] = {1.f, sm.p[0], sm.p[1], sm.p[2]};
-            wave_accumulate(valid, region, v, acc, 0);
-        }
+        lds_bin_add(s_hist, region);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nreg; b += kBlock)
+        if (s_hist[b]) atomicAdd(&hist[b], s_hist[b]);
+}
+// exclusive scan of the histogram -> start offsets (one block); cursor = copy for the scatter; total -> *n_sorted
+__global__ __launch_bounds__(kBlock) void k_train_scan(const DScene *__restrict__ Sp, int f, const unsigned int *__restrict__ hist,
+                                                       unsigned int *__restrict__ cursor, unsigned int *__restrict__ n_sorted) {
+    __shared__ unsigned int s_part[kBlock];
+    const int nreg = Sp->field[f].n_regions;
+    const int per = (nreg + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * per < nreg ? threadIdx.x * per : nreg, hi = lo + per < nreg ? lo + per : nreg;
+    unsigned int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += hist[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int t = 0; t < kBlock; ++t) { const unsigned int v = s_part[t]; s_part[t] = run; run += v; }
+        *n_sorted = run;
+    }
+    __syncthreads();
+    unsigned int run = s_part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { cursor[i] = run; run += hist[i]; }
+}
+// a workgroup recounts its chunk, reserves one range per non-empty bin, then places its samples
+__global__ __launch_bounds__(kBlock) void k_train_scatter(const DScene *__restrict__ Sp, int f, const int *__restrict__ reg_of,
+                                                          unsigned long long n, unsigned int *__restrict__ cursor,
+                                                          unsigned int *__restrict__ order) {
+    __shared__ unsigned int s_hist[kTrainCapRegions], s_base[kTrainCapRegions];
+    const int nreg = Sp->field[f].n_regions;
+    for (int b = threadIdx.x; b < nreg; b += kBlock) s_hist[b] = 0;
+    __syncthreads();
+    unsigned long long lo, hi;
+    train_chunk(n, &lo, &hi);
+    for (unsigned long long i0 = lo; i0 < hi; i0 += kBlock) {
+        const unsigned long long i = i0 + threadIdx.x;
+        lds_bin_add(s_hist, i < hi ? reg_of[i] : -1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nreg; b += kBlock) {
+        const unsigned int c = s_hist[b];
+        s_base[b] = c ? atomicAdd(&cursor[b], c) : 0u;
+        s_hist[b] = 0;
+    }
+    __syncthreads();
+    for (unsigned long long i0 = lo; i0 < hi; i0 += kBlock) {
+        const unsigned long long i = i0 + threadIdx.x;
+        const int region = i < hi ? reg_of[i] : -1;
+        const unsigned int rank = lds_bin_add(s_hist, region);
+        if (region >= 0) order[s_base[region] + rank] = (unsigned int)i;
     }
 }
+// every wavefront takes a contiguous piece of the sorted order
+__device__ __forceinline__ void train_piece(unsigned int n_sorted, unsigned int *lo, unsigned int *hi) {
+    const unsigned int waves = gridDim.x * (kBlock / 64), w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    unsigned int per = (n_sorted + waves - 1) / waves;
+    per = (per + 63u) & ~63u;
+    *lo = w * per < n_sorted ? w * per : n_sorted;
+    *hi = *lo + per < n_sorted ? *lo + per : n_sorted;
+}
+// position statistics {n, sum p, [sum p^2]} of the batch per region -> acc
+template <bool WITH_P2>
+__global__ __launch_bounds__(kBlock) void k_train_pos(const VspgTrainSample *__restrict__ samples, const int *__restrict__ reg_of,
+                                                      const unsigned int *__restrict__ order, const unsigned int *__restrict__ n_sorted,
+                                                      float *__restrict__ acc) {
+    unsigned int lo, hi;
+    train_piece(*n_sorted, &lo, &hi);
+    constexpr int NV = WITH_P2 ? 7 : 4;
+    RunAccumulator<NV> R;
+    R.init(acc, 0);
+    for (unsigned int j0 = lo; j0 < hi; j0 += 64u) {
+        const unsigned int j = j0 + (threadIdx.x & 63);
+        const bool valid = j < hi;
+        float v[NV];
+        int region = -1;
+        for (int k = 0; k < NV; ++k) v[k] = 0.f;
+        if (valid) {
+            const unsigned int i = order[j];
+            region = reg_of[i];
+            const VspgTrainSample sm = samples[i];
+            v[0] = 1.f; v[1] = sm.p[0]; v[2] = sm.p[1]; v[3] = sm.p[2];
+            if constexpr (WITH_P2) { v[4] = sm.p[0] * sm.p[0]; v[5] = sm.p[1] * sm.p[1]; v[6] = sm.p[2] * sm.p[2]; }
+        }
+        R.add(valid, region, v);
+    }
+    R.flush();
+}
 // spatial refinement, ONE thread: sequential like the CPU definition so node / region numbering is the same
-__global__ void k_train_split(DScene *Sp, int f, RegionStats *stats, const float *acc, VspgKdNode *nodes, VspgFieldRegion *regs) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+constexpr int kSplitBlock = 1024;
+__global__ __launch_bounds__(kSplitBlock) void k_train_split(DScene *Sp, int f, RegionStats *stats, const float *acc, VspgKdNode *nodes,
+                                                             VspgFieldRegion *regs) {
+    // The definition is sequential over the nodes (oracle/vspg_oracle.c:field_update_one): a leaf that wants to
+    // split takes the next two node slots and the next region slot, until a capacity runs out.  Slots only grow,
+    // so "rank among the wanting leaves" (a prefix sum) reproduces the sequential numbering exactly.
+    __shared__ unsigned int s_cnt[kSplitBlock];
+    __shared__ int s_n_nodes, s_n_regions;
     DField &F = Sp->field[f];
-    const int n_reg0 = F.n_regions;
-    for (int i = 0; i < n_reg0; ++i) {
+    const int n_reg0 = F.n_regions, n_nodes0 = F.n_nodes;
+    for (int i = threadIdx.x; i < n_reg0; i += kSplitBlock) {
         const float *a = acc + (size_t)i * kStatFloats;
         stats[i].n += a[0];
         for (int k = 0; k < 3; ++k) { stats[i].sum_p[k] += a[1 + k]; stats[i].sum_p2[k] += a[4 + k]; }
     }
-    const int n_nodes0 = F.n_nodes;
-    for (int nd = 0; nd < n_nodes0; ++nd) {
-        if ((nodes[nd].packed & 3u) != 3u) continue;
-        const int reg = (int)(nodes[nd].packed >> 2);
-        RegionStats &s0 = stats[reg];
+    __syncthreads();
+    constexpr int kPer = (kTrainCapNodes + kSplitBlock - 1) / kSplitBlock;
+    const int first = threadIdx.x * kPer;
+    unsigned int want = 0;
+    int axis_of[kPer];
+    float split_of[kPer];
+    for (int j = 0; j < kPer; ++j) {
+        const int nd = first + j;
+        axis_of[j] = 0; split_of[j] = 0;
+        if (nd >= n_nodes0 || (nodes[nd].packed & 3u) != 3u) continue;
+        const RegionStats &s0 = stats[nodes[nd].packed >> 2];
         if (!(s0.n > kTrainSplitCount) || s0.depth >= kTrainMaxDepth) continue;
-        if (F.n_nodes + 2 > kTrainCapNodes || F.n_regions + 1 > kTrainCapRegions) continue;
         float mean[3], var[3];
         for (int k = 0; k < 3; ++k) {
             mean[k] = s0.sum_p[k] / s0.n;
@@ -259,9 +384,33 @@ __global__ void k_train_split(DScene *Sp, int f, RegionStats *stats, const float
         }
         const int axis = var[0] >= var[1] ? (var[0] >= var[2] ? 0 : 2) : (var[1] >= var[2] ? 1 : 2);
         if (!(var[axis] > 0)) continue;
-        const int left = F.n_nodes, newreg = F.n_regions;
-        F.n_nodes += 2;
-        F.n_regions += 1;
+        want |= 1u << j;
+        axis_of[j] = axis;
+        split_of[j] = mean[axis];
+    }
+    s_cnt[threadIdx.x] = (unsigned int)__popc(want);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int t = 0; t < kSplitBlock; ++t) { const unsigned int v = s_cnt[t]; s_cnt[t] = run; run += v; }
+        // how many of the `run` candidates fit: both capacities
+        int fit = (int)run;
+        if (fit > (kTrainCapNodes - n_nodes0) / 2) fit = (kTrainCapNodes - n_nodes0) / 2;
+        if (fit > kTrainCapRegions - n_reg0) fit = kTrainCapRegions - n_reg0;
+        if (fit < 0) fit = 0;
+        s_n_nodes = n_nodes0 + 2 * fit;
+        s_n_regions = n_reg0 + fit;
+    }
+    __syncthreads();
+    int rank = (int)s_cnt[threadIdx.x];
+    for (int j = 0; j < kPer; ++j) {
+        if (!((want >> j) & 1u)) continue;
+        const int left = n_nodes0 + 2 * rank, newreg = n_reg0 + rank;
+        ++rank;
+        if (left + 2 > kTrainCapNodes || newreg + 1 > kTrainCapRegions) continue;
+        const int nd = first + j;
+        const int reg = (int)(nodes[nd].packed >> 2);
+        RegionStats &s0 = stats[reg];
         float *v = &s0.n;
         for (int k = 0; k < kStatFloats; ++k) v[k] *= 0.5f;
         s0.depth += 1;
@@ -269,9 +418,11 @@ __global__ void k_train_split(DScene *Sp, int f, RegionStats *stats, const float
         regs[newreg] = regs[reg];
         nodes[left].split = 0; nodes[left].packed = ((uint32_t)reg << 2) | 3u;
         nodes[left + 1].split = 0; nodes[left + 1].packed = ((uint32_t)newreg << 2) | 3u;
-        nodes[nd].split = mean[axis];
-        nodes[nd].packed = ((uint32_t)left << 2) | (uint32_t)axis;
+        nodes[nd].split = split_of[j];
+        nodes[nd].packed = ((uint32_t)left << 2) | (uint32_t)axis_of[j];
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { F.n_nodes = s_n_nodes; F.n_regions = s_n_regions; }
 }
 __global__ __launch_bounds__(kBlock) void k_train_init_regions(const DScene *__restrict__ Sp, int f, const float *__restrict__ acc,
                                                                VspgFieldRegion *__restrict__ regs) {
@@ -284,58 +435,57 @@ __global__ __launch_bounds__(kBlock) void k_train_init_regions(const DScene *__r
     }
 }
 __global__ __launch_bounds__(kBlock) void k_train_estep(const DScene *__restrict__ Sp, int f, const VspgTrainSample *__restrict__ samples,
-                                                        unsigned long long n, const float *__restrict__ sumw, float *__restrict__ acc) {
+                                                        unsigned long long n, const int *__restrict__ reg_of,
+                                                        const unsigned int *__restrict__ order, const unsigned int *__restrict__ n_sorted,
+                                                        const float *__restrict__ sumw, float *__restrict__ acc) {
     const DScene &S = *Sp;
     vspg_libm::stage_logf_tab_lds();
     __syncthreads();
     const float wmax = kTrainWeightClamp * (*sumw / (float)n);
-    for (unsigned long long i0 = (unsigned long long)blockIdx.x * kBlock; i0 < n; i0 += (unsigned long long)gridDim.x * kBlock) {
-        const unsigned long long i = i0 + threadIdx.x;
-        int region = 0;
-        bool valid = false;
-        float vS[GK], vR0[GK], vR1[GK], vR2[GK], vD[GK], vV[GK], vQv[GK], vQs[GK];
-        for (int k = 0; k < GK; ++k) vS[k] = vR0[k] = vR1[k] = vR2[k] = vD[k] = vV[k] = vQv[k] = vQs[k] = 0.f;
-        if (i < n) {
+    unsigned int lo, hi;
+    train_piece(*n_sorted, &lo, &hi);
+    RunAccumulator<8 * GK> R;
+    R.init(acc, 7);
+    for (unsigned int j0 = lo; j0 < hi; j0 += 64u) {
+        const unsigned int j = j0 + (threadIdx.x & 63);
+        bool valid = j < hi;
+        int region = -1;
+        float vals[8 * GK];  // S, R0, R1, R2, D, V, Qv, Qs -- the order of RegionStats
+        for (int k = 0; k < 8 * GK; ++k) vals[k] = 0.f;
+        if (valid) {
+            const unsigned int i = order[j];
+            region = reg_of[i];
             const VspgTrainSample sm = samples[i];
-            valid = train_sample_region(S, f, sm, &region);
+            const VspgFieldRegion &Rg = S.field[f].regions[region];
+            const int nl = Rg.n_lobes < GK ? Rg.n_lobes : GK;
+            valid = nl > 0;
             if (valid) {
-                const VspgFieldRegion &R = S.field[f].regions[region];
-                const int nl = R.n_lobes < GK ? R.n_lobes : GK;
-                valid = nl > 0;
+                const float w = sm.weight < wmax ? sm.weight : wmax;
+                const V3 om = train_reaim(Rg, ld3(sm.p), ld3(sm.dir), sm.distance);
+                float g[GK], gs = 0;
+                for (int k = 0; k < GK; ++k) {
+                    g[k] = k < nl ? Rg.weight[k] * vmf_eval(V3{Rg.mu[0][k], Rg.mu[1][k], Rg.mu[2][k]}, kappa_clamp(Rg.kappa[k]), om) : 0.f;
+                    gs += g[k];
+                }
+                valid = gs > 0 && !isinf_(gs);
                 if (valid) {
-                    const float w = sm.weight < wmax ? sm.weight : wmax;
-                    const V3 om = train_reaim(R, ld3(sm.p), ld3(sm.dir), sm.distance);
-                    float g[GK], gs = 0;
+                    const bool nextvol = (sm.flags & VSPG_SAMPLE_NEXT_VOLUME) != 0;
+                    const bool hasd = sm.distance > 0 && !isinf_(sm.distance);
                     for (int k = 0; k < GK; ++k) {
-                        g[k] = k < nl ? R.weight[k] * vmf_eval(V3{R.mu[0][k], R.mu[1][k], R.mu[2][k]}, kappa_clamp(R.kappa[k]), om) : 0.f;
-                        gs += g[k];
-                    }
-                    valid = gs > 0 && !isinf_(gs);
-                    if (valid) {
-                        const bool nextvol = (sm.flags & VSPG_SAMPLE_NEXT_VOLUME) != 0;
-                        const bool hasd = sm.distance > 0 && !isinf_(sm.distance);
-                        for (int k = 0; k < GK; ++k) {
-                            const float wg = w * (g[k] / gs);
-                            vS[k] = wg;
-                            vR0[k] = wg * om.x; vR1[k] = wg * om.y; vR2[k] = wg * om.z;
-                            vD[k] = hasd ? wg / sm.distance : 0.f;
-                            vV[k] = nextvol ? wg : 0.f;
-                            vQv[k] = nextvol ? wg * w : 0.f;
-                            vQs[k] = nextvol ? 0.f : wg * w;
-                        }
+                        const float wg = w * (g[k] / gs);
+                        vals[0 * GK + k] = wg;
+                        vals[1 * GK + k] = wg * om.x; vals[2 * GK + k] = wg * om.y; vals[3 * GK + k] = wg * om.z;
+                        vals[4 * GK + k] = hasd ? wg / sm.distance : 0.f;
+                        vals[5 * GK + k] = nextvol ? wg : 0.f;
+                        vals[6 * GK + k] = nextvol ? wg * w : 0.f;
+                        vals[7 * GK + k] = nextvol ? 0.f : wg * w;
                     }
                 }
             }
         }
-        wave_accumulate(valid, region, vS, acc, 7 + 0 * GK);
-        wave_accumulate(valid, region, vR0, acc, 7 + 1 * GK);
-        wave_accumulate(valid, region, vR1, acc, 7 + 2 * GK);
-        wave_accumulate(valid, region, vR2, acc, 7 + 3 * GK);
-        wave_accumulate(valid, region, vD, acc, 7 + 4 * GK);
-        wave_accumulate(valid, region, vV, acc, 7 + 5 * GK);
-        wave_accumulate(valid, region, vQv, acc, 7 + 6 * GK);
-        wave_accumulate(valid, region, vQs, acc, 7 + 7 * GK);
+        R.add(valid, region, vals);
     }
+    R.flush();
 }
 __global__ __launch_bounds__(kBlock) void k_train_mstep(const DScene *__restrict__ Sp, int f, const float *__restrict__ acc,
                                                         RegionStats *__restrict__ stats, VspgFieldRegion *__restrict__ regs) {
@@ -862,6 +1012,9 @@ struct VspgRenderer {
     RegionStats *rstats[2] = {nullptr, nullptr};
     float *train_acc = nullptr;               // kTrainCapRegions x kStatFloats accumulators of one pass
     float *train_sumw = nullptr;
+    int *train_reg = nullptr;                 // region of every sample of the batch (field being updated)
+    unsigned int *train_order = nullptr;      // sample indices sorted by region
+    unsigned int *train_hist = nullptr, *train_cursor = nullptr, *train_nsorted = nullptr;
     float *density = nullptr;   // GridMedium density samples
     float *majorant = nullptr;  // 16^3 majorant grid
     int num_cus = 0;
@@ -1277,6 +1430,11 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         CK(hipMemset(r->train_counters, 0, 4 * sizeof(unsigned long long)));
         CK(hipMalloc(&r->train_acc, (size_t)kTrainCapRegions * kStatFloats * sizeof(float)));
         CK(hipMalloc(&r->train_sumw, sizeof(float)));
+        CK(hipMalloc(&r->train_reg, r->sample_capacity * sizeof(int)));
+        CK(hipMalloc(&r->train_order, r->sample_capacity * sizeof(unsigned int)));
+        CK(hipMalloc(&r->train_hist, (size_t)kTrainCapRegions * sizeof(unsigned int)));
+        CK(hipMalloc(&r->train_cursor, (size_t)kTrainCapRegions * sizeof(unsigned int)));
+        CK(hipMalloc(&r->train_nsorted, sizeof(unsigned int)));
     }
 #undef CK
     *out = r;
@@ -1303,6 +1461,11 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_counters) (void)hipFree(r->train_counters);
     if (r->train_acc) (void)hipFree(r->train_acc);
     if (r->train_sumw) (void)hipFree(r->train_sumw);
+    if (r->train_reg) (void)hipFree(r->train_reg);
+    if (r->train_order) (void)hipFree(r->train_order);
+    if (r->train_hist) (void)hipFree(r->train_hist);
+    if (r->train_cursor) (void)hipFree(r->train_cursor);
+    if (r->train_nsorted) (void)hipFree(r->train_nsorted);
     if (r->density) (void)hipFree(r->density);
     if (r->majorant) (void)hipFree(r->majorant);
     delete r;
@@ -1409,20 +1572,36 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
         unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
         if (grid > (unsigned)r->num_cus * 16u) grid = (unsigned)r->num_cus * 16u;
         const unsigned rgrid = (kTrainCapRegions + kBlock - 1) / kBlock;
+        // counting sort: few, long chunks -- every workgroup flushes one atomic per bin its chunk touched
+        const unsigned sgrid = grid < (unsigned)r->num_cus * 2u ? grid : (unsigned)r->num_cus * 2u;
+        // accumulation passes: every wavefront flushes its running sums at least once, so no more wavefronts than fill the chip
+        const unsigned agrid = grid < (unsigned)r->num_cus * 4u ? grid : (unsigned)r->num_cus * 4u;
         HIPCHK(hipMemsetAsync(r->train_sumw, 0, sizeof(float), s));
-        hipLaunchKernelGGL(k_train_sum_weight, dim3(grid), dim3(kBlock), 0, s, r->samples, n, r->train_sumw);
+        hipLaunchKernelGGL(k_train_sum_weight, dim3(sgrid), dim3(kBlock), 0, s, r->samples, n, r->train_sumw);
+        const size_t hist_bytes = (size_t)kTrainCapRegions * sizeof(unsigned int);
+        auto sort_by_region = [&](int f) -> int {  // reg_of, order, n_sorted for field f as the tree stands now
+            HIPCHK(hipMemsetAsync(r->train_hist, 0, hist_bytes, s));
+            hipLaunchKernelGGL(k_train_lookup, dim3(sgrid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_reg, r->train_hist);
+            hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(kBlock), 0, s, r->dscene, f, r->train_hist, r->train_cursor, r->train_nsorted);
+            hipLaunchKernelGGL(k_train_scatter, dim3(sgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_reg, n, r->train_cursor, r->train_order);
+            return 0;
+        };
         for (int f = 0; f < 2; ++f) {
             hipLaunchKernelGGL(k_train_decay, dim3(rgrid * 8), dim3(kBlock), 0, s, r->dscene, f, r->rstats[f]);
+            if (int rc = sort_by_region(f)) return rc;
             HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
-            hipLaunchKernelGGL((k_train_pos<true>), dim3(grid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_acc);
-            hipLaunchKernelGGL(k_train_split, dim3(1), dim3(64), 0, s, r->dscene, f, r->rstats[f], r->train_acc, r->fnodes[f],
+            hipLaunchKernelGGL((k_train_pos<true>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order,
+                               r->train_nsorted, r->train_acc);
+            hipLaunchKernelGGL(k_train_split, dim3(1), dim3(kSplitBlock), 0, s, r->dscene, f, r->rstats[f], r->train_acc, r->fnodes[f],
                                r->fregions[f]);
+            if (int rc = sort_by_region(f)) return rc;  // the split changed the leaves
             HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
-            hipLaunchKernelGGL((k_train_pos<false>), dim3(grid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_acc);
+            hipLaunchKernelGGL((k_train_pos<false>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order,
+                               r->train_nsorted, r->train_acc);
             hipLaunchKernelGGL(k_train_init_regions, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->fregions[f]);
             HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
-            hipLaunchKernelGGL(k_train_estep, dim3(grid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_sumw,
-                               r->train_acc);
+            hipLaunchKernelGGL(k_train_estep, dim3(agrid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_reg, r->train_order,
+                               r->train_nsorted, r->train_sumw, r->train_acc);
             hipLaunchKernelGGL(k_train_mstep, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->rstats[f],
                                r->fregions[f]);
         }

@@ -181,30 +181,47 @@ struct RegionStats {  // decayed sufficient statistics of one region
 constexpr int kStatFloats = 7 + 8 * GK;  // every float member of RegionStats, in order
 static_assert(sizeof(RegionStats) == (kStatFloats + 1) * 4, "RegionStats layout");
 
-// Add `vals[NV]` of every lane with `valid` into dst[region * kStatFloats + first + v].  Lanes of a
-// wavefront that share a region are summed with a butterfly first, so a region that dominates the
-// batch costs one atomic per value per wavefront; once a wavefront holds more than 8 distinct regions
-// contention is low and the remaining lanes add directly.
+// Accumulation over samples SORTED by region (counting sort, k_train_lookup / k_train_scan / k_train_scatter):
+// a wavefront walks a contiguous piece of the sorted order, so almost every 64-sample group belongs to one
+// region.  The group's NV values are summed with a butterfly; value v's running sum lives in LANE v, and when
+// the region changes (or the piece ends) the wavefront flushes all of them with ONE atomic instruction (lane v
+// adds to statistic v).  Hot regions -- the whole field at iteration 0 -- thus cost one atomic per value per
+// wavefront piece instead of one per sample.
 template <int NV>
-VDEV void wave_accumulate(bool valid, int region, const float (&vals)[NV], float *__restrict__ dst, int first) {
-    unsigned long long todo = __ballot(valid);
-    const int lane = threadIdx.x & 63;
-    for (int round = 0; todo != 0ull && round < 8; ++round) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lreg = __shfl(region, leader);
-        const unsigned long long same = __ballot(valid && region == lreg) & todo;
-        const bool mine = (same >> lane) & 1ull;
-        for (int v = 0; v < NV; ++v) {
-            float x = mine ? vals[v] : 0.f;
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if (lane == leader && x != 0.f) atomicAdd(&dst[(size_t)lreg * kStatFloats + first + v], x);
-        }
-        todo &= ~same;
+struct RunAccumulator {
+    static_assert(NV <= 64, "one lane per statistic");
+    float acc;      // lane v: running sum of statistic v for `region`
+    int region;     // wave-uniform
+    float *dst;
+    int first;
+    VDEV void init(float *d, int f) { acc = 0.f; region = -1; dst = d; first = f; }
+    VDEV void flush() {
+        const int lane = threadIdx.x & 63;
+        if (region >= 0 && lane < NV && acc != 0.f) atomicAdd(&dst[(size_t)region * kStatFloats + first + lane], acc);
+        acc = 0.f;
     }
-    if ((todo >> lane) & 1ull)
-        for (int v = 0; v < NV; ++v)
-            if (vals[v] != 0.f) atomicAdd(&dst[(size_t)region * kStatFloats + first + v], vals[v]);
-}
+    // all lanes call; `valid` lanes contribute vals[] to their `reg`
+    VDEV void add(bool valid, int reg, const float (&vals)[NV]) {
+        const int lane = threadIdx.x & 63;
+        unsigned long long todo = __ballot(valid);
+        while (todo != 0ull) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lreg = __shfl(reg, leader);
+            const unsigned long long same = __ballot(valid && reg == lreg) & todo;
+            const bool mine = (same >> lane) & 1ull;
+            if (lreg != region) {
+                flush();
+                region = lreg;
+            }
+            for (int v = 0; v < NV; ++v) {
+                float x = mine ? vals[v] : 0.f;
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+                if (lane == v) acc += x;
+            }
+            todo &= ~same;
+        }
+    }
+};
 
 VDEV V3 train_reaim(const VspgFieldRegion &R, V3 p, V3 w, float dist) {
     if (!(dist > 0) || isinf_(dist)) return w;
