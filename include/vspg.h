@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSPG_ABI_VERSION 2
+#define VSPG_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define VSPG_OK 0
@@ -127,11 +127,12 @@ typedef struct VspgIntegratorParams {
     float vspmisratio;                 /* 0.5 */
     int32_t vspcriterion;              /* "variance" */
     int32_t vspsamplingmethod;         /* "resampling" */
-    int32_t collisionProbabilityBias;  /* false (NDS+; out of scope -> VSPG_ESCOPE if set) */
+    int32_t collisionProbabilityBias;  /* false (NDS+: needs a transmittance buffer, vspg_renderer_set_tr_buffer) */
     int32_t rrguiding;                 /* false (guided RR; out of scope if set) */
     int32_t lightsampler;              /* "bvh" */
     int32_t regularize;                /* false (no-op for diffuse BxDFs) */
     int32_t guide_num_training_waves;  /* 128, hidden constant integrators.h:502 */
+    int32_t storeTrBuffer;             /* false: record the primary rays' transmittance (TrBuffer) for read-back */
 } VspgIntegratorParams;
 
 /* Film "rgb" + Sampler "independent" + PixelFilter "box" (SURVEY.md App. F). */
@@ -266,6 +267,17 @@ int vspg_vsp_buffer_read(VspgRenderer *r, float *host_vsp /* W*H */, int *is_rea
 #define VSPG_ISG_STATS 8
 int vspg_isg_stats_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);
 
+/* Transmittance buffer (TrBuffer, src/pbrt/cpu/trbuffer.h:17-104): per-pixel running mean of the primary
+ * ray's ratio-tracking transmittance estimate, recorded by the resampling routine
+ * (guidedvolpathvspgintegrator.cpp:727-728) while params.storeTrBuffer is set (or NDS+ is requested and no
+ * buffer was handed over).  get = what TrBuffer::Store writes (RGB per pixel, row-major; host_spp, optional:
+ * the per-pixel sample counts, for merging the buffers of sample-sharded ranks).  set = TrBuffer(fileName):
+ * the renderer stops recording and NDS+ (vspsamplingmethod "nds" + collisionProbabilityBias) biases the
+ * primary ray's real/null-collision probability with it (:929-938). */
+int vspg_renderer_get_tr_buffer(VspgRenderer *r, float *host_rgb /* W*H*3 */, int32_t *host_spp /* W*H or NULL */,
+                                void *stream);
+int vspg_renderer_set_tr_buffer(VspgRenderer *r, const float *host_rgb /* W*H*3 */, void *stream);
+
 int vspg_get_counters(VspgRenderer *r, VspgCounters *out, void *stream);
 int vspg_reset_counters(VspgRenderer *r, void *stream);
 
@@ -343,6 +355,9 @@ int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, flo
 /* out[i] = (float)(-log(1.0 - (double)x[i])) as the kernels evaluate it: the DOUBLE-precision
  * std::log of the optical-depth-space distance sampling (src/pbrt/media_sampleTMaj.h:379-404). */
 int vspg_libm_log1m_batch(VspgRenderer *r, int n, const float *x, float *out, void *stream);
+/* out[i] = powf(x[i], y[i]) as the kernels evaluate it (the std::pow of the NDS+ bias,
+ * src/pbrt/cpu/guidedvolpathvspgintegrator.cpp:937): bit-identical to glibc 2.35's powf. */
+int vspg_libm_powf_batch(VspgRenderer *r, int n, const float *x, const float *y, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -494,6 +494,12 @@ struct OracleRenderer {
     uint64_t n_zero_samples;
     struct region_stats *rstats[2];
     int cap_nodes[2], cap_regions[2];
+    /* TrBuffer (cpu/trbuffer.h:17-104): per-pixel running mean of the primary ray's ratio-tracking
+     * transmittance estimate; tr_calc = calculateTrBuffer, tr_load = trBufferLoad (:180-193) */
+    float *trbuf; /* W*H*3 */
+    int *tr_spp;  /* W*H */
+    int tr_calc, tr_load;
+    int in_wave;  /* render_wave is running (debug path traces do not feed the buffers) */
 };
 
 typedef struct { /* LightSampleContext (base/light.h) */
@@ -1542,6 +1548,7 @@ static void rec_add_scatter_data(pathrec_t *rec, int volume, spec weight, v3 wi,
 typedef struct {
     const OracleRenderer *r;
     int ch;
+    int px, py;                  /* pPixel */
     sampler_t *sampler;
     rng_t *rng;
     pathrec_t *rec;              /* a18 recorder, NULL when not training */
@@ -1686,7 +1693,6 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
 
 /* delta-tracking callback (:885-1078) */
 static int delta_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, spec T_maj, int activateNDS) {
-    (void)activateNDS;
     sd_ctx_t *c = (sd_ctx_t *)vctx;
     const OracleRenderer *r = c->r;
     int ch = c->ch;
@@ -1704,6 +1710,14 @@ static int delta_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, 
     }
     spec sigma_t = s_add(mp->sigma_s, mp->sigma_a);
     float pScatter = sigma_t.c[ch] / sigma_maj.c[ch];
+    int NDS_plus = 0;
+    if (*c->depth == 0 && r->prm.vspsamplingmethod == VSPG_VSP_NDS && r->prm.collisionProbabilityBias && r->tr_load && activateNDS) {
+        /* NDS+: adjust the real/null-collision probability by the cached transmittance (:930-938) */
+        NDS_plus = 1;
+        float trEstCache = r->trbuf[((size_t)c->py * r->cfg.xres + c->px) * 3 + ch];
+        float gamma = 1 + trEstCache;
+        pScatter = powf(pScatter, 1 / gamma);
+    }
     float pNull = fmaxf(0.f, 1 - pScatter);
     float um = rng_float(c->rng);
     int mode = oracle_sample_discrete2(pScatter, pNull, um);
@@ -1720,6 +1734,7 @@ static int delta_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, 
         float pdf = T_maj.c[ch] * sigma_t.c[ch];
         *c->beta = s_mul(*c->beta, s_divf(s_mul(T_maj, mp->sigma_s), pdf));
         *c->r_u = s_mul(*c->r_u, s_divf(s_mul(T_maj, sigma_t), pdf));
+        if (NDS_plus) *c->r_u = s_mul(*c->r_u, s_div(s_scale(sigma_maj, pScatter), sigma_t)); /* :975-976 */
         *c->beta = s_mul(*c->beta, c->beta_factor);
         *c->r_u = s_mul(*c->r_u, c->r_u_factor);
         if (c->rec) { /* :978-986 */
@@ -1741,6 +1756,7 @@ static int delta_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, 
             if (c->rec) *c->transmittanceWeight = S1(0.f);
         }
         *c->r_u = s_mul(*c->r_u, s_divf(s_mul(T_maj, sigma_n), pdf));
+        if (NDS_plus) *c->r_u = s_mul(*c->r_u, s_div(s_scale(sigma_maj, 1 - pScatter), sigma_n)); /* :1072-1073 */
         *c->r_l = s_mul(*c->r_l, s_divf(s_mul(T_maj, sigma_maj), pdf));
         return s_nonzero(*c->beta) && s_nonzero(*c->r_u);
     }
@@ -1830,6 +1846,12 @@ static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
                                              &vrc, &majorantScale, resampling_cb, &rc);
         rc.beta_rs = s_mul(rc.beta_rs, s_divf(T_maj, T_maj.c[ch]));
         rc.r_u_rs = s_mul(rc.r_u_rs, s_divf(T_maj, T_maj.c[ch]));
+        if (*c->depth == 0 && r->tr_calc && r->in_wave) { /* trBuffer->AddSample (:727-728, trbuffer.h:40-45) */
+            size_t pix = (size_t)py * r->cfg.xres + px;
+            r->tr_spp[pix] += 1;
+            float alpha = 1.f / r->tr_spp[pix];
+            for (int k = 0; k < 3; ++k) r->trbuf[pix * 3 + k] = (1.f - alpha) * r->trbuf[pix * 3 + k] + alpha * rc.trRatioEst.c[k];
+        }
         float trScalar = rc.trRatioEst.c[ch];
         /* surfaceCandidate */
         float surf_wi = trScalar, surf_sigmaTTr = trScalar;
@@ -1935,7 +1957,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             rng_set_sequence2(&rng, hash0, hash1);
             sd_ctx_t c;
             memset(&c, 0, sizeof c);
-            c.r = r; c.ch = ch; c.sampler = sampler; c.rng = &rng;
+            c.r = r; c.ch = ch; c.px = px; c.py = py; c.sampler = sampler; c.rng = &rng;
             c.ray_o = &ro; c.ray_d = &rd; c.depth = &depth;
             c.L = &L; c.beta = &beta; c.r_u = &r_u; c.r_l = &r_l;
             c.specularBounce = &specularBounce; c.anyNonSpecularBounces = &anyNonSpecularBounces;
@@ -2486,6 +2508,7 @@ int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int 
     int ntiles = ntx * nty;
     VspgCounters total;
     memset(&total, 0, sizeof total);
+    r->in_wave = 1;
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #else
@@ -2523,6 +2546,7 @@ int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int 
     counters_merge(&r->counters, &(path_counters_t){total.segments, total.volume_scatters, total.surface_hits,
                                                     total.density_queries, total.shadow_rays},
                    total.paths);
+    r->in_wave = 0;
     return 0;
 }
 
@@ -2580,7 +2604,7 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
     if (!scene || !p || !cfg) return VSPG_EINVAL;
     if (cfg->xres <= 0 || cfg->yres <= 0) return VSPG_EINVAL;
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return VSPG_EINVAL;
-    if (p->collisionProbabilityBias || p->rrguiding) return VSPG_ESCOPE;
+    if (p->rrguiding) return VSPG_ESCOPE;
     if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;
         if (m->nx <= 0 || m->ny <= 0 || m->nz <= 0 || !m->density) return VSPG_EINVAL;
@@ -2620,6 +2644,13 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
     r->film = (double *)calloc(npix * 4, sizeof(double));
     r->isg_stats = (float *)calloc(npix * VSPG_ISG_STATS, sizeof(float));
     r->vsp = (float *)calloc(npix, sizeof(float));
+    /* calculateTrBuffer (:190-193); a buffer handed over through oracle_tr_buffer_write is trBufferLoad (:180-188) */
+    r->tr_calc = params->storeTrBuffer || (params->vspguiding && params->vspprimaryguiding &&
+                                           params->vspsamplingmethod == VSPG_VSP_NDS && params->collisionProbabilityBias);
+    if (r->tr_calc) {
+        r->trbuf = (float *)calloc(npix * 3, sizeof(float));
+        r->tr_spp = (int *)calloc(npix, sizeof(int));
+    }
     /* guideTraining (:109).  The reference also trains when only the guided-RR flags are set (they default to
      * true); this build trains iff the field will be queried. */
     r->training = params->surfaceguiding || params->volumeguiding || params->vspsecondaryguiding;
@@ -2635,6 +2666,7 @@ void oracle_renderer_destroy(OracleRenderer *r) {
     if (!r) return;
     free_field(r, 0); free_field(r, 1);
     free(r->samples);
+    free(r->trbuf); free(r->tr_spp);
     free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {
@@ -2652,6 +2684,19 @@ void oracle_vsp_buffer_read(OracleRenderer *r, float *vsp, int *is_ready) {
 void oracle_vsp_buffer_write(OracleRenderer *r, const float *vsp, int is_ready) {
     memcpy(r->vsp, vsp, (size_t)r->cfg.xres * r->cfg.yres * sizeof(float));
     r->vsp_ready = is_ready;
+}
+int oracle_tr_buffer_read(OracleRenderer *r, float *rgb) {
+    if (!r->trbuf) return VSPG_EINVAL;
+    memcpy(rgb, r->trbuf, (size_t)r->cfg.xres * r->cfg.yres * 3 * sizeof(float));
+    return 0;
+}
+int oracle_tr_buffer_write(OracleRenderer *r, const float *rgb) { /* TrBuffer(fileName) (:180-185) */
+    size_t npix = (size_t)r->cfg.xres * r->cfg.yres;
+    if (!r->trbuf) r->trbuf = (float *)calloc(npix * 3, sizeof(float));
+    memcpy(r->trbuf, rgb, npix * 3 * sizeof(float));
+    r->tr_load = 1;
+    r->tr_calc = 0;
+    return 0;
 }
 void oracle_isg_stats_read(OracleRenderer *r, float *stats) {
     memcpy(stats, r->isg_stats, (size_t)r->cfg.xres * r->cfg.yres * VSPG_ISG_STATS * sizeof(float));

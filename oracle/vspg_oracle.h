@@ -72,6 +72,10 @@ void oracle_film_clear(OracleRenderer *r);
 void oracle_vsp_buffer_read(OracleRenderer *r, float *vsp, int *is_ready);
 void oracle_vsp_buffer_write(OracleRenderer *r, const float *vsp, int is_ready);
 void oracle_isg_stats_read(OracleRenderer *r, float *stats);
+/* TrBuffer (cpu/trbuffer.h): read the running-mean transmittance (xres*yres*3, VSPG_EINVAL if none is kept);
+ * write = TrBuffer(fileName): the renderer then uses it (NDS+) and stops recording */
+int oracle_tr_buffer_read(OracleRenderer *r, float *rgb);
+int oracle_tr_buffer_write(OracleRenderer *r, const float *rgb);
 void oracle_get_counters(OracleRenderer *r, VspgCounters *out);
 void oracle_reset_counters(OracleRenderer *r);
 int oracle_trace_paths(OracleRenderer *r, int n, const int32_t *pixel_xy,

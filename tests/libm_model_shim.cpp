@@ -15,5 +15,8 @@ void libm_cosf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[
 // double log (the -std::log(1.0 - x) of the optical-depth-space sampling)
 void model_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::log_host_exact(x[i]); }
 void libm_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = log(x[i]); }
+// powf (the NDS+ collision-probability bias)
+void model_powf(int n, const float *x, const float *y, float *o) { for (int i = 0; i < n; ++i) o[i] = vspg_libm::powf_host_exact(x[i], y[i]); }
+void libm_powf(int n, const float *x, const float *y, float *o) { for (int i = 0; i < n; ++i) o[i] = powf(x[i], y[i]); }
 void libm_neg_log1m(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = (float)(-log(1.0 - (double)x[i])); }
 }

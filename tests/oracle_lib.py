@@ -48,6 +48,8 @@ def load():
         "oracle_film_clear": (None, [vp]),
         "oracle_vsp_buffer_read": (None, [vp, p(C.c_float), p(C.c_int)]),
         "oracle_vsp_buffer_write": (None, [vp, p(C.c_float), C.c_int]),
+        "oracle_tr_buffer_read": (C.c_int, [vp, p(C.c_float)]),
+        "oracle_tr_buffer_write": (C.c_int, [vp, p(C.c_float)]),
         "oracle_isg_stats_read": (None, [vp, p(C.c_float)]),
         "oracle_get_counters": (None, [vp, p(P.VspgCounters)]),
         "oracle_reset_counters": (None, [vp]),
@@ -142,6 +144,17 @@ class OracleRenderer:
     def set_vsp_buffer(self, vsp, ready=True):
         v = np.ascontiguousarray(vsp, dtype=np.float32)
         self.lib.oracle_vsp_buffer_write(self.h, v.ctypes.data_as(C.POINTER(C.c_float)), int(ready))
+
+    def tr_buffer(self):
+        out = np.empty((self.yres, self.xres, 3), dtype=np.float32)
+        rc = self.lib.oracle_tr_buffer_read(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        assert rc == 0, "the oracle renderer keeps no transmittance buffer"
+        return out
+
+    def set_tr_buffer(self, rgb):
+        v = np.ascontiguousarray(rgb, dtype=np.float32)
+        assert v.shape == (self.yres, self.xres, 3)
+        assert self.lib.oracle_tr_buffer_write(self.h, v.ctypes.data_as(C.POINTER(C.c_float))) == 0
 
     def isg_stats(self):
         out = np.empty((self.yres, self.xres, self.P.VSPG_ISG_STATS), dtype=np.float32)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
     assert {n for n, _, _ in pkg.SYMBOLS} == set(names)
-    assert lib.vspg_abi_version() == 2
+    assert lib.vspg_abi_version() == 3
 
 
 def test_defaults_match_reference_create_defaults(pkg):
@@ -64,7 +64,7 @@ def test_parameter_validation_and_no_cpu_fallback(pkg):
 
     cfg = pkg.VspgRenderConfig(32, 32, 1, 0, 0, 1, 0)
     prm = pkg.app_f_params()
-    prm.collisionProbabilityBias = 1
+    prm.rrguiding = 1
     assert create(prm, cfg) == pkg.VSPG_ESCOPE
     prm = pkg.app_f_params()
     prm.vspmisratio = 1.5

@@ -92,3 +92,50 @@ def test_guiding_cache_store_and_load(host_build, gpu_pkg, tmp_path):
     img = read_pfm(str(tmp_path / "b.pfm"))
     assert np.array_equal(img.view(np.uint32), ref.astype(np.float32).view(np.uint32))
     r.close()
+
+
+@pytest.mark.gpu
+def test_tr_buffer_store_and_load(host_build, gpu_pkg, tmp_path):
+    """The NDS+ workflow through the plugin surface: pass 1 (resampling + storeTrBuffer) writes the transmittance
+    buffer, pass 2 (NDS + collisionProbabilityBias + loadTrBuffer) renders with it -- both equal to the raw C-ABI."""
+    from scenes import grid_scene
+    W, H, spp = 64, 48, 6
+    trf = tmp_path / "tr.pfm"
+    exe = os.path.join(host_build, "example_render")
+    a = subprocess.run([exe, str(W), str(H), str(spp), str(tmp_path / "a.pfm"), "trstore", str(trf)], capture_output=True, text=True)
+    assert a.returncode == 0 and trf.exists(), a.stdout + a.stderr
+    b = subprocess.run([exe, str(W), str(H), str(spp), str(tmp_path / "b.pfm"), "trload", str(trf)], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout + b.stderr
+    P = gpu_pkg
+    n = 12
+    i, j, k = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    dens = np.ascontiguousarray((((i * 7 + j * 13 + k * 29) % 17) / 16.0).astype(np.float32).transpose(2, 1, 0))  # x fastest
+    scene = grid_scene(dens.ravel(), (n, n, n), (.02, .03, .04), (.5, .45, .4), g=0.3, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    prm = P.default_params()
+    prm.surfaceguiding = prm.volumeguiding = prm.vspsecondaryguiding = 0
+    prm.vspsamplingmethod = P.VSP_RESAMPLING
+    prm.storeTrBuffer = 1
+    r = P.Renderer(scene, prm, W, H)
+    for w in range(spp):
+        r.render_wave(w, w + 1)
+        r.post_process_wave()
+    tr, cnt = r.tr_buffer()
+    f = r.film()
+    r.close()
+    assert np.all(cnt == spp) and 0.3 < tr.mean() < 0.99
+    assert np.array_equal(read_pfm(str(trf)).view(np.uint32), tr.view(np.uint32))
+    assert np.array_equal(read_pfm(str(tmp_path / "a.pfm")).view(np.uint32), (f[..., :3] / f[..., 3:4]).astype(np.float32).view(np.uint32))
+    prm.vspsamplingmethod = P.VSP_NDS
+    prm.storeTrBuffer = 0
+    prm.collisionProbabilityBias = 1
+    r = P.Renderer(scene, prm, W, H)
+    r.set_tr_buffer(tr)
+    for w in range(spp):
+        r.render_wave(w, w + 1)
+        r.post_process_wave()
+    f = r.film()
+    r.close()
+    assert np.array_equal(read_pfm(str(tmp_path / "b.pfm")).view(np.uint32), (f[..., :3] / f[..., 3:4]).astype(np.float32).view(np.uint32))
+    # a missing file is the reference's warning, not an error (:186)
+    c = subprocess.run([exe, str(W), str(H), "1", str(tmp_path / "c.pfm"), "trload", str(tmp_path / "none.pfm")], capture_output=True, text=True)
+    assert c.returncode == 0 and "Tr buffer file does not exists" in c.stderr

@@ -78,6 +78,41 @@ def test_double_log_equals_host_libm(shim):
                       np.nextafter(1.0 + float.fromhex('0x1.09p-4'), 0), 2.0 ** -24, 2.0 ** -1022, 1.7e308, 0.5, 2.0]))
 
 
+def test_powf_equals_host_libm(shim):
+    """powf_host_exact vs the running libm's powf: the NDS+ arguments (x = sigma_t/sigma_maj in [0, 1],
+    y = 1/(1+Tr) in [0.5, 1]), wide random ranges, and every special-case class of e_powf.c."""
+    rng = np.random.default_rng(5)
+    fp = C.POINTER(C.c_float)
+
+    def check2(x, y):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        a, b = np.empty_like(x), np.empty_like(x)
+        shim.model_powf(x.shape[0], x.ctypes.data_as(fp), y.ctypes.data_as(fp), a.ctypes.data_as(fp))
+        shim.libm_powf(x.shape[0], x.ctypes.data_as(fp), y.ctypes.data_as(fp), b.ctypes.data_as(fp))
+        both_nan = np.isnan(a) & np.isnan(b)
+        bad = np.nonzero((a.view(np.uint32) != b.view(np.uint32)) & ~both_nan)[0]
+        assert bad.size == 0, "powf: %d mismatches, e.g. x=%r y=%r model=%r libm=%r" % (
+            bad.size, x[bad[:3]], y[bad[:3]], a[bad[:3]], b[bad[:3]])
+
+    n = 4_000_000
+    check2(rng.uniform(0, 1, n), np.float32(1) / (np.float32(1) + rng.uniform(0, 1, n).astype(np.float32)))
+    check2(rng.uniform(0, 1.0001, n), rng.uniform(0.4, 1.1, n))
+    check2(np.exp(rng.uniform(-88, 88, n)), rng.uniform(-3, 3, n))
+    check2(np.exp(rng.uniform(-104, -80, n)), rng.uniform(-1.5, 1.5, n))        # subnormal x, results near under/overflow
+    check2(np.exp(rng.uniform(-5, 5, n)), rng.uniform(-40, 40, n))              # |y log2 x| around 126..150
+    check2(-np.exp(rng.uniform(-5, 5, n)), rng.integers(-40, 40, n).astype(np.float32))   # negative x, integer y
+    check2(-np.exp(rng.uniform(-5, 5, 1000)), rng.uniform(-4, 4, 1000))         # negative x, non-integer y -> NaN
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 0.5, -0.5, 2.0, -2.0, 3.0, -3.0, 1e-45, -1e-45,
+                   3.4e38, -3.4e38, 2.0 ** -126, 2.0 ** 24, 2.0 ** 24 + 2, float.fromhex('0x1.fffffep-1')], dtype=np.float32)
+    X, Y = np.meshgrid(sp, sp)
+    check2(X.ravel(), Y.ravel())
+    # every float x in one binade against a few exponents (table-index boundaries of log2_inline)
+    bits = np.arange(0x3f000000, 0x3f800000, 7, dtype=np.uint32)
+    for yv in (0.5, 0.75, 1.0, float.fromhex('0x1.fffffep-1')):
+        check2(bits.view(np.float32), np.full(bits.shape, yv, dtype=np.float32))
+
+
 @pytest.mark.parametrize("fn", ["sinf", "cosf"])
 def test_sincos_equal_host_libm(shim, fn):
     rng = np.random.default_rng(1)

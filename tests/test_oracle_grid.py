@@ -192,3 +192,82 @@ def test_nvdb_trilinear_is_index_space_with_zero_background():
         seen += 1
     assert seen > 50
     r.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# TrBuffer + NDS+ (cpu/trbuffer.h, guidedvolpathvspgintegrator.cpp:727-728, 929-938, 975-976, 1072-1073)
+# ---------------------------------------------------------------------------------------------
+def _tr_scene(P, W, H, seed=11, n=10):
+    rng = np.random.default_rng(seed)
+    dens = np.clip(rng.random(n ** 3).astype(np.float32) * 1.5 - 0.25, 0, None).astype(np.float32)
+    # thin: NDS (hence NDS+) only acts where the wanted scatter probability exceeds 1 - exp(-tau_maj)
+    return grid_scene(P, dens, (n, n, n), 0.02, 0.33, g=0.2, bmin=(-0.8, -0.8, -0.6), bmax=(0.8, 0.6, 0.9), W=W, H=H), dens
+
+
+def test_tr_buffer_is_the_running_mean_of_the_primary_transmittance_estimates():
+    P = load_package()
+    W, H = 24, 18
+    scene, dens = _tr_scene(P, W, H)
+    prm = oracle_lib.app_f_params()
+    prm.vspsamplingmethod = P.VSP_RESAMPLING
+    prm.storeTrBuffer = 1
+    per_wave = []
+    for w in range(3):  # wave w alone: the estimate of sample w (the VSP buffer is not ready before wave 1's update)
+        r = oracle_lib.OracleRenderer(scene, prm, W, H)
+        r.render_wave(w, w + 1)
+        per_wave.append(r.tr_buffer())
+        r.close()
+    r = oracle_lib.OracleRenderer(scene, prm, W, H)
+    r.render_wave(0, 3)
+    tr = r.tr_buffer()
+    r.close()
+    assert np.all(tr >= 0) and np.all(tr <= 1) and 0.05 < tr.mean() < 0.95
+    assert np.allclose(tr, np.mean(per_wave, axis=0), atol=2e-6)
+    # without the flag (and without NDS+) no buffer is kept
+    prm.storeTrBuffer = 0
+    r = oracle_lib.OracleRenderer(scene, prm, W, H)
+    with pytest.raises(AssertionError):
+        r.tr_buffer()
+    r.close()
+
+
+def test_nds_plus_is_unbiased_and_changes_the_collision_decisions():
+    """NDS+ biases the primary ray's real/null-collision probability by the cached transmittance and compensates
+    in r_u: the image mean must stay that of plain NDS, while individual paths differ."""
+    P = load_package()
+    W, H = 40, 30
+    scene, dens = _tr_scene(P, W, H, seed=12)
+    # pass 1 (reference workflow): resampling + storeTrBuffer
+    prm = oracle_lib.app_f_params()
+    prm.vspsamplingmethod = P.VSP_RESAMPLING
+    prm.storeTrBuffer = 1
+    r = oracle_lib.OracleRenderer(scene, prm, W, H)
+    r.render_wave(0, 16)
+    tr = r.tr_buffer()
+    r.close()
+    means, films = [], []
+    for bias in (0, 1):
+        prm = oracle_lib.app_f_params()
+        prm.vspsamplingmethod = P.VSP_NDS
+        prm.collisionProbabilityBias = bias
+        r = oracle_lib.OracleRenderer(scene, prm, W, H)
+        if bias:
+            r.set_tr_buffer(tr)
+        r.render_wave(0, 160)  # (no PostProcessWave: the primary VSP stays 0.5, where NDS acts on most rays of this scene)
+        f = r.film_f64()
+        films.append(f[..., :3] / f[..., 3:4])
+        means.append(films[-1].reshape(-1, 3).mean(0))
+        r.close()
+    assert np.allclose(means[0], means[1], rtol=0.03), means
+    assert np.mean(np.abs(films[0] - films[1]) > 1e-6) > 0.5  # not the same paths
+    # requested but no buffer handed over: the renderer records (nothing, under NDS) and behaves like plain NDS
+    prm = oracle_lib.app_f_params()
+    prm.vspsamplingmethod = P.VSP_NDS
+    prm.collisionProbabilityBias = 1
+    a = oracle_lib.OracleRenderer(scene, prm, W, H)
+    prm.collisionProbabilityBias = 0
+    b = oracle_lib.OracleRenderer(scene, prm, W, H)
+    a.render_wave(0, 2); b.render_wave(0, 2)
+    assert np.array_equal(a.film_f64(), b.film_f64())
+    assert np.all(a.tr_buffer() == 0)
+    a.close(); b.close()

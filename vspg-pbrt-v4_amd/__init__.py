@@ -62,7 +62,7 @@ class VspgIntegratorParams(C.Structure):
                 ("vspcriterion", C.c_int32), ("vspsamplingmethod", C.c_int32),
                 ("collisionProbabilityBias", C.c_int32), ("rrguiding", C.c_int32),
                 ("lightsampler", C.c_int32), ("regularize", C.c_int32),
-                ("guide_num_training_waves", C.c_int32)]
+                ("guide_num_training_waves", C.c_int32), ("storeTrBuffer", C.c_int32)]
 
 
 class VspgRenderConfig(C.Structure):
@@ -156,6 +156,9 @@ SYMBOLS = [
                                                   _P(C.c_int32), _vp]),
     ("vspg_libm_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
     ("vspg_libm_log1m_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _vp]),
+    ("vspg_libm_powf_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
+    ("vspg_renderer_get_tr_buffer", C.c_int, [_vp, _P(C.c_float), _P(C.c_int32), _vp]),
+    ("vspg_renderer_set_tr_buffer", C.c_int, [_vp, _P(C.c_float), _vp]),
     ("vspg_renderer_set_guiding_field", C.c_int, [_vp, _P(VspgField), _P(VspgField), _vp]),
     ("vspg_guiding_query_batch", C.c_int, [_vp, C.c_int, C.c_float, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float),
                                           _P(C.c_float), _P(C.c_int32), _P(C.c_float), _P(C.c_float), _P(C.c_float),
@@ -329,6 +332,31 @@ class Renderer:
         _check(self.lib, self.lib.vspg_vsp_buffer_read(self.h, out.ctypes.data_as(_P(C.c_float)), C.byref(ready),
                                                       _vp(stream or 0)))
         return out, bool(ready.value)
+
+    def tr_buffer(self, stream=None):
+        """TrBuffer read-back: (rgb (H, W, 3) float32, spp (H, W) int32)."""
+        import numpy as np
+        rgb = np.empty((self.yres, self.xres, 3), dtype=np.float32)
+        spp = np.empty((self.yres, self.xres), dtype=np.int32)
+        _check(self.lib, self.lib.vspg_renderer_get_tr_buffer(self.h, rgb.ctypes.data_as(_P(C.c_float)),
+                                                             spp.ctypes.data_as(_P(C.c_int32)), _vp(stream or 0)))
+        return rgb, spp
+
+    def set_tr_buffer(self, rgb, stream=None):
+        import numpy as np
+        v = np.ascontiguousarray(rgb, dtype=np.float32)
+        assert v.shape == (self.yres, self.xres, 3)
+        _check(self.lib, self.lib.vspg_renderer_set_tr_buffer(self.h, v.ctypes.data_as(_P(C.c_float)), _vp(stream or 0)))
+
+    def libm_powf_batch(self, x, y):
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        out = np.empty_like(x)
+        fp = _P(C.c_float)
+        _check(self.lib, self.lib.vspg_libm_powf_batch(self.h, x.shape[0], x.ctypes.data_as(fp), y.ctypes.data_as(fp),
+                                                      out.ctypes.data_as(fp), _vp(0)))
+        return out
 
     def counters(self, stream=None):
         c = VspgCounters()

@@ -927,6 +927,10 @@ __global__ __launch_bounds__(kBlock) void k_libm(int n, const float *__restrict_
     so[i] = sinf_(x[i]);
     co[i] = cosf_(x[i]);
 }
+__global__ __launch_bounds__(kBlock) void k_libm_powf(int n, const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = vspg_libm::powf_host_exact(x[i], y[i]);
+}
 __global__ __launch_bounds__(kBlock) void k_libm_log1m(int n, const float *__restrict__ x, float *__restrict__ out) {
     int i = blockIdx.x * kBlock + threadIdx.x;
     vspg_libm::stage_log_tab_lds();
@@ -993,6 +997,8 @@ struct VspgRenderer {
     DScene *dscene = nullptr;
     float4 *film = nullptr;
     float *isg_stats = nullptr;
+    float *tr_rgb = nullptr;      // TrBuffer: W*H*3 running mean, W*H sample counts
+    int32_t *tr_spp = nullptr;
     float *vsp = nullptr;
     unsigned long long *counters = nullptr;
     unsigned int *work_head = nullptr;
@@ -1227,7 +1233,6 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         return fail(VSPG_EINVAL, "shard_index out of range");
     if (p->maxdepth < 0) return fail(VSPG_EINVAL, "maxdepth must be >= 0");
     if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
-    if (p->collisionProbabilityBias) return fail(VSPG_ESCOPE, "collisionProbabilityBias (NDS+ / TrBuffer) is outside the hot-path scope");
     if (p->rrguiding) return fail(VSPG_ESCOPE, "rrguiding (guided Russian roulette) is outside the hot-path scope");
     if (scene->medium.type == VSPG_MEDIUM_GRID || scene->medium.type == VSPG_MEDIUM_NANOVDB) {
         const VspgMedium &m = scene->medium;
@@ -1404,6 +1409,18 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         CK(hipGetDeviceProperties(&prop, cfg->device));
         r->num_cus = prop.multiProcessorCount;
     }
+    // calculateTrBuffer (guidedvolpathvspgintegrator.cpp:190-193); trBufferLoad is vspg_renderer_set_tr_buffer
+    if (r->prm.storeTrBuffer || (r->prm.vspguiding && r->prm.vspprimaryguiding && r->prm.vspsamplingmethod == VSPG_VSP_NDS &&
+                                 r->prm.collisionProbabilityBias)) {
+        CK(hipMalloc(&r->tr_rgb, r->npix * 3 * sizeof(float)));
+        CK(hipMemset(r->tr_rgb, 0, r->npix * 3 * sizeof(float)));
+        CK(hipMalloc(&r->tr_spp, r->npix * sizeof(int32_t)));
+        CK(hipMemset(r->tr_spp, 0, r->npix * sizeof(int32_t)));
+        r->hscene.tr_rgb = r->tr_rgb;
+        r->hscene.tr_spp = r->tr_spp;
+        r->hscene.tr_calc = 1;
+        CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
+    }
     // guideTraining (guidedvolpathvspgintegrator.cpp:109).  The reference also trains when only the guided-RR
     // flags are set (they default to true); this build trains iff the field will be queried.
     if (wants_guiding(r->prm)) {
@@ -1447,6 +1464,8 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->dscene) (void)hipFree(r->dscene);
     if (r->film) (void)hipFree(r->film);
     if (r->isg_stats) (void)hipFree(r->isg_stats);
+    if (r->tr_rgb) (void)hipFree(r->tr_rgb);
+    if (r->tr_spp) (void)hipFree(r->tr_spp);
     if (r->vsp) (void)hipFree(r->vsp);
     if (r->counters) (void)hipFree(r->counters);
     if (r->work_head) (void)hipFree(r->work_head);
@@ -1521,7 +1540,8 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     // -- and for guided builds.  VSPG_KERNEL=wg|lane overrides (unguided builds only).
     const char *kenv = getenv("VSPG_KERNEL");
     const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
-    const bool use_wg = !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0);
+    // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
+    const bool use_wg = !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
     if (use_wg) {
         const unsigned tiles_magic = tilesX > 1 ? (unsigned)((0x100000000ull + (unsigned)tilesX - 1) / (unsigned)tilesX) : 0u;
         const int wwaves = grid ? kWgWavesGrid : kWgWavesHomog, wblock = grid ? kWgBlockGrid : kWgBlockHomog;
@@ -1671,6 +1691,35 @@ int vspg_vsp_buffer_read(VspgRenderer *r, float *host, int *is_ready, void *stre
     if (is_ready) *is_ready = r->vsp_ready;
     return 0;
 }
+// TrBuffer (cpu/trbuffer.h): read-back = what Store() writes, set = TrBuffer(fileName) / Load()
+int vspg_renderer_get_tr_buffer(VspgRenderer *r, float *host_rgb, int32_t *host_spp, void *stream) {
+    if (!r || !host_rgb) return fail(VSPG_EINVAL, "null argument");
+    if (!r->tr_rgb) return fail(VSPG_EINVAL, "the renderer keeps no transmittance buffer (storeTrBuffer / NDS+ not requested)");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    HIPCHK(hipMemcpyAsync(host_rgb, r->tr_rgb, r->npix * 3 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (host_spp) {
+        if (r->tr_spp) HIPCHK(hipMemcpyAsync(host_spp, r->tr_spp, r->npix * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        else memset(host_spp, 0, r->npix * sizeof(int32_t));
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int vspg_renderer_set_tr_buffer(VspgRenderer *r, const float *host_rgb, void *stream) {
+    if (!r || !host_rgb) return fail(VSPG_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!r->tr_rgb) HIPCHK(hipMalloc(&r->tr_rgb, r->npix * 3 * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(r->tr_rgb, host_rgb, r->npix * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+    // trBufferLoad = true, calculateTrBuffer = false (:182-184).  Only these members are rewritten: the field
+    // counters of the device-side scene belong to the training kernels.
+    r->hscene.tr_rgb = r->tr_rgb;
+    r->hscene.tr_calc = 0;
+    r->hscene.tr_load = 1;
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(r->dscene) + offsetof(DScene, tr_rgb), &r->hscene.tr_rgb,
+                          sizeof(DScene) - offsetof(DScene, tr_rgb), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
 int vspg_isg_stats_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
     if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
     *dev_ptr = r->isg_stats;
@@ -1721,7 +1770,7 @@ int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy, const int3
     if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but no guiding field uploaded");
 #define VSPG_LAUNCH_TRACE(M, G)                                                                                       \
     hipLaunchKernelGGL((k_trace_paths<M, G>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp, \
-                       r->vsp_ready, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p)
+                       r->vsp_ready | VSP_NO_FEED, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p)
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     if (nvdb && guided) VSPG_LAUNCH_TRACE(NanoDenseMedium, true);
     else if (nvdb) VSPG_LAUNCH_TRACE(NanoDenseMedium, false);
@@ -1877,6 +1926,24 @@ int vspg_libm_batch(VspgRenderer *r, int n, const float *x, float *logf_out, flo
     HIPCHK(hipMemcpyAsync(logf_out, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(sinf_out, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(cosf_out, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_libm_powf_batch(VspgRenderer *r, int n, const float *x, const float *y, float *out, void *stream) {
+    if (!r || !x || !y || !out || n <= 0) return fail(VSPG_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dx, dy, dout;
+    HIPCHK(hipMalloc(&dx.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dy.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dout.p, (size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dy.p, y, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_libm_powf, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, (const float *)dx.p, (const float *)dy.p,
+                       (float *)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }

@@ -482,7 +482,15 @@ struct DScene {
     VspgIntegratorParams prm;
     // render config
     int32_t xres, yres, seed, shard_index, shard_count;
+    // TrBuffer (cpu/trbuffer.h): running mean of the primary rays' ratio-tracking transmittance, RGB per pixel;
+    // tr_calc = calculateTrBuffer (the resampling routine records), tr_load = trBufferLoad (NDS+ reads)
+    float *tr_rgb;
+    int32_t *tr_spp;
+    int32_t tr_calc, tr_load;
 };
+// vsp_ready as handed to the path functions: bit 0 = the VSP buffer holds estimates; bit 1 = a debug path trace
+// (vspg_trace_paths), which does not feed the per-pixel buffers
+enum { VSP_READY = 1, VSP_NO_FEED = 2 };
 
 // Rectangle records that are indexed PER LANE (the rectangle a lane hit, the light it sampled) are
 // read from an LDS copy: through the DScene in HBM each such access is a vector load with a full

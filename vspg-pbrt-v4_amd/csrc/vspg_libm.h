@@ -254,6 +254,127 @@ VSPG_HD double log_host_exact(double x) {
     return __builtin_fma(r3, p, q) + hi;
 }
 
+// ---- powf ---------------------------------------------------------------------------------
+// The NDS+ collision-probability bias calls std::pow(float, float) (guidedvolpathvspgintegrator.cpp:937).
+// glibc 2.35's powf (sysdeps/ieee754/flt-32/e_powf.c, optimized-routines): log2 through a 16-entry
+// {invc, logc} table + degree-5 polynomial in double, exp2 through a 32-entry table + degree-3
+// polynomial, one rounding to float at the end; operation order and fusing of the x86-64 `__powf_fma`
+// ifunc variant, round-to-nearest.  Complete over all float arguments (special cases included).
+VSPG_HD double powf_log2_tab_entry(int j) {  // __powf_log2_data.tab: entry i = {T[2i] invc, T[2i+1] logc}
+    static const double T[32] = {
+        0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2, 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2,
+        0x1.49539f0f010bp+0,  -0x1.7418b0a1fb77bp-2, 0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2,
+        0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2, 0x1.25e227b0b8eap+0,  -0x1.97c1d1b3b7afp-3,
+        0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3, 0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4,
+        0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5, 0x1p+0,               0x0p+0,
+        0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4,  0x1.ca4b31f026aap-1,  0x1.476a9543891bap-3,
+        0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3,  0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2,
+        0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2,  0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2,
+    };
+    return T[j];
+}
+VSPG_HD uint64_t exp2f_tab_entry(int j) {  // __exp2f_data.tab
+    static const uint64_t T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+        0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+        0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+        0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+        0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+    };
+    return T[j];
+}
+// checkint (e_powf.c): 0 = y is not an integer, 1 = odd integer, 2 = even integer
+VSPG_HD int powf_checkint(uint32_t iy) {
+    const int e = (int)(iy >> 23 & 0xff);
+    if (e < 0x7f) return 0;
+    if (e > 0x7f + 23) return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+    if (iy & (1u << (0x7f + 23 - e))) return 1;
+    return 2;
+}
+VSPG_HD bool powf_zeroinfnan(uint32_t ix) { return 2u * ix - 1u >= 2u * 0x7f800000u - 1u; }
+VSPG_HD float powf_host_exact(float x, float y) {
+    uint32_t sign_bias = 0;
+    uint32_t ix = asuint(x);
+    const uint32_t iy = asuint(y);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || powf_zeroinfnan(iy)) {
+        // x < 0x1p-126 or inf or nan, or y is 0 or inf or nan
+        if (powf_zeroinfnan(iy)) {
+            if (2u * iy == 0) return 1.0f;                 // (signalling NaNs are not distinguished)
+            if (ix == 0x3f800000u) return 1.0f;
+            if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y;
+            if (2u * ix == 2u * 0x3f800000u) return 1.0f;
+            if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;  // |x|<1 && y==inf or |x|>1 && y==-inf
+            return y * y;
+        }
+        if (powf_zeroinfnan(ix)) {
+            float x2 = x * x;
+            if ((ix & 0x80000000u) && powf_checkint(iy) == 1) {
+                x2 = -x2;
+                sign_bias = 1;
+            }
+            if (2u * ix == 0 && (iy & 0x80000000u)) return sign_bias ? -__builtin_inff() : __builtin_inff();  // __math_divzerof
+            return (iy & 0x80000000u) ? 1 / x2 : x2;
+        }
+        // x and y are non-zero finite
+        if (ix & 0x80000000u) {
+            const int yint = powf_checkint(iy);
+            if (yint == 0) return __builtin_nanf("");      // __math_invalidf
+            if (yint == 1) sign_bias = 1u << 16;           // SIGN_BIAS = 1 << (EXP2F_TABLE_BITS + 11)
+            ix &= 0x7fffffffu;
+        }
+        if (ix < 0x00800000u) {  // normalise a subnormal x
+            ix = asuint(asfloat(ix) * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    // log2_inline
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)top >> 23;
+    const double invc = powf_log2_tab_entry(2 * i), logc = powf_log2_tab_entry(2 * i + 1);
+    const double z = (double)asfloat(iz);
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2,
+                 A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp+0;
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double ya = __builtin_fma(A0, r, A1);
+    const double pp = __builtin_fma(A2, r, A3);
+    const double r2 = r * r;
+    double q = __builtin_fma(A4, r, y0);
+    const double r4 = r2 * r2;
+    q = __builtin_fma(pp, r2, q);
+    const double logx = __builtin_fma(ya, r4, q);
+    const double ylogx = (double)y * logx;
+    if ((asuint64(ylogx) >> 47 & 0xffffu) >= (0x405f800000000000ull >> 47)) {  // |y log2 x| >= 126
+        if (ylogx > 0x1.fffffffd1d571p+6) return sign_bias ? -__builtin_inff() : __builtin_inff();  // __math_oflowf
+        if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;                                       // __math_uflowf
+        if (ylogx < -149.0) return sign_bias ? -0x1p-149f : 0x1p-149f;  // __math_may_uflowf: (0x1.4p-75f)^2 rounded
+    }
+    // exp2_inline
+    const double SHIFT = 0x1.8p47;  // 0x1.8p52 / 32
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    double kd = ylogx + SHIFT;
+    const uint64_t ki = asuint64(kd);
+    kd -= SHIFT;
+    const double rr = ylogx - kd;
+    uint64_t t = exp2f_tab_entry((int)(ki & 31u));
+    const uint64_t ski = ki + sign_bias;
+    t += ski << 47;
+    const double sc = asdouble(t);
+    const double zz = __builtin_fma(C0, rr, C1);
+    const double rr2 = rr * rr;
+    double yy = __builtin_fma(C2, rr, 1.0);
+    yy = __builtin_fma(zz, rr2, yy);
+    return (float)(yy * sc);
+}
+
 // ---- sinf / cosf --------------------------------------------------------------------------
 // __sincosf_table (glibc 2.35 sysdeps/ieee754/flt-32/s_sincosf_data.c); table 1 = table 0 with the
 // cosine coefficients negated (used when bit 1 of the quadrant is set)

@@ -394,6 +394,17 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
         float tm = ch_of(T_maj, ch);
         beta_rs = beta_rs * (T_maj / tm);
         r_u_rs = r_u_rs * (T_maj / tm);
+        if (st.depth == 0 && S.tr_calc && !(vsp_ready & VSP_NO_FEED)) {  // trBuffer->AddSample (:727-728, trbuffer.h:40-45)
+            // one lane owns the pixel for the whole launch and runs its samples in order (k_render_wave)
+            const size_t pix = (size_t)py * S.xres + px;
+            const int n = S.tr_spp[pix] + 1;
+            S.tr_spp[pix] = n;
+            const float alpha = 1.f / (float)n;
+            float *t = S.tr_rgb + pix * 3;
+            t[0] = (1.f - alpha) * t[0] + alpha * trRatioEst.r;
+            t[1] = (1.f - alpha) * t[1] + alpha * trRatioEst.g;
+            t[2] = (1.f - alpha) * t[2] + alpha * trRatioEst.b;
+        }
         float trScalar = ch_of(trRatioEst, ch);
         float surf_wi = trScalar;
         if (guide && trScalar < 1 && trScalar > 0 && weightSum > 0) {
@@ -449,7 +460,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
 #endif
     Spec r_u_factor = sp(1.f);  // beta_factor is never written by the reference (always 1)
     float u = sampler.get1d();
-    auto on_collision = [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+    auto on_collision = [&](V3 p, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool activateNDS) {
             pc.density_query();
             if (!nonzero(st.beta)) {
                 ev.kind = EV_TERMINATE;
@@ -463,6 +474,17 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
             }
             Spec sigma_t = mp.sigma_t;
             float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
+            // NDS+ (:929-938): bias the real/null-collision probability of the PRIMARY ray by the cached transmittance.
+            // With a homogeneous medium pScatter == 1 and every NDS+ factor is exactly 1: compiled out.
+            bool NDS_plus = false;
+            if constexpr (!Medium::kAlwaysRealCollision && SEG != SEG_SECONDARY) {
+                if (st.depth == 0 && S.prm.vspsamplingmethod == VSPG_VSP_NDS && S.prm.collisionProbabilityBias && S.tr_load && activateNDS) {
+                    NDS_plus = true;
+                    const float trEstCache = S.tr_rgb[((size_t)py * S.xres + px) * 3 + ch];
+                    const float gamma = 1 + trEstCache;
+                    pScatter = vspg_libm::powf_host_exact(pScatter, 1 / gamma);
+                }
+            }
             float pNull = fmax_(0.f, 1 - pScatter);
             float um = rng.uniform();
             // Medium::kAlwaysRealCollision: the draw cannot change the outcome (see HomogeneousMedium), and
@@ -481,6 +503,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
                 st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
                 st.r_u = st.r_u * (T_maj * sigma_t / pdf);
+                if (NDS_plus) st.r_u = st.r_u * (sigma_maj * pScatter / sigma_t);  // :975-976
                 st.r_u = st.r_u * r_u_factor;
                 if constexpr (kRec) {  // :978-986 (beta_factor is 1)
                     tw = tw * ((T_maj * mp.sigma_s) / pdf);
@@ -503,6 +526,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                     if constexpr (kRec) tw = sp(0.f);
                 }
                 st.r_u = st.r_u * (T_maj * sigma_n / pdf);
+                if (NDS_plus) st.r_u = st.r_u * (sigma_maj * (1 - pScatter) / sigma_n);  // :1072-1073
                 st.r_l = st.r_l * (T_maj * sigma_maj / pdf);
                 return nonzero(st.beta) && nonzero(st.r_u);
             }
@@ -1040,13 +1064,13 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
 VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, PathState &st, int *ch, IsgSample &isg);
 VDEV void start_path(const DScene &S, const float *vsp_buf, int vsp_ready, int px, int py, int sampleIndex, Sampler &sampler,
                      PathState &st, int *ch, IsgSample &isg) {
-    st.vsp0 = vsp_ready ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
+    st.vsp0 = (vsp_ready & VSP_READY) ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
     sampler.start_pixel_sample(px, py, S.seed, sampleIndex);
     start_path_common(S, px, py, sampler, st, ch, isg);
 }
 VDEV void start_path(const DScene &S, const float *vsp_buf, int vsp_ready, int px, int py, PcgJump jump, Sampler &sampler,
                      PathState &st, int *ch, IsgSample &isg) {
-    st.vsp0 = vsp_ready ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
+    st.vsp0 = (vsp_ready & VSP_READY) ? vsp_buf[(size_t)py * S.xres + px] : 0.5f;
     sampler.start_pixel_sample(px, py, S.seed, jump);
     start_path_common(S, px, py, sampler, st, ch, isg);
 }

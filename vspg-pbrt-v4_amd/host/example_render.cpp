@@ -1,12 +1,15 @@
 // example_render.cpp -- the scene-file lines of SURVEY.md App. F expressed through the host adapter:
 //   Integrator "guidedvolpathvspg" "integer maxdepth" 5 "bool vspguiding" true "bool surfaceguiding" false ...
 //   MakeNamedMedium "fog" "string type" "homogeneous" "rgb sigma_a" [.05 .05 .05] "rgb sigma_s" [.45 .45 .45] "float g" 0
-// usage: example_render [xres yres spp out.pfm [train|load cachefile]]
+// usage: example_render [xres yres spp out.pfm [train|load cachefile | trstore|trload tr.pfm]]
 //   train: the reference's default guiding options (cfg 5: the field trains in-loop) + "bool storeGuidingCache" true
 //   load:  the same options + "bool loadGuidingCache" true (no training, guidedvolpathvspgintegrator.cpp:117-122)
+//   trstore / trload: the NDS+ workflow on a thin 12^3 "uniformgrid" medium -- pass 1 "vspsamplingmethod" resampling +
+//          "bool storeTrBuffer" true, pass 2 "vspsamplingmethod" nds + "bool collisionProbabilityBias" true + "bool loadTrBuffer" true
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "vspg_host.h"
 
@@ -23,7 +26,25 @@ int main(int argc, char **argv) {
                                                              .Float("g", 0.f));
         vspg::ParameterDictionary ip;
         const std::string mode = argc > 6 ? argv[5] : "";
-        if (mode == "train" || mode == "load") {
+        std::vector<float> densityStorage;
+        if (mode == "trstore" || mode == "trload") {
+            const int n = 12;
+            std::vector<float> d((size_t)n * n * n);
+            for (int k = 0; k < n; ++k)
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) d[((size_t)k * n + j) * n + i] = (float)((i * 7 + j * 13 + k * 29) % 17) / 16.f;
+            scene.medium = vspg::CreateMedium("uniformgrid", vspg::ParameterDictionary()
+                                                                 .Int("nx", n).Int("ny", n).Int("nz", n)
+                                                                 .FloatArray("density", d)
+                                                                 .Point3("p0", -0.8f, -0.8f, -0.5f).Point3("p1", 0.8f, 0.7f, 0.9f)
+                                                                 .RGB("sigma_a", .02f, .03f, .04f).RGB("sigma_s", .5f, .45f, .4f)
+                                                                 .Float("g", 0.3f),
+                                             &densityStorage);
+            ip.Int("maxdepth", 5).Bool("vspguiding", true).Bool("surfaceguiding", false).Bool("volumeguiding", false)
+                .Bool("vspsecondaryguiding", false).String("trBufferFileName", argv[6]);
+            if (mode == "trstore") ip.String("vspsamplingmethod", "resampling").Bool("storeTrBuffer", true);
+            else ip.String("vspsamplingmethod", "nds").Bool("collisionProbabilityBias", true).Bool("loadTrBuffer", true);
+        } else if (mode == "train" || mode == "load") {
             ip.Int("maxdepth", 5).Bool("vspguiding", true);  // surface / volume / secondary-VSP guiding default to true
             ip.Bool(mode == "train" ? "storeGuidingCache" : "loadGuidingCache", true).String("guidingCacheFileName", argv[6]);
         } else {

@@ -49,7 +49,6 @@ int main() {
     CHECK(throws([&] { Integrator::Create("guidedvolpath", ParameterDictionary(), scene, 16, 16, 1); }));
     // out-of-scope options are refused loudly, before any device work
     CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("rrguiding", true), scene, 16, 16, 1); }));
-    CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("collisionProbabilityBias", true), scene, 16, 16, 1); }));
     // the reference's parameter-list text (what cmd/nanovdb2pbrt prints for a grid) -> GridMedium::Create
     {
         const char *txt = "  \"integer nx\" 2 \"integer ny\" [ 3 ] \"integer nz\" 1   # comment\n"
@@ -100,6 +99,35 @@ int main() {
         CHECK(cs.store && !cs.load && cs.fileName == "x.fld");
         CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("loadGuidingCache", true)); }));  // no file name
         CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("storeISGBuffer", true)); }));    // still out of scope
+    }
+    // TrBuffer persistence (cpu/trbuffer.h Store / Load): PFM raster, bottom scanline first
+    {
+        TrBuffer tb;
+        tb.xres = 5; tb.yres = 3;
+        tb.rgb.resize(5 * 3 * 3);
+        for (size_t i = 0; i < tb.rgb.size(); ++i) tb.rgb[i] = 0.01f * (float)i;
+        const char *fn = "/tmp/vspg_host_selftest_tr.pfm";
+        tb.Store(fn);
+        TrBuffer rd = TrBuffer::Load(fn);
+        CHECK(rd.xres == 5 && rd.yres == 3 && rd.rgb == tb.rgb);
+        {  // the file's first raster row is the image's BOTTOM row
+            std::FILE *f = std::fopen(fn, "rb");
+            char hdr[32];
+            CHECK(f && std::fgets(hdr, sizeof hdr, f) && std::string(hdr) == "PF\n");
+            CHECK(std::fgets(hdr, sizeof hdr, f) && std::string(hdr) == "5 3\n");
+            CHECK(std::fgets(hdr, sizeof hdr, f) && std::string(hdr) == "-1.000000\n");
+            float first = -1;
+            CHECK(std::fread(&first, 4, 1, f) == 1 && first == tb.rgb[2 * 5 * 3]);
+            std::fclose(f);
+        }
+        std::remove(fn);
+        CHECK(throws([&] { tb.Store("/tmp/vspg_host_selftest_tr.exr"); }));
+        CHECK(throws([] { TrBuffer::Load("/tmp/vspg_no_such_tr.pfm"); }));
+        TrBufferSettings ts;
+        VspgIntegratorParams p = ParseIntegratorParams(
+            ParameterDictionary().Bool("storeTrBuffer", true).String("trBufferFileName", "t.pfm").Bool("collisionProbabilityBias", true), nullptr, &ts);
+        CHECK(ts.store && !ts.load && ts.fileName == "t.pfm" && p.storeTrBuffer == 1 && p.collisionProbabilityBias == 1);
+        CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("loadTrBuffer", true)); }));  // no file name
     }
     std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: ok\n", fails);
     return fails ? 1 : 0;

@@ -1,5 +1,6 @@
 #include "vspg_host.h"
 
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdlib>
@@ -193,7 +194,7 @@ VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p, s
 }
 
 // ---------------------------------------------------------------------------------------
-VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache) {
+VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache, TrBufferSettings *tr) {
     // GuidedVolPathVSPGIntegrator::Create (guidedvolpathvspgintegrator.cpp:1260-1322)
     VspgIntegratorParams p;
     vspg_integrator_params_default(&p);
@@ -223,9 +224,12 @@ VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters
     bool storeISG = parameters.GetOneBool("storeISGBuffer", false);
     bool loadISG = parameters.GetOneBool("loadISGBuffer", false);
     (void)parameters.GetOneString("isgBufferFileName", "");
-    bool storeTr = parameters.GetOneBool("storeTrBuffer", false);
-    bool loadTr = parameters.GetOneBool("loadTrBuffer", false);
-    (void)parameters.GetOneString("trBufferFileName", "");
+    TrBufferSettings ts;
+    ts.store = parameters.GetOneBool("storeTrBuffer", false);
+    ts.load = parameters.GetOneBool("loadTrBuffer", false);
+    ts.fileName = parameters.GetOneString("trBufferFileName", "");
+    if (tr) *tr = ts;
+    p.storeTrBuffer = ts.store;
     p.rrguiding = parameters.GetOneBool("rrguiding", false);
     (void)parameters.GetOneBool("surfacerrguiding", true);
     (void)parameters.GetOneBool("volumerrguiding", true);
@@ -235,8 +239,8 @@ VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters
     else if (ls == "bvh") p.lightsampler = VSPG_LIGHTSAMPLER_BVH;
     else throw Error("Light sample distribution type \"" + ls + "\" unknown.");
     p.regularize = parameters.GetOneBool("regularize", false);
-    if (storeISG || loadISG || storeTr || loadTr)
-        throw Error("ISG-buffer / Tr-buffer persistence is outside this build's scope");
+    if (storeISG || loadISG) throw Error("ISG-buffer persistence is outside this build's scope");
+    if ((ts.store || ts.load) && ts.fileName.empty()) throw Error("storeTrBuffer / loadTrBuffer need \"trBufferFileName\"");
     if ((cs.store || cs.load) && cs.fileName.empty()) throw Error("storeGuidingCache / loadGuidingCache need \"guidingCacheFileName\"");
     return p;
 }
@@ -265,14 +269,15 @@ std::unique_ptr<GuidedVolPathVSPGIntegrator> GuidedVolPathVSPGIntegrator::Create
                                                                                  const VspgScene &scene, int xres, int yres,
                                                                                  int pixelSamples, int seed, int device) {
     GuidingCacheSettings cache;
-    VspgIntegratorParams p = ParseIntegratorParams(parameters, &cache);
-    return std::make_unique<GuidedVolPathVSPGIntegrator>(p, scene, xres, yres, pixelSamples, seed, device, cache);
+    TrBufferSettings tr;
+    VspgIntegratorParams p = ParseIntegratorParams(parameters, &cache, &tr);
+    return std::make_unique<GuidedVolPathVSPGIntegrator>(p, scene, xres, yres, pixelSamples, seed, device, cache, tr);
 }
 
 GuidedVolPathVSPGIntegrator::GuidedVolPathVSPGIntegrator(const VspgIntegratorParams &p, const VspgScene &scene, int xres,
                                                          int yres, int pixelSamples, int seed, int device,
-                                                         const GuidingCacheSettings &cache)
-    : params(p), spp(pixelSamples), cacheSettings(cache) {
+                                                         const GuidingCacheSettings &cache, const TrBufferSettings &tr)
+    : params(p), spp(pixelSamples), cacheSettings(cache), trSettings(tr) {
     std::memset(&cfg, 0, sizeof cfg);
     cfg.xres = xres; cfg.yres = yres; cfg.spp = pixelSamples; cfg.seed = seed;
     cfg.shard_index = 0; cfg.shard_count = 1; cfg.device = device;
@@ -289,8 +294,35 @@ GuidedVolPathVSPGIntegrator::GuidedVolPathVSPGIntegrator(const VspgIntegratorPar
             throw Error("GuidedVolPathVSPGIntegrator: loading \"" + cacheSettings.fileName + "\": " + msg);
         }
     }
+    if (trSettings.load) {  // :180-188: a missing file is a warning, the render goes on without NDS+
+        std::FILE *probe = std::fopen(trSettings.fileName.c_str(), "rb");
+        if (!probe) {
+            std::fprintf(stderr, "Warning: Tr buffer file does not exists: trBufferFileName = %s\n", trSettings.fileName.c_str());
+        } else {
+            std::fclose(probe);
+            std::string msg;
+            try {
+                TrBuffer tb = TrBuffer::Load(trSettings.fileName);
+                if (tb.xres != xres || tb.yres != yres) msg = "resolution differs from the film's";
+                else if (vspg_renderer_set_tr_buffer(renderer, tb.rgb.data(), nullptr) != 0) msg = vspg_last_error();
+            } catch (const Error &e) {
+                msg = e.what();
+            }
+            if (!msg.empty()) {
+                vspg_renderer_destroy(renderer);
+                throw Error("GuidedVolPathVSPGIntegrator: loading \"" + trSettings.fileName + "\": " + msg);
+            }
+        }
+    }
 }
 GuidedVolPathVSPGIntegrator::~GuidedVolPathVSPGIntegrator() {
+    if (trSettings.store) {  // :219-221
+        try {
+            GetTrBuffer().Store(trSettings.fileName);
+        } catch (const Error &e) {
+            std::fprintf(stderr, "GuidedVolPathVSPGIntegrator: storing the transmittance buffer failed: %s\n", e.what());
+        }
+    }
     if (cacheSettings.store) {  // :210-213
         try {
             GetGuidingCache().Write(cacheSettings.fileName);
@@ -304,6 +336,58 @@ VspgTrainStats GuidedVolPathVSPGIntegrator::TrainingStats() {
     VspgTrainStats st;
     if (vspg_renderer_training_stats(renderer, &st, nullptr) != 0) throw Error(vspg_last_error());
     return st;
+}
+TrBuffer GuidedVolPathVSPGIntegrator::GetTrBuffer() {
+    TrBuffer tb;
+    tb.xres = cfg.xres; tb.yres = cfg.yres;
+    tb.rgb.resize((size_t)cfg.xres * cfg.yres * 3);
+    if (vspg_renderer_get_tr_buffer(renderer, tb.rgb.data(), nullptr, nullptr) != 0) throw Error(vspg_last_error());
+    return tb;
+}
+static bool has_pfm_extension(const std::string &fn) {
+    if (fn.size() < 4) return false;
+    std::string e = fn.substr(fn.size() - 4);
+    for (char &c : e) c = (char)std::tolower((unsigned char)c);
+    return e == ".pfm";
+}
+void TrBuffer::Store(const std::string &filename) const {
+    if (!has_pfm_extension(filename)) throw Error(filename + ": only the .pfm format of pbrt's Image class is supported (OpenEXR is absent)");
+    std::FILE *f = std::fopen(filename.c_str(), "wb");
+    if (!f) throw Error(filename + ": cannot open for writing");
+    std::fprintf(f, "PF\n%d %d\n-1.000000\n", xres, yres);
+    bool ok = true;
+    for (int y = yres - 1; y >= 0 && ok; --y)  // bottom scanline first
+        ok = std::fwrite(&rgb[(size_t)y * xres * 3], sizeof(float), (size_t)xres * 3, f) == (size_t)xres * 3;
+    ok = std::fclose(f) == 0 && ok;
+    if (!ok) throw Error(filename + ": write failed");
+}
+TrBuffer TrBuffer::Load(const std::string &filename) {
+    if (!has_pfm_extension(filename)) throw Error(filename + ": only the .pfm format of pbrt's Image class is supported (OpenEXR is absent)");
+    std::FILE *f = std::fopen(filename.c_str(), "rb");
+    if (!f) throw Error(filename + ": cannot open");
+    TrBuffer tb;
+    char magic[3] = {0, 0, 0};
+    float scale = 0;
+    bool ok = std::fscanf(f, "%2s %d %d %f", magic, &tb.xres, &tb.yres, &scale) == 4 && std::string(magic) == "PF" && tb.xres > 0 &&
+              tb.yres > 0 && tb.xres <= 32768 && tb.yres <= 32768 && scale != 0;
+    if (ok) ok = std::fgetc(f) != EOF;  // the single whitespace byte after the header
+    if (ok) {
+        tb.rgb.resize((size_t)tb.xres * tb.yres * 3);
+        for (int y = tb.yres - 1; y >= 0 && ok; --y)
+            ok = std::fread(&tb.rgb[(size_t)y * tb.xres * 3], sizeof(float), (size_t)tb.xres * 3, f) == (size_t)tb.xres * 3;
+    }
+    std::fclose(f);
+    if (!ok) throw Error(filename + ": not a 3-channel PFM image");
+    if (scale > 0)  // big-endian file
+        for (float &v : tb.rgb) {
+            unsigned char *b = reinterpret_cast<unsigned char *>(&v);
+            std::swap(b[0], b[3]);
+            std::swap(b[1], b[2]);
+        }
+    const float mag = scale < 0 ? -scale : scale;
+    if (mag != 1.f)
+        for (float &v : tb.rgb) v *= mag;
+    return tb;
 }
 GuidingCache GuidedVolPathVSPGIntegrator::GetGuidingCache() {
     GuidingCache gc;

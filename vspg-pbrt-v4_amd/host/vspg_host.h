@@ -96,6 +96,23 @@ struct GuidingCacheSettings {  // "storeGuidingCache" / "loadGuidingCache" / "gu
     std::string fileName;
 };
 
+// TrBuffer (src/pbrt/cpu/trbuffer.h:17-104): the per-pixel transmittance estimates of the primary rays, kept between
+// runs for NDS+.  The reference stores it through pbrt's Image class (format by file extension, normally OpenEXR, an
+// absent submodule); this adapter reads and writes the PFM raster of that class (util/image.cpp:1756-1800 WritePFM:
+// "PF", width height, scale -1 = little endian, RGB float32, scanlines bottom to top).  PFM carries no channel
+// names ("Transmittance.R/G/B" in the reference's EXR), so the file is this adapter's own persistence, readable by
+// any PFM tool.  Other extensions are refused.
+struct TrBuffer {
+    int xres = 0, yres = 0;
+    std::vector<float> rgb;  // row-major, top row first, 3 floats per pixel
+    void Store(const std::string &filename) const;
+    static TrBuffer Load(const std::string &filename);
+};
+struct TrBufferSettings {  // "storeTrBuffer" / "loadTrBuffer" / "trBufferFileName"
+    bool store = false, load = false;
+    std::string fileName;
+};
+
 class Integrator {
   public:
     virtual ~Integrator() = default;
@@ -114,7 +131,8 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
                                                                const VspgScene &scene, int xres, int yres,
                                                                int pixelSamples, int seed, int device);
     GuidedVolPathVSPGIntegrator(const VspgIntegratorParams &p, const VspgScene &scene, int xres, int yres,
-                                int pixelSamples, int seed, int device, const GuidingCacheSettings &cache = {});
+                                int pixelSamples, int seed, int device, const GuidingCacheSettings &cache = {},
+                                const TrBufferSettings &tr = {});
     ~GuidedVolPathVSPGIntegrator() override;
     void Render() override;       // wave loop: 1 spp per wave, PostProcessWave after each
     void PostProcessWave();       // guidedvolpathvspgintegrator.cpp:230-260
@@ -123,6 +141,7 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
     VspgCounters Counters();
     VspgTrainStats TrainingStats();      // guideTraining / guiding_field->GetIteration()
     GuidingCache GetGuidingCache();      // the field as it stands (trained in-loop or loaded)
+    TrBuffer GetTrBuffer();              // the transmittance buffer as it stands (recorded or loaded)
     const VspgIntegratorParams &Params() const { return params; }
 
   private:
@@ -131,9 +150,11 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
     VspgRenderer *renderer = nullptr;
     int spp;
     GuidingCacheSettings cacheSettings;
+    TrBufferSettings trSettings;
 };
 
 // parameter parsing only (no device): used by Create and by the CPU self test
-VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache = nullptr);
+VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache = nullptr,
+                                           TrBufferSettings *tr = nullptr);
 
 }  // namespace vspg
