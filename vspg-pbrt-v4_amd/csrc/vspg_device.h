@@ -295,13 +295,11 @@ VDEV float fast_exp(float x) {  // util/math.h:450-474 (CPU branch; NOT __expf)
     float fxp = __builtin_floorf(xp), f = xp - fxp;
     int i = (int)fxp;
     float twoToF = __builtin_fmaf(f, __builtin_fmaf(f, __builtin_fmaf(f, 0.0781455737f, 0.226173572f), 0.695556856f), 1.f);
-    int exponent = (int)((f2b(twoToF) >> 23) & 0xff) - 127 + i;
-    uint32_t bits = f2b(twoToF);
-    bits &= 0x807fffffu;
-    bits |= (uint32_t)(exponent + 127) << 23;
-    float r = b2f(bits);
-    r = exponent > 127 ? kInf : r;   // the reference's two early returns as selects
-    return exponent < -126 ? 0.f : r;
+    // f is in [0, 1] and the polynomial maps it into [1, 2): Exponent(twoToF) == 0, so the reference's exponent
+    // surgery (exponent = Exponent(twoToF) + i, two range checks, bit splice) is an exact scaling by 2^i --
+    // one v_ldexp_f32 (overflow gives +inf like the reference's second early return) plus the underflow select.
+    float r = __builtin_ldexpf(twoToF, i);
+    return i < -126 ? 0.f : r;
 }
 VDEV Spec fast_exp(Spec a) {
     if (__all(grey(a))) {  // wave-uniform grey fast path, see operator/
