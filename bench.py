@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--workload", choices=["fog", "cloud", "cloud-nvdb"], default="fog",
                     help="fog = BASELINE.json's metric workload (default); cloud = procedural heterogeneous GridMedium (configs 3-4 stand-in); "
                          "cloud-nvdb = the same grid with NanoVDBMedium semantics (64^3 majorants)")
+    ap.add_argument("--diag-maxdepth", type=int, default=None,
+                    help="DIAGNOSTIC ONLY (not the benchmark config): override maxdepth to time parts of the path")
     ap.add_argument("--grid", type=int, default=256, help="voxels per axis of the cloud workload's density grid")
     args = ap.parse_args()
 
@@ -121,6 +123,8 @@ def main():
     scene = (pkg.fog_box_scene(W, H) if args.workload == "fog" else pkg.cloud_box_scene(W, H, args.grid) if args.workload == "cloud"
              else pkg.nanovdb_box_scene(W, H, args.grid))
     prm = pkg.app_f_params()
+    if args.diag_maxdepth is not None:
+        prm.maxdepth = args.diag_maxdepth
     r = pkg.Renderer(scene, prm, W, H, spp=args.steps * world, seed=0, shard_index=rank, shard_count=world,
                      device=local_rank)
     fptr, fn = r.film_ptr()
@@ -203,7 +207,7 @@ def main():
                                     "cloud-box %dx%d, %s %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
                                         W, H, "GridMedium" if args.workload == "cloud" else "NanoVDBMedium (dense copy, 64^3 majorants)", args.grid)) +
                                    ", guidedvolpathvspg vspguiding=true (primary-ray VSP), 1 spp per step per GPU, "
-                                   "independent sampler seed 0, maxdepth 5",
+                                   "independent sampler seed 0, maxdepth %d%s" % (prm.maxdepth, "" if args.diag_maxdepth is None else " (DIAGNOSTIC override)"),
                        "paths_per_step_per_gpu": W * H, "mean_segments_per_path": kbar,
                        "parallelism": "sample-index sharding x%d, film all-reduce at frame end" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

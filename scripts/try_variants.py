@@ -7,7 +7,9 @@ variant = sys.argv[1]
 P.LIB_PATH = os.path.join(os.path.dirname(P.LIB_PATH), variant)
 P.load()
 W, H = 1920, 1080
-r = P.Renderer(P.fog_box_scene(W, H), P.app_f_params(), W, H)
+prm = P.app_f_params()
+if os.environ.get('MAXDEPTH'): prm.maxdepth = int(os.environ['MAXDEPTH'])
+r = P.Renderer(P.fog_box_scene(W, H), prm, W, H)
 for w in range(3): r.render_wave(w, w + 1); r.post_process_wave()
 torch.cuda.synchronize()
 t0 = time.perf_counter(); n = 20

@@ -612,7 +612,10 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     stage_scene_lds(S);
     if (threadIdx.x < CNT_COUNT) s_counters[threadIdx.x] = 0;
     if (threadIdx.x < C_COUNT) s_cnt[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < NP; i += kWgBlock) s_free[0][i] = (unsigned short)i;
+    for (int i = threadIdx.x; i < NP; i += kWgBlock) {
+        s_free[0][i] = (unsigned short)i;
+        P.u(PF_FLAGS, i) = 0;
+    }
     __syncthreads();
     if (threadIdx.x == 0) s_cnt[C_NFREE] = NP;
     __syncthreads();
@@ -655,12 +658,41 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
             if (lane == 0) {
                 s_cnt[C_RNEXT] = rnext; s_cnt[C_REND] = rend; s_cnt[C_EXH] = exh; s_cnt[C_RTX] = rtx; s_cnt[C_RTY] = rty;
                 s_cnt[C_NASSIGN] = filled;  // free slots beyond `filled` stay empty: the work has run out
-                s_cnt[C_NFREE + par] = 0;
                 s_cnt[C_BV] = 0; s_cnt[C_BS] = 0; s_cnt[C_CURB] = 0;
                 s_cnt[C_A0 + nxt] = 0; s_cnt[C_A1 + nxt] = 0; s_cnt[C_CURA + nxt] = 0;
             }
+        } else if (single_sample) {
+            // ---- film flush, by the waves the assignment leaves idle ----------------------------------
+            // Paths that ended in the previous iteration parked their radiance in their (now free) slot.  In a
+            // launch of ONE sample per pixel nobody else touches the pixel, so the film and the ISG statistics take a
+            // plain 16-byte load / add / store: the same single IEEE addition per channel as the ten no-return float
+            // atomics this replaces, which were L2-atomic-unit bound (0.28 ms of a 0.42 ms maxdepth-0 wave at 1080p).
+            // Done here in bulk, every lane busy, the load latency is paid once per 64 finished paths.
+            // (Tried: reading the parked record here and doing the global read-modify-write after the barrier, so that
+            //  its latency overlaps segment work -- the registers live across the barrier cost more than the overlap won.)
+            const unsigned n_free = s_cnt[C_NFREE + par];
+            for (unsigned base = (threadIdx.x >> 6) * 64u - 64u; base < n_free; base += (unsigned)kWgBlock - 64u) {
+                const unsigned i = base + (unsigned)lane;
+                if (i < n_free) {
+                    const int slot = s_free[par][i];
+                    const uint32_t fl = P.u(PF_FLAGS, slot);
+                    if (fl & FL_DONE) {
+                        const int pxy = P.i(PF_PIXEL, slot);
+                        const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
+                        const Spec L = P.sp3(PF_L, slot);
+                        IsgSample isg;
+                        isg.valid = (fl & FL_ISG_VALID) != 0;
+                        isg.surface_event = (fl & FL_ISG_SURF) != 0;
+                        isg.vsp_used = P.f(PF_VSP, slot);
+                        film_add_sample_rmw(film + pidx, L);
+                        isg_add_sample_rmw(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+                        P.u(PF_FLAGS, slot) = 0;
+                    }
+                }
+            }
         }
         { VSPG_PROF(PS_WG_BAR_R); __syncthreads(); }
+        if (threadIdx.x == 0) s_cnt[C_NFREE + par] = 0;  // (read by the flush above; refilled from the next iteration on)
         const unsigned nFresh = s_cnt[C_NASSIGN], nA0 = s_cnt[C_A0 + par], nA1 = s_cnt[C_A1 + par];
         const unsigned nPrim = nFresh + nA0, nA = nPrim + nA1;
         if (nA == 0 && s_cnt[C_EXH]) break;  // nothing in flight and nothing left to start
@@ -727,8 +759,15 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 } else if (valid) {
                     const Spec L = finish_radiance(st.L);
                     const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
-                    film_add_sample(film + pidx, L);
-                    isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+                    if (single_sample) {  // parked for the film flush at the top of the next iteration
+                        P.sets(PF_L, slot, L);
+                        P.i(PF_PIXEL, slot) = pxy;
+                        P.f(PF_VSP, slot) = isg.vsp_used;
+                        P.u(PF_FLAGS, slot) = (uint32_t)FL_DONE | (isg.valid ? (uint32_t)FL_ISG_VALID : 0u) | (isg.surface_event ? (uint32_t)FL_ISG_SURF : 0u);
+                    } else {
+                        film_add_sample(film + pidx, L);
+                        isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+                    }
                     pc.path();
                     const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
                     P.i(PF_SAMPLE, slot) = s2;
@@ -769,8 +808,15 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                     const int pxy = P.i(PF_PIXEL, slot);
                     const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
                     const Spec L = finish_radiance(st.L);
-                    film_add_sample(film + pidx, L);
-                    isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+                    if (single_sample) {  // parked for the film flush at the top of the next iteration
+                        P.sets(PF_L, slot, L);
+                        P.i(PF_PIXEL, slot) = pxy;
+                        P.f(PF_VSP, slot) = isg.vsp_used;
+                        P.u(PF_FLAGS, slot) = (uint32_t)FL_DONE | (isg.valid ? (uint32_t)FL_ISG_VALID : 0u) | (isg.surface_event ? (uint32_t)FL_ISG_SURF : 0u);
+                    } else {
+                        film_add_sample(film + pidx, L);
+                        isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+                    }
                     pc.path();
                     const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
                     P.i(PF_SAMPLE, slot) = s2;

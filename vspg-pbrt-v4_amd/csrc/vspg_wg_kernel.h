@@ -58,6 +58,7 @@ enum {
     FL_LIVE = 1 << 16,          // slot holds a path
     FL_RESTART = 1 << 17,       // slot's pixel has another sample to start
     FL_VX_VOLUME = 1 << 18,
+    FL_DONE = 1 << 19,          // finished path parked for the film flush: PF_L = final radiance, PF_VSP = isg.vsp_used
 };
 
 struct Pool {
