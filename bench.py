@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 B_SEGMENT = 256                # 2 x 128 B SoA path state per segment
 B_PATH_FIXED = 32 + 4 + 40     # film RMW + primary-VSP read + ISG sample write
-PMC_PROFILE = "r01_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
+PMC_PROFILE = "r01b_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
 
 
 class DevArray:
@@ -173,15 +173,16 @@ def main():
 
     if rank == 0:
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same
-        # command (profiles/<PMC_PROFILE>; FETCH_SIZE and WRITE_SIZE are separate
-        # passes, KiB per launch).  Reads here are 4-B gathers and scalar loads, a width the
-        # microarch guide lists as uncalibrated (FETCH_SIZE may under-count by up to 2x); writes
-        # are float atomics, which WRITE_SIZE counts at 64 B per request.
+        # command (profiles/<PMC_PROFILE>; FETCH_SIZE and WRITE_SIZE are separate passes, KiB per
+        # launch).  gfx950 correction of the microarch guide: FETCH_SIZE tallies 128-B read requests
+        # at 64 B, so it is doubled (the kernel's reads are 16-B-per-lane film / ISG records, 4-B
+        # spill reloads and scalar loads; for the narrow ones the factor is an upper bound);
+        # WRITE_SIZE is exact for 16-B-per-lane stores (film / ISG records) and dword stores (spills).
         traffic_gbs, traffic_bytes = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
             if W == 1920 and H == 1080 and args.workload == "fog":
-                traffic_bytes = (pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+                traffic_bytes = (2.0 * pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
         except Exception:
             pass
         kbar = segs_rank / max(1, paths_rank)
