@@ -94,6 +94,8 @@ def main():
                          "cloud-nvdb = the same grid with NanoVDBMedium semantics (64^3 majorants)")
     ap.add_argument("--diag-maxdepth", type=int, default=None,
                     help="DIAGNOSTIC ONLY (not the benchmark config): override maxdepth to time parts of the path")
+    ap.add_argument("--diag-guiding", action="store_true",
+                    help="DIAGNOSTIC ONLY: the reference's default guiding options (field trained during the warm-up waves)")
     ap.add_argument("--grid", type=int, default=256, help="voxels per axis of the cloud workload's density grid")
     args = ap.parse_args()
 
@@ -125,6 +127,9 @@ def main():
     prm = pkg.app_f_params()
     if args.diag_maxdepth is not None:
         prm.maxdepth = args.diag_maxdepth
+    if args.diag_guiding:
+        prm = pkg.default_params()
+        prm.guide_num_training_waves = max(1, args.warmup)
     r = pkg.Renderer(scene, prm, W, H, spp=args.steps * world, seed=0, shard_index=rank, shard_count=world,
                      device=local_rank)
     fptr, fn = r.film_ptr()
@@ -208,7 +213,7 @@ def main():
                                     "cloud-box %dx%d, %s %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
                                         W, H, "GridMedium" if args.workload == "cloud" else "NanoVDBMedium (dense copy, 64^3 majorants)", args.grid)) +
                                    ", guidedvolpathvspg vspguiding=true (primary-ray VSP), 1 spp per step per GPU, "
-                                   "independent sampler seed 0, maxdepth %d%s" % (prm.maxdepth, "" if args.diag_maxdepth is None else " (DIAGNOSTIC override)"),
+                                   "independent sampler seed 0, maxdepth %d%s" % (prm.maxdepth, "" if args.diag_maxdepth is None and not args.diag_guiding else " (DIAGNOSTIC override)"),
                        "paths_per_step_per_gpu": W * H, "mean_segments_per_path": kbar,
                        "parallelism": "sample-index sharding x%d, film all-reduce at frame end" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -23,6 +23,7 @@ using namespace vspg;
 namespace {
 
 constexpr int kBlock = 256;
+static_assert(kBlock == kGuideBlock, "the guiding scratch in LDS is sized for kBlock threads");
 #ifndef VSPG_WAVES_PER_SIMD
 #define VSPG_WAVES_PER_SIMD 2
 #endif
@@ -80,9 +81,11 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     const unsigned total_items = (unsigned)(tilesX * tilesY) * 64u;
     const int lane = threadIdx.x & 63;
     // heterogeneous media: the 16^3 majorant grid (16 KB) is staged into LDS once per workgroup with
-    // coalesced 16-B loads; every DDA step then reads LDS instead of HBM/L2
+    // coalesced 16-B loads; every DDA step then reads LDS instead of HBM/L2.  (Guided builds leave it in
+    // global memory -- it stays in the vector L1: their 72 KB of guiding scratch plus the grid would allow
+    // one block per CU only.)
     const float *maj_ptr = nullptr;
-    if constexpr (std::is_same<Medium, GridMedium>::value || std::is_same<Medium, GridMediumGrey>::value) {
+    if constexpr (!GUIDED && (std::is_same<Medium, GridMedium>::value || std::is_same<Medium, GridMediumGrey>::value)) {
         __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
         const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
         float4 *dst = reinterpret_cast<float4 *>(s_maj);
@@ -93,13 +96,10 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     stage_scene_lds(S);
     __syncthreads();
     const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
-    // guided builds: the per-lane product mixture of the guiding cache (5 floats x 8 lobes) lives in
-    // LDS, element e of lane t at s_gmix[e * kBlock + t] (conflict-free)
+    // guided builds: the per-lane guiding scratch (vspg_guiding.h: 9 floats x 8 lobes) lives in LDS,
+    // element e of lane t at s_gmix[e * kBlock + t] (conflict-free)
     float *glds = nullptr;
-    if constexpr (GUIDED) {
-        __shared__ float s_gmix[kBlock * 5 * GK];
-        glds = s_gmix + threadIdx.x;
-    }
+    if constexpr (GUIDED) glds = guide_lds();
     typename std::conditional<TRAIN, PathCountersT<PathRecorder>, PathCounters>::type pc;
     pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = 0;
     if constexpr (TRAIN) {
@@ -188,6 +188,18 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
         }
     }
     flush_counters(pc, paths, counters);
+}
+
+// DField::aux of regions [0, n_regions): the per-lobe constants every mixture evaluation needs
+__global__ __launch_bounds__(kBlock) void k_field_aux(const DScene *__restrict__ Sp, int f, const VspgFieldRegion *__restrict__ regs,
+                                                      float *__restrict__ aux) {
+    const int n = Sp->field[f].n_regions * GK;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int r = i / GK, k = i - r * GK;
+        const float kc = kappa_clamp(regs[r].kappa[k]);
+        aux[(size_t)r * (2 * GK) + k] = vmf_norm(kc);
+        aux[(size_t)r * (2 * GK) + GK + k] = kc;
+    }
 }
 
 // ---- a18: Field::Update stand-in (definitions in vspg_train.h / oracle "Field::Update") --------------
@@ -597,10 +609,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     }
     const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
     float *glds = nullptr;
-    if constexpr (GUIDED) {
-        __shared__ float s_gmix[kWgBlock * 5 * GK];
-        glds = s_gmix + threadIdx.x;
-    }
+    if constexpr (GUIDED) glds = guide_lds();
     __shared__ unsigned int s_counters[CNT_COUNT];
 #ifdef VSPG_WG_WAVE_COUNTERS  // alternative sink: no per-lane registers, ~2 % slower (measured)
     const WaveCounters pc{s_counters};
@@ -858,10 +867,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict
     IsgSample isg;
     int ch;
     float *glds = nullptr;
-    if constexpr (GUIDED) {
-        __shared__ float s_gmix[kBlock * 5 * GK];
-        glds = s_gmix + threadIdx.x;
-    }
+    if constexpr (GUIDED) glds = guide_lds();
     start_path(S, vsp_buf, vsp_ready, px, py, sample_index[i], sampler, st, &ch, isg);
     while (li_segment<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, glds, kBlock)) {
     }
@@ -941,13 +947,12 @@ __global__ __launch_bounds__(kBlock) void k_guiding_query(const DScene *__restri
                                                           int32_t *__restrict__ ok, float *__restrict__ pdf,
                                                           float *__restrict__ inc, float *__restrict__ vsp,
                                                           float *__restrict__ ws, float *__restrict__ pdfs) {
-    __shared__ float s_gmix[kBlock * 5 * GK];
     const DScene &S = *Sp;
     int i = blockIdx.x * kBlock + threadIdx.x;
     vspg_libm::stage_logf_tab_lds();
     __syncthreads();
     if (i >= n) return;
-    float *glds = s_gmix + threadIdx.x;
+    float *glds = guide_lds();
     V3 pp = ld3(p + 3 * i), aa = ld3(a + 3 * i), w = ld3(wi + 3 * i);
     GDist d = is_volume ? gdist_init_volume(S.field, pp, aa, g, glds, kBlock) : gdist_init_surface(S.field, pp, aa, glds, kBlock);
     ok[i] = d.ok ? 1 : 0;
@@ -957,7 +962,7 @@ __global__ __launch_bounds__(kBlock) void k_guiding_query(const DScene *__restri
     if (!d.ok) return;
     pdf[i] = gdist_pdf(d, w);
     inc[i] = gdist_incoming_pdf(S.field, d, w);
-    vsp[i] = gdist_vsp(S.field, d.field, d.region, d.p, w);
+    vsp[i] = gdist_vsp(S.field, d.field, d.region, glds, kBlock, w);
     V3 s;
     pdfs[i] = gdist_sample(d, u[2 * i], u[2 * i + 1], &s);
     ws[3 * i] = s.x; ws[3 * i + 1] = s.y; ws[3 * i + 2] = s.z;
@@ -1050,6 +1055,7 @@ struct VspgRenderer {
     unsigned int *work_head = nullptr;
     VspgKdNode *fnodes[2] = {nullptr, nullptr};        // guiding fields (device copies)
     VspgFieldRegion *fregions[2] = {nullptr, nullptr};
+    float *faux[2] = {nullptr, nullptr};               // DField::aux
     bool field_set = false;
     bool medium_grey = false;   // homogeneous medium with bitwise-grey sigma_a, sigma_s, Le
     bool surfaces_grey = false; // every rectangle's (clamped) Kd bitwise grey
@@ -1481,7 +1487,9 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             CK(hipMemset(r->rstats[f], 0, sizeof(RegionStats) * kTrainCapRegions));
             const VspgKdNode root = {0.f, 3u};  // one leaf -> region 0, untrained (n_lobes 0)
             CK(hipMemcpy(r->fnodes[f], &root, sizeof root, hipMemcpyHostToDevice));
-            r->hscene.field[f] = DField{1, 1, r->fnodes[f], r->fregions[f]};
+            CK(hipMalloc(&r->faux[f], sizeof(float) * 2 * GK * kTrainCapRegions));
+            CK(hipMemset(r->faux[f], 0, sizeof(float) * 2 * GK * kTrainCapRegions));
+            r->hscene.field[f] = DField{1, 1, r->fnodes[f], r->fregions[f], r->faux[f]};
         }
         CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
         r->segbuf_lanes = (size_t)r->num_cus * kBlocksPerCU * kBlock;
@@ -1518,6 +1526,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     for (int f = 0; f < 2; ++f) {
         if (r->fnodes[f]) (void)hipFree(r->fnodes[f]);
         if (r->fregions[f]) (void)hipFree(r->fregions[f]);
+        if (r->faux[f]) (void)hipFree(r->faux[f]);
     }
     for (int f = 0; f < 2; ++f)
         if (r->rstats[f]) (void)hipFree(r->rstats[f]);
@@ -1670,6 +1679,7 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
                                r->train_nsorted, r->train_sumw, r->train_acc);
             hipLaunchKernelGGL(k_train_mstep, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->rstats[f],
                                r->fregions[f]);
+            hipLaunchKernelGGL(k_field_aux, dim3(rgrid * 2), dim3(kBlock), 0, s, r->dscene, f, r->fregions[f], r->faux[f]);
         }
         HIPCHK(hipGetLastError());
         r->field_iteration++;
@@ -1887,7 +1897,8 @@ int vspg_primitives_batch(VspgRenderer *r, int n, const float *f, const float *g
 static int upload_field(VspgRenderer *r, int f, const VspgField *src, hipStream_t s) {
     if (r->fnodes[f]) { (void)hipFree(r->fnodes[f]); r->fnodes[f] = nullptr; }
     if (r->fregions[f]) { (void)hipFree(r->fregions[f]); r->fregions[f] = nullptr; }
-    r->hscene.field[f] = DField{0, 0, nullptr, nullptr};
+    if (r->faux[f]) { (void)hipFree(r->faux[f]); r->faux[f] = nullptr; }
+    r->hscene.field[f] = DField{0, 0, nullptr, nullptr, nullptr};
     if (!src || src->n_nodes <= 0 || src->n_regions <= 0) return 0;
     if (!src->nodes || !src->regions) return fail(VSPG_EINVAL, "guiding field without node / region arrays");
     for (int i = 0; i < src->n_nodes; ++i) {  // structural check: children after their parent, leaves in range
@@ -1902,7 +1913,8 @@ static int upload_field(VspgRenderer *r, int f, const VspgField *src, hipStream_
     HIPCHK(hipMalloc(&r->fregions[f], sizeof(VspgFieldRegion) * src->n_regions));
     HIPCHK(hipMemcpyAsync(r->fnodes[f], src->nodes, sizeof(VspgKdNode) * src->n_nodes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(r->fregions[f], src->regions, sizeof(VspgFieldRegion) * src->n_regions, hipMemcpyHostToDevice, s));
-    r->hscene.field[f] = DField{src->n_nodes, src->n_regions, r->fnodes[f], r->fregions[f]};
+    HIPCHK(hipMalloc(&r->faux[f], sizeof(float) * 2 * GK * src->n_regions));
+    r->hscene.field[f] = DField{src->n_nodes, src->n_regions, r->fnodes[f], r->fregions[f], r->faux[f]};
     return 0;
 }
 
@@ -1918,6 +1930,11 @@ int vspg_renderer_set_guiding_field(VspgRenderer *r, const VspgField *surface_fi
     rc = upload_field(r, 1, volume_field, s);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice, s));
+    for (int f = 0; f < 2; ++f)
+        if (r->faux[f])
+            hipLaunchKernelGGL(k_field_aux, dim3((r->hscene.field[f].n_regions * GK + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene,
+                               f, r->fregions[f], r->faux[f]);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     r->field_set = true;
     return 0;

@@ -451,6 +451,10 @@ struct DField {
     int32_t n_nodes, n_regions;
     const VspgKdNode *nodes;
     const VspgFieldRegion *regions;
+    // per region 2 x VSPG_FIELD_LOBES floats: vmf_norm(kappa_clamp(kappa[k])) then kappa_clamp(kappa[k]) -- functions of
+    // the stored lobes only, evaluated once per field update by the same device code the queries would run
+    // (k_field_aux) instead of once per lobe per mixture evaluation (an IEEE division and a FastExp each)
+    const float *aux;
 };
 struct DScene {
     int32_t n_quads, n_lights;

@@ -51,22 +51,36 @@ VDEV V3 lobe_dir(const VspgFieldRegion &R, int k, V3 p) {
     if (!(l2 > 0)) return mu;
     return normalize(t);
 }
-VDEV void lobe_product(V3 mu, float kappa, float w, V3 m2, float k2, V3 *mo, float *ko, float *wo) {
+// nk = vmf_norm(kappa), nk2 = vmf_norm(k2) (the caller has them); *no = vmf_norm(*ko)
+VDEV void lobe_product(V3 mu, float kappa, float nk, float w, V3 m2, float k2, float nk2, V3 *mo, float *ko, float *wo, float *no) {
     V3 s = mu * kappa + m2 * k2;
     float kp = len(s);
     if (!(kp > 1e-6f)) {
         *mo = mu;
         *ko = 1e-2f;
-        *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(1e-2f)) * fast_exp(1e-2f - kappa - k2);
+        *no = vmf_norm(1e-2f);
+        *wo = w * (nk * nk2 / *no) * fast_exp(1e-2f - kappa - k2);
         return;
     }
     float kc = kappa_clamp(kp);
     *mo = V3{s.x / kp, s.y / kp, s.z / kp};
     *ko = kc;
-    *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(kc)) * fast_exp(kp - kappa - k2);
+    *no = vmf_norm(kc);
+    *wo = w * (nk * nk2 / *no) * fast_exp(kp - kappa - k2);
 }
 
-// per-lane product mixture in LDS: element e of lobe k at lds[(e * GK + k) * stride]
+// Per-lane guiding scratch in LDS, element e of lobe k at lds[(e * GK + k) * stride]:
+//   e 0-4  the product mixture (weight, kappa, mean direction),  e 5  vmf_norm of the product kappa,
+//   e 6-8  the region's raw, parallax-re-aimed lobe directions at the query point.
+// Everything a later evaluation at the same point would otherwise recompute per lobe (a normalisation with three
+// IEEE divisions, a division + FastExp for the normalisation constant) is computed once in gdist_init and read back:
+// same operations on the same inputs, so the same bits.  The scratch of a lane stays valid until the lane's next
+// gdist_init -- in particular for the VolumeScatterProbability query of the NEXT segment (fetch_vsp).
+constexpr int kGFloats = 9 * GK;
+constexpr int kGuideBlock = 256;  // threads per block of every kernel that runs guided path code
+__shared__ float s_gmix[kGuideBlock * kGFloats];
+VDEV float *guide_lds() { return s_gmix + threadIdx.x; }
+VDEV const float *region_aux(const DField &F, int region) { return F.aux + (size_t)region * (2 * GK); }
 struct GDist {
     bool ok;
     int field, region, n;
@@ -81,7 +95,16 @@ struct GDist {
         lds[(3 * GK + k) * stride] = m.y;
         lds[(4 * GK + k) * stride] = m.z;
     }
+    VDEV float &pnorm(int k) const { return lds[(5 * GK + k) * stride]; }
+    VDEV void set_raw(int k, V3 m) const {
+        lds[(6 * GK + k) * stride] = m.x;
+        lds[(7 * GK + k) * stride] = m.y;
+        lds[(8 * GK + k) * stride] = m.z;
+    }
 };
+VDEV V3 guide_raw_dir(const float *lds, int stride, int k) {
+    return V3{lds[(6 * GK + k) * stride], lds[(7 * GK + k) * stride], lds[(8 * GK + k) * stride]};
+}
 
 VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m2, float k2, float *lds, int stride) {
     GDist d;
@@ -97,15 +120,19 @@ VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m
     if (R.n_lobes <= 0) return d;
     d.ok = true;
     d.n = R.n_lobes < GK ? R.n_lobes : GK;
+    const float *ax = region_aux(fields[f], d.region);  // [k] vmf_norm(kappa_clamp(kappa[k])), [GK + k] kappa_clamp(kappa[k])
+    const float nk2 = have_product ? vmf_norm(k2) : 0.f;
     float sum = 0;
     for (int k = 0; k < d.n; ++k) {
         V3 mu = lobe_dir(R, k, p);
-        float kap = kappa_clamp(R.kappa[k]);
+        d.set_raw(k, mu);
+        float kap = ax[GK + k];
         V3 mo = mu;
-        float ko = kap, wo = R.weight[k];
-        if (have_product) lobe_product(mu, kap, R.weight[k], m2, k2, &mo, &ko, &wo);
+        float ko = kap, wo = R.weight[k], no = ax[k];
+        if (have_product) lobe_product(mu, kap, ax[k], R.weight[k], m2, k2, nk2, &mo, &ko, &wo, &no);
         d.set_mu(k, mo);
         d.kappa(k) = ko;
+        d.pnorm(k) = no;
         d.w(k) = wo;
         sum += wo;
     }
@@ -113,8 +140,9 @@ VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m
         for (int k = 0; k < d.n; ++k) d.w(k) = d.w(k) / sum;
     } else {
         for (int k = 0; k < d.n; ++k) {
-            d.set_mu(k, lobe_dir(R, k, p));
-            d.kappa(k) = kappa_clamp(R.kappa[k]);
+            d.set_mu(k, guide_raw_dir(d.lds, d.stride, k));
+            d.kappa(k) = ax[GK + k];
+            d.pnorm(k) = ax[k];
             d.w(k) = R.weight[k];
         }
     }
@@ -133,21 +161,24 @@ VDEV GDist gdist_init_volume(const DField *fields, V3 p, V3 dir, float g, float 
 }
 VDEV float gdist_pdf(const GDist &d, V3 w) {
     float s = 0;
-    for (int k = 0; k < d.n; ++k) s += d.w(k) * vmf_eval(d.mu(k), d.kappa(k), w);
+    for (int k = 0; k < d.n; ++k) s += d.w(k) * (d.pnorm(k) * fast_exp(d.kappa(k) * (dot(d.mu(k), w) - 1)));  // w * vmf_eval
     return s;
 }
 VDEV float gdist_incoming_pdf(const DField *fields, const GDist &d, V3 w) {
     const VspgFieldRegion &R = fields[d.field].regions[d.region];
+    const float *ax = region_aux(fields[d.field], d.region);
     float s = 0;
-    for (int k = 0; k < d.n; ++k) s += R.weight[k] * vmf_eval(lobe_dir(R, k, d.p), kappa_clamp(R.kappa[k]), w);
+    for (int k = 0; k < d.n; ++k) s += R.weight[k] * (ax[k] * fast_exp(ax[GK + k] * (dot(guide_raw_dir(d.lds, d.stride, k), w) - 1)));
     return s;
 }
-VDEV float gdist_vsp(const DField *fields, int f, int region, V3 p, V3 w) {
+// VolumeScatterProbability(w) of the region the lane's scratch was initialised for (field f, `region`, at its point)
+VDEV float gdist_vsp(const DField *fields, int f, int region, const float *lds, int stride, V3 w) {
     const VspgFieldRegion &R = fields[f].regions[region];
+    const float *ax = region_aux(fields[f], region);
     int n = R.n_lobes < GK ? R.n_lobes : GK;
     float num = 0, den = 0;
     for (int k = 0; k < n; ++k) {
-        float e = R.weight[k] * vmf_eval(lobe_dir(R, k, p), kappa_clamp(R.kappa[k]), w);
+        float e = R.weight[k] * (ax[k] * fast_exp(ax[GK + k] * (dot(guide_raw_dir(lds, stride, k), w) - 1)));
         num += e * R.vsp[k];
         den += e;
     }

@@ -301,7 +301,7 @@ VDEV float fetch_vsp(const DScene &S, const PathState &st, bool *guide) {
     } else if constexpr (GUIDED) {
         if (S.prm.vspguiding && S.prm.vspsecondaryguiding) {
             // g{phase,bsdf}.VolumeScatterProbability(ray.d) of the PREVIOUS vertex (:661-668)
-            vsp = st.gs.useScatterGuiding ? gdist_vsp(S.field, st.gs.field, st.gs.region, st.gs.p, st.rd) : -1.f;
+            vsp = st.gs.useScatterGuiding ? gdist_vsp(S.field, st.gs.field, st.gs.region, guide_lds(), kGuideBlock, st.rd) : -1.f;
             *guide = !(isnan_(vsp) || vsp < 0.f || vsp > 1.f);
         }
     }
