@@ -41,11 +41,15 @@ VDEV int field_lookup(const DField &F, V3 p) {
     }
     return -1;
 }
-VDEV V3 lobe_dir(const VspgFieldRegion &R, int k, V3 p) {
-    V3 mu = V3{R.mu[0][k], R.mu[1][k], R.mu[2][k]};
-    float d = R.distance[k];
+// Region records are read four lobes at a time with 16-byte loads (the SoA rows of VspgFieldRegion and of DField::aux
+// are 32 bytes, 16-byte aligned): the lanes of a wavefront sit in unrelated regions, so every load instruction
+// costs one cache-line lookup per lane whatever its width -- the guided kernels were bound by exactly that.
+static_assert(sizeof(VspgFieldRegion) % 16 == 0 && offsetof(VspgFieldRegion, weight) % 16 == 0 && GK % 4 == 0, "16-byte rows");
+VDEV float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+VDEV float c4(float4 v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }  // j is a compile-time constant after unrolling
+VDEV V3 lobe_dir(V3 pivot, V3 mu, float d, V3 p) {
     if (!(d > 0) || isinf_(d)) return mu;
-    V3 src = ld3(R.pivot) + mu * d;
+    V3 src = pivot + mu * d;
     V3 t = src - p;
     float l2 = len2(t);
     if (!(l2 > 0)) return mu;
@@ -122,19 +126,29 @@ VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m
     d.n = R.n_lobes < GK ? R.n_lobes : GK;
     const float *ax = region_aux(fields[f], d.region);  // [k] vmf_norm(kappa_clamp(kappa[k])), [GK + k] kappa_clamp(kappa[k])
     const float nk2 = have_product ? vmf_norm(k2) : 0.f;
+    const V3 pivot = ld3(R.pivot);
     float sum = 0;
-    for (int k = 0; k < d.n; ++k) {
-        V3 mu = lobe_dir(R, k, p);
-        d.set_raw(k, mu);
-        float kap = ax[GK + k];
-        V3 mo = mu;
-        float ko = kap, wo = R.weight[k], no = ax[k];
-        if (have_product) lobe_product(mu, kap, ax[k], R.weight[k], m2, k2, nk2, &mo, &ko, &wo, &no);
-        d.set_mu(k, mo);
-        d.kappa(k) = ko;
-        d.pnorm(k) = no;
-        d.w(k) = wo;
-        sum += wo;
+    for (int h = 0; h < GK; h += 4) {
+        if (h >= d.n) break;
+        const float4 w4 = ld4(R.weight + h), mx4 = ld4(R.mu[0] + h), my4 = ld4(R.mu[1] + h), mz4 = ld4(R.mu[2] + h),
+                     d4 = ld4(R.distance + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = h + j;
+            if (k < d.n) {
+                V3 mu = lobe_dir(pivot, V3{c4(mx4, j), c4(my4, j), c4(mz4, j)}, c4(d4, j), p);
+                d.set_raw(k, mu);
+                float kap = c4(k4, j);
+                V3 mo = mu;
+                float ko = kap, wo = c4(w4, j), no = c4(n4, j);
+                if (have_product) lobe_product(mu, kap, c4(n4, j), c4(w4, j), m2, k2, nk2, &mo, &ko, &wo, &no);
+                d.set_mu(k, mo);
+                d.kappa(k) = ko;
+                d.pnorm(k) = no;
+                d.w(k) = wo;
+                sum += wo;
+            }
+        }
     }
     if (sum > 0 && !isinf_(sum)) {
         for (int k = 0; k < d.n; ++k) d.w(k) = d.w(k) / sum;
@@ -168,7 +182,15 @@ VDEV float gdist_incoming_pdf(const DField *fields, const GDist &d, V3 w) {
     const VspgFieldRegion &R = fields[d.field].regions[d.region];
     const float *ax = region_aux(fields[d.field], d.region);
     float s = 0;
-    for (int k = 0; k < d.n; ++k) s += R.weight[k] * (ax[k] * fast_exp(ax[GK + k] * (dot(guide_raw_dir(d.lds, d.stride, k), w) - 1)));
+    for (int h = 0; h < GK; h += 4) {
+        if (h >= d.n) break;
+        const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = h + j;
+            if (k < d.n) s += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(guide_raw_dir(d.lds, d.stride, k), w) - 1)));
+        }
+    }
     return s;
 }
 // VolumeScatterProbability(w) of the region the lane's scratch was initialised for (field f, `region`, at its point)
@@ -177,10 +199,18 @@ VDEV float gdist_vsp(const DField *fields, int f, int region, const float *lds, 
     const float *ax = region_aux(fields[f], region);
     int n = R.n_lobes < GK ? R.n_lobes : GK;
     float num = 0, den = 0;
-    for (int k = 0; k < n; ++k) {
-        float e = R.weight[k] * (ax[k] * fast_exp(ax[GK + k] * (dot(guide_raw_dir(lds, stride, k), w) - 1)));
-        num += e * R.vsp[k];
-        den += e;
+    for (int h = 0; h < GK; h += 4) {
+        if (h >= n) break;
+        const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h), v4 = ld4(R.vsp + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = h + j;
+            if (k < n) {
+                float e = c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(guide_raw_dir(lds, stride, k), w) - 1)));
+                num += e * c4(v4, j);
+                den += e;
+            }
+        }
     }
     if (!(den > 0)) return -1.f;
     return num / den;
