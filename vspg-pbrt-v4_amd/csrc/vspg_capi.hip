@@ -124,9 +124,17 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     PathState st;
     IsgSample isg;
 
+    // training launches: a finished path waits (`pending`) until kPropagateBatch lanes of its wavefront have one, so that
+    // PropagateSamples -- a lock-step loop over the longest recorded path, ~150 loads of segment records -- runs with
+    // many lanes instead of the handful that end in any one iteration
+    bool pending = false;
+#ifndef VSPG_PROPAGATE_BATCH
+#define VSPG_PROPAGATE_BATCH 24
+#endif
+    constexpr int kPropagateBatch = VSPG_PROPAGATE_BATCH;
     while (true) {
         // ---- regeneration: ballot the empty lanes, prefix-count them, hand out items -----------
-        unsigned long long need = __ballot(!has);
+        unsigned long long need = __ballot(!has && !pending);
         if (need != 0ull && !(exhausted && local_next >= local_end)) {
             if (local_next >= local_end && !exhausted) {
                 unsigned base = 0;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
             }
             const unsigned rank = (unsigned)__popcll(need & ((1ull << lane) - 1ull));
             const unsigned avail = local_end - local_next;  // lanes beyond `avail` wait for the next chunk
-            if (!has && rank < avail) {
+            if (!has && !pending && rank < avail) {
                 VSPG_PROF(PS_START);
                 const unsigned item = local_next + rank;
                 const unsigned tile = item >> 6, l = item & 63u;
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
             const unsigned cnt = (unsigned)__popcll(need);
             local_next += cnt < avail ? cnt : avail;
         }
-        if (__ballot(has) == 0ull) {
+        const bool idle = __ballot(has) == 0ull;
+        if (idle && !(TRAIN && __ballot(pending) != 0ull)) {
             if (exhausted && local_next >= local_end) break;
             continue;
         }
@@ -176,15 +185,31 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
             }
         }
         if constexpr (TRAIN) {  // PropagateSamples (:627), in lock step across the wavefront
-            propagate_samples(pc.rec, finished, train.samples, train.counters, train.capacity);
-            if (finished) pc.rec.reset();
+            if (finished) {
+                pending = true;
+                has = false;
+            }
+            finished = false;
+            const unsigned long long pm = __ballot(pending);
+            // nothing else can happen in this wavefront before the parked paths are propagated: no live lane, or no free lane can be refilled
+            const bool starved = __ballot(has) == 0ull;
+            if (pm != 0ull && ((int)__popcll(pm) >= kPropagateBatch || starved)) {
+                propagate_samples(pc.rec, pending, train.samples, train.counters, train.capacity);
+                if (pending) {
+                    pc.rec.reset();
+                    pending = false;
+                    finished = true;
+                }
+            }
         }
         if (finished) {
             s += S.shard_count > 1 ? S.shard_count : 1;
-            if (s < wave_end)
+            if (s < wave_end) {
                 start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
-            else
+                has = true;
+            } else {
                 has = false;
+            }
         }
     }
     flush_counters(pc, paths, counters);
