@@ -96,6 +96,14 @@ typedef struct VspgMedium {
     float grid_origin[3];
     float density_offset;
     float majorant_scale;
+    /* VSPG_MEDIUM_GRID only -- emission of GridMedium (src/pbrt/media.h:326-342, media.cpp:316-328): Le at a point =
+     * LeScale.Lookup(p) * Le when that scale is positive.  `Le` above is Le_spec sampled (RGB); le_scale is the
+     * "Lescale" grid ALREADY multiplied by the reference's photometric normalisation 1 / SpectrumToPhotometric(Le)
+     * (HOST pointer, le_nx*le_ny*le_nz floats, x fastest, copied at create time).  NULL with a non-zero Le = the
+     * reference's default 1x1x1 grid holding 1 (trilinear against the zero background: a tent over the bounds).
+     * Temperature grids (blackbody emission) are outside this build's scope. */
+    const float *le_scale;
+    int32_t le_nx, le_ny, le_nz;
 } VspgMedium;
 
 typedef struct VspgScene {

@@ -479,6 +479,8 @@ struct OracleRenderer {
     /* GridMedium: density samples (copied) and the 16^3 majorant grid (media.cpp:252-269) */
     float *density;
     float *majorant;
+    float *le_scale; /* emissive GridMedium: the LeScale grid (copied), NULL = not emissive */
+    int le_dim[3];
     /* film: RGBFilm::Pixel (film.h:314-318) */
     double *film; /* W*H*4 */
     /* image-space VSP buffer (own design; OpenPGL absent) */
@@ -600,6 +602,26 @@ static v3 bounds_offset(const VspgMedium *m, v3 p) {
     if (m->bounds_max[1] > m->bounds_min[1]) o.y /= m->bounds_max[1] - m->bounds_min[1];
     if (m->bounds_max[2] > m->bounds_min[2]) o.z /= m->bounds_max[2] - m->bounds_min[2];
     return o;
+}
+/* the same two functions for an arbitrary SampledGrid (the LeScale grid of an emissive GridMedium) */
+static float sgrid_at(const float *data, int nx, int ny, int nz, int x, int y, int z) {
+    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
+    return data[((size_t)z * ny + y) * nx + x];
+}
+static float sgrid_lookup(const float *data, int nx, int ny, int nz, v3 p) {
+    float sx = p.x * nx - .5f, sy = p.y * ny - .5f, sz = p.z * nz - .5f;
+    int ix = (int)floorf(sx), iy = (int)floorf(sy), iz = (int)floorf(sz);
+    float dx = sx - (float)ix, dy = sy - (float)iy, dz = sz - (float)iz;
+#define LERPF(t, a, b) ((1 - (t)) * (a) + (t) * (b))
+#define G(x, y, z) sgrid_at(data, nx, ny, nz, x, y, z)
+    float d00 = LERPF(dx, G(ix, iy, iz), G(ix + 1, iy, iz));
+    float d10 = LERPF(dx, G(ix, iy + 1, iz), G(ix + 1, iy + 1, iz));
+    float d01 = LERPF(dx, G(ix, iy, iz + 1), G(ix + 1, iy, iz + 1));
+    float d11 = LERPF(dx, G(ix, iy + 1, iz + 1), G(ix + 1, iy + 1, iz + 1));
+    float a = LERPF(dy, d00, d10), b = LERPF(dy, d01, d11);
+    return LERPF(dz, a, b);
+#undef G
+#undef LERPF
 }
 /* SampledGrid<Float>::Lookup(Point3i) (containers.h:830-835) */
 static float grid_at(const OracleRenderer *r, int x, int y, int z) {
@@ -791,15 +813,21 @@ static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
     if (medium_is_grid_like(m->type)) {
         /* identity renderFromMedium: ApplyInverse(Point3f) returns p unchanged */
         float d;
+        spec Le = S1(0.f);
         if (m->type == VSPG_MEDIUM_NANOVDB) { /* media.h:686-703 */
             d = nvdb_sample(r, p);
             d += m->density_offset;
         } else {
-            d = grid_lookup(r, bounds_offset(m, p));
+            v3 po = bounds_offset(m, p);
+            d = grid_lookup(r, po);
+            if (r->le_scale) { /* isEmissive (media.h:326-342): Le = scale * Le_spec.Sample(lambda) where the scale is positive */
+                float scale = sgrid_lookup(r->le_scale, r->le_dim[0], r->le_dim[1], r->le_dim[2], po);
+                if (scale > 0) Le = s_scale(s_from(m->Le), scale); /* SampledSpectrum operator*(Float, s): s * a */
+            }
         }
         mp.sigma_a = s_scale(mp.sigma_a, d);
         mp.sigma_s = s_scale(mp.sigma_s, d);
-        mp.Le = S1(0.f); /* emissive grids (Le / temperature) are outside this build's scope */
+        mp.Le = Le; /* temperature grids (blackbody emission) are outside this build's scope */
     }
     return mp;
 }
@@ -2610,7 +2638,10 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
         if (m->nx <= 0 || m->ny <= 0 || m->nz <= 0 || !m->density) return VSPG_EINVAL;
         if (m->type == VSPG_MEDIUM_NANOVDB && !(m->voxel_size[0] > 0 && m->voxel_size[1] > 0 && m->voxel_size[2] > 0 && m->majorant_scale > 0))
             return VSPG_EINVAL;
-        if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) return VSPG_ESCOPE;
+        if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) {
+            if (m->type == VSPG_MEDIUM_NANOVDB) return VSPG_ESCOPE; /* NanoVDBMedium emits through a temperature grid only */
+            if (m->le_scale && (m->le_nx <= 0 || m->le_ny <= 0 || m->le_nz <= 0)) return VSPG_EINVAL;
+        }
     }
     return 0;
 }
@@ -2639,6 +2670,19 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
         r->majorant = (float *)calloc((size_t)MR * MR * MR, sizeof(float));
         if (m->type == VSPG_MEDIUM_NANOVDB) build_majorant_grid_nvdb(r);
         else build_majorant_grid(r);
+        if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) { /* isEmissive = Le_spec.MaxValue() > 0 (media.cpp:250) */
+            if (m->le_scale) {
+                size_t ln = (size_t)m->le_nx * m->le_ny * m->le_nz;
+                r->le_scale = (float *)malloc(ln * sizeof(float));
+                memcpy(r->le_scale, m->le_scale, ln * sizeof(float));
+                r->le_dim[0] = m->le_nx; r->le_dim[1] = m->le_ny; r->le_dim[2] = m->le_nz;
+            } else { /* "Lescale" absent: SampledGrid({1}, 1, 1, 1) (media.cpp:319-320, normalisation applied by the caller) */
+                r->le_scale = (float *)malloc(sizeof(float));
+                r->le_scale[0] = 1.f;
+                r->le_dim[0] = r->le_dim[1] = r->le_dim[2] = 1;
+            }
+            r->scene.medium.le_scale = r->le_scale;
+        }
     }
     size_t npix = (size_t)cfg->xres * cfg->yres;
     r->film = (double *)calloc(npix * 4, sizeof(double));
@@ -2666,7 +2710,7 @@ void oracle_renderer_destroy(OracleRenderer *r) {
     if (!r) return;
     free_field(r, 0); free_field(r, 1);
     free(r->samples);
-    free(r->trbuf); free(r->tr_spp);
+    free(r->trbuf); free(r->tr_spp); free(r->le_scale);
     free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {

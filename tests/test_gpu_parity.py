@@ -646,6 +646,53 @@ def test_tr_buffer_and_nds_plus_vs_oracle(gpu_pkg, medium):
     g0.close(); g.close(); c.close()
 
 
+@pytest.mark.parametrize("lescale", ["grid", "default"])
+def test_emissive_grid_vs_oracle(gpu_pkg, lescale):
+    """GridMedium emission (media.h:326-342): Le = LeScale.Lookup(p) * Le_spec, picked up by the delta-tracking
+    callback (:895-906): device == oracle path by path, film and counters."""
+    from scenes import cloud_density, grid_scene
+    P = gpu_pkg
+    W, H = 64, 48
+    dens = cloud_density(24)
+    scene = grid_scene(dens, (24, 24, 24), (0.3, 0.35, 0.4), (1.6, 1.4, 1.2), g=0.4, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    scene.medium.Le[:] = (2.5, 1.25, 0.4)
+    if lescale == "grid":
+        rng = np.random.default_rng(31)
+        le = np.clip(rng.random((6, 5, 7)).astype(np.float32) * 2 - 0.6, 0, None).astype(np.float32)  # some cells emit nothing
+        scene.medium.le_scale = le.ctypes.data_as(C.POINTER(C.c_float))
+        scene.medium.le_nz, scene.medium.le_ny, scene.medium.le_nx = le.shape
+    prm = P.app_f_params()
+    prm.vspsamplingmethod = P.VSP_NDS
+    g = P.Renderer(scene, prm, W, H, seed=3)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
+    rng = np.random.default_rng(23)
+    n = 20000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    exact = np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)
+    ok = np.all(np.abs(Lg - Lc) <= 1e-4 * np.abs(Lc) + 1e-6, axis=1)
+    print("emissive (%s) paths: same segments %.5f within tol %.5f bit-identical %.5f" % (lescale, np.mean(sg == sc), ok.mean(), exact.mean()))
+    assert np.mean(sg == sc) >= 0.998 and ok.mean() >= 0.998
+    for w in range(4):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fg, fc = g.film(), c.film()
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    relmse = np.mean((ig - ic) ** 2 / (ic ** 2 + 1e-4))
+    print("emissive (%s) film relMSE %.3e" % (lescale, relmse))
+    assert relmse <= 1e-4
+    # the emission is really there: the same render without Le is darker
+    scene.medium.Le[:] = (0, 0, 0)
+    g0 = P.Renderer(scene, prm, W, H, seed=3)
+    for w in range(4):
+        g0.render_wave(w, w + 1); g0.post_process_wave()
+    f0 = g0.film()
+    assert (fg[..., :3].sum() - f0[..., :3].sum()) / f0[..., :3].sum() > 0.05
+    g0.close(); g.close(); c.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # NanoVDBMedium semantics over a dense copy of the grid: 64^3 majorants in HBM, index-space trilinear
 # fetch with zero background, densityoffset / majorantscale

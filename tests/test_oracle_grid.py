@@ -271,3 +271,70 @@ def test_nds_plus_is_unbiased_and_changes_the_collision_decisions():
     assert np.array_equal(a.film_f64(), b.film_f64())
     assert np.all(a.tr_buffer() == 0)
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# emissive GridMedium (media.h:326-342, media.cpp:316-328): Le = LeScale.Lookup(p) * Le_spec where positive
+# ---------------------------------------------------------------------------------------------
+def _emissive_scene(P, W, H, le_grid, n=10, seed=21):
+    rng = np.random.default_rng(seed)
+    dens = np.clip(rng.random(n ** 3).astype(np.float32) * 1.4 - 0.2, 0, None).astype(np.float32)
+    scene = grid_scene(P, dens, (n, n, n), 0.4, 1.2, g=0.1, bmin=(-0.8, -0.8, -0.6), bmax=(0.8, 0.6, 0.9), W=W, H=H)
+    scene.medium.Le[:] = (3.0, 1.5, 0.5)
+    if le_grid is not None:
+        g = np.ascontiguousarray(le_grid, dtype=np.float32)
+        scene.medium.le_scale = g.ctypes.data_as(C.POINTER(C.c_float))
+        scene.medium.le_nz, scene.medium.le_ny, scene.medium.le_nx = g.shape
+        scene._le_keepalive = g
+    return scene, dens
+
+
+def _render_mean(P, scene, W, H, spp, **prm_kw):
+    prm = oracle_lib.app_f_params()
+    for k, v in prm_kw.items():
+        setattr(prm, k, v)
+    r = oracle_lib.OracleRenderer(scene, prm, W, H)
+    r.render_wave(0, spp)
+    f = r.film_f64()
+    r.close()
+    return (f[..., :3] / f[..., 3:4])
+
+
+def test_emissive_grid_adds_radiance_in_the_delta_tracking_routine_only():
+    """Volume emission is sampled by the delta-tracking callback (:895-906); the resampling routine never sees it
+    (SURVEY App. C #12).  With all surfaces black and the light off, the image is the medium's own emission."""
+    P = load_package()
+    W, H = 24, 18
+    le = np.zeros((4, 4, 4), dtype=np.float32)
+    le[1:3, 1:3, 1:3] = 2.0
+    scene, dens = _emissive_scene(P, W, H, le)
+    for i in range(scene.n_quads):
+        scene.quads[i].Kd[:] = (0, 0, 0)
+        scene.quads[i].Le[:] = (0, 0, 0)
+    img_nds = _render_mean(P, scene, W, H, 64, vspsamplingmethod=P.VSP_NDS)
+    assert img_nds.mean() > 1e-2 and np.all(img_nds >= 0)
+    # emission colour: the ratio of the channels follows Le_spec where absorption is grey
+    m = img_nds.reshape(-1, 3).mean(0)
+    assert abs(m[0] / m[1] - 2.0) < 0.1 and abs(m[1] / m[2] - 3.0) < 0.2
+    # twice the LeScale grid -> twice the radiance, sample by sample (same random walk)
+    scene2, _ = _emissive_scene(P, W, H, 2 * le)
+    for i in range(scene2.n_quads):
+        scene2.quads[i].Kd[:] = (0, 0, 0)
+        scene2.quads[i].Le[:] = (0, 0, 0)
+    img2 = _render_mean(P, scene2, W, H, 64, vspsamplingmethod=P.VSP_NDS)
+    assert np.allclose(img2, 2 * img_nds, rtol=1e-5, atol=1e-7)
+    # the resampling routine does not sample volume emission
+    img_rs = _render_mean(P, scene, W, H, 16, vspsamplingmethod=P.VSP_RESAMPLING)
+    assert img_rs.max() == 0
+    # no "Lescale": the reference's 1x1x1 grid holding 1 -- a tent over the bounds, positive inside
+    scene3, _ = _emissive_scene(P, W, H, None)
+    for i in range(scene3.n_quads):
+        scene3.quads[i].Kd[:] = (0, 0, 0)
+        scene3.quads[i].Le[:] = (0, 0, 0)
+    assert _render_mean(P, scene3, W, H, 32, vspsamplingmethod=P.VSP_NDS).mean() > 1e-2
+    # NanoVDBMedium emits through a temperature grid only: refused
+    from scenes import nvdb_scene
+    s4 = nvdb_scene(dens, (10, 10, 10), 0.4, 1.2, W=W, H=H)
+    s4.medium.Le[:] = (1, 1, 1)
+    with pytest.raises(Exception):
+        oracle_lib.OracleRenderer(s4, oracle_lib.app_f_params(), W, H)

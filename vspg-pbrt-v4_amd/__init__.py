@@ -45,7 +45,8 @@ class VspgMedium(C.Structure):
                 ("Le", f3), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("bounds_min", f3), ("bounds_max", f3), ("density", C.POINTER(C.c_float)),
                 ("index_min", C.c_int32 * 3), ("voxel_size", f3), ("grid_origin", f3),
-                ("density_offset", C.c_float), ("majorant_scale", C.c_float)]
+                ("density_offset", C.c_float), ("majorant_scale", C.c_float),
+                ("le_scale", C.POINTER(C.c_float)), ("le_nx", C.c_int32), ("le_ny", C.c_int32), ("le_nz", C.c_int32)]
 
 
 class VspgScene(C.Structure):

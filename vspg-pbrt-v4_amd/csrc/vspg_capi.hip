@@ -1099,6 +1099,7 @@ struct VspgRenderer {
     unsigned int *train_order = nullptr;      // sample indices sorted by region
     unsigned int *train_hist = nullptr, *train_cursor = nullptr, *train_nsorted = nullptr;
     float *density = nullptr;   // GridMedium density samples
+    float *le_scale = nullptr;  // emissive GridMedium: LeScale grid
     float *majorant = nullptr;  // 16^3 majorant grid
     int num_cus = 0;
     int vsp_ready = 0;
@@ -1322,8 +1323,12 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         if ((long long)m.nx * m.ny * m.nz > (1ll << 31)) return fail(VSPG_EINVAL, "density grid too large");
         for (int k = 0; k < 3; ++k)
             if (!(m.bounds_max[k] > m.bounds_min[k])) return fail(VSPG_EINVAL, "grid medium bounds must have positive extent");
-        if (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0)
-            return fail(VSPG_ESCOPE, "emissive grid media (Le / temperature grids) are outside this build's scope");
+        if (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0) {
+            if (m.type == VSPG_MEDIUM_NANOVDB)
+                return fail(VSPG_ESCOPE, "NanoVDBMedium emits through a temperature grid (blackbody emission): outside this build's scope");
+            if (m.le_scale && (m.le_nx <= 0 || m.le_ny <= 0 || m.le_nz <= 0 || (long long)m.le_nx * m.le_ny * m.le_nz > (1ll << 31)))
+                return fail(VSPG_EINVAL, "emissive grid medium: bad Lescale grid size");
+        }
     } else if (scene->medium.type != VSPG_MEDIUM_NONE && scene->medium.type != VSPG_MEDIUM_HOMOGENEOUS)
         return fail(VSPG_EINVAL, "unknown medium type");
     int nl = 0;
@@ -1469,6 +1474,18 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         r->hscene.density = r->density;
         r->hscene.majorant = r->majorant;
         r->scene.medium.density = nullptr;  // the host array belongs to the caller
+        const VspgMedium &m = scene->medium;
+        if (m.type == VSPG_MEDIUM_GRID && (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0)) {  // isEmissive (media.cpp:250)
+            const float one = 1.f;  // "Lescale" absent: SampledGrid({1}, 1, 1, 1) (media.cpp:319-320)
+            const float *src = m.le_scale ? m.le_scale : &one;
+            const int lx = m.le_scale ? m.le_nx : 1, ly = m.le_scale ? m.le_ny : 1, lz = m.le_scale ? m.le_nz : 1;
+            const size_t ln = (size_t)lx * ly * lz;
+            CK(hipMalloc(&r->le_scale, ln * sizeof(float)));
+            CK(hipMemcpy(r->le_scale, src, ln * sizeof(float), hipMemcpyHostToDevice));
+            r->hscene.le_scale = r->le_scale;
+            r->hscene.le_nx = lx; r->hscene.le_ny = ly; r->hscene.le_nz = lz;
+        }
+        r->scene.medium.le_scale = nullptr;
     }
     CK(hipMalloc(&r->dscene, sizeof(DScene)));
     CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
@@ -1566,6 +1583,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_cursor) (void)hipFree(r->train_cursor);
     if (r->train_nsorted) (void)hipFree(r->train_nsorted);
     if (r->density) (void)hipFree(r->density);
+    if (r->le_scale) (void)hipFree(r->le_scale);
     if (r->majorant) (void)hipFree(r->majorant);
     delete r;
     return 0;

@@ -480,6 +480,9 @@ struct DScene {
     // NanoVDB-semantics dense medium: index bbox min, 1 / voxel_size, world position of index (0,0,0), density offset
     int32_t index_min[3];
     float inv_voxel[3], grid_origin[3], density_offset;
+    // emissive GridMedium (media.h:326-342): the LeScale grid, null = not emissive
+    const float *le_scale;
+    int32_t le_nx, le_ny, le_nz;
     // integrator parameters
     VspgIntegratorParams prm;
     // render config
@@ -723,6 +726,9 @@ struct GridMediumT {
     int imx, imy, imz;      // NVDB: index bbox min
     V3 inv_voxel, origin;   // NVDB: worldToIndexF(p) = (p - origin) * inv_voxel
     float density_offset;   // NVDB
+    const float *le_scale;  // emissive GridMedium: LeScale grid (null = not emissive), its size, Le_spec
+    int lnx, lny, lnz;
+    Spec Le;
 
     struct Iter {  // DDAMajorantIterator
         Spec sigma_t;
@@ -763,11 +769,14 @@ struct GridMediumT {
         if (bmax.z > bmin.z) o.z /= bmax.z - bmin.z;
         return o;
     }
-    VDEV float at(int x, int y, int z) const {  // SampledGrid::Lookup(Point3i) (containers.h:830-835)
+    VDEV float at(int x, int y, int z) const { return at(density, nx, ny, nz, x, y, z); }
+    VDEV float lookup(V3 p) const { return lookup(density, nx, ny, nz, p); }
+    static VDEV float at(const float *data, int nx, int ny, int nz, int x, int y, int z) {  // SampledGrid::Lookup(Point3i) (containers.h:830-835)
         if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
-        return density[((size_t)z * ny + y) * nx + x];
+        return data[((size_t)z * ny + y) * nx + x];
     }
-    VDEV float lookup(V3 p) const {  // SampledGrid::Lookup(Point3f) (containers.h:804-819)
+    static VDEV float lookup(const float *data, int nx, int ny, int nz, V3 p) {  // SampledGrid::Lookup(Point3f) (containers.h:804-819)
+        auto at = [&](int x, int y, int z) { return GridMediumT::at(data, nx, ny, nz, x, y, z); };
         float sx = p.x * nx - .5f, sy = p.y * ny - .5f, sz = p.z * nz - .5f;
         float fx = __builtin_floorf(sx), fy = __builtin_floorf(sy), fz = __builtin_floorf(sz);
         int ix = (int)fx, iy = (int)fy, iz = (int)fz;
@@ -870,17 +879,23 @@ struct GridMediumT {
         const float b0 = a00 + v * (a01 - a00), b1 = a10 + v * (a11 - a10);
         return b0 + u * (b1 - b0);
     }
-    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703 (no emission grids in scope)
+    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703 (temperature grids are out of scope)
         float d;
+        Spec le = sp(0.f);
         if constexpr (NVDB) {
             const V3 xi = V3{(p.x - origin.x) * inv_voxel.x, (p.y - origin.y) * inv_voxel.y, (p.z - origin.z) * inv_voxel.z};
             d = lookup_index(xi);
             d += density_offset;
         } else {
-            d = lookup(offset(p));
+            const V3 po = offset(p);
+            d = lookup(po);
+            if (le_scale) {  // isEmissive (wave-uniform): Le = scale * Le_spec where the LeScale grid is positive (:326-342)
+                const float scale = lookup(le_scale, lnx, lny, lnz, po);
+                if (scale > 0) le = Le * scale;
+            }
         }
         Spec sa = sigma_a * d, ss = sigma_s * d;
-        return MediumProps{sa, ss, sp(0.f), g, ss + sa};
+        return MediumProps{sa, ss, le, g, ss + sa};
     }
     VDEV Spec sigma_n(const MediumProps &mp, Spec sigma_maj) const { return clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s); }
     VDEV bool is_homogeneous() const { return false; }
@@ -894,7 +909,7 @@ template <bool NVDB, bool GREY>
 VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
     return GridMediumT<NVDB, GREY>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
                              majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
-                             S.density_offset};
+                             S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le)};
 }
 template <class M> struct MediumMaker;
 template <int GREY> struct MediumMaker<HomogeneousMediumT<GREY>> {

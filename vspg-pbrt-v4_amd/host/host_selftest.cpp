@@ -100,6 +100,21 @@ int main() {
         CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("loadGuidingCache", true)); }));  // no file name
         CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("storeISGBuffer", true)); }));    // still out of scope
     }
+    // emissive "uniformgrid" (media.cpp:306-328): "Le" + "Lescale" (LeNorm = 1 in RGB rendering mode)
+    {
+        std::vector<float> dens(8, 0.5f), lesc = {0, 1, 2, 3, 4, 5, 6, 7}, ds, ls;
+        VspgMedium m = CreateMedium("uniformgrid", ParameterDictionary().Int("nx", 2).Int("ny", 2).Int("nz", 2).FloatArray("density", dens)
+                                                       .RGB("Le", 1.f, 2.f, 3.f).FloatArray("Lescale", lesc), &ds, &ls);
+        CHECK(m.type == VSPG_MEDIUM_GRID && m.Le[1] == 2.f && m.le_scale == ls.data() && ls == lesc && m.le_nx == 2 && m.le_nz == 2);
+        m = CreateMedium("uniformgrid", ParameterDictionary().Int("nx", 2).Int("ny", 2).Int("nz", 2).FloatArray("density", dens).RGB("Le", 1.f, 2.f, 3.f), &ds);
+        CHECK(m.Le[2] == 3.f && m.le_scale == nullptr);  // the library builds the 1x1x1 default grid
+        m = CreateMedium("uniformgrid", ParameterDictionary().Int("nx", 2).Int("ny", 2).Int("nz", 2).FloatArray("density", dens).RGB("Le", 0.f, 0.f, 0.f), &ds);
+        CHECK(m.Le[0] == 0.f && m.le_scale == nullptr);  // Le.MaxValue() == 0: not emissive
+        CHECK(throws([&] { CreateMedium("uniformgrid", ParameterDictionary().Int("nx", 2).Int("ny", 2).Int("nz", 2).FloatArray("density", dens)
+                                                           .RGB("Le", 1.f, 1.f, 1.f).FloatArray("Lescale", {1.f, 2.f}), &ds, &ls); }));
+        CHECK(throws([&] { CreateMedium("uniformgrid", ParameterDictionary().Int("nx", 2).Int("ny", 2).Int("nz", 2).FloatArray("density", dens)
+                                                           .FloatArray("temperature", dens), &ds); }));
+    }
     // TrBuffer persistence (cpu/trbuffer.h Store / Load): PFM raster, bottom scanline first
     {
         TrBuffer tb;

@@ -128,7 +128,7 @@ void ParameterDictionary::ReportUnused() const {
 }
 
 // ---------------------------------------------------------------------------------------
-static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<float> *densityStorage) {
+static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<float> *densityStorage, std::vector<float> *leScaleStorage) {
     // GridMedium::Create (media.cpp:272-361)
     VspgMedium m;
     std::memset(&m, 0, sizeof m);
@@ -140,8 +140,16 @@ static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<flo
     if ((long long)density.size() != (long long)nx * ny * nz)
         throw Error("Grid medium has " + std::to_string(density.size()) + " density values; expected nx*ny*nz = " +
                     std::to_string((long long)nx * ny * nz));
-    float le[3];
-    if (p.GetOneRGB("Le", le) || !p.GetFloatArray("Lescale").empty()) throw Error("grid medium \"Le\" / \"Lescale\" are outside this build's scope");
+    // emission (media.cpp:306-328): in RGB rendering mode SpectrumToPhotometric() is 1 (util/spectrum.cpp:48-49), so LeNorm = 1
+    float le[3] = {0.f, 0.f, 0.f};
+    const bool hasLe = p.GetOneRGB("Le", le);
+    std::vector<float> leScale = p.GetFloatArray("Lescale");
+    const bool emissive = hasLe && (le[0] > 0 || le[1] > 0 || le[2] > 0);  // Le.MaxValue() == 0 -> ConstantSpectrum(0)
+    if (!leScale.empty() && (long long)leScale.size() != (long long)nx * ny * nz)
+        throw Error("Expected " + std::to_string(nx) + " x " + std::to_string(ny) + " " + std::to_string(nz) + " = " +
+                    std::to_string((long long)nx * ny * nz) + " values for \"Lescale\" but were given " + std::to_string(leScale.size()) + ".");
+    if (emissive && !leScale.empty() && !leScaleStorage)
+        throw Error("CreateMedium(\"uniformgrid\") with \"Lescale\" needs a leScaleStorage vector to own the grid");
     float p0[3] = {0.f, 0.f, 0.f}, p1[3] = {1.f, 1.f, 1.f};
     p.GetOnePoint3("p0", p0);
     p.GetOnePoint3("p1", p1);
@@ -164,13 +172,22 @@ static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<flo
     m.g = g;
     m.nx = nx; m.ny = ny; m.nz = nz;
     m.density = densityStorage->data();
+    if (emissive) {
+        for (int i = 0; i < 3; ++i) m.Le[i] = le[i];
+        if (!leScale.empty()) {  // LeScale[i] *= LeNorm (= 1)
+            *leScaleStorage = std::move(leScale);
+            m.le_scale = leScaleStorage->data();
+            m.le_nx = nx; m.le_ny = ny; m.le_nz = nz;
+        }  // else: the library builds the reference's 1x1x1 grid {LeNorm}
+    }
     return m;
 }
 
-VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p, std::vector<float> *densityStorage) {
+VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p, std::vector<float> *densityStorage,
+                        std::vector<float> *leScaleStorage) {
     VspgMedium m;
     std::memset(&m, 0, sizeof m);
-    if (name == "uniformgrid") return CreateGridMedium(p, densityStorage);
+    if (name == "uniformgrid") return CreateGridMedium(p, densityStorage, leScaleStorage);
     if (name != "homogeneous")
         throw Error("medium \"" + name + "\": only \"homogeneous\" and \"uniformgrid\" are inside this build's scope");
     // HomogeneousMedium::Create (media.cpp:167-206)

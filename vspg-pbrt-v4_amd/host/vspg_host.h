@@ -69,7 +69,7 @@ class ParameterDictionary {
 // (GridMedium::Create :272-361; the density array is copied into *densityStorage, which must outlive the
 // renderer creation -- VspgMedium.density points into it); other names -> Error: outside scope
 VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &parameters,
-                        std::vector<float> *densityStorage = nullptr);
+                        std::vector<float> *densityStorage = nullptr, std::vector<float> *leScaleStorage = nullptr);
 
 struct Film {
     int xres = 0, yres = 0;
