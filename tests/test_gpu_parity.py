@@ -335,9 +335,10 @@ def test_ragged_resolutions_film_equals_replayed_paths(gpu_pkg, W, H):
 
 
 def test_grey_specialisations_are_bit_identical(gpu_pkg):
-    """The workgroup kernel has three instantiations for homogeneous media: generic, grey medium (medium spectra
-    built from one value) and grey scene (surface reflectances and the throughput too).  Same film, bit for bit --
-    also for a scene where only the medium is grey (one wall coloured), which must pick the middle one."""
+    """The workgroup kernel has four instantiations for homogeneous media: generic, grey medium (medium spectra
+    built from one value), grey scene (surface reflectances and the throughput too) and grey scene with an exactly
+    zero null-collision coefficient (shadow rays end at their first tentative collision).  Same film, bit for bit --
+    also for a scene where only the medium is grey (one wall coloured), which must pick the second one."""
     P = gpu_pkg
     W, H = 96, 64
     films = []
@@ -346,7 +347,7 @@ def test_grey_specialisations_are_bit_identical(gpu_pkg):
         if coloured_wall:
             scene.quads[1].Kd[0], scene.quads[1].Kd[1], scene.quads[1].Kd[2] = 0.63, 0.065, 0.05
         ref = None
-        for env in ({"VSPG_NO_GREY": "1"}, {"VSPG_NO_GREY_KD": "1"}, {}):
+        for env in ({"VSPG_NO_GREY": "1"}, {"VSPG_NO_GREY_KD": "1"}, {"VSPG_NO_NULLZERO": "1"}, {}):
             os.environ.update(env)
             try:
                 r = P.Renderer(scene, P.app_f_params(), W, H, seed=5)

@@ -1084,6 +1084,7 @@ struct VspgRenderer {
     bool field_set = false;
     bool medium_grey = false;   // homogeneous medium with bitwise-grey sigma_a, sigma_s, Le
     bool surfaces_grey = false; // every rectangle's (clamped) Kd bitwise grey
+    bool null_zero = false;     // homogeneous medium whose ClampZero((sigma_t - sigma_a) - sigma_s) is exactly 0 per channel
     // a18: on-device training of the guiding field
     bool training = false;
     int field_iteration = 0;
@@ -1452,6 +1453,8 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         const VspgMedium &m = r->scene.medium;
         r->medium_grey = m.type != VSPG_MEDIUM_NONE && same(m.sigma_a) && same(m.sigma_s) && same(m.Le) && !getenv("VSPG_NO_GREY");
         r->surfaces_grey = !getenv("VSPG_NO_GREY_KD");
+        r->null_zero = m.type == VSPG_MEDIUM_HOMOGENEOUS && !getenv("VSPG_NO_NULLZERO");
+        for (int k = 0; k < 3; ++k) r->null_zero = r->null_zero && !(r->hscene.sigma_n_raw[k] > 0) && r->hscene.sigma_n_raw[k] == r->hscene.sigma_n_raw[k];
         for (int i = 0; i < r->hscene.n_quads; ++i) r->surfaces_grey = r->surfaces_grey && same(r->hscene.quads[i].Kd);
     }
     r->npix = (size_t)cfg->xres * cfg->yres;
@@ -1649,6 +1652,11 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         if (grid)
             hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
+                               r->work_head, r->counters);
+        else if (r->medium_grey && r->surfaces_grey && r->null_zero)  // ... and the null-collision coefficient is exactly 0
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreySceneNullZero, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
                                r->work_head, r->counters);
         else if (r->medium_grey && r->surfaces_grey)  // ... and every Kd bitwise grey: beta is grey by construction too

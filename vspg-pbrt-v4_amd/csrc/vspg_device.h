@@ -661,9 +661,14 @@ struct MajSeg {
 // GREY = 2 additionally promises that every rectangle's Kd is bitwise grey: the BSDF's reflectance is built
 // the same way and the path throughput beta (only ever multiplied by grey medium terms, grey BSDF weights and
 // scalars) is grey by construction too.
-template <int GREY>
+// NULLZERO promises (the host checked the uploaded floats) that the null-collision coefficient
+// ClampZero((sigma_t - sigma_a) - sigma_s) is exactly 0 in every channel -- the usual outcome of the float
+// arithmetic for a homogeneous medium: the ratio-tracking estimate of a shadow ray is then 0 at its first
+// tentative collision (sample_Ld), a fact the compiler cannot see in the runtime constants.
+template <int GREY, bool NULLZERO = false>
 struct HomogeneousMediumT {
     static constexpr int kGrey = GREY;   // 0 none, 1 medium spectra, 2 medium spectra + surface reflectances
+    static constexpr bool kNullZero = NULLZERO;
     // constants live in the workgroup's LDS copy (s_scene_medium, staged by stage_scene_lds)
     static VDEV Spec m3(int o) {
         if constexpr (GREY) {
@@ -699,6 +704,7 @@ struct HomogeneousMediumT {
 using HomogeneousMedium = HomogeneousMediumT<0>;
 using HomogeneousMediumGrey = HomogeneousMediumT<1>;
 using HomogeneousMediumGreyScene = HomogeneousMediumT<2>;
+using HomogeneousMediumGreySceneNullZero = HomogeneousMediumT<2, true>;
 
 // ---------------------------------------------------------------------------------------
 // a6: GridMedium (media.h:284-390) with the 3-D DDA majorant iterator (media.h:140-218),
@@ -901,6 +907,7 @@ struct GridMediumT {
     VDEV bool is_homogeneous() const { return false; }
     static constexpr bool kSingleSegment = false;
     static constexpr bool kAlwaysRealCollision = false;
+    static constexpr bool kNullZero = false;
 };
 using GridMedium = GridMediumT<false>;
 using GridMediumGrey = GridMediumT<false, true>;
@@ -912,8 +919,8 @@ VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
                              S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le)};
 }
 template <class M> struct MediumMaker;
-template <int GREY> struct MediumMaker<HomogeneousMediumT<GREY>> {
-    static VDEV HomogeneousMediumT<GREY> make(const DScene &, const float *) { return HomogeneousMediumT<GREY>{}; }
+template <int GREY, bool NZ> struct MediumMaker<HomogeneousMediumT<GREY, NZ>> {
+    static VDEV HomogeneousMediumT<GREY, NZ> make(const DScene &, const float *) { return HomogeneousMediumT<GREY, NZ>{}; }
 };
 template <bool NVDB, bool GREY> struct MediumMaker<GridMediumT<NVDB, GREY>> {
     static VDEV GridMediumT<NVDB, GREY> make(const DScene &S, const float *majorant) {

@@ -244,8 +244,17 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
             Spec T_maj = sample_T_maj(medium, lo, ld, tMax, us, rng, ch,
                                       [&](V3, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
                                           // ratio tracking (:1207-1232)
-                                          Spec sigma_n = medium.sigma_n(mp, sigma_maj);
                                           float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
+                                          if constexpr (Medium::kNullZero) {
+                                              // sigma_n == 0: T_ray *= T_maj * 0 / pdf is an exact 0 for a positive finite pdf (T_maj is
+                                              // finite), whatever the Russian roulette below draws; the callback's `!T_ray -> return false`
+                                              // follows.  (pdf == 0 -- a FastExp underflow over ~175 mean free paths -- keeps the generic code.)
+                                              if (pdf > 0 && !isinf_(pdf)) {
+                                                  T_ray = sp(0.f);
+                                                  return false;
+                                              }
+                                          }
+                                          Spec sigma_n = medium.sigma_n(mp, sigma_maj);
                                           T_ray = T_ray * (T_maj * sigma_n / pdf);
                                           r_l = r_l * (T_maj * sigma_maj / pdf);
                                           r_u = r_u * (T_maj * sigma_n / pdf);
