@@ -623,6 +623,16 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     __shared__ unsigned int s_item[NP];
     __shared__ unsigned int s_cnt[C_COUNT];
     const Pool P{s_pool, NP};
+    // Heterogeneous media: a tracking walk visits every tentative collision of its ray, and the rays of one list chunk
+    // have wildly different expected counts (0 for a ray that misses the cloud, tens through its core): a chunk lasts
+    // as long as its longest walk.  Before the segment phase the continuing paths are therefore counting-sorted by the
+    // majorant optical depth of their ray (the traversals' own pre-pass quantity), thickest first, so that the lanes of
+    // a chunk walk about equally long and the dynamic chunk queue starts with the long chunks.
+    constexpr bool kSortWalks = !Medium::kSingleSegment;
+    constexpr int kWalkBuckets = 32;
+    __shared__ unsigned short s_order[kSortWalks ? NP : 1];
+    __shared__ unsigned char s_key[kSortWalks ? NP : 1];
+    __shared__ unsigned int s_hist[kSortWalks ? kWalkBuckets : 1];
 
     const float *maj_ptr = nullptr;
     if constexpr (std::is_same<Medium, GridMedium>::value || std::is_same<Medium, GridMediumGrey>::value) {
@@ -731,6 +741,33 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
         const unsigned nPrim = nFresh + nA0, nA = nPrim + nA1;
         if (nA == 0 && s_cnt[C_EXH]) break;  // nothing in flight and nothing left to start
 
+        if constexpr (kSortWalks) {  // ---- order the continuing paths by expected walk length -----------------------
+            if (threadIdx.x < kWalkBuckets) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (unsigned j = threadIdx.x; j < nA1; j += (unsigned)kWgBlock) {
+                const int slot = s_listA[par][NP - 1 - (int)j];
+                const V3 ro = P.v3(PF_RO, slot), rd = P.v3(PF_RD, slot);
+                const int ch = (int)((P.u(PF_FLAGS, slot) >> FL_CH_SHIFT) & 3u);
+                const Isect si = scene_intersect(S, ro, rd, kInf);
+                float tau = 0.f;
+                if (si.hit && S.medium_type != VSPG_MEDIUM_NONE) tau = majorant_optical_depth(medium, ro, rd, si.t, ch);
+                int b = tau > 0.f ? 1 + (int)(tau * 0.75f) : 0;
+                b = b > kWalkBuckets - 1 ? kWalkBuckets - 1 : b;
+                s_key[j] = (unsigned char)b;
+                atomicAdd(&s_hist[b], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {  // exclusive offsets, thickest bucket first
+                unsigned run = 0;
+                for (int b = kWalkBuckets - 1; b >= 0; --b) { const unsigned c = s_hist[b]; s_hist[b] = run; run += c; }
+            }
+            __syncthreads();
+            for (unsigned j = threadIdx.x; j < nA1; j += (unsigned)kWgBlock) {
+                const unsigned pos = atomicAdd(&s_hist[s_key[j]], 1u);
+                s_order[pos] = s_listA[par][NP - 1 - (int)j];
+            }
+            __syncthreads();
+        }
         // ---- S: camera ray + primary segment for new paths, one secondary segment for the others ------
         while (true) {
             unsigned base = 0;
@@ -779,7 +816,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                         freed = true;
                     }
                 } else {
-                    slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
+                    if constexpr (kSortWalks) slot = s_order[i - nPrim];
+                    else slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
                     const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
                     pxy = P.i(PF_PIXEL, slot);
                     const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);

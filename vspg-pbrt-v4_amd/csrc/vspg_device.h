@@ -974,6 +974,24 @@ VDEV Spec sample_T_maj(const Medium &medium, V3 ro, V3 rd, float tMax, float u, 
     return sp(1.f);
 }
 
+// The pre-pass of the two guided traversals on its own: sum of sigma_maj * dt over the ray's majorant segments = the
+// expected number of tentative collisions of a tracking walk along it.  The workgroup kernel sorts rays by it.
+template <class Medium>
+VDEV float majorant_optical_depth(const Medium &medium, V3 ro, V3 rd, float tMax, int ch) {
+    tMax *= len(rd);
+    rd = normalize(rd);
+    auto pre = medium.sample_ray(ro, rd, tMax);
+    float total = 0.f;
+    while (true) {
+        MajSeg seg;
+        if (!pre.next(&seg)) break;
+        float smaj = ch_of(seg.sigma_maj, ch);
+        if (smaj == 0) continue;
+        total += smaj * (seg.tMax - seg.tMin);
+    }
+    return total;
+}
+
 // ---------------------------------------------------------------------------------------
 // a9: SampleT_maj_Resampling (media_sampleTMaj.h:136-248)
 // ---------------------------------------------------------------------------------------
