@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 B_SEGMENT = 256                # 2 x 128 B SoA path state per segment
 B_PATH_FIXED = 32 + 4 + 40     # film RMW + primary-VSP read + ISG sample write
-PMC_PROFILE = "r01b_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
+PMC_PROFILE = "r01c_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
 
 
 class DevArray:
@@ -220,7 +220,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic_bytes / (kern_ms * 1e-3) / 1e9) if traffic_bytes and kern_ms > 0 else None,
                          "traffic_bytes_per_launch": traffic_bytes,
-                         "kernel": "k_render_wave_wg", "kernel_ms": kern_ms, "density_queries_per_path": dq_rank / max(1, paths_rank),
+                         "kernel": "k_render_wave_wg" if args.workload == "fog" and not args.diag_guiding and os.environ.get("VSPG_KERNEL") != "lane"
+                                   else "k_render_wave", "kernel_ms": kern_ms, "density_queries_per_path": dq_rank / max(1, paths_rank),
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:
