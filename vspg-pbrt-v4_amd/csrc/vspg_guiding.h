@@ -118,13 +118,17 @@ VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m
     d.n = 0;
     d.lds = lds;
     d.stride = stride;
-    d.region = field_lookup(fields[f], p);
+    // f differs per lane when a wavefront holds volume and surface vertices: select between the two (scalar-loaded)
+    // field records instead of indexing the array per lane
+    DField F = fields[0];
+    if (f) F = fields[1];
+    d.region = field_lookup(F, p);
     if (d.region < 0) return d;
-    const VspgFieldRegion &R = fields[f].regions[d.region];
+    const VspgFieldRegion &R = F.regions[d.region];
     if (R.n_lobes <= 0) return d;
     d.ok = true;
     d.n = R.n_lobes < GK ? R.n_lobes : GK;
-    const float *ax = region_aux(fields[f], d.region);  // [k] vmf_norm(kappa_clamp(kappa[k])), [GK + k] kappa_clamp(kappa[k])
+    const float *ax = region_aux(F, d.region);  // [k] vmf_norm(kappa_clamp(kappa[k])), [GK + k] kappa_clamp(kappa[k])
     const float nk2 = have_product ? vmf_norm(k2) : 0.f;
     const V3 pivot = ld3(R.pivot);
     float sum = 0;
@@ -162,6 +166,22 @@ VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m
     }
     return d;
 }
+// The product lobe of GuidedPhaseFunction::init as data (so that one gdist_init call serves both vertex kinds)
+VDEV void volume_product_lobe(V3 dir, float g, bool *have_product, V3 *m2, float *k2) {
+    float ag = __builtin_fabsf(g);
+    if (ag < 1e-3f) {
+        *have_product = false;
+        *m2 = mk(0, 0, 1);
+        *k2 = 0;
+        return;
+    }
+    if (ag > 0.99f) ag = 0.99f;
+    float kg = ag * (3 - ag * ag) / (1 - ag * ag);
+    V3 axis = g > 0 ? dir : -dir;
+    *have_product = true;
+    *m2 = normalize(axis);
+    *k2 = kg;
+}
 VDEV GDist gdist_init_surface(const DField *fields, V3 p, V3 n, float *lds, int stride) {
     return gdist_init(fields, 0, p, true, n, kCosineLobeKappa, lds, stride);
 }
@@ -179,8 +199,10 @@ VDEV float gdist_pdf(const GDist &d, V3 w) {
     return s;
 }
 VDEV float gdist_incoming_pdf(const DField *fields, const GDist &d, V3 w) {
-    const VspgFieldRegion &R = fields[d.field].regions[d.region];
-    const float *ax = region_aux(fields[d.field], d.region);
+    DField F = fields[0];
+    if (d.field) F = fields[1];
+    const VspgFieldRegion &R = F.regions[d.region];
+    const float *ax = region_aux(F, d.region);
     float s = 0;
     for (int h = 0; h < GK; h += 4) {
         if (h >= d.n) break;
@@ -193,10 +215,36 @@ VDEV float gdist_incoming_pdf(const DField *fields, const GDist &d, V3 w) {
     }
     return s;
 }
+// IncomingRadiancePDF of two directions in one pass over the region record (RIS: both candidates); per direction the
+// same operations in the same order as gdist_incoming_pdf
+VDEV void gdist_incoming_pdf2(const DField *fields, const GDist &d, bool want0, V3 w0, V3 w1, float *inc0, float *inc1) {
+    DField F = fields[0];
+    if (d.field) F = fields[1];
+    const VspgFieldRegion &R = F.regions[d.region];
+    const float *ax = region_aux(F, d.region);
+    float s0 = 0, s1 = 0;
+    for (int h = 0; h < GK; h += 4) {
+        if (h >= d.n) break;
+        const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = h + j;
+            if (k < d.n) {
+                const V3 dir = guide_raw_dir(d.lds, d.stride, k);
+                if (want0) s0 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w0) - 1)));
+                s1 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w1) - 1)));
+            }
+        }
+    }
+    *inc0 = s0;
+    *inc1 = s1;
+}
 // VolumeScatterProbability(w) of the region the lane's scratch was initialised for (field f, `region`, at its point)
 VDEV float gdist_vsp(const DField *fields, int f, int region, const float *lds, int stride, V3 w) {
-    const VspgFieldRegion &R = fields[f].regions[region];
-    const float *ax = region_aux(fields[f], region);
+    DField F = fields[0];
+    if (f) F = fields[1];
+    const VspgFieldRegion &R = F.regions[region];
+    const float *ax = region_aux(F, region);
     int n = R.n_lobes < GK ? R.n_lobes : GK;
     float num = 0, den = 0;
     for (int h = 0; h < GK; h += 4) {

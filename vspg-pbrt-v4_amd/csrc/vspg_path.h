@@ -831,31 +831,42 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
     GDist gd;
     bool useGuiding;
     float survivalProb = 1.f;
+    // gphase.init(&phase, p, ray.d, v) / gbsdf.init(&bsdf, ray, si, v): ONE Init call site for both vertex kinds -- a
+    // wavefront usually holds both, and two inlined copies of the most expensive guiding routine would run one after
+    // the other at half occupancy each.  The kinds differ in data only: field, point, product lobe.
+    int gfield;
+    V3 gpoint, gm2;
+    float gk2;
+    bool gprod, ginit;
     if (volume_vertex) {
-        gd = gdist_init_volume(S.field, vp, st.rd, vg, glds, gstride);  // gphase.init(&phase, p, ray.d, v)
+        gfield = 1;
+        gpoint = vp;
+        ginit = true;
+        volume_product_lobe(st.rd, vg, &gprod, &gm2, &gk2);
+    } else {
+        gfield = 0;
+        gpoint = st.ro + st.rd * si.t;  // p = ray.o + si->tHit * ray.d (guiding.h:85)
+        ginit = bsdf.has_lobes;
+        gprod = true;
+        gm2 = si.n;
+        if (dot(-st.rd, si.n) < 0.f) gm2 = -gm2;
+        gk2 = kCosineLobeKappa;
+    }
+    gd.ok = false;
+    gd.region = -1;
+    if (ginit) gd = gdist_init(S.field, gfield, gpoint, gprod, gm2, gk2, glds, gstride);
+    st.gs.useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
+    st.gs.field = gfield;
+    st.gs.region = gd.region;
+    st.gs.p = gpoint;
+    if (volume_vertex) {
         useGuiding = S.prm.volumeguiding ? gd.ok : false;
-        st.gs.useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
-        st.gs.field = 1;
-        st.gs.region = gd.region;
-        st.gs.p = vp;
         if (st.depth > S.prm.minrrdepth) {
             Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction;
             survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
         }
     } else {
-        gd.ok = false;
-        gd.region = -1;
-        V3 pg = st.ro + st.rd * si.t;  // p = ray.o + si->tHit * ray.d (guiding.h:85)
-        if (bsdf.has_lobes) {
-            V3 ng = si.n;
-            if (dot(-st.rd, si.n) < 0.f) ng = -ng;
-            gd = gdist_init_surface(S.field, pg, ng, glds, gstride);
-        }
         useGuiding = S.prm.surfaceguiding ? gd.ok : false;
-        st.gs.useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
-        st.gs.field = 0;
-        st.gs.region = gd.region;
-        st.gs.p = pg;
     }
     if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {
         Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, useGuiding ? &gd : nullptr);
@@ -863,91 +874,143 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         pc.rec.add_scattered_direct_light(Ld);  // :485 / :838
     }
 
-    if (volume_vertex) {
+    // ---- new direction: Sample_p / Sample_f, MIS or RIS flavour (guiding.h:120-257, 404-530) ----------------------
+    // One flow for volume and surface vertices and for both flavours: the expensive mixture routines (gdist_pdf,
+    // gdist_sample, the two IncomingRadiancePDF evaluations) have ONE call site each, entered by every lane that needs
+    // them, whatever its vertex kind -- a wavefront holds both kinds, and the reference's defaults even mix the flavours
+    // (surfaces RIS, volumes MIS).  Per lane the operations, their order and the sampler dimensions are those of the four
+    // separate routines; only the cheap scattering-function pieces (Henyey-Greenstein / diffuse BSDF) branch on the kind.
+    if (volume_vertex) {  // Russian roulette comes BEFORE the direction at a volume vertex (:848-853)
         if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
             float q = fmax_(0.f, 1 - survivalProb);
             if (sampler.get1d() < q) return false;
             st.beta = st.beta / (1 - q);
         }
-        float u0 = sampler.get1d(), u1 = sampler.get1d();
-        V3 wo = -st.rd;
-        float ps_p = 0, ps_pdf = 0;
-        V3 wi = mk(0, 0, 0);
-        bool have = false;
-        if (!useGuiding) {
-            wi = sample_henyey_greenstein(wo, vg, u0, u1, &ps_pdf);
-            ps_p = ps_pdf;
-            have = true;
-        } else if (S.prm.volumeguidingtype == VSPG_GUIDE_MIS) {  // Sample_p_MIS (guiding.h:404-445)
-            bool samplePhase = true;
-            if (kGuidingProbability > u0) {
-                u0 /= kGuidingProbability;
-                samplePhase = false;
+    } else {
+        st.prevCtx.p = si.p;
+        st.prevCtx.quad = si.quad;
+    }
+    const V3 wo = -st.rd;
+    float usel = 0;  // surface: the MIS selector u; volume: u0 doubles as selector
+    if (!volume_vertex) usel = sampler.get1d();
+    float ua = sampler.get1d(), ub = sampler.get1d();  // u0,u1 (volume) / u2 (surface)
+    const bool ris = useGuiding && (volume_vertex ? S.prm.volumeguidingtype : S.prm.surfaceguidingtype) != VSPG_GUIDE_MIS;
+    bool sampleSF = true;  // MIS: take the direction from the scattering function (else from the mixture)
+    if (useGuiding && !ris) {
+        if (volume_vertex) {
+            if (kGuidingProbability > ua) {
+                ua /= kGuidingProbability;
+                sampleSF = false;
             } else {
-                u0 -= kGuidingProbability;
-                u0 /= (1.0f - kGuidingProbability);
+                ua -= kGuidingProbability;
+                ua /= (1.0f - kGuidingProbability);
             }
-            if (samplePhase) {
-                wi = sample_henyey_greenstein(wo, vg, u0, u1, &ps_pdf);
-                ps_p = ps_pdf;
-                float guidedPDF = gdist_pdf(gd, wi);
-                ps_pdf = ((1.0f - kGuidingProbability) * ps_pdf) + (kGuidingProbability * guidedPDF);
-                have = true;
-            } else {
-                float guidedPDF = gdist_sample(gd, u0, u1, &wi);
-                float pp = henyey_greenstein(dot(wo, wi), vg);
-                if (pp > 0.f) {
-                    ps_p = pp;
-                    ps_pdf = ((1.0f - kGuidingProbability) * pp) + (kGuidingProbability * guidedPDF);
-                    have = true;
-                }
-            }
-        } else {  // Sample_p_RIS (guiding.h:447-530)
-            float rphase0, rp1;
-            V3 w0 = sample_henyey_greenstein(wo, vg, u0, u1, &rphase0);
-            float rguid0 = gdist_pdf(gd, w0);
-            float rinc0 = gdist_incoming_pdf(S.field, gd, w0);
-            float rmis0 = 0.5f * (rphase0 + rguid0);
-            float s0 = sampler.get1d(), s1 = sampler.get1d();
-            V3 w1;
-            float rguid1 = gdist_sample(gd, s0, s1, &w1);
-            float rinc1 = gdist_incoming_pdf(S.field, gd, w1);
-            rp1 = henyey_greenstein(dot(wo, w1), vg);
-            float rmis1 = 0.5f * (rp1 + rguid1);
-            float sumW = 0.f, rw0 = 0.f, rw1 = 0.f;
-            int nS = 0;
-            if (rphase0 > 0.f) {
-                rw0 = (rphase0 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc0));
-                rw0 /= rmis0;
-                sumW += rw0;
-                nS++;
-            }
-            if (rp1 > 0.f) {
-                rw1 = (rp1 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc1));
-                rw1 /= rmis1;
-                sumW += rw1;
-                nS++;
-            }
-            if (!(nS == 0 || sumW <= 0.f)) {
-                float sample1D = sumW * sampler.get1d();
-                // for (i < 2) { sumRis += w_i; if (sample1D <= sumRis) { idx = i; break; } }  (idx defaults to 0)
-                float sumR = 0.f + rw0;
-                int idx = 0;
-                if (!(sample1D <= sumR)) {
-                    sumR += rw1;
-                    if (sample1D <= sumR) idx = 1;
-                }
-                float rw = idx ? rw1 : rw0, rmis = idx ? rmis1 : rmis0;
-                ps_pdf = (rw * rmis) * ((float)2 / sumW);
-                ps_p = idx ? rp1 : rphase0;
-                wi = idx ? w1 : w0;
-                have = true;
-            }
+        } else if (kGuidingProbability > usel) {
+            sampleSF = false;
         }
-        if (!have || ps_pdf == 0) return false;
-        float w = ps_p / ps_pdf;
+    }
+    // candidate 0: the scattering function's own sample (unguided lanes, RIS, MIS when it was chosen)
+    V3 w0 = mk(0, 0, 0);
+    float sf0 = 0;        // its pdf (== its value for the phase function)
+    Spec f0 = sp(0.f);    // surface: BSDF value
+    bool ok0 = false;
+    if (!useGuiding || ris || sampleSF) {
+        if (volume_vertex) {
+            w0 = sample_henyey_greenstein(wo, vg, ua, ub, &sf0);
+            ok0 = true;
+        } else {
+            ok0 = bsdf_sample_f(bsdf, wo, ua, ub, &f0, &w0, &sf0);
+        }
+    }
+    float g0 = 0, inc0 = 0, g1 = 0, inc1 = 0;
+    V3 w1 = mk(0, 0, 0);
+    if (useGuiding && ok0 && (ris || sampleSF)) g0 = gdist_pdf(gd, w0);
+    float s0 = ua, s1 = ub;  // MIS samples the mixture with the vertex's own 2D sample, RIS with a fresh one
+    if (ris) {
+        s0 = sampler.get1d();
+        s1 = sampler.get1d();
+    }
+    const bool cand1 = useGuiding && (ris || !sampleSF);
+    if (cand1) g1 = gdist_sample(gd, s0, s1, &w1);
+    if (ris) gdist_incoming_pdf2(S.field, gd, ok0, w0, w1, &inc0, &inc1);
+    // scattering function at the mixture's direction
+    float sf1 = 0;
+    Spec f1 = sp(0.f);
+    if (cand1) {
+        if (volume_vertex) {
+            sf1 = henyey_greenstein(dot(wo, w1), vg);
+        } else {
+            f1 = bsdf_f(bsdf, wo, w1);
+            sf1 = bsdf_pdf(bsdf, wo, w1);
+        }
+    }
+    // combine
+    V3 wi = mk(0, 0, 0);
+    Spec f = sp(0.f);
+    float pdf = 0, sfPdf = 0, misPdf = 0;
+    bool have = false;
+    if (!useGuiding) {
+        have = ok0;
+        wi = w0; f = f0;
+        pdf = sfPdf = misPdf = sf0;
+    } else if (!ris) {
+        if (sampleSF) {
+            if (ok0) {
+                wi = w0; f = f0;
+                sfPdf = sf0;
+                pdf = ((1.0f - kGuidingProbability) * sf0) + (kGuidingProbability * g0);
+                misPdf = pdf;
+                have = true;
+            }
+        } else if (sf1 > 0.f) {
+            wi = w1; f = f1;
+            sfPdf = sf1;
+            pdf = ((1.0f - kGuidingProbability) * sf1) + (kGuidingProbability * g1);
+            misPdf = pdf;
+            have = true;
+        }
+    } else {
+        const float rb0 = ok0 ? sf0 : 0.f;
+        const float rmis0 = ok0 ? 0.5f * (rb0 + g0) : 0.f;
+        const float rmis1 = 0.5f * (sf1 + g1);
+        float sumW = 0.f, rw0 = 0.f, rw1 = 0.f;
+        int nS = 0;
+        if (rb0 > 0.f) {
+            rw0 = (rb0 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * inc0));
+            rw0 /= rmis0;
+            sumW += rw0;
+            nS++;
+        }
+        if (sf1 > 0.f) {
+            rw1 = (sf1 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * inc1));
+            rw1 /= rmis1;
+            sumW += rw1;
+            nS++;
+        }
+        if (!(nS == 0 || sumW <= 0.f)) {
+            float sample1D = sumW * sampler.get1d();
+            // for (i < 2) { sumRis += w_i; if (sample1D <= sumRis) { idx = i; break; } }  (idx defaults to 0)
+            float sumR = 0.f + rw0;
+            int idx = 0;
+            if (!(sample1D <= sumR)) {
+                sumR += rw1;
+                if (sample1D <= sumR) idx = 1;
+            }
+            const float rw = idx ? rw1 : rw0;
+            misPdf = idx ? rmis1 : rmis0;
+            pdf = (rw * misPdf) * ((float)2 / sumW);
+            sfPdf = idx ? sf1 : rb0;
+            f = idx ? f1 : f0;
+            wi = idx ? w1 : w0;
+            have = true;
+        }
+    }
+
+    if (volume_vertex) {
+        if (!have || pdf == 0) return false;
+        float w = sfPdf / pdf;  // ps->p / ps->pdf
         st.beta = st.beta * w;
-        st.r_l = st.r_u / ps_pdf;
+        st.r_l = st.r_u / pdf;
         st.prevCtx.p = vp;
         st.prevCtx.quad = -1;
         st.ro = vp;
@@ -955,97 +1018,13 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         st.specularBounce = false;
         st.anyNonSpecularBounces = true;
         // guiding_addVolumeData(..., phaseFunctionWeight, ps->wi, ps->pdf, ps->meanCosine, survivalProb) (:871)
-        pc.rec.add_scatter_data(true, sp(w), wi, ps_pdf, 1.0f - __builtin_fabsf(vg), survivalProb);
+        pc.rec.add_scatter_data(true, sp(w), wi, pdf, 1.0f - __builtin_fabsf(vg), survivalProb);
         st.lastVertexVolume = true;
         return true;
     }
-
-    st.prevCtx.p = si.p;
-    st.prevCtx.quad = si.quad;
-    V3 wo = -st.rd;
-    float u = sampler.get1d();
-    float u20 = sampler.get1d(), u21 = sampler.get1d();
-    Spec f = sp(0.f);
-    V3 wi = mk(0, 0, 0);
-    float pdf = 0, bsdfPdf = 0, misPdf = 0;
-    bool have = false;
-    if (!useGuiding) {
-        have = bsdf_sample_f(bsdf, wo, u20, u21, &f, &wi, &pdf);
-        bsdfPdf = misPdf = pdf;
-    } else if (S.prm.surfaceguidingtype == VSPG_GUIDE_MIS) {  // Sample_f_MIS (guiding.h:120-167)
-        bool sampleBSDF = true;
-        if (kGuidingProbability > u) {
-            sampleBSDF = false;
-        }
-        if (sampleBSDF) {
-            have = bsdf_sample_f(bsdf, wo, u20, u21, &f, &wi, &pdf);
-            if (have) {
-                float guidedPDF = gdist_pdf(gd, wi);
-                bsdfPdf = pdf;
-                pdf = ((1.0f - kGuidingProbability) * pdf) + (kGuidingProbability * guidedPDF);
-                misPdf = pdf;
-            }
-        } else {
-            float guidedPDF = gdist_sample(gd, u20, u21, &wi);
-            f = bsdf_f(bsdf, wo, wi);
-            float bPDF = bsdf_pdf(bsdf, wo, wi);
-            if (bPDF > 0.f) {
-                pdf = ((1.0f - kGuidingProbability) * bPDF) + (kGuidingProbability * guidedPDF);
-                bsdfPdf = bPDF;
-                misPdf = pdf;
-                have = true;
-            }
-        }
-    } else {  // Sample_f_RIS (guiding.h:169-257)
-        Spec rf0 = sp(0.f), rf1;
-        V3 w0 = mk(0, 0, 0), w1;
-        float rb0 = 0, rguid0 = 0, rmis0 = 0, rinc0 = 0, p0;
-        if (bsdf_sample_f(bsdf, wo, u20, u21, &rf0, &w0, &p0)) {
-            rb0 = p0;
-            rguid0 = gdist_pdf(gd, w0);
-            rinc0 = gdist_incoming_pdf(S.field, gd, w0);
-            rmis0 = 0.5f * (rb0 + rguid0);
-        }
-        float s0 = sampler.get1d(), s1 = sampler.get1d();
-        float rguid1 = gdist_sample(gd, s0, s1, &w1);
-        float rinc1 = gdist_incoming_pdf(S.field, gd, w1);
-        rf1 = bsdf_f(bsdf, wo, w1);
-        float rb1 = bsdf_pdf(bsdf, wo, w1);
-        float rmis1 = 0.5f * (rb1 + rguid1);
-        float sumW = 0.f, rw0 = 0.f, rw1 = 0.f;
-        int nS = 0;
-        if (rb0 > 0.f) {
-            rw0 = (rb0 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc0));
-            rw0 /= rmis0;
-            sumW += rw0;
-            nS++;
-        }
-        if (rb1 > 0.f) {
-            rw1 = (rb1 * ((1.0f - kGuidingProbability) * kUniformIncomingRadiancePDF + kGuidingProbability * rinc1));
-            rw1 /= rmis1;
-            sumW += rw1;
-            nS++;
-        }
-        if (!(nS == 0 || sumW <= 0.f)) {
-            float sample1D = sumW * sampler.get1d();
-            float sumR = 0.f + rw0;
-            int idx = 0;
-            if (!(sample1D <= sumR)) {
-                sumR += rw1;
-                if (sample1D <= sumR) idx = 1;
-            }
-            float rw = idx ? rw1 : rw0;
-            misPdf = idx ? rmis1 : rmis0;
-            pdf = (rw * misPdf) * ((float)2 / sumW);
-            bsdfPdf = idx ? rb1 : rb0;
-            f = idx ? rf1 : rf0;
-            wi = idx ? w1 : w0;
-            have = true;
-        }
-    }
     if (!have) return false;
     st.lastVertexVolume = false;
-    st.rr_correction *= pdf / bsdfPdf;
+    st.rr_correction *= pdf / sfPdf;
     Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
     st.beta = st.beta * bsdfWeight;
     st.r_l = st.r_u / misPdf;
