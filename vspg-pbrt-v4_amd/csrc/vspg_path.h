@@ -915,11 +915,30 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
     Spec f0 = sp(0.f);    // surface: BSDF value
     bool ok0 = false;
     if (!useGuiding || ris || sampleSF) {
+        // SampleHenyeyGreenstein and DiffuseBxDF::Sample_f both need sin/cos of one angle: one evaluation for both kinds
+        // (as in vertex_tail)
+        float ang, a0 = 0, a1 = 0;
+        bool degenerate = false, okf = true;
         if (volume_vertex) {
-            w0 = sample_henyey_greenstein(wo, vg, ua, ub, &sf0);
-            ok0 = true;
+            ang = hg_pre(vg, ua, ub, &a0, &a1);  // a0 = sinTheta, a1 = cosTheta
         } else {
-            ok0 = bsdf_sample_f(bsdf, wo, ua, ub, &f0, &w0, &sf0);
+            a1 = bsdf.frame.to_local(wo).z;     // BSDF::Sample_f / DiffuseBxDF::Sample_f (bsdf.h:58-78, bxdfs.h:47-58)
+            okf = !(a1 == 0 || !bsdf.has_lobes);
+            ang = cos_hemi_pre(ua, ub, &a0, &degenerate);  // a0 = r
+        }
+        const float sinA = sinf_(ang), cosA = cosf_(ang);
+        if (volume_vertex) {
+            w0 = hg_post(wo, vg, a0, a1, sinA, cosA, &sf0);
+            ok0 = true;
+        } else if (okf) {
+            V3 wl = cos_hemi_post(a0, degenerate, sinA, cosA);
+            if (a1 < 0) wl.z *= -1;
+            sf0 = __builtin_fabsf(wl.z) * kInvPi;
+            f0 = bsdf.R * kInvPi;
+            if (!(!nonzero(f0) || sf0 == 0 || wl.z == 0)) {
+                w0 = bsdf.frame.from_local(wl);
+                ok0 = true;
+            }
         }
     }
     float g0 = 0, inc0 = 0, g1 = 0, inc1 = 0;
