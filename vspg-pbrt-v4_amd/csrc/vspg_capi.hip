@@ -59,10 +59,13 @@ __device__ __forceinline__ void flush_counters(const PC &pc, uint32_t paths, uns
 //   items are tile-ordered (8x8 pixels per 64 items) so a fresh wavefront starts on one coherent
 //   tile of primary rays.
 struct TrainArgs {  // a18: where a training launch records (all null / 0 otherwise)
-    float *segbuf;                   // per-lane segment records, SoA over the launch's lanes
+    float *segbuf;                   // segment records, one column per work item (pixel of the wave): record (seg, field) of
+                                     // item i at segbuf[(seg * SG_FLOATS + field) * n_items + i]
+    int *seg_count;                  // records written per work item (0 = no path)
     VspgTrainSample *samples;        // radiance samples of this wave
     unsigned long long *counters;    // [0] samples appended, [1] zero-valued samples dropped
     unsigned long long capacity;
+    unsigned int n_items;
 };
 template <class Medium, bool GUIDED, bool TRAIN = false>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     typename std::conditional<TRAIN, PathCountersT<PathRecorder>, PathCounters>::type pc;
     pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = 0;
     if constexpr (TRAIN) {
-        pc.rec.base = train.segbuf + (size_t)blockIdx.x * kBlock + threadIdx.x;
-        pc.rec.stride = (int)(gridDim.x * kBlock);
+        pc.rec.base = train.segbuf;  // re-pointed at the lane's work item when a path starts
+        pc.rec.stride = (int)train.n_items;
         pc.rec.max_seg = S.prm.maxdepth + 2;
         pc.rec.reset();
     }
@@ -124,17 +127,15 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     PathState st;
     IsgSample isg;
 
-    // training launches: a finished path waits (`pending`) until kPropagateBatch lanes of its wavefront have one, so that
-    // PropagateSamples -- a lock-step loop over the longest recorded path, ~150 loads of segment records -- runs with
-    // many lanes instead of the handful that end in any one iteration
-    bool pending = false;
-#ifndef VSPG_PROPAGATE_BATCH
-#define VSPG_PROPAGATE_BATCH 24
-#endif
-    constexpr int kPropagateBatch = VSPG_PROPAGATE_BATCH;
+    // Training launches (one sample per pixel): every path writes its segment records into its OWN column of a
+    // buffer sized for the whole wave (1.3 GB at 1080p -- this part has 288 GB) and leaves; PropagateSamples runs
+    // afterwards as its own kernel over all paths at full occupancy (k_propagate).  Propagating inside this kernel
+    // meant a lock-step loop over the longest recorded path, ~100 dependent loads, for the few lanes that had just
+    // finished (8.0 ms per training wave), or parking finished lanes until enough had gathered (4.4 ms).
+    unsigned my_item = 0;
     while (true) {
         // ---- regeneration: ballot the empty lanes, prefix-count them, hand out items -----------
-        unsigned long long need = __ballot(!has && !pending);
+        unsigned long long need = __ballot(!has);
         if (need != 0ull && !(exhausted && local_next >= local_end)) {
             if (local_next >= local_end && !exhausted) {
                 unsigned base = 0;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
             }
             const unsigned rank = (unsigned)__popcll(need & ((1ull << lane) - 1ull));
             const unsigned avail = local_end - local_next;  // lanes beyond `avail` wait for the next chunk
-            if (!has && !pending && rank < avail) {
+            if (!has && rank < avail) {
                 VSPG_PROF(PS_START);
                 const unsigned item = local_next + rank;
                 const unsigned tile = item >> 6, l = item & 63u;
@@ -160,13 +161,17 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
                     else
                         start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);
                     has = true;
+                    if constexpr (TRAIN) {
+                        my_item = item;
+                        pc.rec.base = train.segbuf + item;
+                        pc.rec.reset();
+                    }
                 }
             }
             const unsigned cnt = (unsigned)__popcll(need);
             local_next += cnt < avail ? cnt : avail;
         }
-        const bool idle = __ballot(has) == 0ull;
-        if (idle && !(TRAIN && __ballot(pending) != 0ull)) {
+        if (__ballot(has) == 0ull) {
             if (exhausted && local_next >= local_end) break;
             continue;
         }
@@ -182,37 +187,48 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
                 isg_add_sample_atomic(isg_stats + idx * VSPG_ISG_STATS, L, isg);
                 paths++;
                 finished = true;
-            }
-        }
-        if constexpr (TRAIN) {  // PropagateSamples (:627), in lock step across the wavefront
-            if (finished) {
-                pending = true;
-                has = false;
-            }
-            finished = false;
-            const unsigned long long pm = __ballot(pending);
-            // nothing else can happen in this wavefront before the parked paths are propagated: no live lane, or no free lane can be refilled
-            const bool starved = __ballot(has) == 0ull;
-            if (pm != 0ull && ((int)__popcll(pm) >= kPropagateBatch || starved)) {
-                propagate_samples(pc.rec, pending, train.samples, train.counters, train.capacity);
-                if (pending) {
-                    pc.rec.reset();
-                    pending = false;
-                    finished = true;
-                }
+                if constexpr (TRAIN) train.seg_count[my_item] = pc.rec.n;  // PropagateSamples (:627) follows in k_propagate
             }
         }
         if (finished) {
             s += S.shard_count > 1 ? S.shard_count : 1;
-            if (s < wave_end) {
+            if (!TRAIN && s < wave_end)
                 start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
-                has = true;
-            } else {
+            else
                 has = false;
-            }
         }
     }
     flush_counters(pc, paths, counters);
+}
+
+// PathSegmentStorage::PropagateSamples (:627) for every path of a training wave: one thread per work item
+constexpr int kStagePerLane = 6;  // samples a lane can stage (maxdepth 5: at most maxdepth + 1 samples per path)
+__global__ __launch_bounds__(kBlock) void k_propagate(TrainArgs train, int max_seg) {
+    __shared__ VspgTrainSample s_stage[kBlock * kStagePerLane];  // 61 KB
+    __shared__ unsigned int s_wcount[kBlock / 64];
+    __shared__ unsigned long long s_base;
+    const unsigned i = blockIdx.x * kBlock + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    PathRecorder rec;
+    rec.base = train.segbuf + (i < train.n_items ? i : 0u);
+    rec.stride = (int)train.n_items;
+    rec.max_seg = max_seg;
+    rec.reset();
+    rec.n = i < train.n_items ? train.seg_count[i] : 0;
+    StageSink sink{s_stage + wave * 64 * kStagePerLane, 64u * kStagePerLane, 0u, train.samples, train.counters, train.capacity};
+    propagate_samples(rec, rec.n > 0, sink);
+    if (lane == 0) s_wcount[wave] = sink.count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) total += s_wcount[w];
+        s_base = total ? atomicAdd(&train.counters[0], (unsigned long long)total) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long base = s_base;
+    for (int w = 0; w < wave; ++w) base += s_wcount[w];
+    for (unsigned int j = (unsigned int)lane; j < sink.count; j += 64u)
+        if (base + j < train.capacity) train.samples[base + j] = sink.stage[j];
 }
 
 // DField::aux of regions [0, n_regions): the per-lobe constants every mixture evaluation needs
@@ -1126,8 +1142,9 @@ struct VspgRenderer {
     // a18: on-device training of the guiding field
     bool training = false;
     int field_iteration = 0;
-    float *segbuf = nullptr;                  // per-lane segment records of the training launches
-    size_t segbuf_lanes = 0;
+    float *segbuf = nullptr;                  // segment records of a training wave, one column per work item
+    int *seg_count = nullptr;                 // records per work item
+    size_t segbuf_items = 0;
     VspgTrainSample *samples = nullptr;
     unsigned long long sample_capacity = 0;
     unsigned long long *train_counters = nullptr;  // [0] samples, [1] zero-valued, [2..3] spare
@@ -1575,8 +1592,9 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             r->hscene.field[f] = DField{1, 1, r->fnodes[f], r->fregions[f], r->faux[f]};
         }
         CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
-        r->segbuf_lanes = (size_t)r->num_cus * kBlocksPerCU * kBlock;
-        CK(hipMalloc(&r->segbuf, r->segbuf_lanes * (size_t)(r->prm.maxdepth + 2) * SG_FLOATS * sizeof(float)));
+        r->segbuf_items = (size_t)((cfg->xres + 7) / 8) * (size_t)((cfg->yres + 7) / 8) * 64;  // the work items of a 1-spp wave
+        CK(hipMalloc(&r->segbuf, r->segbuf_items * (size_t)(r->prm.maxdepth + 2) * SG_FLOATS * sizeof(float)));
+        CK(hipMalloc(&r->seg_count, r->segbuf_items * sizeof(int)));
         r->sample_capacity = (unsigned long long)r->npix * (unsigned long long)(r->prm.maxdepth + 1);
         if (r->sample_capacity > (1ull << 26)) r->sample_capacity = 1ull << 26;
         CK(hipMalloc(&r->samples, r->sample_capacity * sizeof(VspgTrainSample)));
@@ -1614,6 +1632,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     for (int f = 0; f < 2; ++f)
         if (r->rstats[f]) (void)hipFree(r->rstats[f]);
     if (r->segbuf) (void)hipFree(r->segbuf);
+    if (r->seg_count) (void)hipFree(r->seg_count);
     if (r->samples) (void)hipFree(r->samples);
     if (r->train_counters) (void)hipFree(r->train_counters);
     if (r->train_acc) (void)hipFree(r->train_acc);
@@ -1659,8 +1678,18 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but the renderer holds no guiding field");
     // a18: while the field trains, the guided kernels record path segments and emit radiance samples
     const bool train = guided && r->training;
-    TrainArgs targs = {nullptr, nullptr, nullptr, 0};
-    if (train) targs = TrainArgs{r->segbuf, r->samples, r->train_counters, r->sample_capacity};
+    TrainArgs targs = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (train) {
+        if (n_samples > 1) {  // a training launch covers one sample per pixel (the record buffer is sized for that): split
+            for (int w = first; w < wave_end; w += sc > 1 ? sc : 1) {
+                const int rc = vspg_render_wave(r, w, w + 1, stream);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+        targs = TrainArgs{r->segbuf, r->seg_count, r->samples, r->train_counters, r->sample_capacity, (unsigned)items};
+        HIPCHK(hipMemsetAsync(r->seg_count, 0, (size_t)items * sizeof(int), (hipStream_t)stream));
+    }
 #define VSPG_LAUNCH_RENDER(M, G)                                                                                          \
     do {                                                                                                                  \
         if (G && train)                                                                                                   \
@@ -1721,6 +1750,11 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     else VSPG_LAUNCH_RENDER(HomogeneousMedium, false);
 #undef VSPG_LAUNCH_RENDER
     HIPCHK(hipGetLastError());
+    if (train) {
+        hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, targs,
+                           r->prm.maxdepth + 2);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 

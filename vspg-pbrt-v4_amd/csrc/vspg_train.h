@@ -35,83 +35,113 @@ struct NullRecorder {  // every hook compiles to nothing
     VDEV void add_scatter_data(bool, Spec, V3, float, float, float) const {}
 };
 
+// Records live in HBM (a column per lane).  A record's groups of fields are written only when the path sets them; the
+// flags word says which groups are present and PropagateSamples substitutes the defaults for the others (so a new
+// segment costs 4 stores instead of 22, and the propagation loads what exists).  The current record's flags and its
+// NEE sum are kept in registers and written through: no read-modify-write of HBM in the path code.
+enum : uint32_t {
+    SGF_HAS_WI = 1u,      // add_scatter_data ran: WI, PDF, SW, RR present
+    SGF_VOLUME = 2u,
+    SGF_DELTA = 4u,
+    SGF_T = 8u,           // transmittance weight present (default 1,1,1)
+    SGF_DIRECT = 16u,     // DIRECT + MI present (defaults 0 and 1)
+    SGF_SCAT = 32u,       // SCAT present (default 0)
+};
 struct PathRecorder {
     static constexpr bool kActive = true;
     float *base;  // this lane's column: element (seg, field) at base[(seg * SG_FLOATS + field) * stride]
     int stride, max_seg;
     int n, cur;  // cur: the reference's pathSegmentData pointer, -1 = nullptr
+    uint32_t cur_flags;     // flags of record `cur`
+    float scat_r, scat_g, scat_b;  // its accumulated scattered direct light
     VDEV float &at(int seg, int f) const { return base[(size_t)(seg * SG_FLOATS + f) * (size_t)stride]; }
     VDEV uint32_t &flags(int seg) const { return reinterpret_cast<uint32_t &>(at(seg, SG_FLAGS)); }
     VDEV void set3(int seg, int f, float x, float y, float z) const { at(seg, f) = x; at(seg, f + 1) = y; at(seg, f + 2) = z; }
-    VDEV void reset() { n = 0; cur = -1; }
+    VDEV void reset() { n = 0; cur = -1; cur_flags = 0; scat_r = scat_g = scat_b = 0.f; }
     // guiding_newSurfacePathSegment / guiding_newVolumePathSegment (:682-732)
     VDEV void new_segment(V3 p, bool volume) {
         if (n >= max_seg) { cur = -1; return; }  // NextSegment() == nullptr
         const int s = n;
         set3(s, SG_P, p.x, p.y, p.z);
-        set3(s, SG_WI, 0, 0, 0);
-        at(s, SG_PDF) = 0;
-        at(s, SG_MI) = 1.f;
-        at(s, SG_RR) = 1.f;
-        set3(s, SG_SW, 0, 0, 0);
-        set3(s, SG_T, 1.f, 1.f, 1.f);
-        set3(s, SG_DIRECT, 0, 0, 0);
-        set3(s, SG_SCAT, 0, 0, 0);
-        flags(s) = volume ? 2u : 0u;
+        cur_flags = volume ? SGF_VOLUME : 0u;
+        flags(s) = cur_flags;
+        scat_r = scat_g = scat_b = 0.f;
         cur = n++;
     }
-    VDEV void add_transmittance_weight(Spec T) const {  // :754-764
+    VDEV void add_transmittance_weight(Spec T) {  // :754-764
         if (cur < 0) return;
         T = clamp_zero(T);
         set3(cur, SG_T, T.r, T.g, T.b);
+        cur_flags |= SGF_T;
+        flags(cur) = cur_flags;
     }
-    VDEV void add_surface_emission(Spec Le, float w) const {  // :744-752
+    VDEV void add_surface_emission(Spec Le, float w) {  // :744-752
         if (cur < 0) return;
         Le = clamp_zero(Le);
         set3(cur, SG_DIRECT, Le.r, Le.g, Le.b);
         at(cur, SG_MI) = w;
+        cur_flags |= SGF_DIRECT;
+        flags(cur) = cur_flags;
     }
-    VDEV void add_scattered_direct_light(Spec Ld) const {  // :734-742
+    VDEV void add_scattered_direct_light(Spec Ld) {  // :734-742
         if (cur < 0) return;
         Ld = clamp_zero(Ld);
-        at(cur, SG_SCAT) = at(cur, SG_SCAT) + Ld.r;
-        at(cur, SG_SCAT + 1) = at(cur, SG_SCAT + 1) + Ld.g;
-        at(cur, SG_SCAT + 2) = at(cur, SG_SCAT + 2) + Ld.b;
+        scat_r = scat_r + Ld.r;
+        scat_g = scat_g + Ld.g;
+        scat_b = scat_b + Ld.b;
+        set3(cur, SG_SCAT, scat_r, scat_g, scat_b);
+        cur_flags |= SGF_SCAT;
+        flags(cur) = cur_flags;
     }
     // guiding_addSurfaceData / guiding_addVolumeData (:791-832)
-    VDEV void add_scatter_data(bool volume, Spec weight, V3 wi, float pdf, float roughness, float survivalProb) const {
+    VDEV void add_scatter_data(bool volume, Spec weight, V3 wi, float pdf, float roughness, float survivalProb) {
         if (cur < 0) return;
         weight = clamp_zero(weight);
-        set3(cur, SG_T, 1.f, 1.f, 1.f);
         set3(cur, SG_WI, wi.x, wi.y, wi.z);
         at(cur, SG_PDF) = pdf;
         set3(cur, SG_SW, weight.r, weight.g, weight.b);
         at(cur, SG_RR) = survivalProb;
-        flags(cur) = 1u | (volume ? 2u : 0u) | (roughness < 0.001f ? 4u : 0u);
+        // (the reference resets the transmittance weight to 1 here: drop the group) and rewrites the kind bits
+        cur_flags = (cur_flags & (SGF_DIRECT | SGF_SCAT)) | SGF_HAS_WI | (volume ? SGF_VOLUME : 0u) | (roughness < 0.001f ? SGF_DELTA : 0u);
+        flags(cur) = cur_flags;
     }
 };
 
-// append to the sample buffer: one returning atomic per wavefront (ballot + prefix count)
-VDEV void sample_append(bool emit, const VspgTrainSample &smp, VspgTrainSample *__restrict__ samples,
-                        unsigned long long *__restrict__ counters /* [0] n_samples, [1] n_zero, [2] dropped */,
-                        unsigned long long capacity) {
-    const unsigned long long m = __ballot(emit);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long)__popcll(m));
-    base = __shfl(base, leader);
-    if (emit) {
-        const unsigned long long idx = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-        if (idx < capacity) samples[idx] = smp;
+// Sample sink of k_propagate: a wavefront stages its samples in LDS (ballot + prefix count, no atomics at all) and the
+// workgroup reserves its range of the global buffer with ONE returning atomic -- the counter is a single address, and
+// same-address returning atomics retire at ~10 ns each on this chip: one per wavefront per loop iteration (2*10^5 of
+// them for a 1080p wave) made the propagation a 2 ms kernel.
+struct StageSink {
+    VspgTrainSample *stage;  // this wavefront's LDS staging area
+    unsigned int cap;        // its capacity in samples
+    unsigned int count;      // staged so far (wave-uniform)
+    VspgTrainSample *samples;
+    unsigned long long *counters;
+    unsigned long long capacity;
+    VDEV void flush_wave() {  // overflow path (paths longer than the staging area was sized for): one atomic per wavefront
+        if (count == 0) return;
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)count);
+        base = __shfl(base, 0);
+        for (unsigned int j = (unsigned int)lane; j < count; j += 64u)
+            if (base + j < capacity) samples[base + j] = stage[j];
+        count = 0;
     }
-}
+    VDEV void append(bool emit, const VspgTrainSample &smp) {
+        const unsigned long long m = __ballot(emit);
+        if (m == 0ull) return;
+        const unsigned int k = (unsigned int)__popcll(m);
+        if (count + k > cap) flush_wave();
+        const int lane = threadIdx.x & 63;
+        if (emit) stage[count + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = smp;
+        count += k;
+    }
+};
 
 // PathSegmentStorage::PropagateSamples stand-in (see oracle/vspg_oracle.c:propagate_samples for the
 // definition): walk the path's records from the last vertex to the first, in lock step across the wave.
-VDEV void propagate_samples(const PathRecorder &rec, bool active, VspgTrainSample *__restrict__ samples,
-                            unsigned long long *__restrict__ counters, unsigned long long capacity) {
+VDEV void propagate_samples(const PathRecorder &rec, bool active, StageSink &sink) {
     const int n = active ? rec.n : 0;
     int nmax = n;
     for (int off = 32; off > 0; off >>= 1) {
@@ -127,10 +157,10 @@ VDEV void propagate_samples(const PathRecorder &rec, bool active, VspgTrainSampl
         VspgTrainSample smp;
         if (i < n) {
             const uint32_t fl = rec.flags(i);
-            const bool has_wi = (fl & 1u) != 0, volume = (fl & 2u) != 0, is_delta = (fl & 4u) != 0;
+            const bool has_wi = (fl & SGF_HAS_WI) != 0, volume = (fl & SGF_VOLUME) != 0, is_delta = (fl & SGF_DELTA) != 0;
             const V3 p = V3{rec.at(i, SG_P), rec.at(i, SG_P + 1), rec.at(i, SG_P + 2)};
-            const Spec T = Spec{rec.at(i, SG_T), rec.at(i, SG_T + 1), rec.at(i, SG_T + 2)};
-            const float pdf = rec.at(i, SG_PDF);
+            const Spec T = (fl & SGF_T) ? Spec{rec.at(i, SG_T), rec.at(i, SG_T + 1), rec.at(i, SG_T + 2)} : sp(1.f);
+            const float pdf = has_wi ? rec.at(i, SG_PDF) : 0.f;
             const Spec Lin = have_next ? T * Lout_next : sp(0.f);
             if (has_wi && !is_delta && have_next && pdf > 0) {
                 const float w = avg(Lin) / pdf;
@@ -146,9 +176,11 @@ VDEV void propagate_samples(const PathRecorder &rec, bool active, VspgTrainSampl
                     zero++;
                 }
             }
-            const Spec direct = Spec{rec.at(i, SG_DIRECT), rec.at(i, SG_DIRECT + 1), rec.at(i, SG_DIRECT + 2)};
-            const Spec scat = Spec{rec.at(i, SG_SCAT), rec.at(i, SG_SCAT + 1), rec.at(i, SG_SCAT + 2)};
-            Spec Lout = direct * rec.at(i, SG_MI) + scat;
+            const bool has_direct = (fl & SGF_DIRECT) != 0;
+            const Spec direct = has_direct ? Spec{rec.at(i, SG_DIRECT), rec.at(i, SG_DIRECT + 1), rec.at(i, SG_DIRECT + 2)} : sp(0.f);
+            const float mi = has_direct ? rec.at(i, SG_MI) : 1.f;
+            const Spec scat = (fl & SGF_SCAT) ? Spec{rec.at(i, SG_SCAT), rec.at(i, SG_SCAT + 1), rec.at(i, SG_SCAT + 2)} : sp(0.f);
+            Spec Lout = direct * mi + scat;
             if (has_wi) {
                 const Spec sw = Spec{rec.at(i, SG_SW), rec.at(i, SG_SW + 1), rec.at(i, SG_SW + 2)};
                 Lout = Lout + (sw * Lin) / rec.at(i, SG_RR);
@@ -158,9 +190,9 @@ VDEV void propagate_samples(const PathRecorder &rec, bool active, VspgTrainSampl
             have_next = true;
             next_volume = volume;
         }
-        sample_append(emit, smp, samples, counters, capacity);
+        sink.append(emit, smp);
     }
-    if (zero) atomicAdd(&counters[1], (unsigned long long)zero);
+    if (zero) atomicAdd(&sink.counters[1], (unsigned long long)zero);
 }
 
 // ---- Field::Update stand-in (definition: oracle/vspg_oracle.c "Field::Update") ------------------
