@@ -850,10 +850,11 @@ def _sorted_samples(a):
     return a[key]
 
 
-@pytest.mark.parametrize("medium", ["homogeneous", "grid"])
+@pytest.mark.parametrize("medium", ["homogeneous", "grid", "homogeneous-deep"])
 def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     """Wave 0 of a training run (field still empty -> unguided paths): the radiance samples the device
-    records and propagates are the oracle's, bit for bit, as a multiset; so is the dropped-sample count."""
+    records and propagates are the oracle's, bit for bit, as a multiset; so is the dropped-sample count.
+    ("deep": maxdepth 9 -- more samples per path than a lane of k_propagate stages, so its overflow flush runs.)"""
     import scenes
     P = gpu_pkg
     W, H = 48, 40
@@ -864,6 +865,12 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
         scene = P.fog_box_scene(W, H)
         scene.medium.g = 0.3
     prm = P.default_params()
+    if medium == "homogeneous-deep":
+        prm.maxdepth = 9
+        prm.minrrdepth = 8   # no Russian roulette before depth 9: long paths
+        for k in range(3):
+            scene.medium.sigma_a[k] = 0.01
+            scene.medium.sigma_s[k] = 1.5
     g = P.Renderer(scene, prm, W, H, seed=3)
     c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
     g.render_wave(0, 2)
