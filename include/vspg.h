@@ -271,6 +271,10 @@ int vspg_film_clear(VspgRenderer *r, void *stream);
 int vspg_vsp_buffer_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);
 int vspg_vsp_buffer_read(VspgRenderer *r, float *host_vsp /* W*H */, int *is_ready,
                          void *stream);
+/* ImageSpaceGuidingBuffer(fileName) (guidedvolpathvspgintegrator.cpp:151-159): the buffer is used as handed over
+ * (ready from the first wave on) and never updated again (calculateImageSpaceGuidingBuffer = false, :251-256).
+ * Values outside [0,1] mean "no estimate for this pixel" (:1101-1112). */
+int vspg_vsp_buffer_load(VspgRenderer *r, const float *host_vsp /* W*H */, void *stream);
 /* per-pixel sufficient statistics (W*H*VSPG_ISG_STATS floats) for multi-GPU all-reduce */
 #define VSPG_ISG_STATS 8
 int vspg_isg_stats_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);

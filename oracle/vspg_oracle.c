@@ -487,6 +487,7 @@ struct OracleRenderer {
     float *isg_stats; /* W*H*VSPG_ISG_STATS */
     float *vsp;       /* W*H */
     int vsp_ready;
+    int vsp_loaded; /* ImageSpaceGuidingBuffer(fileName): never updated (:151-159, :251-256) */
     int wave_counter, buffer_wave;
     VspgCounters counters;
     /* a18: guiding-cache training (see "training" section below) */
@@ -2593,7 +2594,7 @@ int oracle_post_process_wave(OracleRenderer *r) {
     r->n_zero_samples = 0;
     if ((double)r->wave_counter == pow(2.0, (double)r->buffer_wave)) {
         int W = r->cfg.xres, H = r->cfg.yres;
-        if (r->prm.vspguiding && r->prm.vspprimaryguiding) {
+        if (r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded) {
             for (int y = 0; y < H; ++y)
                 for (int x = 0; x < W; ++x) {
                     float a[5] = {0, 0, 0, 0, 0};
@@ -2728,6 +2729,11 @@ void oracle_vsp_buffer_read(OracleRenderer *r, float *vsp, int *is_ready) {
 void oracle_vsp_buffer_write(OracleRenderer *r, const float *vsp, int is_ready) {
     memcpy(r->vsp, vsp, (size_t)r->cfg.xres * r->cfg.yres * sizeof(float));
     r->vsp_ready = is_ready;
+}
+void oracle_vsp_buffer_load(OracleRenderer *r, const float *vsp) {
+    memcpy(r->vsp, vsp, (size_t)r->cfg.xres * r->cfg.yres * sizeof(float));
+    r->vsp_ready = 1;
+    r->vsp_loaded = 1;
 }
 int oracle_tr_buffer_read(OracleRenderer *r, float *rgb) {
     if (!r->trbuf) return VSPG_EINVAL;

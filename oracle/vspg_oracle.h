@@ -71,6 +71,7 @@ void oracle_film_read_f64(OracleRenderer *r, double *rgbw);
 void oracle_film_clear(OracleRenderer *r);
 void oracle_vsp_buffer_read(OracleRenderer *r, float *vsp, int *is_ready);
 void oracle_vsp_buffer_write(OracleRenderer *r, const float *vsp, int is_ready);
+void oracle_vsp_buffer_load(OracleRenderer *r, const float *vsp); /* ImageSpaceGuidingBuffer(fileName): used as is, never updated */
 void oracle_isg_stats_read(OracleRenderer *r, float *stats);
 /* TrBuffer (cpu/trbuffer.h): read the running-mean transmittance (xres*yres*3, VSPG_EINVAL if none is kept);
  * write = TrBuffer(fileName): the renderer then uses it (NDS+) and stops recording */

@@ -48,6 +48,7 @@ def load():
         "oracle_film_clear": (None, [vp]),
         "oracle_vsp_buffer_read": (None, [vp, p(C.c_float), p(C.c_int)]),
         "oracle_vsp_buffer_write": (None, [vp, p(C.c_float), C.c_int]),
+        "oracle_vsp_buffer_load": (None, [vp, p(C.c_float)]),
         "oracle_tr_buffer_read": (C.c_int, [vp, p(C.c_float)]),
         "oracle_tr_buffer_write": (C.c_int, [vp, p(C.c_float)]),
         "oracle_isg_stats_read": (None, [vp, p(C.c_float)]),
@@ -144,6 +145,11 @@ class OracleRenderer:
     def set_vsp_buffer(self, vsp, ready=True):
         v = np.ascontiguousarray(vsp, dtype=np.float32)
         self.lib.oracle_vsp_buffer_write(self.h, v.ctypes.data_as(C.POINTER(C.c_float)), int(ready))
+
+    def load_vsp_buffer(self, vsp):
+        v = np.ascontiguousarray(vsp, dtype=np.float32)
+        assert v.shape == (self.yres, self.xres)
+        self.lib.oracle_vsp_buffer_load(self.h, v.ctypes.data_as(C.POINTER(C.c_float)))
 
     def tr_buffer(self):
         out = np.empty((self.yres, self.xres, 3), dtype=np.float32)

@@ -558,6 +558,31 @@ def test_grid_paths_and_film_vs_oracle(cloud_pair):
         assert abs(cg[k] - cc[k]) <= 2e-3 * cc[k] + 5, (k, cg[k], cc[k])
 
 
+def test_loaded_vsp_buffer_vs_oracle(gpu_pkg):
+    """loadISGBuffer (:151-159, :251-256): a buffer handed over is used from wave 0 on and never updated -- device == oracle."""
+    P = gpu_pkg
+    W, H = 96, 64
+    scene = P.fog_box_scene(W, H)
+    prm = P.app_f_params()
+    rng = np.random.default_rng(4)
+    vsp = rng.uniform(0.05, 0.95, (H, W)).astype(np.float32)
+    vsp[::7, ::5] = -1.0  # pixels without an estimate
+    g = P.Renderer(scene, prm, W, H, seed=2)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=2)
+    g.load_vsp_buffer(vsp); c.load_vsp_buffer(vsp)
+    for w in range(3):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    vg, rg = g.vsp_buffer()
+    assert rg and np.array_equal(vg, vsp)
+    fg, fc = g.film(), c.film()
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    relmse = np.mean((ig - ic) ** 2 / (ic ** 2 + 1e-4))
+    print("loaded VSP buffer film relMSE %.3e" % relmse)
+    assert relmse <= 1e-10
+    g.close(); c.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # TrBuffer + NDS+ (cpu/trbuffer.h; guidedvolpathvspgintegrator.cpp:727-728, 929-938, 975-976, 1072-1073)
 # ---------------------------------------------------------------------------------------------

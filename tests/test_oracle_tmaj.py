@@ -106,3 +106,28 @@ def test_edge_cases(orc):
     tau_min = -np.log(1 - np.float32(0.9))
     assert abs(o.majorant_scale - tau_min / 0.05) < 1e-3 * o.majorant_scale
     assert abs(o.vrc - 0.9 / (1 - np.exp(-tau_min))) < 2e-3
+
+
+def test_loaded_vsp_buffer_is_used_as_is_and_never_updated():
+    """loadISGBuffer (guidedvolpathvspgintegrator.cpp:151-159, 251-256): the buffer is ready from the first wave on and
+    PostProcessWave leaves it alone; an in-loop buffer of the same scene is estimated at waves 1, 2, 4, ..."""
+    import oracle_lib
+    from conftest import load_package
+    P = load_package()
+    W, H = 24, 16
+    scene = oracle_lib.fog_box_scene(W, H)
+    prm = oracle_lib.app_f_params()
+    rng = np.random.default_rng(3)
+    vsp = rng.uniform(0.1, 0.9, (H, W)).astype(np.float32)
+    vsp[0, 0] = -1.0  # "no estimate" for this pixel: unguided there (:1101-1112)
+    a = oracle_lib.OracleRenderer(scene, prm, W, H)
+    a.load_vsp_buffer(vsp)
+    b = oracle_lib.OracleRenderer(scene, prm, W, H)
+    for w in range(4):
+        a.render_wave(w, w + 1); a.post_process_wave()
+        b.render_wave(w, w + 1); b.post_process_wave()
+    va, ra = a.vsp_buffer()
+    vb, rb = b.vsp_buffer()
+    assert ra and rb and np.array_equal(va, vsp) and not np.array_equal(vb, vsp)
+    assert not np.array_equal(a.film_f64(), b.film_f64())  # wave 0 already used the loaded estimates instead of 0.5
+    a.close(); b.close()

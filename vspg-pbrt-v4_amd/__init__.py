@@ -145,6 +145,7 @@ SYMBOLS = [
     ("vspg_film_clear", C.c_int, [_vp, _vp]),
     ("vspg_vsp_buffer_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("vspg_vsp_buffer_read", C.c_int, [_vp, _P(C.c_float), _P(C.c_int), _vp]),
+    ("vspg_vsp_buffer_load", C.c_int, [_vp, _P(C.c_float), _vp]),
     ("vspg_isg_stats_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("vspg_get_counters", C.c_int, [_vp, _P(VspgCounters), _vp]),
     ("vspg_reset_counters", C.c_int, [_vp, _vp]),
@@ -333,6 +334,12 @@ class Renderer:
         _check(self.lib, self.lib.vspg_vsp_buffer_read(self.h, out.ctypes.data_as(_P(C.c_float)), C.byref(ready),
                                                       _vp(stream or 0)))
         return out, bool(ready.value)
+
+    def load_vsp_buffer(self, vsp, stream=None):
+        import numpy as np
+        v = np.ascontiguousarray(vsp, dtype=np.float32)
+        assert v.shape == (self.yres, self.xres)
+        _check(self.lib, self.lib.vspg_vsp_buffer_load(self.h, v.ctypes.data_as(_P(C.c_float)), _vp(stream or 0)))
 
     def tr_buffer(self, stream=None):
         """TrBuffer read-back: (rgb (H, W, 3) float32, spp (H, W) int32)."""

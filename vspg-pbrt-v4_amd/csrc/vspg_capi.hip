@@ -1159,6 +1159,7 @@ struct VspgRenderer {
     float *majorant = nullptr;  // 16^3 majorant grid
     int num_cus = 0;
     int vsp_ready = 0;
+    bool vsp_loaded = false;  // ImageSpaceGuidingBuffer(fileName): no further updates
     int wave_counter = 0, buffer_wave = 0;
     size_t npix = 0;
 };
@@ -1824,7 +1825,7 @@ int vspg_post_process_wave(VspgRenderer *r, void *stream) {
         HIPCHK(hipMemsetAsync(r->train_counters, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));  // Clear() (:248)
     }
     if ((double)r->wave_counter == std::pow(2.0, (double)r->buffer_wave)) {
-        if (r->prm.vspguiding && r->prm.vspprimaryguiding) {
+        if (r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded) {  // calculateImageSpaceGuidingBuffer (:251)
             HIPCHK(hipSetDevice(r->cfg.device));
             int blocks = (int)((r->npix + kBlock - 1) / kBlock);
             hipLaunchKernelGGL(k_isg_update, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, r->cfg.xres, r->cfg.yres,
@@ -1897,6 +1898,15 @@ int vspg_renderer_set_tr_buffer(VspgRenderer *r, const float *host_rgb, void *st
     HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(r->dscene) + offsetof(DScene, tr_rgb), &r->hscene.tr_rgb,
                           sizeof(DScene) - offsetof(DScene, tr_rgb), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+int vspg_vsp_buffer_load(VspgRenderer *r, const float *host, void *stream) {
+    if (!r || !host) return fail(VSPG_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(r->cfg.device));
+    HIPCHK(hipMemcpyAsync(r->vsp, host, r->npix * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    r->vsp_ready = 1;
+    r->vsp_loaded = true;
     return 0;
 }
 int vspg_isg_stats_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {

@@ -98,7 +98,7 @@ int main() {
         (void)ParseIntegratorParams(ParameterDictionary().Bool("storeGuidingCache", true).String("guidingCacheFileName", "x.fld"), &cs);
         CHECK(cs.store && !cs.load && cs.fileName == "x.fld");
         CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("loadGuidingCache", true)); }));  // no file name
-        CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("storeISGBuffer", true)); }));    // still out of scope
+        CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("storeISGBuffer", true)); }));    // no file name
     }
     // emissive "uniformgrid" (media.cpp:306-328): "Le" + "Lescale" (LeNorm = 1 in RGB rendering mode)
     {
@@ -143,6 +143,22 @@ int main() {
             ParameterDictionary().Bool("storeTrBuffer", true).String("trBufferFileName", "t.pfm").Bool("collisionProbabilityBias", true), nullptr, &ts);
         CHECK(ts.store && !ts.load && ts.fileName == "t.pfm" && p.storeTrBuffer == 1 && p.collisionProbabilityBias == 1);
         CHECK(throws([] { (void)ParseIntegratorParams(ParameterDictionary().Bool("loadTrBuffer", true)); }));  // no file name
+    }
+    // image-space VSP buffer persistence: single-channel PFM
+    {
+        VspBuffer vb;
+        vb.xres = 4; vb.yres = 3; vb.ready = true;
+        vb.vsp.resize(12);
+        for (size_t i = 0; i < vb.vsp.size(); ++i) vb.vsp[i] = 0.05f * (float)i;
+        const char *fn = "/tmp/vspg_host_selftest_isg.pfm";
+        vb.Store(fn);
+        VspBuffer rd = VspBuffer::Load(fn);
+        CHECK(rd.xres == 4 && rd.yres == 3 && rd.ready && rd.vsp == vb.vsp);
+        std::remove(fn);
+        CHECK(throws([] { VspBuffer::Load("/tmp/vspg_no_such_isg.pfm"); }));
+        IsgBufferSettings is;
+        (void)ParseIntegratorParams(ParameterDictionary().Bool("loadISGBuffer", true).String("isgBufferFileName", "v.pfm"), nullptr, nullptr, &is);
+        CHECK(is.load && !is.store && is.fileName == "v.pfm");
     }
     std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: ok\n", fails);
     return fails ? 1 : 0;

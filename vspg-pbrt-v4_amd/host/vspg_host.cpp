@@ -211,7 +211,8 @@ VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p, s
 }
 
 // ---------------------------------------------------------------------------------------
-VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache, TrBufferSettings *tr) {
+VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache, TrBufferSettings *tr,
+                                           IsgBufferSettings *isg) {
     // GuidedVolPathVSPGIntegrator::Create (guidedvolpathvspgintegrator.cpp:1260-1322)
     VspgIntegratorParams p;
     vspg_integrator_params_default(&p);
@@ -238,9 +239,11 @@ VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters
     if (meth == "Resampling" || meth == "resampling") p.vspsamplingmethod = VSPG_VSP_RESAMPLING;
     else if (meth == "NDS" || meth == "nds") p.vspsamplingmethod = VSPG_VSP_NDS;
     p.collisionProbabilityBias = parameters.GetOneBool("collisionProbabilityBias", false);
-    bool storeISG = parameters.GetOneBool("storeISGBuffer", false);
-    bool loadISG = parameters.GetOneBool("loadISGBuffer", false);
-    (void)parameters.GetOneString("isgBufferFileName", "");
+    IsgBufferSettings is;
+    is.store = parameters.GetOneBool("storeISGBuffer", false);
+    is.load = parameters.GetOneBool("loadISGBuffer", false);
+    is.fileName = parameters.GetOneString("isgBufferFileName", "");
+    if (isg) *isg = is;
     TrBufferSettings ts;
     ts.store = parameters.GetOneBool("storeTrBuffer", false);
     ts.load = parameters.GetOneBool("loadTrBuffer", false);
@@ -256,7 +259,7 @@ VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters
     else if (ls == "bvh") p.lightsampler = VSPG_LIGHTSAMPLER_BVH;
     else throw Error("Light sample distribution type \"" + ls + "\" unknown.");
     p.regularize = parameters.GetOneBool("regularize", false);
-    if (storeISG || loadISG) throw Error("ISG-buffer persistence is outside this build's scope");
+    if ((is.store || is.load) && is.fileName.empty()) throw Error("storeISGBuffer / loadISGBuffer need \"isgBufferFileName\"");
     if ((ts.store || ts.load) && ts.fileName.empty()) throw Error("storeTrBuffer / loadTrBuffer need \"trBufferFileName\"");
     if ((cs.store || cs.load) && cs.fileName.empty()) throw Error("storeGuidingCache / loadGuidingCache need \"guidingCacheFileName\"");
     return p;
@@ -287,14 +290,16 @@ std::unique_ptr<GuidedVolPathVSPGIntegrator> GuidedVolPathVSPGIntegrator::Create
                                                                                  int pixelSamples, int seed, int device) {
     GuidingCacheSettings cache;
     TrBufferSettings tr;
-    VspgIntegratorParams p = ParseIntegratorParams(parameters, &cache, &tr);
-    return std::make_unique<GuidedVolPathVSPGIntegrator>(p, scene, xres, yres, pixelSamples, seed, device, cache, tr);
+    IsgBufferSettings isg;
+    VspgIntegratorParams p = ParseIntegratorParams(parameters, &cache, &tr, &isg);
+    return std::make_unique<GuidedVolPathVSPGIntegrator>(p, scene, xres, yres, pixelSamples, seed, device, cache, tr, isg);
 }
 
 GuidedVolPathVSPGIntegrator::GuidedVolPathVSPGIntegrator(const VspgIntegratorParams &p, const VspgScene &scene, int xres,
                                                          int yres, int pixelSamples, int seed, int device,
-                                                         const GuidingCacheSettings &cache, const TrBufferSettings &tr)
-    : params(p), spp(pixelSamples), cacheSettings(cache), trSettings(tr) {
+                                                         const GuidingCacheSettings &cache, const TrBufferSettings &tr,
+                                                         const IsgBufferSettings &isg)
+    : params(p), spp(pixelSamples), cacheSettings(cache), trSettings(tr), isgSettings(isg) {
     std::memset(&cfg, 0, sizeof cfg);
     cfg.xres = xres; cfg.yres = yres; cfg.spp = pixelSamples; cfg.seed = seed;
     cfg.shard_index = 0; cfg.shard_count = 1; cfg.device = device;
@@ -309,6 +314,26 @@ GuidedVolPathVSPGIntegrator::GuidedVolPathVSPGIntegrator(const VspgIntegratorPar
             std::string msg = vspg_last_error();
             vspg_renderer_destroy(renderer);
             throw Error("GuidedVolPathVSPGIntegrator: loading \"" + cacheSettings.fileName + "\": " + msg);
+        }
+    }
+    if (isgSettings.load) {  // :151-159: a missing file is a warning, the buffer is then estimated in-loop as usual
+        std::FILE *probe = std::fopen(isgSettings.fileName.c_str(), "rb");
+        if (!probe) {
+            std::fprintf(stderr, "Warning: ImageSpaceGuidingBuffer file does not exists: isgBufferFileName = %s\n", isgSettings.fileName.c_str());
+        } else {
+            std::fclose(probe);
+            std::string msg;
+            try {
+                VspBuffer vb = VspBuffer::Load(isgSettings.fileName);
+                if (vb.xres != xres || vb.yres != yres) msg = "resolution differs from the film's";
+                else if (vspg_vsp_buffer_load(renderer, vb.vsp.data(), nullptr) != 0) msg = vspg_last_error();
+            } catch (const Error &e) {
+                msg = e.what();
+            }
+            if (!msg.empty()) {
+                vspg_renderer_destroy(renderer);
+                throw Error("GuidedVolPathVSPGIntegrator: loading \"" + isgSettings.fileName + "\": " + msg);
+            }
         }
     }
     if (trSettings.load) {  // :180-188: a missing file is a warning, the render goes on without NDS+
@@ -333,6 +358,13 @@ GuidedVolPathVSPGIntegrator::GuidedVolPathVSPGIntegrator(const VspgIntegratorPar
     }
 }
 GuidedVolPathVSPGIntegrator::~GuidedVolPathVSPGIntegrator() {
+    if (isgSettings.store) {  // :214-216
+        try {
+            GetVspBuffer().Store(isgSettings.fileName);
+        } catch (const Error &e) {
+            std::fprintf(stderr, "GuidedVolPathVSPGIntegrator: storing the image-space guiding buffer failed: %s\n", e.what());
+        }
+    }
     if (trSettings.store) {  // :219-221
         try {
             GetTrBuffer().Store(trSettings.fileName);
@@ -354,6 +386,16 @@ VspgTrainStats GuidedVolPathVSPGIntegrator::TrainingStats() {
     if (vspg_renderer_training_stats(renderer, &st, nullptr) != 0) throw Error(vspg_last_error());
     return st;
 }
+VspBuffer GuidedVolPathVSPGIntegrator::GetVspBuffer() {
+    VspBuffer vb;
+    vb.xres = cfg.xres; vb.yres = cfg.yres;
+    vb.vsp.resize((size_t)cfg.xres * cfg.yres);
+    int ready = 0;
+    if (vspg_vsp_buffer_read(renderer, vb.vsp.data(), &ready, nullptr) != 0) throw Error(vspg_last_error());
+    vb.ready = ready != 0;
+    if (!vb.ready) std::fill(vb.vsp.begin(), vb.vsp.end(), -1.f);  // no estimate yet
+    return vb;
+}
 TrBuffer GuidedVolPathVSPGIntegrator::GetTrBuffer() {
     TrBuffer tb;
     tb.xres = cfg.xres; tb.yres = cfg.yres;
@@ -366,6 +408,36 @@ static bool has_pfm_extension(const std::string &fn) {
     std::string e = fn.substr(fn.size() - 4);
     for (char &c : e) c = (char)std::tolower((unsigned char)c);
     return e == ".pfm";
+}
+void VspBuffer::Store(const std::string &filename) const {
+    if (!has_pfm_extension(filename)) throw Error(filename + ": only the .pfm format is supported for the image-space guiding buffer");
+    std::FILE *f = std::fopen(filename.c_str(), "wb");
+    if (!f) throw Error(filename + ": cannot open for writing");
+    std::fprintf(f, "Pf\n%d %d\n-1.000000\n", xres, yres);
+    bool ok = true;
+    for (int y = yres - 1; y >= 0 && ok; --y) ok = std::fwrite(&vsp[(size_t)y * xres], sizeof(float), (size_t)xres, f) == (size_t)xres;
+    ok = std::fclose(f) == 0 && ok;
+    if (!ok) throw Error(filename + ": write failed");
+}
+VspBuffer VspBuffer::Load(const std::string &filename) {
+    if (!has_pfm_extension(filename)) throw Error(filename + ": only the .pfm format is supported for the image-space guiding buffer");
+    std::FILE *f = std::fopen(filename.c_str(), "rb");
+    if (!f) throw Error(filename + ": cannot open");
+    VspBuffer vb;
+    char magic[3] = {0, 0, 0};
+    float scale = 0;
+    bool ok = std::fscanf(f, "%2s %d %d %f", magic, &vb.xres, &vb.yres, &scale) == 4 && std::string(magic) == "Pf" && vb.xres > 0 &&
+              vb.yres > 0 && vb.xres <= 32768 && vb.yres <= 32768 && scale < 0;  // little endian only
+    if (ok) ok = std::fgetc(f) != EOF;
+    if (ok) {
+        vb.vsp.resize((size_t)vb.xres * vb.yres);
+        for (int y = vb.yres - 1; y >= 0 && ok; --y)
+            ok = std::fread(&vb.vsp[(size_t)y * vb.xres], sizeof(float), (size_t)vb.xres, f) == (size_t)vb.xres;
+    }
+    std::fclose(f);
+    if (!ok) throw Error(filename + ": not a little-endian single-channel PFM image");
+    vb.ready = true;
+    return vb;
 }
 void TrBuffer::Store(const std::string &filename) const {
     if (!has_pfm_extension(filename)) throw Error(filename + ": only the .pfm format of pbrt's Image class is supported (OpenEXR is absent)");

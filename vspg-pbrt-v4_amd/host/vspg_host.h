@@ -108,6 +108,21 @@ struct TrBuffer {
     void Store(const std::string &filename) const;
     static TrBuffer Load(const std::string &filename);
 };
+// The image-space VSP buffer between runs ("storeISGBuffer" / "loadISGBuffer" / "isgBufferFileName",
+// guidedvolpathvspgintegrator.cpp:151-159, 214-216).  OpenPGL's own file format is not part of the reference tree; this
+// adapter keeps the one plane the path reads -- the per-pixel volume-scatter-probability estimate -- as a single-channel
+// PFM ("Pf", same raster conventions as TrBuffer; a value outside [0,1] = no estimate for the pixel).
+struct VspBuffer {
+    int xres = 0, yres = 0;
+    bool ready = false;
+    std::vector<float> vsp;  // row-major, top row first
+    void Store(const std::string &filename) const;
+    static VspBuffer Load(const std::string &filename);
+};
+struct IsgBufferSettings {
+    bool store = false, load = false;
+    std::string fileName;
+};
 struct TrBufferSettings {  // "storeTrBuffer" / "loadTrBuffer" / "trBufferFileName"
     bool store = false, load = false;
     std::string fileName;
@@ -132,7 +147,7 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
                                                                int pixelSamples, int seed, int device);
     GuidedVolPathVSPGIntegrator(const VspgIntegratorParams &p, const VspgScene &scene, int xres, int yres,
                                 int pixelSamples, int seed, int device, const GuidingCacheSettings &cache = {},
-                                const TrBufferSettings &tr = {});
+                                const TrBufferSettings &tr = {}, const IsgBufferSettings &isg = {});
     ~GuidedVolPathVSPGIntegrator() override;
     void Render() override;       // wave loop: 1 spp per wave, PostProcessWave after each
     void PostProcessWave();       // guidedvolpathvspgintegrator.cpp:230-260
@@ -142,6 +157,7 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
     VspgTrainStats TrainingStats();      // guideTraining / guiding_field->GetIteration()
     GuidingCache GetGuidingCache();      // the field as it stands (trained in-loop or loaded)
     TrBuffer GetTrBuffer();              // the transmittance buffer as it stands (recorded or loaded)
+    VspBuffer GetVspBuffer();            // the image-space VSP estimate as it stands
     const VspgIntegratorParams &Params() const { return params; }
 
   private:
@@ -151,10 +167,11 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
     int spp;
     GuidingCacheSettings cacheSettings;
     TrBufferSettings trSettings;
+    IsgBufferSettings isgSettings;
 };
 
 // parameter parsing only (no device): used by Create and by the CPU self test
 VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters, GuidingCacheSettings *cache = nullptr,
-                                           TrBufferSettings *tr = nullptr);
+                                           TrBufferSettings *tr = nullptr, IsgBufferSettings *isg = nullptr);
 
 }  // namespace vspg
