@@ -47,6 +47,12 @@ __device__ __forceinline__ void flush_counters(const PC &pc, uint32_t paths, uns
     if (threadIdx.x < kNumCounters) atomicAdd(&g[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
+// The global work head is a PAIR of counters used by alternate launches: a launch zeroes the one the NEXT launch will use
+// (nobody reads it meanwhile, launches of a renderer are stream-ordered), so no memset sits between two waves.
+__device__ __forceinline__ void reset_sibling_head(unsigned int *work_head) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned int *>(reinterpret_cast<uintptr_t>(work_head) ^ 4u) = 0u;
+}
+
 // Persistent wavefront kernel with path regeneration.
 //   work item  = one pixel (all its samples [wave_start, wave_end) run in order by the lane that
 //                claims it, so film / ISG statistics are read-modify-written by exactly one lane
@@ -83,6 +89,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
     const unsigned total_items = (unsigned)(tilesX * tilesY) * 64u;
     const int lane = threadIdx.x & 63;
+    reset_sibling_head(work_head);
     // heterogeneous media: the 16^3 majorant grid (16 KB) is staged into LDS once per workgroup with
     // coalesced 16-B loads; every DDA step then reads LDS instead of HBM/L2.  (Guided builds leave it in
     // global memory -- it stays in the vector L1: their 72 KB of guiding scratch plus the grid would allow
@@ -631,6 +638,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const unsigned total_items = (unsigned)(tilesX * tilesY) * 64u;
     const int lane = threadIdx.x & 63;
     const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
+    reset_sibling_head(work_head);
 
     static_assert(!GUIDED, "PF_VXP aliases PF_RO: the guided vertex code reads the old ray origin");
     constexpr int NF = GUIDED ? (int)PF_COUNT : (int)PF_GS;
@@ -1131,7 +1139,8 @@ struct VspgRenderer {
     int32_t *tr_spp = nullptr;
     float *vsp = nullptr;
     unsigned long long *counters = nullptr;
-    unsigned int *work_head = nullptr;
+    unsigned int *work_head = nullptr;   // two counters, used by alternate launches (reset_sibling_head)
+    unsigned int head_parity = 0;
     VspgKdNode *fnodes[2] = {nullptr, nullptr};        // guiding fields (device copies)
     VspgFieldRegion *fregions[2] = {nullptr, nullptr};
     float *faux[2] = {nullptr, nullptr};               // DField::aux
@@ -1556,7 +1565,8 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     CK(hipMemset(r->vsp, 0, r->npix * sizeof(float)));
     CK(hipMalloc(&r->counters, kNumCounters * sizeof(unsigned long long)));
     CK(hipMemset(r->counters, 0, kNumCounters * sizeof(unsigned long long)));
-    CK(hipMalloc(&r->work_head, sizeof(unsigned int)));
+    CK(hipMalloc(&r->work_head, 2 * sizeof(unsigned int)));
+    CK(hipMemset(r->work_head, 0, 2 * sizeof(unsigned int)));
     {
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, cfg->device));
@@ -1672,7 +1682,6 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     if (first >= wave_end) return 0;  // nothing for this shard in the range
     const int n_samples = (wave_end - 1 - first) / sc + 1;
     const PcgJump jump = pcg_jump((unsigned long long)first * 65536ull);
-    HIPCHK(hipMemsetAsync(r->work_head, 0, sizeof(unsigned int), (hipStream_t)stream));
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
@@ -1691,16 +1700,19 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         targs = TrainArgs{r->segbuf, r->seg_count, r->samples, r->train_counters, r->sample_capacity, (unsigned)items};
         HIPCHK(hipMemsetAsync(r->seg_count, 0, (size_t)items * sizeof(int), (hipStream_t)stream));
     }
+    // exactly one path-kernel launch follows: it uses the counter the previous launch zeroed and zeroes the other one
+    unsigned int *const work_head = r->work_head + (r->head_parity & 1u);
+    r->head_parity ^= 1u;
 #define VSPG_LAUNCH_RENDER(M, G)                                                                                          \
     do {                                                                                                                  \
         if (G && train)                                                                                                   \
             hipLaunchKernelGGL((k_render_wave<M, G, G>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,    \
                                r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first,        \
-                               n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, r->work_head, r->counters, targs); \
+                               n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, work_head, r->counters, targs); \
         else                                                                                                              \
             hipLaunchKernelGGL((k_render_wave<M, G, false>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, \
                                r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first,        \
-                               n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, r->work_head, r->counters, targs); \
+                               n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, work_head, r->counters, targs); \
     } while (0)
     // scheduler: "wg" = workgroup-level wavefront kernel, "lane" = per-lane persistent kernel.  Default: wg for
     // homogeneous media (dense, equally long phases); lane for grid media, whose tracking walks have very
@@ -1721,27 +1733,27 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               r->work_head, r->counters);
+                               work_head, r->counters);
         else if (r->medium_grey && r->surfaces_grey && r->null_zero)  // ... and the null-collision coefficient is exactly 0
             hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreySceneNullZero, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               r->work_head, r->counters);
+                               work_head, r->counters);
         else if (r->medium_grey && r->surfaces_grey)  // ... and every Kd bitwise grey: beta is grey by construction too
             hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreyScene, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               r->work_head, r->counters);
+                               work_head, r->counters);
         else if (r->medium_grey)  // sigma_a, sigma_s, Le bitwise grey: the broadcast-spectrum instantiation
             hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGrey, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               r->work_head, r->counters);
+                               work_head, r->counters);
         else
             hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               r->work_head, r->counters);
+                               work_head, r->counters);
     } else if (nvdb && guided) VSPG_LAUNCH_RENDER(NanoDenseMedium, true);
     else if (nvdb) VSPG_LAUNCH_RENDER(NanoDenseMedium, false);
     else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
