@@ -392,13 +392,13 @@ def test_grey_grid_medium_film_equals_replayed_paths(gpu_pkg):
     assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
 
 
-def test_full_size_wave_properties(gpu_pkg):
-    """BASELINE size (1920x1080): size-independent properties of one wave -- every pixel got exactly one
-    sample, path / segment counters are consistent, 20 000 random pixels equal their replayed paths bit
-    for bit, a second identical renderer reproduces the film exactly (run-to-run determinism), and the
+@pytest.mark.parametrize("W,H", [(1920, 1080), (3840, 2160)])
+def test_full_size_wave_properties(gpu_pkg, W, H):
+    """BASELINE sizes (1920x1080 of configs 2-3, 3840x2160 of config 4): size-independent properties of one wave -- every
+    pixel got exactly one sample, path / segment counters are consistent, 20 000 random pixels equal their replayed
+    paths bit for bit, a second identical renderer reproduces the film exactly (run-to-run determinism), and the
     per-lane and workgroup kernels agree bit for bit."""
     P = gpu_pkg
-    W, H = 1920, 1080
     scene = P.fog_box_scene(W, H)
     films = {}
     for kernel in ("wg", "lane", "wg"):
