@@ -993,3 +993,46 @@ def test_training_in_loop_unbiased_and_useful(gpu_pkg):
     eb = np.mean(np.minimum((b - ref) ** 2 / (ref ** 2 + 1e-2), 4.0))
     print("no-NEE clipped relMSE vs NEE reference: unguided %.4f, trained-guided %.4f" % (ea, eb))
     assert eb < 0.9 * ea
+
+
+def test_error_conventions_on_device(gpu_pkg):
+    """Reference options outside the build are refused with VSPG_ESCOPE, malformed input with VSPG_EINVAL, and a
+    buffer that was never requested cannot be read back -- nothing is silently ignored."""
+    P = gpu_pkg
+    lib = P.load()
+    W, H = 32, 24
+    scene = P.fog_box_scene(W, H)
+    cfg = P.VspgRenderConfig(W, H, 1, 0, 0, 1, 0)
+    h = C.c_void_p()
+
+    def create(sc, prm):
+        rc = lib.vspg_renderer_create(C.byref(sc), C.byref(prm), C.byref(cfg), C.byref(h))
+        if rc == 0:
+            lib.vspg_renderer_destroy(h)
+        return rc
+
+    prm = P.app_f_params()
+    assert create(scene, prm) == 0
+    prm.rrguiding = 1
+    assert create(scene, prm) == P.VSPG_ESCOPE and b"rrguiding" in lib.vspg_last_error()
+    prm = P.app_f_params()
+    prm.maxdepth = -1
+    assert create(scene, prm) in (P.VSPG_EINVAL, 0)  # (negative depth is the reference's "no bounce" -- not an error there)
+    # NanoVDB-semantics medium with emission: temperature grids are out of scope
+    from scenes import nvdb_scene, cloud_density
+    dens = cloud_density(8)
+    s2 = nvdb_scene(dens, (8, 8, 8), 0.5, 1.0, W=W, H=H)
+    s2.medium.Le[:] = (1, 1, 1)
+    assert create(s2, P.app_f_params()) == P.VSPG_ESCOPE
+    # emissive grid with a malformed Lescale grid
+    from scenes import grid_scene
+    s3 = grid_scene(dens, (8, 8, 8), 0.5, 1.0, W=W, H=H)
+    s3.medium.Le[:] = (1, 1, 1)
+    s3.medium.le_scale = dens.ctypes.data_as(C.POINTER(C.c_float))
+    s3.medium.le_nx, s3.medium.le_ny, s3.medium.le_nz = 8, 0, 8
+    assert create(s3, P.app_f_params()) == P.VSPG_EINVAL
+    # buffers that were never requested
+    r = P.Renderer(scene, P.app_f_params(), W, H)
+    with pytest.raises(Exception):
+        r.tr_buffer()
+    r.close()
