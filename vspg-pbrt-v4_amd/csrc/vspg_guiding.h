@@ -286,12 +286,13 @@ VDEV float gdist_sample(const GDist &d, float u0, float u1, V3 *wi) {
     return gdist_pdf(d, *wi);
 }
 
-// GuidedBSDF / GuidedPhaseFunction state that outlives the vertex: what the NEXT segment's
-// VolumeScatterProbability(ray.d) needs (guiding.h:295-305, 564-574)
+// GuidedBSDF / GuidedPhaseFunction state that outlives the vertex: the NEXT segment asks the vertex's distribution for
+// VolumeScatterProbability(ray.d) (guiding.h:295-305, 564-574).  The new direction is known when the vertex code ends,
+// so the value is evaluated there (no random numbers involved: same inputs, same result) and ONE float crosses to the
+// next segment instead of {field, region, point} plus the lane's scratch; -1 = no estimate (scatter guiding off,
+// region untrained), exactly what the deferred query would return.
 struct GuideState {
-    bool useScatterGuiding;
-    int field, region;
-    V3 p;
+    float vsp_next;
 };
 
 }  // namespace vspg

@@ -310,7 +310,7 @@ VDEV float fetch_vsp(const DScene &S, const PathState &st, bool *guide) {
     } else if constexpr (GUIDED) {
         if (S.prm.vspguiding && S.prm.vspsecondaryguiding) {
             // g{phase,bsdf}.VolumeScatterProbability(ray.d) of the PREVIOUS vertex (:661-668)
-            vsp = st.gs.useScatterGuiding ? gdist_vsp(S.field, st.gs.field, st.gs.region, guide_lds(), kGuideBlock, st.rd) : -1.f;
+            vsp = st.gs.vsp_next;  // evaluated by the previous vertex (li_vertex_guided)
             *guide = !(isnan_(vsp) || vsp < 0.f || vsp > 1.f);
         }
     }
@@ -855,10 +855,8 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
     gd.ok = false;
     gd.region = -1;
     if (ginit) gd = gdist_init(S.field, gfield, gpoint, gprod, gm2, gk2, glds, gstride);
-    st.gs.useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
-    st.gs.field = gfield;
-    st.gs.region = gd.region;
-    st.gs.p = gpoint;
+    const bool useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
+    st.gs.vsp_next = -1.f;
     if (volume_vertex) {
         useGuiding = S.prm.volumeguiding ? gd.ok : false;
         if (st.depth > S.prm.minrrdepth) {
@@ -1025,46 +1023,52 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         }
     }
 
+    bool cont = false;  // the path goes on with (st.ro, st.rd)
     if (volume_vertex) {
-        if (!have || pdf == 0) return false;
-        float w = sfPdf / pdf;  // ps->p / ps->pdf
-        st.beta = st.beta * w;
-        st.r_l = st.r_u / pdf;
-        st.prevCtx.p = vp;
-        st.prevCtx.quad = -1;
-        st.ro = vp;
-        st.rd = wi;
+        if (have && pdf != 0) {
+            float w = sfPdf / pdf;  // ps->p / ps->pdf
+            st.beta = st.beta * w;
+            st.r_l = st.r_u / pdf;
+            st.prevCtx.p = vp;
+            st.prevCtx.quad = -1;
+            st.ro = vp;
+            st.rd = wi;
+            st.specularBounce = false;
+            st.anyNonSpecularBounces = true;
+            // guiding_addVolumeData(..., phaseFunctionWeight, ps->wi, ps->pdf, ps->meanCosine, survivalProb) (:871)
+            pc.rec.add_scatter_data(true, sp(w), wi, pdf, 1.0f - __builtin_fabsf(vg), survivalProb);
+            st.lastVertexVolume = true;
+            cont = true;
+        }
+    } else if (have) {
+        st.lastVertexVolume = false;
+        st.rr_correction *= pdf / sfPdf;
+        Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
+        st.beta = st.beta * bsdfWeight;
+        st.r_l = st.r_u / misPdf;
         st.specularBounce = false;
         st.anyNonSpecularBounces = true;
-        // guiding_addVolumeData(..., phaseFunctionWeight, ps->wi, ps->pdf, ps->meanCosine, survivalProb) (:871)
-        pc.rec.add_scatter_data(true, sp(w), wi, pdf, 1.0f - __builtin_fabsf(vg), survivalProb);
-        st.lastVertexVolume = true;
-        return true;
+        st.ro = offset_ray_origin(intr.pi, si.n, wi);
+        st.rd = wi;
+        if (nonzero(st.beta)) {
+            if (st.depth > S.prm.minrrdepth) {
+                Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;
+                survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+            }
+            cont = true;
+            if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
+                float qq = fmax_(0.f, 1 - survivalProb);
+                if (sampler.get1d() < qq) cont = false;
+                else st.beta = st.beta / (1 - qq);
+            }
+            // guiding_addSurfaceData(..., bsdfWeight, bs->wi, bs->eta, bs->sampledRoughness, bs->pdf, survivalProb) (:608);
+            // DiffuseBxDF: sampledRoughness 1
+            if (cont) pc.rec.add_scatter_data(false, bsdfWeight, wi, pdf, 1.0f, survivalProb);
+        }
     }
-    if (!have) return false;
-    st.lastVertexVolume = false;
-    st.rr_correction *= pdf / sfPdf;
-    Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
-    st.beta = st.beta * bsdfWeight;
-    st.r_l = st.r_u / misPdf;
-    st.specularBounce = false;
-    st.anyNonSpecularBounces = true;
-    st.ro = offset_ray_origin(intr.pi, si.n, wi);
-    st.rd = wi;
-    if (!nonzero(st.beta)) return false;
-    if (st.depth > S.prm.minrrdepth) {
-        Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;
-        survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
-    }
-    if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
-        float qq = fmax_(0.f, 1 - survivalProb);
-        if (sampler.get1d() < qq) return false;
-        st.beta = st.beta / (1 - qq);
-    }
-    // guiding_addSurfaceData(..., bsdfWeight, bs->wi, bs->eta, bs->sampledRoughness, bs->pdf, survivalProb) (:608);
-    // DiffuseBxDF: sampledRoughness 1
-    pc.rec.add_scatter_data(false, bsdfWeight, wi, pdf, 1.0f, survivalProb);
-    return true;
+    // the next segment's VolumeScatterProbability(ray.d) of this vertex's distribution (one call site for both kinds)
+    if (cont && useScatterGuiding) st.gs.vsp_next = gdist_vsp(S.field, gfield, gd.region, glds, gstride, wi);
+    return cont;
 }
 
 // EvaluatePixelSample up to the camera ray (src/pbrt/cpu/integrators.cpp:272-304)
@@ -1110,10 +1114,7 @@ VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, P
     st.lastVertexVolume = false;
     st.rr_correction = 1.0f;
     st.etaScale = 1;
-    st.gs.useScatterGuiding = false;
-    st.gs.field = 0;
-    st.gs.region = 0;
-    st.gs.p = mk(0, 0, 0);
+    st.gs.vsp_next = -1.f;
     isg.valid = false;
     isg.surface_event = false;
     isg.vsp_used = -1.f;

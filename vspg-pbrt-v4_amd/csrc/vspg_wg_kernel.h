@@ -39,7 +39,7 @@ enum {
     PF_VSP = 30,      // 1  isg.vsp_used (the primary VSP itself never leaves the primary phase)
     PF_VXG = 31,      // 1  vertex: volume: g; surface: rectangle index (int)
     PF_VXT = 32,      // 1  vertex: surface tHit
-    PF_GS = 33,       // 4  guided builds: gs.region (int), gs.p
+    PF_GS = 33,       // 4  guided builds: gs.vsp_next (1 used)
     PF_COUNT = 37,
     // The vertex position lives only from the segment phase to the vertex phase, the ray origin only
     // from the vertex phase to the next segment phase (the unguided vertex code never reads the old
@@ -119,10 +119,7 @@ VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sa
     pool_store_rng(P, slot, sampler);
     uint32_t fl = pool_pack_flags(st, ch, isg, keep_flags);
     if constexpr (GUIDED) {
-        if (st.gs.useScatterGuiding) fl |= FL_GS_SCATTER;
-        if (st.gs.field) fl |= FL_GS_FIELD;
-        P.i(PF_GS, slot) = st.gs.region;
-        P.set3(PF_GS + 1, slot, st.gs.p);
+        P.f(PF_GS, slot) = st.gs.vsp_next;
     }
     P.u(PF_FLAGS, slot) = fl;
     P.f(PF_RRC, slot) = st.rr_correction;
@@ -190,15 +187,9 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     st.vsp0 = v;
     isg.vsp_used = st.depth == 0 ? -1.f : v;
     if constexpr (GUIDED) {
-        st.gs.useScatterGuiding = (fl & FL_GS_SCATTER) != 0;
-        st.gs.field = (fl & FL_GS_FIELD) ? 1 : 0;
-        st.gs.region = P.i(PF_GS, slot);
-        st.gs.p = P.v3(PF_GS + 1, slot);
+        st.gs.vsp_next = P.f(PF_GS, slot);
     } else {
-        st.gs.useScatterGuiding = false;
-        st.gs.field = 0;
-        st.gs.region = 0;
-        st.gs.p = mk(0, 0, 0);
+        st.gs.vsp_next = -1.f;
     }
     return fl;
 }
