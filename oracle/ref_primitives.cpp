@@ -10,8 +10,10 @@
 // incl. SetSequence / Advance / Uniform<float>, IndependentSampler, FastExp, SampleExponential,
 // SampleDiscrete, HenyeyGreenstein, SampleHenyeyGreenstein, SampleUniformSphere,
 // SampleCosineHemisphere, CoordinateSystem, OffsetRayOrigin, SampledWavelengths::ChannelIdx.
-// NOT buildable without the absent third-party headers (nanovdb, openpgl, ...): media.h,
-// media_sampleTMaj.h, the integrator -- see DESIGN.md.
+// Bounds3f::Offset / IntersectP (the ray-vs-medium-bounds step of GridMedium::SampleRay).
+// NOT buildable without the absent third-party headers (nanovdb, openpgl, double-conversion ...): media.h,
+// media_sampleTMaj.h, the integrator; SampledGrid's constructors CHECK through util/print.cpp, which needs
+// double-conversion -- see DESIGN.md.
 #include <pbrt/pbrt.h>
 #include <pbrt/ray.h>
 #include <pbrt/samplers.h>
@@ -239,6 +241,28 @@ int main() {
         for (float u : us) {
             SampledWavelengths swl = SampledWavelengths::SampleVisible(u);
             sep(first); printf("["); pf(u); printf(",%d]", swl.ChannelIdx());
+        }
+        printf("],\n");
+    }
+    // ---- Bounds3f::Offset / IntersectP(o, d, tMax, &t0, &t1) (util/vecmath.h:1323-1332, 1547-1571) ----
+    {
+        printf("\"bounds3\": [");
+        bool first = true;
+        Bounds3f b(Point3f(-0.8f, -0.8f, -0.5f), Point3f(0.8f, 0.7f, 0.9f));
+        for (int i = 0; i < 48; ++i) {
+            Point3f o(3 * U() - 1.5f, 3 * U() - 1.5f, 3 * U() - 1.5f);
+            Vector3f d(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            if (i % 8 == 0) d.x = 0;
+            if (i % 8 == 1) d = Vector3f(0, -0.f, 1);
+            Float tMax = (i % 3 == 0) ? Infinity : 4 * U();
+            Float t0 = -1, t1 = -1;
+            bool hit = b.IntersectP(o, d, tMax, &t0, &t1);
+            Vector3f off = b.Offset(o);
+            sep(first); printf("[");
+            pf(o.x); printf(","); pf(o.y); printf(","); pf(o.z); printf(",");
+            pf(d.x); printf(","); pf(d.y); printf(","); pf(d.z); printf(","); pf(tMax); printf(",");
+            printf("%d,", hit ? 1 : 0); pf(hit ? t0 : 0.f); printf(","); pf(hit ? t1 : 0.f); printf(",");
+            pf(off.x); printf(","); pf(off.y); printf(","); pf(off.z); printf("]");
         }
         printf("]\n");
     }

@@ -624,6 +624,36 @@ static float sgrid_lookup(const float *data, int nx, int ny, int nz, v3 p) {
 #undef G
 #undef LERPF
 }
+/* Bounds3::IntersectP(o, d, tMax, &t0, &t1) (vecmath.h:1547-1571) */
+static int bounds_intersect_p(const float bmin[3], const float bmax[3], v3 o, v3 d, float tMax, float *hit0, float *hit1) {
+    const float g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS);
+    float t0 = 0, t1 = tMax;
+    const float *oo = &o.x, *dd = &d.x;
+    for (int i = 0; i < 3; ++i) {
+        float invRayDir = 1 / dd[i];
+        float tNear = (bmin[i] - oo[i]) * invRayDir;
+        float tFar = (bmax[i] - oo[i]) * invRayDir;
+        if (tNear > tFar) { float t = tNear; tNear = tFar; tFar = t; }
+        tFar *= 1 + 2 * g3;
+        t0 = tNear > t0 ? tNear : t0;
+        t1 = tFar < t1 ? tFar : t1;
+        if (t0 > t1) return 0;
+    }
+    *hit0 = t0;
+    *hit1 = t1;
+    return 1;
+}
+/* exported for the golden-vector test of Bounds3::Offset / IntersectP (tests/golden/primitives.json "bounds3") */
+int oracle_bounds3(const float bmin[3], const float bmax[3], const float o[3], const float d[3], float tMax, float t01[2],
+                   float offset[3]) {
+    VspgMedium m;
+    memset(&m, 0, sizeof m);
+    for (int i = 0; i < 3; ++i) { m.bounds_min[i] = bmin[i]; m.bounds_max[i] = bmax[i]; }
+    v3 off = bounds_offset(&m, v3_from(o));
+    offset[0] = off.x; offset[1] = off.y; offset[2] = off.z;
+    t01[0] = t01[1] = 0.f;
+    return bounds_intersect_p(bmin, bmax, v3_from(o), v3_from(d), tMax, &t01[0], &t01[1]);
+}
 /* SampledGrid<Float>::Lookup(Point3i) (containers.h:830-835) */
 static float grid_at(const OracleRenderer *r, int x, int y, int z) {
     const VspgMedium *m = &r->scene.medium;
@@ -703,19 +733,8 @@ static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tM
             tMax -= dt;
         }
         v3 ro = p3i_mid(oi);
-        /* bounds.IntersectP(ray.o, ray.d, raytMax, &tMin, &tMax) (vecmath.h:1547-1571) */
-        float t0 = 0, t1 = tMax;
-        const float *oo = &ro.x, *dd = &d.x;
-        for (int i = 0; i < 3; ++i) {
-            float invRayDir = 1 / dd[i];
-            float tNear = (m->bounds_min[i] - oo[i]) * invRayDir;
-            float tFar = (m->bounds_max[i] - oo[i]) * invRayDir;
-            if (tNear > tFar) { float t = tNear; tNear = tFar; tFar = t; }
-            tFar *= 1 + 2 * g3;
-            t0 = tNear > t0 ? tNear : t0;
-            t1 = tFar < t1 ? tFar : t1;
-            if (t0 > t1) return it;
-        }
+        float t0, t1;
+        if (!bounds_intersect_p(m->bounds_min, m->bounds_max, ro, d, tMax, &t0, &t1)) return it;
         /* DDAMajorantIterator ctor (media.h:145-176) */
         it.tMin = t0; it.tMax = t1;
         it.maj = r->majorant;

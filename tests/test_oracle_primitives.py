@@ -169,6 +169,25 @@ def test_offset_ray_origin(oracle, pkg):
         assert all(same(a, b) for a, b in zip(out, v[12:15])), row
 
 
+def test_bounds3_offset_and_intersect(oracle, pkg):
+    """Bounds3f::Offset / IntersectP(o, d, tMax, &t0, &t1) of the REFERENCE (vecmath.h:1323-1332, 1547-1571; the
+    ray-vs-medium-bounds step of GridMedium::SampleRay): the oracle reproduces hit flag, t0, t1 and the offset bit for bit."""
+    bmin, bmax = pkg.f3(-0.8, -0.8, -0.5), pkg.f3(0.8, 0.7, 0.9)
+    hits = 0
+    for row in G["bounds3"]:
+        o, d = [fh(t) for t in row[0:3]], [fh(t) for t in row[3:6]]
+        tMax = fh(row[6]) if row[6] != "inf" else float("inf")
+        t01 = (C.c_float * 2)()
+        off = pkg.f3()
+        hit = oracle.oracle_bounds3(bmin, bmax, f3(pkg, o), f3(pkg, d), C.c_float(tMax), C.byref(t01), off)
+        assert hit == row[7], row
+        if hit:
+            hits += 1
+            assert same(t01[0], fh(row[8])) and same(t01[1], fh(row[9])), row
+        assert all(same(a, fh(b)) for a, b in zip(off, row[10:13])), row
+    assert 5 < hits < len(G["bounds3"]) - 5
+
+
 def test_channel_idx():
     # spectrum.h:380-384: channelIdx = min(floor(3u), 2); the oracle inlines it in
     # evaluate_pixel_sample -- check the formula against the reference's outputs
