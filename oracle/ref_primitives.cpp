@@ -10,7 +10,8 @@
 // incl. SetSequence / Advance / Uniform<float>, IndependentSampler, FastExp, SampleExponential,
 // SampleDiscrete, HenyeyGreenstein, SampleHenyeyGreenstein, SampleUniformSphere,
 // SampleCosineHemisphere, CoordinateSystem, OffsetRayOrigin, SampledWavelengths::ChannelIdx.
-// Bounds3f::Offset / IntersectP (the ray-vs-medium-bounds step of GridMedium::SampleRay).
+// Bounds3f::Offset / IntersectP and Transform::ApplyInverse(Ray, &tMax) (the first two steps of GridMedium::SampleRay;
+// links the reference's util/transform.cpp and util/math.cpp compiled in place).
 // NOT buildable without the absent third-party headers (nanovdb, openpgl, double-conversion ...): media.h,
 // media_sampleTMaj.h, the integrator; SampledGrid's constructors CHECK through util/print.cpp, which needs
 // double-conversion -- see DESIGN.md.
@@ -23,6 +24,7 @@
 #include <pbrt/util/sampling.h>
 #include <pbrt/util/scattering.h>
 #include <pbrt/util/spectrum.h>
+#include <pbrt/util/transform.h>
 #include <pbrt/util/vecmath.h>
 
 #include <cstdio>
@@ -263,6 +265,28 @@ int main() {
             pf(d.x); printf(","); pf(d.y); printf(","); pf(d.z); printf(","); pf(tMax); printf(",");
             printf("%d,", hit ? 1 : 0); pf(hit ? t0 : 0.f); printf(","); pf(hit ? t1 : 0.f); printf(",");
             pf(off.x); printf(","); pf(off.y); printf(","); pf(off.z); printf("]");
+        }
+        printf("],\n");
+    }
+    // ---- Transform::ApplyInverse(const Ray &, Float *tMax), identity matrix (util/transform.h:416-429,
+    //      util/transform.cpp:263-303): the first step of GridMedium / NanoVDBMedium::SampleRay ----
+    {
+        printf("\"apply_inverse_identity\": [");
+        bool first = true;
+        Transform T;
+        for (int i = 0; i < 48; ++i) {
+            Point3f o(4 * U() - 2, 4 * U() - 2, 4 * U() - 2);
+            Vector3f d(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            if (i % 8 == 0) d = d * 1e-3f;
+            if (i % 8 == 1) o = Point3f(0, 0, 0);
+            if (i % 8 == 2) d = Vector3f(0, 0, 0);
+            Float tMax = (i % 3 == 0) ? Infinity : 4 * U();
+            Float t = tMax;
+            Ray q = T.ApplyInverse(Ray(o, d), &t);
+            sep(first); printf("[");
+            pf(o.x); printf(","); pf(o.y); printf(","); pf(o.z); printf(",");
+            pf(d.x); printf(","); pf(d.y); printf(","); pf(d.z); printf(","); pf(tMax); printf(",");
+            pf(q.o.x); printf(","); pf(q.o.y); printf(","); pf(q.o.z); printf(","); pf(t); printf("]");
         }
         printf("]\n");
     }

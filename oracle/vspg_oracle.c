@@ -643,6 +643,30 @@ static int bounds_intersect_p(const float bmin[3], const float bmax[3], v3 o, v3
     *hit1 = t1;
     return 1;
 }
+/* Transform::ApplyInverse(const Ray &, Float *tMax) with an IDENTITY matrix (transform.h:416-429, transform.cpp:263-303):
+ * the origin picks up the conservative error bound gamma(3)*|o| and is pushed along d by dt, tMax shrinks by dt
+ * (SURVEY.md App. C #15).  Returns the new origin. */
+static v3 apply_inverse_identity(v3 o, v3 d, float *tMax) {
+    const float g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS);
+    v3 oerr = V3(g3 * (fabsf(o.x) + 0.f + 0.f), g3 * (0.f + fabsf(o.y) + 0.f), g3 * (0.f + 0.f + fabsf(o.z)));
+    p3i oi = p3i_from_err(o, oerr);
+    float lengthSquared = v_len2(d);
+    if (lengthSquared > 0) {
+        v3 oe = p3i_err(oi);
+        float dt = v_dot(v_abs(d), oe) / lengthSquared;
+        v3 sh = v_scale(d, dt);
+        /* Interval + Float: {AddRoundDown(low, f), AddRoundUp(high, f)} (math.h:873-875) */
+        oi.lo = V3(next_float_down(oi.lo.x + sh.x), next_float_down(oi.lo.y + sh.y), next_float_down(oi.lo.z + sh.z));
+        oi.hi = V3(next_float_up(oi.hi.x + sh.x), next_float_up(oi.hi.y + sh.y), next_float_up(oi.hi.z + sh.z));
+        *tMax -= dt;
+    }
+    return p3i_mid(oi);
+}
+void oracle_apply_inverse_identity(const float o[3], const float d[3], float tMax, float out_o[3], float *out_tMax) {
+    v3 r = apply_inverse_identity(v3_from(o), v3_from(d), &tMax);
+    out_o[0] = r.x; out_o[1] = r.y; out_o[2] = r.z;
+    *out_tMax = tMax;
+}
 /* exported for the golden-vector test of Bounds3::Offset / IntersectP (tests/golden/primitives.json "bounds3") */
 int oracle_bounds3(const float bmin[3], const float bmax[3], const float o[3], const float d[3], float tMax, float t01[2],
                    float offset[3]) {
@@ -719,20 +743,7 @@ static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tM
         /* ray = renderFromMedium.ApplyInverse(ray, &raytMax) with an identity transform
          * (transform.h:416-429, transform.cpp:263-303): the origin picks up the conservative
          * error bound gamma(3)*|o| and is pushed along d by dt */
-        const float g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS);
-        v3 oerr = V3(g3 * (fabsf(o.x) + 0.f + 0.f), g3 * (0.f + fabsf(o.y) + 0.f), g3 * (0.f + 0.f + fabsf(o.z)));
-        p3i oi = p3i_from_err(o, oerr);
-        float lengthSquared = v_len2(d);
-        if (lengthSquared > 0) {
-            v3 oe = p3i_err(oi);
-            float dt = v_dot(v_abs(d), oe) / lengthSquared;
-            v3 sh = v_scale(d, dt);
-            /* Interval + Float: {AddRoundDown(low, f), AddRoundUp(high, f)} (math.h:873-875) */
-            oi.lo = V3(next_float_down(oi.lo.x + sh.x), next_float_down(oi.lo.y + sh.y), next_float_down(oi.lo.z + sh.z));
-            oi.hi = V3(next_float_up(oi.hi.x + sh.x), next_float_up(oi.hi.y + sh.y), next_float_up(oi.hi.z + sh.z));
-            tMax -= dt;
-        }
-        v3 ro = p3i_mid(oi);
+        v3 ro = apply_inverse_identity(o, d, &tMax);
         float t0, t1;
         if (!bounds_intersect_p(m->bounds_min, m->bounds_max, ro, d, tMax, &t0, &t1)) return it;
         /* DDAMajorantIterator ctor (media.h:145-176) */

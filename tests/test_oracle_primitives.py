@@ -188,6 +188,21 @@ def test_bounds3_offset_and_intersect(oracle, pkg):
     assert 5 < hits < len(G["bounds3"]) - 5
 
 
+def test_apply_inverse_identity(oracle, pkg):
+    """Transform::ApplyInverse(Ray, &tMax) of the REFERENCE with an identity matrix (transform.h:416-429): the origin shift
+    by the conservative error bound and the shortened tMax -- first step of GridMedium / NanoVDBMedium::SampleRay."""
+    moved = 0
+    for row in G["apply_inverse_identity"]:
+        v = [fh(t) if t not in ("inf", "-inf") else float(t) for t in row]
+        out = pkg.f3()
+        t = C.c_float()
+        oracle.oracle_apply_inverse_identity(f3(pkg, v[0:3]), f3(pkg, v[3:6]), C.c_float(v[6]), out, C.byref(t))
+        assert all(same(a, b) for a, b in zip(out, v[7:10])), row
+        assert same(t.value, v[10]) or (np.isinf(v[10]) and np.isinf(t.value)), row
+        moved += any(not same(a, b) for a, b in zip(out, v[0:3]))
+    assert moved > 20  # the shift is real
+
+
 def test_channel_idx():
     # spectrum.h:380-384: channelIdx = min(floor(3u), 2); the oracle inlines it in
     # evaluate_pixel_sample -- check the formula against the reference's outputs
