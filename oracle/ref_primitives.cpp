@@ -288,6 +288,28 @@ int main() {
             pf(d.x); printf(","); pf(d.y); printf(","); pf(d.z); printf(","); pf(tMax); printf(",");
             pf(q.o.x); printf(","); pf(q.o.y); printf(","); pf(q.o.z); printf(","); pf(t); printf("]");
         }
+        printf("],\n");
+    }
+    // ---- SpawnRayTo(Point3fi pFrom, Normal3f nFrom, time, Point3fi pTo, Normal3f nTo) (ray.h:103-108): the NEE shadow
+    //      ray, whose origin and direction seed the shadow ray's RNG (guidedvolpathvspgintegrator.cpp:1193) ----
+    {
+        printf("\"spawn_ray_to\": [");
+        bool first = true;
+        for (int i = 0; i < 48; ++i) {
+            Point3f a(2 * U() - 1, 2 * U() - 1, 2 * U() - 1), b(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            Vector3f ea(1e-6f * U(), 1e-6f * U(), 1e-6f * U()), eb(1e-6f * U(), 1e-6f * U(), 1e-6f * U());
+            Normal3f na = Normal3f(Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1)));
+            Normal3f nb = Normal3f(Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1)));
+            if (i % 4 == 0) { na = Normal3f(0, 0, 0); ea = Vector3f(0, 0, 0); }  // medium vertex: exact point, no normal
+            if (i % 4 == 1) nb = Normal3f(0, -1, 0);
+            Ray r = SpawnRayTo(Point3fi(a, ea), na, 0.f, Point3fi(b, eb), nb);
+            sep(first); printf("[");
+            pf(a.x); printf(","); pf(a.y); printf(","); pf(a.z); printf(","); pf(ea.x); printf(","); pf(ea.y); printf(","); pf(ea.z); printf(",");
+            pf(na.x); printf(","); pf(na.y); printf(","); pf(na.z); printf(",");
+            pf(b.x); printf(","); pf(b.y); printf(","); pf(b.z); printf(","); pf(eb.x); printf(","); pf(eb.y); printf(","); pf(eb.z); printf(",");
+            pf(nb.x); printf(","); pf(nb.y); printf(","); pf(nb.z); printf(",");
+            pf(r.o.x); printf(","); pf(r.o.y); printf(","); pf(r.o.z); printf(","); pf(r.d.x); printf(","); pf(r.d.y); printf(","); pf(r.d.z); printf("]");
+        }
         printf("]\n");
     }
     printf("}\n");

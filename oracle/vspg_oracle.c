@@ -387,6 +387,20 @@ static v3 offset_ray_origin(p3i pi, v3 n, v3 w) {
     }
     return po;
 }
+/* SpawnRayTo(Point3fi pFrom, Normal3f nFrom, Float time, Point3fi pTo, Normal3f nTo) (ray.h:103-108) */
+static void spawn_ray_to(p3i pFrom, v3 nFrom, p3i pTo, v3 nTo, v3 *o, v3 *d) {
+    v3 pf = offset_ray_origin(pFrom, nFrom, v_sub(p3i_mid(pTo), p3i_mid(pFrom)));
+    v3 pt = offset_ray_origin(pTo, nTo, v_sub(pf, p3i_mid(pTo)));
+    *o = pf;
+    *d = v_sub(pt, pf);
+}
+void oracle_spawn_ray_to(const float pf[3], const float pferr[3], const float nf[3], const float pt[3], const float pterr[3],
+                         const float nt[3], float out_o[3], float out_d[3]) {
+    v3 o, d;
+    spawn_ray_to(p3i_from_err(v3_from(pf), v3_from(pferr)), v3_from(nf), p3i_from_err(v3_from(pt), v3_from(pterr)), v3_from(nt), &o, &d);
+    out_o[0] = o.x; out_o[1] = o.y; out_o[2] = o.z;
+    out_d[0] = d.x; out_d[1] = d.y; out_d[2] = d.z;
+}
 void oracle_offset_ray_origin(const float p[3], const float perr[3], const float n[3],
                               const float w[3], float out[3]) {
     v3 r = offset_ray_origin(p3i_from_err(v3_from(p), v3_from(perr)), v3_from(n), v3_from(w));
@@ -1514,9 +1528,8 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
     if (!s_nonzero(f_hat)) return S1(0.f);
 
     /* lightRay = intr.SpawnRayTo(ls->pLight) (interaction.h:111-115, ray.h:103-108) */
-    v3 pf = offset_ray_origin(intr->pi, intr->n, v_sub(p3i_mid(ls.pLight), p3i_mid(intr->pi)));
-    v3 pt = offset_ray_origin(ls.pLight, ls.nLight, v_sub(pf, p3i_mid(ls.pLight)));
-    v3 lo = pf, ld = v_sub(pt, pf);
+    v3 lo, ld;
+    spawn_ray_to(intr->pi, intr->n, ls.pLight, ls.nLight, &lo, &ld);
     spec T_ray = S1(1.f), r_l = S1(1.f), r_u = S1(1.f);
     rng_t rng;
     rng_set_sequence2(&rng, oracle_hash_point3(lo.x, lo.y, lo.z), oracle_hash_point3(ld.x, ld.y, ld.z));

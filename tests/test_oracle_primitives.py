@@ -188,6 +188,17 @@ def test_bounds3_offset_and_intersect(oracle, pkg):
     assert 5 < hits < len(G["bounds3"]) - 5
 
 
+def test_spawn_ray_to(oracle, pkg):
+    """SpawnRayTo(Point3fi, Normal3f, time, Point3fi, Normal3f) of the REFERENCE (ray.h:103-108): origin and direction of the
+    NEE shadow ray -- the two values that seed its RNG -- bit for bit."""
+    for row in G["spawn_ray_to"]:
+        v = [fh(t) for t in row]
+        o, d = pkg.f3(), pkg.f3()
+        oracle.oracle_spawn_ray_to(f3(pkg, v[0:3]), f3(pkg, v[3:6]), f3(pkg, v[6:9]), f3(pkg, v[9:12]), f3(pkg, v[12:15]),
+                                   f3(pkg, v[15:18]), o, d)
+        assert all(same(a, b) for a, b in zip(list(o) + list(d), v[18:24])), row
+
+
 def test_apply_inverse_identity(oracle, pkg):
     """Transform::ApplyInverse(Ray, &tMax) of the REFERENCE with an identity matrix (transform.h:416-429): the origin shift
     by the conservative error bound and the shortened tMax -- first step of GridMedium / NanoVDBMedium::SampleRay."""
