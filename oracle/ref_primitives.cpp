@@ -310,6 +310,27 @@ int main() {
             pf(nb.x); printf(","); pf(nb.y); printf(","); pf(nb.z); printf(",");
             pf(r.o.x); printf(","); pf(r.o.y); printf(","); pf(r.o.z); printf(","); pf(r.d.x); printf(","); pf(r.d.y); printf(","); pf(r.d.z); printf("]");
         }
+        printf("],\n");
+    }
+    // ---- Frame::FromXZ / ToLocal / FromLocal (vecmath.h:1850-1920): the shading frame of BSDF (bsdf.h:20-88) ----
+    {
+        printf("\"frame_xz\": [");
+        bool first = true;
+        for (int i = 0; i < 32; ++i) {
+            Vector3f z = Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1));
+            Vector3f t(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            Vector3f x = Normalize(t - Dot(t, z) * z);  // some unit vector orthogonal to z (up to rounding)
+            if (i == 0) { x = Vector3f(1, 0, 0); z = Vector3f(0, 0, 1); }
+            if (i == 1) { x = Vector3f(0, 0, -1); z = Vector3f(0, 1, 0); }
+            Frame f = Frame::FromXZ(x, z);
+            Vector3f v(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            Vector3f l = f.ToLocal(v), w = f.FromLocal(v);
+            sep(first); printf("[");
+            pf(x.x); printf(","); pf(x.y); printf(","); pf(x.z); printf(","); pf(z.x); printf(","); pf(z.y); printf(","); pf(z.z); printf(",");
+            pf(v.x); printf(","); pf(v.y); printf(","); pf(v.z); printf(",");
+            pf(f.y.x); printf(","); pf(f.y.y); printf(","); pf(f.y.z); printf(",");
+            pf(l.x); printf(","); pf(l.y); printf(","); pf(l.z); printf(","); pf(w.x); printf(","); pf(w.y); printf(","); pf(w.z); printf("]");
+        }
         printf("]\n");
     }
     printf("}\n");

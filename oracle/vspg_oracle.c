@@ -295,6 +295,17 @@ static inline v3 frame_from_local(const frame_t *f, v3 v) {
     return v_add(v_add(v_scale(f->x, v.x), v_scale(f->y, v.y)), v_scale(f->z, v.z));
 }
 static inline v3 frame_to_local(const frame_t *f, v3 v) { return V3(v_dot(v, f->x), v_dot(v, f->y), v_dot(v, f->z)); }
+/* exported for the golden-vector test: Frame::FromXZ(x, z) = Frame(x, Cross(z, x), z) (vecmath.h:1862), ToLocal, FromLocal */
+void oracle_frame_xz(const float x[3], const float z[3], const float v[3], float out_y[3], float out_local[3], float out_world[3]) {
+    frame_t f;
+    f.x = v3_from(x);
+    f.z = v3_from(z);
+    f.y = v_cross(f.z, f.x);
+    v3 l = frame_to_local(&f, v3_from(v)), w = frame_from_local(&f, v3_from(v));
+    out_y[0] = f.y.x; out_y[1] = f.y.y; out_y[2] = f.y.z;
+    out_local[0] = l.x; out_local[1] = l.y; out_local[2] = l.z;
+    out_world[0] = w.x; out_world[1] = w.y; out_world[2] = w.z;
+}
 /* util/vecmath.h:1666-1672 */
 static inline v3 spherical_direction(float sinTheta, float cosTheta, float phi) {
     return V3(clampf(sinTheta, -1, 1) * cosf(phi), clampf(sinTheta, -1, 1) * sinf(phi),

@@ -50,6 +50,8 @@ void oracle_sample_henyey_greenstein(const float wo[3], float g, float u0, float
 void oracle_sample_uniform_sphere(float u0, float u1, float out[3]);
 void oracle_sample_cosine_hemisphere(float u0, float u1, float out[3]);
 void oracle_coordinate_system(const float v[3], float v2[3], float v3[3]);
+/* Frame::FromXZ(x, z) (its y axis), Frame::ToLocal(v), Frame::FromLocal(v) */
+void oracle_frame_xz(const float x[3], const float z[3], const float v[3], float out_y[3], float out_local[3], float out_world[3]);
 /* SpawnRayTo(Point3fi pFrom, Normal3f nFrom, time, Point3fi pTo, Normal3f nTo) (ray.h:103-108): the NEE shadow ray */
 void oracle_spawn_ray_to(const float pf[3], const float pferr[3], const float nf[3], const float pt[3], const float pterr[3],
                          const float nt[3], float out_o[3], float out_d[3]);

@@ -37,6 +37,7 @@ def load():
         "oracle_sample_cosine_hemisphere": (None, [C.c_float, C.c_float, f3]),
         "oracle_coordinate_system": (None, [f3, f3, f3]),
         "oracle_offset_ray_origin": (None, [f3, f3, f3, f3, f3]),
+        "oracle_frame_xz": (None, [f3, f3, f3, f3, f3, f3]),
         "oracle_spawn_ray_to": (None, [f3, f3, f3, f3, f3, f3, f3, f3]),
         "oracle_apply_inverse_identity": (None, [f3, f3, C.c_float, f3, p(C.c_float)]),
         "oracle_bounds3": (C.c_int, [f3, f3, f3, f3, C.c_float, C.POINTER(C.c_float * 2), f3]),

@@ -188,6 +188,15 @@ def test_bounds3_offset_and_intersect(oracle, pkg):
     assert 5 < hits < len(G["bounds3"]) - 5
 
 
+def test_frame_from_xz(oracle, pkg):
+    """Frame::FromXZ / ToLocal / FromLocal of the REFERENCE (vecmath.h:1850-1920): the BSDF's shading frame."""
+    for row in G["frame_xz"]:
+        v = [fh(t) for t in row]
+        y, l, w = pkg.f3(), pkg.f3(), pkg.f3()
+        oracle.oracle_frame_xz(f3(pkg, v[0:3]), f3(pkg, v[3:6]), f3(pkg, v[6:9]), y, l, w)
+        assert all(same(a, b) for a, b in zip(list(y) + list(l) + list(w), v[9:18])), row
+
+
 def test_spawn_ray_to(oracle, pkg):
     """SpawnRayTo(Point3fi, Normal3f, time, Point3fi, Normal3f) of the REFERENCE (ray.h:103-108): origin and direction of the
     NEE shadow ray -- the two values that seed its RNG -- bit for bit."""
