@@ -168,8 +168,8 @@ typedef struct VspgCounters {
  * (guidedvolpathvspgintegrator.cpp:111-128, 234-246).  OpenPGL is not part of the reference tree,
  * so the layout and the mixture math are this build's own design: a kd-tree over
  * positions whose leaves hold a parallax-aware von-Mises-Fisher mixture of the incident radiance
- * plus a per-lobe volume-scatter-probability estimate.  Training on device (Field::Update, SURVEY
- * 8a row a18) is not built yet: the caller supplies a trained field. */
+ * plus a per-lobe volume-scatter-probability estimate.  The renderer trains the field in-loop (Field::Update,
+ * SURVEY 8a row a18; see "guiding-cache training" below) or takes a trained one (vspg_renderer_set_guiding_field). */
 #define VSPG_FIELD_LOBES 8
 typedef struct VspgKdNode {
     float split;      /* inner node: split plane position along `axis` */
