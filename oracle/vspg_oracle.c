@@ -1884,9 +1884,9 @@ static int resampling_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_
     return 1;
 }
 
-/* VSP fetch (:654-671, :1098-1134).  Secondary-ray VSP comes from the guiding cache, which is
- * never trained in the configurations this oracle covers -> GuidedBSDF/GuidedPhaseFunction
- * ::VolumeScatterProbability return -1 (guiding.h:295-298, 564-567). */
+/* VSP fetch (:654-671, :1098-1134).  Primary rays: the image-space buffer; secondary rays: the previous vertex's
+ * GuidedBSDF / GuidedPhaseFunction::VolumeScatterProbability(ray.d) (guiding.h:295-305, 564-574), -1 where the cache
+ * has no trained distribution. */
 static float fetch_vsp(const OracleRenderer *r, int px, int py, int depth, int lastVertexVolume, const gwrap_t *gbsdf,
                        const gwrap_t *gphase, v3 rayd, int *guide) {
     float vsp = -1.f;
