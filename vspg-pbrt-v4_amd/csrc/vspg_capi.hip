@@ -1376,6 +1376,9 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count))
         return fail(VSPG_EINVAL, "shard_index out of range");
     if (p->maxdepth < 0) return fail(VSPG_EINVAL, "maxdepth must be >= 0");
+    if (p->maxdepth > 254) return fail(VSPG_EINVAL, "maxdepth above 254 (the path depth travels in 8 bits of the packed path flags)");
+    if ((p->surfaceguiding || p->volumeguiding || p->vspsecondaryguiding) && p->maxdepth + 2 > 32)
+        return fail(VSPG_ESCOPE, "guiding-cache training keeps at most 32 segment records per path (maxdepth <= 30)");
     if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
     if (p->rrguiding) return fail(VSPG_ESCOPE, "rrguiding (guided Russian roulette) is outside the hot-path scope");
     if (scene->medium.type == VSPG_MEDIUM_GRID || scene->medium.type == VSPG_MEDIUM_NANOVDB) {
