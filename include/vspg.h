@@ -136,11 +136,13 @@ typedef struct VspgIntegratorParams {
     int32_t vspcriterion;              /* "variance" */
     int32_t vspsamplingmethod;         /* "resampling" */
     int32_t collisionProbabilityBias;  /* false (NDS+: needs a transmittance buffer, vspg_renderer_set_tr_buffer) */
-    int32_t rrguiding;                 /* false (guided RR; out of scope if set) */
+    int32_t rrguiding;                 /* false: guided Russian roulette (needs the image-space contribution estimate) */
     int32_t lightsampler;              /* "bvh" */
     int32_t regularize;                /* false (no-op for diffuse BxDFs) */
     int32_t guide_num_training_waves;  /* 128, hidden constant integrators.h:502 */
     int32_t storeTrBuffer;             /* false: record the primary rays' transmittance (TrBuffer) for read-back */
+    int32_t surfacerrguiding;          /* true  (with rrguiding: guided survival probability at surface vertices, else 1) */
+    int32_t volumerrguiding;           /* true  (same for volume vertices) */
 } VspgIntegratorParams;
 
 /* Film "rgb" + Sampler "independent" + PixelFilter "box" (SURVEY.md App. F). */

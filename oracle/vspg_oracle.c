@@ -527,6 +527,10 @@ struct OracleRenderer {
     float *trbuf; /* W*H*3 */
     int *tr_spp;  /* W*H */
     int tr_calc, tr_load;
+    /* image-space contribution estimate for guided RR (own stand-in for ImageSpaceGuidingBuffer::GetContributionEstimate):
+     * 5x5 box-filtered film mean, refreshed with the VSP buffer at waves 1, 2, 4, ... */
+    float *contrib; /* W*H*3 */
+    int contrib_ready;
     int in_wave;  /* render_wave is running (debug path traces do not feed the buffers) */
 };
 
@@ -1571,6 +1575,22 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
 /* StandardThroughputBasedRussianRoulette lives in OpenPGL (absent; SURVEY.md App. A.5
  * "[unverified]"): restated as pbrt's own rule q = max(0, 1 - maxComponent)
  * (cf. the commented-out rrBeta code at guidedvolpathvspgintegrator.cpp:594-596). UNPINNED. */
+/* openpgl::cpp::util::GuidedRussianRoulette(throughput, adjointEstimate, pixelContributionEstimate, minSurvival) is
+ * OpenPGL code (absent from the reference tree).  Own definition in the spirit of adjoint-driven RR: the survival
+ * probability is the largest per-channel ratio of the path's expected contribution (throughput x adjoint) to the pixel's
+ * contribution estimate, clamped to [minSurvival, 1]; channels without an estimate do not vote, none -> 1.  Unpinned. */
+static float guided_russian_roulette(spec throughput, spec adjoint, spec reference, float minSurvival) {
+    float s = 0.f;
+    int any = 0;
+    for (int k = 0; k < 3; ++k)
+        if (reference.c[k] > 0) {
+            float q = throughput.c[k] * adjoint.c[k] / reference.c[k];
+            s = q > s ? q : s;
+            any = 1;
+        }
+    if (!any) return 1.f;
+    return fminf(1.f, fmaxf(minSurvival, s));
+}
 static float standard_throughput_rr(spec w) {
     float m = s_max(w);
     return fminf(1.f, fmaxf(0.f, m));
@@ -1632,6 +1652,8 @@ typedef struct {
     const OracleRenderer *r;
     int ch;
     int px, py;                  /* pPixel */
+    int guideRR;                 /* :276-285 */
+    spec pixelContributionEstimate;
     sampler_t *sampler;
     rng_t *rng;
     pathrec_t *rec;              /* a18 recorder, NULL when not training */
@@ -1667,9 +1689,16 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
         c->gphase->useGuiding = r->prm.volumeguiding ? c->gphase->d.ok : 0;
         c->gphase->useScatterGuiding = r->prm.vspsecondaryguiding ? c->gphase->d.ok : 0;
         float survivalProb = 1.0f;
-        if (*c->depth > r->prm.minrrdepth) {
-            spec rrw = s_scale(s_divf(*c->beta, s_avg(*c->r_u)), c->rr_correction);
-            survivalProb = *c->specularBounce ? 0.95f : standard_throughput_rr(rrw);
+        if (*c->depth > r->prm.minrrdepth) { /* :817-830 */
+            if (c->guideRR) {
+                if (r->prm.volumerrguiding)
+                    survivalProb = *c->specularBounce ? 0.95f : guided_russian_roulette(*c->beta, S1(1.f), c->pixelContributionEstimate, 0.1f);
+                else
+                    survivalProb = 1.f;
+            } else {
+                spec rrw = s_scale(s_divf(*c->beta, s_avg(*c->r_u)), c->rr_correction);
+                survivalProb = *c->specularBounce ? 0.95f : standard_throughput_rr(rrw);
+            }
         }
         if (r->prm.usenee) {
             spec Ld = sample_Ld(r, &intr, c->gphase, c->ch, c->sampler, *c->r_u, c->pc);
@@ -2027,6 +2056,15 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
     gwrap_t gbsdf, gphase; /* GuidedBSDF gbsdf / GuidedPhaseFunction gphase (:287-288) */
     memset(&gbsdf, 0, sizeof gbsdf);
     memset(&gphase, 0, sizeof gphase);
+    /* :274-285: guided RR needs the pixel's contribution estimate; until the image-space buffer is ready the path
+     * uses the standard rule */
+    int guideRR = 0;
+    spec pixelContributionEstimate = S1(1.f);
+    if (r->prm.rrguiding && r->contrib_ready) {
+        const float *ce = &r->contrib[((size_t)py * r->cfg.xres + px) * 3];
+        pixelContributionEstimate.c[0] = ce[0]; pixelContributionEstimate.c[1] = ce[1]; pixelContributionEstimate.c[2] = ce[2];
+        guideRR = 1;
+    }
 
     while (1) {
         pc->segments++;
@@ -2041,6 +2079,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             sd_ctx_t c;
             memset(&c, 0, sizeof c);
             c.r = r; c.ch = ch; c.px = px; c.py = py; c.sampler = sampler; c.rng = &rng;
+            c.guideRR = guideRR; c.pixelContributionEstimate = pixelContributionEstimate;
             c.ray_o = &ro; c.ray_d = &rd; c.depth = &depth;
             c.L = &L; c.beta = &beta; c.r_u = &r_u; c.r_l = &r_l;
             c.specularBounce = &specularBounce; c.anyNonSpecularBounces = &anyNonSpecularBounces;
@@ -2089,6 +2128,12 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         float v = sampler_get1d(sampler);
         (void)v;
         float survivalProb = 1.f;
+        if (guideRR && depth > r->prm.minrrdepth) { /* :465-472 (adjointEstimate stays 1: OPENPGL_RADIANCE_CACHES is not defined) */
+            if (r->prm.surfacerrguiding)
+                survivalProb = specularBounce ? 0.95f : guided_russian_roulette(beta, S1(1.f), pixelContributionEstimate, 0.1f);
+            else
+                survivalProb = 1.f;
+        }
         intr_t intr;
         memset(&intr, 0, sizeof intr);
         intr.is_surface = 1;
@@ -2203,7 +2248,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         rd = wi;
 
         if (!s_nonzero(beta)) break;
-        if (depth > r->prm.minrrdepth) {
+        if (!guideRR && depth > r->prm.minrrdepth) { /* :597-600 */
             spec rrw = s_scale(s_scale(s_divf(beta, s_avg(r_u)), rr_correction), etaScale);
             survivalProb = specularBounce ? 0.95f : standard_throughput_rr(rrw);
         }
@@ -2648,7 +2693,9 @@ int oracle_post_process_wave(OracleRenderer *r) {
     r->n_zero_samples = 0;
     if ((double)r->wave_counter == pow(2.0, (double)r->buffer_wave)) {
         int W = r->cfg.xres, H = r->cfg.yres;
-        if (r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded) {
+        const int do_vsp = r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded;
+        const int do_contrib = r->prm.rrguiding != 0; /* cfg.EnableContributionEstimate(guideRR) (:164-168) */
+        if (do_vsp || do_contrib) {
             for (int y = 0; y < H; ++y)
                 for (int x = 0; x < W; ++x) {
                     float a[5] = {0, 0, 0, 0, 0};
@@ -2659,21 +2706,31 @@ int oracle_post_process_wave(OracleRenderer *r) {
                             const float *st = &r->isg_stats[((size_t)yy * W + xx) * VSPG_ISG_STATS];
                             for (int k = 0; k < 5; ++k) a[k] += st[k];
                         }
-                    float vsp = -1.f;
-                    if (a[0] > 0) {
-                        float v, s;
-                        if (r->prm.vspcriterion == VSPG_VSP_VARIANCE) {
-                            v = sqrtf(a[3] / a[0]);
-                            s = sqrtf(a[4] / a[0]);
-                        } else {
-                            v = a[1] / a[0];
-                            s = a[2] / a[0];
+                    if (do_vsp) {
+                        float vsp = -1.f;
+                        if (a[0] > 0) {
+                            float v, s;
+                            if (r->prm.vspcriterion == VSPG_VSP_VARIANCE) {
+                                v = sqrtf(a[3] / a[0]);
+                                s = sqrtf(a[4] / a[0]);
+                            } else {
+                                v = a[1] / a[0];
+                                s = a[2] / a[0];
+                            }
+                            if (v + s > 0) vsp = v / (v + s);
                         }
-                        if (v + s > 0) vsp = v / (v + s);
+                        r->vsp[(size_t)y * W + x] = vsp;
                     }
-                    r->vsp[(size_t)y * W + x] = vsp;
+                    if (do_contrib) {
+                        /* contribution estimate (own stand-in): filtered mean of the samples' average radiance, the same value
+                         * in the three channels; 0 = no estimate */
+                        float ce = a[0] > 0 ? (a[1] + a[2]) / a[0] : 0.f;
+                        float *dst = &r->contrib[((size_t)y * W + x) * 3];
+                        dst[0] = dst[1] = dst[2] = ce;
+                    }
                 }
-            r->vsp_ready = 1;
+            if (do_vsp) r->vsp_ready = 1;
+            if (do_contrib) r->contrib_ready = 1;
         }
         r->buffer_wave++;
     }
@@ -2687,7 +2744,6 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
     if (!scene || !p || !cfg) return VSPG_EINVAL;
     if (cfg->xres <= 0 || cfg->yres <= 0) return VSPG_EINVAL;
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return VSPG_EINVAL;
-    if (p->rrguiding) return VSPG_ESCOPE;
     if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;
         if (m->nx <= 0 || m->ny <= 0 || m->nz <= 0 || !m->density) return VSPG_EINVAL;
@@ -2743,6 +2799,10 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
     r->film = (double *)calloc(npix * 4, sizeof(double));
     r->isg_stats = (float *)calloc(npix * VSPG_ISG_STATS, sizeof(float));
     r->vsp = (float *)calloc(npix, sizeof(float));
+    if (params->rrguiding) { /* :195-197 */
+        r->prm.minrrdepth = 1;
+        r->contrib = (float *)calloc(npix * 3, sizeof(float));
+    }
     /* calculateTrBuffer (:190-193); a buffer handed over through oracle_tr_buffer_write is trBufferLoad (:180-188) */
     r->tr_calc = params->storeTrBuffer || (params->vspguiding && params->vspprimaryguiding &&
                                            params->vspsamplingmethod == VSPG_VSP_NDS && params->collisionProbabilityBias);
@@ -2765,7 +2825,7 @@ void oracle_renderer_destroy(OracleRenderer *r) {
     if (!r) return;
     free_field(r, 0); free_field(r, 1);
     free(r->samples);
-    free(r->trbuf); free(r->tr_spp); free(r->le_scale);
+    free(r->trbuf); free(r->tr_spp); free(r->le_scale); free(r->contrib);
     free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {
@@ -2891,6 +2951,7 @@ void oracle_integrator_params_default(VspgIntegratorParams *p) {
     p->collisionProbabilityBias = 0; p->rrguiding = 0;
     p->lightsampler = VSPG_LIGHTSAMPLER_BVH; p->regularize = 0;
     p->guide_num_training_waves = 128;
+    p->surfacerrguiding = 1; p->volumerrguiding = 1;
 }
 
 int oracle_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3], const float up[3],

@@ -1013,8 +1013,10 @@ def test_error_conventions_on_device(gpu_pkg):
 
     prm = P.app_f_params()
     assert create(scene, prm) == 0
-    prm.rrguiding = 1
-    assert create(scene, prm) == P.VSPG_ESCOPE and b"rrguiding" in lib.vspg_last_error()
+    prm.lightsampler = P.LIGHTSAMPLER_POWER   # more than one light: only "uniform" is built
+    s1 = P.fog_box_scene(W, H)
+    s1.quads[0].Le[0] = s1.quads[0].Le[1] = s1.quads[0].Le[2] = 1.0
+    assert create(s1, prm) == P.VSPG_ESCOPE and b"lightsampler" in lib.vspg_last_error()
     prm = P.app_f_params()
     prm.maxdepth = -1
     assert create(scene, prm) in (P.VSPG_EINVAL, 0)  # (negative depth is the reference's "no bounce" -- not an error there)
@@ -1036,3 +1038,55 @@ def test_error_conventions_on_device(gpu_pkg):
     with pytest.raises(Exception):
         r.tr_buffer()
     r.close()
+
+
+@pytest.mark.parametrize("guiding", [False, True])
+def test_guided_russian_roulette_vs_oracle(gpu_pkg, guiding):
+    """rrguiding: survival probability from throughput / image-space contribution estimate (own stand-in for OpenPGL's
+    GuidedRussianRoulette), minRRDepth 1 -- device == oracle: contribution estimates after the buffer updates,
+    replayed paths and film; with and without directional guiding on top."""
+    P = gpu_pkg
+    W, H = 64, 48
+    scene = P.fog_box_scene(W, H)
+    prm = P.default_params() if guiding else P.app_f_params()
+    prm.rrguiding = 1
+    prm.maxdepth = 8
+    prm.guide_num_training_waves = 3
+    g = P.Renderer(scene, prm, W, H, seed=7)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=7)
+    if guiding:  # the same field on both sides (in-loop training sums floats in a different order)
+        field = light_field_for(P)
+        g.set_guiding_field(field, field); c.set_guiding_field(field, field)
+    for w in range(3):   # the image-space buffer (and with it the contribution estimate) becomes ready after wave 0
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    rng = np.random.default_rng(29)
+    n = 20000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(8, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    exact = np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)
+    print("rrguiding (guiding=%s) paths: same segments %.5f bit-identical %.5f" % (guiding, np.mean(sg == sc), exact.mean()))
+    assert np.mean(sg == sc) >= 0.999 and exact.mean() >= 0.999
+    fg, fc = g.film(), c.film()
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    relmse = np.mean((ig - ic) ** 2 / (ic ** 2 + 1e-4))
+    print("rrguiding film relMSE %.3e" % relmse)
+    assert relmse <= 1e-8
+    # the rule is really in force: the standard rule gives other path lengths on the same samples
+    prm.rrguiding = 0
+    prm.minrrdepth = 1
+    g0 = P.Renderer(scene, prm, W, H, seed=7)
+    if guiding:
+        g0.set_guiding_field(field, field)
+    for w in range(3):
+        g0.render_wave(w, w + 1); g0.post_process_wave()
+    L0, s0 = g0.trace_paths(pix, si)
+    assert np.mean(s0 != sg) > 0.02
+    g0.close(); g.close(); c.close()
+
+
+def light_field_for(P):
+    from scenes import light_field
+    return light_field(P, n=4)

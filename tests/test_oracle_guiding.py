@@ -218,3 +218,31 @@ def test_in_loop_training_is_unbiased_and_uploading_a_field_stops_it():
     r.render_wave(0, 1)
     assert r.training_stats()["n_samples"] == 0
     r.close()
+
+
+def test_guided_russian_roulette_is_unbiased_and_active():
+    """rrguiding (guidedvolpathvspgintegrator.cpp:195-197, 274-285, 465-472, 597-600, 817-830): the survival probability comes
+    from throughput / pixel contribution estimate once the image-space buffer is ready, minRRDepth becomes 1; the estimator
+    stays unbiased (any survival probability in (0,1] is) and the paths really change."""
+    import oracle_lib
+    from conftest import load_package
+    P = load_package()
+    W, H = 40, 30
+    scene = oracle_lib.fog_box_scene(W, H)
+    means, segs = [], []
+    for rrg in (0, 1):
+        prm = oracle_lib.app_f_params()
+        prm.minrrdepth = 1
+        prm.maxdepth = 8
+        prm.rrguiding = rrg
+        r = oracle_lib.OracleRenderer(scene, prm, W, H)
+        for w in range(192):
+            r.render_wave(w, w + 1)
+            r.post_process_wave()
+        f = r.film_f64()
+        means.append((f[..., :3] / f[..., 3:4]).reshape(-1, 3).mean(0))
+        c = r.counters()
+        segs.append(c["segments"] / c["paths"])
+        r.close()
+    assert np.allclose(means[0], means[1], rtol=0.03), means
+    assert abs(segs[0] - segs[1]) > 0.02, segs  # another survival rule, other path lengths

@@ -63,7 +63,8 @@ class VspgIntegratorParams(C.Structure):
                 ("vspcriterion", C.c_int32), ("vspsamplingmethod", C.c_int32),
                 ("collisionProbabilityBias", C.c_int32), ("rrguiding", C.c_int32),
                 ("lightsampler", C.c_int32), ("regularize", C.c_int32),
-                ("guide_num_training_waves", C.c_int32), ("storeTrBuffer", C.c_int32)]
+                ("guide_num_training_waves", C.c_int32), ("storeTrBuffer", C.c_int32),
+                ("surfacerrguiding", C.c_int32), ("volumerrguiding", C.c_int32)]
 
 
 class VspgRenderConfig(C.Structure):

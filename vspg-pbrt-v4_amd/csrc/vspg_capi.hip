@@ -47,6 +47,12 @@ __device__ __forceinline__ void flush_counters(const PC &pc, uint32_t paths, uns
     if (threadIdx.x < kNumCounters) atomicAdd(&g[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
+// guided RR (:274-285): the pixel's contribution estimate, once the image-space buffer is ready
+__device__ __forceinline__ void load_contribution_estimate(const DScene &S, int px, int py, PathState &st) {
+    st.guideRR = S.prm.rrguiding && S.contrib_ready;
+    st.pce = st.guideRR ? S.contrib[(size_t)py * S.xres + px] : 0.f;
+}
+
 // The global work head is a PAIR of counters used by alternate launches: a launch zeroes the one the NEXT launch will use
 // (nobody reads it meanwhile, launches of a renderer are stream-ordered), so no memset sits between two waves.
 __device__ __forceinline__ void reset_sibling_head(unsigned int *work_head) {
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
                     else
                         start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);
                     has = true;
+                    if constexpr (GUIDED) load_contribution_estimate(S, px, py, st);
                     if constexpr (TRAIN) {
                         my_item = item;
                         pc.rec.base = train.segbuf + item;
@@ -199,10 +206,12 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
         }
         if (finished) {
             s += S.shard_count > 1 ? S.shard_count : 1;
-            if (!TRAIN && s < wave_end)
+            if (!TRAIN && s < wave_end) {
                 start_path(S, vsp_buf, vsp_ready, px, py, s, sampler, st, &ch, isg);  // next sample of the same pixel
-            else
+                if constexpr (GUIDED) load_contribution_estimate(S, px, py, st);
+            } else {
                 has = false;
+            }
         }
     }
     flush_counters(pc, paths, counters);
@@ -956,6 +965,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict
     float *glds = nullptr;
     if constexpr (GUIDED) glds = guide_lds();
     start_path(S, vsp_buf, vsp_ready, px, py, sample_index[i], sampler, st, &ch, isg);
+    if constexpr (GUIDED) load_contribution_estimate(S, px, py, st);
     while (li_segment<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, glds, kBlock)) {
     }
     Spec L = finish_radiance(st.L);
@@ -1081,7 +1091,8 @@ __global__ __launch_bounds__(kBlock) void k_libm_log1m(int n, const float *__res
 // then the contribution / variance criterion (own design, unpinned).
 constexpr int kIsgRadius = 2;
 __global__ __launch_bounds__(kBlock) void k_isg_update(int W, int H, int criterion, const float *__restrict__ stats,
-                                                       float *__restrict__ vsp) {
+                                                       float *__restrict__ vsp /* null: leave the VSP buffer alone */,
+                                                       float *__restrict__ contrib /* null: no contribution estimate */) {
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= W * H) return;
     int x = i % W, y = i / W;
@@ -1107,7 +1118,9 @@ __global__ __launch_bounds__(kBlock) void k_isg_update(int W, int H, int criteri
         }
         if (v + s > 0) r = v / (v + s);
     }
-    vsp[i] = r;
+    if (vsp) vsp[i] = r;
+    // contribution estimate for guided RR (own stand-in): filtered mean of the samples' average radiance, 0 = none
+    if (contrib) contrib[i] = a[0] > 0 ? (a[1] + a[2]) / a[0] : 0.f;
 }
 
 }  // namespace
@@ -1135,6 +1148,7 @@ struct VspgRenderer {
     DScene *dscene = nullptr;
     float4 *film = nullptr;
     float *isg_stats = nullptr;
+    float *contrib = nullptr;     // guided RR: contribution estimate, W*H
     float *tr_rgb = nullptr;      // TrBuffer: W*H*3 running mean, W*H sample counts
     int32_t *tr_spp = nullptr;
     float *vsp = nullptr;
@@ -1329,6 +1343,9 @@ static std::vector<float> build_majorant_grid(const VspgMedium &m) {
 }
 
 static bool wants_guiding(const VspgIntegratorParams &p) {
+    return p.surfaceguiding || p.volumeguiding || (p.vspguiding && p.vspsecondaryguiding) || p.rrguiding;  // guided kernels
+}
+static bool wants_training(const VspgIntegratorParams &p) {  // the field is queried
     return p.surfaceguiding || p.volumeguiding || (p.vspguiding && p.vspsecondaryguiding);
 }
 
@@ -1380,7 +1397,6 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     if ((p->surfaceguiding || p->volumeguiding || p->vspsecondaryguiding) && p->maxdepth + 2 > 32)
         return fail(VSPG_ESCOPE, "guiding-cache training keeps at most 32 segment records per path (maxdepth <= 30)");
     if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
-    if (p->rrguiding) return fail(VSPG_ESCOPE, "rrguiding (guided Russian roulette) is outside the hot-path scope");
     if (scene->medium.type == VSPG_MEDIUM_GRID || scene->medium.type == VSPG_MEDIUM_NANOVDB) {
         const VspgMedium &m = scene->medium;
         if (m.nx <= 0 || m.ny <= 0 || m.nz <= 0 || !m.density) return fail(VSPG_EINVAL, "grid medium needs nx,ny,nz > 0 and a density array");
@@ -1433,6 +1449,8 @@ void vspg_integrator_params_default(VspgIntegratorParams *p) {
     p->vspsamplingmethod = VSPG_VSP_RESAMPLING;
     p->lightsampler = VSPG_LIGHTSAMPLER_BVH;
     p->guide_num_training_waves = 128;
+    p->surfacerrguiding = 1;
+    p->volumerrguiding = 1;
 }
 
 int vspg_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3], const float up[3], float fov_degrees,
@@ -1513,6 +1531,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     VspgRenderer *r = new VspgRenderer();
     r->scene = *scene;
     r->prm = *params;
+    if (r->prm.rrguiding) r->prm.minrrdepth = 1;  // guidedvolpathvspgintegrator.cpp:195-197
     r->cfg = *cfg;
     if (r->cfg.shard_count < 1) { r->cfg.shard_count = 1; r->cfg.shard_index = 0; }
     build_dscene(r->scene, r->prm, r->cfg, &r->hscene);
@@ -1575,6 +1594,12 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         CK(hipGetDeviceProperties(&prop, cfg->device));
         r->num_cus = prop.multiProcessorCount;
     }
+    if (r->prm.rrguiding) {
+        CK(hipMalloc(&r->contrib, r->npix * sizeof(float)));
+        CK(hipMemset(r->contrib, 0, r->npix * sizeof(float)));
+        r->hscene.contrib = r->contrib;
+        CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
+    }
     // calculateTrBuffer (guidedvolpathvspgintegrator.cpp:190-193); trBufferLoad is vspg_renderer_set_tr_buffer
     if (r->prm.storeTrBuffer || (r->prm.vspguiding && r->prm.vspprimaryguiding && r->prm.vspsamplingmethod == VSPG_VSP_NDS &&
                                  r->prm.collisionProbabilityBias)) {
@@ -1590,7 +1615,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     // guideTraining (guidedvolpathvspgintegrator.cpp:109).  The reference also trains when only the guided-RR
     // flags are set (they default to true); this build trains iff the field will be queried.
     if (wants_guiding(r->prm)) {
-        r->training = true;
+        r->training = wants_training(r->prm);
         r->field_set = true;
         for (int f = 0; f < 2; ++f) {
             CK(hipMalloc(&r->fnodes[f], sizeof(VspgKdNode) * kTrainCapNodes));
@@ -1633,6 +1658,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->dscene) (void)hipFree(r->dscene);
     if (r->film) (void)hipFree(r->film);
     if (r->isg_stats) (void)hipFree(r->isg_stats);
+    if (r->contrib) (void)hipFree(r->contrib);
     if (r->tr_rgb) (void)hipFree(r->tr_rgb);
     if (r->tr_spp) (void)hipFree(r->tr_spp);
     if (r->vsp) (void)hipFree(r->vsp);
@@ -1840,13 +1866,20 @@ int vspg_post_process_wave(VspgRenderer *r, void *stream) {
         HIPCHK(hipMemsetAsync(r->train_counters, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));  // Clear() (:248)
     }
     if ((double)r->wave_counter == std::pow(2.0, (double)r->buffer_wave)) {
-        if (r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded) {  // calculateImageSpaceGuidingBuffer (:251)
+        const bool do_vsp = r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded;  // calculateImageSpaceGuidingBuffer (:251)
+        const bool do_contrib = r->prm.rrguiding != 0;  // cfg.EnableContributionEstimate(guideRR) (:164-168)
+        if (do_vsp || do_contrib) {
             HIPCHK(hipSetDevice(r->cfg.device));
             int blocks = (int)((r->npix + kBlock - 1) / kBlock);
             hipLaunchKernelGGL(k_isg_update, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, r->cfg.xres, r->cfg.yres,
-                               r->prm.vspcriterion, r->isg_stats, r->vsp);
+                               r->prm.vspcriterion, r->isg_stats, do_vsp ? r->vsp : nullptr, do_contrib ? r->contrib : nullptr);
             HIPCHK(hipGetLastError());
-            r->vsp_ready = 1;
+            if (do_vsp) r->vsp_ready = 1;
+            if (do_contrib && !r->hscene.contrib_ready) {
+                r->hscene.contrib_ready = 1;
+                HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(r->dscene) + offsetof(DScene, contrib_ready), &r->hscene.contrib_ready,
+                                      sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+            }
         }
         r->buffer_wave++;
     }

@@ -492,6 +492,10 @@ struct DScene {
     float *tr_rgb;
     int32_t *tr_spp;
     int32_t tr_calc, tr_load;
+    // guided Russian roulette: the image-space contribution estimate (one float per pixel, 0 = none; own stand-in for
+    // ImageSpaceGuidingBuffer::GetContributionEstimate), refreshed with the VSP buffer
+    const float *contrib;
+    int32_t contrib_ready;
 };
 // vsp_ready as handed to the path functions: bit 0 = the VSP buffer holds estimates; bit 1 = a debug path trace
 // (vspg_trace_paths), which does not feed the per-pixel buffers

@@ -170,6 +170,22 @@ struct IsgSample {
     float vsp_used;
 };
 
+// GuidedRussianRoulette(throughput, adjointEstimate, pixelContributionEstimate, minSurvival) is OpenPGL code (absent):
+// own definition (oracle/vspg_oracle.c:guided_russian_roulette), adjoint-driven in spirit -- the largest per-channel ratio of
+// throughput x adjoint to the pixel's contribution estimate, clamped to [minSurvival, 1]; no estimate -> 1.  Unpinned.
+// (adjointEstimate is 1 in the reference: OPENPGL_RADIANCE_CACHES is not defined; the estimate here is one value for
+// the three channels.)
+VDEV float guided_russian_roulette(Spec throughput, float reference, float minSurvival) {
+    if (!(reference > 0)) return 1.f;
+    float s = 0.f;
+    float q = throughput.r * 1.f / reference;
+    s = q > s ? q : s;
+    q = throughput.g * 1.f / reference;
+    s = q > s ? q : s;
+    q = throughput.b * 1.f / reference;
+    s = q > s ? q : s;
+    return fmin_(1.f, fmax_(minSurvival, s));
+}
 // StandardThroughputBasedRussianRoulette is OpenPGL code (absent from the reference tree):
 // pbrt's own rule, survival = clamp(maxComponent, 0, 1).  Unpinned, see DESIGN.md.
 VDEV float standard_throughput_rr(Spec w) { return fmin_(1.f, fmax_(0.f, maxc(w))); }
@@ -292,6 +308,8 @@ struct PathState {
     bool specularBounce, anyNonSpecularBounces, lastVertexVolume;
     float rr_correction, etaScale;
     float vsp0;  // primary-ray VSP of this pixel, loaded when the path starts (hides the HBM latency)
+    float pce;   // guided builds, rrguiding: the pixel's contribution estimate (0 = none); guideRR = rrguiding && buffer ready
+    bool guideRR;
     GuideState gs;  // guided builds only: the previous vertex's distribution for the secondary-ray VSP
 };
 
@@ -859,12 +877,18 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
     st.gs.vsp_next = -1.f;
     if (volume_vertex) {
         useGuiding = S.prm.volumeguiding ? gd.ok : false;
-        if (st.depth > S.prm.minrrdepth) {
-            Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction;
-            survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+        if (st.depth > S.prm.minrrdepth) {  // :817-830
+            if (st.guideRR) {
+                survivalProb = S.prm.volumerrguiding ? (st.specularBounce ? 0.95f : guided_russian_roulette(st.beta, st.pce, 0.1f)) : 1.f;
+            } else {
+                Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction;
+                survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
+            }
         }
     } else {
         useGuiding = S.prm.surfaceguiding ? gd.ok : false;
+        if (st.guideRR && st.depth > S.prm.minrrdepth)  // :465-472, BEFORE the NEE with the pre-bounce throughput
+            survivalProb = S.prm.surfacerrguiding ? (st.specularBounce ? 0.95f : guided_russian_roulette(st.beta, st.pce, 0.1f)) : 1.f;
     }
     if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {
         Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, useGuiding ? &gd : nullptr);
@@ -1051,7 +1075,7 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         st.ro = offset_ray_origin(intr.pi, si.n, wi);
         st.rd = wi;
         if (nonzero(st.beta)) {
-            if (st.depth > S.prm.minrrdepth) {
+            if (!st.guideRR && st.depth > S.prm.minrrdepth) {  // :597-600
                 Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;
                 survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
             }
@@ -1115,6 +1139,8 @@ VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, P
     st.rr_correction = 1.0f;
     st.etaScale = 1;
     st.gs.vsp_next = -1.f;
+    st.pce = 0.f;
+    st.guideRR = false;
     isg.valid = false;
     isg.surface_event = false;
     isg.vsp_used = -1.f;

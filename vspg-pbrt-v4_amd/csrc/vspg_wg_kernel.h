@@ -188,8 +188,12 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     isg.vsp_used = st.depth == 0 ? -1.f : v;
     if constexpr (GUIDED) {
         st.gs.vsp_next = P.f(PF_GS, slot);
+        st.pce = 0.f;        // (guided RR is served by the per-lane kernels)
+        st.guideRR = false;
     } else {
         st.gs.vsp_next = -1.f;
+        st.pce = 0.f;
+        st.guideRR = false;
     }
     return fl;
 }

@@ -47,8 +47,11 @@ int main() {
     vspg_scene_fog_box(&scene, 16, 16);
     CHECK(throws([&] { Integrator::Create("path", ParameterDictionary(), scene, 16, 16, 1); }));
     CHECK(throws([&] { Integrator::Create("guidedvolpath", ParameterDictionary(), scene, 16, 16, 1); }));
-    // out-of-scope options are refused loudly, before any device work
-    CHECK(throws([&] { Integrator::Create("guidedvolpathvspg", ParameterDictionary().Bool("rrguiding", true), scene, 16, 16, 1); }));
+    // guided Russian roulette flags (guidedvolpathvspgintegrator.cpp:1314-1316)
+    {
+        VspgIntegratorParams rp = ParseIntegratorParams(ParameterDictionary().Bool("rrguiding", true).Bool("volumerrguiding", false));
+        CHECK(rp.rrguiding == 1 && rp.surfacerrguiding == 1 && rp.volumerrguiding == 0);
+    }
     // the reference's parameter-list text (what cmd/nanovdb2pbrt prints for a grid) -> GridMedium::Create
     {
         const char *txt = "  \"integer nx\" 2 \"integer ny\" [ 3 ] \"integer nz\" 1   # comment\n"

@@ -251,8 +251,8 @@ VspgIntegratorParams ParseIntegratorParams(const ParameterDictionary &parameters
     if (tr) *tr = ts;
     p.storeTrBuffer = ts.store;
     p.rrguiding = parameters.GetOneBool("rrguiding", false);
-    (void)parameters.GetOneBool("surfacerrguiding", true);
-    (void)parameters.GetOneBool("volumerrguiding", true);
+    p.surfacerrguiding = parameters.GetOneBool("surfacerrguiding", true);
+    p.volumerrguiding = parameters.GetOneBool("volumerrguiding", true);
     std::string ls = parameters.GetOneString("lightsampler", "bvh");
     if (ls == "uniform") p.lightsampler = VSPG_LIGHTSAMPLER_UNIFORM;
     else if (ls == "power") p.lightsampler = VSPG_LIGHTSAMPLER_POWER;
