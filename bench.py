@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 B_SEGMENT = 256                # 2 x 128 B SoA path state per segment
 B_PATH_FIXED = 32 + 4 + 40     # film RMW + primary-VSP read + ISG sample write
-PMC_PROFILE = "r01d_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
+PMC_PROFILE = "r01e_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
 
 
 class DevArray:
