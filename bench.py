@@ -3,26 +3,39 @@
 homogeneous-fog scene (BASELINE.json configs[1]).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+With N > 1 and no torch.distributed environment this process starts its own ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`) as a CHILD process -- before
+anything here has touched the GPU -- and relays rank 0's JSON line; started under
+torch.distributed.run it is one of the ranks.
 
 A step is one WAVE: one pass of the hot path (EvaluatePixelSample -> Li -> SampleDistance ->
 film.AddSample, then PostProcessWave) over one 1-spp batch of 1920x1080 = 2,073,600 camera
 paths per GPU.  With N GPUs every rank renders its own sample indices of the same frame
-(weak scaling: per-GPU work fixed), and the float film tiles are all-reduced over RCCL at frame
-end, inside the timed region.  Inputs (scene, film, VSP buffer) are resident in HBM before the
+(weak scaling: per-GPU work fixed); the image-space VSP statistics are all-reduced at the waves
+where the buffer updates (1, 2, 4, ... global waves) and the float film tiles at frame end, over
+RCCL, inside the timed region.  Inputs (scene, film, VSP buffer) are resident in HBM before the
 timed region starts.
 
 The JSON line carries
-  roofline     : dominant kernel (k_render_wave_wg) -- algorithmic bytes per launch (SURVEY.md 8d:
-                 256 B per path segment + 76 B per path) / mean launch duration measured with
-                 HIP events on the launch stream, against the 8 TB/s HBM peak.
+  roofline     : dominant kernel -- algorithmic bytes per launch (256 B per path
+                 segment + 76 B per path [+ 36 B per density query]) / mean launch duration measured
+                 with HIP events on the launch stream, against the 8 TB/s HBM peak.
   cpu_baseline : the CPU oracle (a port of the reference path; the reference itself cannot be
                  built) timed on this box's host cores on a bounded sample.
+  relmse       : the metric's second half -- the same waves rendered by the GPU path and by the
+                 CPU oracle at equal spp and seeds: relMSE, bit-identical pixel fraction, max abs
+                 difference, and the relMSE of each against a 16x-spp render (noise floor).
+  generic_instantiation : the same workload through the kernel instantiation a chromatic medium
+                 takes (no grey-spectrum / zero-null-coefficient specialisation), untimed for `value`.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +46,41 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 B_SEGMENT = 256                # 2 x 128 B SoA path state per segment
 B_PATH_FIXED = 32 + 4 + 40     # film RMW + primary-VSP read + ISG sample write
-PMC_PROFILE = "r01e_pmc_k_render_wave.json"  # scripts/gpu_profile.sh + scripts/summarize_profile.py
+B_DENSITY_QUERY = 36           # heterogeneous media: 8 voxels x 4 B + 4 B majorant per density query
+RELMSE_EPS = 1e-4              # mean (I_gpu - I_cpu)^2 / (I_cpu^2 + eps)
+
+
+def csrc_hash():
+    """Identity of the kernel sources a PMC summary was taken on (profiles/*_pmc_*.json carry it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vspg-pbrt-v4_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".h", ".hip")) or n == "Makefile":
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_bytes(workload, W, H):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary of
+    this same command taken on THESE kernel sources (profiles/*_pmc_<workload>.json, written by
+    scripts/summarize_profile.py with the source hash); None when the sources have changed since."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for n in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not (n.endswith(".json") and "_pmc_" in n):
+            continue
+        try:
+            pmc = json.load(open(os.path.join(pdir, n)))
+        except Exception:
+            continue
+        if pmc.get("_csrc_hash") != csrc_hash() or pmc.get("_workload", "fog") != workload or pmc.get("_res", [1920, 1080]) != [W, H]:
+            continue
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # gfx950 correction of the microarch guide: FETCH_SIZE tallies 128-B read requests at 64 B -> x2;
+            # WRITE_SIZE is exact for 16-B-per-lane and dword stores.  Both KiB per launch.
+            best = (2.0 * pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+    return best
 
 
 class DevArray:
@@ -56,8 +103,9 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("VSPG_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(pkg, scene, prm, W, H, budget_s=15.0):
-    """Oracle timed on the host cores over a bounded sample of the same workload."""
+def cpu_baseline(pkg, scene, prm, W, H, budget_s=15.0, min_waves=4):
+    """Oracle timed on the host cores over a bounded sample of the same workload.  Returns the
+    baseline record, the oracle's film after those waves and the wave count (for the relMSE leg)."""
     import oracle_lib
 
     cpu = oracle_lib.OracleRenderer(scene, prm, W, H)
@@ -67,7 +115,8 @@ def cpu_baseline(pkg, scene, prm, W, H, budget_s=15.0):
     cpu.post_process_wave()
     t1 = time.perf_counter() - t0
     waves = 1
-    extra = int(max(0.0, min(budget_s, 30.0) - t1) / max(t1, 1e-3))
+    extra = max(min_waves - 1, int(max(0.0, min(budget_s, 30.0) - t1) / max(t1, 1e-3)))
+    extra = min(extra, 63)
     if extra > 0:
         t0 = time.perf_counter()
         for w in range(1, 1 + extra):
@@ -76,28 +125,86 @@ def cpu_baseline(pkg, scene, prm, W, H, budget_s=15.0):
         t1 += time.perf_counter() - t0
         waves += extra
     paths = cpu.counters()["paths"]
+    film = cpu.film()
     cpu.close()
-    return {"value": paths / t1 / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
-            "sample": "%d full-frame 1-spp waves of %dx%d (%d paths) in %.1f s, OpenMP over 16x16 tiles" % (waves, W, H, paths, t1)}
+    rec = {"value": paths / t1 / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+           "sample": "%d full-frame 1-spp waves of %dx%d (%d paths) in %.1f s, OpenMP over 16x16 tiles" % (waves, W, H, paths, t1)}
+    return rec, film, waves
 
 
-def main():
+def film_image(f):
+    import numpy as np
+    w = np.maximum(f[..., 3:4], 1e-30)
+    return (f[..., :3] / w).astype(np.float64)
+
+
+def relmse_leg(pkg, scene, prm, W, H, cpu_film, waves, device, torch):
+    """relMSE vs the CPU oracle at equal spp on identical seeds (untimed), plus the relMSE of both
+    against a 16x-spp render of an independent seed (the noise floor that separates bias from noise)."""
+    import numpy as np
+
+    g = pkg.Renderer(scene, prm, W, H, spp=waves, seed=0, device=device)
+    for w in range(waves):
+        g.render_wave(w, w + 1)
+        g.post_process_wave()
+    gf = g.film()
+    g.close()
+    ig, ic = film_image(gf), film_image(cpu_film)
+    rel = (ig - ic) ** 2 / (ic ** 2 + RELMSE_EPS)
+    same = np.all(gf == cpu_film, axis=-1)
+    t = pkg.Renderer(scene, prm, W, H, spp=16 * waves, seed=7919, device=device)
+    for w in range(16 * waves):
+        t.render_wave(w, w + 1)
+        t.post_process_wave()
+    it = film_image(t.film())
+    t.close()
+    return {"value": float(rel.mean()), "spp": waves, "bit_identical_pixel_frac": float(same.mean()),
+            "max_abs_diff": float(np.abs(ig - ic).max()), "eps": RELMSE_EPS,
+            "vs": "CPU oracle (port of the reference path), same seeds, float film on both sides",
+            "vs_16x_truth": {"gpu": float(((ig - it) ** 2 / (it ** 2 + RELMSE_EPS)).mean()),
+                             "cpu": float(((ic - it) ** 2 / (it ** 2 + RELMSE_EPS)).mean()),
+                             "truth": "GPU path, %d spp, independent seed" % (16 * waves)}}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--xres", type=int, default=1920)
     ap.add_argument("--yres", type=int, default=1080)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["fog", "cloud", "cloud-nvdb"], default="fog",
-                    help="fog = BASELINE.json's metric workload (default); cloud = procedural heterogeneous GridMedium (configs 3-4 stand-in); "
-                         "cloud-nvdb = the same grid with NanoVDBMedium semantics (64^3 majorants)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline and relmse legs")
+    ap.add_argument("--no-generic", action="store_true", help="skip the generic-instantiation leg")
+    ap.add_argument("--workload", choices=["fog", "fog-guided", "cloud", "cloud-nvdb"], default="fog",
+                    help="fog = BASELINE.json's metric workload (default); fog-guided = the same scene with the reference's DEFAULT "
+                         "integrator options (directional guiding + secondary-ray VSP: cache query in the loop; the field trains "
+                         "in-loop during untimed waves, reported separately); cloud = procedural heterogeneous GridMedium "
+                         "(configs 3-4 stand-in); cloud-nvdb = the same grid with NanoVDBMedium semantics (64^3 majorants)")
     ap.add_argument("--diag-maxdepth", type=int, default=None,
                     help="DIAGNOSTIC ONLY (not the benchmark config): override maxdepth to time parts of the path")
-    ap.add_argument("--diag-guiding", action="store_true",
-                    help="DIAGNOSTIC ONLY: the reference's default guiding options (field trained during the warm-up waves)")
+    ap.add_argument("--train-waves", type=int, default=16, help="fog-guided: in-loop training waves before the timed region")
     ap.add_argument("--grid", type=int, default=256, help="voxels per axis of the cloud workload's density grid")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: start the ranks as a child process.  Nothing in this process has touched
+        # the GPU yet (no torch import, no HIP call), and it never will: it only relays the child's exit code.
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -107,7 +214,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -122,28 +229,41 @@ def main():
     sh = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(sh)
     W, H = args.xres, args.yres
-    scene = (pkg.fog_box_scene(W, H) if args.workload == "fog" else pkg.cloud_box_scene(W, H, args.grid) if args.workload == "cloud"
+    fog = args.workload in ("fog", "fog-guided")
+    guided = args.workload == "fog-guided"
+    scene = (pkg.fog_box_scene(W, H) if fog else pkg.cloud_box_scene(W, H, args.grid) if args.workload == "cloud"
              else pkg.nanovdb_box_scene(W, H, args.grid))
     prm = pkg.app_f_params()
     if args.diag_maxdepth is not None:
         prm.maxdepth = args.diag_maxdepth
-    if args.diag_guiding:
-        prm = pkg.default_params()
-        prm.guide_num_training_waves = max(1, args.warmup)
-    r = pkg.Renderer(scene, prm, W, H, spp=args.steps * world, seed=0, shard_index=rank, shard_count=world,
-                     device=local_rank)
+    if guided:
+        prm = pkg.default_params()  # GuidedVolPathVSPGIntegrator::Create defaults (:1263-1319)
+        prm.guide_num_training_waves = max(1, args.train_waves)
+    total_waves = (args.warmup + args.steps + (args.train_waves if guided else 0)) * world
+    r = pkg.Renderer(scene, prm, W, H, spp=total_waves, seed=0, shard_index=rank, shard_count=world, device=local_rank)
     fptr, fn = r.film_ptr()
     film = torch.as_tensor(DevArray(fptr, fn), device=torch.device("cuda", local_rank))
+    sync = sh.ShardSync(dist, r, world, torch, device=torch.device("cuda", local_rank))
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
         # global waves [i*world, (i+1)*world): this rank runs exactly the one with w % world == rank
         w0, w1 = sh.step_wave_range(i, world)
         r.render_wave(w0, w1, stream)
-        r.post_process_wave(stream)
+        sync.post_process_step(stream)
 
+    train_ms = None
+    step0 = 0
+    if guided:  # in-loop training (guideTraining, :109, :230-248): timed on its own, never part of `value`
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.train_waves):
+            step(i)
+        torch.cuda.synchronize()
+        train_ms = (time.perf_counter() - t0) / max(1, args.train_waves) * 1e3
+        step0 = args.train_waves
     for i in range(args.warmup):
-        step(i)
+        step(step0 + i)
     # untimed: first use of the communicator at the film's size (RCCL sets up channels / buffers lazily)
     sh.frame_end_allreduce(dist, film, world)
     torch.cuda.synchronize()
@@ -158,10 +278,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        w0, w1 = sh.step_wave_range(args.warmup + i, world)
+        w0, w1 = sh.step_wave_range(step0 + args.warmup + i, world)
         r.render_wave(w0, w1, stream)
         ev[i][1].record()
-        r.post_process_wave(stream)
+        sync.post_process_step(stream)
     sh.frame_end_allreduce(dist, film, world)  # frame-end film all-reduce over RCCL / xGMI
     torch.cuda.synchronize()
     if world > 1:
@@ -175,29 +295,29 @@ def main():
     paths_rank = cnt["paths"]
     segs_rank = cnt["segments"]
     paths_total, segs_total = sh.sum_over_ranks(dist, [paths_rank, segs_rank], world, "cuda")
+    kernel_name = r.kernel_name()
+    r.close()
 
     if rank == 0:
-        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same
-        # command (profiles/<PMC_PROFILE>; FETCH_SIZE and WRITE_SIZE are separate passes, KiB per
-        # launch).  gfx950 correction of the microarch guide: FETCH_SIZE tallies 128-B read requests
-        # at 64 B, so it is doubled (the kernel's reads are 16-B-per-lane film / ISG records, 4-B
-        # spill reloads and scalar loads; for the narrow ones the factor is an upper bound);
-        # WRITE_SIZE is exact for 16-B-per-lane stores (film / ISG records) and dword stores (spills).
-        traffic_gbs, traffic_bytes = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
-            if W == 1920 and H == 1080 and args.workload == "fog":
-                traffic_bytes = (2.0 * pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-        except Exception:
-            pass
+        traffic_bytes = pmc_traffic_bytes(args.workload, W, H)
         kbar = segs_rank / max(1, paths_rank)
-        # heterogeneous media add 36 B per density query (8 voxels + 1 majorant)
-        dq_rank = cnt["density_queries"] if args.workload != "fog" else 0
-        bytes_per_launch = (segs_rank * B_SEGMENT + paths_rank * B_PATH_FIXED + dq_rank * 36) / max(1, args.steps)
+        dq_rank = cnt["density_queries"] if not fog else 0
+        bytes_per_launch = (segs_rank * B_SEGMENT + paths_rank * B_PATH_FIXED + dq_rank * B_DENSITY_QUERY) / max(1, args.steps)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        diag = args.diag_maxdepth is not None
+        if args.workload == "fog":
+            metric = "Mpaths/sec on 1920x1080 homogeneous fog; relMSE vs CPU ref at equal spp"
+            wl = "fog-box %dx%d, guidedvolpathvspg vspguiding=true (primary-ray VSP; App. F options)" % (W, H)
+        elif guided:
+            metric = "Mpaths/sec on 1920x1080 homogeneous fog, reference-default integrator options (not BASELINE.json's metric configuration)"
+            wl = ("fog-box %dx%d, guidedvolpathvspg with the reference's default options (surface RIS + volume MIS guiding, "
+                  "primary + secondary VSP), field trained in-loop for %d waves before the timed region" % (W, H, args.train_waves))
+        else:
+            metric = "Mpaths/sec on a procedural %d^3 cloud grid (not BASELINE.json's metric workload)" % args.grid
+            wl = "cloud-box %dx%d, %s %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
+                W, H, "GridMedium" if args.workload == "cloud" else "NanoVDBMedium (brick layout, 64^3 majorants)", args.grid)
         out = {
-            "metric": "Mpaths/sec on 1920x1080 homogeneous fog; relMSE vs CPU ref at equal spp" if args.workload == "fog"
-                      else "Mpaths/sec on a procedural %d^3 cloud grid (not BASELINE.json's metric workload)" % args.grid,
+            "metric": metric,
             "value": paths_total / elapsed / 1e6,
             "unit": "Mpaths/s",
             "n_gpus": world,
@@ -209,25 +329,57 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("fog-box %dx%d" % (W, H) if args.workload == "fog" else
-                                    "cloud-box %dx%d, %s %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
-                                        W, H, "GridMedium" if args.workload == "cloud" else "NanoVDBMedium (dense copy, 64^3 majorants)", args.grid)) +
-                                   ", guidedvolpathvspg vspguiding=true (primary-ray VSP), 1 spp per step per GPU, "
-                                   "independent sampler seed 0, maxdepth %d%s" % (prm.maxdepth, "" if args.diag_maxdepth is None and not args.diag_guiding else " (DIAGNOSTIC override)"),
+            "config": {"workload": wl + ", 1 spp per step per GPU, independent sampler seed 0, maxdepth %d%s" % (
+                           prm.maxdepth, " (DIAGNOSTIC override)" if diag else ""),
                        "paths_per_step_per_gpu": W * H, "mean_segments_per_path": kbar,
-                       "parallelism": "sample-index sharding x%d, film all-reduce at frame end" % world},
+                       "parallelism": "sample-index sharding x%d, VSP statistics all-reduced at buffer updates, film all-reduce at frame end" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic_bytes / (kern_ms * 1e-3) / 1e9) if traffic_bytes and kern_ms > 0 else None,
                          "traffic_bytes_per_launch": traffic_bytes,
-                         "kernel": "k_render_wave_wg" if args.workload == "fog" and not args.diag_guiding and os.environ.get("VSPG_KERNEL") != "lane"
-                                   else "k_render_wave", "kernel_ms": kern_ms, "density_queries_per_path": dq_rank / max(1, paths_rank),
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "density_queries_per_path": dq_rank / max(1, paths_rank),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time: the path state lives in LDS, so this is a notional "
+                                 "rate; traffic = measured HBM bytes (PMC FETCH_SIZE x2 + WRITE_SIZE) of the committed profile taken on "
+                                 "these kernel sources, null when the sources changed since"},
         }
+        if train_ms is not None:
+            out["training"] = {"waves": args.train_waves, "ms_per_wave": train_ms,
+                               "note": "render with segment recording + PropagateSamples + Field::Update, host-timed, untimed for value"}
+        if args.workload == "fog" and not args.no_generic and world == 1 and not diag:
+            # the instantiation a chromatic medium takes: every specialisation off, same scene, same results
+            for k in ("VSPG_NO_GREY", "VSPG_NO_GREY_KD", "VSPG_NO_NULLZERO"):
+                os.environ[k] = "1"
+            g = pkg.Renderer(scene, prm, W, H, spp=args.warmup + 16, seed=0, device=local_rank)
+            for k in ("VSPG_NO_GREY", "VSPG_NO_GREY_KD", "VSPG_NO_NULLZERO"):
+                del os.environ[k]
+            for i in range(args.warmup):
+                g.render_wave(i, i + 1, stream)
+                g.post_process_wave(stream)
+            g.reset_counters(stream)
+            gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(16)]
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for i in range(16):
+                gev[i][0].record()
+                g.render_wave(args.warmup + i, args.warmup + i + 1, stream)
+                gev[i][1].record()
+                g.post_process_wave(stream)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            out["generic_instantiation"] = {"value": g.counters()["paths"] / tg / 1e6, "unit": "Mpaths/s", "steps": 16,
+                                            "kernel_ms": sum(a.elapsed_time(b) for a, b in gev) / 16, "kernel": g.kernel_name(),
+                                            "note": "same scene through the instantiation a chromatic medium / coloured walls take"}
+            g.close()
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg, scene, prm, W, H)
+            # the relMSE leg needs the same waves on both sides: at least 4 spp (training waves would make the oracle
+            # side minutes long for fog-guided: that workload reports cpu_baseline on its untrained first waves only)
+            rec, cpu_film, waves = cpu_baseline(pkg, scene, prm if not guided else pkg.app_f_params(), W, H)
+            out["cpu_baseline"] = rec
+            if not guided:
+                out["relmse"] = relmse_leg(pkg, scene, prm, W, H, cpu_film, waves, local_rank, torch)
         print(json.dumps(out))
-    r.close()
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -215,6 +215,10 @@ typedef struct VspgTrainStats {
     uint64_t n_samples;    /* radiance samples recorded since the last update */
     uint64_t n_zero;       /* zero-valued samples dropped since the last update */
     int32_t n_nodes[2], n_regions[2];  /* [0] surface field, [1] volume field */
+    uint64_t n_dropped;    /* samples beyond the sample buffer's capacity (xres*yres*(maxdepth+1), at most 2^26) since the
+                            * last update: a training vspg_render_wave() over SEVERAL sample indices runs them as 1-spp
+                            * launches into one buffer that the single following vspg_post_process_wave() consumes --
+                            * call render_wave / post_process_wave per sample index (the reference's waves) to lose none */
 } VspgTrainStats;
 
 typedef struct VspgRenderer VspgRenderer; /* opaque */
@@ -260,6 +264,22 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
  * (guidedvolpathvspgintegrator.cpp:230-260): waveCounter++, image-space VSP buffer update
  * when waveCounter == 2^bufferWave.  Asynchronous on `stream`. */
 int vspg_post_process_wave(VspgRenderer *r, void *stream);
+
+/* The same after a STEP that covered n_waves sample indices -- a sharded render: every rank runs its own
+ * sample index of the step, then all ranks post-process with n_waves = the number of ranks.  waveCounter += n_waves;
+ * the image-space buffer update runs on the step that takes waveCounter to or past 2^bufferWave (n_waves = 1: exactly
+ * the reference's schedule, :251).  isg_stats_sum: DEVICE pointer to W*H*VSPG_ISG_STATS floats holding the SUM over
+ * all ranks of the per-rank statistics (vspg_isg_stats_device_ptr, all-reduced by the caller -- only needed when
+ * vspg_isg_update_due() says the update falls on this step), or NULL to use the renderer's own.  The renderer's own
+ * statistics are never overwritten, so nothing is counted twice.  N ranks stepping this way compute what ONE renderer
+ * computes that renders [w, w + N) per step and post-processes with n_waves = N (up to float summation order of the
+ * statistics).  vspg_post_process_wave(r, s) == vspg_post_process_step(r, 1, NULL, s). */
+int vspg_isg_update_due(VspgRenderer *r, int n_waves);
+int vspg_post_process_step(VspgRenderer *r, int n_waves, const float *isg_stats_sum, void *stream);
+
+/* Name of the kernel instantiation vspg_render_wave launches for this renderer as it stands (bench / profile
+ * bookkeeping; static storage). */
+const char *vspg_renderer_kernel_name(VspgRenderer *r);
 
 /* Film access.  The film is W*H float4 {sum w*r, sum w*g, sum w*b, sum w} in HBM
  * (the accumulate contract of RGBFilm::AddSample, src/pbrt/film.h:251-267, in float).

@@ -2312,7 +2312,7 @@ static void propagate_samples(OracleRenderer *r, const pathrec_t *rec) {
             r->samples = (VspgTrainSample *)realloc(r->samples, nc * sizeof(VspgTrainSample));
             r->cap_samples = nc;
         }
-        memcpy(r->samples + r->n_samples, out, (size_t)n_out * sizeof(VspgTrainSample));
+        if (n_out > 0) memcpy(r->samples + r->n_samples, out, (size_t)n_out * sizeof(VspgTrainSample));
         r->n_samples += (size_t)n_out;
         r->n_zero_samples += (uint64_t)n_zero;
     }
@@ -2686,12 +2686,23 @@ int oracle_render_wave(OracleRenderer *r, int wave_start, int wave_end, int nthr
  * training branch: field_update above); VSP buffer update at waveCounter == 2^bufferWave.
  * Update() = 5x5 box filter over the sufficient statistics, then the criterion (own design). */
 #define ISG_FILTER_RADIUS 2
-int oracle_post_process_wave(OracleRenderer *r) {
-    r->wave_counter++;
+static int isg_update_due(const OracleRenderer *r, int n_waves) {
+    return (double)(r->wave_counter + n_waves) >= pow(2.0, (double)r->buffer_wave);
+}
+int oracle_isg_update_due(OracleRenderer *r, int n_waves) {
+    const int do_vsp = r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded;
+    return (do_vsp || r->prm.rrguiding) && isg_update_due(r, n_waves);
+}
+/* PostProcessWave after a step of n_waves sample indices (a sharded render: n_waves = ranks); stats_sum = the statistics
+ * summed over all ranks, or NULL for the renderer's own.  n_waves = 1, NULL: the reference's schedule (:251). */
+int oracle_post_process_step(OracleRenderer *r, int n_waves, const float *stats_sum) {
+    const int due = isg_update_due(r, n_waves);
+    const float *stats = stats_sum ? stats_sum : r->isg_stats;
+    r->wave_counter += n_waves;
     if (r->training) field_update(r); /* :234-246 */
     r->n_samples = 0;                 /* guiding_sampleStorage->Clear() (:248) */
     r->n_zero_samples = 0;
-    if ((double)r->wave_counter == pow(2.0, (double)r->buffer_wave)) {
+    if (due) {
         int W = r->cfg.xres, H = r->cfg.yres;
         const int do_vsp = r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded;
         const int do_contrib = r->prm.rrguiding != 0; /* cfg.EnableContributionEstimate(guideRR) (:164-168) */
@@ -2703,7 +2714,7 @@ int oracle_post_process_wave(OracleRenderer *r) {
                         for (int dx = -ISG_FILTER_RADIUS; dx <= ISG_FILTER_RADIUS; ++dx) {
                             int xx = x + dx, yy = y + dy;
                             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-                            const float *st = &r->isg_stats[((size_t)yy * W + xx) * VSPG_ISG_STATS];
+                            const float *st = &stats[((size_t)yy * W + xx) * VSPG_ISG_STATS];
                             for (int k = 0; k < 5; ++k) a[k] += st[k];
                         }
                     if (do_vsp) {
@@ -2732,10 +2743,12 @@ int oracle_post_process_wave(OracleRenderer *r) {
             if (do_vsp) r->vsp_ready = 1;
             if (do_contrib) r->contrib_ready = 1;
         }
-        r->buffer_wave++;
+        while (pow(2.0, (double)r->buffer_wave) <= (double)r->wave_counter) r->buffer_wave++;
     }
     return 0;
 }
+int oracle_post_process_wave(OracleRenderer *r) { return oracle_post_process_step(r, 1, NULL); }
+
 
 /* ------------------------------------------------------------------------------------ */
 /* life cycle + accessors                                                                 */

@@ -14,10 +14,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    # VSPG_ORACLE_SO=liboracle_asan.so: the sanitizer build (scripts/run_sanitized_cpu_tests.sh)
+    target = os.environ.get("VSPG_ORACLE_SO", "liboracle.so")
+    so = os.path.join(ROOT, "oracle", target)
     src = os.path.join(ROOT, "oracle", "vspg_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), target])
     P = load_package()
     lib = C.CDLL(so)
     p, vp, f3 = C.POINTER, C.c_void_p, P.f3
@@ -47,6 +49,8 @@ def load():
         "oracle_render_wave": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "oracle_render_window": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
         "oracle_post_process_wave": (C.c_int, [vp]),
+        "oracle_isg_update_due": (C.c_int, [vp, C.c_int]),
+        "oracle_post_process_step": (C.c_int, [vp, C.c_int, p(C.c_float)]),
         "oracle_film_read": (None, [vp, p(C.c_float)]),
         "oracle_film_read_f64": (None, [vp, p(C.c_double)]),
         "oracle_film_clear": (None, [vp]),
@@ -129,6 +133,21 @@ class OracleRenderer:
 
     def post_process_wave(self):
         assert self.lib.oracle_post_process_wave(self.h) == 0
+
+    def isg_update_due(self, n_waves=1):
+        return bool(self.lib.oracle_isg_update_due(self.h, int(n_waves)))
+
+    def post_process_step(self, n_waves, stats_sum=None):
+        """stats_sum: torch / numpy float32 array of the all-reduced statistics, or None."""
+        ptr = None
+        if stats_sum is not None:
+            a = stats_sum.numpy() if hasattr(stats_sum, "numpy") else np.asarray(stats_sum)
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.size == self.xres * self.yres * self.P.VSPG_ISG_STATS
+            ptr = a.ctypes.data_as(C.POINTER(C.c_float))
+        assert self.lib.oracle_post_process_step(self.h, int(n_waves), ptr) == 0
+
+    def isg_stats_tensor(self, torch):
+        return torch.from_numpy(self.isg_stats().reshape(-1))
 
     def film(self):
         out = np.empty((self.yres, self.xres, 4), dtype=np.float32)

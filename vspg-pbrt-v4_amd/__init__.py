@@ -88,11 +88,12 @@ class VspgTrainSample(C.Structure):
 
 class VspgTrainStats(C.Structure):
     _fields_ = [("training", C.c_int32), ("iteration", C.c_int32), ("n_samples", C.c_uint64), ("n_zero", C.c_uint64),
-                ("n_nodes", C.c_int32 * 2), ("n_regions", C.c_int32 * 2)]
+                ("n_nodes", C.c_int32 * 2), ("n_regions", C.c_int32 * 2), ("n_dropped", C.c_uint64)]
 
     def as_dict(self):
         return {"training": int(self.training), "iteration": int(self.iteration), "n_samples": int(self.n_samples),
-                "n_zero": int(self.n_zero), "n_nodes": list(self.n_nodes), "n_regions": list(self.n_regions)}
+                "n_zero": int(self.n_zero), "n_nodes": list(self.n_nodes), "n_regions": list(self.n_regions),
+                "n_dropped": int(self.n_dropped)}
 
 
 TRAIN_SAMPLE_DTYPE = [("p", "<f4", 3), ("dir", "<f4", 3), ("weight", "<f4"), ("pdf", "<f4"), ("distance", "<f4"),
@@ -141,6 +142,9 @@ SYMBOLS = [
     ("vspg_renderer_destroy", C.c_int, [_vp]),
     ("vspg_render_wave", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     ("vspg_post_process_wave", C.c_int, [_vp, _vp]),
+    ("vspg_isg_update_due", C.c_int, [_vp, C.c_int]),
+    ("vspg_post_process_step", C.c_int, [_vp, C.c_int, _vp, _vp]),
+    ("vspg_renderer_kernel_name", C.c_char_p, [_vp]),
     ("vspg_film_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("vspg_film_read", C.c_int, [_vp, _P(C.c_float), _vp]),
     ("vspg_film_clear", C.c_int, [_vp, _vp]),
@@ -300,6 +304,17 @@ class Renderer:
 
     def render_wave(self, w0, w1, stream=None):
         _check(self.lib, self.lib.vspg_render_wave(self.h, w0, w1, _vp(stream or 0)))
+
+    def isg_update_due(self, n_waves=1):
+        return bool(self.lib.vspg_isg_update_due(self.h, int(n_waves)))
+
+    def post_process_step(self, n_waves, isg_stats_sum_ptr=None, stream=None):
+        """PostProcessWave after a step of n_waves sample indices; isg_stats_sum_ptr = device pointer (int) to the
+        all-reduced statistics or None."""
+        _check(self.lib, self.lib.vspg_post_process_step(self.h, int(n_waves), _vp(isg_stats_sum_ptr or 0), _vp(stream or 0)))
+
+    def kernel_name(self):
+        return (self.lib.vspg_renderer_kernel_name(self.h) or b"").decode()
 
     def post_process_wave(self, stream=None):
         _check(self.lib, self.lib.vspg_post_process_wave(self.h, _vp(stream or 0)))

@@ -1394,7 +1394,7 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         return fail(VSPG_EINVAL, "shard_index out of range");
     if (p->maxdepth < 0) return fail(VSPG_EINVAL, "maxdepth must be >= 0");
     if (p->maxdepth > 254) return fail(VSPG_EINVAL, "maxdepth above 254 (the path depth travels in 8 bits of the packed path flags)");
-    if ((p->surfaceguiding || p->volumeguiding || p->vspsecondaryguiding) && p->maxdepth + 2 > 32)
+    if (wants_training(*p) && p->maxdepth + 2 > 32)
         return fail(VSPG_ESCOPE, "guiding-cache training keeps at most 32 segment records per path (maxdepth <= 30)");
     if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
     if (scene->medium.type == VSPG_MEDIUM_GRID || scene->medium.type == VSPG_MEDIUM_NANOVDB) {
@@ -1631,6 +1631,10 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             r->hscene.field[f] = DField{1, 1, r->fnodes[f], r->fregions[f], r->faux[f]};
         }
         CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
+    }
+    // segment records, radiance samples and the update's scratch exist only for a renderer that trains (an
+    // rrguiding-only renderer queries nothing and records nothing)
+    if (r->training) {
         r->segbuf_items = (size_t)((cfg->xres + 7) / 8) * (size_t)((cfg->yres + 7) / 8) * 64;  // the work items of a 1-spp wave
         CK(hipMalloc(&r->segbuf, r->segbuf_items * (size_t)(r->prm.maxdepth + 2) * SG_FLOATS * sizeof(float)));
         CK(hipMalloc(&r->seg_count, r->segbuf_items * sizeof(int)));
@@ -1689,6 +1693,38 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     return 0;
 }
 
+// scheduler: "wg" = workgroup-level wavefront kernel, "lane" = per-lane persistent kernel.  Default: wg for
+// homogeneous media (dense, equally long phases); lane for grid media, whose tracking walks have very
+// different lengths per path -- a phase lasts as long as its longest walk, while the per-lane kernel
+// refills a lane the moment its path ends (measured on the 256^3 cloud stand-in: 30.5 vs 38.6 ms per wave)
+// -- and for guided builds.  VSPG_KERNEL=wg|lane overrides (unguided builds only).
+static bool uses_wg_kernel(const VspgRenderer *r) {
+    const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
+    const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
+    const bool guided = wants_guiding(r->prm);
+    const char *kenv = getenv("VSPG_KERNEL");
+    const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
+    // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
+    return !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
+}
+const char *vspg_renderer_kernel_name(VspgRenderer *r) {
+    if (!r) return "";
+    const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
+    const bool guided = wants_guiding(r->prm);
+    if (uses_wg_kernel(r)) {
+        if (grid) return "k_render_wave_wg<GridMedium>";
+        if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg<HomogeneousMediumT<2,true>>";
+        if (r->medium_grey && r->surfaces_grey) return "k_render_wave_wg<HomogeneousMediumT<2,false>>";
+        if (r->medium_grey) return "k_render_wave_wg<HomogeneousMediumT<1,false>>";
+        return "k_render_wave_wg<HomogeneousMediumT<0,false>>";
+    }
+    const bool train = guided && r->training;
+    if (nvdb) return guided ? (train ? "k_render_wave<NanoDenseMedium,guided,train>" : "k_render_wave<NanoDenseMedium,guided>") : "k_render_wave<NanoDenseMedium>";
+    if (grid) return guided ? (train ? "k_render_wave<GridMedium,guided,train>" : "k_render_wave<GridMedium,guided>")
+                            : (r->medium_grey ? "k_render_wave<GridMediumGrey>" : "k_render_wave<GridMedium>");
+    return guided ? (train ? "k_render_wave<HomogeneousMedium,guided,train>" : "k_render_wave<HomogeneousMedium,guided>") : "k_render_wave<HomogeneousMedium>";
+}
+
 int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream) {
     if (!r) return fail(VSPG_EINVAL, "null renderer");
     if (wave_end < wave_start || wave_start < 0) return fail(VSPG_EINVAL, "bad wave range");
@@ -1743,15 +1779,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                                r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_start, wave_end, first,        \
                                n_samples == 1 ? 1 : 0, jump, static_per_wave, dyn_base, work_head, r->counters, targs); \
     } while (0)
-    // scheduler: "wg" = workgroup-level wavefront kernel, "lane" = per-lane persistent kernel.  Default: wg for
-    // homogeneous media (dense, equally long phases); lane for grid media, whose tracking walks have very
-    // different lengths per path -- a phase lasts as long as its longest walk, while the per-lane kernel
-    // refills a lane the moment its path ends (measured on the 256^3 cloud stand-in: 30.5 vs 38.6 ms per wave)
-    // -- and for guided builds.  VSPG_KERNEL=wg|lane overrides (unguided builds only).
-    const char *kenv = getenv("VSPG_KERNEL");
-    const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
-    // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
-    const bool use_wg = !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
+    const bool use_wg = uses_wg_kernel(r);
     if (use_wg) {
         const unsigned tiles_magic = tilesX > 1 ? (unsigned)((0x100000000ull + (unsigned)tilesX - 1) / (unsigned)tilesX) : 0u;
         const int wwaves = grid ? kWgWavesGrid : kWgWavesHomog, wblock = grid ? kWgBlockGrid : kWgBlockHomog;
@@ -1853,10 +1881,23 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
     return 0;
 }
 
-int vspg_post_process_wave(VspgRenderer *r, void *stream) {
-    // PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260)
+// The image-space buffer update falls on the step that takes the wave counter to (or past) 2^bufferWave; with one
+// wave per step this is the reference's `waveCounter == pow(2, bufferWave)` (:251).
+static bool isg_update_due(const VspgRenderer *r, int n_waves) {
+    return (double)(r->wave_counter + n_waves) >= std::pow(2.0, (double)r->buffer_wave);
+}
+int vspg_isg_update_due(VspgRenderer *r, int n_waves) {
+    if (!r || n_waves < 1) return 0;
+    const bool do_vsp = r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded;
+    return (do_vsp || r->prm.rrguiding) && isg_update_due(r, n_waves) ? 1 : 0;
+}
+
+int vspg_post_process_step(VspgRenderer *r, int n_waves, const float *isg_stats_sum, void *stream) {
+    // PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260) after a step that covered n_waves sample indices
     if (!r) return fail(VSPG_EINVAL, "null renderer");
-    r->wave_counter++;
+    if (n_waves < 1) return fail(VSPG_EINVAL, "n_waves must be >= 1");
+    const bool due = isg_update_due(r, n_waves);
+    r->wave_counter += n_waves;
     if (r->train_counters) {
         HIPCHK(hipSetDevice(r->cfg.device));
         if (r->training) {
@@ -1865,14 +1906,15 @@ int vspg_post_process_wave(VspgRenderer *r, void *stream) {
         }
         HIPCHK(hipMemsetAsync(r->train_counters, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));  // Clear() (:248)
     }
-    if ((double)r->wave_counter == std::pow(2.0, (double)r->buffer_wave)) {
+    if (due) {
         const bool do_vsp = r->prm.vspguiding && r->prm.vspprimaryguiding && !r->vsp_loaded;  // calculateImageSpaceGuidingBuffer (:251)
         const bool do_contrib = r->prm.rrguiding != 0;  // cfg.EnableContributionEstimate(guideRR) (:164-168)
         if (do_vsp || do_contrib) {
             HIPCHK(hipSetDevice(r->cfg.device));
             int blocks = (int)((r->npix + kBlock - 1) / kBlock);
             hipLaunchKernelGGL(k_isg_update, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, r->cfg.xres, r->cfg.yres,
-                               r->prm.vspcriterion, r->isg_stats, do_vsp ? r->vsp : nullptr, do_contrib ? r->contrib : nullptr);
+                               r->prm.vspcriterion, isg_stats_sum ? isg_stats_sum : r->isg_stats, do_vsp ? r->vsp : nullptr,
+                               do_contrib ? r->contrib : nullptr);
             HIPCHK(hipGetLastError());
             if (do_vsp) r->vsp_ready = 1;
             if (do_contrib && !r->hscene.contrib_ready) {
@@ -1881,10 +1923,11 @@ int vspg_post_process_wave(VspgRenderer *r, void *stream) {
                                       sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
             }
         }
-        r->buffer_wave++;
+        while (std::pow(2.0, (double)r->buffer_wave) <= (double)r->wave_counter) r->buffer_wave++;
     }
     return 0;
 }
+int vspg_post_process_wave(VspgRenderer *r, void *stream) { return vspg_post_process_step(r, 1, nullptr, stream); }
 
 int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
     if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
@@ -2205,6 +2248,7 @@ int vspg_renderer_training_stats(VspgRenderer *r, VspgTrainStats *out, void *str
         HIPCHK(hipStreamSynchronize(s));
         out->n_samples = cnt[0];
         out->n_zero = cnt[1];
+        out->n_dropped = cnt[0] > r->sample_capacity ? cnt[0] - r->sample_capacity : 0;
         DScene h;
         HIPCHK(hipMemcpyAsync(&h, r->dscene, sizeof h, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -21,7 +21,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define VSPG_HD __host__ __device__ __forceinline__
 #if defined(__HIP_DEVICE_COMPILE__)
 #define VSPG_LIBM_OUT_OF_SCOPE(expr) __builtin_nanf("")

@@ -305,15 +305,27 @@ GuidedVolPathVSPGIntegrator::GuidedVolPathVSPGIntegrator(const VspgIntegratorPar
     cfg.shard_index = 0; cfg.shard_count = 1; cfg.device = device;
     int rc = vspg_renderer_create(&scene, &params, &cfg, &renderer);
     if (rc != 0) throw Error(std::string("GuidedVolPathVSPGIntegrator: ") + vspg_last_error());
-    if (cacheSettings.load) {  // :117-122: a loaded cache is used as is, guideTraining = false
-        GuidingCache gc = GuidingCache::Read(cacheSettings.fileName);
-        VspgField f[2];
-        for (int i = 0; i < 2; ++i)
-            f[i] = VspgField{(int32_t)gc.nodes[i].size(), (int32_t)gc.regions[i].size(), gc.nodes[i].data(), gc.regions[i].data()};
-        if (vspg_renderer_set_guiding_field(renderer, &f[0], &f[1], nullptr) != 0) {
-            std::string msg = vspg_last_error();
-            vspg_renderer_destroy(renderer);
-            throw Error("GuidedVolPathVSPGIntegrator: loading \"" + cacheSettings.fileName + "\": " + msg);
+    if (cacheSettings.load) {  // :116-125: FileExists() ? load (guideTraining = false) : warn and train a fresh field
+        std::FILE *probe = std::fopen(cacheSettings.fileName.c_str(), "rb");
+        if (!probe) {
+            std::fprintf(stderr, "Warning: guiding cache file does not exists: guidingCacheFileName = %s\n", cacheSettings.fileName.c_str());
+        } else {
+            std::fclose(probe);
+            std::string msg;
+            try {
+                GuidingCache gc = GuidingCache::Read(cacheSettings.fileName);
+                VspgField f[2];
+                for (int i = 0; i < 2; ++i)
+                    f[i] = VspgField{(int32_t)gc.nodes[i].size(), (int32_t)gc.regions[i].size(), gc.nodes[i].data(), gc.regions[i].data()};
+                if (vspg_renderer_set_guiding_field(renderer, &f[0], &f[1], nullptr) != 0) msg = vspg_last_error();
+            } catch (const std::exception &e) {  // corrupt / truncated file: the renderer exists already, release it
+                msg = e.what();
+            }
+            if (!msg.empty()) {
+                vspg_renderer_destroy(renderer);
+                renderer = nullptr;
+                throw Error("GuidedVolPathVSPGIntegrator: loading \"" + cacheSettings.fileName + "\": " + msg);
+            }
         }
     }
     if (isgSettings.load) {  // :151-159: a missing file is a warning, the buffer is then estimated in-loop as usual

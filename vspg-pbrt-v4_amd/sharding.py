@@ -36,3 +36,53 @@ def sum_over_ranks(dist, values, world, device):
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(v) for v in t.tolist()]
+
+
+class ShardSync:
+    """Cross-rank state of a sharded render: the image-space VSP statistics.
+
+    Every rank accumulates the statistics of its own sample indices; on the steps where the buffer
+    update falls (the global wave counter reaches 1, 2, 4, ... -- `isg_update_due`) the per-rank
+    statistics are summed over the ranks into a scratch tensor and every rank runs the update on
+    the SUM (`post_process_step(world, sum)`), so all ranks hold the buffer ONE renderer would hold
+    that renders `world` sample indices per step (up to float summation order).  The renderer's own
+    statistics are left as they are: nothing is counted twice.  `renderer` is anything with the
+    C-ABI's `isg_update_due / post_process_step / isg_stats_tensor` contract: the HIP renderer
+    (bench.py, RCCL) or the CPU oracle (tests, gloo)."""
+
+    def __init__(self, dist, renderer, world, torch, device=None):
+        self.dist, self.r, self.world, self.torch, self.device = dist, renderer, world, torch, device
+        self._stats = None
+        self._sum = None
+
+    def _stats_tensor(self):
+        if hasattr(self.r, "isg_stats_tensor"):       # CPU oracle: a fresh host copy per call
+            return self.r.isg_stats_tensor(self.torch)
+        if self._stats is None:                       # HIP renderer: wrap the device pointer once (no copy)
+            if True:
+                ptr, n = self.r.isg_stats_ptr()
+
+                class _Dev:
+                    __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+                self._stats = self.torch.as_tensor(_Dev(), device=self.device)
+        return self._stats
+
+    def post_process_step(self, stream=None):
+        if self.world <= 1:
+            if hasattr(self.r, "isg_stats_tensor"):
+                self.r.post_process_step(1, None)
+            else:
+                self.r.post_process_step(1, None, stream)
+            return
+        total = None
+        if self.r.isg_update_due(self.world):
+            st = self._stats_tensor()
+            if self._sum is None:
+                self._sum = self.torch.empty_like(st)
+            self._sum.copy_(st)
+            self.dist.all_reduce(self._sum, op=self.dist.ReduceOp.SUM)
+            total = self._sum
+        if hasattr(self.r, "isg_stats_tensor"):
+            self.r.post_process_step(self.world, total)
+        else:
+            self.r.post_process_step(self.world, total.data_ptr() if total is not None else None, stream)
