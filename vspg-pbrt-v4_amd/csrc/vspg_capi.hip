@@ -14,6 +14,7 @@
 
 #include "vspg_path.h"
 #include "vspg_wg_kernel.h"
+#include "vspg_wavefront.h"
 
 using namespace vspg;
 
@@ -1087,6 +1088,44 @@ __global__ __launch_bounds__(kBlock) void k_libm_log1m(int n, const float *__res
     out[i] = neg_log1m_d(x[i]);
 }
 
+// ---- octet bricks (DScene::brick_index / octets) built on the device from the uploaded raw samples -------------------
+// brick (bx, by, bz) covers the octets of base voxels [8b - 1, 8b + 6]^3, i.e. raw voxels [8b - 1, 8b + 7]^3
+__device__ __forceinline__ float raw_at(const float *d, int nx, int ny, int nz, int x, int y, int z) {
+    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
+    return d[((size_t)z * ny + y) * nx + x];
+}
+__global__ __launch_bounds__(kBlock) void k_brick_flags(const float *__restrict__ d, int nx, int ny, int nz, int bnx, int bny,
+                                                        int32_t *__restrict__ flags) {
+    const int b = blockIdx.x;
+    const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    bool any = false;
+    for (int i = threadIdx.x; i < 9 * 9 * 9; i += kBlock) {
+        const int x = 8 * bx - 1 + i % 9, y = 8 * by - 1 + (i / 9) % 9, z = 8 * bz - 1 + i / 81;
+        any = any || raw_at(d, nx, ny, nz, x, y, z) != 0.f;
+    }
+    if (any) s_any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) flags[b] = s_any;
+}
+__global__ __launch_bounds__(512) void k_brick_fill(const float *__restrict__ d, int nx, int ny, int nz, int bnx, int bny,
+                                                    const int32_t *__restrict__ active /* brick number of slot */, float4 *__restrict__ octets) {
+    const int b = active[blockIdx.x];
+    const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
+    const int l = threadIdx.x, lx = l & 7, ly = (l >> 3) & 7, lz = l >> 6;
+    const int ix = 8 * bx + lx - 1, iy = 8 * by + ly - 1, iz = 8 * bz + lz - 1;  // base voxel of this octet
+    float4 lo, hi;
+    lo.x = raw_at(d, nx, ny, nz, ix, iy, iz);         lo.y = raw_at(d, nx, ny, nz, ix + 1, iy, iz);
+    lo.z = raw_at(d, nx, ny, nz, ix, iy + 1, iz);     lo.w = raw_at(d, nx, ny, nz, ix + 1, iy + 1, iz);
+    hi.x = raw_at(d, nx, ny, nz, ix, iy, iz + 1);     hi.y = raw_at(d, nx, ny, nz, ix + 1, iy, iz + 1);
+    hi.z = raw_at(d, nx, ny, nz, ix, iy + 1, iz + 1); hi.w = raw_at(d, nx, ny, nz, ix + 1, iy + 1, iz + 1);
+    float4 *q = octets + ((size_t)blockIdx.x * 512u + (size_t)l) * 2u;
+    q[0] = lo;
+    q[1] = hi;
+}
+
 // ImageSpaceGuidingBuffer::Update stand-in: 5x5 box filter over the sufficient statistics,
 // then the contribution / variance criterion (own design, unpinned).
 constexpr int kIsgRadius = 2;
@@ -1177,9 +1216,17 @@ struct VspgRenderer {
     int *train_reg = nullptr;                 // region of every sample of the batch (field being updated)
     unsigned int *train_order = nullptr;      // sample indices sorted by region
     unsigned int *train_hist = nullptr, *train_cursor = nullptr, *train_nsorted = nullptr;
-    float *density = nullptr;   // GridMedium density samples
+    float *density = nullptr;   // GridMedium density samples (raw; released once the octet bricks are built)
+    int32_t *brick_index = nullptr;
+    float4 *octets = nullptr;
+    size_t n_bricks = 0;
     float *le_scale = nullptr;  // emissive GridMedium: LeScale grid
     float *majorant = nullptr;  // 16^3 majorant grid
+    // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
+    float *wf_pool = nullptr;
+    unsigned int *wf_lists = nullptr;   // 4 x n_items: active, vertex, walk, shadow
+    WfIter *wf_iters = nullptr;
+    size_t wf_items = 0;
     int num_cus = 0;
     int vsp_ready = 0;
     bool vsp_loaded = false;  // ImageSpaceGuidingBuffer(fileName): no further updates
@@ -1426,6 +1473,57 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     return 0;
 }
 
+// One pass of the wavefront pipeline: sample index `sample` of every pixel.
+template <class Medium>
+static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
+    const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
+    const size_t items = (size_t)tilesX * tilesY * 64;
+    const int n_iters = r->prm.maxdepth + 2;
+    if (!r->wf_pool || r->wf_items != items) {
+        if (r->wf_pool) (void)hipFree(r->wf_pool);
+        if (r->wf_lists) (void)hipFree(r->wf_lists);
+        if (r->wf_iters) (void)hipFree(r->wf_iters);
+        r->wf_pool = nullptr; r->wf_lists = nullptr; r->wf_iters = nullptr;
+        HIPCHK(hipMalloc(&r->wf_pool, (size_t)WF_COUNT * items * sizeof(float)));
+        HIPCHK(hipMalloc(&r->wf_lists, 4 * items * sizeof(unsigned int)));
+        HIPCHK(hipMalloc(&r->wf_iters, (size_t)n_iters * sizeof(WfIter)));
+        r->wf_items = items;
+    }
+    HIPCHK(hipMemsetAsync(r->wf_iters, 0, (size_t)n_iters * sizeof(WfIter), s));
+    WfArgs a;
+    a.scene = r->dscene;
+    a.P = WfPool{r->wf_pool, items};
+    a.film = r->film;
+    a.isg_stats = r->isg_stats;
+    a.vsp_buf = r->vsp;
+    a.vsp_ready = r->vsp_ready;
+    a.sample = sample;
+    a.jump = pcg_jump((unsigned long long)sample * 65536ull);
+    a.n_items = (unsigned)items;
+    a.tilesX = (unsigned)tilesX;
+    a.list_active = r->wf_lists;
+    a.list_vertex = r->wf_lists + items;
+    a.list_walk = r->wf_lists + 2 * items;
+    a.list_shadow = r->wf_lists + 3 * items;
+    a.iters = r->wf_iters;
+    a.counters = r->counters;
+    // persistent grids: the dense kernels stride over their list, the walk kernels pull jobs
+    const unsigned max_blocks = (unsigned)((items + kWfBlock - 1) / kWfBlock);
+    unsigned dense = (unsigned)r->num_cus * 8u, walk = (unsigned)r->num_cus * (unsigned)kWfWalkWavesPerSimd;
+    if (dense > max_blocks) dense = max_blocks;
+    unsigned swalk = (unsigned)r->num_cus * (unsigned)kWfShadowWavesPerSimd;
+    if (walk > max_blocks) walk = max_blocks;
+    if (swalk > max_blocks) swalk = max_blocks;
+    for (int it = 0; it <= r->prm.maxdepth; ++it) {
+        hipLaunchKernelGGL(k_wf_advance<Medium>, dim3(dense), dim3(kWfBlock), 0, s, a, it);
+        hipLaunchKernelGGL(k_wf_dist_walk<Medium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
+        hipLaunchKernelGGL(k_wf_seg_end<Medium>, dim3(dense), dim3(kWfBlock), 0, s, a, it);
+        if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<Medium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int vspg_abi_version(void) { return VSPG_ABI_VERSION; }
@@ -1561,8 +1659,43 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         CK(hipMemcpy(r->density, scene->medium.density, n * sizeof(float), hipMemcpyHostToDevice));
         CK(hipMalloc(&r->majorant, maj.size() * sizeof(float)));
         CK(hipMemcpy(r->majorant, maj.data(), maj.size() * sizeof(float), hipMemcpyHostToDevice));
-        r->hscene.density = r->density;
+        r->hscene.density = nullptr;
         r->hscene.majorant = r->majorant;
+        {   // octet bricks (see DScene): flags on the device, slot numbering on the host, fill on the device
+            const int nx = scene->medium.nx, ny = scene->medium.ny, nz = scene->medium.nz;
+            const int bnx = (nx + 1 + 7) / 8, bny = (ny + 1 + 7) / 8, bnz = (nz + 1 + 7) / 8;
+            const size_t nb = (size_t)bnx * bny * bnz;
+            int32_t *dflags = nullptr, *dactive = nullptr;
+            CK(hipMalloc(&dflags, nb * sizeof(int32_t)));
+            hipLaunchKernelGGL(k_brick_flags, dim3((unsigned)nb), dim3(kBlock), 0, 0, r->density, nx, ny, nz, bnx, bny, dflags);
+            std::vector<int32_t> flags(nb), index(nb), active;
+            hipError_t ef = hipMemcpy(flags.data(), dflags, nb * sizeof(int32_t), hipMemcpyDeviceToHost);
+            (void)hipFree(dflags);
+            CK(ef);
+            for (size_t b = 0; b < nb; ++b) {
+                index[b] = flags[b] ? (int32_t)active.size() : -1;
+                if (flags[b]) active.push_back((int32_t)b);
+            }
+            r->n_bricks = active.size();
+            CK(hipMalloc(&r->brick_index, nb * sizeof(int32_t)));
+            CK(hipMemcpy(r->brick_index, index.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice));
+            CK(hipMalloc(&r->octets, (r->n_bricks ? r->n_bricks : 1) * 512 * 2 * sizeof(float4)));
+            if (r->n_bricks) {
+                CK(hipMalloc(&dactive, r->n_bricks * sizeof(int32_t)));
+                hipError_t ea = hipMemcpy(dactive, active.data(), r->n_bricks * sizeof(int32_t), hipMemcpyHostToDevice);
+                if (ea == hipSuccess) {
+                    hipLaunchKernelGGL(k_brick_fill, dim3((unsigned)r->n_bricks), dim3(512), 0, 0, r->density, nx, ny, nz, bnx, bny, dactive, r->octets);
+                    ea = hipDeviceSynchronize();
+                }
+                (void)hipFree(dactive);
+                CK(ea);
+            }
+            (void)hipFree(r->density);  // the kernels read the bricks only
+            r->density = nullptr;
+            r->hscene.brick_index = r->brick_index;
+            r->hscene.octets = r->octets;
+            r->hscene.bnx = bnx; r->hscene.bny = bny; r->hscene.bnz = bnz;
+        }
         r->scene.medium.density = nullptr;  // the host array belongs to the caller
         const VspgMedium &m = scene->medium;
         if (m.type == VSPG_MEDIUM_GRID && (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0)) {  // isEmissive (media.cpp:250)
@@ -1686,7 +1819,12 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_hist) (void)hipFree(r->train_hist);
     if (r->train_cursor) (void)hipFree(r->train_cursor);
     if (r->train_nsorted) (void)hipFree(r->train_nsorted);
+    if (r->wf_pool) (void)hipFree(r->wf_pool);
+    if (r->wf_lists) (void)hipFree(r->wf_lists);
+    if (r->wf_iters) (void)hipFree(r->wf_iters);
     if (r->density) (void)hipFree(r->density);
+    if (r->brick_index) (void)hipFree(r->brick_index);
+    if (r->octets) (void)hipFree(r->octets);
     if (r->le_scale) (void)hipFree(r->le_scale);
     if (r->majorant) (void)hipFree(r->majorant);
     delete r;
@@ -1707,10 +1845,20 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
     // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
     return !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
 }
+// "wf" = the multi-kernel wavefront pipeline (vspg_wavefront.h): heterogeneous media whose every segment runs the
+// resampling routine (the reference's default vspsamplingmethod), unguided.  Default for those; VSPG_KERNEL=lane|wg
+// selects the single-kernel schedulers instead (kept for the guided / NDS configurations and as cross-checks).
+static bool uses_wf_pipeline(const VspgRenderer *r) {
+    const bool het = r->scene.medium.type == VSPG_MEDIUM_GRID || r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
+    const char *kenv = getenv("VSPG_KERNEL");
+    if (kenv && strcmp(kenv, "wf") != 0) return false;
+    return het && !wants_guiding(r->prm) && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
+}
 const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (!r) return "";
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
+    if (uses_wf_pipeline(r)) return nvdb ? "k_wf_dist_walk<NanoDenseMedium>" : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
     if (uses_wg_kernel(r)) {
         if (grid) return "k_render_wave_wg<GridMedium>";
         if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg<HomogeneousMediumT<2,true>>";
@@ -1751,6 +1899,15 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but the renderer holds no guiding field");
+    if (uses_wf_pipeline(r)) {  // one pass per sample index of this shard, in order
+        for (int w = first; w < wave_end; w += sc > 1 ? sc : 1) {
+            const int rc = nvdb ? wf_render_pass<NanoDenseMedium>(r, w, (hipStream_t)stream)
+                                : (r->medium_grey ? wf_render_pass<GridMediumGrey>(r, w, (hipStream_t)stream)
+                                                  : wf_render_pass<GridMedium>(r, w, (hipStream_t)stream));
+            if (rc) return rc;
+        }
+        return 0;
+    }
     // a18: while the field trains, the guided kernels record path segments and emit radiance samples
     const bool train = guided && r->training;
     TrainArgs targs = {nullptr, nullptr, nullptr, nullptr, 0, 0};

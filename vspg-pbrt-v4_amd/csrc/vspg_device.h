@@ -475,8 +475,18 @@ struct DScene {
     // majorant grid (media.cpp:252-269), both in HBM
     int32_t nx, ny, nz;
     float bounds_min[3], bounds_max[3];
-    const float *density;
+    const float *density;       // raw samples: only the brick build reads them (freed afterwards)
     const float *majorant;
+    // Device layout of the density grid ("octet bricks behind a coarse index"): the trilinear filter of a query needs the
+    // 2x2x2 voxels around it; as 8 scattered 4-byte loads from the raw array they cost ~4 cache lines (512 B of HBM /
+    // Infinity-Cache traffic per query -- the walk kernels ran at ~6 TB/s of it).  Here every base voxel (ix, iy, iz) in
+    // [-1, n-1]^3 owns an OCTET {v000, v100, v010, v110, v001, v101, v011, v111} (voxels outside the grid = 0, the
+    // reference's bounds checks baked in): a query is ONE aligned 32-byte fetch.  Octets are stored per 8x8x8 BRICK and
+    // only for bricks that hold a non-zero value; brick_index[bz][by][bx] is the brick's slot or -1 (all zero: no fetch).
+    // 8x the voxel bytes for the occupied part -- this part has 288 GB.  Same floats, same interpolation: same bits.
+    const int32_t *brick_index;
+    const float4 *octets;
+    int32_t bnx, bny, bnz;
     // NanoVDB-semantics dense medium: index bbox min, 1 / voxel_size, world position of index (0,0,0), density offset
     int32_t index_min[3];
     float inv_voxel[3], grid_origin[3], density_offset;
@@ -726,12 +736,17 @@ VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis
 template <bool NVDB, bool GREY = false>
 struct GridMediumT {
     static constexpr int kRes = NVDB ? kMajResNvdb : kMajRes;
+    // wavefront walk kernels: majorant-cell advances tried per tracking step before the collision code runs (a 64^3
+    // majorant grid has 4x as many cell crossings per tentative collision as the 16^3 one)
+    static constexpr int kAdvanceRounds = NVDB ? 3 : 1;
     static constexpr int kGrey = GREY ? 1 : 0;  // sigma_a, sigma_s built from one value each (see HomogeneousMediumT)
     Spec sigma_a, sigma_s;
     float g;
     int nx, ny, nz;
     V3 bmin, bmax;
-    const float *density;
+    const int32_t *brick_index;  // octet bricks (DScene)
+    const float4 *octets;
+    int bnx, bny;
     const float *majorant;  // HBM or the block's LDS copy
     int imx, imy, imz;      // NVDB: index bbox min
     V3 inv_voxel, origin;   // NVDB: worldToIndexF(p) = (p - origin) * inv_voxel
@@ -779,8 +794,34 @@ struct GridMediumT {
         if (bmax.z > bmin.z) o.z /= bmax.z - bmin.z;
         return o;
     }
-    VDEV float at(int x, int y, int z) const { return at(density, nx, ny, nz, x, y, z); }
-    VDEV float lookup(V3 p) const { return lookup(density, nx, ny, nz, p); }
+    // the octet of base voxel (ix, iy, iz): its 2x2x2 corner values (zeros outside the grid / in an empty brick)
+    struct Octet { float v000, v100, v010, v110, v001, v101, v011, v111; };
+    VDEV Octet octet(int ix, int iy, int iz) const {
+        const int ox = ix + 1, oy = iy + 1, oz = iz + 1;
+        Octet o{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ox <= (unsigned)nx && (unsigned)oy <= (unsigned)ny && (unsigned)oz <= (unsigned)nz) {
+            const int b = brick_index[((oz >> 3) * bny + (oy >> 3)) * bnx + (ox >> 3)];
+            if (b >= 0) {
+                const float4 *q = octets + ((size_t)b * 512u + (size_t)((ox & 7) + 8 * ((oy & 7) + 8 * (oz & 7)))) * 2u;
+                const float4 lo = q[0], hi = q[1];
+                o = Octet{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+        }
+        return o;
+    }
+    VDEV float lookup(V3 p) const {  // SampledGrid::Lookup(Point3f) (containers.h:804-819) over the octet of floor(p * n - .5)
+        float sx = p.x * nx - .5f, sy = p.y * ny - .5f, sz = p.z * nz - .5f;
+        float fx = __builtin_floorf(sx), fy = __builtin_floorf(sy), fz = __builtin_floorf(sz);
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        float dx = sx - (float)ix, dy = sy - (float)iy, dz = sz - (float)iz;
+        const Octet o = octet(ix, iy, iz);
+        float d00 = (1 - dx) * o.v000 + dx * o.v100;
+        float d10 = (1 - dx) * o.v010 + dx * o.v110;
+        float d01 = (1 - dx) * o.v001 + dx * o.v101;
+        float d11 = (1 - dx) * o.v011 + dx * o.v111;
+        float a = (1 - dy) * d00 + dy * d10, b = (1 - dy) * d01 + dy * d11;
+        return (1 - dz) * a + dz * b;
+    }
     static VDEV float at(const float *data, int nx, int ny, int nz, int x, int y, int z) {  // SampledGrid::Lookup(Point3i) (containers.h:830-835)
         if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
         return data[((size_t)z * ny + y) * nx + x];
@@ -801,16 +842,20 @@ struct GridMediumT {
         float a = (1 - dy) * d00 + dy * d10, b = (1 - dy) * d01 + dy * d11;
         return (1 - dz) * a + dz * b;
     }
-    VDEV Iter sample_ray(V3 o, V3 d, float raytMax) const {  // media.h:347-362
+    VDEV Iter empty_iter() const {  // default-constructed iterator: next() yields nothing
         Iter it;
         it.sigma_t = sigma_a + sigma_s;
         it.tMin = kInf;
-        it.tMax = -kInf;  // default-constructed iterator: next() yields nothing
+        it.tMax = -kInf;
         it.maj = majorant;
         it.ncx = it.ncy = it.ncz = 0;
         it.dtx = it.dty = it.dtz = 0;
         it.vx = it.vy = it.vz = 0;
         it.neg = 0;
+        return it;
+    }
+    VDEV Iter sample_ray(V3 o, V3 d, float raytMax) const {  // media.h:347-362
+        Iter it = empty_iter();
         // Transform::ApplyInverse(ray, &tMax), identity matrix (transform.h:416-429, transform.cpp:263-303):
         // the origin carries the error bound gamma(3)*|o| and is pushed along d by dt
         const float g3 = (3 * kMachineEps) / (1 - 3 * kMachineEps);
@@ -872,18 +917,14 @@ struct GridMediumT {
     }
     // nanovdb::SampleFromVoxels<Tree, 1, false> over the dense copy: ijk = floor(x), uvw = x - ijk, corner values
     // with background 0, lerp(a, b, w) = a + w (b - a) along z, then y, then x
-    VDEV float at_index(int i, int j, int k) const {
-        const int x = i - imx, y = j - imy, z = k - imz;
-        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
-        return density[((size_t)z * ny + y) * nx + x];
-    }
     VDEV float lookup_index(V3 x) const {
         const float fx = __builtin_floorf(x.x), fy = __builtin_floorf(x.y), fz = __builtin_floorf(x.z);
-        const int i = (int)fx, j = (int)fy, k = (int)fz;
+        // a query far outside the grid must not wrap the int conversion into the valid range: clamp (any such octet is zero)
+        const float cx = fmax_(fmin_(fx, 1e9f), -1e9f), cy = fmax_(fmin_(fy, 1e9f), -1e9f), cz = fmax_(fmin_(fz, 1e9f), -1e9f);
+        const int i = (int)cx, j = (int)cy, k = (int)cz;
         const float u = x.x - fx, v = x.y - fy, w = x.z - fz;
-        const float v000 = at_index(i, j, k), v001 = at_index(i, j, k + 1), v010 = at_index(i, j + 1, k), v011 = at_index(i, j + 1, k + 1);
-        const float v100 = at_index(i + 1, j, k), v101 = at_index(i + 1, j, k + 1), v110 = at_index(i + 1, j + 1, k),
-                    v111 = at_index(i + 1, j + 1, k + 1);
+        const Octet o = octet(i - imx, j - imy, k - imz);  // accessor.getValue: background 0 outside the index bounding box
+        const float v000 = o.v000, v001 = o.v001, v010 = o.v010, v011 = o.v011, v100 = o.v100, v101 = o.v101, v110 = o.v110, v111 = o.v111;
         const float a00 = v000 + w * (v001 - v000), a01 = v010 + w * (v011 - v010);
         const float a10 = v100 + w * (v101 - v100), a11 = v110 + w * (v111 - v110);
         const float b0 = a00 + v * (a01 - a00), b1 = a10 + v * (a11 - a10);
@@ -918,7 +959,7 @@ using GridMediumGrey = GridMediumT<false, true>;
 using NanoDenseMedium = GridMediumT<true>;
 template <bool NVDB, bool GREY>
 VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
-    return GridMediumT<NVDB, GREY>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.density,
+    return GridMediumT<NVDB, GREY>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
                              majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
                              S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le)};
 }

@@ -1,0 +1,984 @@
+// vspg_wavefront.h -- multi-kernel wavefront pipeline for heterogeneous media (gfx950).
+//
+// A tracking walk through a grid medium visits every tentative collision of its ray, and the rays of a frame have wildly
+// different collision counts (0 for a ray that misses the cloud, tens through its core).  Inside one kernel that keeps a
+// path in a lane (k_render_wave) or a segment in a lane (k_render_wave_wg) a wavefront lasts as long as its longest
+// walk: 18 % of the vector lanes did useful work on the 256^3 cloud (round 1, profiles/r01_pmc_wave_state_cloud.txt).
+//
+// Here the frame's paths live in HBM as a field-major SoA (one column per pixel of the wave: this part has 288 GB, the
+// ~400 B per path of a 4K wave are 3.3 GB) and every path-loop iteration (:309-609) is cut at its two walks:
+//
+//   k_wf_advance     dense   vertex end of the previous iteration (NEE result, Russian roulette, new direction :842-874 /
+//                            :487-606) fused with the next segment's begin (scene intersection, RNG seeding :323-325, the
+//                            resampling routine's majorant pre-pass, media_sampleTMaj.h:150-176); survivors are compacted
+//                            into the next list with a wave ballot + prefix count + one atomic per wavefront
+//   k_wf_dist_walk   WALK    SampleT_maj_Resampling's traversal + the reservoir callback (:691-719) -- one JOB per path
+//   k_wf_seg_end     dense   candidate selection (:721-771), surface emission / depth test (:350-412), vertex setup, the
+//                            NEE's light sample and shadow-ray set-up (:1136-1200)
+//   k_wf_shadow_walk WALK    the shadow ray's ratio-tracking transmittance (:1205-1232) -- one JOB per unoccluded NEE
+//
+// The WALK kernels are persistent: a lane runs one job at a time and a wavefront refills its idle lanes from the job
+// list once a quarter of them are idle (one returning atomic per 64 jobs), so the lanes of a wavefront are at DIFFERENT
+// jobs but always in the SAME loop -- one tracking step per iteration: majorant-cell advance, then the tentative-collision
+// draw, then the collision itself (8-voxel fetch + callback) for the lanes that drew one.  Path state crosses a kernel
+// boundary once per walk, as coalesced 4-byte-per-lane SoA accesses.
+//
+// Per path the operations and their order are those of li_segment_a / li_segment_b / sample_distance / sample_Ld /
+// sample_T_maj*: the film is bit-identical to the per-lane kernel's (and to the oracle's paths).
+#pragma once
+#include "vspg_path.h"
+#include "vspg_wg_kernel.h"  // flag bits, list_push
+
+namespace vspg {
+
+// ---- SoA record: field f of path slot s at base[f * n + s] -----------------------------------------------------
+enum {
+    WF_RO = 0,        // 3  ray origin
+    WF_RD = 3,        // 3  ray direction
+    WF_L = 6,         // 3
+    WF_BETA = 9,      // 3
+    WF_RU = 12,       // 3
+    WF_RL = 15,       // 3
+    WF_PCP = 18,      // 3  previous light-sample context: raw point
+    WF_PCQ = 21,      // 1  ... its rectangle, -1 = medium vertex
+    WF_RNG = 22,      // 4  sampler PCG state / inc
+    WF_FLAGS = 26,    // 1  packed like the LDS pool's (vspg_wg_kernel.h) + WFL_* bits
+    WF_RRC = 27,      // 1  rr_correction
+    WF_VSP = 28,      // 1  vsp0 (depth 0) / isg.vsp_used
+    WF_VXP = 29,      // 3  vertex position (surface: re-projected hit point; volume: selected candidate)
+    WF_VXG = 32,      // 1  surface: rectangle (int); volume: g
+    WF_VXT = 33,      // 1  surface tHit
+    // walk job (distance walk, later re-used by the shadow walk of the same iteration)
+    WF_IT = 34,       // 9  DDA iterator at the start of the ray: tMin, tMax, nextCrossingT[3], deltaT[3], packed voxel | step signs
+    WF_RDN = 43,      // 3  normalised direction
+    WF_WRNG = 46,     // 4  the walk's private PCG (:323-325 / :1193)
+    WF_WU = 50,       // 1  first uniform of the walk
+    WF_MSCALE = 51,   // 1  majorantScale
+    WF_VRC = 52,      // 1  vsp / (1 - exp(-tau)) (media_sampleTMaj.h:172)
+    WF_VSPG = 53,     // 1  the VSP the segment is guided with (-1: none)
+    // distance-walk result
+    WF_TMAJ = 54,     // 3
+    WF_WSUM = 57,     // 1  weightSum
+    WF_TRR = 58,      // 3  trRatioEst
+    WF_BRS = 61,      // 3  beta_rs
+    WF_RURS = 64,     // 3  r_u_rs
+    WF_SELP = 67,     // 3  selected candidate: position
+    WF_SELW = 70,     // 1  ... its weight (0: none selected)
+    WF_SELNUM = 71,   // 3
+    WF_SELDEN = 74,   // 3
+    // shadow job / result
+    WF_SLO = 77,      // 3  shadow-ray origin
+    WF_FHAT = 80,     // 3  f_hat
+    WF_LSL = 83,      // 3  ls.L
+    WF_PL = 86,       // 1  p_l
+    WF_SPDF = 87,     // 1  scatterPDF
+    WF_SURV = 88,     // 1  survivalProb of the vertex
+    WF_TRAY = 89,     // 3  shadow result: T_ray
+    WF_SRL = 92,      // 3  ... r_l
+    WF_SRU = 95,      // 3  ... r_u
+    WF_STMAJ = 98,    // 3  ... residual T_maj
+    WF_COUNT = 101
+};
+enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
+    WFL_NODIST = 1 << 20,    // no SampleDistance this segment (no medium / the ray escapes)
+    WFL_NOWALK = 1 << 21,    // the resampling routine returned before its traversal (tau == 0)
+    WFL_GUIDE = 1 << 22,     // the segment is VSP-guided
+    WFL_SHADOW_WALK = 1 << 23,   // NEE: a ratio-tracking walk was queued
+    WFL_SHADOW_CLEAR = 1 << 24,  // NEE: contributes without a walk (T_ray = 1)
+    WFL_HIT = 1 << 25,       // the segment's ray hit a surface
+    WFL_NEE = 1 << 26,       // SampleLd ran at the vertex (its result is added even when it is zero, :483 / :836)
+};
+
+struct WfPool {
+    float *base;
+    size_t n;
+    VDEV float &f(int field, unsigned slot) const { return base[(size_t)field * n + slot]; }
+    VDEV int &i(int field, unsigned slot) const { return reinterpret_cast<int *>(base)[(size_t)field * n + slot]; }
+    VDEV uint32_t &u(int field, unsigned slot) const { return reinterpret_cast<uint32_t *>(base)[(size_t)field * n + slot]; }
+    VDEV V3 v3(int field, unsigned slot) const { return V3{f(field, slot), f(field + 1, slot), f(field + 2, slot)}; }
+    VDEV void set3(int field, unsigned slot, V3 v) const { f(field, slot) = v.x; f(field + 1, slot) = v.y; f(field + 2, slot) = v.z; }
+    VDEV Spec sp3(int field, unsigned slot) const { return Spec{f(field, slot), f(field + 1, slot), f(field + 2, slot)}; }
+    VDEV void sets(int field, unsigned slot, Spec v) const { f(field, slot) = v.r; f(field + 1, slot) = v.g; f(field + 2, slot) = v.b; }
+    VDEV void load_rng(int field, unsigned slot, Rng &r) const {
+        r.state = (uint64_t)u(field, slot) | ((uint64_t)u(field + 1, slot) << 32);
+        r.inc = (uint64_t)u(field + 2, slot) | ((uint64_t)u(field + 3, slot) << 32);
+    }
+    VDEV void store_rng(int field, unsigned slot, const Rng &r) const {
+        u(field, slot) = (uint32_t)r.state; u(field + 1, slot) = (uint32_t)(r.state >> 32);
+        u(field + 2, slot) = (uint32_t)r.inc; u(field + 3, slot) = (uint32_t)(r.inc >> 32);
+    }
+};
+
+// per-iteration control block (one per path-loop iteration, zeroed once per launch of the pipeline)
+struct WfIter {
+    unsigned int n_active;       // paths with a segment in this iteration (k_wf_advance -> k_wf_seg_end)
+    unsigned int n_vertex;       // paths standing at a vertex after it (k_wf_seg_end -> the next k_wf_advance)
+    unsigned int n_walk;         // distance-walk jobs
+    unsigned int n_shadow;       // shadow-walk jobs
+    unsigned int walk_head;      // job cursors of the two walk kernels
+    unsigned int shadow_head;
+    unsigned int pad[2];
+};
+struct WfArgs {
+    const DScene *scene;
+    WfPool P;
+    float4 *film;
+    float *isg_stats;
+    const float *vsp_buf;
+    int vsp_ready;
+    int sample;                  // the sample index this pass renders
+    PcgJump jump;                // PCG skip-ahead for sample * 65536
+    unsigned int n_items;        // tiles * 64
+    unsigned int tilesX;
+    unsigned int *list_active;   // slots with a segment in flight
+    unsigned int *list_vertex;   // slots standing at a vertex
+    unsigned int *list_walk;
+    unsigned int *list_shadow;
+    WfIter *iters;               // [maxdepth + 2]
+    unsigned long long *counters;
+};
+
+VDEV void wf_pixel_of(unsigned slot, unsigned tilesX, int *px, int *py) {
+    const unsigned tile = slot >> 6, l = slot & 63u;
+    const unsigned ty = tile / tilesX, tx = tile - ty * tilesX;
+    *px = (int)(tx * 8u + (l & 7u));
+    *py = (int)(ty * 8u + (l >> 3));
+}
+
+// Appending to a global list.  One returning atomic per WAVEFRONT on the list's counter is too many: a single hot
+// word serves ~88 returning atomics per microsecond on this chip, and a dense kernel over a 1080p wave would issue
+// 32 k of them per list (measured: 0.6-0.75 ms per dense kernel, all of it that).  So a workgroup stages the slots of
+// kWfStageRounds rounds in LDS (wave ballot + prefix count + one LDS atomic per wavefront) and flushes them with ONE
+// global atomic.  List order is irrelevant: every path's result depends on its own state only.
+constexpr int kWfStageRounds = 4;
+struct WfStage {
+    unsigned int *buf;   // LDS, kWfStageRounds * block entries
+    unsigned int *cnt;   // LDS
+    VDEV void push(bool pred, unsigned slot) const {
+        const unsigned long long m = __ballot(pred);
+        if (m == 0ull) return;
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(cnt, (unsigned int)__popcll(m));
+        base = __shfl(base, leader);
+        if (pred) buf[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+    }
+    // every thread of the workgroup calls this (two barriers)
+    VDEV void flush(unsigned int *list, unsigned int *gcount, unsigned int *s_base) const {
+        __syncthreads();
+        const unsigned int c = *cnt;
+        if (threadIdx.x == 0 && c) *s_base = atomicAdd(gcount, c);
+        __syncthreads();
+        const unsigned int b = *s_base;
+        for (unsigned int i = threadIdx.x; i < c; i += blockDim.x) list[b + i] = buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) *cnt = 0;
+    }
+};
+
+template <int GREY>
+VDEV void wf_store_path(const WfPool &P, unsigned slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
+                        uint32_t extra_flags) {
+    P.set3(WF_RO, slot, st.ro);
+    P.set3(WF_RD, slot, st.rd);
+    P.sets(WF_L, slot, st.L);
+    P.sets(WF_BETA, slot, st.beta);
+    if constexpr (GREY >= 1) {
+        P.f(WF_RU, slot) = st.r_u.r;
+        P.f(WF_RL, slot) = st.r_l.r;
+    } else {
+        P.sets(WF_RU, slot, st.r_u);
+        P.sets(WF_RL, slot, st.r_l);
+    }
+    P.set3(WF_PCP, slot, st.prevCtx.p);
+    P.i(WF_PCQ, slot) = st.prevCtx.quad;
+    P.store_rng(WF_RNG, slot, sampler.rng);
+    P.u(WF_FLAGS, slot) = pool_pack_flags(st, ch, isg, extra_flags);
+    P.f(WF_RRC, slot) = st.rr_correction;
+    P.f(WF_VSP, slot) = isg.vsp_used;  // (the pixel's primary VSP itself is consumed by the first segment's begin)
+}
+template <int GREY>
+VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sampler &sampler, int *ch, IsgSample &isg) {
+    st.ro = P.v3(WF_RO, slot);
+    st.rd = P.v3(WF_RD, slot);
+    st.L = P.sp3(WF_L, slot);
+    st.beta = P.sp3(WF_BETA, slot);
+    if constexpr (GREY >= 1) {
+        st.r_u = sp(P.f(WF_RU, slot));
+        st.r_l = sp(P.f(WF_RL, slot));
+    } else {
+        st.r_u = P.sp3(WF_RU, slot);
+        st.r_l = P.sp3(WF_RL, slot);
+    }
+    st.prevCtx.p = P.v3(WF_PCP, slot);
+    st.prevCtx.quad = P.i(WF_PCQ, slot);
+    P.load_rng(WF_RNG, slot, sampler.rng);
+    const uint32_t fl = P.u(WF_FLAGS, slot);
+    st.depth = (int)(fl & FL_DEPTH_MASK);
+    *ch = (int)((fl >> FL_CH_SHIFT) & 3u);
+    st.specularBounce = (fl & FL_SPECULAR) != 0;
+    st.anyNonSpecularBounces = false;
+    st.lastVertexVolume = (fl & FL_LASTVOL) != 0;
+    isg.valid = (fl & FL_ISG_VALID) != 0;
+    isg.surface_event = (fl & FL_ISG_SURF) != 0;
+    st.rr_correction = P.f(WF_RRC, slot);
+    st.etaScale = 1;
+    isg.vsp_used = P.f(WF_VSP, slot);
+    st.vsp0 = isg.vsp_used;
+    st.gs.vsp_next = -1.f;
+    st.pce = 0.f;
+    st.guideRR = false;
+    return fl;
+}
+
+// DDA iterator <-> 9 dwords
+template <class Iter>
+VDEV void wf_store_iter(const WfPool &P, unsigned slot, const Iter &it) {
+    P.f(WF_IT + 0, slot) = it.tMin; P.f(WF_IT + 1, slot) = it.tMax;
+    P.f(WF_IT + 2, slot) = it.ncx; P.f(WF_IT + 3, slot) = it.ncy; P.f(WF_IT + 4, slot) = it.ncz;
+    P.f(WF_IT + 5, slot) = it.dtx; P.f(WF_IT + 6, slot) = it.dty; P.f(WF_IT + 7, slot) = it.dtz;
+    P.u(WF_IT + 8, slot) = (uint32_t)it.vx | ((uint32_t)it.vy << 7) | ((uint32_t)it.vz << 14) | ((uint32_t)it.neg << 21);
+}
+template <class Medium>
+VDEV typename Medium::Iter wf_load_iter(const WfPool &P, unsigned slot, const Medium &medium) {
+    typename Medium::Iter it = medium.empty_iter();
+    it.tMin = P.f(WF_IT + 0, slot); it.tMax = P.f(WF_IT + 1, slot);
+    it.ncx = P.f(WF_IT + 2, slot); it.ncy = P.f(WF_IT + 3, slot); it.ncz = P.f(WF_IT + 4, slot);
+    it.dtx = P.f(WF_IT + 5, slot); it.dty = P.f(WF_IT + 6, slot); it.dtz = P.f(WF_IT + 7, slot);
+    const uint32_t pk = P.u(WF_IT + 8, slot);
+    it.vx = (int)(pk & 127u); it.vy = (int)((pk >> 7) & 127u); it.vz = (int)((pk >> 14) & 127u); it.neg = (int)(pk >> 21);
+    return it;
+}
+
+// a finished path: RGBFilm::AddSample + the image-space statistics.  The pipeline renders ONE sample per pixel per
+// pass, so nobody else touches the pixel: plain read-modify-write (film_add_sample_rmw).
+VDEV void wf_finish_path(const WfArgs &a, unsigned slot, const PathState &st, const IsgSample &isg) {
+    int px, py;
+    wf_pixel_of(slot, a.tilesX, &px, &py);
+    const size_t pidx = (size_t)py * a.scene->xres + px;
+    const Spec L = finish_radiance(st.L);
+    film_add_sample_rmw(a.film + pidx, L);
+    isg_add_sample_rmw(a.isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+}
+
+// ---- a15 cut at the shadow walk: SampleLd up to the transmittance estimate (:1136-1204) ... ------------------------
+struct ShadowSetup {
+    int status;  // 0: no contribution; 1: ratio-tracking walk needed; 2: contributes with T_ray = 1 (no medium on the way)
+    Spec f_hat, L;
+    float p_l, scatterPDF;
+    V3 lo, ld;
+    Rng rng;
+    float us;
+};
+template <class PC>
+VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *bsdf, Sampler &sampler, PC &pc) {
+    ShadowSetup r;
+    r.status = 0;
+    r.f_hat = r.L = sp(0.f);
+    r.p_l = r.scatterPDF = r.us = 0.f;
+    r.lo = r.ld = mk(0, 0, 0);
+    r.rng.state = r.rng.inc = 0;
+    V3 ctxp = intr.pi.mid();
+    if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
+    float u = sampler.get1d();
+    bool have_light = S.n_lights > 0;
+    int lightIndex = 0;
+    float lightPmf = 0;
+    if (have_light) {  // UniformLightSampler::Sample (lightsamplers.h:33-38)
+        int li = (int)(u * (float)S.n_lights);
+        lightIndex = li < S.n_lights - 1 ? li : S.n_lights - 1;
+        lightPmf = 1.f / (float)S.n_lights;
+    }
+    float ul0 = sampler.get1d(), ul1 = sampler.get1d();
+    if (!have_light) return r;
+    const DQuad &lq = light_quad_at(lightIndex);
+    LightLi ls;
+    if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return r;
+    r.p_l = lightPmf * ls.pdf;
+    V3 wo = intr.wo, wi = ls.wi;
+    if (intr.is_surface) {
+        r.f_hat = bsdf_f(*bsdf, wo, wi) * absdot(wi, intr.n);
+        r.scatterPDF = 1.0f * bsdf_pdf(*bsdf, wo, wi);
+    } else {
+        float p = henyey_greenstein(dot(wo, wi), intr.g);
+        r.f_hat = sp(p);
+        r.scatterPDF = 1.0f * p;
+    }
+    if (!nonzero(r.f_hat)) return r;
+    r.L = ls.L;
+    // lightRay = intr.SpawnRayTo(ls->pLight) (interaction.h:111-115, ray.h:103-108)
+    V3 pf = offset_ray_origin(intr.pi, intr.n, ls.pLight.mid() - intr.pi.mid());
+    V3 pt = offset_ray_origin(ls.pLight, ls.nLight, pf - ls.pLight.mid());
+    r.lo = pf;
+    r.ld = pt - pf;
+    r.rng.set_sequence(hash_v3(r.lo), hash_v3(r.ld));  // :1193
+    pc.shadow_ray();
+    r.status = 2;
+    if (!(r.ld.x == 0 && r.ld.y == 0 && r.ld.z == 0)) {
+        if (scene_intersect_any(S, r.lo, r.ld, 1 - kShadowEps)) {
+            r.status = 0;
+            return r;
+        }
+        if (S.medium_type != VSPG_MEDIUM_NONE) {
+            r.us = r.rng.uniform();
+            r.status = 1;
+        }
+    }
+    return r;
+}
+// ... and from the estimate on (:1233-1251).  walked: the medium block ran (T_maj is the walk's residual majorant transmittance)
+VDEV Spec sample_Ld_end(bool walked, Spec T_ray, Spec r_l, Spec r_u, Spec T_maj, int ch, Spec f_hat, Spec Ll, float p_l, float scatterPDF, Spec r_p) {
+    if (walked) {
+        float tm = ch_of(T_maj, ch);
+        T_ray = T_ray * (T_maj / tm);
+        r_l = r_l * (T_maj / tm);
+        r_u = r_u * (T_maj / tm);
+    }
+    if (!nonzero(T_ray)) return sp(0.f);
+    r_l = r_l * (r_p * p_l);
+    r_u = r_u * (r_p * scatterPDF);
+    return f_hat * T_ray * Ll / avg(r_l + r_u);
+}
+
+// ---- one tracking step of a walk (media_sampleTMaj.h:66-114 == :190-246), cut where the callback sits --------------
+// A walk is: { while segments: [zero majorant: T *= exp, next] else inner loop { draw t; collision -> callback | leave } }.
+// State between two steps: the iterator, the current segment, the position in it, T_maj, u, the private RNG.
+template <class Medium>
+struct WalkState {
+    typename Medium::Iter iter;
+    Spec sigma_maj;   // of the current segment (scaled)
+    float seg_tMax, tMin;
+    Spec T_maj;
+    float u;
+    Rng rng;
+    int count;
+    bool in_seg;
+};
+enum { WALK_MOVED = 0, WALK_COLLISION = 1, WALK_END = 2 };
+// advance: everything up to (not including) the collision.  Returns WALK_COLLISION with *t_out set when a tentative collision
+// was drawn inside the current segment, WALK_END when the iterator ran out, WALK_MOVED otherwise (call again).
+template <class Medium, bool CAP>
+VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out) {
+    if (!w.in_seg) {
+        MajSeg seg;
+        if (!w.iter.next(&seg)) return WALK_END;
+        seg.sigma_maj = seg.sigma_maj * scale;
+        const float smaj = ch_of(seg.sigma_maj, ch);
+        if (smaj == 0) {
+            float dt = seg.tMax - seg.tMin;
+            if (isinf_(dt)) dt = kFltMax;
+            w.T_maj = w.T_maj * fast_exp(seg.sigma_maj * -dt);
+            return WALK_MOVED;
+        }
+        w.sigma_maj = seg.sigma_maj;
+        w.seg_tMax = seg.tMax;
+        w.tMin = seg.tMin;
+        w.in_seg = true;
+    }
+    const float smaj = ch_of(w.sigma_maj, ch);
+    if constexpr (CAP) w.count++;
+    const float t = w.tMin + sample_exponential(w.u, smaj);
+    w.u = w.rng.uniform();
+    if (t < w.seg_tMax) {
+        if (CAP && w.count > 10000) {  // media_sampleTMaj.h:216-219: leaves the inner loop only
+            w.in_seg = false;
+            return WALK_MOVED;
+        }
+        *t_out = t;
+        return WALK_COLLISION;
+    }
+    float dt = w.seg_tMax - w.tMin;
+    if (isinf_(dt)) dt = kFltMax;
+    w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -dt);
+    w.in_seg = false;
+    return WALK_MOVED;
+}
+
+// =====================================================================================================================
+// kernels
+// =====================================================================================================================
+constexpr int kWfBlock = 256;
+constexpr int kWfWalkWavesPerSimd = 4;  // launch bound of the walk kernels (register budget 128)
+constexpr int kWfShadowWavesPerSimd = 5;  // the shadow walk carries less state (<= 96 registers)
+constexpr int kWfRefill = 16;
+constexpr int kWfClaim = 256;  // jobs a walk wavefront claims per returning atomic  // a walk wavefront refills its idle lanes once this many are idle
+
+struct WfCounters : PathCounters {
+    uint32_t paths;
+    VDEV void path() { paths++; }
+    VDEV void zero() { segments = volume_scatters = surface_hits = density_queries = shadow_rays = paths = 0; }
+};
+VDEV void wf_flush_counters(const WfCounters &pc, unsigned long long *g) {
+    __shared__ unsigned int s_c[CNT_COUNT];
+    if (threadIdx.x < CNT_COUNT) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t v[CNT_COUNT] = {pc.paths, pc.segments, pc.volume_scatters, pc.surface_hits, pc.density_queries, pc.shadow_rays};
+    for (int k = 0; k < CNT_COUNT; ++k) {
+        uint32_t x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&s_c[k], x);
+    }
+    __syncthreads();
+    if (threadIdx.x < CNT_COUNT && s_c[threadIdx.x]) atomicAdd(&g[threadIdx.x], (unsigned long long)s_c[threadIdx.x]);
+}
+
+// the block's medium: GridMedium stages its 16^3 majorant grid in LDS (every DDA step reads it), the 64^3 one stays in L2
+template <class Medium>
+VDEV Medium wf_block_medium(const DScene &S) {
+    const float *maj_ptr = nullptr;
+    if constexpr (Medium::kRes == kMajRes) {
+        __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
+        const float4 *src = reinterpret_cast<const float4 *>(S.majorant);
+        float4 *dst = reinterpret_cast<float4 *>(s_maj);
+        for (int i = threadIdx.x; i < kMajRes * kMajRes * kMajRes / 4; i += kWfBlock) dst[i] = src[i];
+        maj_ptr = s_maj;
+    }
+    stage_scene_lds(S);
+    __syncthreads();
+    return MediumMaker<Medium>::make(S, maj_ptr);
+}
+
+// ---- vertex end of iteration it-1 + segment begin of iteration it ---------------------------------------------------
+template <class Medium>
+__global__ __launch_bounds__(kWfBlock) void k_wf_advance(WfArgs a, int it) {
+    const DScene &S = *a.scene;
+    const Medium medium = wf_block_medium<Medium>(S);
+    const WfPool &P = a.P;
+    constexpr int G = Medium::kGrey;
+    const bool first = it == 0;
+    const unsigned n = first ? a.n_items : a.iters[it - 1].n_vertex;
+    WfIter *I = &a.iters[it];
+    WfCounters pc;
+    pc.zero();
+    __shared__ unsigned int s_stage[2][kWfStageRounds * kWfBlock], s_cnt[2], s_gbase[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const WfStage stA{s_stage[0], &s_cnt[0]}, stB{s_stage[1], &s_cnt[1]};
+    int round = 0;
+    for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
+        const unsigned idx = base + threadIdx.x;
+        bool alive = false, walk = false;
+        unsigned slot = 0;
+        if (idx < n) {
+            slot = first ? idx : a.list_vertex[idx];
+            PathState st;
+            Sampler sampler;
+            IsgSample isg;
+            int ch = 0;
+            if (first) {
+                int px, py;
+                wf_pixel_of(slot, a.tilesX, &px, &py);
+                if (px < S.xres && py < S.yres) {
+                    start_path(S, a.vsp_buf, a.vsp_ready, px, py, a.jump, sampler, st, &ch, isg);
+                    alive = true;
+                }
+            } else {
+                // ---- li_segment_b from the NEE estimate on (:483 / :836, :842-874 / :487-606) --------------------
+                const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
+                Vertex vx;
+                vx.volume = (fl & FL_VX_VOLUME) != 0;
+                vx.p = P.v3(WF_VXP, slot);
+                vx.g = vx.volume ? P.f(WF_VXG, slot) : 0.f;
+                vx.quad = vx.volume ? -1 : P.i(WF_VXG, slot);
+                vx.t = P.f(WF_VXT, slot);
+                VertexCtx c;
+                vertex_setup<false>(st, vx, c);
+                if (fl & WFL_NEE) {
+                    Spec Ld = sp(0.f);
+                    if (fl & (WFL_SHADOW_WALK | WFL_SHADOW_CLEAR)) {
+                        const bool walked = (fl & WFL_SHADOW_WALK) != 0;
+                        Spec T_ray = sp(1.f), r_l = sp(1.f), r_u = sp(1.f), T_maj = sp(1.f);
+                        if (walked) {
+                            T_ray = P.sp3(WF_TRAY, slot); r_l = P.sp3(WF_SRL, slot); r_u = P.sp3(WF_SRU, slot);
+                            T_maj = P.sp3(WF_STMAJ, slot);
+                        }
+                        Ld = sample_Ld_end(walked, T_ray, r_l, r_u, T_maj, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
+                                           P.f(WF_SPDF, slot), st.r_u);
+                    }
+                    st.L = st.L + st.beta * Ld;
+                }
+                alive = vertex_tail(S, st, sampler, vx, c, P.f(WF_SURV, slot));
+                if (!alive) {
+                    wf_finish_path(a, slot, st, isg);
+                    pc.path();
+                }
+            }
+            if (alive) {
+                // ---- li_segment_a up to the traversal (:312-325, sample_distance / SampleT_maj_Resampling prologue) --
+                pc.segment();
+                const Isect si = scene_intersect(S, st.ro, st.rd, kInf);
+                const float tMax = si.hit ? si.t : kInf;
+                uint32_t extra = FL_LIVE | (si.hit ? (uint32_t)WFL_HIT : 0u);
+                P.set3(WF_VXP, slot, si.p);
+                P.i(WF_VXG, slot) = si.quad;
+                P.f(WF_VXT, slot) = si.t;
+                if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
+                    Rng rng;
+                    {
+                        uint64_t hash0 = hash_float(sampler.get1d());
+                        uint64_t hash1 = hash_float(sampler.get1d());
+                        rng.set_sequence(hash0, hash1);
+                    }
+                    bool guide = false;
+                    const float vsp = fetch_vsp<false>(S, st, &guide);
+                    if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
+                    const float u = sampler.get1d();
+                    const float tM = tMax * len(st.rd);
+                    const V3 rdn = normalize(st.rd);
+                    const auto iter = medium.sample_ray(st.ro, rdn, tM);
+                    auto pre = iter;
+                    float totalLength = 0.f;
+                    while (true) {
+                        MajSeg seg;
+                        if (!pre.next(&seg)) break;
+                        const float smaj = ch_of(seg.sigma_maj, ch);
+                        if (smaj == 0) continue;
+                        totalLength += smaj * (seg.tMax - seg.tMin);
+                    }
+                    if (guide) extra |= WFL_GUIDE;
+                    P.f(WF_VSPG, slot) = vsp;
+                    if (totalLength == 0.f) {
+                        extra |= WFL_NOWALK;
+                    } else {
+                        float majorantScale = 1.0f, vrc = vsp;
+                        if (guide) {
+                            float minTotalLength = -logf_(1 - vsp);
+                            if (minTotalLength > totalLength) {
+                                majorantScale = minTotalLength / totalLength;
+                                totalLength = minTotalLength;
+                            }
+                            float expNegTotalLength = fast_exp(-totalLength);
+                            vrc = vsp / (1 - expNegTotalLength);
+                        }
+                        wf_store_iter(P, slot, iter);
+                        P.set3(WF_RDN, slot, rdn);
+                        P.store_rng(WF_WRNG, slot, rng);
+                        P.f(WF_WU, slot) = u;
+                        P.f(WF_MSCALE, slot) = majorantScale;
+                        P.f(WF_VRC, slot) = vrc;
+                        walk = true;
+                    }
+                } else {
+                    extra |= WFL_NODIST;
+                }
+                wf_store_path<G>(P, slot, st, sampler, ch, isg, extra);
+            }
+        }
+        stA.push(alive, slot);
+        stB.push(walk, slot);
+        if ((round % kWfStageRounds) == kWfStageRounds - 1) {
+            stA.flush(a.list_active, &I->n_active, &s_gbase[0]);
+            stB.flush(a.list_walk, &I->n_walk, &s_gbase[1]);
+        }
+    }
+    stA.flush(a.list_active, &I->n_active, &s_gbase[0]);
+    stB.flush(a.list_walk, &I->n_walk, &s_gbase[1]);
+    wf_flush_counters(pc, a.counters);
+}
+
+// ---- the two walk kernels share the job-claiming loop ---------------------------------------------------------------
+// claim: lanes with `want` set receive the next jobs of list[0, n) (slot in *slot_out, returns true); the wavefront keeps a
+// local range [next, end) claimed kWfClaim jobs at a time with one returning atomic (64 at a time put 32 k returning
+// atomics per launch on one word: a third of the kernel's time).
+struct WfClaim {
+    unsigned next, end;
+    bool exhausted;
+};
+VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, unsigned int *head, unsigned *slot_out) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long need = __ballot(want);
+    const unsigned cnt = (unsigned)__popcll(need);
+    const unsigned rank = (unsigned)__popcll(need & ((1ull << lane) - 1ull));
+    bool got = false;
+    unsigned served = 0;
+    while (served < cnt) {
+        if (c.next >= c.end) {
+            if (c.exhausted) break;
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(head, (unsigned)kWfClaim);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n) { c.exhausted = true; break; }
+            c.next = base;
+            c.end = base + (unsigned)kWfClaim < n ? base + (unsigned)kWfClaim : n;
+        }
+        const unsigned avail = c.end - c.next;
+        const unsigned take = cnt - served < avail ? cnt - served : avail;
+        if (want && !got && rank >= served && rank < served + take) {
+            *slot_out = list[c.next + (rank - served)];
+            got = true;
+        }
+        c.next += take;
+        served += take;
+    }
+    return got;
+}
+
+// ---- SampleT_maj_Resampling's traversal (media_sampleTMaj.h:178-247) + the reservoir callback (:691-719) --------------
+template <class Medium>
+__global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(WfArgs a, int it) {
+    const DScene &S = *a.scene;
+    const Medium medium = wf_block_medium<Medium>(S);
+    const WfPool &P = a.P;
+    WfIter *I = &a.iters[it];
+    const unsigned n = I->n_walk;
+    WfCounters pc;
+    pc.zero();
+    WfClaim claim{0u, 0u, false};
+    bool active = false, result = false;  // result: a finished walk whose result is still in registers
+    unsigned slot = 0;
+    WalkState<Medium> w;
+    w.iter = medium.empty_iter();
+    w.sigma_maj = sp(0.f); w.seg_tMax = w.tMin = 0.f; w.T_maj = sp(1.f); w.u = 0.f; w.rng.state = w.rng.inc = 0; w.count = 0; w.in_seg = false;
+    V3 ro = mk(0, 0, 0), rdn = mk(0, 0, 1);
+    float scale = 1.f;
+    int ch = 0;
+    Sampler sampler;
+    sampler.rng.state = sampler.rng.inc = 0;
+    // reservoir state (:684-690)
+    float weightSum = 0, sel_wi = 0;
+    Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f), sel_num = sp(0.f), sel_den = sp(0.f);
+    V3 sel_p = mk(0, 0, 0);
+    while (true) {
+        const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
+        if (n_idle == 64u || (n_idle >= (unsigned)kWfRefill && !(claim.exhausted && claim.next >= claim.end))) {
+            if (result) {  // park the finished walks' results
+                P.sets(WF_TMAJ, slot, w.T_maj);
+                P.f(WF_WSUM, slot) = weightSum;
+                P.sets(WF_TRR, slot, trRatioEst);
+                P.sets(WF_BRS, slot, beta_rs);
+                P.sets(WF_RURS, slot, r_u_rs);
+                P.set3(WF_SELP, slot, sel_p);
+                P.f(WF_SELW, slot) = sel_wi;
+                P.sets(WF_SELNUM, slot, sel_num);
+                P.sets(WF_SELDEN, slot, sel_den);
+                P.store_rng(WF_RNG, slot, sampler.rng);
+                result = false;
+            }
+            unsigned ns = 0;
+            if (wf_claim(claim, !active, a.list_walk, n, &I->walk_head, &ns)) {
+                slot = ns;
+                w.iter = wf_load_iter(P, slot, medium);
+                w.in_seg = false;
+                w.T_maj = sp(1.f);
+                w.u = P.f(WF_WU, slot);
+                P.load_rng(WF_WRNG, slot, w.rng);
+                w.count = 0;
+                ro = P.v3(WF_RO, slot);
+                rdn = P.v3(WF_RDN, slot);
+                scale = P.f(WF_MSCALE, slot);
+                ch = (int)((P.u(WF_FLAGS, slot) >> FL_CH_SHIFT) & 3u);
+                P.load_rng(WF_RNG, slot, sampler.rng);
+                weightSum = 0; sel_wi = 0;
+                trRatioEst = beta_rs = r_u_rs = sp(1.f);
+                sel_num = sel_den = sp(0.f);
+                sel_p = mk(0, 0, 0);
+                active = true;
+            }
+            if (__ballot(active) == 0ull) break;  // nothing in flight and the list has run out
+        }
+        // ---- one tracking step ------------------------------------------------------------------------------------
+        float t = 0.f;
+        int r = WALK_MOVED;
+        if (active) {
+            r = walk_advance<Medium, true>(w, ch, scale, &t);
+            if (Medium::kAdvanceRounds > 1 && r == WALK_MOVED) r = walk_advance<Medium, true>(w, ch, scale, &t);
+            if (Medium::kAdvanceRounds > 2 && r == WALK_MOVED) r = walk_advance<Medium, true>(w, ch, scale, &t);
+        }
+        if (active && r == WALK_COLLISION) {
+            w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
+            const V3 p = ro + rdn * t;
+            const MediumProps mp = medium.sample_point(p);
+            // the resampling callback (:691-719); it never stops the traversal
+            pc.density_query();
+            const Spec sigma_maj = w.sigma_maj, T_maj = w.T_maj;
+            const Spec sigma_t = mp.sigma_t;
+            const Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
+            const float wi = ch_of(sigma_t / sigma_maj * trRatioEst, ch);
+            if (wi > 0) {
+                weightSum += wi;
+                if (sampler.get1d() < wi / weightSum) {
+                    const float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
+                    sel_num = beta_rs * T_maj * mp.sigma_s / pdf;
+                    sel_den = r_u_rs * T_maj * sigma_t / pdf;
+                    sel_p = p;
+                    sel_wi = wi;
+                }
+            }
+            const float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
+            beta_rs = beta_rs * (T_maj * sigma_n / pdf);
+            r_u_rs = r_u_rs * (T_maj * sigma_n / pdf);
+            trRatioEst = trRatioEst * (sigma_n / sigma_maj);
+            w.T_maj = sp(1.f);
+            w.tMin = t;
+        } else if (active && r == WALK_END) {
+            active = false;
+            result = true;
+        }
+    }
+    wf_flush_counters(pc, a.counters);
+}
+
+// ---- candidate selection, surface emission, depth test, vertex setup, NEE light sample + shadow-ray set-up -------------
+template <class Medium>
+__global__ __launch_bounds__(kWfBlock) void k_wf_seg_end(WfArgs a, int it) {
+    const DScene &S = *a.scene;
+    const Medium medium = wf_block_medium<Medium>(S);
+    const WfPool &P = a.P;
+    constexpr int G = Medium::kGrey;
+    WfIter *I = &a.iters[it];
+    const unsigned n = I->n_active;
+    WfCounters pc;
+    pc.zero();
+    __shared__ unsigned int s_stage[2][kWfStageRounds * kWfBlock], s_cnt[2], s_gbase[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const WfStage stA{s_stage[0], &s_cnt[0]}, stB{s_stage[1], &s_cnt[1]};
+    int round = 0;
+    for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
+        const unsigned idx = base + threadIdx.x;
+        bool alive = false, shadow = false;
+        unsigned slot = 0;
+        if (idx < n) {
+            slot = a.list_active[idx];
+            PathState st;
+            Sampler sampler;
+            IsgSample isg;
+            int ch;
+            const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
+            int px, py;
+            wf_pixel_of(slot, a.tilesX, &px, &py);
+            Isect si;
+            si.hit = (fl & WFL_HIT) != 0;
+            si.quad = P.i(WF_VXG, slot);
+            si.t = P.f(WF_VXT, slot);
+            si.p = P.v3(WF_VXP, slot);
+            si.n = ld3(quad_at(si.quad).n);
+            Vertex vx;
+            vx.volume = false;
+            vx.p = si.p;
+            vx.g = 0;
+            vx.quad = si.quad;
+            vx.t = si.t;
+            int kind = EV_PASS;
+            if (!(fl & WFL_NODIST)) {
+                // ---- sample_distance after the traversal (:721-802) ---------------------------------------------
+                const bool guide = (fl & WFL_GUIDE) != 0;
+                const float vsp = P.f(WF_VSPG, slot);
+                float weightSum = 0, sel_wi = 0, vrc = 0;
+                Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f), sel_num = sp(0.f), sel_den = sp(0.f), T_maj = sp(1.f);
+                V3 sel_p = mk(0, 0, 0);
+                if (!(fl & WFL_NOWALK)) {
+                    T_maj = P.sp3(WF_TMAJ, slot);
+                    weightSum = P.f(WF_WSUM, slot);
+                    trRatioEst = P.sp3(WF_TRR, slot);
+                    beta_rs = P.sp3(WF_BRS, slot);
+                    r_u_rs = P.sp3(WF_RURS, slot);
+                    sel_p = P.v3(WF_SELP, slot);
+                    sel_wi = P.f(WF_SELW, slot);
+                    sel_num = P.sp3(WF_SELNUM, slot);
+                    sel_den = P.sp3(WF_SELDEN, slot);
+                    vrc = P.f(WF_VRC, slot);
+                    P.load_rng(WF_RNG, slot, sampler.rng);  // the traversal drew one sampler dimension per candidate (:702)
+                }
+                float sel_sTTr = sel_wi;
+                const float tm = ch_of(T_maj, ch);
+                beta_rs = beta_rs * (T_maj / tm);
+                r_u_rs = r_u_rs * (T_maj / tm);
+                if (st.depth == 0 && S.tr_calc) {  // trBuffer->AddSample (:727-728, trbuffer.h:40-45); one sample per pixel per pass, passes in order
+                    const size_t pix = (size_t)py * S.xres + px;
+                    const int ns = S.tr_spp[pix] + 1;
+                    S.tr_spp[pix] = ns;
+                    const float alpha = 1.f / (float)ns;
+                    float *tb = S.tr_rgb + pix * 3;
+                    tb[0] = (1.f - alpha) * tb[0] + alpha * trRatioEst.r;
+                    tb[1] = (1.f - alpha) * tb[1] + alpha * trRatioEst.g;
+                    tb[2] = (1.f - alpha) * tb[2] + alpha * trRatioEst.b;
+                }
+                const float trScalar = ch_of(trRatioEst, ch);
+                float surf_wi = trScalar;
+                if (guide && trScalar < 1 && trScalar > 0 && weightSum > 0) {
+                    float volRatio = vrc * S.prm.vspmisratio + (1 - trScalar) * (1 - S.prm.vspmisratio);
+                    float surfRatio = 1 - volRatio;
+                    surf_wi = surfRatio / volRatio * weightSum;
+                }
+                weightSum += surf_wi;
+                if (weightSum != 0) {
+                    bool selectSurface = false;
+                    if (sampler.get1d() < surf_wi / weightSum) {
+                        sel_wi = surf_wi;
+                        sel_sTTr = trScalar;
+                        sel_num = beta_rs;
+                        sel_den = r_u_rs;
+                        selectSurface = true;
+                    }
+                    const float factor = weightSum * sel_sTTr / sel_wi;
+                    bool term = false;
+                    if (!selectSurface) {
+                        if (st.depth == 0) {
+                            isg.valid = true;
+                            isg.surface_event = false;
+                        }
+                        if (st.depth++ >= S.prm.maxdepth) term = true;
+                        else pc.volume_scatter();
+                    }
+                    if (!term) {
+                        st.beta = st.beta * (sel_num * factor);
+                        st.r_u = st.r_u * sel_den;
+                        if (has_nan(st.beta) || has_nan(st.r_u) || has_inf(st.beta) || has_inf(st.r_u)) term = true;
+                    }
+                    if (term) kind = EV_TERMINATE;
+                    else if (!selectSurface) {
+                        kind = EV_SCATTER;
+                        vx.volume = true;
+                        vx.p = sel_p;
+                        vx.g = medium.g;
+                    }
+                }
+            }
+            if (kind == EV_TERMINATE || (!(fl & WFL_NODIST) && (!nonzero(st.beta) || !nonzero(st.r_u)))) {  // :343-344
+                alive = false;
+            } else if (kind == EV_SCATTER) {
+                alive = true;
+            } else {
+                alive = li_surface_pre(S, st, isg, pc, si, sp(1.f));
+            }
+            if (!alive) {
+                wf_finish_path(a, slot, st, isg);
+                pc.path();
+            } else {
+                // ---- li_segment_b up to the shadow ray's transmittance estimate -----------------------------------
+                P.set3(WF_VXP, slot, vx.p);
+                if (vx.volume) P.f(WF_VXG, slot) = vx.g; else P.i(WF_VXG, slot) = vx.quad;
+                VertexCtx c;
+                vertex_setup<false>(st, vx, c);
+                const float survivalProb = vertex_pre(S, st, sampler, vx);
+                uint32_t extra = FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u);
+                if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833
+                    extra |= WFL_NEE;
+                    const ShadowSetup ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc);
+                    if (ss.status != 0) {
+                        P.sets(WF_FHAT, slot, ss.f_hat);
+                        P.sets(WF_LSL, slot, ss.L);
+                        P.f(WF_PL, slot) = ss.p_l;
+                        P.f(WF_SPDF, slot) = ss.scatterPDF;
+                    }
+                    if (ss.status == 1) {
+                        const float tM = (1 - kShadowEps) * len(ss.ld);
+                        const V3 rdn = normalize(ss.ld);
+                        const auto iter = medium.sample_ray(ss.lo, rdn, tM);
+                        if (iter.tMin >= iter.tMax) {
+                            extra |= WFL_SHADOW_CLEAR;  // the ray misses the medium's bounds: the walk would return T_maj = 1 at once
+                        } else {
+                            wf_store_iter(P, slot, iter);
+                            P.set3(WF_RDN, slot, rdn);
+                            P.set3(WF_SLO, slot, ss.lo);
+                            P.store_rng(WF_WRNG, slot, ss.rng);
+                            P.f(WF_WU, slot) = ss.us;
+                            extra |= WFL_SHADOW_WALK;
+                            shadow = true;
+                        }
+                    } else if (ss.status == 2) {
+                        extra |= WFL_SHADOW_CLEAR;
+                    }
+                }
+                P.f(WF_SURV, slot) = survivalProb;
+                wf_store_path<G>(P, slot, st, sampler, ch, isg, extra);
+            }
+        }
+        stA.push(alive, slot);
+        stB.push(shadow, slot);
+        if ((round % kWfStageRounds) == kWfStageRounds - 1) {
+            stA.flush(a.list_vertex, &I->n_vertex, &s_gbase[0]);
+            stB.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
+        }
+    }
+    stA.flush(a.list_vertex, &I->n_vertex, &s_gbase[0]);
+    stB.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
+    wf_flush_counters(pc, a.counters);
+}
+
+// ---- the shadow ray's ratio-tracking walk (SampleT_maj, media_sampleTMaj.h:49-117, with the callback of :1207-1232) -----
+template <class Medium>
+__global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_walk(WfArgs a, int it) {
+    const DScene &S = *a.scene;
+    const Medium medium = wf_block_medium<Medium>(S);
+    const WfPool &P = a.P;
+    WfIter *I = &a.iters[it];
+    const unsigned n = I->n_shadow;
+    WfClaim claim{0u, 0u, false};
+    bool active = false, result = false;
+    unsigned slot = 0;
+    WalkState<Medium> w;
+    w.iter = medium.empty_iter();
+    w.sigma_maj = sp(0.f); w.seg_tMax = w.tMin = 0.f; w.T_maj = sp(1.f); w.u = 0.f; w.rng.state = w.rng.inc = 0; w.count = 0; w.in_seg = false;
+    V3 ro = mk(0, 0, 0), rdn = mk(0, 0, 1);
+    int ch = 0;
+    Spec T_ray = sp(1.f), r_l = sp(1.f), r_u = sp(1.f), T_res = sp(1.f);
+    while (true) {
+        const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
+        if (n_idle == 64u || (n_idle >= (unsigned)kWfRefill && !(claim.exhausted && claim.next >= claim.end))) {
+            if (result) {
+                P.sets(WF_TRAY, slot, T_ray);
+                P.sets(WF_SRL, slot, r_l);
+                P.sets(WF_SRU, slot, r_u);
+                P.sets(WF_STMAJ, slot, T_res);
+                result = false;
+            }
+            unsigned ns = 0;
+            if (wf_claim(claim, !active, a.list_shadow, n, &I->shadow_head, &ns)) {
+                slot = ns;
+                w.iter = wf_load_iter(P, slot, medium);
+                w.in_seg = false;
+                w.T_maj = sp(1.f);
+                w.u = P.f(WF_WU, slot);
+                P.load_rng(WF_WRNG, slot, w.rng);
+                ro = P.v3(WF_SLO, slot);
+                rdn = P.v3(WF_RDN, slot);
+                ch = (int)((P.u(WF_FLAGS, slot) >> FL_CH_SHIFT) & 3u);
+                T_ray = r_l = r_u = sp(1.f);
+                active = true;
+            }
+            if (__ballot(active) == 0ull) break;
+        }
+        float t = 0.f;
+        int r = WALK_MOVED;
+        if (active) {
+            r = walk_advance<Medium, false>(w, ch, 1.f, &t);
+            if (Medium::kAdvanceRounds > 1 && r == WALK_MOVED) r = walk_advance<Medium, false>(w, ch, 1.f, &t);
+            if (Medium::kAdvanceRounds > 2 && r == WALK_MOVED) r = walk_advance<Medium, false>(w, ch, 1.f, &t);
+        }
+        if (active && r == WALK_COLLISION) {
+            w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
+            const V3 p = ro + rdn * t;
+            const MediumProps mp = medium.sample_point(p);
+            // ratio tracking (:1207-1232)
+            const Spec sigma_maj = w.sigma_maj, T_maj = w.T_maj;
+            const float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
+            const Spec sigma_n = medium.sigma_n(mp, sigma_maj);
+            T_ray = T_ray * (T_maj * sigma_n / pdf);
+            r_l = r_l * (T_maj * sigma_maj / pdf);
+            r_u = r_u * (T_maj * sigma_n / pdf);
+            const Spec Tr = T_ray / avg(r_l + r_u);
+            if (maxc(Tr) < 0.05f) {
+                const float q = 0.75f;
+                if (w.rng.uniform() < q) T_ray = sp(0.f);
+                else T_ray = T_ray / (1 - q);
+            }
+            if (!nonzero(T_ray)) {  // the callback stops the traversal: SampleT_maj returns 1
+                T_res = sp(1.f);
+                active = false;
+                result = true;
+            } else {
+                w.T_maj = sp(1.f);
+                w.tMin = t;
+            }
+        } else if (active && r == WALK_END) {
+            T_res = w.T_maj;
+            active = false;
+            result = true;
+        }
+    }
+}
+
+}  // namespace vspg
