@@ -1507,6 +1507,14 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     a.list_shadow = r->wf_lists + 3 * items;
     a.iters = r->wf_iters;
     a.counters = r->counters;
+    {   // tuning knobs (defaults measured on the 256^3 cloud stand-in)
+        const char *e1 = getenv("VSPG_WF_ROUNDS"), *e2 = getenv("VSPG_WF_REFILL");
+        a.walk_rounds = e1 ? atoi(e1) : Medium::kAdvanceRounds;
+        a.walk_refill = e2 ? atoi(e2) : kWfRefill;
+        if (a.walk_rounds < 1) a.walk_rounds = 1;
+        if (a.walk_refill < 1) a.walk_refill = 1;
+        if (a.walk_refill > 64) a.walk_refill = 64;
+    }
     // persistent grids: the dense kernels stride over their list, the walk kernels pull jobs
     const unsigned max_blocks = (unsigned)((items + kWfBlock - 1) / kWfBlock);
     unsigned dense = (unsigned)r->num_cus * 8u, walk = (unsigned)r->num_cus * (unsigned)kWfWalkWavesPerSimd;

@@ -738,7 +738,7 @@ struct GridMediumT {
     static constexpr int kRes = NVDB ? kMajResNvdb : kMajRes;
     // wavefront walk kernels: majorant-cell advances tried per tracking step before the collision code runs (a 64^3
     // majorant grid has 4x as many cell crossings per tentative collision as the 16^3 one)
-    static constexpr int kAdvanceRounds = NVDB ? 3 : 1;
+    static constexpr int kAdvanceRounds = NVDB ? 6 : 3;
     static constexpr int kGrey = GREY ? 1 : 0;  // sigma_a, sigma_s built from one value each (see HomogeneousMediumT)
     Spec sigma_a, sigma_s;
     float g;

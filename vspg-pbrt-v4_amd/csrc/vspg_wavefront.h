@@ -31,53 +31,56 @@
 
 namespace vspg {
 
-// ---- SoA record: field f of path slot s at base[f * n + s] -----------------------------------------------------
+// ---- path record: groups of four floats, group-major ("AoSoA-4"): field f of slot s at base[((f >> 2) * n + s) * 4 + (f & 3)] --
+// A 3-vector / spectrum / RNG state sits inside ONE 16-byte group, so a lane moves it with one dwordx3 / dwordx4 access and a
+// wavefront over consecutive slots touches whole cache lines (as 4-byte-per-lane SoA the dense kernels sat at ~3 TB/s on
+// ~110 memory instructions per path).
 enum {
-    WF_RO = 0,        // 3  ray origin
-    WF_RD = 3,        // 3  ray direction
-    WF_L = 6,         // 3
-    WF_BETA = 9,      // 3
-    WF_RU = 12,       // 3
-    WF_RL = 15,       // 3
-    WF_PCP = 18,      // 3  previous light-sample context: raw point
-    WF_PCQ = 21,      // 1  ... its rectangle, -1 = medium vertex
-    WF_RNG = 22,      // 4  sampler PCG state / inc
-    WF_FLAGS = 26,    // 1  packed like the LDS pool's (vspg_wg_kernel.h) + WFL_* bits
-    WF_RRC = 27,      // 1  rr_correction
-    WF_VSP = 28,      // 1  vsp0 (depth 0) / isg.vsp_used
-    WF_VXP = 29,      // 3  vertex position (surface: re-projected hit point; volume: selected candidate)
-    WF_VXG = 32,      // 1  surface: rectangle (int); volume: g
-    WF_VXT = 33,      // 1  surface tHit
+    WF_RO = 0,        // 3  ray origin            | +3: WF_VSP
+    WF_VSP = 3,       // 1  isg.vsp_used
+    WF_RD = 4,        // 3  ray direction         | +3: WF_RRC
+    WF_RRC = 7,       // 1  rr_correction
+    WF_L = 8,         // 3                        | +3: WF_FLAGS
+    WF_FLAGS = 11,    // 1  packed like the LDS pool's (vspg_wg_kernel.h) + WFL_* bits
+    WF_BETA = 12,     // 3                        | +3: WF_SURV
+    WF_SURV = 15,     // 1  survivalProb of the vertex
+    WF_RU = 16,       // 3                        | +3: WF_PL
+    WF_PL = 19,       // 1  NEE: p_l
+    WF_RL = 20,       // 3                        | +3: WF_SPDF
+    WF_SPDF = 23,     // 1  NEE: scatterPDF
+    WF_PCP = 24,      // 3  previous light-sample context: raw point | +3: WF_PCQ
+    WF_PCQ = 27,      // 1  ... its rectangle, -1 = medium vertex
+    WF_RNG = 28,      // 4  sampler PCG state / inc
+    WF_VXP = 32,      // 3  vertex position (surface: re-projected hit point; volume: selected candidate) | +3: WF_VXG
+    WF_VXG = 35,      // 1  surface: rectangle (int); volume: g
     // walk job (distance walk, later re-used by the shadow walk of the same iteration)
-    WF_IT = 34,       // 9  DDA iterator at the start of the ray: tMin, tMax, nextCrossingT[3], deltaT[3], packed voxel | step signs
-    WF_RDN = 43,      // 3  normalised direction
-    WF_WRNG = 46,     // 4  the walk's private PCG (:323-325 / :1193)
-    WF_WU = 50,       // 1  first uniform of the walk
-    WF_MSCALE = 51,   // 1  majorantScale
-    WF_VRC = 52,      // 1  vsp / (1 - exp(-tau)) (media_sampleTMaj.h:172)
-    WF_VSPG = 53,     // 1  the VSP the segment is guided with (-1: none)
+    WF_IT = 36,       // 9 (+3 below)  DDA iterator at the start of the ray: tMin, tMax, nextCrossingT[3], deltaT[3], packed voxel | step signs
+    WF_VXT = 45,      // 1  surface tHit
+    WF_WU = 46,       // 1  first uniform of the walk
+    WF_MSCALE = 47,   // 1  majorantScale
+    WF_RDN = 48,      // 3  normalised direction  | +3: WF_VRC
+    WF_VRC = 51,      // 1  vsp / (1 - exp(-tau)) (media_sampleTMaj.h:172)
+    WF_WRNG = 52,     // 4  the walk's private PCG (:323-325 / :1193)
     // distance-walk result
-    WF_TMAJ = 54,     // 3
-    WF_WSUM = 57,     // 1  weightSum
-    WF_TRR = 58,      // 3  trRatioEst
-    WF_BRS = 61,      // 3  beta_rs
-    WF_RURS = 64,     // 3  r_u_rs
-    WF_SELP = 67,     // 3  selected candidate: position
-    WF_SELW = 70,     // 1  ... its weight (0: none selected)
-    WF_SELNUM = 71,   // 3
-    WF_SELDEN = 74,   // 3
+    WF_TMAJ = 56,     // 3                        | +3: WF_WSUM
+    WF_WSUM = 59,     // 1  weightSum
+    WF_TRR = 60,      // 3  trRatioEst            | +3: WF_SELW
+    WF_SELW = 63,     // 1  selected candidate's weight (0: none selected)
+    WF_BRS = 64,      // 3  beta_rs               | +3: WF_VSPG
+    WF_VSPG = 67,     // 1  the VSP the segment is guided with (-1: none)
+    WF_RURS = 68,     // 3  r_u_rs
+    WF_SELP = 72,     // 3  selected candidate: position
+    WF_SELNUM = 76,   // 3
+    WF_SELDEN = 80,   // 3
     // shadow job / result
-    WF_SLO = 77,      // 3  shadow-ray origin
-    WF_FHAT = 80,     // 3  f_hat
-    WF_LSL = 83,      // 3  ls.L
-    WF_PL = 86,       // 1  p_l
-    WF_SPDF = 87,     // 1  scatterPDF
-    WF_SURV = 88,     // 1  survivalProb of the vertex
-    WF_TRAY = 89,     // 3  shadow result: T_ray
-    WF_SRL = 92,      // 3  ... r_l
-    WF_SRU = 95,      // 3  ... r_u
-    WF_STMAJ = 98,    // 3  ... residual T_maj
-    WF_COUNT = 101
+    WF_SLO = 84,      // 3  shadow-ray origin
+    WF_FHAT = 88,     // 3  f_hat
+    WF_LSL = 92,      // 3  ls.L
+    WF_TRAY = 96,     // 3  shadow result: T_ray
+    WF_SRL = 100,     // 3  ... r_l
+    WF_SRU = 104,     // 3  ... r_u
+    WF_STMAJ = 108,   // 3  ... residual T_maj
+    WF_COUNT = 112
 };
 enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_NODIST = 1 << 20,    // no SampleDistance this segment (no medium / the ray escapes)
@@ -92,9 +95,10 @@ enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
 struct WfPool {
     float *base;
     size_t n;
-    VDEV float &f(int field, unsigned slot) const { return base[(size_t)field * n + slot]; }
-    VDEV int &i(int field, unsigned slot) const { return reinterpret_cast<int *>(base)[(size_t)field * n + slot]; }
-    VDEV uint32_t &u(int field, unsigned slot) const { return reinterpret_cast<uint32_t *>(base)[(size_t)field * n + slot]; }
+    VDEV size_t at(int field, unsigned slot) const { return ((size_t)(field >> 2) * n + slot) * 4u + (size_t)(field & 3); }
+    VDEV float &f(int field, unsigned slot) const { return base[at(field, slot)]; }
+    VDEV int &i(int field, unsigned slot) const { return reinterpret_cast<int *>(base)[at(field, slot)]; }
+    VDEV uint32_t &u(int field, unsigned slot) const { return reinterpret_cast<uint32_t *>(base)[at(field, slot)]; }
     VDEV V3 v3(int field, unsigned slot) const { return V3{f(field, slot), f(field + 1, slot), f(field + 2, slot)}; }
     VDEV void set3(int field, unsigned slot, V3 v) const { f(field, slot) = v.x; f(field + 1, slot) = v.y; f(field + 2, slot) = v.z; }
     VDEV Spec sp3(int field, unsigned slot) const { return Spec{f(field, slot), f(field + 1, slot), f(field + 2, slot)}; }
@@ -136,6 +140,8 @@ struct WfArgs {
     unsigned int *list_shadow;
     WfIter *iters;               // [maxdepth + 2]
     unsigned long long *counters;
+    int walk_rounds;             // majorant-cell advances tried per tracking step before the collision code runs
+    int walk_refill;             // a walk wavefront refills its idle lanes once this many are idle
 };
 
 VDEV void wf_pixel_of(unsigned slot, unsigned tilesX, int *px, int *py) {
@@ -402,7 +408,7 @@ constexpr int kWfBlock = 256;
 constexpr int kWfWalkWavesPerSimd = 4;  // launch bound of the walk kernels (register budget 128)
 constexpr int kWfShadowWavesPerSimd = 5;  // the shadow walk carries less state (<= 96 registers)
 constexpr int kWfRefill = 16;
-constexpr int kWfClaim = 256;  // jobs a walk wavefront claims per returning atomic  // a walk wavefront refills its idle lanes once this many are idle
+constexpr int kWfClaim = 128;  // jobs a walk wavefront claims per returning atomic  // a walk wavefront refills its idle lanes once this many are idle
 
 struct WfCounters : PathCounters {
     uint32_t paths;
@@ -441,7 +447,7 @@ VDEV Medium wf_block_medium(const DScene &S) {
 
 // ---- vertex end of iteration it-1 + segment begin of iteration it ---------------------------------------------------
 template <class Medium>
-__global__ __launch_bounds__(kWfBlock) void k_wf_advance(WfArgs a, int it) {
+__global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
     const WfPool &P = a.P;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     V3 sel_p = mk(0, 0, 0);
     while (true) {
         const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
-        if (n_idle == 64u || (n_idle >= (unsigned)kWfRefill && !(claim.exhausted && claim.next >= claim.end))) {
+        if (n_idle == 64u || (n_idle >= (unsigned)a.walk_refill && !(claim.exhausted && claim.next >= claim.end))) {
             if (result) {  // park the finished walks' results
                 P.sets(WF_TMAJ, slot, w.T_maj);
                 P.f(WF_WSUM, slot) = weightSum;
@@ -682,8 +688,13 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
         int r = WALK_MOVED;
         if (active) {
             r = walk_advance<Medium, true>(w, ch, scale, &t);
-            if (Medium::kAdvanceRounds > 1 && r == WALK_MOVED) r = walk_advance<Medium, true>(w, ch, scale, &t);
-            if (Medium::kAdvanceRounds > 2 && r == WALK_MOVED) r = walk_advance<Medium, true>(w, ch, scale, &t);
+        }
+        // lanes that only moved (crossed into the next majorant cell, skipped an empty one) try again before the wavefront
+        // enters the collision code, so that code runs with most lanes: up to walk_rounds tries while >= 8 lanes would sit idle
+        for (int rr = 1; rr < a.walk_rounds; ++rr) {
+            const bool again = active && r == WALK_MOVED;
+            if (__popcll(__ballot(again)) < 8) break;
+            if (again) r = walk_advance<Medium, true>(w, ch, scale, &t);
         }
         if (active && r == WALK_COLLISION) {
             w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
 
 // ---- candidate selection, surface emission, depth test, vertex setup, NEE light sample + shadow-ray set-up -------------
 template <class Medium>
-__global__ __launch_bounds__(kWfBlock) void k_wf_seg_end(WfArgs a, int it) {
+__global__ __launch_bounds__(kWfBlock, 3) void k_wf_seg_end(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
     const WfPool &P = a.P;
@@ -917,7 +928,7 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
     Spec T_ray = sp(1.f), r_l = sp(1.f), r_u = sp(1.f), T_res = sp(1.f);
     while (true) {
         const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
-        if (n_idle == 64u || (n_idle >= (unsigned)kWfRefill && !(claim.exhausted && claim.next >= claim.end))) {
+        if (n_idle == 64u || (n_idle >= (unsigned)a.walk_refill && !(claim.exhausted && claim.next >= claim.end))) {
             if (result) {
                 P.sets(WF_TRAY, slot, T_ray);
                 P.sets(WF_SRL, slot, r_l);
@@ -945,8 +956,13 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
         int r = WALK_MOVED;
         if (active) {
             r = walk_advance<Medium, false>(w, ch, 1.f, &t);
-            if (Medium::kAdvanceRounds > 1 && r == WALK_MOVED) r = walk_advance<Medium, false>(w, ch, 1.f, &t);
-            if (Medium::kAdvanceRounds > 2 && r == WALK_MOVED) r = walk_advance<Medium, false>(w, ch, 1.f, &t);
+        }
+        // lanes that only moved (crossed into the next majorant cell, skipped an empty one) try again before the wavefront
+        // enters the collision code, so that code runs with most lanes: up to walk_rounds tries while >= 8 lanes would sit idle
+        for (int rr = 1; rr < a.walk_rounds; ++rr) {
+            const bool again = active && r == WALK_MOVED;
+            if (__popcll(__ballot(again)) < 8) break;
+            if (again) r = walk_advance<Medium, false>(w, ch, 1.f, &t);
         }
         if (active && r == WALK_COLLISION) {
             w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
