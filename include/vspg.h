@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSPG_ABI_VERSION 3
+#define VSPG_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define VSPG_OK 0
@@ -104,13 +104,42 @@ typedef struct VspgMedium {
      * Temperature grids (blackbody emission) are outside this build's scope. */
     const float *le_scale;
     int32_t le_nx, le_ny, le_nz;
+    /* grid media -- renderFromMedium (src/pbrt/media.h:322, :354, :693, :708; the Transform the scene file's CTM gave
+     * the medium): has_transform = 0 means identity.  Both matrices of pbrt's Transform are passed, row-major
+     * (m and mInv, util/transform.h:186-187): a pbrt host hands over its own inverse, so that
+     * Transform::ApplyInverse(Ray, &tMax) / ApplyInverse(Point3f) (transform.h:387-429, transform.cpp:263-303) see the same
+     * floats.  vspg_transform_inverse() fills medium_from_render for callers that only have m.  Affine matrices only
+     * (last row 0 0 0 1). */
+    int32_t has_transform;
+    float render_from_medium[16];
+    float medium_from_render[16];
 } VspgMedium;
+
+/* Triangle geometry (src/pbrt/shapes.h:828-1030, shapes.cpp:168-262, cpu/aggregates.cpp:529-640):
+ * a soup of diffuse, non-emissive, two-sided triangles next to the rectangles; the library builds a BVH over them
+ * (own builder) and traverses it on the device.  tri_p: 9 floats per triangle (p0, p1, p2), tri_kd: 3 per triangle.
+ * HOST pointers, copied at create time. */
+/* Infinite lights (src/pbrt/lights.h:  UniformInfiniteLight :554-601, DistantLight :207-250; escaped-ray MIS
+ * guidedvolpathvspgintegrator.cpp:353-374): L = scale * Lemit already multiplied out (RGB).  Distant: w_light = the
+ * normalised direction TOWARDS the light in render space. */
+enum { VSPG_LIGHT_UNIFORM_INFINITE = 0, VSPG_LIGHT_DISTANT = 1 };
+#define VSPG_MAX_INFINITE_LIGHTS 4
+typedef struct VspgInfiniteLight {
+    int32_t type;
+    float L[3];
+    float w_light[3];
+} VspgInfiniteLight;
 
 typedef struct VspgScene {
     int32_t n_quads;
     VspgQuad quads[VSPG_MAX_QUADS];
     VspgCamera camera;
     VspgMedium medium;
+    int32_t n_triangles;
+    const float *tri_p;
+    const float *tri_kd;
+    int32_t n_infinite_lights;
+    VspgInfiniteLight infinite_lights[VSPG_MAX_INFINITE_LIGHTS];
 } VspgScene;
 
 /* ---- integrator parameters: same names and defaults as
@@ -231,6 +260,8 @@ void vspg_integrator_params_default(VspgIntegratorParams *p);
  * src/pbrt/cameras.cpp:474-489), world == render space. */
 int vspg_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3],
                         const float up[3], float fov_degrees, int xres, int yres);
+/* inv = m^-1 for an affine row-major 4x4 (computed in double, rounded once); returns VSPG_EINVAL for a singular matrix. */
+int vspg_transform_inverse(const float m[16], float inv[16]);
 /* Fills `scene` with the App.-F fog box: box [-1,1]^3, Kd .73 walls, 0.5x0.5 ceiling
  * light Le (17,12,4) at y=.999, homogeneous fog sigma_a .05 sigma_s .45 g 0, camera at
  * (0,0,-.95) looking +z, fov 60. */

@@ -290,6 +290,42 @@ int main() {
         }
         printf("],\n");
     }
+    // ---- Transform::ApplyInverse(const Ray &, Float *tMax) and ApplyInverse(Point3f) for general affine transforms
+    //      (util/transform.h:387-429, util/transform.cpp:263-303): renderFromMedium of a placed GridMedium / NanoVDBMedium
+    //      (media.h:322, :354).  The reference's own m and mInv are emitted with every case. ----
+    {
+        printf("\"apply_inverse_xform\": [");
+        bool first = true;
+        for (int i = 0; i < 48; ++i) {
+            Transform T;
+            switch (i % 6) {
+            case 0: T = Translate(Vector3f(4 * U() - 2, 4 * U() - 2, 4 * U() - 2)); break;
+            case 1: T = Scale(0.25f + 3 * U(), 0.25f + 3 * U(), 0.25f + 3 * U()); break;
+            case 2: T = Rotate(360 * U(), Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1))); break;
+            case 3: T = Translate(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1)) * RotateY(360 * U()) * Scale(0.5f + U(), 0.5f + U(), 0.5f + U()); break;
+            case 4: T = RotateX(90) * Translate(Vector3f(0.5f, -0.25f, 3 * U())); break;
+            default: T = Translate(Vector3f(10 * U(), -7 * U(), 5 * U())) * Rotate(360 * U(), Normalize(Vector3f(U(), U(), U() + 0.1f))) * Scale(2 * U() + 0.1f, 2 * U() + 0.1f, 2 * U() + 0.1f); break;
+            }
+            Point3f o(4 * U() - 2, 4 * U() - 2, 4 * U() - 2);
+            Vector3f d(2 * U() - 1, 2 * U() - 1, 2 * U() - 1);
+            if (i % 8 == 7) d = Vector3f(0, 0, 0);
+            Float tMax = (i % 5 == 0) ? Infinity : 4 * U();
+            Float t = tMax;
+            Ray q = T.ApplyInverse(Ray(o, d), &t);
+            // (ApplyInverse(Point3f) itself CHECKs through util/print.cpp, which needs the absent double-conversion library:
+            //  its arithmetic is the xp/yp/zp expression of the Point3fi form pinned here through the ray's origin)
+            Vector3f vq = T.ApplyInverse(d);
+            const SquareMatrix<4> &M = T.GetMatrix(), &MI = T.GetInverseMatrix();
+            sep(first); printf("[");
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { pf(M[r][c]); printf(","); }
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { pf(MI[r][c]); printf(","); }
+            pf(o.x); printf(","); pf(o.y); printf(","); pf(o.z); printf(",");
+            pf(d.x); printf(","); pf(d.y); printf(","); pf(d.z); printf(","); pf(tMax); printf(",");
+            pf(q.o.x); printf(","); pf(q.o.y); printf(","); pf(q.o.z); printf(","); pf(q.d.x); printf(","); pf(q.d.y); printf(","); pf(q.d.z); printf(","); pf(t); printf(",");
+            pf(vq.x); printf(","); pf(vq.y); printf(","); pf(vq.z); printf("]");
+        }
+        printf("],\n");
+    }
     // ---- SpawnRayTo(Point3fi pFrom, Normal3f nFrom, time, Point3fi pTo, Normal3f nTo) (ray.h:103-108): the NEE shadow
     //      ray, whose origin and direction seed the shadow ray's RNG (guidedvolpathvspgintegrator.cpp:1193) ----
     {

@@ -696,6 +696,52 @@ void oracle_apply_inverse_identity(const float o[3], const float d[3], float tMa
     out_o[0] = r.x; out_o[1] = r.y; out_o[2] = r.z;
     *out_tMax = tMax;
 }
+/* Transform::ApplyInverse(const Point3fi &) for an EXACT point (transform.cpp:263-303) then ApplyInverse(const Ray &, Float *tMax)
+ * (transform.h:416-429), general affine matrix mInv (row-major).  With the identity matrix every product is exact and
+ * the result equals apply_inverse_identity. */
+static v3 apply_inverse_ray(const float mi[16], v3 o, v3 d, float *tMax, v3 *d_out) {
+    const float g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS);
+    float x = o.x, y = o.y, z = o.z;
+    float xp = (mi[0] * x + mi[1] * y) + (mi[2] * z + mi[3]);
+    float yp = (mi[4] * x + mi[5] * y) + (mi[6] * z + mi[7]);
+    float zp = (mi[8] * x + mi[9] * y) + (mi[10] * z + mi[11]);
+    float wp = (mi[12] * x + mi[13] * y) + (mi[14] * z + mi[15]);
+    v3 oerr = V3(g3 * (fabsf(mi[0] * x) + fabsf(mi[1] * y) + fabsf(mi[2] * z)),
+                 g3 * (fabsf(mi[4] * x) + fabsf(mi[5] * y) + fabsf(mi[6] * z)),
+                 g3 * (fabsf(mi[8] * x) + fabsf(mi[9] * y) + fabsf(mi[10] * z)));
+    p3i oi = p3i_from_err(V3(xp, yp, zp), oerr);
+    (void)wp; /* affine matrices only: wp == 1, no division (vspg.h) */
+    v3 dd = V3(mi[0] * d.x + mi[1] * d.y + mi[2] * d.z, mi[4] * d.x + mi[5] * d.y + mi[6] * d.z, mi[8] * d.x + mi[9] * d.y + mi[10] * d.z);
+    float lengthSquared = v_len2(dd);
+    if (lengthSquared > 0) {
+        v3 oe = p3i_err(oi);
+        float dt = v_dot(v_abs(dd), oe) / lengthSquared;
+        v3 sh = v_scale(dd, dt);
+        oi.lo = V3(next_float_down(oi.lo.x + sh.x), next_float_down(oi.lo.y + sh.y), next_float_down(oi.lo.z + sh.z));
+        oi.hi = V3(next_float_up(oi.hi.x + sh.x), next_float_up(oi.hi.y + sh.y), next_float_up(oi.hi.z + sh.z));
+        *tMax -= dt;
+    }
+    *d_out = dd;
+    return p3i_mid(oi);
+}
+/* Transform::ApplyInverse(Point3<T>) (transform.h:387-398), affine */
+static v3 apply_inverse_point(const float mi[16], v3 p) {
+    float x = p.x, y = p.y, z = p.z;
+    return V3((mi[0] * x + mi[1] * y) + (mi[2] * z + mi[3]), (mi[4] * x + mi[5] * y) + (mi[6] * z + mi[7]),
+              (mi[8] * x + mi[9] * y) + (mi[10] * z + mi[11]));
+}
+void oracle_apply_inverse_ray(const float minv[16], const float o[3], const float d[3], float tMax, float out_o[3], float out_d[3],
+                              float *out_tMax) {
+    v3 dd;
+    v3 r = apply_inverse_ray(minv, v3_from(o), v3_from(d), &tMax, &dd);
+    out_o[0] = r.x; out_o[1] = r.y; out_o[2] = r.z;
+    out_d[0] = dd.x; out_d[1] = dd.y; out_d[2] = dd.z;
+    *out_tMax = tMax;
+}
+void oracle_apply_inverse_point(const float minv[16], const float p[3], float out[3]) {
+    v3 r = apply_inverse_point(minv, v3_from(p));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
 /* exported for the golden-vector test of Bounds3::Offset / IntersectP (tests/golden/primitives.json "bounds3") */
 int oracle_bounds3(const float bmin[3], const float bmax[3], const float o[3], const float d[3], float tMax, float t01[2],
                    float offset[3]) {
@@ -772,7 +818,9 @@ static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tM
         /* ray = renderFromMedium.ApplyInverse(ray, &raytMax) with an identity transform
          * (transform.h:416-429, transform.cpp:263-303): the origin picks up the conservative
          * error bound gamma(3)*|o| and is pushed along d by dt */
-        v3 ro = apply_inverse_identity(o, d, &tMax);
+        v3 ro;
+        if (m->has_transform) ro = apply_inverse_ray(m->medium_from_render, o, d, &tMax, &d); /* d: the medium-space direction from here on */
+        else ro = apply_inverse_identity(o, d, &tMax);
         float t0, t1;
         if (!bounds_intersect_p(m->bounds_min, m->bounds_max, ro, d, tMax, &t0, &t1)) return it;
         /* DDAMajorantIterator ctor (media.h:145-176) */
@@ -871,7 +919,8 @@ static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
     mp.Le = s_from(m->Le);
     mp.g = m->g;
     if (medium_is_grid_like(m->type)) {
-        /* identity renderFromMedium: ApplyInverse(Point3f) returns p unchanged */
+        /* p = renderFromMedium.ApplyInverse(p) (media.h:322 / :693); identity: p unchanged */
+        if (m->has_transform) p = apply_inverse_point(m->medium_from_render, p);
         float d;
         spec Le = S1(0.f);
         if (m->type == VSPG_MEDIUM_NANOVDB) { /* media.h:686-703 */

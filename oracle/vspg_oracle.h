@@ -76,6 +76,8 @@ int oracle_render_wave(OracleRenderer *r, int wave_start, int wave_end, int nthr
 int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int wave_start,
                          int wave_end, int nthreads);
 int oracle_post_process_wave(OracleRenderer *r);
+void oracle_apply_inverse_ray(const float minv[16], const float o[3], const float d[3], float tMax, float out_o[3], float out_d[3], float *out_tMax);
+void oracle_apply_inverse_point(const float minv[16], const float p[3], float out[3]);
 int oracle_isg_update_due(OracleRenderer *r, int n_waves);
 int oracle_post_process_step(OracleRenderer *r, int n_waves, const float *stats_sum);
 void oracle_film_read(OracleRenderer *r, float *rgbw /* W*H*4, from double accum */);

@@ -42,6 +42,8 @@ def load():
         "oracle_frame_xz": (None, [f3, f3, f3, f3, f3, f3]),
         "oracle_spawn_ray_to": (None, [f3, f3, f3, f3, f3, f3, f3, f3]),
         "oracle_apply_inverse_identity": (None, [f3, f3, C.c_float, f3, p(C.c_float)]),
+        "oracle_apply_inverse_ray": (None, [C.c_float * 16, f3, f3, C.c_float, f3, f3, p(C.c_float)]),
+        "oracle_apply_inverse_point": (None, [C.c_float * 16, f3, f3]),
         "oracle_bounds3": (C.c_int, [f3, f3, f3, f3, C.c_float, C.POINTER(C.c_float * 2), f3]),
         "oracle_independent_sampler": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, p(C.c_float)]),
         "oracle_renderer_create": (C.c_int, [p(P.VspgScene), p(P.VspgIntegratorParams), p(P.VspgRenderConfig), p(vp)]),

@@ -908,6 +908,92 @@ def test_nvdb_paths_and_film_vs_oracle(nvdb_pair):
 
 
 # ---------------------------------------------------------------------------------------------
+# non-identity renderFromMedium (media.h:322, :354; util/transform.h:387-429, transform.cpp:263-303)
+# ---------------------------------------------------------------------------------------------
+def _placed(P, scene, kind):
+    """rotate the cloud about a tilted axis, squash it and move it off-centre (still inside the box)"""
+    import math
+    ang = math.radians(33.0)
+    ax = np.array([0.3, 1.0, -0.2]); ax /= np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
+    S = np.diag([0.8, 0.6, 0.7])
+    M = np.eye(4)
+    M[:3, :3] = R @ S
+    M[:3, 3] = (0.1, -0.15, 0.2) if kind == "grid" else (0.05, 0.1, 0.15)
+    return P.set_medium_transform(scene, M.astype(np.float32))
+
+
+@pytest.mark.parametrize("kind", ["grid", "nvdb"])
+def test_transformed_medium_vs_oracle(gpu_pkg, kind):
+    """A grid medium PLACED with a rotation * scale * translation: free flight (3 variants), 20 000 paths, the film of every
+    kernel the library offers, all against the oracle -- whose ApplyInverse is pinned to the reference's by
+    tests/golden/primitives.json "apply_inverse_xform"."""
+    from scenes import cloud_density, grid_scene, nvdb_scene
+    P = gpu_pkg
+    W, H = 64, 48
+    dens = cloud_density(24)
+    if kind == "grid":
+        scene = grid_scene(dens, (24, 24, 24), 0.08, 7.9, g=0.6, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    else:
+        scene = nvdb_scene(dens, (24, 24, 24), 0.08, 7.9, g=0.6, index_min=(-3, 2, 0), voxel=(0.066, 0.0625, 0.058), origin=(-0.6, -0.93, -0.5),
+                           density_offset=0.01, majorant_scale=1.1, W=W, H=H)
+    _placed(P, scene, kind)
+    prm = P.app_f_params()
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=4)
+    g = P.Renderer(scene, prm, W, H, seed=4)
+    # the transform really changes the picture
+    plain = grid_scene(dens, (24, 24, 24), 0.08, 7.9, g=0.6, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H) if kind == "grid" else None
+    for variant in (0, 1, 2):
+        qs = _queries(P, 6000, 50 + variant)
+        go, co = g.sample_tmaj_batch(variant, qs), c.sample_tmaj_batch(variant, qs)
+        n_cb = 0
+        for a, b in zip(go, co):
+            assert a.n_callbacks == b.n_callbacks
+            assert a.last_t == b.last_t and list(a.T_maj) == list(b.T_maj) and list(a.r_u_factor) == list(b.r_u_factor)
+            n_cb += a.n_callbacks
+        assert n_cb > 500
+    rng = np.random.default_rng(23)
+    n = 20000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    if plain is not None:
+        p2 = P.Renderer(plain, prm, W, H, seed=4)
+        Lp, _ = p2.trace_paths(pix, si)
+        p2.close()
+        assert np.mean(np.all(Lp == Lg, axis=1)) < 0.5
+    for w in range(3):
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fc = c.film()
+    ic = fc[..., :3] / fc[..., 3:4]
+    g.close()
+    films = {}
+    for kernel in (None, "lane", "wg"):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=4)
+            for w in range(3):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            films[r.kernel_name()] = r.film()
+            r.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    print(kind, "kernels:", sorted(films))
+    assert len(films) >= 2
+    ref = next(iter(films.values()))
+    for name, fg in films.items():
+        assert np.array_equal(fg.view(np.uint32), ref.view(np.uint32)), name
+    ig = ref[..., :3] / ref[..., 3:4]
+    assert np.array_equal(ref[..., 3], fc[..., 3])
+    assert np.mean(np.all(np.abs(ig - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
+    c.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # guiding cache query (own design behind the restated GuidedBSDF / GuidedPhaseFunction logic)
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")

@@ -223,6 +223,32 @@ def test_apply_inverse_identity(oracle, pkg):
     assert moved > 20  # the shift is real
 
 
+def test_apply_inverse_general_transforms(oracle, pkg):
+    """Transform::ApplyInverse(Ray, &tMax) and ApplyInverse(Vector3f) of the REFERENCE for translations, scales, rotations and
+    their products (transform.h:401-429, transform.cpp:263-303) -- renderFromMedium of a placed grid medium (media.h:322, :354).
+    Each case carries the reference's own m and mInv.  The library's vspg_transform_inverse (used by callers that only have
+    m) must agree with the reference's inverse to rounding."""
+    lib = pkg.load()
+    moved = 0
+    for row in G["apply_inverse_xform"]:
+        v = [fh(t) if t not in ("inf", "-inf") else float(t) for t in row]
+        m, minv = v[0:16], v[16:32]
+        o, d, tMax = v[32:35], v[35:38], v[38]
+        want_o, want_d, want_t, want_v = v[39:42], v[42:45], v[45], v[46:49]
+        MI = (C.c_float * 16)(*minv)
+        out_o, out_d = pkg.f3(), pkg.f3()
+        t = C.c_float()
+        oracle.oracle_apply_inverse_ray(MI, f3(pkg, o), f3(pkg, d), C.c_float(tMax), out_o, out_d, C.byref(t))
+        assert all(same(a, b) for a, b in zip(out_o, want_o)), row
+        assert all(same(a, b) for a, b in zip(out_d, want_d)) and all(same(a, b) for a, b in zip(out_d, want_v)), row
+        assert same(t.value, want_t) or (np.isinf(want_t) and np.isinf(t.value)), row
+        moved += any(not same(a, b) for a, b in zip(out_o, o))
+        inv = (C.c_float * 16)()
+        assert lib.vspg_transform_inverse((C.c_float * 16)(*m), inv) == 0
+        assert np.allclose(list(inv), minv, rtol=2e-6, atol=2e-6), row
+    assert moved > 40
+
+
 def test_channel_idx():
     # spectrum.h:380-384: channelIdx = min(floor(3u), 2); the oracle inlines it in
     # evaluate_pixel_sample -- check the formula against the reference's outputs

@@ -46,12 +46,23 @@ class VspgMedium(C.Structure):
                 ("bounds_min", f3), ("bounds_max", f3), ("density", C.POINTER(C.c_float)),
                 ("index_min", C.c_int32 * 3), ("voxel_size", f3), ("grid_origin", f3),
                 ("density_offset", C.c_float), ("majorant_scale", C.c_float),
-                ("le_scale", C.POINTER(C.c_float)), ("le_nx", C.c_int32), ("le_ny", C.c_int32), ("le_nz", C.c_int32)]
+                ("le_scale", C.POINTER(C.c_float)), ("le_nx", C.c_int32), ("le_ny", C.c_int32), ("le_nz", C.c_int32),
+                ("has_transform", C.c_int32), ("render_from_medium", C.c_float * 16), ("medium_from_render", C.c_float * 16)]
+
+
+VSPG_MAX_INFINITE_LIGHTS = 4
+LIGHT_UNIFORM_INFINITE, LIGHT_DISTANT = 0, 1
+
+
+class VspgInfiniteLight(C.Structure):
+    _fields_ = [("type", C.c_int32), ("L", f3), ("w_light", f3)]
 
 
 class VspgScene(C.Structure):
     _fields_ = [("n_quads", C.c_int32), ("quads", VspgQuad * VSPG_MAX_QUADS),
-                ("camera", VspgCamera), ("medium", VspgMedium)]
+                ("camera", VspgCamera), ("medium", VspgMedium),
+                ("n_triangles", C.c_int32), ("tri_p", C.POINTER(C.c_float)), ("tri_kd", C.POINTER(C.c_float)),
+                ("n_infinite_lights", C.c_int32), ("infinite_lights", VspgInfiniteLight * VSPG_MAX_INFINITE_LIGHTS)]
 
 
 class VspgIntegratorParams(C.Structure):
@@ -138,6 +149,7 @@ SYMBOLS = [
     ("vspg_integrator_params_default", None, [_P(VspgIntegratorParams)]),
     ("vspg_camera_look_at", C.c_int, [_P(VspgCamera), f3, f3, f3, C.c_float, C.c_int, C.c_int]),
     ("vspg_scene_fog_box", C.c_int, [_P(VspgScene), C.c_int, C.c_int]),
+    ("vspg_transform_inverse", C.c_int, [C.c_float * 16, C.c_float * 16]),
     ("vspg_renderer_create", C.c_int, [_P(VspgScene), _P(VspgIntegratorParams), _P(VspgRenderConfig), _P(_vp)]),
     ("vspg_renderer_destroy", C.c_int, [_vp]),
     ("vspg_render_wave", C.c_int, [_vp, C.c_int, C.c_int, _vp]),
@@ -272,6 +284,19 @@ def nanovdb_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed
     m.density_offset = density_offset
     m.majorant_scale = majorant_scale
     return s
+
+
+def set_medium_transform(scene, m):
+    """renderFromMedium = the row-major 4x4 `m` (affine); the inverse is filled by vspg_transform_inverse."""
+    import numpy as np
+    lib = load()
+    a = (C.c_float * 16)(*[float(x) for x in np.asarray(m, dtype=np.float32).reshape(16)])
+    inv = (C.c_float * 16)()
+    _check(lib, lib.vspg_transform_inverse(a, inv))
+    scene.medium.has_transform = 1
+    scene.medium.render_from_medium[:] = list(a)
+    scene.medium.medium_from_render[:] = list(inv)
+    return scene
 
 
 def app_f_params():

@@ -1344,6 +1344,8 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
         D->grid_origin[k] = sc.medium.grid_origin[k];
     }
     D->density_offset = sc.medium.density_offset;
+    D->has_xform = sc.medium.has_transform ? 1 : 0;
+    for (int k = 0; k < 12; ++k) D->minv[k] = sc.medium.has_transform ? sc.medium.medium_from_render[k] : ((k % 5) == 0 ? 1.f : 0.f);
     D->nx = sc.medium.nx;
     D->ny = sc.medium.ny;
     D->nz = sc.medium.nz;
@@ -1455,6 +1457,13 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         if ((long long)m.nx * m.ny * m.nz > (1ll << 31)) return fail(VSPG_EINVAL, "density grid too large");
         for (int k = 0; k < 3; ++k)
             if (!(m.bounds_max[k] > m.bounds_min[k])) return fail(VSPG_EINVAL, "grid medium bounds must have positive extent");
+        if (m.has_transform) {
+            const float *a = m.render_from_medium, *b = m.medium_from_render;
+            if (a[12] != 0 || a[13] != 0 || a[14] != 0 || a[15] != 1 || b[12] != 0 || b[13] != 0 || b[14] != 0 || b[15] != 1)
+                return fail(VSPG_EINVAL, "renderFromMedium must be affine (last row 0 0 0 1)");
+            for (int k = 0; k < 16; ++k)
+                if (!(a[k] == a[k]) || !(b[k] == b[k])) return fail(VSPG_EINVAL, "renderFromMedium holds a NaN");
+        }
         if (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0) {
             if (m.type == VSPG_MEDIUM_NANOVDB)
                 return fail(VSPG_ESCOPE, "NanoVDBMedium emits through a temperature grid (blackbody emission): outside this build's scope");
@@ -1588,6 +1597,25 @@ int vspg_camera_look_at(VspgCamera *cam, const float eye[3], const float look[3]
     cam->ox = (float)(-wx * th);
     cam->sy = (float)(-2.0 * wy * th / yres);
     cam->oy = (float)(wy * th);
+    return 0;
+}
+
+int vspg_transform_inverse(const float m[16], float inv[16]) {
+    if (!m || !inv) return fail(VSPG_EINVAL, "null argument");
+    if (m[12] != 0 || m[13] != 0 || m[14] != 0 || m[15] != 1) return fail(VSPG_EINVAL, "affine matrices only (last row 0 0 0 1)");
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double A = e * i - f * h, B = -(d * i - f * g), Cc = d * h - e * g;
+    const double det = a * A + b * B + c * Cc;
+    if (det == 0 || det != det) return fail(VSPG_EINVAL, "singular matrix");
+    double r[9] = {A / det, -(b * i - c * h) / det, (b * f - c * e) / det, B / det, (a * i - c * g) / det, -(a * f - c * d) / det,
+                   Cc / det, -(a * h - b * g) / det, (a * e - b * d) / det};
+    const double t[3] = {m[3], m[7], m[11]};
+    for (int row = 0; row < 3; ++row) {
+        for (int col = 0; col < 3; ++col) inv[4 * row + col] = (float)r[3 * row + col];
+        inv[4 * row + 3] = (float)-(r[3 * row] * t[0] + r[3 * row + 1] * t[1] + r[3 * row + 2] * t[2]);
+    }
+    inv[12] = inv[13] = inv[14] = 0.f;
+    inv[15] = 1.f;
     return 0;
 }
 

@@ -487,6 +487,9 @@ struct DScene {
     const int32_t *brick_index;
     const float4 *octets;
     int32_t bnx, bny, bnz;
+    // renderFromMedium of grid media: rows 0..2 of mInv (row-major, affine), has_xform = 0: identity
+    int32_t has_xform;
+    float minv[12];
     // NanoVDB-semantics dense medium: index bbox min, 1 / voxel_size, world position of index (0,0,0), density offset
     int32_t index_min[3];
     float inv_voxel[3], grid_origin[3], density_offset;
@@ -754,6 +757,14 @@ struct GridMediumT {
     const float *le_scale;  // emissive GridMedium: LeScale grid (null = not emissive), its size, Le_spec
     int lnx, lny, lnz;
     Spec Le;
+    const float *minv;      // rows 0..2 of mInv when renderFromMedium is not the identity, else null (wave-uniform)
+
+    // Transform::ApplyInverse(Point3<T>) (util/transform.h:387-398), affine matrix
+    VDEV V3 to_medium(V3 p) const {
+        if (!minv) return p;
+        return V3{(minv[0] * p.x + minv[1] * p.y) + (minv[2] * p.z + minv[3]), (minv[4] * p.x + minv[5] * p.y) + (minv[6] * p.z + minv[7]),
+                  (minv[8] * p.x + minv[9] * p.y) + (minv[10] * p.z + minv[11])};
+    }
 
     struct Iter {  // DDAMajorantIterator
         Spec sigma_t;
@@ -856,11 +867,22 @@ struct GridMediumT {
     }
     VDEV Iter sample_ray(V3 o, V3 d, float raytMax) const {  // media.h:347-362
         Iter it = empty_iter();
-        // Transform::ApplyInverse(ray, &tMax), identity matrix (transform.h:416-429, transform.cpp:263-303):
-        // the origin carries the error bound gamma(3)*|o| and is pushed along d by dt
+        // ray = renderFromMedium.ApplyInverse(ray, &tMax) (transform.h:416-429, transform.cpp:263-303): the origin carries the
+        // error bound gamma(3) * sum |mInv[i][k] * o[k]| and is pushed along d by dt; from here on (o, d)
+        // is the medium-space ray -- its t parametrises the render-space ray too (affine map)
         const float g3 = (3 * kMachineEps) / (1 - 3 * kMachineEps);
-        V3 oerr = V3{g3 * (__builtin_fabsf(o.x) + 0.f + 0.f), g3 * (0.f + __builtin_fabsf(o.y) + 0.f),
-                     g3 * (0.f + 0.f + __builtin_fabsf(o.z))};
+        V3 oerr;
+        if (minv) {
+            const float x = o.x, y = o.y, z = o.z;
+            oerr = V3{g3 * (__builtin_fabsf(minv[0] * x) + __builtin_fabsf(minv[1] * y) + __builtin_fabsf(minv[2] * z)),
+                      g3 * (__builtin_fabsf(minv[4] * x) + __builtin_fabsf(minv[5] * y) + __builtin_fabsf(minv[6] * z)),
+                      g3 * (__builtin_fabsf(minv[8] * x) + __builtin_fabsf(minv[9] * y) + __builtin_fabsf(minv[10] * z))};
+            o = to_medium(o);
+            d = V3{minv[0] * d.x + minv[1] * d.y + minv[2] * d.z, minv[4] * d.x + minv[5] * d.y + minv[6] * d.z,
+                   minv[8] * d.x + minv[9] * d.y + minv[10] * d.z};
+        } else {
+            oerr = V3{g3 * (__builtin_fabsf(o.x) + 0.f + 0.f), g3 * (0.f + __builtin_fabsf(o.y) + 0.f), g3 * (0.f + 0.f + __builtin_fabsf(o.z))};
+        }
         P3i oi = p3i_from_err(o, oerr);
         float lengthSquared = len2(d);
         if (lengthSquared > 0) {
@@ -933,6 +955,7 @@ struct GridMediumT {
     VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703 (temperature grids are out of scope)
         float d;
         Spec le = sp(0.f);
+        p = to_medium(p);  // renderFromMedium.ApplyInverse(p) (media.h:322 / :693)
         if constexpr (NVDB) {
             const V3 xi = V3{(p.x - origin.x) * inv_voxel.x, (p.y - origin.y) * inv_voxel.y, (p.z - origin.z) * inv_voxel.z};
             d = lookup_index(xi);
@@ -961,7 +984,7 @@ template <bool NVDB, bool GREY>
 VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
     return GridMediumT<NVDB, GREY>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
                              majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
-                             S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le)};
+                             S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le), S.has_xform ? S.minv : nullptr};
 }
 template <class M> struct MediumMaker;
 template <int GREY, bool NZ> struct MediumMaker<HomogeneousMediumT<GREY, NZ>> {
