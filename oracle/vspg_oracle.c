@@ -436,9 +436,21 @@ typedef struct {
 typedef struct {
     int hit;
     float t;
-    int quad;
+    int quad;   /* rectangle index, or -1 when `tri` names a triangle */
+    int tri;    /* triangle (index into r->tris), -1 for a rectangle hit */
     v3 p, n;
+    v3 perr;    /* error bound of p */
 } isect_t;
+
+/* f1: a triangle of the soup with what Triangle::InteractionFromIntersection derives from its vertices (shapes.h:888-938) */
+typedef struct {
+    v3 p0, p1, p2;
+    v3 n;       /* Normalize(Cross(p0 - p2, p1 - p2)) */
+    v3 dpdu_n;  /* Normalize(dpdu), default (u,v) parameterisation */
+    spec Kd;
+    int id;
+    int has_bsdf_lobes;
+} rtri_t;
 
 static void quad_init(rquad_t *q, const VspgQuad *in) {
     q->p00 = v3_from(in->p00);
@@ -497,6 +509,8 @@ struct OracleRenderer {
     VspgRenderConfig cfg;
     int n_quads;
     rquad_t quads[VSPG_MAX_QUADS];
+    rtri_t *tris; /* non-degenerate triangles of the soup, caller's order */
+    int n_tris;
     int n_lights;
     int light_quads[VSPG_MAX_QUADS];
     /* guiding fields (copies): [0] surface, [1] volume; nodes == NULL -> untrained */
@@ -552,16 +566,99 @@ typedef struct {
 static _Thread_local uint32_t g_dbg_flags;
 #define DBG(f) (g_dbg_flags |= (f))
 
-/* closest hit over all quads (stands in for Integrator::Intersect, integrators.cpp:341-349) */
+/* IntersectTriangle (shapes.cpp:168-262) */
+static float max3abs(float a, float b, float c) {
+    float m = fabsf(a);
+    m = m < fabsf(b) ? fabsf(b) : m;
+    return m < fabsf(c) ? fabsf(c) : m;
+}
+static float v_comp(v3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+static int tri_intersect(v3 o, v3 d, float tMax, v3 p0, v3 p1, v3 p2, float *t_out, float b_out[3]) {
+    if (v_len2(v_cross(v_sub(p2, p0), v_sub(p1, p0))) == 0) return 0;
+    v3 p0t = v_sub(p0, o), p1t = v_sub(p1, o), p2t = v_sub(p2, o);
+    v3 ad = v_abs(d);
+    int kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    v3 dp = V3(v_comp(d, kx), v_comp(d, ky), v_comp(d, kz));
+    p0t = V3(v_comp(p0t, kx), v_comp(p0t, ky), v_comp(p0t, kz));
+    p1t = V3(v_comp(p1t, kx), v_comp(p1t, ky), v_comp(p1t, kz));
+    p2t = V3(v_comp(p2t, kx), v_comp(p2t, ky), v_comp(p2t, kz));
+    float Sx = -dp.x / dp.z, Sy = -dp.y / dp.z, Sz = 1 / dp.z;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = diff_of_products(p1t.x, p2t.y, p1t.y, p2t.x);
+    float e1 = diff_of_products(p2t.x, p0t.y, p2t.y, p0t.x);
+    float e2 = diff_of_products(p0t.x, p1t.y, p0t.y, p1t.x);
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+        double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return 0;
+    float det = e0 + e1 + e2;
+    if (det == 0) return 0;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < tMax * det)) return 0;
+    else if (det > 0 && (tScaled <= 0 || tScaled > tMax * det)) return 0;
+    float invDet = 1 / det;
+    float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    float t = tScaled * invDet;
+    const float g2 = (2 * MACHINE_EPS) / (1 - 2 * MACHINE_EPS), g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS),
+                g5 = (5 * MACHINE_EPS) / (1 - 5 * MACHINE_EPS);
+    float maxZt = max3abs(p0t.z, p1t.z, p2t.z);
+    float deltaZ = g3 * maxZt;
+    float maxXt = max3abs(p0t.x, p1t.x, p2t.x), maxYt = max3abs(p0t.y, p1t.y, p2t.y);
+    float deltaX = g5 * (maxXt + maxZt), deltaY = g5 * (maxYt + maxZt);
+    float deltaE = 2 * (g2 * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    float maxE = max3abs(e0, e1, e2);
+    float deltaT = 3 * (g3 * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * fabsf(invDet);
+    if (t <= deltaT) return 0;
+    *t_out = t; b_out[0] = b0; b_out[1] = b1; b_out[2] = b2;
+    return 1;
+}
+/* closest hit (stands in for Integrator::Intersect -> BVHAggregate::Intersect, integrators.cpp:341-349, cpu/aggregates.cpp:529-590):
+ * rectangles first, then EVERY triangle against the rectangles' closest distance (brute force: no BVH on this side);
+ * equal distances go to the smaller triangle index -- the device's BVH traversal applies the same rule, so the visiting
+ * order never matters.  (The reference's traversal lets the LAST visited of equal distances win: ties are measure-zero.) */
 static isect_t scene_intersect(const OracleRenderer *r, v3 o, v3 d, float tMax) {
     isect_t best;
     memset(&best, 0, sizeof best);
     best.t = tMax;
+    best.tri = -1;
     for (int i = 0; i < r->n_quads; ++i) {
         float t;
         v3 p;
         if (quad_intersect(&r->quads[i], o, d, best.t, &t, &p)) {
             best.hit = 1; best.t = t; best.quad = i; best.p = p; best.n = r->quads[i].n;
+        }
+    }
+    best.perr = r->quads[best.quad].perr;
+    if (r->n_tris > 0) {
+        const float tRect = best.t;
+        int found = 0, bi = -1;
+        float bt = 0, bb[3] = {0, 0, 0};
+        for (int i = 0; i < r->n_tris; ++i) {
+            float t, b[3];
+            const rtri_t *T = &r->tris[i];
+            if (tri_intersect(o, d, tRect, T->p0, T->p1, T->p2, &t, b) && t < tRect &&
+                (!found || t < bt || (t == bt && T->id < r->tris[bi].id))) {
+                found = 1; bi = i; bt = t; bb[0] = b[0]; bb[1] = b[1]; bb[2] = b[2];
+            }
+        }
+        if (found) {
+            const rtri_t *T = &r->tris[bi];
+            best.hit = 1; best.t = bt; best.quad = -1; best.tri = bi;
+            best.p = v_add(v_add(v_scale(T->p0, bb[0]), v_scale(T->p1, bb[1])), v_scale(T->p2, bb[2])); /* shapes.h:922 */
+            v3 sum = v_add(v_add(v_abs(v_scale(T->p0, bb[0])), v_abs(v_scale(T->p1, bb[1]))), v_abs(v_scale(T->p2, bb[2])));
+            const float g7 = (7 * MACHINE_EPS) / (1 - 7 * MACHINE_EPS);
+            best.perr = V3(g7 * sum.x, g7 * sum.y, g7 * sum.z); /* shapes.h:929-930 */
+            best.n = T->n;
         }
     }
     return best;
@@ -571,6 +668,11 @@ static int scene_intersect_any(const OracleRenderer *r, v3 o, v3 d, float tMax) 
         float t;
         v3 p;
         if (quad_intersect(&r->quads[i], o, d, tMax, &t, &p)) return 1;
+    }
+    for (int i = 0; i < r->n_tris; ++i) {
+        float t, b[3];
+        const rtri_t *T = &r->tris[i];
+        if (tri_intersect(o, d, tMax, T->p0, T->p1, T->p2, &t, b) && t < tMax) return 1;
     }
     return 0;
 }
@@ -605,7 +707,7 @@ static int majiter_next(majiter_t *it, majseg_t *seg) {
     }
     if (medium_is_grid_like(it->type)) { /* DDAMajorantIterator::Next (media.h:178-207) */
         const int MR = medium_maj_res(it->type);
-        if (it->tMin >= it->tMax) return 0;
+        if (!(it->tMin < it->tMax)) return 0; /* == the reference's `tMin >= tMax` for ordered values; a NaN ray ends here instead of leaving the grid */
         int bits = ((it->nextCrossingT[0] < it->nextCrossingT[1]) << 2) +
                    ((it->nextCrossingT[0] < it->nextCrossingT[2]) << 1) +
                    ((it->nextCrossingT[1] < it->nextCrossingT[2]));
@@ -1221,6 +1323,15 @@ static bsdf_t bsdf_make(const rquad_t *q) {
     b.frame.y = v_cross(q->n, q->dpdu_n);
     b.R = q->Kd;
     b.has_lobes = q->has_bsdf_lobes;
+    return b;
+}
+static bsdf_t bsdf_make_tri(const rtri_t *T) {
+    bsdf_t b;
+    b.frame.x = T->dpdu_n;
+    b.frame.z = T->n;
+    b.frame.y = v_cross(T->n, T->dpdu_n);
+    b.R = T->Kd;
+    b.has_lobes = T->has_bsdf_lobes;
     return b;
 }
 static spec bsdf_f(const bsdf_t *b, v3 woR, v3 wiR) {
@@ -2144,9 +2255,9 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         rec_add_transmittance_weight(rec, transmittanceWeight); /* :350 */
         if (!si.hit) break; /* no infinite lights in scope (:353-374) */
 
-        const rquad_t *q = &r->quads[si.quad];
-        /* isect.Le(-ray.d) (:377-397) */
-        spec Le = q->is_light ? light_L(q, si.n, v_neg(rd)) : S1(0.f);
+        const rquad_t *q = &r->quads[si.tri >= 0 ? 0 : si.quad];
+        /* isect.Le(-ray.d) (:377-397); triangles carry no area light */
+        spec Le = si.tri < 0 && q->is_light ? light_L(q, si.n, v_neg(rd)) : S1(0.f);
         int add_direct_contribution = 0;
         float w_direct = 0.f;
         if (s_nonzero(Le)) {
@@ -2164,7 +2275,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
                 w_direct = w_l;
             }
         }
-        bsdf_t bsdf = bsdf_make(q);
+        bsdf_t bsdf = si.tri >= 0 ? bsdf_make_tri(&r->tris[si.tri]) : bsdf_make(q);
         rec_new_segment(rec, v_add(ro, v_scale(rd, si.t)), 0); /* guiding_newSurfacePathSegment (:406) */
         if (add_direct_contribution) rec_add_surface_emission(rec, Le, w_direct); /* :409-412 */
         if (depth == 0) {
@@ -2186,7 +2297,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         intr_t intr;
         memset(&intr, 0, sizeof intr);
         intr.is_surface = 1;
-        p3i pi = p3i_from_err(si.p, q->perr); /* SurfaceInteraction pi (shapes.h InteractionFromIntersection) */
+        p3i pi = p3i_from_err(si.p, si.perr); /* SurfaceInteraction pi (shapes.h InteractionFromIntersection) */
         intr.pi = pi; intr.n = si.n;
         intr.wo = v_normalize(v_neg(rd)); /* Interaction ctor normalises wo (interaction.h:31-32) */
         intr.bsdf = &bsdf;
@@ -2833,6 +2944,35 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
         quad_init(&r->quads[i], &scene->quads[i]);
         if (r->quads[i].is_light) r->light_quads[r->n_lights++] = i;
     }
+    if (scene->n_triangles > 0 && scene->tri_p) { /* f1: what InteractionFromIntersection derives per triangle (shapes.h:888-938) */
+        r->tris = (rtri_t *)calloc((size_t)scene->n_triangles, sizeof(rtri_t));
+        for (int i = 0; i < scene->n_triangles; ++i) {
+            const float *q = scene->tri_p + 9 * (size_t)i;
+            v3 p0 = V3(q[0], q[1], q[2]), p1 = V3(q[3], q[4], q[5]), p2 = V3(q[6], q[7], q[8]);
+            if (v_len2(v_cross(v_sub(p2, p0), v_sub(p1, p0))) == 0) continue; /* IntersectTriangle never reports it */
+            v3 dp02 = v_sub(p0, p2), dp12 = v_sub(p1, p2);
+            const float duv02[2] = {0.f - 1.f, 0.f - 1.f}, duv12[2] = {1.f - 1.f, 0.f - 1.f}; /* default uv (0,0), (1,0), (1,1) */
+            float determinant = diff_of_products(duv02[0], duv12[1], duv02[1], duv12[0]);
+            if (fabsf(determinant) < 1e-9f) continue;
+            float invdet = 1 / determinant;
+            v3 dpdu = V3(diff_of_products(duv12[1], dp02.x, duv02[1], dp12.x) * invdet, diff_of_products(duv12[1], dp02.y, duv02[1], dp12.y) * invdet,
+                         diff_of_products(duv12[1], dp02.z, duv02[1], dp12.z) * invdet);
+            v3 dpdv = V3(diff_of_products(duv02[0], dp12.x, duv12[0], dp02.x) * invdet, diff_of_products(duv02[0], dp12.y, duv12[0], dp02.y) * invdet,
+                         diff_of_products(duv02[0], dp12.z, duv12[0], dp02.z) * invdet);
+            if (v_len2(v_cross(dpdu, dpdv)) == 0) continue; /* (the reference's CoordinateSystem fallback: such slivers are dropped on both sides) */
+            rtri_t *T = &r->tris[r->n_tris++];
+            T->p0 = p0; T->p1 = p1; T->p2 = p2;
+            T->n = v_normalize(v_cross(dp02, dp12));
+            T->dpdu_n = v_normalize(dpdu);
+            T->id = i;
+            for (int k = 0; k < 3; ++k) {
+                float v = scene->tri_kd ? scene->tri_kd[3 * (size_t)i + k] : 0.5f;
+                T->Kd.c[k] = v < 0 ? 0 : (v > 1 ? 1 : v);
+            }
+            T->has_bsdf_lobes = T->Kd.c[0] != 0 || T->Kd.c[1] != 0 || T->Kd.c[2] != 0;
+        }
+        r->scene.tri_p = NULL; r->scene.tri_kd = NULL;
+    }
     if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;
         size_t n = (size_t)m->nx * m->ny * m->nz;
@@ -2888,7 +3028,7 @@ void oracle_renderer_destroy(OracleRenderer *r) {
     free_field(r, 0); free_field(r, 1);
     free(r->samples);
     free(r->trbuf); free(r->tr_spp); free(r->le_scale); free(r->contrib);
-    free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r);
+    free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r->tris); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {
     size_t n = (size_t)r->cfg.xres * r->cfg.yres * 4;

@@ -133,3 +133,39 @@ def nvdb_scene(density, n, sigma_a, sigma_s, g=0.0, index_min=(0, 0, 0), voxel=(
     m.density_offset = density_offset
     m.majorant_scale = majorant_scale
     return s
+
+
+def heightfield_triangles(n, x0=-1.0, x1=1.0, z0=-1.0, z1=1.0, y=-0.7, amp=0.25, seed=2):
+    """2 n^2 triangles of a bumpy terrain over [x0,x1] x [z0,z1] around height y (smooth low-frequency bumps + fine ripples)."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(x0, x1, n + 1, dtype=np.float32)
+    zs = np.linspace(z0, z1, n + 1, dtype=np.float32)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    ph = rng.uniform(0, 6.28, 6)
+    Y = (y + amp * (0.5 * np.sin(3.1 * X + ph[0]) * np.cos(2.3 * Z + ph[1]) + 0.3 * np.sin(7.7 * X + 5.1 * Z + ph[2]) +
+                    0.08 * np.sin(31 * X + ph[3]) * np.sin(29 * Z + ph[4]))).astype(np.float32)
+    P = np.stack([X, Y, Z], -1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t1 = np.stack([a, c, b], -2)   # faces +y
+    t2 = np.stack([a, d, c], -2)
+    tris = np.concatenate([t1.reshape(-1, 3, 3), t2.reshape(-1, 3, 3)], 0).astype(np.float32)
+    kd = np.tile(np.array([[0.6, 0.45, 0.3]], dtype=np.float32), (tris.shape[0], 1))
+    kd[::3] = (0.3, 0.5, 0.6)
+    return np.ascontiguousarray(tris), np.ascontiguousarray(kd)
+
+
+def box_wall_triangles():
+    """The five non-emissive walls of the App.-F box ... plus the wall behind the camera, as 12 triangles (Kd .73)."""
+    def quad(p, e1, e2):
+        p, e1, e2 = (np.array(v, dtype=np.float32) for v in (p, e1, e2))
+        a, b, c, d = p, p + e1, p + e1 + e2, p + e2
+        return [np.stack([a, b, c]), np.stack([a, c, d])]
+    tris = []
+    tris += quad((-1, -1, -1), (0, 0, 2), (2, 0, 0))   # floor
+    tris += quad((-1, 1, -1), (2, 0, 0), (0, 0, 2))    # ceiling
+    tris += quad((-1, -1, 1), (0, 2, 0), (2, 0, 0))    # back
+    tris += quad((-1, -1, -1), (2, 0, 0), (0, 2, 0))   # front
+    tris += quad((-1, -1, -1), (0, 2, 0), (0, 0, 2))   # left
+    tris += quad((1, -1, -1), (0, 0, 2), (0, 2, 0))    # right
+    tris = np.stack(tris).astype(np.float32)
+    return tris, np.full((tris.shape[0], 3), 0.73, dtype=np.float32)

@@ -994,6 +994,136 @@ def test_transformed_medium_vs_oracle(gpu_pkg, kind):
 
 
 # ---------------------------------------------------------------------------------------------
+# f1: triangle geometry behind a BVH (shapes.cpp:168-262, shapes.h:883-1010, cpu/aggregates.cpp:529-640)
+# ---------------------------------------------------------------------------------------------
+def _light_only(P, scene):
+    """keep only the emissive rectangle of the fog box (the walls come as triangles)"""
+    light = type(scene.quads[6]).from_buffer_copy(scene.quads[6])
+    for i in range(P.VSPG_MAX_QUADS):
+        scene.quads[i] = type(light)()
+    scene.quads[0] = light
+    scene.n_quads = 1
+    return scene
+
+
+def test_triangle_box_matches_rectangle_box(gpu_pkg):
+    """The box's walls as a 12-triangle soup: bit-identical to the oracle (which tests every triangle, no BVH), and the same
+    picture as the rectangle box up to noise (hit points differ in the last bits: b0 p0 + b1 p1 + b2 p2 vs p00 + u e1 + v e2)."""
+    from scenes import box_wall_triangles
+    P = gpu_pkg
+    W, H = 64, 48
+    prm = P.app_f_params()
+    scene = _light_only(P, P.fog_box_scene(W, H))
+    tris, kd = box_wall_triangles()
+    P.set_triangles(scene, tris, kd)
+    g = P.Renderer(scene, prm, W, H, seed=1)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=1)
+    rng = np.random.default_rng(31)
+    n = 20000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    for w in range(8):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fg, fc = g.film(), c.film()
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    assert np.mean(np.all(np.abs(ig - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
+    rect = P.Renderer(P.fog_box_scene(W, H), prm, W, H, seed=1)
+    Lr, sr = rect.trace_paths(pix, si)
+    rect.close()
+    print("triangle box vs rectangle box: mean radiance %.4f vs %.4f, same segment counts %.4f" % (Lg.mean(), Lr.mean(), np.mean(sg == sr)))
+    assert abs(Lg.mean() / Lr.mean() - 1) < 0.03 and np.mean(sg == sr) > 0.9
+    g.close(); c.close()
+
+
+@pytest.mark.parametrize("medium", ["fog", "cloud"])
+def test_triangle_terrain_vs_oracle(gpu_pkg, medium):
+    """A 20 000-triangle terrain in the box (homogeneous fog: per-lane kernel; heterogeneous cloud: the wavefront pipeline
+    and the per-lane kernel): paths and film bit-identical to the oracle's brute-force intersection."""
+    from scenes import cloud_density, grid_scene, heightfield_triangles
+    P = gpu_pkg
+    W, H = 64, 48
+    prm = P.app_f_params()
+    if medium == "fog":
+        scene = P.fog_box_scene(W, H)
+    else:
+        dens = cloud_density(24)
+        scene = grid_scene(dens, (24, 24, 24), 0.08, 7.9, g=0.6, bmin=(-0.8, -0.5, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    tris, kd = heightfield_triangles(100)
+    assert tris.shape[0] == 20000
+    P.set_triangles(scene, tris, kd)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=6)
+    g = P.Renderer(scene, prm, W, H, seed=6)
+    rng = np.random.default_rng(37)
+    n = 3000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    cnt = g.counters()
+    g.render_wave(0, 1)
+    film = g.film()
+    names = {g.kernel_name()}
+    # every pixel of the film equals its replayed path (and with it the oracle's path, sampled above)
+    xy = np.stack(np.meshgrid(np.arange(W), np.arange(H), indexing="xy"), -1).reshape(-1, 2).astype(np.int32)
+    L0, _ = g.trace_paths(xy, np.zeros(len(xy), dtype=np.int32))
+    assert np.array_equal(film[..., :3].reshape(-1, 3).view(np.uint32), L0.astype(np.float32).view(np.uint32))
+    Lc0, _ = c.trace_paths(xy[::7], np.zeros(len(xy[::7]), dtype=np.int32))
+    assert np.array_equal(L0[::7].view(np.uint32), Lc0.view(np.uint32))
+    g.close()
+    if medium == "cloud":
+        os.environ["VSPG_KERNEL"] = "lane"
+        try:
+            g2 = P.Renderer(scene, prm, W, H, seed=6)
+            g2.render_wave(0, 1)
+            names.add(g2.kernel_name())
+            assert np.array_equal(g2.film().view(np.uint32), film.view(np.uint32))
+            g2.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+        assert len(names) == 2
+    # the terrain is really hit: the picture differs from the empty box
+    e = P.Renderer(P.fog_box_scene(W, H) if medium == "fog" else grid_scene(cloud_density(24), (24, 24, 24), 0.08, 7.9, g=0.6, bmin=(-0.8, -0.5, -0.5),
+                                                                          bmax=(0.8, 0.7, 0.9), W=W, H=H), prm, W, H, seed=6)
+    e.render_wave(0, 1)
+    assert np.mean(np.all(e.film() == film, axis=-1)) < 0.95
+    e.close(); c.close()
+
+
+def test_hundred_thousand_triangles(gpu_pkg):
+    """SURVEY 8f row 1's size: 100 352 triangles at 256 x 192, fog; the film equals the replayed paths, sampled paths equal the
+    oracle's (brute force over all triangles), guided configurations are refused."""
+    from scenes import heightfield_triangles
+    P = gpu_pkg
+    W, H = 256, 192
+    prm = P.app_f_params()
+    scene = P.fog_box_scene(W, H)
+    tris, kd = heightfield_triangles(224)
+    assert tris.shape[0] == 100352
+    P.set_triangles(scene, tris, kd)
+    g = P.Renderer(scene, prm, W, H, seed=8)
+    g.render_wave(0, 1)
+    film = g.film()
+    assert g.counters()["paths"] == W * H
+    rng = np.random.default_rng(41)
+    n = 4000
+    xy = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    L, sg = g.trace_paths(xy, np.zeros(n, dtype=np.int32))
+    assert np.array_equal(film[xy[:, 1], xy[:, 0], :3].view(np.uint32), L.astype(np.float32).view(np.uint32))
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=8)
+    Lc, sc = c.trace_paths(xy[:300], np.zeros(300, dtype=np.int32))
+    assert np.array_equal(sg[:300], sc) and np.array_equal(L[:300].view(np.uint32), Lc.view(np.uint32))
+    g.close(); c.close()
+    with pytest.raises(P.VspgError) as e:
+        P.Renderer(scene, P.default_params(), W, H)
+    assert e.value.code == P.VSPG_ESCOPE
+
+
+# ---------------------------------------------------------------------------------------------
 # guiding cache query (own design behind the restated GuidedBSDF / GuidedPhaseFunction logic)
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")

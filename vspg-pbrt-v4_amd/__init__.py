@@ -13,7 +13,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvspg_hip.so")
+LIB_PATH = os.environ.get("VSPG_LIB") or os.path.join(_HERE, "csrc", "libvspg_hip.so")  # VSPG_LIB: experiment builds (scripts/)
 
 VSPG_MAX_QUADS = 16
 VSPG_ISG_STATS = 8
@@ -296,6 +296,21 @@ def set_medium_transform(scene, m):
     scene.medium.has_transform = 1
     scene.medium.render_from_medium[:] = list(a)
     scene.medium.medium_from_render[:] = list(inv)
+    return scene
+
+
+def set_triangles(scene, tri_p, tri_kd=None):
+    """Attach a triangle soup (n x 3 x 3 vertex array, optional n x 3 diffuse reflectances) to the scene."""
+    import numpy as np
+    tp = np.ascontiguousarray(tri_p, dtype=np.float32).reshape(-1, 9)
+    scene.n_triangles = tp.shape[0]
+    scene.tri_p = tp.ctypes.data_as(C.POINTER(C.c_float))
+    scene._tri_keepalive = [tp]
+    if tri_kd is not None:
+        tk = np.ascontiguousarray(tri_kd, dtype=np.float32).reshape(-1, 3)
+        assert tk.shape[0] == tp.shape[0]
+        scene.tri_kd = tk.ctypes.data_as(C.POINTER(C.c_float))
+        scene._tri_keepalive.append(tk)
     return scene
 
 

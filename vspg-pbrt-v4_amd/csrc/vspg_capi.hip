@@ -11,6 +11,7 @@
 #include <string>
 #include <type_traits>
 #include <vector>
+#include <algorithm>
 
 #include "vspg_path.h"
 #include "vspg_wg_kernel.h"
@@ -1222,6 +1223,8 @@ struct VspgRenderer {
     size_t n_bricks = 0;
     float *le_scale = nullptr;  // emissive GridMedium: LeScale grid
     float *majorant = nullptr;  // 16^3 majorant grid
+    DTri *tris = nullptr;          // triangle soup in BVH leaf order + the BVH (depth-first, skip links)
+    DBvhNode *bvh = nullptr;
     // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
     float *wf_pool = nullptr;
     unsigned int *wf_lists = nullptr;   // 4 x n_items: active, vertex, walk, shadow
@@ -1391,6 +1394,100 @@ static std::vector<float> build_majorant_grid(const VspgMedium &m) {
     return maj;
 }
 
+// ---- f1: BVH over the triangle soup (own builder: binned SAH on centroids, leaves of <= 4 triangles, depth-first
+// layout with skip links -- see DBvhNode).  cpu/aggregates.cpp:529-640 is what it stands in for; WHICH triangles a ray
+// tests never changes a result (vspg_device.h: bvh_closest), so the builder is free.
+namespace bvhbuild {
+struct Box { float lo[3], hi[3]; };
+static Box empty_box() { return Box{{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}}; }
+static void grow(Box &b, const float *p) { for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], p[k]); b.hi[k] = std::max(b.hi[k], p[k]); } }
+static void merge(Box &b, const Box &o) { for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); } }
+static float area(const Box &b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx < 0 ? 0.f : 2 * (dx * dy + dy * dz + dz * dx);
+}
+struct Builder {
+    const float *p;                 // 9 floats per triangle
+    std::vector<int> order;         // triangle indices, permuted in place
+    std::vector<Box> tbox;
+    std::vector<float> cen;         // 3 per triangle
+    std::vector<DBvhNode> nodes;
+    void build(int lo, int hi) {
+        const int me = (int)nodes.size();
+        nodes.push_back(DBvhNode{});
+        Box b = empty_box(), cb = empty_box();
+        for (int i = lo; i < hi; ++i) { merge(b, tbox[order[i]]); grow(cb, &cen[3 * order[i]]); }
+        for (int k = 0; k < 3; ++k) { nodes[me].bmin[k] = b.lo[k]; nodes[me].bmax[k] = b.hi[k]; }
+        const int n = hi - lo;
+        int axis = 0;
+        for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+        const float ext = cb.hi[axis] - cb.lo[axis];
+        int mid = -1;
+        if (n > 4 && ext > 0) {
+            constexpr int NB = 16;
+            Box bb[NB]; int cnt[NB];
+            for (int i = 0; i < NB; ++i) { bb[i] = empty_box(); cnt[i] = 0; }
+            auto bin_of = [&](int t) { int k = (int)(NB * ((cen[3 * t + axis] - cb.lo[axis]) / ext)); return k < 0 ? 0 : (k >= NB ? NB - 1 : k); };
+            for (int i = lo; i < hi; ++i) { const int k = bin_of(order[i]); cnt[k]++; merge(bb[k], tbox[order[i]]); }
+            float best = kInf; int bs = -1;
+            for (int s = 0; s < NB - 1; ++s) {
+                Box l = empty_box(), rr = empty_box(); int nl = 0, nr = 0;
+                for (int i = 0; i <= s; ++i) { merge(l, bb[i]); nl += cnt[i]; }
+                for (int i = s + 1; i < NB; ++i) { merge(rr, bb[i]); nr += cnt[i]; }
+                if (!nl || !nr) continue;
+                const float c = nl * area(l) + nr * area(rr);
+                if (c < best) { best = c; bs = s; }
+            }
+            if (bs >= 0) {
+                auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](int t) { return bin_of(t) <= bs; });
+                mid = (int)(it - order.begin());
+            }
+        }
+        if (n > 7 && (mid <= lo || mid >= hi)) {  // no useful split but too many for a leaf: median by index
+            mid = lo + n / 2;
+            std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
+                             [&](int a, int c) { return cen[3 * a + axis] < cen[3 * c + axis]; });
+        }
+        if (mid > lo && mid < hi) {
+            nodes[me].leaf = -1;
+            build(lo, mid);
+            build(mid, hi);
+        } else {
+            nodes[me].leaf = lo * 8 + n;  // n <= 7
+        }
+        nodes[me].skip = (int)nodes.size();
+    }
+};
+}  // namespace bvhbuild
+
+// what Triangle::InteractionFromIntersection derives from the vertices alone (shapes.h:888-938), same float operations
+static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T) {
+    using namespace hostmath;
+    const H3 p0 = ld(p9), p1 = ld(p9 + 3), p2 = ld(p9 + 6);
+    auto sub = [](H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    if (len2v(crossv(sub(p2, p0), sub(p1, p0))) == 0) return false;  // IntersectTriangle: degenerate -> never hit (shapes.cpp:172-173)
+    const H3 dp02 = sub(p0, p2), dp12 = sub(p1, p2);
+    // default (u,v) = (0,0), (1,0), (1,1): duv02 = (-1,-1), duv12 = (0,-1)
+    const float duv02[2] = {0.f - 1.f, 0.f - 1.f}, duv12[2] = {1.f - 1.f, 0.f - 1.f};
+    const float determinant = dop(duv02[0], duv12[1], duv02[1], duv12[0]);
+    H3 dpdu{0, 0, 0}, dpdv{0, 0, 0};
+    const bool degenerateUV = std::fabs(determinant) < 1e-9f;
+    if (!degenerateUV) {
+        const float invdet = 1 / determinant;
+        dpdu = H3{dop(duv12[1], dp02.x, duv02[1], dp12.x) * invdet, dop(duv12[1], dp02.y, duv02[1], dp12.y) * invdet, dop(duv12[1], dp02.z, duv02[1], dp12.z) * invdet};
+        dpdv = H3{dop(duv02[0], dp12.x, duv12[0], dp02.x) * invdet, dop(duv02[0], dp12.y, duv12[0], dp02.y) * invdet, dop(duv02[0], dp12.z, duv12[0], dp02.z) * invdet};
+    }
+    if (degenerateUV || len2v(crossv(dpdu, dpdv)) == 0) return false;  // (the reference falls back to CoordinateSystem(ng); such slivers are dropped here)
+    const H3 n = normv(crossv(dp02, dp12));
+    memset(T, 0, sizeof *T);
+    stv(T->p0, p0); stv(T->p1, p1); stv(T->p2, p2);
+    T->nx = n.x; T->ny = n.y; T->nz = n.z;
+    stv(T->dpdu_n, normv(dpdu));
+    T->id = id;
+    for (int k = 0; k < 3; ++k) { float v = kd ? kd[3 * id + k] : 0.5f; T->Kd[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+    return true;
+}
+
 static bool wants_guiding(const VspgIntegratorParams &p) {
     return p.surfaceguiding || p.volumeguiding || (p.vspguiding && p.vspsecondaryguiding) || p.rrguiding;  // guided kernels
 }
@@ -1472,6 +1569,10 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         }
     } else if (scene->medium.type != VSPG_MEDIUM_NONE && scene->medium.type != VSPG_MEDIUM_HOMOGENEOUS)
         return fail(VSPG_EINVAL, "unknown medium type");
+    if (scene->n_triangles < 0 || scene->n_triangles > (1 << 27)) return fail(VSPG_EINVAL, "n_triangles out of range");
+    if (scene->n_triangles > 0 && !scene->tri_p) return fail(VSPG_EINVAL, "triangles without vertex data");
+    if (scene->n_triangles > 0 && wants_guiding(*p))
+        return fail(VSPG_ESCOPE, "triangle geometry with the directional guiding cache is outside this build's scope");
     int nl = 0;
     for (int i = 0; i < scene->n_quads; ++i)
         if (scene->quads[i].Le[0] != 0 || scene->quads[i].Le[1] != 0 || scene->quads[i].Le[2] != 0) nl++;
@@ -1746,6 +1847,41 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         }
         r->scene.medium.le_scale = nullptr;
     }
+    if (scene->n_triangles > 0) {
+        std::vector<DTri> all;
+        all.reserve(scene->n_triangles);
+        for (int i = 0; i < scene->n_triangles; ++i) {
+            DTri T;
+            if (derive_triangle(scene->tri_p + 9 * (size_t)i, scene->tri_kd, i, &T)) all.push_back(T);
+        }
+        if (!all.empty()) {
+            bvhbuild::Builder B;
+            B.order.resize(all.size());
+            B.tbox.resize(all.size());
+            B.cen.resize(3 * all.size());
+            for (size_t i = 0; i < all.size(); ++i) {
+                B.order[i] = (int)i;
+                bvhbuild::Box b = bvhbuild::empty_box();
+                bvhbuild::grow(b, all[i].p0); bvhbuild::grow(b, all[i].p1); bvhbuild::grow(b, all[i].p2);
+                B.tbox[i] = b;
+                for (int k = 0; k < 3; ++k) B.cen[3 * i + k] = 0.5f * (b.lo[k] + b.hi[k]);
+            }
+            B.nodes.reserve(2 * all.size());
+            B.build(0, (int)all.size());
+            std::vector<DTri> sorted(all.size());
+            for (size_t i = 0; i < all.size(); ++i) sorted[i] = all[B.order[i]];
+            CK(hipMalloc(&r->tris, sorted.size() * sizeof(DTri)));
+            CK(hipMemcpy(r->tris, sorted.data(), sorted.size() * sizeof(DTri), hipMemcpyHostToDevice));
+            CK(hipMalloc(&r->bvh, B.nodes.size() * sizeof(DBvhNode)));
+            CK(hipMemcpy(r->bvh, B.nodes.data(), B.nodes.size() * sizeof(DBvhNode), hipMemcpyHostToDevice));
+            r->hscene.n_tris = (int32_t)sorted.size();
+            r->hscene.n_bvh_nodes = (int32_t)B.nodes.size();
+            r->hscene.tris = r->tris;
+            r->hscene.bvh = r->bvh;
+        }
+        r->scene.tri_p = nullptr;  // the host arrays belong to the caller
+        r->scene.tri_kd = nullptr;
+    }
     CK(hipMalloc(&r->dscene, sizeof(DScene)));
     CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
     CK(hipMalloc(&r->film, r->npix * sizeof(float4)));
@@ -1855,6 +1991,8 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_hist) (void)hipFree(r->train_hist);
     if (r->train_cursor) (void)hipFree(r->train_cursor);
     if (r->train_nsorted) (void)hipFree(r->train_nsorted);
+    if (r->tris) (void)hipFree(r->tris);
+    if (r->bvh) (void)hipFree(r->bvh);
     if (r->wf_pool) (void)hipFree(r->wf_pool);
     if (r->wf_lists) (void)hipFree(r->wf_lists);
     if (r->wf_iters) (void)hipFree(r->wf_iters);
@@ -1879,6 +2017,7 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
     const char *kenv = getenv("VSPG_KERNEL");
     const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
     // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
+    if (r->hscene.n_tris > 0) return false;  // triangle hits carry a per-hit error bound the LDS pool record has no room for
     return !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
 }
 // "wf" = the multi-kernel wavefront pipeline (vspg_wavefront.h): heterogeneous media whose every segment runs the
@@ -1936,12 +2075,38 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const bool guided = wants_guiding(r->prm);
     if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but the renderer holds no guiding field");
     if (uses_wf_pipeline(r)) {  // one pass per sample index of this shard, in order
+#ifdef VSPG_WF_DEBUG
+        auto checksum = [&](const void *dptr, size_t bytes) -> unsigned long long {
+            if (!dptr || !bytes) return 0ull;
+            std::vector<unsigned char> h(bytes);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h.data(), dptr, bytes, hipMemcpyDeviceToHost);
+            unsigned long long x = 1469598103934665603ull;
+            for (size_t i = 0; i < bytes; ++i) { x ^= h[i]; x *= 1099511628211ull; }
+            return x;
+        };
+        const size_t nb = (size_t)r->hscene.bnx * r->hscene.bny * r->hscene.bnz;
+        const void *bufs[6] = {r->tris, r->bvh, r->brick_index, r->octets, r->dscene, r->majorant};
+        const size_t sizes[6] = {(size_t)r->hscene.n_tris * sizeof(DTri), (size_t)r->hscene.n_bvh_nodes * sizeof(DBvhNode), nb * 4, r->n_bricks * 512 * 32,
+                                 sizeof(DScene), (size_t)16 * 16 * 16 * 4};
+        unsigned long long before[6];
+        for (int k = 0; k < 6; ++k) before[k] = checksum(bufs[k], sizes[k]);
+#endif
         for (int w = first; w < wave_end; w += sc > 1 ? sc : 1) {
             const int rc = nvdb ? wf_render_pass<NanoDenseMedium>(r, w, (hipStream_t)stream)
                                 : (r->medium_grey ? wf_render_pass<GridMediumGrey>(r, w, (hipStream_t)stream)
                                                   : wf_render_pass<GridMedium>(r, w, (hipStream_t)stream));
             if (rc) return rc;
         }
+#ifdef VSPG_WF_DEBUG
+        {
+            const char *names[6] = {"tris", "bvh", "brick_index", "octets", "dscene", "majorant"};
+            for (int k = 0; k < 6; ++k)
+                if (checksum(bufs[k], sizes[k]) != before[k]) fprintf(stderr, "VSPG_WF_DEBUG: the pipeline changed %s (%zu bytes at %p)\n", names[k], sizes[k], bufs[k]);
+            fprintf(stderr, "VSPG_WF_DEBUG: pool %p..%p lists %p film %p isg %p tris %p bvh %p\n", (void *)r->wf_pool,
+                    (void *)((char *)r->wf_pool + (size_t)WF_COUNT * r->wf_items * 4), (void *)r->wf_lists, (void *)r->film, (void *)r->isg_stats, (void *)r->tris, (void *)r->bvh);
+        }
+#endif
         return 0;
     }
     // a18: while the field trains, the guided kernels record path segments and emit radiance samples
@@ -2504,6 +2669,13 @@ int vspg_libm_log1m_batch(VspgRenderer *r, int n, const float *x, float *out, vo
     return 0;
 }
 
+#ifdef VSPG_WF_DEBUG
+int vspg_dbg_read(unsigned int *out8) {  // diagnostic build only
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg_err), 8 * sizeof(unsigned int)));
+    return 0;
+}
+#endif
 #ifdef VSPG_PROFILE
 // diagnostic build only: dump and clear the per-section counters
 int vspg_prof_read(unsigned long long *out /* PS_COUNT*3 */, int *n_sections) {

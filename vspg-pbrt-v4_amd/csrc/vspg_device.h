@@ -15,6 +15,12 @@
 #include "vspg_libm.h"
 
 #define VDEV __device__ __forceinline__
+#ifdef VSPG_WF_DEBUG  // diagnostic build only: out-of-range accesses are clamped and flagged instead of faulting
+__device__ unsigned int g_dbg_err[8];
+#define VSPG_DBG_CHECK(cond, bit) do { if (!(cond)) atomicOr(&g_dbg_err[0], 1u << (bit)); } while (0)
+#else
+#define VSPG_DBG_CHECK(cond, bit)
+#endif
 // leaf functions with small interfaces.  Measured on MI355X (round 1): as real calls
 // (-DVSPG_NOINLINE_LEAVES) k_render_wave drops from 248 to 220 VGPRs but runs 8 % slower at the same
 // 2 waves/SIMD, and the 168-VGPR build (3 waves/SIMD) still spills 101 registers and is 17 % slower,
@@ -456,8 +462,31 @@ struct DField {
     // (k_field_aux) instead of once per lobe per mixture evaluation (an IEEE division and a FastExp each)
     const float *aux;
 };
+// Triangle geometry.  DTri: the three vertices plus what Triangle::InteractionFromIntersection
+// (shapes.h:883-1010) derives from them alone -- n = Normalize(Cross(p0 - p2, p1 - p2)) and the normalised dpdu of the
+// default (u,v) parameterisation -- computed once on the host with the same float operations.  80 bytes = five 16-byte loads.
+struct DTri {
+    float p0[3], nx;
+    float p1[3], ny;
+    float p2[3], nz;
+    float dpdu_n[3];
+    int32_t id;      // index in the caller's soup (the tie-break of equal hit distances)
+    float Kd[3];
+    int32_t pad;
+};
+// BVH in depth-first order (own builder, vspg_capi.hip): an inner node's first child is the next node; `skip` is where
+// the traversal continues when the node is missed or its subtree is done -- no stack, no per-lane scratch.
+struct DBvhNode {
+    float bmin[3];
+    int32_t skip;
+    float bmax[3];
+    int32_t leaf;    // >= 0: first triangle * 8 + count (1..7); -1: inner node
+};
 struct DScene {
     int32_t n_quads, n_lights;
+    int32_t n_tris, n_bvh_nodes;
+    const DTri *tris;          // in BVH leaf order
+    const DBvhNode *bvh;
     DField field[2];
     IsectRec irec[VSPG_MAX_QUADS];
     int32_t light_quads[VSPG_MAX_QUADS];
@@ -546,12 +575,17 @@ VDEV void stage_scene_lds(const DScene &S) {
 VDEV const DQuad &quad_at(int i) { return s_scene_quads[i]; }
 VDEV const DQuad &light_quad_at(int lightIndex) { return s_scene_quads[s_scene_light_quads[lightIndex]]; }
 
+// `quad`: rectangle index >= 0, or -2 - (triangle position in S.tris) for a triangle hit; perr = the hit point's error
+// bound (rectangles: the rectangle's constant one; triangles: gamma(7) * (|b0 p0| + |b1 p1| + |b2 p2|), shapes.h:929-930)
 struct Isect {
     bool hit;
     float t;
     int quad;
     V3 p, n;
+    V3 perr;
 };
+VDEV bool is_tri(int prim) { return prim <= -2; }
+VDEV int tri_of(int prim) { return -2 - prim; }
 
 // ray / rectangle (own geometry stand-in, contract in DESIGN.md): plane hit t = n.(p00-o)/n.d,
 // accepted when 0 < t < tMax and the parametric (u,v) of o+t*d lie in [0,1]^2; the reported point
@@ -627,6 +661,136 @@ VDEV bool quad_intersect(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, V3
     *pHit = quad_point(q, u, v);
     return true;
 }
+// ---------------------------------------------------------------------------------------
+// f1: triangles.  IntersectTriangle (shapes.cpp:168-262) restated; the BVH only decides WHICH triangles are tested.
+// ---------------------------------------------------------------------------------------
+struct TriHit { float t, b0, b1, b2; };
+VDEV V3 permute3(V3 v, int kx, int ky, int kz) { return V3{comp(v, kx), comp(v, ky), comp(v, kz)}; }
+VDEV float max3abs(float a, float b, float c) { return fmax_(fmax_(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)); }
+VDEV bool tri_intersect(V3 o, V3 d, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit) {
+    if (len2(cross(p2 - p0, p1 - p0)) == 0) return false;
+    V3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    const V3 ad = vabs(d);
+    const int kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxComponentIndex (vecmath.h:454-456)
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    const V3 dp = permute3(d, kx, ky, kz);
+    p0t = permute3(p0t, kx, ky, kz); p1t = permute3(p1t, kx, ky, kz); p2t = permute3(p2t, kx, ky, kz);
+    const float Sx = -dp.x / dp.z, Sy = -dp.y / dp.z, Sz = 1 / dp.z;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = diff_of_products(p1t.x, p2t.y, p1t.y, p2t.x);
+    float e1 = diff_of_products(p2t.x, p0t.y, p2t.y, p0t.x);
+    float e2 = diff_of_products(p0t.x, p1t.y, p0t.y, p1t.x);
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // double-precision test at triangle edges
+        const double p2txp1ty = (double)p2t.x * (double)p1t.y, p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        const double p0txp2ty = (double)p0t.x * (double)p2t.y, p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        const double p1txp0ty = (double)p1t.x * (double)p0t.y, p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    const float det = e0 + e1 + e2;
+    if (det == 0) return false;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    const float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0 && (tScaled >= 0 || tScaled < tMax * det)) return false;
+    else if (det > 0 && (tScaled <= 0 || tScaled > tMax * det)) return false;
+    const float invDet = 1 / det;
+    const float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+    const float t = tScaled * invDet;
+    // ensure that the computed t is conservatively greater than zero (shapes.cpp:237-256)
+    constexpr float g2 = (2 * kMachineEps) / (1 - 2 * kMachineEps), g3 = (3 * kMachineEps) / (1 - 3 * kMachineEps),
+                    g5 = (5 * kMachineEps) / (1 - 5 * kMachineEps);
+    const float maxZt = max3abs(p0t.z, p1t.z, p2t.z);
+    const float deltaZ = g3 * maxZt;
+    const float maxXt = max3abs(p0t.x, p1t.x, p2t.x), maxYt = max3abs(p0t.y, p1t.y, p2t.y);
+    const float deltaX = g5 * (maxXt + maxZt), deltaY = g5 * (maxYt + maxZt);
+    const float deltaE = 2 * (g2 * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+    const float maxE = max3abs(e0, e1, e2);
+    const float deltaT = 3 * (g3 * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * __builtin_fabsf(invDet);
+    if (t <= deltaT) return false;
+    hit->t = t; hit->b0 = b0; hit->b1 = b1; hit->b2 = b2;
+    return true;
+}
+// slab test for the traversal only: a conservative SUPERSET test (every triangle whose hit distance is <= tLimit lies in a
+// box this accepts), so which boxes are visited never changes a result
+VDEV bool bvh_box_hit(const float4 &lo, const float4 &hi, V3 o, V3 inv, float tLimit) {
+    float t0 = 0.f, t1 = tLimit;
+    float a = (lo.x - o.x) * inv.x, b = (hi.x - o.x) * inv.x;
+    t0 = fmax_(t0, fmin_(a, b)); t1 = fmin_(t1, fmax_(a, b) * 1.00001f);
+    a = (lo.y - o.y) * inv.y; b = (hi.y - o.y) * inv.y;
+    t0 = fmax_(t0, fmin_(a, b)); t1 = fmin_(t1, fmax_(a, b) * 1.00001f);
+    a = (lo.z - o.z) * inv.z; b = (hi.z - o.z) * inv.z;
+    t0 = fmax_(t0, fmin_(a, b)); t1 = fmin_(t1, fmax_(a, b) * 1.00001f);
+    return !(t0 > t1);  // NaN (0 * inf on a slab boundary) keeps the node
+}
+// closest triangle hit with distance < tMax: every triangle is tested against the RAY's tMax (never against the running
+// closest distance -- the test's acceptance would then depend on the visiting order), candidates compare by (t, id)
+VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, TriHit *best) {
+    const V3 inv = V3{1 / d.x, 1 / d.y, 1 / d.z};
+    bool found = false;
+    int best_id = 0x7fffffff;
+    float limit = tMax;
+    int i = 0;
+    while (i < S.n_bvh_nodes) {
+        const float4 *nd = reinterpret_cast<const float4 *>(S.bvh + i);
+        const float4 lo = nd[0], hi = nd[1];
+        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+        // cull with slack: the box may touch the triangle exactly where it is hit
+        if (bvh_box_hit(lo, hi, o, inv, found ? limit * 1.00001f : limit)) {
+            if (leaf >= 0) {
+                const int first = leaf >> 3, cnt = leaf & 7;
+                for (int k = 0; k < cnt; ++k) {
+                    const DTri &T = S.tris[first + k];
+                    TriHit h;
+                    if (tri_intersect(o, d, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax &&
+                        (!found || h.t < best->t || (h.t == best->t && T.id < best_id))) {
+                        found = true;
+                        *best = h;
+                        best_id = T.id;
+                        *tri_pos = first + k;
+                        limit = h.t;
+                    }
+                }
+                i = skip;
+            } else {
+                i = i + 1;
+            }
+        } else {
+            i = skip;
+        }
+    }
+    return found;
+}
+VDEV bool bvh_any(const DScene &S, V3 o, V3 d, float tMax) {
+    const V3 inv = V3{1 / d.x, 1 / d.y, 1 / d.z};
+    int i = 0;
+    while (i < S.n_bvh_nodes) {
+        const float4 *nd = reinterpret_cast<const float4 *>(S.bvh + i);
+        const float4 lo = nd[0], hi = nd[1];
+        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
+        if (bvh_box_hit(lo, hi, o, inv, tMax)) {
+            if (leaf >= 0) {
+                const int first = leaf >> 3, cnt = leaf & 7;
+                for (int k = 0; k < cnt; ++k) {
+                    const DTri &T = S.tris[first + k];
+                    TriHit h;
+                    if (tri_intersect(o, d, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax) return true;
+                }
+                i = skip;
+            } else {
+                i = i + 1;
+            }
+        } else {
+            i = skip;
+        }
+    }
+    return false;
+}
+
 VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     Isect best;
     best.hit = false;
@@ -646,6 +810,23 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     const DQuad &q = quad_at(best.quad);  // per-lane index: LDS copy
     best.p = quad_point(q, bu, bv);
     best.n = ld3(q.n);
+    best.perr = ld3(q.perr);
+    if (S.n_tris > 0) {  // wave-uniform: rectangles win ties (they are tested first, strictly closer)
+        int tp = 0;
+        TriHit h;
+        if (bvh_closest(S, o, d, best.t, &tp, &h)) {
+            const DTri &T = S.tris[tp];
+            const V3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
+            best.hit = true;
+            best.t = h.t;
+            best.quad = -2 - tp;
+            best.p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;  // pHit = b0 p0 + b1 p1 + b2 p2 (shapes.h:922)
+            const V3 s = vabs(p0 * h.b0) + vabs(p1 * h.b1) + vabs(p2 * h.b2);
+            constexpr float g7 = (7 * kMachineEps) / (1 - 7 * kMachineEps);
+            best.perr = V3{g7 * s.x, g7 * s.y, g7 * s.z};
+            best.n = V3{T.nx, T.ny, T.nz};
+        }
+    }
     return best;
 }
 VLEAF bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
@@ -654,6 +835,7 @@ VLEAF bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
         float t, u, v;
         any = any || rect_hit_uv(S.irec[i], o, d, tMax, &t, &u, &v);
     }
+    if (S.n_tris > 0 && !any) any = bvh_any(S, o, d, tMax);
     return any;
 }
 
@@ -775,11 +957,22 @@ struct GridMediumT {
         int vx, vy, vz;       // voxel
         int neg;              // bit a set: step[a] == -1 (voxelLimit -1), else +1 (voxelLimit res)
         VDEV bool next(MajSeg *s) {  // media.h:178-207
-            if (tMin >= tMax) return false;
+            // `!(tMin < tMax)` == the reference's `tMin >= tMax` for every ordered pair; a NaN ray (the reference would walk
+            // its majorant grid out of bounds) ends the iteration instead
+            if (!(tMin < tMax)) return false;
             int bits = ((ncx < ncy) << 2) + ((ncx < ncz) << 1) + ((ncy < ncz));
             int stepAxis = (0xA66 >> (2 * bits)) & 3;  // cmpToAxis[8] = {2,1,2,1,2,2,0,0}
             float nc = sel3(ncx, ncy, ncz, stepAxis);
             float tVoxelExit = fmin_(tMax, nc);
+            VSPG_DBG_CHECK((unsigned)vx < (unsigned)kRes && (unsigned)vy < (unsigned)kRes && (unsigned)vz < (unsigned)kRes, 2);
+#ifdef VSPG_WF_DEBUG
+            if (!((unsigned)vx < (unsigned)kRes && (unsigned)vy < (unsigned)kRes && (unsigned)vz < (unsigned)kRes)) {
+                g_dbg_err[2] = (unsigned)vx; g_dbg_err[3] = (unsigned)vy; g_dbg_err[4] = (unsigned)vz; g_dbg_err[5] = (unsigned)neg;
+                g_dbg_err[6] = __float_as_uint(tMin); g_dbg_err[7] = __float_as_uint(tMax);
+                tMin = tMax;
+                return false;
+            }
+#endif
             float md = maj[vx + kRes * (vy + kRes * vz)];
             s->tMin = tMin;
             s->tMax = tVoxelExit;
@@ -812,6 +1005,10 @@ struct GridMediumT {
         Octet o{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if ((unsigned)ox <= (unsigned)nx && (unsigned)oy <= (unsigned)ny && (unsigned)oz <= (unsigned)nz) {
             const int b = brick_index[((oz >> 3) * bny + (oy >> 3)) * bnx + (ox >> 3)];
+            VSPG_DBG_CHECK(b < 1 << 20, 1);
+#ifdef VSPG_WF_DEBUG
+            if (b >= 1 << 20) return o;
+#endif
             if (b >= 0) {
                 const float4 *q = octets + ((size_t)b * 512u + (size_t)((ox & 7) + 8 * ((oy & 7) + 8 * (oz & 7)))) * 2u;
                 const float4 lo = q[0], hi = q[1];

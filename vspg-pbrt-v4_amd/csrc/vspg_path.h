@@ -25,6 +25,15 @@ VDEV Bsdf bsdf_make(const DQuad &q) {
     b.has_lobes = q.has_lobes != 0;
     return b;
 }
+VDEV Bsdf bsdf_make_tri(const DTri &T) {  // DiffuseMaterial on a triangle: BSDF(ns, dpdus) with ns = n, dpdus = dpdu (shapes.h:933-938)
+    Bsdf b;
+    b.frame.x = ld3(T.dpdu_n);
+    b.frame.z = V3{T.nx, T.ny, T.nz};
+    b.frame.y = cross(b.frame.z, b.frame.x);
+    b.R = lds(T.Kd);
+    b.has_lobes = T.Kd[0] != 0 || T.Kd[1] != 0 || T.Kd[2] != 0;
+    return b;
+}
 VDEV Spec bsdf_f(const Bsdf &b, V3 woR, V3 wiR) {
     V3 wi = b.frame.to_local(wiR), wo = b.frame.to_local(woR);
     if (wo.z == 0) return sp(0.f);
@@ -105,12 +114,17 @@ struct LsCtx {  // LightSampleContext
 struct PrevCtx {
     V3 p;
     int quad;
-    VDEV LsCtx expand() const {
+    V3 perr;  // triangle vertices only (a rectangle's bound is a constant of the rectangle)
+    VDEV LsCtx expand(const DScene &S) const {
         LsCtx c;
         if (quad >= 0) {
             const DQuad &q = quad_at(quad);
             c.pi = p3i_from_err(p, ld3(q.perr));
             c.n = ld3(q.n);
+        } else if (is_tri(quad)) {
+            const DTri &T = S.tris[tri_of(quad)];
+            c.pi = p3i_from_err(p, perr);
+            c.n = V3{T.nx, T.ny, T.nz};
         } else {
             c.pi = p3i_exact(p);
             c.n = mk(0, 0, 0);
@@ -595,8 +609,9 @@ struct Vertex {
     bool volume;
     V3 p;      // volume: scatter position; surface: re-projected hit point (si.p)
     float g;   // volume: HG asymmetry
-    int quad;  // surface: rectangle index
+    int quad;  // surface: rectangle index, or -2 - triangle (Isect::quad)
     float t;   // surface: tHit (only the guided build needs it, for p = ray.o + tHit * ray.d)
+    V3 perr;   // surface: error bound of p (Isect::perr)
 };
 
 // the part of the path-loop iteration between distance sampling and the vertex, for a path that reached
@@ -607,15 +622,15 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
     VSPG_PROF(PS_SURF_PRE);
     if constexpr (kRec) pc.rec.add_transmittance_weight(tw);  // :350
     if (!si.hit) return false;  // no infinite lights in scope (:353-374)
-    const DQuad &q = quad_at(si.quad);
-    Spec Le = q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377
+    const DQuad &q = quad_at(is_tri(si.quad) ? 0 : si.quad);
+    Spec Le = !is_tri(si.quad) && q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377 (triangles carry no area light)
     float w_direct = 0.f;
     if (nonzero(Le)) {
         if (st.depth == 0 || st.specularBounce) {
             st.L = st.L + st.beta * Le / avg(st.r_u);
             w_direct = 1.0f;
         } else {
-            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx.expand(), st.rd);
+            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx.expand(S), st.rd);
             st.r_l = st.r_l * lightPDF;
             float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
             st.L = st.L + st.beta * w_l * Le;
@@ -651,6 +666,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
     vx.g = 0;
     vx.quad = si.quad;
     vx.t = si.t;
+    vx.perr = si.perr;
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     Spec tw = sp(1.f);  // transmittanceWeight (:317)
     if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
@@ -688,7 +704,7 @@ struct VertexCtx {
     Bsdf bsdf;
 };
 template <bool GREY_KD = false>
-VDEV void vertex_setup(const PathState &st, const Vertex &vx, VertexCtx &c) {
+VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, VertexCtx &c) {
     Isect &si = c.si;
     Intr &intr = c.intr;
     Bsdf &bsdf = c.bsdf;
@@ -709,11 +725,18 @@ VDEV void vertex_setup(const PathState &st, const Vertex &vx, VertexCtx &c) {
         intr.g = vg;
         bsdf.has_lobes = false;
     } else {
-        const DQuad &q = quad_at(vx.quad);
-        si.n = ld3(q.n);
-        bsdf = bsdf_make<GREY_KD>(q);
+        if (is_tri(vx.quad)) {
+            const DTri &T = S.tris[tri_of(vx.quad)];
+            si.n = V3{T.nx, T.ny, T.nz};
+            bsdf = bsdf_make_tri(T);
+        } else {
+            const DQuad &q = quad_at(vx.quad);
+            si.n = ld3(q.n);
+            bsdf = bsdf_make<GREY_KD>(q);
+        }
+        si.perr = vx.perr;
         intr.is_surface = true;
-        intr.pi = p3i_from_err(si.p, ld3(q.perr));
+        intr.pi = p3i_from_err(si.p, vx.perr);
         intr.n = si.n;
         intr.wo = normalize(-st.rd);  // Interaction ctor normalises wo (interaction.h:31-32)
         intr.g = 0;
@@ -754,6 +777,7 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
         VSPG_PROF(PS_SURF_SAMPLE);
         st.prevCtx.p = si.p;  // :487 LightSampleContext(isect)
         st.prevCtx.quad = vx.quad;
+        st.prevCtx.perr = vx.perr;
         (void)sampler.get1d();  // u (unused by DiffuseBxDF)
         float u20 = sampler.get1d(), u21 = sampler.get1d();
         // BSDF::Sample_f / DiffuseBxDF::Sample_f (bsdf.h:58-78, bxdfs.h:47-58)
@@ -815,7 +839,7 @@ template <class Medium, bool GUIDED = false, class PC>
 VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                        const Vertex &vx, float *glds = nullptr, int gstride = 0) {
     VertexCtx c;
-    vertex_setup<(Medium::kGrey >= 2)>(st, vx, c);
+    vertex_setup<(Medium::kGrey >= 2)>(S, st, vx, c);
     if constexpr (GUIDED)
         return li_vertex_guided<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, glds, gstride);
     const float survivalProb = vertex_pre(S, st, sampler, vx);
@@ -911,6 +935,7 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
     } else {
         st.prevCtx.p = si.p;
         st.prevCtx.quad = si.quad;
+        st.prevCtx.perr = si.perr;
     }
     const V3 wo = -st.rd;
     float usel = 0;  // surface: the MIS selector u; volume: u0 doubles as selector
@@ -1132,6 +1157,7 @@ VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, P
     st.r_l = sp(1.f);
     st.prevCtx.p = mk(0, 0, 0);
     st.prevCtx.quad = -1;
+    st.prevCtx.perr = mk(0, 0, 0);
     st.depth = 0;
     st.specularBounce = false;
     st.anyNonSpecularBounces = false;

@@ -80,7 +80,9 @@ enum {
     WF_SRL = 100,     // 3  ... r_l
     WF_SRU = 104,     // 3  ... r_u
     WF_STMAJ = 108,   // 3  ... residual T_maj
-    WF_COUNT = 112
+    WF_PCE = 112,     // 3  previous light-sample context: error bound (triangle vertices)
+    WF_VXE = 116,     // 3  vertex: error bound of the hit point
+    WF_COUNT = 120
 };
 enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_NODIST = 1 << 20,    // no SampleDistance this segment (no medium / the ray escapes)
@@ -95,7 +97,12 @@ enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
 struct WfPool {
     float *base;
     size_t n;
-    VDEV size_t at(int field, unsigned slot) const { return ((size_t)(field >> 2) * n + slot) * 4u + (size_t)(field & 3); }
+    VDEV size_t at(int field, unsigned slot) const {
+#ifdef VSPG_WF_DEBUG
+        if (slot >= n) { atomicOr(&g_dbg_err[0], 1u); atomicMax(&g_dbg_err[1], slot); slot = 0; }
+#endif
+        return ((size_t)(field >> 2) * n + slot) * 4u + (size_t)(field & 3);
+    }
     VDEV float &f(int field, unsigned slot) const { return base[at(field, slot)]; }
     VDEV int &i(int field, unsigned slot) const { return reinterpret_cast<int *>(base)[at(field, slot)]; }
     VDEV uint32_t &u(int field, unsigned slot) const { return reinterpret_cast<uint32_t *>(base)[at(field, slot)]; }
@@ -170,16 +177,18 @@ struct WfStage {
         base = __shfl(base, leader);
         if (pred) buf[base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = slot;
     }
-    // every thread of the workgroup calls this (two barriers)
+    // every thread of the workgroup calls this (three barriers).  The counter is reset BETWEEN the second and the third
+    // barrier, when every thread has read it and nobody can push yet: resetting it after the last barrier raced with the
+    // next round's pushes of faster wavefronts (lost and duplicated list entries).
     VDEV void flush(unsigned int *list, unsigned int *gcount, unsigned int *s_base) const {
         __syncthreads();
         const unsigned int c = *cnt;
         if (threadIdx.x == 0 && c) *s_base = atomicAdd(gcount, c);
         __syncthreads();
         const unsigned int b = *s_base;
+        if (threadIdx.x == 0) *cnt = 0;
         for (unsigned int i = threadIdx.x; i < c; i += blockDim.x) list[b + i] = buf[i];
         __syncthreads();
-        if (threadIdx.x == 0) *cnt = 0;
     }
 };
 
@@ -199,6 +208,7 @@ VDEV void wf_store_path(const WfPool &P, unsigned slot, const PathState &st, con
     }
     P.set3(WF_PCP, slot, st.prevCtx.p);
     P.i(WF_PCQ, slot) = st.prevCtx.quad;
+    if (is_tri(st.prevCtx.quad)) P.set3(WF_PCE, slot, st.prevCtx.perr);
     P.store_rng(WF_RNG, slot, sampler.rng);
     P.u(WF_FLAGS, slot) = pool_pack_flags(st, ch, isg, extra_flags);
     P.f(WF_RRC, slot) = st.rr_correction;
@@ -219,6 +229,7 @@ VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sample
     }
     st.prevCtx.p = P.v3(WF_PCP, slot);
     st.prevCtx.quad = P.i(WF_PCQ, slot);
+    st.prevCtx.perr = is_tri(st.prevCtx.quad) ? P.v3(WF_PCE, slot) : mk(0, 0, 0);
     P.load_rng(WF_RNG, slot, sampler.rng);
     const uint32_t fl = P.u(WF_FLAGS, slot);
     st.depth = (int)(fl & FL_DEPTH_MASK);
@@ -488,8 +499,9 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                 vx.g = vx.volume ? P.f(WF_VXG, slot) : 0.f;
                 vx.quad = vx.volume ? -1 : P.i(WF_VXG, slot);
                 vx.t = P.f(WF_VXT, slot);
+                vx.perr = vx.volume ? mk(0, 0, 0) : (is_tri(vx.quad) ? P.v3(WF_VXE, slot) : ld3(quad_at(vx.quad).perr));
                 VertexCtx c;
-                vertex_setup<false>(st, vx, c);
+                vertex_setup<false>(S, st, vx, c);
                 if (fl & WFL_NEE) {
                     Spec Ld = sp(0.f);
                     if (fl & (WFL_SHADOW_WALK | WFL_SHADOW_CLEAR)) {
@@ -519,6 +531,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                 P.set3(WF_VXP, slot, si.p);
                 P.i(WF_VXG, slot) = si.quad;
                 P.f(WF_VXT, slot) = si.t;
+                if (is_tri(si.quad)) P.set3(WF_VXE, slot, si.perr);
                 if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
                     Rng rng;
                     {
@@ -764,13 +777,22 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_seg_end(WfArgs a, int it) {
             si.quad = P.i(WF_VXG, slot);
             si.t = P.f(WF_VXT, slot);
             si.p = P.v3(WF_VXP, slot);
-            si.n = ld3(quad_at(si.quad).n);
+            if (is_tri(si.quad)) {
+                const DTri &T = S.tris[tri_of(si.quad)];
+                si.n = V3{T.nx, T.ny, T.nz};
+                si.perr = P.v3(WF_VXE, slot);
+            } else {
+                const DQuad &q = quad_at(si.quad);
+                si.n = ld3(q.n);
+                si.perr = ld3(q.perr);
+            }
             Vertex vx;
             vx.volume = false;
             vx.p = si.p;
             vx.g = 0;
             vx.quad = si.quad;
             vx.t = si.t;
+            vx.perr = si.perr;
             int kind = EV_PASS;
             if (!(fl & WFL_NODIST)) {
                 // ---- sample_distance after the traversal (:721-802) ---------------------------------------------
@@ -862,7 +884,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_seg_end(WfArgs a, int it) {
                 P.set3(WF_VXP, slot, vx.p);
                 if (vx.volume) P.f(WF_VXG, slot) = vx.g; else P.i(WF_VXG, slot) = vx.quad;
                 VertexCtx c;
-                vertex_setup<false>(st, vx, c);
+                vertex_setup<false>(S, st, vx, c);
                 const float survivalProb = vertex_pre(S, st, sampler, vx);
                 uint32_t extra = FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u);
                 if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833

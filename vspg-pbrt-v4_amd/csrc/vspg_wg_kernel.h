@@ -152,7 +152,9 @@ VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
     vx.p = P.v3(PF_VXP, slot);
     vx.g = vx.volume ? P.f(PF_VXG, slot) : 0.f;
     vx.quad = vx.volume ? -1 : P.i(PF_VXG, slot);
+    __builtin_assume(vx.quad >= -1);
     vx.t = P.f(PF_VXT, slot);
+    vx.perr = vx.volume ? mk(0, 0, 0) : ld3(quad_at(vx.quad).perr);
     return vx;
 }
 
@@ -171,6 +173,8 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     }
     st.prevCtx.p = P.v3(PF_PCP, slot);
     st.prevCtx.quad = P.i(PF_PCQ, slot);
+    st.prevCtx.perr = mk(0, 0, 0);  // (triangle scenes run the per-lane / wavefront kernels)
+    __builtin_assume(st.prevCtx.quad >= -1);
     sampler.rng.state = (uint64_t)P.u(PF_RNG + 0, slot) | ((uint64_t)P.u(PF_RNG + 1, slot) << 32);
     sampler.rng.inc = (uint64_t)P.u(PF_RNG + 2, slot) | ((uint64_t)P.u(PF_RNG + 3, slot) << 32);
     const uint32_t fl = P.u(PF_FLAGS, slot);
