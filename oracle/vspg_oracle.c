@@ -511,6 +511,9 @@ struct OracleRenderer {
     rquad_t quads[VSPG_MAX_QUADS];
     rtri_t *tris; /* non-degenerate triangles of the soup, caller's order */
     int n_tris;
+    /* infinite lights (lights.h:207-250 DistantLight, :554-601 UniformInfiniteLight); light order = emissive rectangles, then these */
+    int n_inf;
+    float scene_radius; /* Bounds3::BoundingSphere of the scene bounds (vecmath.h:1335-1338), light.Preprocess (integrators.h:74-81) */
     int n_lights;
     int light_quads[VSPG_MAX_QUADS];
     /* guiding fields (copies): [0] surface, [1] volume; nodes == NULL -> untrained */
@@ -1669,19 +1672,35 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
     }
     float u = sampler_get1d(sampler);
     /* UniformLightSampler::Sample (lightsamplers.h:33-38) */
-    int have_light = r->n_lights > 0;
+    const int n_all = r->n_lights + r->n_inf;
+    int have_light = n_all > 0;
     int lightIndex = 0;
     float lightPmf = 0;
     if (have_light) {
-        int li = (int)(u * (float)r->n_lights);
-        lightIndex = li < r->n_lights - 1 ? li : r->n_lights - 1;
-        lightPmf = 1.f / (float)r->n_lights;
+        int li = (int)(u * (float)n_all);
+        lightIndex = li < n_all - 1 ? li : n_all - 1;
+        lightPmf = 1.f / (float)n_all;
     }
     float ul0 = sampler_get1d(sampler), ul1 = sampler_get1d(sampler);
     if (!have_light) return S1(0.f);
-    const rquad_t *lq = &r->quads[r->light_quads[lightIndex]];
     lightli_t ls;
-    if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return S1(0.f);
+    int delta_light = 0;
+    if (lightIndex < r->n_lights) {
+        const rquad_t *lq = &r->quads[r->light_quads[lightIndex]];
+        if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return S1(0.f);
+    } else {
+        const VspgInfiniteLight *il = &r->scene.infinite_lights[lightIndex - r->n_lights];
+        /* UniformInfiniteLight::SampleLi(ctx, u, lambda, allowIncompletePDF = true) returns {} (lights.cpp:1019-1023) */
+        if (il->type != VSPG_LIGHT_DISTANT) return S1(0.f);
+        /* DistantLight::SampleLi (lights.h:320-327): wi = the light's direction, pdf 1, pLight = ctx.p() + wi * (2 * sceneRadius) */
+        ls.L = s_from(il->L);
+        if (!s_nonzero(ls.L)) return S1(0.f);
+        ls.wi = v3_from(il->w_light);
+        ls.pdf = 1;
+        ls.pLight = p3i_exact(v_add(ctxp, v_scale(ls.wi, 2 * r->scene_radius)));
+        ls.nLight = V3(0, 0, 0);
+        delta_light = 1;
+    }
     float p_l = lightPmf * ls.pdf;
 
     float scatterPDF;
@@ -1727,8 +1746,8 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
     }
     r_l = s_mul(r_l, s_scale(r_p, p_l));
     r_u = s_mul(r_u, s_scale(r_p, scatterPDF));
-    /* area light is not a delta light */
     DBG(intr->is_surface ? 32 : 64);
+    if (delta_light) return s_divf(s_mul(s_mul(f_hat, T_ray), ls.L), s_avg(r_l)); /* IsDeltaLight (:1248-1249) */
     return s_divf(s_mul(s_mul(f_hat, T_ray), ls.L), s_avg(s_add(r_l, r_u)));
 }
 
@@ -2231,7 +2250,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         isect_t si = scene_intersect(r, ro, rd, INFINITY);
         float tMax = si.hit ? si.t : INFINITY;
         spec transmittanceWeight = S1(1.0f); /* :317 */
-        if (r->scene.medium.type != VSPG_MEDIUM_NONE && !isinf(tMax)) {
+        if (r->scene.medium.type != VSPG_MEDIUM_NONE) { /* ray.medium: one medium fills the scene (an escaping ray is sampled too, tMax = Infinity) */
             rng_t rng;
             uint64_t hash0 = oracle_hash_float(sampler_get1d(sampler));
             uint64_t hash1 = oracle_hash_float(sampler_get1d(sampler));
@@ -2253,7 +2272,24 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             if (c.scattered) continue;
         }
         rec_add_transmittance_weight(rec, transmittanceWeight); /* :350 */
-        if (!si.hit) break; /* no infinite lights in scope (:353-374) */
+        if (!si.hit) { /* :353-374: contributions from infinite light sources (this fork lists DeltaDirection lights there too, integrators.h:79) */
+            const int n_all = r->n_lights + r->n_inf;
+            for (int k = 0; k < r->n_inf; ++k) {
+                const VspgInfiniteLight *il = &r->scene.infinite_lights[k];
+                spec Le = s_from(il->L); /* UniformInfiniteLight::Le / DistantLight::Le (lights.cpp:1014-1017, lights.h:291-293) */
+                if (il->type == VSPG_LIGHT_DISTANT && depth != 0) Le = S1(0.f);
+                if (depth == 0 || specularBounce) {
+                    L = s_add(L, s_divf(s_mul(beta, Le), s_avg(r_u)));
+                } else {
+                    /* lightSampler.PMF * light.PDF_Li(prevIntrContext, ray.d, true): both light types return 0 for the incomplete PDF */
+                    float lightPDF = (1.f / (float)n_all) * 0.f;
+                    r_l = s_scale(r_l, lightPDF);
+                    float w_b = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.f;
+                    L = s_add(L, s_mul(s_scale(beta, w_b), Le));
+                }
+            }
+            break;
+        }
 
         const rquad_t *q = &r->quads[si.tri >= 0 ? 0 : si.quad];
         /* isect.Le(-ray.d) (:377-397); triangles carry no area light */
@@ -2268,7 +2304,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
                 w_direct = 1.0f;
             } else {
                 DBG(lastVertexVolume ? 2 : 4);
-                float lightPDF = (1.f / (float)r->n_lights) * light_pdf_li(q, &prevIntrCtx, rd);
+                float lightPDF = (1.f / (float)(r->n_lights + r->n_inf)) * light_pdf_li(q, &prevIntrCtx, rd);
                 r_l = s_scale(r_l, lightPDF);
                 float w_l = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.0f;
                 L = s_add(L, s_mul(s_scale(beta, w_l), Le));
@@ -2972,6 +3008,30 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
             T->has_bsdf_lobes = T->Kd.c[0] != 0 || T->Kd.c[1] != 0 || T->Kd.c[2] != 0;
         }
         r->scene.tri_p = NULL; r->scene.tri_kd = NULL;
+    }
+    r->n_inf = scene->n_infinite_lights;
+    { /* scene bounds = union of every primitive's bounds (the rectangles' corners, the triangles' vertices), BoundingSphere */
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < r->n_quads; ++i) {
+            const v3 c[4] = {r->quads[i].p00, r->quads[i].p10, r->quads[i].p01, r->quads[i].p11};
+            for (int j = 0; j < 4; ++j) {
+                const float q[3] = {c[j].x, c[j].y, c[j].z};
+                for (int k = 0; k < 3; ++k) { lo[k] = q[k] < lo[k] ? q[k] : lo[k]; hi[k] = q[k] > hi[k] ? q[k] : hi[k]; }
+            }
+        }
+        for (int i = 0; i < r->n_tris; ++i) {
+            const v3 c[3] = {r->tris[i].p0, r->tris[i].p1, r->tris[i].p2};
+            for (int j = 0; j < 3; ++j) {
+                const float q[3] = {c[j].x, c[j].y, c[j].z};
+                for (int k = 0; k < 3; ++k) { lo[k] = q[k] < lo[k] ? q[k] : lo[k]; hi[k] = q[k] > hi[k] ? q[k] : hi[k]; }
+            }
+        }
+        r->scene_radius = 0.f;
+        if (lo[0] <= hi[0]) {
+            const float cx = (lo[0] + hi[0]) / 2, cy = (lo[1] + hi[1]) / 2, cz = (lo[2] + hi[2]) / 2;
+            const float dx = cx - hi[0], dy = cy - hi[1], dz = cz - hi[2];
+            r->scene_radius = sqrtf(dx * dx + dy * dy + dz * dz); /* Distance(center, pMax) */
+        }
     }
     if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;

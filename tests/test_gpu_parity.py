@@ -1124,6 +1124,81 @@ def test_hundred_thousand_triangles(gpu_pkg):
 
 
 # ---------------------------------------------------------------------------------------------
+# infinite lights: escaped-ray contributions (:353-374), DistantLight NEE (lights.h:320-327, delta-light return :1248-1249)
+# ---------------------------------------------------------------------------------------------
+def _open_scene(P, W, H, medium):
+    """a ground rectangle + a bumpy terrain under an open sky: uniform sky, a sun, NO emissive geometry"""
+    from scenes import cloud_density, grid_scene, heightfield_triangles
+    if medium == "cloud":
+        scene = grid_scene(cloud_density(24), (24, 24, 24), 0.08, 7.9, g=0.6, bmin=(-0.8, -0.3, -0.5), bmax=(0.8, 0.8, 0.9), W=W, H=H)
+    else:
+        scene = P.fog_box_scene(W, H)
+        for k in range(3):
+            scene.medium.sigma_a[k] = 0.02
+            scene.medium.sigma_s[k] = 0.25
+    floor = type(scene.quads[0]).from_buffer_copy(scene.quads[0])
+    for i in range(P.VSPG_MAX_QUADS):
+        scene.quads[i] = type(floor)()
+    scene.quads[0] = floor
+    scene.n_quads = 1
+    tris, kd = heightfield_triangles(40, y=-0.75, amp=0.2)
+    P.set_triangles(scene, tris, kd)
+    P.add_infinite_light(scene, P.LIGHT_UNIFORM_INFINITE, (0.35, 0.5, 0.9))
+    P.add_infinite_light(scene, P.LIGHT_DISTANT, (9.0, 8.0, 6.5), (0.3, 1.0, -0.4))
+    return scene
+
+
+@pytest.mark.parametrize("medium", ["fog", "cloud"])
+def test_infinite_lights_vs_oracle(gpu_pkg, medium):
+    """Sky (UniformInfiniteLight: reached by escaping rays only -- its SampleLi returns nothing for the incomplete PDF) and
+    sun (DistantLight: next-event estimation only past the camera ray, delta-light weighting) over an open scene whose rays
+    leave through the medium (SampleDistance with tMax = Infinity): paths and film against the oracle, every kernel."""
+    P = gpu_pkg
+    W, H = 64, 48
+    prm = P.app_f_params()
+    prm.lightsampler = 0  # "uniform" (the BVH light sampler's treatment of several lights is outside this build's scope)
+    scene = _open_scene(P, W, H, medium)
+    g = P.Renderer(scene, prm, W, H, seed=9)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=9)
+    rng = np.random.default_rng(43)
+    n = 6000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    assert Lg.mean() > 0.05 and np.isfinite(Lg).all()
+    for w in range(3):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fg, fc = g.film(), c.film()
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    assert np.array_equal(fg[..., 3], fc[..., 3])
+    assert np.mean(np.all(np.abs(ig - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
+    names = {g.kernel_name()}
+    g.close()
+    if medium == "cloud":
+        os.environ["VSPG_KERNEL"] = "lane"
+        try:
+            g2 = P.Renderer(scene, prm, W, H, seed=9)
+            for w in range(3):
+                g2.render_wave(w, w + 1); g2.post_process_wave()
+            names.add(g2.kernel_name())
+            assert np.array_equal(g2.film().view(np.uint32), fg.view(np.uint32))
+            g2.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+        assert len(names) == 2
+    # the sun matters: without it the picture is darker
+    dark = _open_scene(P, W, H, medium)
+    dark.n_infinite_lights = 1
+    d = oracle_lib.OracleRenderer(dark, prm, W, H, seed=9)
+    Ld, _ = d.trace_paths(pix[:2000], si[:2000])
+    assert Ld.mean() < 0.9 * Lc[:2000].mean()
+    c.close(); d.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # guiding cache query (own design behind the restated GuidedBSDF / GuidedPhaseFunction logic)
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")

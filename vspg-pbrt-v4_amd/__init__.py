@@ -299,6 +299,21 @@ def set_medium_transform(scene, m):
     return scene
 
 
+def add_infinite_light(scene, kind, L, w_light=(0.0, 1.0, 0.0)):
+    """kind: LIGHT_UNIFORM_INFINITE (sky, radiance L) or LIGHT_DISTANT (sun, radiance L from direction w_light, normalised here)."""
+    import numpy as np
+    k = scene.n_infinite_lights
+    assert k < VSPG_MAX_INFINITE_LIGHTS
+    w = np.asarray(w_light, dtype=np.float64)
+    w = (w / np.linalg.norm(w)).astype(np.float32)
+    il = scene.infinite_lights[k]
+    il.type = kind
+    il.L[:] = [float(x) for x in L]
+    il.w_light[:] = [float(x) for x in w]
+    scene.n_infinite_lights = k + 1
+    return scene
+
+
 def set_triangles(scene, tri_p, tri_kd=None):
     """Attach a triangle soup (n x 3 x 3 vertex array, optional n x 3 diffuse reflectances) to the scene."""
     import numpy as np

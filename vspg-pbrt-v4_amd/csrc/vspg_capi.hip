@@ -1270,6 +1270,7 @@ static PcgJump pcg_jump(unsigned long long delta) {
     return PcgJump{accMult, accPlus};
 }
 
+static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T);
 static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, const VspgRenderConfig &cfg, DScene *D) {
     using namespace hostmath;
     memset(D, 0, sizeof *D);
@@ -1325,6 +1326,29 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
             rec.f[12] = q.inv_l1; rec.f[13] = q.inv_l2;
         }
         if (light) D->light_quads[D->n_lights++] = i;
+    }
+    D->n_inf = sc.n_infinite_lights;
+    for (int i = 0; i < sc.n_infinite_lights && i < VSPG_MAX_INFINITE_LIGHTS; ++i) {
+        D->inf_type[i] = sc.infinite_lights[i].type;
+        for (int k = 0; k < 3; ++k) { D->inf_L[i][k] = sc.infinite_lights[i].L[k]; D->inf_w[i][k] = sc.infinite_lights[i].w_light[k]; }
+    }
+    {   // scene bounds = union of the primitives' bounds; light.Preprocess: BoundingSphere (integrators.h:74-81, vecmath.h:1335-1338)
+        float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+        auto grow = [&](const float *q) { for (int k = 0; k < 3; ++k) { lo[k] = q[k] < lo[k] ? q[k] : lo[k]; hi[k] = q[k] > hi[k] ? q[k] : hi[k]; } };
+        for (int i = 0; i < D->n_quads; ++i) { grow(D->quads[i].p00); grow(D->quads[i].p10); grow(D->quads[i].p01); grow(D->quads[i].p11); }
+        for (int i = 0; i < sc.n_triangles && sc.tri_p; ++i) {
+            DTri T;
+            if (derive_triangle(sc.tri_p + 9 * (size_t)i, nullptr, i, &T)) { grow(T.p0); grow(T.p1); grow(T.p2); }
+        }
+        D->scene_radius = 0.f;
+        if (lo[0] <= hi[0]) {
+            volatile float cx = (lo[0] + hi[0]) / 2, cy = (lo[1] + hi[1]) / 2, cz = (lo[2] + hi[2]) / 2;
+            volatile float dx = cx - hi[0], dy = cy - hi[1], dz = cz - hi[2];
+            volatile float l2 = dx * dx;
+            l2 = l2 + dy * dy;
+            l2 = l2 + dz * dz;
+            D->scene_radius = std::sqrt(l2);
+        }
     }
     D->cam = sc.camera;
     D->medium_type = sc.medium.type;
@@ -1571,9 +1595,15 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         return fail(VSPG_EINVAL, "unknown medium type");
     if (scene->n_triangles < 0 || scene->n_triangles > (1 << 27)) return fail(VSPG_EINVAL, "n_triangles out of range");
     if (scene->n_triangles > 0 && !scene->tri_p) return fail(VSPG_EINVAL, "triangles without vertex data");
+    if (scene->n_infinite_lights < 0 || scene->n_infinite_lights > VSPG_MAX_INFINITE_LIGHTS) return fail(VSPG_EINVAL, "n_infinite_lights out of range");
+    for (int i = 0; i < scene->n_infinite_lights; ++i)
+        if (scene->infinite_lights[i].type != VSPG_LIGHT_UNIFORM_INFINITE && scene->infinite_lights[i].type != VSPG_LIGHT_DISTANT)
+            return fail(VSPG_EINVAL, "unknown infinite light type");
+    if (scene->n_infinite_lights > 0 && wants_guiding(*p))
+        return fail(VSPG_ESCOPE, "infinite lights with the directional guiding cache are outside this build's scope (guiding_addInfiniteLightEmission)");
     if (scene->n_triangles > 0 && wants_guiding(*p))
         return fail(VSPG_ESCOPE, "triangle geometry with the directional guiding cache is outside this build's scope");
-    int nl = 0;
+    int nl = scene->n_infinite_lights;
     for (int i = 0; i < scene->n_quads; ++i)
         if (scene->quads[i].Le[0] != 0 || scene->quads[i].Le[1] != 0 || scene->quads[i].Le[2] != 0) nl++;
     if (p->lightsampler == VSPG_LIGHTSAMPLER_BVH && nl > 1)

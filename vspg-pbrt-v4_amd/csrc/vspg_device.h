@@ -487,6 +487,11 @@ struct DScene {
     int32_t n_tris, n_bvh_nodes;
     const DTri *tris;          // in BVH leaf order
     const DBvhNode *bvh;
+    // infinite lights (light order: the emissive rectangles, then these); scene_radius: Bounds3::BoundingSphere of the scene bounds
+    int32_t n_inf;
+    int32_t inf_type[VSPG_MAX_INFINITE_LIGHTS];
+    float inf_L[VSPG_MAX_INFINITE_LIGHTS][3], inf_w[VSPG_MAX_INFINITE_LIGHTS][3];
+    float scene_radius;
     DField field[2];
     IsectRec irec[VSPG_MAX_QUADS];
     int32_t light_quads[VSPG_MAX_QUADS];

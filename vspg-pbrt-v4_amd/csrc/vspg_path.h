@@ -103,6 +103,23 @@ VDEV bool light_sample_li(const DQuad &q, V3 ctxp, float u0, float u1, LightLi *
     ls->nLight = n;
     return true;
 }
+// light.SampleLi(ctx, uLight, lambda, allowIncompletePDF = true) for light `lightIndex` of the scene's light list
+VDEV bool sample_light(const DScene &S, int lightIndex, V3 ctxp, float u0, float u1, LightLi *ls, bool *delta_light) {
+    *delta_light = false;
+    if (lightIndex < S.n_lights) return light_sample_li(light_quad_at(lightIndex), ctxp, u0, u1, ls);
+    const int k = lightIndex - S.n_lights;
+    // UniformInfiniteLight::SampleLi returns {} for the incomplete PDF (lights.cpp:1019-1023): the sky is reached by escaping rays only
+    if (S.inf_type[k] != VSPG_LIGHT_DISTANT) return false;
+    // DistantLight::SampleLi (lights.h:320-327)
+    ls->L = lds(S.inf_L[k]);
+    if (!nonzero(ls->L)) return false;
+    ls->wi = ld3(S.inf_w[k]);
+    ls->pdf = 1;
+    ls->pLight = p3i_exact(ctxp + ls->wi * (2 * S.scene_radius));
+    ls->nLight = mk(0, 0, 0);
+    *delta_light = true;
+    return true;
+}
 struct LsCtx {  // LightSampleContext
     P3i pi;
     V3 n;
@@ -220,20 +237,21 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     V3 ctxp = intr.pi.mid();
     if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
     float u = sampler.get1d();
-    // UniformLightSampler::Sample (lightsamplers.h:33-38)
-    bool have_light = S.n_lights > 0;
+    // UniformLightSampler::Sample (lightsamplers.h:33-38) over the emissive rectangles followed by the infinite lights
+    const int n_all = S.n_lights + S.n_inf;
+    bool have_light = n_all > 0;
     int lightIndex = 0;
     float lightPmf = 0;
     if (have_light) {
-        int li = (int)(u * (float)S.n_lights);
-        lightIndex = li < S.n_lights - 1 ? li : S.n_lights - 1;
-        lightPmf = 1.f / (float)S.n_lights;
+        int li = (int)(u * (float)n_all);
+        lightIndex = li < n_all - 1 ? li : n_all - 1;
+        lightPmf = 1.f / (float)n_all;
     }
     float ul0 = sampler.get1d(), ul1 = sampler.get1d();
     if (!have_light) return sp(0.f);
-    const DQuad &lq = light_quad_at(lightIndex);
     LightLi ls;
-    if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return sp(0.f);
+    bool delta_light = false;
+    if (!sample_light(S, lightIndex, ctxp, ul0, ul1, &ls, &delta_light)) return sp(0.f);
     float p_l = lightPmf * ls.pdf;
 
     float scatterPDF;
@@ -308,7 +326,8 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     }
     r_l = r_l * (r_p * p_l);
     r_u = r_u * (r_p * scatterPDF);
-    return f_hat * T_ray * ls.L / avg(r_l + r_u);  // area light: not a delta light (:1248-1251)
+    if (delta_light) return f_hat * T_ray * ls.L / avg(r_l);  // IsDeltaLight (:1248-1249)
+    return f_hat * T_ray * ls.L / avg(r_l + r_u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -621,7 +640,23 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     VSPG_PROF(PS_SURF_PRE);
     if constexpr (kRec) pc.rec.add_transmittance_weight(tw);  // :350
-    if (!si.hit) return false;  // no infinite lights in scope (:353-374)
+    if (!si.hit) {  // :353-374: infinite light sources (this fork lists DeltaDirection lights among them, integrators.h:79)
+        const int n_all = S.n_lights + S.n_inf;
+        for (int k = 0; k < S.n_inf; ++k) {
+            Spec Le = lds(S.inf_L[k]);  // UniformInfiniteLight::Le / DistantLight::Le (lights.cpp:1014-1017, lights.h:291-293)
+            if (S.inf_type[k] == VSPG_LIGHT_DISTANT && st.depth != 0) Le = sp(0.f);
+            if (st.depth == 0 || st.specularBounce) {
+                st.L = st.L + st.beta * Le / avg(st.r_u);
+            } else {
+                // lightSampler.PMF * light.PDF_Li(prevIntrContext, ray.d, true): both light types return 0 for the incomplete PDF
+                const float lightPDF = (1.f / (float)n_all) * 0.f;
+                st.r_l = st.r_l * lightPDF;
+                const float w_b = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.f;
+                st.L = st.L + st.beta * w_b * Le;
+            }
+        }
+        return false;
+    }
     const DQuad &q = quad_at(is_tri(si.quad) ? 0 : si.quad);
     Spec Le = !is_tri(si.quad) && q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377 (triangles carry no area light)
     float w_direct = 0.f;
@@ -630,7 +665,7 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
             st.L = st.L + st.beta * Le / avg(st.r_u);
             w_direct = 1.0f;
         } else {
-            float lightPDF = (1.f / (float)S.n_lights) * light_pdf_li(q, st.prevCtx.expand(S), st.rd);
+            float lightPDF = (1.f / (float)(S.n_lights + S.n_inf)) * light_pdf_li(q, st.prevCtx.expand(S), st.rd);
             st.r_l = st.r_l * lightPDF;
             float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
             st.L = st.L + st.beta * w_l * Le;
@@ -669,7 +704,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
     vx.perr = si.perr;
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     Spec tw = sp(1.f);  // transmittanceWeight (:317)
-    if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
+    if (S.medium_type != VSPG_MEDIUM_NONE) {  // ray.medium: one medium fills the scene (an escaping ray is sampled too, tMax = Infinity)
         Rng rng;
         {
             VSPG_PROF(PS_HASHRNG);

@@ -92,6 +92,7 @@ enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_SHADOW_CLEAR = 1 << 24,  // NEE: contributes without a walk (T_ray = 1)
     WFL_HIT = 1 << 25,       // the segment's ray hit a surface
     WFL_NEE = 1 << 26,       // SampleLd ran at the vertex (its result is added even when it is zero, :483 / :836)
+    WFL_DELTA = 1 << 27,     // NEE sampled a delta light (DistantLight)
 };
 
 struct WfPool {
@@ -287,6 +288,7 @@ struct ShadowSetup {
     V3 lo, ld;
     Rng rng;
     float us;
+    bool delta_light;
 };
 template <class PC>
 VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *bsdf, Sampler &sampler, PC &pc) {
@@ -296,22 +298,23 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *
     r.p_l = r.scatterPDF = r.us = 0.f;
     r.lo = r.ld = mk(0, 0, 0);
     r.rng.state = r.rng.inc = 0;
+    r.delta_light = false;
     V3 ctxp = intr.pi.mid();
     if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
     float u = sampler.get1d();
-    bool have_light = S.n_lights > 0;
+    const int n_all = S.n_lights + S.n_inf;
+    bool have_light = n_all > 0;
     int lightIndex = 0;
     float lightPmf = 0;
     if (have_light) {  // UniformLightSampler::Sample (lightsamplers.h:33-38)
-        int li = (int)(u * (float)S.n_lights);
-        lightIndex = li < S.n_lights - 1 ? li : S.n_lights - 1;
-        lightPmf = 1.f / (float)S.n_lights;
+        int li = (int)(u * (float)n_all);
+        lightIndex = li < n_all - 1 ? li : n_all - 1;
+        lightPmf = 1.f / (float)n_all;
     }
     float ul0 = sampler.get1d(), ul1 = sampler.get1d();
     if (!have_light) return r;
-    const DQuad &lq = light_quad_at(lightIndex);
     LightLi ls;
-    if (!light_sample_li(lq, ctxp, ul0, ul1, &ls)) return r;
+    if (!sample_light(S, lightIndex, ctxp, ul0, ul1, &ls, &r.delta_light)) return r;
     r.p_l = lightPmf * ls.pdf;
     V3 wo = intr.wo, wi = ls.wi;
     if (intr.is_surface) {
@@ -345,7 +348,7 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *
     return r;
 }
 // ... and from the estimate on (:1233-1251).  walked: the medium block ran (T_maj is the walk's residual majorant transmittance)
-VDEV Spec sample_Ld_end(bool walked, Spec T_ray, Spec r_l, Spec r_u, Spec T_maj, int ch, Spec f_hat, Spec Ll, float p_l, float scatterPDF, Spec r_p) {
+VDEV Spec sample_Ld_end(bool walked, bool delta_light, Spec T_ray, Spec r_l, Spec r_u, Spec T_maj, int ch, Spec f_hat, Spec Ll, float p_l, float scatterPDF, Spec r_p) {
     if (walked) {
         float tm = ch_of(T_maj, ch);
         T_ray = T_ray * (T_maj / tm);
@@ -355,6 +358,7 @@ VDEV Spec sample_Ld_end(bool walked, Spec T_ray, Spec r_l, Spec r_u, Spec T_maj,
     if (!nonzero(T_ray)) return sp(0.f);
     r_l = r_l * (r_p * p_l);
     r_u = r_u * (r_p * scatterPDF);
+    if (delta_light) return f_hat * T_ray * Ll / avg(r_l);  // IsDeltaLight (:1248-1249)
     return f_hat * T_ray * Ll / avg(r_l + r_u);
 }
 
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                             T_ray = P.sp3(WF_TRAY, slot); r_l = P.sp3(WF_SRL, slot); r_u = P.sp3(WF_SRU, slot);
                             T_maj = P.sp3(WF_STMAJ, slot);
                         }
-                        Ld = sample_Ld_end(walked, T_ray, r_l, r_u, T_maj, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
+                        Ld = sample_Ld_end(walked, (fl & WFL_DELTA) != 0, T_ray, r_l, r_u, T_maj, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
                                            P.f(WF_SPDF, slot), st.r_u);
                     }
                     st.L = st.L + st.beta * Ld;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                 P.i(WF_VXG, slot) = si.quad;
                 P.f(WF_VXT, slot) = si.t;
                 if (is_tri(si.quad)) P.set3(WF_VXE, slot, si.perr);
-                if (S.medium_type != VSPG_MEDIUM_NONE && !isinf_(tMax)) {
+                if (S.medium_type != VSPG_MEDIUM_NONE) {
                     Rng rng;
                     {
                         uint64_t hash0 = hash_float(sampler.get1d());
@@ -891,6 +895,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_seg_end(WfArgs a, int it) {
                     extra |= WFL_NEE;
                     const ShadowSetup ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc);
                     if (ss.status != 0) {
+                        if (ss.delta_light) extra |= WFL_DELTA;
                         P.sets(WF_FHAT, slot, ss.f_hat);
                         P.sets(WF_LSL, slot, ss.L);
                         P.f(WF_PL, slot) = ss.p_l;
