@@ -2,6 +2,7 @@
 over the C-ABI.  CPU part: parameter names, defaults, unused-parameter and registry errors
 (host_selftest, no device calls).  GPU part: the App.-F scene rendered through
 Integrator::Create("guidedvolpathvspg") equals the same render driven through the raw C-ABI."""
+import ctypes as C
 import os
 import subprocess
 
@@ -139,3 +140,113 @@ def test_tr_buffer_store_and_load(host_build, gpu_pkg, tmp_path):
     # a missing file is the reference's warning, not an error (:186)
     c = subprocess.run([exe, str(W), str(H), "1", str(tmp_path / "c.pfm"), "trload", str(tmp_path / "none.pfm")], capture_output=True, text=True)
     assert c.returncode == 0 and "Tr buffer file does not exists" in c.stderr
+
+
+# ---------------------------------------------------------------------------------------------
+# f4: the scene-file front end (host/vspg_scenefile.*, host/vspg_pbrt_main.cpp)
+# ---------------------------------------------------------------------------------------------
+SCENES = os.path.join(ROOT, "tests", "scenes")
+
+
+def test_scene_files_parse(host_build):
+    """CPU: the App.-F fog box and the placed-cloud / sky / sun / triangle-mesh scene parse; unknown directives, unknown
+    parameters and out-of-scope shapes are errors that name the offender (nothing is dropped silently)."""
+    exe = os.path.join(host_build, "vspg_pbrt")
+    a = subprocess.run([exe, os.path.join(SCENES, "fog_box.pbrt"), "--parse-only"], capture_output=True, text=True)
+    assert a.returncode == 0, a.stderr
+    assert "7 rectangles, 0 triangles, 0 infinite lights, medium type 1, film 64x48 @ 4 spp" in a.stdout
+    b = subprocess.run([exe, os.path.join(SCENES, "cloud_sky.pbrt"), "--parse-only"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    assert "0 rectangles, 4 triangles, 2 infinite lights, medium type 2 (placed), film 48x32 @ 2 spp" in b.stdout
+
+
+@pytest.mark.parametrize("bad,needle", [
+    ('Shape "sphere" "float radius" 1', 'Shape "sphere"'),
+    ('Texture "t" "spectrum" "checkerboard"', 'directive "Texture"'),
+    ('Material "diffuse" "rgb reflectance" [ .5 .5 .5 ] "float bogus" 1', "unused parameter"),
+    ('Material "conductor"', 'Material "conductor"'),
+    ('LightSource "spot"', 'LightSource "spot"'),
+])
+def test_scene_file_errors(host_build, tmp_path, bad, needle):
+    exe = os.path.join(host_build, "vspg_pbrt")
+    f = tmp_path / "bad.pbrt"
+    f.write_text('Camera "perspective"\nFilm "rgb"\nPixelFilter "box"\nWorldBegin\n' + bad + "\n")
+    r = subprocess.run([exe, str(f), "--parse-only"], capture_output=True, text=True)
+    assert r.returncode == 1 and needle in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_scene_file_render_equals_the_api_scene(host_build, gpu_pkg, tmp_path):
+    """`vspg_pbrt tests/scenes/fog_box.pbrt` == the same scene built through the C-ABI helpers, bit for bit."""
+    exe = os.path.join(host_build, "vspg_pbrt")
+    out = tmp_path / "fog.pfm"
+    a = subprocess.run([exe, os.path.join(SCENES, "fog_box.pbrt"), "--outfile", str(out)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout + a.stderr
+    P = gpu_pkg
+    W, H, spp = 64, 48, 4
+    r = P.Renderer(P.fog_box_scene(W, H), P.app_f_params(), W, H)
+    for w in range(spp):
+        r.render_wave(w, w + 1)
+        r.post_process_wave()
+    f = r.film()
+    r.close()
+    assert np.array_equal(read_pfm(str(out)).view(np.uint32), (f[..., :3] / f[..., 3:4]).astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_scene_file_cloud_sky_renders(host_build, gpu_pkg, tmp_path):
+    """The placed cloud under sky + sun over a triangle-mesh ground, from the scene file: deterministic, lit, and the
+    same picture (up to the CTM's float composition) as the scene assembled in Python."""
+    import math
+    exe = os.path.join(host_build, "vspg_pbrt")
+    outs = []
+    for k in range(2):
+        out = tmp_path / ("c%d.pfm" % k)
+        a = subprocess.run([exe, os.path.join(SCENES, "cloud_sky.pbrt"), "--outfile", str(out), "--spp", "16"], capture_output=True, text=True)
+        assert a.returncode == 0, a.stdout + a.stderr
+        outs.append(read_pfm(str(out)))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    img = outs[0]
+    assert np.isfinite(img).all() and img.mean() > 0.05
+    P = gpu_pkg
+    W, H = 48, 32
+    s = P.fog_box_scene(W, H)
+    for i in range(P.VSPG_MAX_QUADS):
+        s.quads[i] = type(s.quads[0])()
+    s.n_quads = 0
+    P.load().vspg_camera_look_at(C.byref(s.camera), P.f3(0, 0.1, -2.2), P.f3(0, 0.1, 0), P.f3(0, 1, 0), 50.0, W, H)
+    m = s.medium
+    m.type = P.MEDIUM_GRID
+    m.sigma_a[:] = (.02,) * 3
+    m.sigma_s[:] = (3.0,) * 3
+    m.g = 0.6
+    m.nx = m.ny = m.nz = 2
+    m.bounds_min[:] = (-1, -1, -1)
+    m.bounds_max[:] = (1, 1, 1)
+    dens = np.array([0.2, 1, 0.7, 0.1, 0.9, 0.4, 1, 0.6], dtype=np.float32)
+    m.density = dens.ctypes.data_as(C.POINTER(C.c_float))
+    ang = math.radians(30.0)
+    ax = np.array([0.2, 1.0, 0.1]); ax /= np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
+    M = np.eye(4)
+    M[:3, :3] = R @ np.diag([0.8, 0.6, 0.7])
+    M[:3, 3] = (0.1, 0.25, 0.2)
+    P.set_medium_transform(s, M.astype(np.float32))
+    Pts = np.array([[-3, -1, -3], [3, -1, -3], [3, -1.2, 3], [-3, -0.9, 3], [0, -0.6, 0]], dtype=np.float32)
+    idx = [[0, 4, 1], [1, 4, 2], [2, 4, 3], [3, 4, 0]]
+    P.set_triangles(s, Pts[idx], np.tile(np.array([[.4, .5, .3]], dtype=np.float32), (4, 1)))
+    P.add_infinite_light(s, P.LIGHT_UNIFORM_INFINITE, (.35, .5, .9))
+    P.add_infinite_light(s, P.LIGHT_DISTANT, (9, 8, 6.5), (0.3, 1, -0.4))
+    prm = P.app_f_params()
+    prm.maxdepth = 4
+    prm.lightsampler = P.LIGHTSAMPLER_UNIFORM
+    r = P.Renderer(s, prm, W, H)
+    for w in range(16):
+        r.render_wave(w, w + 1)
+        r.post_process_wave()
+    f = r.film()
+    r.close()
+    ref = f[..., :3] / f[..., 3:4]
+    assert abs(img.mean() / ref.mean() - 1) < 0.02, (img.mean(), ref.mean())
+    assert np.mean(np.abs(img - ref) <= 0.05 * (1 + ref)) > 0.9

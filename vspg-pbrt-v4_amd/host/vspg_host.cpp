@@ -18,6 +18,8 @@ ParameterDictionary &ParameterDictionary::String(const std::string &n, const std
 ParameterDictionary &ParameterDictionary::RGB(const std::string &n, float r, float g, float b) { Value x; x.type = 'c'; x.f[0] = r; x.f[1] = g; x.f[2] = b; values[n] = x; return *this; }
 
 ParameterDictionary &ParameterDictionary::Point3(const std::string &n, float x, float y, float z) { Value v; v.type = 'p'; v.f[0] = x; v.f[1] = y; v.f[2] = z; values[n] = v; return *this; }
+ParameterDictionary &ParameterDictionary::IntArray(const std::string &n, std::vector<int> a) { Value v; v.type = 'I'; v.iarr = std::move(a); values[n] = v; return *this; }
+ParameterDictionary &ParameterDictionary::Point3Array(const std::string &n, std::vector<float> a) { Value v; v.type = 'P'; v.arr = std::move(a); values[n] = v; return *this; }
 ParameterDictionary &ParameterDictionary::FloatArray(const std::string &n, std::vector<float> a) { Value v; v.type = 'a'; v.arr = std::move(a); values[n] = v; return *this; }
 
 ParameterDictionary ParameterDictionary::Parse(const std::string &text) {
@@ -71,8 +73,8 @@ ParameterDictionary ParameterDictionary::Parse(const std::string &text) {
             return v;
         };
         if (type == "integer") {
-            if (toks.size() != 1) throw Error("parameter \"" + name + "\": integer arrays are outside this build's scope");
-            d.Int(name, (int)std::strtol(toks[0].c_str(), nullptr, 10));
+            if (toks.size() == 1) d.Int(name, (int)std::strtol(toks[0].c_str(), nullptr, 10));
+            else { std::vector<int> a; for (auto &t : toks) a.push_back((int)std::strtol(t.c_str(), nullptr, 10)); d.IntArray(name, std::move(a)); }
         } else if (type == "float") {
             if (toks.size() == 1) d.Float(name, num(toks[0]));
             else { std::vector<float> a; for (auto &t : toks) a.push_back(num(t)); d.FloatArray(name, std::move(a)); }
@@ -81,10 +83,17 @@ ParameterDictionary ParameterDictionary::Parse(const std::string &text) {
             d.Bool(name, toks[0] == "true");
         } else if (type == "string") {
             d.String(name, toks[0]);
+        } else if (type == "point3" && toks.size() > 3) {
+            if (toks.size() % 3) throw Error("parameter \"" + name + "\": point3 values come in threes");
+            std::vector<float> a; for (auto &t : toks) a.push_back(num(t));
+            d.Point3Array(name, std::move(a));
         } else if (type == "rgb" || type == "point3") {
             if (toks.size() != 3) throw Error("parameter \"" + name + "\": " + type + " needs three values");
             if (type == "rgb") d.RGB(name, num(toks[0]), num(toks[1]), num(toks[2]));
             else d.Point3(name, num(toks[0]), num(toks[1]), num(toks[2]));
+        } else if (type == "point2" || type == "vector3" || type == "normal3" || type == "normal" || type == "vector2") {
+            std::vector<float> a; for (auto &t : toks) a.push_back(num(t));
+            d.FloatArray(name, std::move(a));
         } else
             throw Error("parameter \"" + name + "\": type \"" + type + "\" is outside this build's scope");
     }
@@ -120,6 +129,20 @@ std::vector<float> ParameterDictionary::GetFloatArray(const std::string &n) cons
     if (it == values.end()) return {};
     if (it->second.type == 'f') { it->second.lookedUp = true; return {it->second.f[0]}; }
     auto v = find(n, 'a');
+    return v->arr;
+}
+std::vector<int> ParameterDictionary::GetIntArray(const std::string &n) const {
+    auto it = values.find(n);
+    if (it == values.end()) return {};
+    if (it->second.type == 'i') { it->second.lookedUp = true; return {it->second.i}; }
+    auto v = find(n, 'I');
+    return v->iarr;
+}
+std::vector<float> ParameterDictionary::GetPoint3Array(const std::string &n) const {
+    auto it = values.find(n);
+    if (it == values.end()) return {};
+    if (it->second.type == 'p') { it->second.lookedUp = true; return {it->second.f[0], it->second.f[1], it->second.f[2]}; }
+    auto v = find(n, 'P');
     return v->arr;
 }
 void ParameterDictionary::ReportUnused() const {

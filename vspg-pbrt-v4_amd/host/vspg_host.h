@@ -35,10 +35,13 @@ class ParameterDictionary {
     ParameterDictionary &RGB(const std::string &n, float r, float g, float b);
     ParameterDictionary &Point3(const std::string &n, float x, float y, float z);
     ParameterDictionary &FloatArray(const std::string &n, std::vector<float> v);
+    ParameterDictionary &IntArray(const std::string &n, std::vector<int> v);
+    ParameterDictionary &Point3Array(const std::string &n, std::vector<float> xyz);
     // The reference's scene-file parameter-list syntax ("type name" value | [ values ]), e.g. the block
     // cmd/nanovdb2pbrt.cpp:97-126 prints for a grid:
     //   "integer nx" 64 "integer ny" 64 "integer nz" 32 "point3 p0" [ -1 -1 0 ] "point3 p1" [ 1 1 1 ] "float density" [ ... ]
-    // Types: integer, float (one value -> Float, several -> FloatArray), bool, string, rgb, point3.
+    // Types: integer (several -> IntArray), float (one value -> Float, several -> FloatArray), bool, string, rgb,
+    // point3 (several points -> Point3Array); point2 / vector3 / normal3 arrays are kept as float arrays under their name.
     static ParameterDictionary Parse(const std::string &text);
 
     int GetOneInt(const std::string &n, int def) const;
@@ -49,13 +52,17 @@ class ParameterDictionary {
     bool GetOneRGB(const std::string &n, float rgb[3]) const;
     bool GetOnePoint3(const std::string &n, float p[3]) const;
     std::vector<float> GetFloatArray(const std::string &n) const;  // a single "float" value is a 1-element array
+    std::vector<int> GetIntArray(const std::string &n) const;      // a single "integer" value is a 1-element array
+    std::vector<float> GetPoint3Array(const std::string &n) const; // x y z x y z ...; a single "point3" is one point
+    bool Has(const std::string &n) const { return values.count(n) != 0; }
     // paramdict.cpp:642-664: any parameter that was never looked up is a fatal error
     void ReportUnused() const;
 
   private:
     struct Value {
-        char type;  // i f b s c p a(rray)
+        char type;  // i f b s c p a(rray) I(nt array) P(oint array)
         int i = 0;
+        std::vector<int> iarr;
         float f[3] = {0, 0, 0};
         std::string s;
         std::vector<float> arr;
