@@ -2047,7 +2047,9 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
     const char *kenv = getenv("VSPG_KERNEL");
     const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
     // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
-    if (r->hscene.n_tris > 0) return false;  // triangle hits carry a per-hit error bound the LDS pool record has no room for
+    // triangle hits carry a per-hit error bound the LDS pool record has no room for, and the kernel's homogeneous instantiations
+    // are built for rectangle scenes with area lights only (HomogeneousMediumT::kSimpleScene)
+    if (r->hscene.n_tris > 0 || r->hscene.n_inf > 0) return false;
     return !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
 }
 // "wf" = the multi-kernel wavefront pipeline (vspg_wavefront.h): heterogeneous media whose every segment runs the
@@ -2195,7 +2197,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
                                work_head, r->counters);
         else
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMedium, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
                                work_head, r->counters);

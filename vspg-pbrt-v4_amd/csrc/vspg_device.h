@@ -796,6 +796,8 @@ VDEV bool bvh_any(const DScene &S, V3 o, V3 d, float tMax) {
     return false;
 }
 
+// FULL = false: the scene is known to hold rectangles only (the workgroup kernel's instantiations, see HomogeneousMediumT::kSimpleScene)
+template <bool FULL = true>
 VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     Isect best;
     best.hit = false;
@@ -816,7 +818,7 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     best.p = quad_point(q, bu, bv);
     best.n = ld3(q.n);
     best.perr = ld3(q.perr);
-    if (S.n_tris > 0) {  // wave-uniform: rectangles win ties (they are tested first, strictly closer)
+    if (FULL && S.n_tris > 0) {  // wave-uniform: rectangles win ties (they are tested first, strictly closer)
         int tp = 0;
         TriHit h;
         if (bvh_closest(S, o, d, best.t, &tp, &h)) {
@@ -834,13 +836,14 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     }
     return best;
 }
+template <bool FULL = true>
 VLEAF bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
     bool any = false;
     for (int i = 0; i < S.n_quads; ++i) {
         float t, u, v;
         any = any || rect_hit_uv(S.irec[i], o, d, tMax, &t, &u, &v);
     }
-    if (S.n_tris > 0 && !any) any = bvh_any(S, o, d, tMax);
+    if (FULL && S.n_tris > 0 && !any) any = bvh_any(S, o, d, tMax);
     return any;
 }
 
@@ -869,10 +872,14 @@ struct MajSeg {
 // ClampZero((sigma_t - sigma_a) - sigma_s) is exactly 0 in every channel -- the usual outcome of the float
 // arithmetic for a homogeneous medium: the ratio-tracking estimate of a shadow ray is then 0 at its first
 // tentative collision (sample_Ld), a fact the compiler cannot see in the runtime constants.
-template <int GREY, bool NULLZERO = false>
+// SIMPLE promises (the host routes accordingly) a scene of rectangles and area lights only -- no triangle soup, no infinite
+// lights: the code for those (BVH traversal, per-hit error bounds, the escaped-ray light loop, DistantLight sampling) is
+// compiled out of the instantiation, which keeps the benchmark kernel at its round-1 register shape.
+template <int GREY, bool NULLZERO = false, bool SIMPLE = false>
 struct HomogeneousMediumT {
     static constexpr int kGrey = GREY;   // 0 none, 1 medium spectra, 2 medium spectra + surface reflectances
     static constexpr bool kNullZero = NULLZERO;
+    static constexpr bool kSimpleScene = SIMPLE;
     // constants live in the workgroup's LDS copy (s_scene_medium, staged by stage_scene_lds)
     static VDEV Spec m3(int o) {
         if constexpr (GREY) {
@@ -906,9 +913,10 @@ struct HomogeneousMediumT {
     static constexpr bool kAlwaysRealCollision = true;
 };
 using HomogeneousMedium = HomogeneousMediumT<0>;
-using HomogeneousMediumGrey = HomogeneousMediumT<1>;
-using HomogeneousMediumGreyScene = HomogeneousMediumT<2>;
-using HomogeneousMediumGreySceneNullZero = HomogeneousMediumT<2, true>;
+using HomogeneousMediumSimple = HomogeneousMediumT<0, false, true>;
+using HomogeneousMediumGrey = HomogeneousMediumT<1, false, true>;
+using HomogeneousMediumGreyScene = HomogeneousMediumT<2, false, true>;
+using HomogeneousMediumGreySceneNullZero = HomogeneousMediumT<2, true, true>;
 
 // ---------------------------------------------------------------------------------------
 // a6: GridMedium (media.h:284-390) with the 3-D DDA majorant iterator (media.h:140-218),
@@ -930,6 +938,7 @@ struct GridMediumT {
     // majorant grid has 4x as many cell crossings per tentative collision as the 16^3 one)
     static constexpr int kAdvanceRounds = NVDB ? 6 : 3;
     static constexpr int kGrey = GREY ? 1 : 0;  // sigma_a, sigma_s built from one value each (see HomogeneousMediumT)
+    static constexpr bool kSimpleScene = false;
     Spec sigma_a, sigma_s;
     float g;
     int nx, ny, nz;
@@ -1189,8 +1198,8 @@ VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
                              S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le), S.has_xform ? S.minv : nullptr};
 }
 template <class M> struct MediumMaker;
-template <int GREY, bool NZ> struct MediumMaker<HomogeneousMediumT<GREY, NZ>> {
-    static VDEV HomogeneousMediumT<GREY, NZ> make(const DScene &, const float *) { return HomogeneousMediumT<GREY, NZ>{}; }
+template <int GREY, bool NZ, bool SIMPLE> struct MediumMaker<HomogeneousMediumT<GREY, NZ, SIMPLE>> {
+    static VDEV HomogeneousMediumT<GREY, NZ, SIMPLE> make(const DScene &, const float *) { return HomogeneousMediumT<GREY, NZ, SIMPLE>{}; }
 };
 template <bool NVDB, bool GREY> struct MediumMaker<GridMediumT<NVDB, GREY>> {
     static VDEV GridMediumT<NVDB, GREY> make(const DScene &S, const float *majorant) {

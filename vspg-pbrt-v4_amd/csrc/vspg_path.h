@@ -104,9 +104,10 @@ VDEV bool light_sample_li(const DQuad &q, V3 ctxp, float u0, float u1, LightLi *
     return true;
 }
 // light.SampleLi(ctx, uLight, lambda, allowIncompletePDF = true) for light `lightIndex` of the scene's light list
+template <bool FULL = true>
 VDEV bool sample_light(const DScene &S, int lightIndex, V3 ctxp, float u0, float u1, LightLi *ls, bool *delta_light) {
     *delta_light = false;
-    if (lightIndex < S.n_lights) return light_sample_li(light_quad_at(lightIndex), ctxp, u0, u1, ls);
+    if (!FULL || lightIndex < S.n_lights) return light_sample_li(light_quad_at(lightIndex), ctxp, u0, u1, ls);
     const int k = lightIndex - S.n_lights;
     // UniformInfiniteLight::SampleLi returns {} for the incomplete PDF (lights.cpp:1019-1023): the sky is reached by escaping rays only
     if (S.inf_type[k] != VSPG_LIGHT_DISTANT) return false;
@@ -132,13 +133,14 @@ struct PrevCtx {
     V3 p;
     int quad;
     V3 perr;  // triangle vertices only (a rectangle's bound is a constant of the rectangle)
+    template <bool FULL = true>
     VDEV LsCtx expand(const DScene &S) const {
         LsCtx c;
         if (quad >= 0) {
             const DQuad &q = quad_at(quad);
             c.pi = p3i_from_err(p, ld3(q.perr));
             c.n = ld3(q.n);
-        } else if (is_tri(quad)) {
+        } else if (FULL && is_tri(quad)) {
             const DTri &T = S.tris[tri_of(quad)];
             c.pi = p3i_from_err(p, perr);
             c.n = V3{T.nx, T.ny, T.nz};
@@ -238,7 +240,8 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
     float u = sampler.get1d();
     // UniformLightSampler::Sample (lightsamplers.h:33-38) over the emissive rectangles followed by the infinite lights
-    const int n_all = S.n_lights + S.n_inf;
+    constexpr bool kFull = !Medium::kSimpleScene;
+    const int n_all = kFull ? S.n_lights + S.n_inf : S.n_lights;
     bool have_light = n_all > 0;
     int lightIndex = 0;
     float lightPmf = 0;
@@ -251,7 +254,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     if (!have_light) return sp(0.f);
     LightLi ls;
     bool delta_light = false;
-    if (!sample_light(S, lightIndex, ctxp, ul0, ul1, &ls, &delta_light)) return sp(0.f);
+    if (!sample_light<kFull>(S, lightIndex, ctxp, ul0, ul1, &ls, &delta_light)) return sp(0.f);
     float p_l = lightPmf * ls.pdf;
 
     float scatterPDF;
@@ -283,7 +286,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
         // every surface here carries a material: any hit is an opaque blocker (:1197-1200)
 #ifndef VSPG_EXP_NOANYHIT
-        if (scene_intersect_any(S, lo, ld, 1 - kShadowEps)) return sp(0.f);
+        if (scene_intersect_any<kFull>(S, lo, ld, 1 - kShadowEps)) return sp(0.f);
 #endif
         if (S.medium_type != VSPG_MEDIUM_NONE) {
             VSPG_PROF(PS_NEE_TR);
@@ -326,7 +329,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     }
     r_l = r_l * (r_p * p_l);
     r_u = r_u * (r_p * scatterPDF);
-    if (delta_light) return f_hat * T_ray * ls.L / avg(r_l);  // IsDeltaLight (:1248-1249)
+    if (kFull && delta_light) return f_hat * T_ray * ls.L / avg(r_l);  // IsDeltaLight (:1248-1249)
     return f_hat * T_ray * ls.L / avg(r_l + r_u);
 }
 
@@ -635,14 +638,14 @@ struct Vertex {
 
 // the part of the path-loop iteration between distance sampling and the vertex, for a path that reached
 // the surface (:350-412): emission with MIS, ISG bookkeeping, depth test
-template <class PC>
+template <bool FULL = true, class PC>
 VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, const Isect &si, Spec tw) {
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     VSPG_PROF(PS_SURF_PRE);
     if constexpr (kRec) pc.rec.add_transmittance_weight(tw);  // :350
     if (!si.hit) {  // :353-374: infinite light sources (this fork lists DeltaDirection lights among them, integrators.h:79)
         const int n_all = S.n_lights + S.n_inf;
-        for (int k = 0; k < S.n_inf; ++k) {
+        for (int k = 0; FULL && k < S.n_inf; ++k) {
             Spec Le = lds(S.inf_L[k]);  // UniformInfiniteLight::Le / DistantLight::Le (lights.cpp:1014-1017, lights.h:291-293)
             if (S.inf_type[k] == VSPG_LIGHT_DISTANT && st.depth != 0) Le = sp(0.f);
             if (st.depth == 0 || st.specularBounce) {
@@ -657,15 +660,16 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
         }
         return false;
     }
-    const DQuad &q = quad_at(is_tri(si.quad) ? 0 : si.quad);
-    Spec Le = !is_tri(si.quad) && q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377 (triangles carry no area light)
+    const bool tri_hit = FULL && is_tri(si.quad);
+    const DQuad &q = quad_at(tri_hit ? 0 : si.quad);
+    Spec Le = !tri_hit && q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377 (triangles carry no area light)
     float w_direct = 0.f;
     if (nonzero(Le)) {
         if (st.depth == 0 || st.specularBounce) {
             st.L = st.L + st.beta * Le / avg(st.r_u);
             w_direct = 1.0f;
         } else {
-            float lightPDF = (1.f / (float)(S.n_lights + S.n_inf)) * light_pdf_li(q, st.prevCtx.expand(S), st.rd);
+            float lightPDF = (1.f / (float)(FULL ? S.n_lights + S.n_inf : S.n_lights)) * light_pdf_li(q, st.prevCtx.template expand<FULL>(S), st.rd);
             st.r_l = st.r_l * lightPDF;
             float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
             st.L = st.L + st.beta * w_l * Le;
@@ -693,7 +697,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
     Isect si;
     {
         VSPG_PROF(PS_INTERSECT);
-        si = scene_intersect(S, st.ro, st.rd, kInf);
+        si = scene_intersect<!Medium::kSimpleScene>(S, st.ro, st.rd, kInf);
     }
     float tMax = si.hit ? si.t : kInf;
     vx.volume = false;
@@ -721,7 +725,7 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
             return true;
         }
     }
-    return li_surface_pre(S, st, isg, pc, si, tw);
+    return li_surface_pre<!Medium::kSimpleScene>(S, st, isg, pc, si, tw);
 }
 
 template <class Medium, bool GUIDED, class PC>
@@ -738,7 +742,7 @@ struct VertexCtx {
     Intr intr;
     Bsdf bsdf;
 };
-template <bool GREY_KD = false>
+template <bool GREY_KD = false, bool FULL = true>
 VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, VertexCtx &c) {
     Isect &si = c.si;
     Intr &intr = c.intr;
@@ -760,7 +764,7 @@ VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, V
         intr.g = vg;
         bsdf.has_lobes = false;
     } else {
-        if (is_tri(vx.quad)) {
+        if (FULL && is_tri(vx.quad)) {
             const DTri &T = S.tris[tri_of(vx.quad)];
             si.n = V3{T.nx, T.ny, T.nz};
             bsdf = bsdf_make_tri(T);
@@ -874,7 +878,7 @@ template <class Medium, bool GUIDED = false, class PC>
 VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                        const Vertex &vx, float *glds = nullptr, int gstride = 0) {
     VertexCtx c;
-    vertex_setup<(Medium::kGrey >= 2)>(S, st, vx, c);
+    vertex_setup<(Medium::kGrey >= 2), !Medium::kSimpleScene>(S, st, vx, c);
     if constexpr (GUIDED)
         return li_vertex_guided<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, glds, gstride);
     const float survivalProb = vertex_pre(S, st, sampler, vx);
