@@ -6,8 +6,7 @@ src = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
-        k = re.sub(r"\(anonymous namespace\)::|vspg::", "", k)
+        k = re.sub(r"\(anonymous namespace\)::|vspg::", "", re.sub(r"^void ", "", r["Kernel_Name"])).split("(")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, cs in agg.items():

@@ -1241,6 +1241,36 @@ def test_guiding_query_vs_oracle(guided_pair, is_volume, gg):
         assert same == 1.0
 
 
+def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
+    """The reference-default guided configuration (surface RIS + volume MIS + secondary VSP) with a field in place: the
+    workgroup kernel (mixture scratch in registers, vertices compacted by kind) and the per-lane kernel (scratch in LDS)
+    render the same film bit for bit, at a size with many workgroups."""
+    import scenes
+    P = gpu_pkg
+    W, H = 320, 200
+    scene = P.fog_box_scene(W, H)
+    scene.medium.g = 0.4
+    prm = P.default_params()
+    field = scenes.light_field(P, n=4)
+    films = {}
+    for kernel in ("wg", "lane"):
+        os.environ["VSPG_KERNEL"] = kernel
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=2)
+            r.set_guiding_field(field, field)
+            for w in range(3):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            films[r.kernel_name()] = r.film()
+            cnt = r.counters()
+            assert cnt["paths"] == 3 * W * H
+            r.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    assert sorted(films) == ["k_render_wave<HomogeneousMedium,guided>", "k_render_wave_wg<HomogeneousMedium,guided>"], sorted(films)
+    a, b = films.values()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 @pytest.mark.parametrize("stype,vtype", [(1, 0), (0, 1)])  # (ris, mis) = reference defaults; (mis, ris)
 def test_guided_paths_and_film_vs_oracle(gpu_pkg, stype, vtype):
     import scenes

@@ -632,6 +632,7 @@ __global__ __launch_bounds__(kBlock) void k_train_mstep(const DScene *__restrict
 #endif
 constexpr int kWgWavesHomog = VSPG_WG_WAVES, kWgBlockHomog = VSPG_WG_BLOCK, kWgPoolHomog = VSPG_WG_NP;
 constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 384;
+constexpr int kWgWavesGuided = 2, kWgBlockGuided = 256, kWgPoolGuided = 320;  // guided vertices: ~250 registers, 40-dword records
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
@@ -651,8 +652,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
     reset_sibling_head(work_head);
 
-    static_assert(!GUIDED, "PF_VXP aliases PF_RO: the guided vertex code reads the old ray origin");
-    constexpr int NF = GUIDED ? (int)PF_COUNT : (int)PF_GS;
+    constexpr int NF = GUIDED ? (int)PF_COUNT_GUIDED : (int)PF_GS;
     __shared__ float s_pool[NF * NP];
     __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
     __shared__ unsigned int s_item[NP];
@@ -678,8 +678,17 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
         maj_ptr = s_maj;
     }
     const Medium medium = MediumMaker<Medium>::make(S, maj_ptr);
+    // guided builds keep the mixture scratch in registers here (GStoreReg): the LDS belongs to the pool -- and to a copy of
+    // the upper levels of the two kd-trees (north star: "LDS-staged kd-tree nodes"), which `glds` then points at
     float *glds = nullptr;
-    if constexpr (GUIDED) glds = guide_lds();
+    if constexpr (GUIDED) {
+        __shared__ VspgKdNode s_kd[2][kKdLdsNodes];
+        for (int f = 0; f < 2; ++f) {
+            const int nl = S.field[f].n_nodes < kKdLdsNodes ? S.field[f].n_nodes : kKdLdsNodes;
+            for (int i = threadIdx.x; i < nl; i += kWgBlock) s_kd[f][i] = S.field[f].nodes[i];
+        }
+        glds = reinterpret_cast<float *>(&s_kd[0][0]);
+    }
     __shared__ unsigned int s_counters[CNT_COUNT];
 #ifdef VSPG_WG_WAVE_COUNTERS  // alternative sink: no per-lane registers, ~2 % slower (measured)
     const WaveCounters pc{s_counters};
@@ -845,7 +854,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                                                                           isg, pc, vx);
                         if (alive) {
                             pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
-                            pool_store_vertex(P, slot, vx);
+                            pool_store_vertex<GUIDED>(P, slot, vx);
                         }
                     } else {
                         freed = true;
@@ -858,7 +867,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                     const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
                     alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                         isg, pc, vx);
-                    if (alive) pool_store_a<Medium::kGrey>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                    if (alive) pool_store_a<Medium::kGrey, GUIDED>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
                 }
                 if (alive) {
                     toV = vx.volume;
@@ -907,8 +916,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 IsgSample isg;
                 int ch;
                 const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
-                const Vertex vx = pool_load_vertex(P, slot, fl);
-                if (li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock)) {
+                const Vertex vx = pool_load_vertex<GUIDED>(P, slot, fl);
+                if (li_segment_b<Medium, GUIDED, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock)) {
                     pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE);
                     cont = true;
                 } else {
@@ -1061,7 +1070,7 @@ __global__ __launch_bounds__(kBlock) void k_guiding_query(const DScene *__restri
     if (!d.ok) return;
     pdf[i] = gdist_pdf(d, w);
     inc[i] = gdist_incoming_pdf(S.field, d, w);
-    vsp[i] = gdist_vsp(S.field, d.field, d.region, glds, kBlock, w);
+    vsp[i] = gdist_vsp(S.field, d.field, d.region, d, w);
     V3 s;
     pdfs[i] = gdist_sample(d, u[2 * i], u[2 * i + 1], &s);
     ws[3 * i] = s.x; ws[3 * i + 1] = s.y; ws[3 * i + 2] = s.z;
@@ -2040,10 +2049,23 @@ int vspg_renderer_destroy(VspgRenderer *r) {
 // different lengths per path -- a phase lasts as long as its longest walk, while the per-lane kernel
 // refills a lane the moment its path ends (measured on the 256^3 cloud stand-in: 30.5 vs 38.6 ms per wave)
 // -- and for guided builds.  VSPG_KERNEL=wg|lane overrides (unguided builds only).
+// guided renders on the workgroup kernel (VSPG_KERNEL=wg): a trained (or loaded) field being QUERIED over a homogeneous medium
+// -- training launches record path segments and guided Russian roulette carries per-pixel state, both on the per-lane kernel.
+// Opt-in, not the default: measured on MI355X (1080p fog box, reference-default options) the per-lane kernel
+// runs a guided wave in 2.33 ms, this one in 2.58 ms (384-path pool, kd nodes in L2) / 2.93 ms (320-path pool + the upper kd
+// levels in LDS): it issues 18 % fewer vector instructions at 68 % instead of 54 % lane utilisation, but the guided vertex code
+// needs ~240 registers either way (2 waves per SIMD) and at that occupancy the phase barriers cost more than the compaction saves.
+static bool uses_wg_guided(const VspgRenderer *r) {
+    const char *kenv = getenv("VSPG_KERNEL");
+    if (!kenv || strcmp(kenv, "wg") != 0) return false;
+    return wants_guiding(r->prm) && !r->training && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
+           r->hscene.n_tris == 0 && r->hscene.n_inf == 0;
+}
 static bool uses_wg_kernel(const VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
+    if (uses_wg_guided(r)) return true;
     const char *kenv = getenv("VSPG_KERNEL");
     const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
     // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
@@ -2066,6 +2088,7 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (uses_wf_pipeline(r)) return nvdb ? "k_wf_dist_walk<NanoDenseMedium>" : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
+    if (uses_wg_guided(r)) return "k_render_wave_wg<HomogeneousMedium,guided>";
     if (uses_wg_kernel(r)) {
         if (grid) return "k_render_wave_wg<GridMedium>";
         if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg<HomogeneousMediumT<2,true>>";
@@ -2172,11 +2195,17 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const bool use_wg = uses_wg_kernel(r);
     if (use_wg) {
         const unsigned tiles_magic = tilesX > 1 ? (unsigned)((0x100000000ull + (unsigned)tilesX - 1) / (unsigned)tilesX) : 0u;
-        const int wwaves = grid ? kWgWavesGrid : kWgWavesHomog, wblock = grid ? kWgBlockGrid : kWgBlockHomog;
+        const bool gwg = uses_wg_guided(r);
+        const int wwaves = gwg ? kWgWavesGuided : grid ? kWgWavesGrid : kWgWavesHomog, wblock = gwg ? kWgBlockGuided : grid ? kWgBlockGrid : kWgBlockHomog;
         long long wblocks = (long long)r->num_cus * (wwaves * 4 / (wblock / 64));
         const long long wmax = (items + kWgChunk - 1) / kWgChunk;
         if (wblocks > wmax) wblocks = wmax;
-        if (grid)
+        if (gwg)
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, true, kWgPoolGuided, kWgBlockGuided, kWgWavesGuided>),
+                               dim3((unsigned)wblocks), dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film,
+                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
+                               work_head, r->counters);
+        else if (grid)
             hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,

@@ -28,11 +28,14 @@ VDEV float vmf_norm(float kappa) { return kappa / (kTwoPi * (1 - fast_exp(-2 * k
 VDEV float vmf_eval(V3 mu, float kappa, V3 w) { return vmf_norm(kappa) * fast_exp(kappa * (dot(mu, w) - 1)); }
 VDEV float kappa_clamp(float k) { return k < 1e-2f ? 1e-2f : (k > 1e4f ? 1e4f : k); }
 
-VDEV int field_lookup(const DField &F, V3 p) {
+// lds / n_lds: the first n_lds nodes of the tree staged in LDS (the workgroup kernel, guided builds).  Node numbers grow with
+// creation time, so the low-numbered nodes are the upper levels: a descent takes its first ~10 steps at LDS latency (~64
+// cycles each) instead of L2 latency (~500 each, dependent) and finishes in HBM/L2 for the last one or two.
+VDEV int field_lookup(const DField &F, V3 p, const VspgKdNode *lds = nullptr, int n_lds = 0) {
     if (!F.nodes || F.n_nodes <= 0) return -1;
     uint32_t node = 0;
     for (int depth = 0; depth < 64; ++depth) {
-        VspgKdNode nd = F.nodes[node];
+        VspgKdNode nd = (int)node < n_lds ? lds[node] : F.nodes[node];
         uint32_t axis = nd.packed & 3u, idx = nd.packed >> 2;
         if (axis == 3u) return (int)idx < F.n_regions ? (int)idx : -1;
         float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
@@ -81,90 +84,115 @@ VDEV void lobe_product(V3 mu, float kappa, float nk, float w, V3 m2, float k2, f
 // same operations on the same inputs, so the same bits.  The scratch of a lane stays valid until the lane's next
 // gdist_init -- in particular for the VolumeScatterProbability query of the NEXT segment (fetch_vsp).
 constexpr int kGFloats = 9 * GK;
-constexpr int kGuideBlock = 256;  // threads per block of every kernel that runs guided path code
+constexpr int kGuideBlock = 256;  // threads per block of every kernel that keeps the guided scratch in LDS
 __shared__ float s_gmix[kGuideBlock * kGFloats];
 VDEV float *guide_lds() { return s_gmix + threadIdx.x; }
 VDEV const float *region_aux(const DField &F, int region) { return F.aux + (size_t)region * (2 * GK); }
-struct GDist {
+// Two homes for the scratch, same contents:
+//   GStoreLds  per-lane columns of s_gmix (the per-lane kernels: a path lives in a lane's registers for its whole life and
+//              has none to spare);
+//   GStoreReg  72 registers (the workgroup kernel's vertex phase: a path's registers exist only inside a phase, and the LDS
+//              belongs to the path pool).  Every loop over lobes is fully unrolled with `k < n` predicates, so all indices are
+//              compile-time constants and the array never leaves the register file.
+struct GStoreLds {
+    float *lds;
+    int stride;
+    VDEV float get(int e, int k) const { return lds[(e * GK + k) * stride]; }
+    VDEV void set(int e, int k, float v) { lds[(e * GK + k) * stride] = v; }
+};
+struct GStoreReg {
+    float a[kGFloats];
+    VDEV float get(int e, int k) const { return a[e * GK + k]; }
+    VDEV void set(int e, int k, float v) { a[e * GK + k] = v; }
+};
+template <class ST>
+struct GDistT {
     bool ok;
     int field, region, n;
     V3 p;
-    float *lds;
-    int stride;
-    VDEV float &w(int k) const { return lds[(0 * GK + k) * stride]; }
-    VDEV float &kappa(int k) const { return lds[(1 * GK + k) * stride]; }
-    VDEV V3 mu(int k) const { return V3{lds[(2 * GK + k) * stride], lds[(3 * GK + k) * stride], lds[(4 * GK + k) * stride]}; }
-    VDEV void set_mu(int k, V3 m) const {
-        lds[(2 * GK + k) * stride] = m.x;
-        lds[(3 * GK + k) * stride] = m.y;
-        lds[(4 * GK + k) * stride] = m.z;
-    }
-    VDEV float &pnorm(int k) const { return lds[(5 * GK + k) * stride]; }
-    VDEV void set_raw(int k, V3 m) const {
-        lds[(6 * GK + k) * stride] = m.x;
-        lds[(7 * GK + k) * stride] = m.y;
-        lds[(8 * GK + k) * stride] = m.z;
-    }
+    ST st;
+    VDEV float w(int k) const { return st.get(0, k); }
+    VDEV void set_w(int k, float v) { st.set(0, k, v); }
+    VDEV float kappa(int k) const { return st.get(1, k); }
+    VDEV void set_kappa(int k, float v) { st.set(1, k, v); }
+    VDEV V3 mu(int k) const { return V3{st.get(2, k), st.get(3, k), st.get(4, k)}; }
+    VDEV void set_mu(int k, V3 m) { st.set(2, k, m.x); st.set(3, k, m.y); st.set(4, k, m.z); }
+    VDEV float pnorm(int k) const { return st.get(5, k); }
+    VDEV void set_pnorm(int k, float v) { st.set(5, k, v); }
+    VDEV V3 raw(int k) const { return V3{st.get(6, k), st.get(7, k), st.get(8, k)}; }
+    VDEV void set_raw(int k, V3 m) { st.set(6, k, m.x); st.set(7, k, m.y); st.set(8, k, m.z); }
 };
-VDEV V3 guide_raw_dir(const float *lds, int stride, int k) {
-    return V3{lds[(6 * GK + k) * stride], lds[(7 * GK + k) * stride], lds[(8 * GK + k) * stride]};
-}
+using GDist = GDistT<GStoreLds>;
+using GDistReg = GDistT<GStoreReg>;
+VDEV GStoreLds gstore_lds(float *lds, int stride) { return GStoreLds{lds, stride}; }
 
-VDEV GDist gdist_init(const DField *fields, int f, V3 p, bool have_product, V3 m2, float k2, float *lds, int stride) {
-    GDist d;
+// fills `d` in place (d.st is set by the caller for the LDS home; the register home is never copied: a by-value copy of the
+// 72-float array would pin it in scratch memory)
+constexpr int kKdLdsNodes = 1024;  // nodes per field staged in LDS by the workgroup kernel (8 KB per field)
+template <class ST>
+VDEV void gdist_init(GDistT<ST> &d, const DField *fields, int f, V3 p, bool have_product, V3 m2, float k2,
+                     const VspgKdNode *kd_lds = nullptr) {
     d.ok = false;
     d.field = f;
     d.p = p;
     d.n = 0;
-    d.lds = lds;
-    d.stride = stride;
     // f differs per lane when a wavefront holds volume and surface vertices: select between the two (scalar-loaded)
     // field records instead of indexing the array per lane
     DField F = fields[0];
     if (f) F = fields[1];
-    d.region = field_lookup(F, p);
-    if (d.region < 0) return d;
+    if (kd_lds) {
+        const int nl = F.n_nodes < kKdLdsNodes ? F.n_nodes : kKdLdsNodes;
+        d.region = field_lookup(F, p, kd_lds + (f ? kKdLdsNodes : 0), nl);
+    } else {
+        d.region = field_lookup(F, p);
+    }
+    if (d.region < 0) return;
     const VspgFieldRegion &R = F.regions[d.region];
-    if (R.n_lobes <= 0) return d;
+    if (R.n_lobes <= 0) return;
     d.ok = true;
     d.n = R.n_lobes < GK ? R.n_lobes : GK;
     const float *ax = region_aux(F, d.region);  // [k] vmf_norm(kappa_clamp(kappa[k])), [GK + k] kappa_clamp(kappa[k])
     const float nk2 = have_product ? vmf_norm(k2) : 0.f;
     const V3 pivot = ld3(R.pivot);
     float sum = 0;
-    for (int h = 0; h < GK; h += 4) {
-        if (h >= d.n) break;
-        const float4 w4 = ld4(R.weight + h), mx4 = ld4(R.mu[0] + h), my4 = ld4(R.mu[1] + h), mz4 = ld4(R.mu[2] + h),
-                     d4 = ld4(R.distance + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = h + j;
-            if (k < d.n) {
-                V3 mu = lobe_dir(pivot, V3{c4(mx4, j), c4(my4, j), c4(mz4, j)}, c4(d4, j), p);
-                d.set_raw(k, mu);
-                float kap = c4(k4, j);
-                V3 mo = mu;
-                float ko = kap, wo = c4(w4, j), no = c4(n4, j);
-                if (have_product) lobe_product(mu, kap, c4(n4, j), c4(w4, j), m2, k2, nk2, &mo, &ko, &wo, &no);
-                d.set_mu(k, mo);
-                d.kappa(k) = ko;
-                d.pnorm(k) = no;
-                d.w(k) = wo;
-                sum += wo;
+    for (int h = 0; h < GK; h += 4) {
+        if (h < d.n) {
+            const float4 w4 = ld4(R.weight + h), mx4 = ld4(R.mu[0] + h), my4 = ld4(R.mu[1] + h), mz4 = ld4(R.mu[2] + h),
+                         d4 = ld4(R.distance + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = h + j;
+                if (k < d.n) {
+                    V3 mu = lobe_dir(pivot, V3{c4(mx4, j), c4(my4, j), c4(mz4, j)}, c4(d4, j), p);
+                    d.set_raw(k, mu);
+                    float kap = c4(k4, j);
+                    V3 mo = mu;
+                    float ko = kap, wo = c4(w4, j), no = c4(n4, j);
+                    if (have_product) lobe_product(mu, kap, c4(n4, j), c4(w4, j), m2, k2, nk2, &mo, &ko, &wo, &no);
+                    d.set_mu(k, mo);
+                    d.set_kappa(k, ko);
+                    d.set_pnorm(k, no);
+                    d.set_w(k, wo);
+                    sum += wo;
+                }
             }
         }
     }
     if (sum > 0 && !isinf_(sum)) {
-        for (int k = 0; k < d.n; ++k) d.w(k) = d.w(k) / sum;
+#pragma unroll
+        for (int k = 0; k < GK; ++k)
+            if (k < d.n) d.set_w(k, d.w(k) / sum);
     } else {
-        for (int k = 0; k < d.n; ++k) {
-            d.set_mu(k, guide_raw_dir(d.lds, d.stride, k));
-            d.kappa(k) = ax[GK + k];
-            d.pnorm(k) = ax[k];
-            d.w(k) = R.weight[k];
-        }
+#pragma unroll
+        for (int k = 0; k < GK; ++k)
+            if (k < d.n) {
+                d.set_mu(k, d.raw(k));
+                d.set_kappa(k, ax[GK + k]);
+                d.set_pnorm(k, ax[k]);
+                d.set_w(k, R.weight[k]);
+            }
     }
-    return d;
 }
 // The product lobe of GuidedPhaseFunction::init as data (so that one gdist_init call serves both vertex kinds)
 VDEV void volume_product_lobe(V3 dir, float g, bool *have_product, V3 *m2, float *k2) {
@@ -183,104 +211,138 @@ VDEV void volume_product_lobe(V3 dir, float g, bool *have_product, V3 *m2, float
     *k2 = kg;
 }
 VDEV GDist gdist_init_surface(const DField *fields, V3 p, V3 n, float *lds, int stride) {
-    return gdist_init(fields, 0, p, true, n, kCosineLobeKappa, lds, stride);
+    GDist d;
+    d.st = gstore_lds(lds, stride);
+    gdist_init(d, fields, 0, p, true, n, kCosineLobeKappa);
+    return d;
 }
 VDEV GDist gdist_init_volume(const DField *fields, V3 p, V3 dir, float g, float *lds, int stride) {
-    float ag = __builtin_fabsf(g);
-    if (ag < 1e-3f) return gdist_init(fields, 1, p, false, mk(0, 0, 1), 0, lds, stride);
-    if (ag > 0.99f) ag = 0.99f;
-    float kg = ag * (3 - ag * ag) / (1 - ag * ag);
-    V3 axis = g > 0 ? dir : -dir;
-    return gdist_init(fields, 1, p, true, normalize(axis), kg, lds, stride);
+    GDist d;
+    d.st = gstore_lds(lds, stride);
+    bool hp;
+    V3 m2;
+    float k2;
+    volume_product_lobe(dir, g, &hp, &m2, &k2);
+    gdist_init(d, fields, 1, p, hp, m2, k2);
+    return d;
 }
-VDEV float gdist_pdf(const GDist &d, V3 w) {
+template <class ST>
+VDEV float gdist_pdf(const GDistT<ST> &d, V3 w) {
     float s = 0;
-    for (int k = 0; k < d.n; ++k) s += d.w(k) * (d.pnorm(k) * fast_exp(d.kappa(k) * (dot(d.mu(k), w) - 1)));  // w * vmf_eval
+#pragma unroll
+    for (int k = 0; k < GK; ++k)
+        if (k < d.n) s += d.w(k) * (d.pnorm(k) * fast_exp(d.kappa(k) * (dot(d.mu(k), w) - 1)));  // w * vmf_eval
     return s;
 }
-VDEV float gdist_incoming_pdf(const DField *fields, const GDist &d, V3 w) {
+template <class ST>
+VDEV float gdist_incoming_pdf(const DField *fields, const GDistT<ST> &d, V3 w) {
     DField F = fields[0];
     if (d.field) F = fields[1];
     const VspgFieldRegion &R = F.regions[d.region];
     const float *ax = region_aux(F, d.region);
     float s = 0;
-    for (int h = 0; h < GK; h += 4) {
-        if (h >= d.n) break;
-        const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = h + j;
-            if (k < d.n) s += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(guide_raw_dir(d.lds, d.stride, k), w) - 1)));
+    for (int h = 0; h < GK; h += 4) {
+        if (h < d.n) {
+            const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = h + j;
+                if (k < d.n) s += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(d.raw(k), w) - 1)));
+            }
         }
     }
     return s;
 }
 // IncomingRadiancePDF of two directions in one pass over the region record (RIS: both candidates); per direction the
 // same operations in the same order as gdist_incoming_pdf
-VDEV void gdist_incoming_pdf2(const DField *fields, const GDist &d, bool want0, V3 w0, V3 w1, float *inc0, float *inc1) {
+template <class ST>
+VDEV void gdist_incoming_pdf2(const DField *fields, const GDistT<ST> &d, bool want0, V3 w0, V3 w1, float *inc0, float *inc1) {
     DField F = fields[0];
     if (d.field) F = fields[1];
     const VspgFieldRegion &R = F.regions[d.region];
     const float *ax = region_aux(F, d.region);
     float s0 = 0, s1 = 0;
-    for (int h = 0; h < GK; h += 4) {
-        if (h >= d.n) break;
-        const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = h + j;
-            if (k < d.n) {
-                const V3 dir = guide_raw_dir(d.lds, d.stride, k);
-                if (want0) s0 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w0) - 1)));
-                s1 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w1) - 1)));
+    for (int h = 0; h < GK; h += 4) {
+        if (h < d.n) {
+            const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = h + j;
+                if (k < d.n) {
+                    const V3 dir = d.raw(k);
+                    if (want0) s0 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w0) - 1)));
+                    s1 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w1) - 1)));
+                }
             }
         }
     }
     *inc0 = s0;
     *inc1 = s1;
 }
-// VolumeScatterProbability(w) of the region the lane's scratch was initialised for (field f, `region`, at its point)
-VDEV float gdist_vsp(const DField *fields, int f, int region, const float *lds, int stride, V3 w) {
+// VolumeScatterProbability(w) of the region the scratch was initialised for (field f, `region`, at its point)
+template <class ST>
+VDEV float gdist_vsp(const DField *fields, int f, int region, const GDistT<ST> &d, V3 w) {
     DField F = fields[0];
     if (f) F = fields[1];
     const VspgFieldRegion &R = F.regions[region];
     const float *ax = region_aux(F, region);
     int n = R.n_lobes < GK ? R.n_lobes : GK;
     float num = 0, den = 0;
-    for (int h = 0; h < GK; h += 4) {
-        if (h >= n) break;
-        const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h), v4 = ld4(R.vsp + h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = h + j;
-            if (k < n) {
-                float e = c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(guide_raw_dir(lds, stride, k), w) - 1)));
-                num += e * c4(v4, j);
-                den += e;
+    for (int h = 0; h < GK; h += 4) {
+        if (h < n) {
+            const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h), v4 = ld4(R.vsp + h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = h + j;
+                if (k < n) {
+                    float e = c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(d.raw(k), w) - 1)));
+                    num += e * c4(v4, j);
+                    den += e;
+                }
             }
         }
     }
     if (!(den > 0)) return -1.f;
     return num / den;
 }
-VDEV float gdist_sample(const GDist &d, float u0, float u1, V3 *wi) {
-    int k = 0;
+template <class ST>
+VDEV float gdist_sample(const GDistT<ST> &d, float u0, float u1, V3 *wi) {
+    // the lobe: `for (k = 0; k < n - 1; ++k) { if (u0 < acc + w_k) break; acc += w_k; }` as a predicated scan (constant indices)
+    bool scanning = true;
+    int ks = 0;
     float acc = 0;
-    for (; k < d.n - 1; ++k) {
-        float wk = d.w(k);
-        if (u0 < acc + wk) break;
-        acc += wk;
+#pragma unroll
+    for (int j = 0; j < GK - 1; ++j) {
+        if (scanning && j < d.n - 1) {
+            const float wj = d.w(j);
+            if (u0 < acc + wj) {
+                scanning = false;
+            } else {
+                acc += wj;
+                ks = j + 1;
+            }
+        }
     }
-    float wk = d.w(k);
+    float wk = 0, kap = 0;
+    V3 mz = mk(0, 0, 1);
+#pragma unroll
+    for (int j = 0; j < GK; ++j)
+        if (j == ks) {
+            wk = d.w(j);
+            kap = d.kappa(j);
+            mz = d.mu(j);
+        }
     float uw = wk > 0 ? (u0 - acc) / wk : 0.f;
     uw = uw < 0 ? 0 : (uw > kOneMinusEps ? kOneMinusEps : uw);
-    float kap = d.kappa(k);
     float W = 1 + logf_(uw + (1 - uw) * fast_exp(-2 * kap)) / kap;
     W = clampf(W, -1, 1);
     float sinT = safe_sqrt(1 - W * W);
     float phi = kTwoPi * u1;
     Frame fr;
-    fr.z = d.mu(k);
+    fr.z = mz;
     coordinate_system(fr.z, &fr.x, &fr.y);
     *wi = fr.from_local(V3{sinT * cosf_(phi), sinT * sinf_(phi), W});
     return gdist_pdf(d, *wi);

@@ -1,6 +1,8 @@
 // vspg_path.h -- device-side path logic: SampleLd, SampleDistance, Li, EvaluatePixelSample.
 // (reference: src/pbrt/cpu/guidedvolpathvspgintegrator.cpp; citations per function)
 #pragma once
+#include <type_traits>
+
 #include "vspg_device.h"
 #include "vspg_guiding.h"
 #include "vspg_train.h"
@@ -233,9 +235,10 @@ struct Intr {
     V3 wo;
     float g;
 };
-template <class Medium, class PC>
+template <class Medium, class PC, class GD = GDist>
 VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, const Bsdf *bsdf, int ch,
-                    Sampler &sampler, Spec r_p, PC &pc, const GDist *gd = nullptr) {
+                    Sampler &sampler, Spec r_p, PC &pc, const GD *gd = nullptr, bool use_gd = false) {
+    // (use_gd separate from the pointer: a `cond ? &gd : nullptr` argument keeps a register-resident distribution in scratch)
     V3 ctxp = intr.pi.mid();
     if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
     float u = sampler.get1d();
@@ -264,13 +267,13 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     if (intr.is_surface) {
         f_hat = bsdf_f(*bsdf, wo, wi) * absdot(wi, intr.n);
         float bsdfPDF = bsdf_pdf(*bsdf, wo, wi);
-        if (gd) bsdfPDF = ((1.0f - kGuidingProbability) * bsdfPDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        if (use_gd) bsdfPDF = ((1.0f - kGuidingProbability) * bsdfPDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
         scatterPDF = 1.0f * bsdfPDF;
     } else {
         float p = henyey_greenstein(dot(wo, wi), intr.g);
         f_hat = sp(p);
         float phasePDF = p;
-        if (gd) phasePDF = ((1.0f - kGuidingProbability) * phasePDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        if (use_gd) phasePDF = ((1.0f - kGuidingProbability) * phasePDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
         scatterPDF = 1.0f * phasePDF;
     }
     if (!nonzero(f_hat)) return sp(0.f);
@@ -728,7 +731,8 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
     return li_surface_pre<!Medium::kSimpleScene>(S, st, isg, pc, si, tw);
 }
 
-template <class Medium, bool GUIDED, class PC>
+// GREG: the guiding scratch lives in registers (GStoreReg, the workgroup kernel) instead of the lane's LDS column (glds, gstride)
+template <class Medium, bool GUIDED, bool GREG, class PC>
 VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                            bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride);
 
@@ -874,13 +878,13 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
     return true;
 }
 
-template <class Medium, bool GUIDED = false, class PC>
+template <class Medium, bool GUIDED = false, bool GREG = false, class PC>
 VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                        const Vertex &vx, float *glds = nullptr, int gstride = 0) {
     VertexCtx c;
     vertex_setup<(Medium::kGrey >= 2), !Medium::kSimpleScene>(S, st, vx, c);
     if constexpr (GUIDED)
-        return li_vertex_guided<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, glds, gstride);
+        return li_vertex_guided<Medium, GUIDED, GREG>(S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, glds, gstride);
     const float survivalProb = vertex_pre(S, st, sampler, vx);
     if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 IsNonSpecular(bsdf.Flags()) / :833
         VSPG_PROF(PS_NEE);
@@ -896,7 +900,7 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
                      int gstride = 0) {
     Vertex vx;
     if (!li_segment_a<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, vx)) return false;
-    return li_segment_b<Medium, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, gstride);
+    return li_segment_b<Medium, GUIDED, false>(S, medium, st, ch, sampler, pc, vx, glds, gstride);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -905,11 +909,14 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
 // 383-398, 404-540) -- same flow as the unguided tail of li_segment, written straight (no sin/cos
 // fusion) because the sampling branches differ per guiding type.
 // ---------------------------------------------------------------------------------------
-template <class Medium, bool GUIDED, class PC>
+template <class Medium, bool GUIDED, bool GREG, class PC>
 VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                            bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride) {
     (void)sampler.get1d();  // v (the stochastic-lookup sample of Init)
-    GDist gd;
+    using Store = typename std::conditional<GREG, GStoreReg, GStoreLds>::type;
+    using GD = GDistT<Store>;
+    GD gd;
+    if constexpr (!GREG) gd.st = gstore_lds(glds, gstride);
     bool useGuiding;
     float survivalProb = 1.f;
     // gphase.init(&phase, p, ray.d, v) / gbsdf.init(&bsdf, ray, si, v): ONE Init call site for both vertex kinds -- a
@@ -935,7 +942,8 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
     }
     gd.ok = false;
     gd.region = -1;
-    if (ginit) gd = gdist_init(S.field, gfield, gpoint, gprod, gm2, gk2, glds, gstride);
+    // (register home: `glds` carries the workgroup's LDS copy of the upper kd levels instead of a scratch column)
+    if (ginit) gdist_init(gd, S.field, gfield, gpoint, gprod, gm2, gk2, GREG ? reinterpret_cast<const VspgKdNode *>(glds) : nullptr);
     const bool useScatterGuiding = S.prm.vspsecondaryguiding ? gd.ok : false;
     st.gs.vsp_next = -1.f;
     if (volume_vertex) {
@@ -954,7 +962,7 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
             survivalProb = S.prm.surfacerrguiding ? (st.specularBounce ? 0.95f : guided_russian_roulette(st.beta, st.pce, 0.1f)) : 1.f;
     }
     if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {
-        Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, useGuiding ? &gd : nullptr);
+        Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, &gd, useGuiding);
         st.L = st.L + st.beta * Ld;
         pc.rec.add_scattered_direct_light(Ld);  // :485 / :838
     }
@@ -1155,7 +1163,7 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
         }
     }
     // the next segment's VolumeScatterProbability(ray.d) of this vertex's distribution (one call site for both kinds)
-    if (cont && useScatterGuiding) st.gs.vsp_next = gdist_vsp(S.field, gfield, gd.region, glds, gstride, wi);
+    if (cont && useScatterGuiding) st.gs.vsp_next = gdist_vsp(S.field, gfield, gd.region, gd, wi);
     return cont;
 }
 

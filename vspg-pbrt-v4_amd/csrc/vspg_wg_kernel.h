@@ -44,8 +44,12 @@ enum {
     // The vertex position lives only from the segment phase to the vertex phase, the ray origin only
     // from the vertex phase to the next segment phase (the unguided vertex code never reads the old
     // origin): they share three dwords.  480 -> 512 paths fit the 80 KB a workgroup may use.
-    PF_VXP = PF_RO
+    PF_VXP = PF_RO,
+    // guided builds: gbsdf.init queries the cache at ray.o + tHit * ray.d (guiding.h:85), so the origin must survive
+    PF_VXP_GUIDED = 37,  // 3
+    PF_COUNT_GUIDED = 40
 };
+template <bool GUIDED> struct PoolVx { static constexpr int kField = GUIDED ? (int)PF_VXP_GUIDED : (int)PF_VXP; };
 enum {
     FL_DEPTH_MASK = 0xff,
     FL_CH_SHIFT = 8,            // 2 bits
@@ -126,14 +130,15 @@ VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sa
     P.f(PF_VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
 }
 
+template <bool GUIDED = false>
 VDEV void pool_store_vertex(const Pool &P, int slot, const Vertex &vx) {
-    P.set3(PF_VXP, slot, vx.p);
+    P.set3(PoolVx<GUIDED>::kField, slot, vx.p);
     if (vx.volume) P.f(PF_VXG, slot) = vx.g; else P.i(PF_VXG, slot) = vx.quad;
     P.f(PF_VXT, slot) = vx.t;
 }
 // after li_segment_a: only what that half changes (L, beta, r_u, r_l, sampler, depth / ISG flags) plus
 // the vertex it stopped at; ray, previous context, rr_correction and guiding state are untouched
-template <int GREY = 0>
+template <int GREY = 0, bool GUIDED = false>
 VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                        const Vertex &vx, uint32_t keep_flags) {
     P.sets(PF_L, slot, st.L);
@@ -144,12 +149,13 @@ VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampl
     if (vx.volume) fl |= FL_VX_VOLUME;
     P.u(PF_FLAGS, slot) = fl;
     P.f(PF_VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
-    pool_store_vertex(P, slot, vx);
+    pool_store_vertex<GUIDED>(P, slot, vx);
 }
+template <bool GUIDED = false>
 VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
     Vertex vx;
     vx.volume = (fl & FL_VX_VOLUME) != 0;
-    vx.p = P.v3(PF_VXP, slot);
+    vx.p = P.v3(PoolVx<GUIDED>::kField, slot);
     vx.g = vx.volume ? P.f(PF_VXG, slot) : 0.f;
     vx.quad = vx.volume ? -1 : P.i(PF_VXG, slot);
     __builtin_assume(vx.quad >= -1);
