@@ -113,6 +113,14 @@ typedef struct VspgMedium {
     int32_t has_transform;
     float render_from_medium[16];
     float medium_from_render[16];
+    /* VSPG_MEDIUM_NANOVDB only -- the temperature grid of NanoVDBMedium (media.h:724-735; config 5 "explosion"):
+     * Le(p) = nvdb_le_scale * Blackbody((T(p) - temperature_offset) * temperature_scale).  The path adds volume emission in
+     * the DELTA-TRACKING callback only (guidedvolpathvspgintegrator.cpp:895-906); a heterogeneous medium under the default
+     * "vspsamplingmethod" "resampling" never evaluates it, so with that method the grid is accepted and
+     * has no effect on the result (it is not even copied).  With "nds" the emission would be sampled -- blackbody emission
+     * at RGB-mode wavelengths (App. C #13) is outside this build's scope: VSPG_ESCOPE.  HOST pointer, same layout as density. */
+    const float *temperature;
+    float nvdb_le_scale, temperature_offset, temperature_scale;
 } VspgMedium;
 
 /* Triangle geometry (src/pbrt/shapes.h:828-1030, shapes.cpp:168-262, cpu/aggregates.cpp:529-640):

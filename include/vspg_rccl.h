@@ -1,0 +1,37 @@
+/* vspg_rccl.h -- the multi-GPU step of the GuidedVolPathVSPG path in C (north star: "host code stays C++",
+ * "RCCL all-reduce over xGMI of the float film/weight tiles at frame end"), exported by csrc/libvspg_rccl.so.
+ *
+ * One process per GPU.  Every rank renders its own sample indices of the same frame through include/vspg.h
+ * (VspgRenderConfig.shard_index / shard_count); these entry points add the two collectives of the path:
+ *   - the image-space VSP statistics, summed over the ranks on the steps where the buffer updates
+ *     (PostProcessWave, guidedvolpathvspgintegrator.cpp:230-260, with waveCounter advancing by the rank count), and
+ *   - the float film {sum w*rgb, sum w} (RGBFilm accumulate contract, film.h:251-267) at frame end.
+ * `comm` is an ncclComm_t (RCCL), `stream` a hipStream_t; both collectives are enqueued on `stream`.
+ * The reference has no counterpart (it is a single-process CPU renderer): this is what a multi-GPU pbrt host links next to
+ * libvspg_hip.so.  Python (bench.py, vspg-pbrt-v4_amd/sharding.py) runs the same two collectives through torch.distributed. */
+#ifndef VSPG_RCCL_H
+#define VSPG_RCCL_H
+#include "vspg.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Communicator for the ranks of one node from the launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK as set by
+ * torch.distributed.run / mpirun wrappers): rank 0 creates the ncclUniqueId and publishes it in the file `id_file`
+ * (NULL: $VSPG_RCCL_ID_FILE, else /tmp/vspg_rccl_id.<MASTER_PORT or 29500>), the others wait for it (at most 60 s).
+ * hipSetDevice(LOCAL_RANK) is called.  *comm receives the ncclComm_t.  world == 1 needs no file. */
+int vspg_rccl_init_from_env(const char *id_file, int *rank, int *world, int *local_rank, void **comm);
+int vspg_rccl_destroy(void *comm);
+
+/* PostProcessWave of a sharded step: vspg_post_process_step(r, world, sum, stream) where `sum` is the all-reduced
+ * copy of the ranks' VSP statistics when vspg_isg_update_due(r, world), NULL otherwise. */
+int vspg_rccl_post_process_step(VspgRenderer *r, int world, void *comm, void *stream);
+/* frame end: in-place sum of the film over the ranks */
+int vspg_rccl_allreduce_film(VspgRenderer *r, void *comm, void *stream);
+/* sum of the path counters over the ranks (host values) */
+int vspg_rccl_sum_counters(VspgRenderer *r, void *comm, void *stream, VspgCounters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -2959,9 +2959,13 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
         if (m->type == VSPG_MEDIUM_NANOVDB && !(m->voxel_size[0] > 0 && m->voxel_size[1] > 0 && m->voxel_size[2] > 0 && m->majorant_scale > 0))
             return VSPG_EINVAL;
         if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) {
-            if (m->type == VSPG_MEDIUM_NANOVDB) return VSPG_ESCOPE; /* NanoVDBMedium emits through a temperature grid only */
+            if (m->type == VSPG_MEDIUM_NANOVDB) return VSPG_EINVAL; /* NanoVDBMedium emits through its temperature grid only */
             if (m->le_scale && (m->le_nx <= 0 || m->le_ny <= 0 || m->le_nz <= 0)) return VSPG_EINVAL;
         }
+        /* temperature grid (media.h:724-735): volume emission is sampled by the delta-tracking routine only (:895-906) -- never
+         * evaluated under "resampling" (accepted, no effect), outside scope under "nds" */
+        if (m->type == VSPG_MEDIUM_NANOVDB && m->temperature && m->nvdb_le_scale > 0 && p->vspsamplingmethod != VSPG_VSP_RESAMPLING)
+            return VSPG_ESCOPE;
     }
     return 0;
 }

@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.vspg_abi_version() == 4
 
 
+def test_rccl_library_exports_every_declared_symbol(pkg):
+    """include/vspg_rccl.h (the multi-GPU step in C, over RCCL) is exported by csrc/libvspg_rccl.so; no calls without a GPU."""
+    import subprocess
+    csrc = os.path.join(ROOT, "vspg-pbrt-v4_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "libvspg_rccl.so"])
+    pkg.load()  # libvspg_hip.so first: libvspg_rccl.so links it
+    lib = C.CDLL(os.path.join(csrc, "libvspg_rccl.so"))
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vspg_rccl.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(vspg_rccl_[a-z0-9_]+)\s*\(", src)))
+    assert names == ["vspg_rccl_allreduce_film", "vspg_rccl_destroy", "vspg_rccl_init_from_env", "vspg_rccl_post_process_step",
+                     "vspg_rccl_sum_counters"]
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    assert lib.vspg_rccl_post_process_step(None, 2, None, None) == pkg.VSPG_EINVAL   # argument check only
+
+
 def test_defaults_match_reference_create_defaults(pkg):
     # GuidedVolPathVSPGIntegrator::Create (guidedvolpathvspgintegrator.cpp:1263-1319)
     p = pkg.default_params()

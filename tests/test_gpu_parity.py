@@ -1462,12 +1462,26 @@ def test_error_conventions_on_device(gpu_pkg):
     prm = P.app_f_params()
     prm.maxdepth = -1
     assert create(scene, prm) in (P.VSPG_EINVAL, 0)  # (negative depth is the reference's "no bounce" -- not an error there)
-    # NanoVDB-semantics medium with emission: temperature grids are out of scope
+    # NanoVDBMedium emits through its temperature grid only (config 5 "explosion"): the path samples volume emission in the
+    # delta-tracking routine, never under "resampling" -- accepted there (and without effect), refused under "nds"
     from scenes import nvdb_scene, cloud_density
     dens = cloud_density(8)
     s2 = nvdb_scene(dens, (8, 8, 8), 0.5, 1.0, W=W, H=H)
     s2.medium.Le[:] = (1, 1, 1)
-    assert create(s2, P.app_f_params()) == P.VSPG_ESCOPE
+    assert create(s2, P.app_f_params()) == P.VSPG_EINVAL and b"temperature grid" in lib.vspg_last_error()
+    s2.medium.Le[:] = (0, 0, 0)
+    temp = (dens * 3000).astype(np.float32)
+    s2.medium.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+    s2.medium.nvdb_le_scale, s2.medium.temperature_offset, s2.medium.temperature_scale = 1.0, 0.0, 1.0
+    nds = P.app_f_params()
+    nds.vspsamplingmethod = P.VSP_NDS
+    assert create(s2, nds) == P.VSPG_ESCOPE and b"temperature" in lib.vspg_last_error()
+    hot = P.Renderer(s2, P.app_f_params(), W, H)
+    s2.medium.temperature = None
+    cold = P.Renderer(s2, P.app_f_params(), W, H)
+    hot.render_wave(0, 2); cold.render_wave(0, 2)
+    assert np.array_equal(hot.film().view(np.uint32), cold.film().view(np.uint32))   # App. C #12: no volume emission under resampling
+    hot.close(); cold.close()
     # emissive grid with a malformed Lescale grid
     from scenes import grid_scene
     s3 = grid_scene(dens, (8, 8, 8), 0.5, 1.0, W=W, H=H)

@@ -250,3 +250,20 @@ def test_scene_file_cloud_sky_renders(host_build, gpu_pkg, tmp_path):
     ref = f[..., :3] / f[..., 3:4]
     assert abs(img.mean() / ref.mean() - 1) < 0.02, (img.mean(), ref.mean())
     assert np.mean(np.abs(img - ref) <= 0.05 * (1 + ref)) > 0.9
+
+
+@pytest.mark.gpu
+def test_sharded_cpp_render_world_one_equals_unsharded(host_build, gpu_pkg, tmp_path):
+    """The all-C++ multi-GPU entry (vspg_pbrt_sharded over libvspg_rccl.so / RCCL) with ONE rank: communicator set-up, the
+    statistics / film / counter collectives and the stepping reproduce `vspg_pbrt` bit for bit.  (More ranks need more GPUs:
+    the N-rank stepping is covered by the gloo tests and test_sharded_steps_with_buffer_updates_vs_oracle_shards.)"""
+    a, b = tmp_path / "one.pfm", tmp_path / "sharded.pfm"
+    scene = os.path.join(SCENES, "fog_box.pbrt")
+    r1 = subprocess.run([os.path.join(host_build, "vspg_pbrt"), scene, "--outfile", str(a), "--spp", "6"], capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r2 = subprocess.run([os.path.join(host_build, "vspg_pbrt_sharded"), scene, "--outfile", str(b), "--spp", "6"], capture_output=True,
+                        text=True, env=env)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert "ranks 1: paths %d" % (64 * 48 * 6) in r2.stdout
+    assert np.array_equal(read_pfm(str(a)).view(np.uint32), read_pfm(str(b)).view(np.uint32))

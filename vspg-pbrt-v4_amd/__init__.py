@@ -47,7 +47,9 @@ class VspgMedium(C.Structure):
                 ("index_min", C.c_int32 * 3), ("voxel_size", f3), ("grid_origin", f3),
                 ("density_offset", C.c_float), ("majorant_scale", C.c_float),
                 ("le_scale", C.POINTER(C.c_float)), ("le_nx", C.c_int32), ("le_ny", C.c_int32), ("le_nz", C.c_int32),
-                ("has_transform", C.c_int32), ("render_from_medium", C.c_float * 16), ("medium_from_render", C.c_float * 16)]
+                ("has_transform", C.c_int32), ("render_from_medium", C.c_float * 16), ("medium_from_render", C.c_float * 16),
+                ("temperature", C.POINTER(C.c_float)), ("nvdb_le_scale", C.c_float), ("temperature_offset", C.c_float),
+                ("temperature_scale", C.c_float)]
 
 
 VSPG_MAX_INFINITE_LIGHTS = 4

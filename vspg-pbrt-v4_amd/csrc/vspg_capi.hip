@@ -1587,6 +1587,10 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         if ((long long)m.nx * m.ny * m.nz > (1ll << 31)) return fail(VSPG_EINVAL, "density grid too large");
         for (int k = 0; k < 3; ++k)
             if (!(m.bounds_max[k] > m.bounds_min[k])) return fail(VSPG_EINVAL, "grid medium bounds must have positive extent");
+        // IsEmissive (media.h:680): temperatureFloatGrid && LeScale > 0.  Volume emission is sampled by the delta-tracking routine only
+        if (m.type == VSPG_MEDIUM_NANOVDB && m.temperature && m.nvdb_le_scale > 0 && p->vspsamplingmethod != VSPG_VSP_RESAMPLING)
+            return fail(VSPG_ESCOPE, "NanoVDBMedium temperature grid with \"vspsamplingmethod\" \"nds\": blackbody volume emission is outside this build's scope "
+                                     "(under \"resampling\" the path never evaluates it and the grid is accepted)");
         if (m.has_transform) {
             const float *a = m.render_from_medium, *b = m.medium_from_render;
             if (a[12] != 0 || a[13] != 0 || a[14] != 0 || a[15] != 1 || b[12] != 0 || b[13] != 0 || b[14] != 0 || b[15] != 1)
@@ -1596,7 +1600,7 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         }
         if (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0) {
             if (m.type == VSPG_MEDIUM_NANOVDB)
-                return fail(VSPG_ESCOPE, "NanoVDBMedium emits through a temperature grid (blackbody emission): outside this build's scope");
+                return fail(VSPG_EINVAL, "NanoVDBMedium has no Le spectrum: it emits through its temperature grid (VspgMedium.temperature)");
             if (m.le_scale && (m.le_nx <= 0 || m.le_ny <= 0 || m.le_nz <= 0 || (long long)m.le_nx * m.le_ny * m.le_nz > (1ll << 31)))
                 return fail(VSPG_EINVAL, "emissive grid medium: bad Lescale grid size");
         }
@@ -1885,6 +1889,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             r->hscene.le_nx = lx; r->hscene.le_ny = ly; r->hscene.le_nz = lz;
         }
         r->scene.medium.le_scale = nullptr;
+        r->scene.medium.temperature = nullptr;  // never dereferenced (see vspg.h)
     }
     if (scene->n_triangles > 0) {
         std::vector<DTri> all;
