@@ -152,6 +152,19 @@ def relmse_leg(pkg, scene, prm, W, H, cpu_film, waves, device, torch):
     ig, ic = film_image(gf), film_image(cpu_film)
     rel = (ig - ic) ** 2 / (ic ** 2 + RELMSE_EPS)
     same = np.all(gf == cpu_film, axis=-1)
+    # the film sums float on the GPU and double in the oracle (the reference's RGBFilm, film.h:316-317): individual PATHS are the
+    # sharper statement -- 20 000 (pixel, sample) pairs replayed on both sides, radiance compared bit for bit
+    import oracle_lib
+    rng = np.random.default_rng(1)
+    pix = np.stack([rng.integers(0, W, 20000), rng.integers(0, H, 20000)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, 20000).astype(np.int32)
+    g2 = pkg.Renderer(scene, prm, W, H, device=device)
+    Lg, _ = g2.trace_paths(pix, si)
+    g2.close()
+    c2 = oracle_lib.OracleRenderer(scene, prm, W, H)
+    Lc, _ = c2.trace_paths(pix, si)
+    c2.close()
+    path_same = float(np.mean(np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)))
     t = pkg.Renderer(scene, prm, W, H, spp=16 * waves, seed=7919, device=device)
     for w in range(16 * waves):
         t.render_wave(w, w + 1)
@@ -159,6 +172,7 @@ def relmse_leg(pkg, scene, prm, W, H, cpu_film, waves, device, torch):
     it = film_image(t.film())
     t.close()
     return {"value": float(rel.mean()), "spp": waves, "bit_identical_pixel_frac": float(same.mean()),
+            "bit_identical_path_frac": path_same, "paths_compared": 20000,
             "max_abs_diff": float(np.abs(ig - ic).max()), "eps": RELMSE_EPS,
             "vs": "CPU oracle (port of the reference path), same seeds, float film on both sides",
             "vs_16x_truth": {"gpu": float(((ig - it) ** 2 / (it ** 2 + RELMSE_EPS)).mean()),

@@ -1352,6 +1352,59 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c.close()
 
 
+def test_config5_standin_vs_oracle(gpu_pkg):
+    """Config 5 ("explosion": NanoVDB medium with a temperature grid, secondary-ray VSPG, cache train + query) in one scene:
+    a NanoVDBMedium-semantics medium with density AND temperature grids, placed by a rotation * scale * translation,
+    rendered with the reference's DEFAULT guiding options.  (1) query side: with an uploaded field 20 000 paths are the
+    oracle's bit for bit; (2) training side: wave 0/1 of an in-loop training run record the oracle's samples bit for bit."""
+    import scenes
+    P = gpu_pkg
+    W, H = 64, 48
+    dens = scenes.cloud_density(24)
+    scene = scenes.nvdb_scene(dens, (24, 24, 24), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5, index_min=(-3, 2, 0), voxel=(0.066, 0.0625, 0.058),
+                              origin=(-0.6, -0.93, -0.5), density_offset=0.02, majorant_scale=1.25, W=W, H=H)
+    temp = (dens * 2500 + 300).astype(np.float32)
+    scene.medium.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+    scene.medium.nvdb_le_scale, scene.medium.temperature_offset, scene.medium.temperature_scale = 1.0, 100.0, 1.5
+    _placed(P, scene, "nvdb")
+    prm = P.default_params()      # surface RIS, volume MIS, primary + secondary VSP guiding, resampling
+    assert prm.vspsecondaryguiding and prm.volumeguiding and prm.surfaceguiding
+    field = scenes.light_field(P, n=4)
+    g = P.Renderer(scene, prm, W, H, seed=8)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=8)
+    g.set_guiding_field(field, field)
+    c.set_guiding_field(field, field)
+    rng = np.random.default_rng(29)
+    n = 20000
+    pix = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 4096, n).astype(np.int32)
+    Lg, sg = g.trace_paths(pix, si)
+    Lc, sc = c.trace_paths(pix, si)
+    print("config-5 stand-in: segments/path %.2f, bit-identical %.5f" % (sc.mean(), np.mean(np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1))))
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    for w in range(3):
+        g.render_wave(w, w + 1); g.post_process_wave()
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fg, fc = g.film(), c.film()
+    assert np.array_equal(fg[..., 3], fc[..., 3])
+    ig, ic = fg[..., :3] / fg[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    assert np.mean(np.all(np.abs(ig - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
+    (vg, rg), (vc, rc) = g.vsp_buffer(), c.vsp_buffer()
+    assert rg and rc and np.mean(np.abs(vg - vc) <= 1e-6) == 1.0
+    g.close(); c.close()
+    # training side
+    g = P.Renderer(scene, prm, W, H, seed=8)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=8)
+    g.render_wave(0, 2)
+    c.render_wave(0, 2)
+    sg, sc = g.training_stats(), c.training_stats()
+    assert sg["training"] == sc["training"] == 1
+    assert sg["n_samples"] == sc["n_samples"] > 1000 and sg["n_zero"] == sc["n_zero"]
+    a, b = _sorted_samples(g.train_samples()), _sorted_samples(c.train_samples())
+    assert a.tobytes() == b.tobytes()
+    g.close(); c.close()
+
+
 def _field_arrays(P, regs, n):
     out = {}
     for name in ("weight", "kappa", "distance", "vsp"):
