@@ -632,16 +632,26 @@ __global__ __launch_bounds__(kBlock) void k_train_mstep(const DScene *__restrict
 #endif
 constexpr int kWgWavesHomog = VSPG_WG_WAVES, kWgBlockHomog = VSPG_WG_BLOCK, kWgPoolHomog = VSPG_WG_NP;
 constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 384;
-constexpr int kWgWavesGuided = 2, kWgBlockGuided = 256, kWgPoolGuided = 320;  // guided vertices: ~250 registers, 40-dword records
+#ifndef VSPG_WGG_NP
+#define VSPG_WGG_NP 320
+#endif
+#ifndef VSPG_WGG_POOLG
+#define VSPG_WGG_POOLG 0
+#endif
+#ifndef VSPG_WG_POOLG
+#define VSPG_WG_POOLG 0
+#endif
+constexpr int kWgWavesGuided = 2, kWgBlockGuided = 256, kWgPoolGuided = VSPG_WGG_NP;  // guided vertices: ~250 registers, 40-dword records
+constexpr bool kWgPoolGlobalHomog = VSPG_WG_POOLG != 0, kWgPoolGlobalGuided = VSPG_WGG_POOLG != 0;
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
 
-template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd>
+template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd, bool POOLG = false>
 __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
     int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int tiles_magic,
-    unsigned int *__restrict__ work_head, unsigned long long *__restrict__ counters) {
+    unsigned int *__restrict__ work_head, unsigned long long *__restrict__ counters, float *__restrict__ gpool = nullptr) {
     // tiles_magic = ceil(2^32 / tilesX): the one integer division of the kernel (tile index -> tile row, once
     // per claimed chunk) is a multiply-high by it plus a fix-up; pixels travel as packed (x | y << 16)
     const DScene &S = *Sp;
@@ -653,11 +663,22 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     reset_sibling_head(work_head);
 
     constexpr int NF = GUIDED ? (int)PF_COUNT_GUIDED : (int)PF_GS;
-    __shared__ float s_pool[NF * NP];
+    // POOLG (build-time experiment, -DVSPG_WG_POOLG=1 / -DVSPG_WGG_POOLG=1; off): the pool in the workgroup's own piece of
+    // GLOBAL memory instead of LDS -- the segment-streaming layout SURVEY 8d's byte model describes.  It lifts the LDS bound
+    // on NP (long lists, many chunks per wavefront and phase) at the price of the records' round trips; measured on the
+    // 1080p fog wave (scripts/gpu_poolg.sh): 0.82 ms (LDS, 512 paths) -> 2.49 / 3.39 / 2.95 ms (global, 1024 / 2048 / 4096
+    // paths); guided instantiation 2.93 ms (LDS, 320 paths) -> 4.21 / 5.59 ms (global, 1024 / 2048).  The state belongs on chip.
+    float *pool_base;
+    if constexpr (POOLG) {
+        pool_base = gpool + (size_t)blockIdx.x * ((size_t)NF * NP);
+    } else {
+        __shared__ float s_pool[NF * NP];
+        pool_base = s_pool;
+    }
     __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
     __shared__ unsigned int s_item[NP];
     __shared__ unsigned int s_cnt[C_COUNT];
-    const Pool P{s_pool, NP};
+    const Pool P{pool_base, NP};
     // Heterogeneous media: a tracking walk visits every tentative collision of its ray, and the rays of one list chunk
     // have wildly different expected counts (0 for a ray that misses the cloud, tens through its core): a chunk lasts
     // as long as its longest walk.  Before the segment phase the continuing paths are therefore counting-sorted by the
@@ -1236,6 +1257,8 @@ struct VspgRenderer {
     DBvhNode *bvh = nullptr;
     // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
     float *wf_pool = nullptr;
+    float *wg_gpool = nullptr;   // k_render_wave_wg<..., POOLG>: the workgroups' path pools in global memory
+    size_t wg_gpool_floats = 0;
     unsigned int *wf_lists = nullptr;   // 4 x n_items: active, vertex, walk, shadow
     WfIter *wf_iters = nullptr;
     size_t wf_items = 0;
@@ -2037,6 +2060,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_nsorted) (void)hipFree(r->train_nsorted);
     if (r->tris) (void)hipFree(r->tris);
     if (r->bvh) (void)hipFree(r->bvh);
+    if (r->wg_gpool) (void)hipFree(r->wg_gpool);
     if (r->wf_pool) (void)hipFree(r->wf_pool);
     if (r->wf_lists) (void)hipFree(r->wf_lists);
     if (r->wf_iters) (void)hipFree(r->wf_iters);
@@ -2060,8 +2084,13 @@ int vspg_renderer_destroy(VspgRenderer *r) {
 // runs a guided wave in 2.33 ms, this one in 2.58 ms (384-path pool, kd nodes in L2) / 2.93 ms (320-path pool + the upper kd
 // levels in LDS): it issues 18 % fewer vector instructions at 68 % instead of 54 % lane utilisation, but the guided vertex code
 // needs ~240 registers either way (2 waves per SIMD) and at that occupancy the phase barriers cost more than the compaction saves.
+// VSPG_KERNEL=wg|lane|wf picks a path kernel where several serve a configuration (tests, A/B runs); empty == unset
+static const char *kernel_env() {
+    const char *e = getenv("VSPG_KERNEL");
+    return e && *e ? e : nullptr;
+}
 static bool uses_wg_guided(const VspgRenderer *r) {
-    const char *kenv = getenv("VSPG_KERNEL");
+    const char *kenv = kernel_env();
     if (!kenv || strcmp(kenv, "wg") != 0) return false;
     return wants_guiding(r->prm) && !r->training && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
            r->hscene.n_tris == 0 && r->hscene.n_inf == 0;
@@ -2071,7 +2100,7 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (uses_wg_guided(r)) return true;
-    const char *kenv = getenv("VSPG_KERNEL");
+    const char *kenv = kernel_env();
     const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
     // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
     // triangle hits carry a per-hit error bound the LDS pool record has no room for, and the kernel's homogeneous instantiations
@@ -2084,7 +2113,7 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
 // selects the single-kernel schedulers instead (kept for the guided / NDS configurations and as cross-checks).
 static bool uses_wf_pipeline(const VspgRenderer *r) {
     const bool het = r->scene.medium.type == VSPG_MEDIUM_GRID || r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
-    const char *kenv = getenv("VSPG_KERNEL");
+    const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wf") != 0) return false;
     return het && !wants_guiding(r->prm) && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
 }
@@ -2205,36 +2234,45 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         long long wblocks = (long long)r->num_cus * (wwaves * 4 / (wblock / 64));
         const long long wmax = (items + kWgChunk - 1) / kWgChunk;
         if (wblocks > wmax) wblocks = wmax;
+        if ((gwg && kWgPoolGlobalGuided) || (!gwg && !grid && kWgPoolGlobalHomog)) {
+            const size_t need = (size_t)wblocks * (gwg ? (size_t)PF_COUNT_GUIDED * kWgPoolGuided : (size_t)PF_GS * kWgPoolHomog);
+            if (need > r->wg_gpool_floats) {
+                if (r->wg_gpool) HIPCHK(hipFree(r->wg_gpool));
+                r->wg_gpool = nullptr;
+                HIPCHK(hipMalloc(&r->wg_gpool, need * sizeof(float)));
+                r->wg_gpool_floats = need;
+            }
+        }
         if (gwg)
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, true, kWgPoolGuided, kWgBlockGuided, kWgWavesGuided>),
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, true, kWgPoolGuided, kWgBlockGuided, kWgWavesGuided, kWgPoolGlobalGuided>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters);
+                               work_head, r->counters, r->wg_gpool);
         else if (grid)
             hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
                                work_head, r->counters);
         else if (r->medium_grey && r->surfaces_grey && r->null_zero)  // ... and the null-collision coefficient is exactly 0
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreySceneNullZero, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreySceneNullZero, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters);
+                               work_head, r->counters, r->wg_gpool);
         else if (r->medium_grey && r->surfaces_grey)  // ... and every Kd bitwise grey: beta is grey by construction too
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreyScene, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreyScene, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters);
+                               work_head, r->counters, r->wg_gpool);
         else if (r->medium_grey)  // sigma_a, sigma_s, Le bitwise grey: the broadcast-spectrum instantiation
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGrey, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGrey, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters);
+                               work_head, r->counters, r->wg_gpool);
         else
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog>),
+            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
                                dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
                                r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters);
+                               work_head, r->counters, r->wg_gpool);
     } else if (nvdb && guided) VSPG_LAUNCH_RENDER(NanoDenseMedium, true);
     else if (nvdb) VSPG_LAUNCH_RENDER(NanoDenseMedium, false);
     else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
