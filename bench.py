@@ -197,7 +197,7 @@ def parse_args():
     ap.add_argument("--yres", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline and relmse legs")
     ap.add_argument("--no-generic", action="store_true", help="skip the generic-instantiation leg")
-    ap.add_argument("--workload", choices=["fog", "fog-guided", "cloud", "cloud-nvdb"], default="fog",
+    ap.add_argument("--workload", choices=["fog", "fog-guided", "cloud", "cloud-nvdb", "cloud-guided", "cloud-nvdb-guided"], default="fog",
                     help="fog = BASELINE.json's metric workload (default); fog-guided = the same scene with the reference's DEFAULT "
                          "integrator options (directional guiding + secondary-ray VSP: cache query in the loop; the field trains "
                          "in-loop during untimed waves, reported separately); cloud = procedural heterogeneous GridMedium "
@@ -244,8 +244,8 @@ def main():
     spec.loader.exec_module(sh)
     W, H = args.xres, args.yres
     fog = args.workload in ("fog", "fog-guided")
-    guided = args.workload == "fog-guided"
-    scene = (pkg.fog_box_scene(W, H) if fog else pkg.cloud_box_scene(W, H, args.grid) if args.workload == "cloud"
+    guided = args.workload.endswith("-guided")
+    scene = (pkg.fog_box_scene(W, H) if fog else pkg.cloud_box_scene(W, H, args.grid) if args.workload in ("cloud", "cloud-guided")
              else pkg.nanovdb_box_scene(W, H, args.grid))
     prm = pkg.app_f_params()
     if args.diag_maxdepth is not None:
@@ -322,14 +322,17 @@ def main():
         if args.workload == "fog":
             metric = "Mpaths/sec on 1920x1080 homogeneous fog; relMSE vs CPU ref at equal spp"
             wl = "fog-box %dx%d, guidedvolpathvspg vspguiding=true (primary-ray VSP; App. F options)" % (W, H)
-        elif guided:
+        elif guided and fog:
             metric = "Mpaths/sec on 1920x1080 homogeneous fog, reference-default integrator options (not BASELINE.json's metric configuration)"
             wl = ("fog-box %dx%d, guidedvolpathvspg with the reference's default options (surface RIS + volume MIS guiding, "
                   "primary + secondary VSP), field trained in-loop for %d waves before the timed region" % (W, H, args.train_waves))
         else:
             metric = "Mpaths/sec on a procedural %d^3 cloud grid (not BASELINE.json's metric workload)" % args.grid
             wl = "cloud-box %dx%d, %s %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
-                W, H, "GridMedium" if args.workload == "cloud" else "NanoVDBMedium (brick layout, 64^3 majorants)", args.grid)
+                W, H, "GridMedium" if args.workload in ("cloud", "cloud-guided") else "NanoVDBMedium (brick layout, 64^3 majorants)", args.grid)
+            if guided:  # config 5's shape: secondary-ray VSP + cache train + query on a heterogeneous medium
+                wl += ("; the reference's default options (surface RIS + volume MIS guiding, primary + secondary VSP), field trained "
+                       "in-loop for %d waves before the timed region" % args.train_waves)
         out = {
             "metric": metric,
             "value": paths_total / elapsed / 1e6,

@@ -1352,6 +1352,52 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c.close()
 
 
+@pytest.mark.parametrize("kind", ["grid", "nvdb"])
+def test_guided_wavefront_pipeline_equals_per_lane_kernel(gpu_pkg, kind):
+    """The reference-default guided configuration over a heterogeneous medium with a field in place (config 5's query side):
+    the wavefront pipeline -- whole guided vertex in k_wf_seg_end, NEE result added by the next k_wf_advance -- renders the
+    per-lane guided kernel's film bit for bit, and both agree with the oracle's."""
+    import scenes
+    P = gpu_pkg
+    W, H = 96, 64
+    dens = scenes.cloud_density(24)
+    if kind == "grid":
+        scene = scenes.grid_scene(dens, (24, 24, 24), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    else:
+        scene = scenes.nvdb_scene(dens, (24, 24, 24), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5, index_min=(-3, 2, 0), voxel=(0.066, 0.0625, 0.058),
+                                  origin=(-0.6, -0.93, -0.5), density_offset=0.02, majorant_scale=1.25, W=W, H=H)
+        _placed(P, scene, "nvdb")
+    prm = P.default_params()
+    field = scenes.light_field(P, n=4)
+    films = {}
+    for kernel in (None, "lane"):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=12)
+            r.set_guiding_field(field, field)
+            for w in range(4):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            films[r.kernel_name()] = (r.film(), r.counters())
+            r.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    print(kind, sorted(films))
+    assert len(films) == 2 and any(k.startswith("k_wf_") and "guided" in k for k in films) and any(k.startswith("k_render_wave<") for k in films)
+    (fa, ca), (fb, cb) = films.values()
+    assert ca == cb
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=12)
+    c.set_guiding_field(field, field)
+    for w in range(4):
+        c.render_wave(w, w + 1); c.post_process_wave()
+    fc = c.film()
+    c.close()
+    assert np.array_equal(fa[..., 3], fc[..., 3])
+    ia, ic = fa[..., :3] / fa[..., 3:4], fc[..., :3] / fc[..., 3:4]
+    assert np.mean(np.all(np.abs(ia - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
+
+
 def test_config5_standin_vs_oracle(gpu_pkg):
     """Config 5 ("explosion": NanoVDB medium with a temperature grid, secondary-ray VSPG, cache train + query) in one scene:
     a NanoVDBMedium-semantics medium with density AND temperature grids, placed by a rotation * scale * translation,

@@ -1650,7 +1650,7 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
 }
 
 // One pass of the wavefront pipeline: sample index `sample` of every pixel.
-template <class Medium>
+template <class Medium, bool GUIDED = false>
 static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
     const size_t items = (size_t)tilesX * tilesY * 64;
@@ -1699,9 +1699,9 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     if (walk > max_blocks) walk = max_blocks;
     if (swalk > max_blocks) swalk = max_blocks;
     for (int it = 0; it <= r->prm.maxdepth; ++it) {
-        hipLaunchKernelGGL(k_wf_advance<Medium>, dim3(dense), dim3(kWfBlock), 0, s, a, it);
+        hipLaunchKernelGGL((k_wf_advance<Medium, GUIDED>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
         hipLaunchKernelGGL(k_wf_dist_walk<Medium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
-        hipLaunchKernelGGL(k_wf_seg_end<Medium>, dim3(dense), dim3(kWfBlock), 0, s, a, it);
+        hipLaunchKernelGGL((k_wf_seg_end<Medium, GUIDED>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
         if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<Medium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
     }
     HIPCHK(hipGetLastError());
@@ -2115,13 +2115,19 @@ static bool uses_wf_pipeline(const VspgRenderer *r) {
     const bool het = r->scene.medium.type == VSPG_MEDIUM_GRID || r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wf") != 0) return false;
-    return het && !wants_guiding(r->prm) && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
+    // guided builds: while the field is being QUERIED (trained or loaded); training waves record on the per-lane kernel, and
+    // guided Russian roulette stays there too
+    if (wants_guiding(r->prm) && (r->training || r->prm.rrguiding)) return false;
+    return het && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
 }
 const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (!r) return "";
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
-    if (uses_wf_pipeline(r)) return nvdb ? "k_wf_dist_walk<NanoDenseMedium>" : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
+    if (uses_wf_pipeline(r)) {
+        if (guided) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided>" : "k_wf_dist_walk<GridMedium,guided>";
+        return nvdb ? "k_wf_dist_walk<NanoDenseMedium>" : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
+    }
     if (uses_wg_guided(r)) return "k_render_wave_wg<HomogeneousMedium,guided>";
     if (uses_wg_kernel(r)) {
         if (grid) return "k_render_wave_wg<GridMedium>";
@@ -2182,9 +2188,11 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         for (int k = 0; k < 6; ++k) before[k] = checksum(bufs[k], sizes[k]);
 #endif
         for (int w = first; w < wave_end; w += sc > 1 ? sc : 1) {
-            const int rc = nvdb ? wf_render_pass<NanoDenseMedium>(r, w, (hipStream_t)stream)
-                                : (r->medium_grey ? wf_render_pass<GridMediumGrey>(r, w, (hipStream_t)stream)
-                                                  : wf_render_pass<GridMedium>(r, w, (hipStream_t)stream));
+            const int rc = guided ? (nvdb ? wf_render_pass<NanoDenseMedium, true>(r, w, (hipStream_t)stream)
+                                          : wf_render_pass<GridMedium, true>(r, w, (hipStream_t)stream))
+                           : nvdb ? wf_render_pass<NanoDenseMedium>(r, w, (hipStream_t)stream)
+                                  : (r->medium_grey ? wf_render_pass<GridMediumGrey>(r, w, (hipStream_t)stream)
+                                                    : wf_render_pass<GridMedium>(r, w, (hipStream_t)stream));
             if (rc) return rc;
         }
 #ifdef VSPG_WF_DEBUG

@@ -735,6 +735,12 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
 template <class Medium, bool GUIDED, bool GREG, class PC>
 VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                            bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride);
+// the same with the NEE as a hook: nee(gd, useGuiding) -> Ld.  SPLIT (the wavefront pipeline): the hook only SETS UP the shadow ray
+// (sample_Ld_begin); its result is added to L by the next kernel, with the throughput the hook saw
+template <class Medium, bool GREG, bool SPLIT, class PC, class NeeFn>
+VDEV bool li_vertex_guided_impl(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
+                                bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride,
+                                NeeFn &&nee);
 
 // li_segment_b in three pieces, so that a scheduler can park a path between them (the per-lane state
 // machine for grid media runs the NEE transmittance walk step by step in between):
@@ -912,6 +918,15 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
 template <class Medium, bool GUIDED, bool GREG, class PC>
 VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                            bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride) {
+    return li_vertex_guided_impl<Medium, GREG, false>(S, medium, st, ch, sampler, pc, volume_vertex, vp, vg, si, intr, bsdf, glds, gstride,
+                                                      [&](const auto &gd, bool use_gd) {
+                                                          return sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, &gd, use_gd);
+                                                      });
+}
+template <class Medium, bool GREG, bool SPLIT, class PC, class NeeFn>
+VDEV bool li_vertex_guided_impl(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
+                                bool volume_vertex, V3 vp, float vg, const Isect &si, Intr &intr, Bsdf &bsdf, float *glds, int gstride,
+                                NeeFn &&nee) {
     (void)sampler.get1d();  // v (the stochastic-lookup sample of Init)
     using Store = typename std::conditional<GREG, GStoreReg, GStoreLds>::type;
     using GD = GDistT<Store>;
@@ -962,9 +977,13 @@ VDEV bool li_vertex_guided(const DScene &S, const Medium &medium, PathState &st,
             survivalProb = S.prm.surfacerrguiding ? (st.specularBounce ? 0.95f : guided_russian_roulette(st.beta, st.pce, 0.1f)) : 1.f;
     }
     if (S.prm.usenee && (volume_vertex || bsdf.has_lobes)) {
-        Spec Ld = sample_Ld(S, medium, intr, &bsdf, ch, sampler, st.r_u, pc, &gd, useGuiding);
-        st.L = st.L + st.beta * Ld;
-        pc.rec.add_scattered_direct_light(Ld);  // :485 / :838
+        if constexpr (SPLIT) {
+            (void)nee(gd, useGuiding);
+        } else {
+            Spec Ld = nee(gd, useGuiding);
+            st.L = st.L + st.beta * Ld;
+            pc.rec.add_scattered_direct_light(Ld);  // :485 / :838
+        }
     }
 
     // ---- new direction: Sample_p / Sample_f, MIS or RIS flavour (guiding.h:120-257, 404-530) ----------------------

@@ -82,7 +82,10 @@ enum {
     WF_STMAJ = 108,   // 3  ... residual T_maj
     WF_PCE = 112,     // 3  previous light-sample context: error bound (triangle vertices)
     WF_VXE = 116,     // 3  vertex: error bound of the hit point
-    WF_COUNT = 120
+    // guided pipeline: the whole vertex (cache init, NEE set-up, Russian roulette, new direction) runs in k_wf_seg_end
+    WF_BNEE = 120,    // 3  the throughput the NEE saw (the vertex code has since moved st.beta on) | +3: WF_GSVSP
+    WF_GSVSP = 123,   // 1  VolumeScatterProbability(ray.d) of the vertex for the next segment (gs.vsp_next)
+    WF_COUNT = 124
 };
 enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_NODIST = 1 << 20,    // no SampleDistance this segment (no medium / the ray escapes)
@@ -93,6 +96,7 @@ enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_HIT = 1 << 25,       // the segment's ray hit a surface
     WFL_NEE = 1 << 26,       // SampleLd ran at the vertex (its result is added even when it is zero, :483 / :836)
     WFL_DELTA = 1 << 27,     // NEE sampled a delta light (DistantLight)
+    WFL_DEAD = 1 << 28,      // guided pipeline: the vertex code ended the path; only its NEE result is still to be added
 };
 
 struct WfPool {
@@ -290,8 +294,9 @@ struct ShadowSetup {
     float us;
     bool delta_light;
 };
-template <class PC>
-VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *bsdf, Sampler &sampler, PC &pc) {
+template <class PC, class GD = GDist>
+VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *bsdf, Sampler &sampler, PC &pc, const GD *gd = nullptr,
+                                 bool use_gd = false) {
     ShadowSetup r;
     r.status = 0;
     r.f_hat = r.L = sp(0.f);
@@ -317,13 +322,18 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *
     if (!sample_light(S, lightIndex, ctxp, ul0, ul1, &ls, &r.delta_light)) return r;
     r.p_l = lightPmf * ls.pdf;
     V3 wo = intr.wo, wi = ls.wi;
+    // GuidedBSDF::PDF / GuidedPhaseFunction::PDF (guiding.h:271-289, 542-558) when the vertex is guided (sample_Ld, vspg_path.h)
     if (intr.is_surface) {
         r.f_hat = bsdf_f(*bsdf, wo, wi) * absdot(wi, intr.n);
-        r.scatterPDF = 1.0f * bsdf_pdf(*bsdf, wo, wi);
+        float bsdfPDF = bsdf_pdf(*bsdf, wo, wi);
+        if (use_gd) bsdfPDF = ((1.0f - kGuidingProbability) * bsdfPDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        r.scatterPDF = 1.0f * bsdfPDF;
     } else {
         float p = henyey_greenstein(dot(wo, wi), intr.g);
         r.f_hat = sp(p);
-        r.scatterPDF = 1.0f * p;
+        float phasePDF = p;
+        if (use_gd) phasePDF = ((1.0f - kGuidingProbability) * phasePDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        r.scatterPDF = 1.0f * phasePDF;
     }
     if (!nonzero(r.f_hat)) return r;
     r.L = ls.L;
@@ -461,7 +471,9 @@ VDEV Medium wf_block_medium(const DScene &S) {
 }
 
 // ---- vertex end of iteration it-1 + segment begin of iteration it ---------------------------------------------------
-template <class Medium>
+// GUIDED (a trained / loaded guiding field being queried): k_wf_seg_end has run the WHOLE vertex (li_vertex_guided_impl); what is
+// left of it here is adding the NEE's result, with the throughput the NEE saw (WF_BNEE), before the next segment begins.
+template <class Medium, bool GUIDED = false>
 __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
@@ -498,14 +510,20 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                 // ---- li_segment_b from the NEE estimate on (:483 / :836, :842-874 / :487-606) --------------------
                 const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
                 Vertex vx;
-                vx.volume = (fl & FL_VX_VOLUME) != 0;
-                vx.p = P.v3(WF_VXP, slot);
-                vx.g = vx.volume ? P.f(WF_VXG, slot) : 0.f;
-                vx.quad = vx.volume ? -1 : P.i(WF_VXG, slot);
-                vx.t = P.f(WF_VXT, slot);
-                vx.perr = vx.volume ? mk(0, 0, 0) : (is_tri(vx.quad) ? P.v3(WF_VXE, slot) : ld3(quad_at(vx.quad).perr));
                 VertexCtx c;
-                vertex_setup<false>(S, st, vx, c);
+                Spec beta_nee = st.beta;
+                if constexpr (GUIDED) {
+                    beta_nee = P.sp3(WF_BNEE, slot);
+                    st.gs.vsp_next = P.f(WF_GSVSP, slot);
+                } else {
+                    vx.volume = (fl & FL_VX_VOLUME) != 0;
+                    vx.p = P.v3(WF_VXP, slot);
+                    vx.g = vx.volume ? P.f(WF_VXG, slot) : 0.f;
+                    vx.quad = vx.volume ? -1 : P.i(WF_VXG, slot);
+                    vx.t = P.f(WF_VXT, slot);
+                    vx.perr = vx.volume ? mk(0, 0, 0) : (is_tri(vx.quad) ? P.v3(WF_VXE, slot) : ld3(quad_at(vx.quad).perr));
+                    vertex_setup<false>(S, st, vx, c);
+                }
                 if (fl & WFL_NEE) {
                     Spec Ld = sp(0.f);
                     if (fl & (WFL_SHADOW_WALK | WFL_SHADOW_CLEAR)) {
@@ -518,9 +536,10 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                         Ld = sample_Ld_end(walked, (fl & WFL_DELTA) != 0, T_ray, r_l, r_u, T_maj, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
                                            P.f(WF_SPDF, slot), st.r_u);
                     }
-                    st.L = st.L + st.beta * Ld;
+                    st.L = st.L + beta_nee * Ld;
                 }
-                alive = vertex_tail(S, st, sampler, vx, c, P.f(WF_SURV, slot));
+                if constexpr (GUIDED) alive = !(fl & WFL_DEAD);
+                else alive = vertex_tail(S, st, sampler, vx, c, P.f(WF_SURV, slot));
                 if (!alive) {
                     wf_finish_path(a, slot, st, isg);
                     pc.path();
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                         rng.set_sequence(hash0, hash1);
                     }
                     bool guide = false;
-                    const float vsp = fetch_vsp<false>(S, st, &guide);
+                    const float vsp = fetch_vsp<GUIDED>(S, st, &guide);
                     if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
                     const float u = sampler.get1d();
                     const float tM = tMax * len(st.rd);
@@ -748,8 +767,10 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
 }
 
 // ---- candidate selection, surface emission, depth test, vertex setup, NEE light sample + shadow-ray set-up -------------
-template <class Medium>
-__global__ __launch_bounds__(kWfBlock, 3) void k_wf_seg_end(WfArgs a, int it) {
+// GUIDED: the vertex code is li_vertex_guided_impl -- cache init, NEE set-up with the guided PDF, Russian roulette, MIS / RIS
+// direction sampling, the next segment's VSP -- with the product mixture in registers (GStoreReg; ~240 VGPRs: 2 waves per SIMD)
+template <class Medium, bool GUIDED = false>
+__global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
     const WfPool &P = a.P;
@@ -889,11 +910,32 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_seg_end(WfArgs a, int it) {
                 if (vx.volume) P.f(WF_VXG, slot) = vx.g; else P.i(WF_VXG, slot) = vx.quad;
                 VertexCtx c;
                 vertex_setup<false>(S, st, vx, c);
-                const float survivalProb = vertex_pre(S, st, sampler, vx);
+                float survivalProb = 1.f;
                 uint32_t extra = FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u);
-                if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833
+                ShadowSetup ss;
+                ss.status = 0;
+                bool nee = false;
+                if constexpr (GUIDED) {
+                    Spec beta_nee = st.beta;
+                    const bool cont = li_vertex_guided_impl<Medium, true, true>(
+                        S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, nullptr, 0, [&](const auto &gd, bool use_gd) {
+                            nee = true;
+                            beta_nee = st.beta;
+                            ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc, &gd, use_gd);
+                            return sp(0.f);
+                        });
+                    P.sets(WF_BNEE, slot, beta_nee);
+                    P.f(WF_GSVSP, slot) = st.gs.vsp_next;
+                    if (!cont) extra |= WFL_DEAD;
+                } else {
+                    survivalProb = vertex_pre(S, st, sampler, vx);
+                    if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833
+                        nee = true;
+                        ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc);
+                    }
+                }
+                if (nee) {
                     extra |= WFL_NEE;
-                    const ShadowSetup ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc);
                     if (ss.status != 0) {
                         if (ss.delta_light) extra |= WFL_DELTA;
                         P.sets(WF_FHAT, slot, ss.f_hat);
