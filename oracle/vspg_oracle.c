@@ -1791,13 +1791,18 @@ typedef struct {
 } pathseg_t;
 typedef struct {
     int n, cur; /* cur: the reference's pathSegmentData pointer, -1 = nullptr */
+    int cap;    /* pss->Reserve(maxDepth >= 1 ? maxDepth * 2 : 30) (:135-138): NextSegment() returns nullptr beyond it */
     pathseg_t seg[TRAIN_MAX_SEG];
 } pathrec_t;
+static int rec_capacity(int maxdepth) {
+    const int c = maxdepth >= 1 ? maxdepth * 2 : 30;
+    return c < TRAIN_MAX_SEG ? c : TRAIN_MAX_SEG;
+}
 static spec s_max0(spec a) { return s_clamp_zero(a); } /* std::max(0.f, .) per component */
 /* guiding_newSurfacePathSegment / guiding_newVolumePathSegment (:682-732) */
 static void rec_new_segment(pathrec_t *rec, v3 p, int volume) {
     if (!rec) return;
-    if (rec->n >= TRAIN_MAX_SEG) { rec->cur = -1; return; } /* NextSegment() == nullptr */
+    if (rec->n >= rec->cap) { rec->cur = -1; return; } /* NextSegment() == nullptr */
     pathseg_t *g = &rec->seg[rec->n];
     memset(g, 0, sizeof *g);
     g->p = p; g->volume = volume;
@@ -1813,6 +1818,15 @@ static void rec_add_surface_emission(pathrec_t *rec, spec Le, float w) { /* :744
 }
 static void rec_add_scattered_direct_light(pathrec_t *rec, spec Ld) { /* :734-742 */
     if (rec && rec->cur >= 0) rec->seg[rec->cur].scattered = s_add(rec->seg[rec->cur].scattered, s_max0(Ld));
+}
+/* guiding_addInfiniteLightEmission (guiding.h:759-784): a NEW segment at ray.o + guidingInfiniteLightDistance * ray.d
+ * (integrators.h:608: 1e6f) carrying the light's emission and its MIS weight -- one per infinite light */
+#define GUIDING_INFINITE_LIGHT_DISTANCE 1e6f
+static void rec_new_segment(pathrec_t *rec, v3 p, int volume);
+static void rec_add_infinite_light_emission(pathrec_t *rec, v3 o, v3 d, spec Le, float misWeight) {
+    if (!rec) return;
+    rec_new_segment(rec, v_add(o, v_scale(d, GUIDING_INFINITE_LIGHT_DISTANCE)), 0);
+    if (rec->cur >= 0) { rec->seg[rec->cur].direct = s_max0(Le); rec->seg[rec->cur].mi_weight = misWeight; }
 }
 /* guiding_addSurfaceData / guiding_addVolumeData (:791-832) */
 static void rec_add_scatter_data(pathrec_t *rec, int volume, spec weight, v3 wi, float pdf, float roughness, float survivalProb) {
@@ -2280,12 +2294,14 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
                 if (il->type == VSPG_LIGHT_DISTANT && depth != 0) Le = S1(0.f);
                 if (depth == 0 || specularBounce) {
                     L = s_add(L, s_divf(s_mul(beta, Le), s_avg(r_u)));
+                    rec_add_infinite_light_emission(rec, ro, rd, Le, 1.0f); /* :361 */
                 } else {
                     /* lightSampler.PMF * light.PDF_Li(prevIntrContext, ray.d, true): both light types return 0 for the incomplete PDF */
                     float lightPDF = (1.f / (float)n_all) * 0.f;
                     r_l = s_scale(r_l, lightPDF);
                     float w_b = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.f;
                     L = s_add(L, s_mul(s_scale(beta, w_b), Le));
+                    rec_add_infinite_light_emission(rec, ro, rd, Le, w_b); /* :369 */
                 }
             }
             break;
@@ -2782,7 +2798,7 @@ static spec evaluate_pixel_sample(const OracleRenderer *r, int px, int py, int s
     *filterWeight = 1.f;
     v3 o, d;
     camera_ray(&r->scene.camera, pfx, pfy, &o, &d);
-    if (rec) { rec->n = 0; rec->cur = -1; }
+    if (rec) { rec->n = 0; rec->cur = -1; rec->cap = rec_capacity(r->prm.maxdepth); }
     spec L = Li(r, px, py, o, d, ch, &sampler, isg, pc, rec);
     /* L = cameraRay->weight * L with weight 1; NaN / Inf -> black (:308-318) */
     if (s_has_nan(L)) L = S1(0.f);
@@ -3080,7 +3096,7 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
      * true); this build trains iff the field will be queried. */
     r->training = params->surfaceguiding || params->volumeguiding || params->vspsecondaryguiding;
     if (r->training) {
-        if (params->maxdepth + 2 > TRAIN_MAX_SEG) { oracle_renderer_destroy(r); return VSPG_ESCOPE; }
+        if ((params->maxdepth >= 1 ? params->maxdepth * 2 : 30) > TRAIN_MAX_SEG) { oracle_renderer_destroy(r); return VSPG_ESCOPE; }
         field_alloc(r, 0);
         field_alloc(r, 1);
     }

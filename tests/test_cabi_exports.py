@@ -91,7 +91,7 @@ def test_parameter_validation_and_no_cpu_fallback(pkg):
     prm.maxdepth = 255   # the packed path flags keep the depth in 8 bits
     assert create(prm, cfg) == pkg.VSPG_EINVAL
     prm = pkg.default_params()
-    prm.maxdepth = 31    # guiding-cache training keeps at most 32 segment records per path (the oracle's limit too)
+    prm.maxdepth = 17    # guiding-cache training keeps at most 32 segment records per path, 2 * maxdepth of them reserved (the oracle's limit too)
     assert create(prm, cfg) == pkg.VSPG_ESCOPE
     bad = pkg.VspgRenderConfig(0, 32, 1, 0, 0, 1, 0)
     assert create(pkg.app_f_params(), bad) == pkg.VSPG_EINVAL

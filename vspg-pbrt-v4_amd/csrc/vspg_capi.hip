@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     if constexpr (TRAIN) {
         pc.rec.base = train.segbuf;  // re-pointed at the lane's work item when a path starts
         pc.rec.stride = (int)train.n_items;
-        pc.rec.max_seg = S.prm.maxdepth + 2;
+        pc.rec.max_seg = train_rec_capacity(S.prm.maxdepth);
         pc.rec.reset();
     }
     uint32_t paths = 0;
@@ -1596,8 +1596,8 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         return fail(VSPG_EINVAL, "shard_index out of range");
     if (p->maxdepth < 0) return fail(VSPG_EINVAL, "maxdepth must be >= 0");
     if (p->maxdepth > 254) return fail(VSPG_EINVAL, "maxdepth above 254 (the path depth travels in 8 bits of the packed path flags)");
-    if (wants_training(*p) && p->maxdepth + 2 > 32)
-        return fail(VSPG_ESCOPE, "guiding-cache training keeps at most 32 segment records per path (maxdepth <= 30)");
+    if (wants_training(*p) && (p->maxdepth >= 1 ? p->maxdepth * 2 : 30) > kTrainMaxSeg)
+        return fail(VSPG_ESCOPE, "guiding-cache training keeps at most 32 segment records per path (2 * maxdepth <= 32)");
     if (!(p->vspmisratio >= 0.f && p->vspmisratio <= 1.f)) return fail(VSPG_EINVAL, "vspmisratio must be in [0,1]");
     if (scene->medium.type == VSPG_MEDIUM_GRID || scene->medium.type == VSPG_MEDIUM_NANOVDB) {
         const VspgMedium &m = scene->medium;
@@ -1635,10 +1635,6 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     for (int i = 0; i < scene->n_infinite_lights; ++i)
         if (scene->infinite_lights[i].type != VSPG_LIGHT_UNIFORM_INFINITE && scene->infinite_lights[i].type != VSPG_LIGHT_DISTANT)
             return fail(VSPG_EINVAL, "unknown infinite light type");
-    if (scene->n_infinite_lights > 0 && wants_guiding(*p))
-        return fail(VSPG_ESCOPE, "infinite lights with the directional guiding cache are outside this build's scope (guiding_addInfiniteLightEmission)");
-    if (scene->n_triangles > 0 && wants_guiding(*p))
-        return fail(VSPG_ESCOPE, "triangle geometry with the directional guiding cache is outside this build's scope");
     int nl = scene->n_infinite_lights;
     for (int i = 0; i < scene->n_quads; ++i)
         if (scene->quads[i].Le[0] != 0 || scene->quads[i].Le[1] != 0 || scene->quads[i].Le[2] != 0) nl++;
@@ -2008,7 +2004,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     // rrguiding-only renderer queries nothing and records nothing)
     if (r->training) {
         r->segbuf_items = (size_t)((cfg->xres + 7) / 8) * (size_t)((cfg->yres + 7) / 8) * 64;  // the work items of a 1-spp wave
-        CK(hipMalloc(&r->segbuf, r->segbuf_items * (size_t)(r->prm.maxdepth + 2) * SG_FLOATS * sizeof(float)));
+        CK(hipMalloc(&r->segbuf, r->segbuf_items * (size_t)train_rec_capacity(r->prm.maxdepth) * SG_FLOATS * sizeof(float)));
         CK(hipMalloc(&r->seg_count, r->segbuf_items * sizeof(int)));
         r->sample_capacity = (unsigned long long)r->npix * (unsigned long long)(r->prm.maxdepth + 1);
         if (r->sample_capacity > (1ull << 26)) r->sample_capacity = 1ull << 26;
@@ -2292,7 +2288,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     HIPCHK(hipGetLastError());
     if (train) {
         hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, targs,
-                           r->prm.maxdepth + 2);
+                           train_rec_capacity(r->prm.maxdepth));
         HIPCHK(hipGetLastError());
     }
     return 0;

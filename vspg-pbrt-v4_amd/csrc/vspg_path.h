@@ -653,12 +653,14 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
             if (S.inf_type[k] == VSPG_LIGHT_DISTANT && st.depth != 0) Le = sp(0.f);
             if (st.depth == 0 || st.specularBounce) {
                 st.L = st.L + st.beta * Le / avg(st.r_u);
+                if constexpr (kRec) pc.rec.add_infinite_light_emission(st.ro + st.rd * kGuidingInfiniteLightDistance, Le, 1.0f);  // :361
             } else {
                 // lightSampler.PMF * light.PDF_Li(prevIntrContext, ray.d, true): both light types return 0 for the incomplete PDF
                 const float lightPDF = (1.f / (float)n_all) * 0.f;
                 st.r_l = st.r_l * lightPDF;
                 const float w_b = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.f;
                 st.L = st.L + st.beta * w_b * Le;
+                if constexpr (kRec) pc.rec.add_infinite_light_emission(st.ro + st.rd * kGuidingInfiniteLightDistance, Le, w_b);  // :369
             }
         }
         return false;

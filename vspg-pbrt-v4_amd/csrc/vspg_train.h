@@ -33,7 +33,16 @@ struct NullRecorder {  // every hook compiles to nothing
     VDEV void add_surface_emission(Spec, float) const {}
     VDEV void add_scattered_direct_light(Spec) const {}
     VDEV void add_scatter_data(bool, Spec, V3, float, float, float) const {}
+    VDEV void add_infinite_light_emission(V3, Spec, float) const {}
 };
+// pss->Reserve(maxDepth >= 1 ? maxDepth * 2 : 30) (guidedvolpathvspgintegrator.cpp:135-138): the records a path may keep;
+// NextSegment() returns nullptr beyond it (what OpenPGL's storage does then is restated, not pinned: the library is absent)
+constexpr int kTrainMaxSeg = 32;
+__host__ __device__ inline int train_rec_capacity(int maxdepth) {
+    const int c = maxdepth >= 1 ? maxdepth * 2 : 30;
+    return c < kTrainMaxSeg ? c : kTrainMaxSeg;
+}
+constexpr float kGuidingInfiniteLightDistance = 1e6f;  // integrators.h:608
 
 // Records live in HBM (a column per lane).  A record's groups of fields are written only when the path sets them; the
 // flags word says which groups are present and PropagateSamples substitutes the defaults for the others (so a new
@@ -92,6 +101,12 @@ struct PathRecorder {
         set3(cur, SG_SCAT, scat_r, scat_g, scat_b);
         cur_flags |= SGF_SCAT;
         flags(cur) = cur_flags;
+    }
+    // guiding_addInfiniteLightEmission (guiding.h:759-784): a NEW segment at ray.o + guidingInfiniteLightDistance * ray.d that
+    // carries the light's emission and its MIS weight (one per infinite light an escaped ray sees)
+    VDEV void add_infinite_light_emission(V3 p, Spec Le, float w) {
+        new_segment(p, false);
+        add_surface_emission(Le, w);
     }
     // guiding_addSurfaceData / guiding_addVolumeData (:791-832)
     VDEV void add_scatter_data(bool volume, Spec weight, V3 wi, float pdf, float roughness, float survivalProb) {
