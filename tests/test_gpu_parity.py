@@ -1398,6 +1398,8 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
             scene.medium.sigma_s[k] = 1.5
     g = P.Renderer(scene, prm, W, H, seed=3)
     c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
+    # grid media record on the wavefront pipeline (recorder state travels in the path record), homogeneous ones on the per-lane kernel
+    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave<HomogeneousMedium,guided,train>")
     g.render_wave(0, 2)
     c.render_wave(0, 2)
     sg, sc = g.training_stats(), c.training_stats()
@@ -1407,6 +1409,16 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     assert a.tobytes() == b.tobytes()
     assert set(np.unique(a["flags"])) <= {0, 1, 2, 3} and (a["flags"] & 1).any() and (~a["flags"] & 1).any()
     g.close()
+    if medium == "grid":  # ... and the per-lane training kernel records the same samples
+        os.environ["VSPG_KERNEL"] = "lane"
+        try:
+            g2 = P.Renderer(scene, prm, W, H, seed=3)
+            assert g2.kernel_name() == "k_render_wave<GridMedium,guided,train>"
+            g2.render_wave(0, 2)
+            assert _sorted_samples(g2.train_samples()).tobytes() == b.tobytes()
+            g2.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
     c.close()
 
 

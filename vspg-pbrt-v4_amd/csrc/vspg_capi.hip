@@ -72,15 +72,6 @@ __device__ __forceinline__ void reset_sibling_head(unsigned int *work_head) {
 //   path state = registers for the whole life of a path (no HBM round trip per segment);
 //   items are tile-ordered (8x8 pixels per 64 items) so a fresh wavefront starts on one coherent
 //   tile of primary rays.
-struct TrainArgs {  // a18: where a training launch records (all null / 0 otherwise)
-    float *segbuf;                   // segment records, one column per work item (pixel of the wave): record (seg, field) of
-                                     // item i at segbuf[(seg * SG_FLOATS + field) * n_items + i]
-    int *seg_count;                  // records written per work item (0 = no path)
-    VspgTrainSample *samples;        // radiance samples of this wave
-    unsigned long long *counters;    // [0] samples appended, [1] zero-valued samples dropped
-    unsigned long long capacity;
-    unsigned int n_items;
-};
 template <class Medium, bool GUIDED, bool TRAIN = false>
 __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DScene *__restrict__ Sp, float4 *__restrict__ film,
                                                         float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
@@ -1646,7 +1637,7 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
 }
 
 // One pass of the wavefront pipeline: sample index `sample` of every pixel.
-template <class Medium, bool GUIDED = false>
+template <class Medium, bool GUIDED = false, bool TRAIN = false>
 static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
     const size_t items = (size_t)tilesX * tilesY * 64;
@@ -1679,6 +1670,12 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     a.list_shadow = r->wf_lists + 3 * items;
     a.iters = r->wf_iters;
     a.counters = r->counters;
+    a.train = TrainArgs{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    a.rec_cap = train_rec_capacity(r->prm.maxdepth);
+    if (TRAIN) {  // a18: the pass records path segments; PropagateSamples (k_propagate) follows it
+        a.train = TrainArgs{r->segbuf, r->seg_count, r->samples, r->train_counters, r->sample_capacity, (unsigned)items};
+        HIPCHK(hipMemsetAsync(r->seg_count, 0, items * sizeof(int), s));
+    }
     {   // tuning knobs (defaults measured on the 256^3 cloud stand-in)
         const char *e1 = getenv("VSPG_WF_ROUNDS"), *e2 = getenv("VSPG_WF_REFILL");
         a.walk_rounds = e1 ? atoi(e1) : Medium::kAdvanceRounds;
@@ -1695,12 +1692,16 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     if (walk > max_blocks) walk = max_blocks;
     if (swalk > max_blocks) swalk = max_blocks;
     for (int it = 0; it <= r->prm.maxdepth; ++it) {
-        hipLaunchKernelGGL((k_wf_advance<Medium, GUIDED>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
+        hipLaunchKernelGGL((k_wf_advance<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
         hipLaunchKernelGGL(k_wf_dist_walk<Medium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
-        hipLaunchKernelGGL((k_wf_seg_end<Medium, GUIDED>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
+        hipLaunchKernelGGL((k_wf_seg_end<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
         if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<Medium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
     }
     HIPCHK(hipGetLastError());
+    if (TRAIN) {
+        hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a.train, a.rec_cap);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -2111,9 +2112,9 @@ static bool uses_wf_pipeline(const VspgRenderer *r) {
     const bool het = r->scene.medium.type == VSPG_MEDIUM_GRID || r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wf") != 0) return false;
-    // guided builds: while the field is being QUERIED (trained or loaded); training waves record on the per-lane kernel, and
-    // guided Russian roulette stays there too
-    if (wants_guiding(r->prm) && (r->training || r->prm.rrguiding)) return false;
+    // guided builds too, training passes included (segment recording in the dense kernels); guided Russian roulette stays on
+    // the per-lane kernel
+    if (wants_guiding(r->prm) && r->prm.rrguiding) return false;
     return het && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
 }
 const char *vspg_renderer_kernel_name(VspgRenderer *r) {
@@ -2121,6 +2122,7 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (uses_wf_pipeline(r)) {
+        if (guided && r->training) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided,train>" : "k_wf_dist_walk<GridMedium,guided,train>";
         if (guided) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided>" : "k_wf_dist_walk<GridMedium,guided>";
         return nvdb ? "k_wf_dist_walk<NanoDenseMedium>" : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
     }
@@ -2184,8 +2186,10 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         for (int k = 0; k < 6; ++k) before[k] = checksum(bufs[k], sizes[k]);
 #endif
         for (int w = first; w < wave_end; w += sc > 1 ? sc : 1) {
-            const int rc = guided ? (nvdb ? wf_render_pass<NanoDenseMedium, true>(r, w, (hipStream_t)stream)
-                                          : wf_render_pass<GridMedium, true>(r, w, (hipStream_t)stream))
+            const int rc = guided && r->training ? (nvdb ? wf_render_pass<NanoDenseMedium, true, true>(r, w, (hipStream_t)stream)
+                                                         : wf_render_pass<GridMedium, true, true>(r, w, (hipStream_t)stream))
+                           : guided ? (nvdb ? wf_render_pass<NanoDenseMedium, true>(r, w, (hipStream_t)stream)
+                                            : wf_render_pass<GridMedium, true>(r, w, (hipStream_t)stream))
                            : nvdb ? wf_render_pass<NanoDenseMedium>(r, w, (hipStream_t)stream)
                                   : (r->medium_grey ? wf_render_pass<GridMediumGrey>(r, w, (hipStream_t)stream)
                                                     : wf_render_pass<GridMedium>(r, w, (hipStream_t)stream));

@@ -122,6 +122,16 @@ struct PathRecorder {
     }
 };
 
+struct TrainArgs {  // a18: where a training launch records (all null / 0 otherwise)
+    float *segbuf;                   // segment records, one column per work item (pixel of the wave): record (seg, field) of
+                                     // item i at segbuf[(seg * SG_FLOATS + field) * n_items + i]
+    int *seg_count;                  // records written per work item (0 = no path)
+    VspgTrainSample *samples;        // radiance samples of this wave
+    unsigned long long *counters;    // [0] samples appended, [1] zero-valued samples dropped
+    unsigned long long capacity;
+    unsigned int n_items;
+};
+
 // Sample sink of k_propagate: a wavefront stages its samples in LDS (ballot + prefix count, no atomics at all) and the
 // workgroup reserves its range of the global buffer with ONE returning atomic -- the counter is a single address, and
 // same-address returning atomics retire at ~10 ns each on this chip: one per wavefront per loop iteration (2*10^5 of

@@ -85,7 +85,11 @@ enum {
     // guided pipeline: the whole vertex (cache init, NEE set-up, Russian roulette, new direction) runs in k_wf_seg_end
     WF_BNEE = 120,    // 3  the throughput the NEE saw (the vertex code has since moved st.beta on) | +3: WF_GSVSP
     WF_GSVSP = 123,   // 1  VolumeScatterProbability(ray.d) of the vertex for the next segment (gs.vsp_next)
-    WF_COUNT = 124
+    // training passes: the path recorder's state (vspg_train.h: PathRecorder) between kernels
+    WF_RECN = 124,    // 1  records written so far
+    WF_RECCUR = 125,  // 1  current record (-1: none)
+    WF_RECFL = 126,   // 1  its flags word
+    WF_COUNT = 128
 };
 enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_NODIST = 1 << 20,    // no SampleDistance this segment (no medium / the ray escapes)
@@ -154,7 +158,29 @@ struct WfArgs {
     unsigned long long *counters;
     int walk_rounds;             // majorant-cell advances tried per tracking step before the collision code runs
     int walk_refill;             // a walk wavefront refills its idle lanes once this many are idle
+    TrainArgs train;             // training passes (a18): the wave's segment-record buffer; k_propagate runs after the pass
+    int rec_cap;                 // records a path may keep (train_rec_capacity)
 };
+// the recorder of a path between two kernels of a training pass: records go straight to the path's column of the wave's
+// buffer; n / cur / flags travel in the path record.  (scat_*: a record sees at most one NEE, added by k_wf_advance.)
+VDEV void wf_rec_load(const WfArgs &a, unsigned slot, PathRecorder &rec) {
+    rec.base = a.train.segbuf + slot;
+    rec.stride = (int)a.train.n_items;
+    rec.max_seg = a.rec_cap;
+    rec.n = a.P.i(WF_RECN, slot);
+    rec.cur = a.P.i(WF_RECCUR, slot);
+    rec.cur_flags = a.P.u(WF_RECFL, slot);
+    rec.scat_r = rec.scat_g = rec.scat_b = 0.f;
+}
+VDEV void wf_rec_store(const WfArgs &a, unsigned slot, const PathRecorder &rec) {
+    a.P.i(WF_RECN, slot) = rec.n;
+    a.P.i(WF_RECCUR, slot) = rec.cur;
+    a.P.u(WF_RECFL, slot) = rec.cur_flags;
+}
+VDEV void wf_rec_load(const WfArgs &, unsigned, NullRecorder &) {}
+VDEV void wf_rec_store(const WfArgs &, unsigned, const NullRecorder &) {}
+VDEV void wf_rec_finish(const WfArgs &a, unsigned slot, const PathRecorder &rec) { a.train.seg_count[slot] = rec.n; }  // PropagateSamples (:627) follows in k_propagate
+VDEV void wf_rec_finish(const WfArgs &, unsigned, const NullRecorder &) {}
 
 VDEV void wf_pixel_of(unsigned slot, unsigned tilesX, int *px, int *py) {
     const unsigned tile = slot >> 6, l = slot & 63u;
@@ -435,12 +461,15 @@ constexpr int kWfShadowWavesPerSimd = 5;  // the shadow walk carries less state 
 constexpr int kWfRefill = 16;
 constexpr int kWfClaim = 128;  // jobs a walk wavefront claims per returning atomic  // a walk wavefront refills its idle lanes once this many are idle
 
-struct WfCounters : PathCounters {
+template <class REC>
+struct WfCountersT : PathCountersT<REC> {
     uint32_t paths;
     VDEV void path() { paths++; }
-    VDEV void zero() { segments = volume_scatters = surface_hits = density_queries = shadow_rays = paths = 0; }
+    VDEV void zero() { this->segments = this->volume_scatters = this->surface_hits = this->density_queries = this->shadow_rays = paths = 0; }
 };
-VDEV void wf_flush_counters(const WfCounters &pc, unsigned long long *g) {
+using WfCounters = WfCountersT<NullRecorder>;
+template <class REC>
+VDEV void wf_flush_counters(const WfCountersT<REC> &pc, unsigned long long *g) {
     __shared__ unsigned int s_c[CNT_COUNT];
     if (threadIdx.x < CNT_COUNT) s_c[threadIdx.x] = 0;
     __syncthreads();
@@ -473,7 +502,8 @@ VDEV Medium wf_block_medium(const DScene &S) {
 // ---- vertex end of iteration it-1 + segment begin of iteration it ---------------------------------------------------
 // GUIDED (a trained / loaded guiding field being queried): k_wf_seg_end has run the WHOLE vertex (li_vertex_guided_impl); what is
 // left of it here is adding the NEE's result, with the throughput the NEE saw (WF_BNEE), before the next segment begins.
-template <class Medium, bool GUIDED = false>
+// TRAIN (a18, with GUIDED): the pass records path segments; here the NEE's result reaches its record (guiding_addScatteredDirectLight)
+template <class Medium, bool GUIDED = false, bool TRAIN = false>
 __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
@@ -482,7 +512,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
     const bool first = it == 0;
     const unsigned n = first ? a.n_items : a.iters[it - 1].n_vertex;
     WfIter *I = &a.iters[it];
-    WfCounters pc;
+    WfCountersT<typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type> pc;
     pc.zero();
     __shared__ unsigned int s_stage[2][kWfStageRounds * kWfBlock], s_cnt[2], s_gbase[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -505,6 +535,11 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                 if (px < S.xres && py < S.yres) {
                     start_path(S, a.vsp_buf, a.vsp_ready, px, py, a.jump, sampler, st, &ch, isg);
                     alive = true;
+                    if constexpr (TRAIN) {
+                        wf_rec_load(a, slot, pc.rec);
+                        pc.rec.reset();
+                        wf_rec_store(a, slot, pc.rec);
+                    }
                 }
             } else {
                 // ---- li_segment_b from the NEE estimate on (:483 / :836, :842-874 / :487-606) --------------------
@@ -537,12 +572,21 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                                            P.f(WF_SPDF, slot), st.r_u);
                     }
                     st.L = st.L + beta_nee * Ld;
+                    if constexpr (TRAIN) {  // :485 / :838 (the flags word is order-independent: add_scatter_data keeps the SCAT bit)
+                        wf_rec_load(a, slot, pc.rec);
+                        pc.rec.add_scattered_direct_light(Ld);
+                        wf_rec_store(a, slot, pc.rec);
+                    }
                 }
                 if constexpr (GUIDED) alive = !(fl & WFL_DEAD);
                 else alive = vertex_tail(S, st, sampler, vx, c, P.f(WF_SURV, slot));
                 if (!alive) {
                     wf_finish_path(a, slot, st, isg);
                     pc.path();
+                    if constexpr (TRAIN) {
+                        if (!(fl & WFL_NEE)) wf_rec_load(a, slot, pc.rec);
+                        wf_rec_finish(a, slot, pc.rec);
+                    }
                 }
             }
             if (alive) {
@@ -769,7 +813,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
 // ---- candidate selection, surface emission, depth test, vertex setup, NEE light sample + shadow-ray set-up -------------
 // GUIDED: the vertex code is li_vertex_guided_impl -- cache init, NEE set-up with the guided PDF, Russian roulette, MIS / RIS
 // direction sampling, the next segment's VSP -- with the product mixture in registers (GStoreReg; ~240 VGPRs: 2 waves per SIMD)
-template <class Medium, bool GUIDED = false>
+template <class Medium, bool GUIDED = false, bool TRAIN = false>
 __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
@@ -777,7 +821,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs 
     constexpr int G = Medium::kGrey;
     WfIter *I = &a.iters[it];
     const unsigned n = I->n_active;
-    WfCounters pc;
+    WfCountersT<typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type> pc;
     pc.zero();
     __shared__ unsigned int s_stage[2][kWfStageRounds * kWfBlock], s_cnt[2], s_gbase[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -795,6 +839,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs 
             IsgSample isg;
             int ch;
             const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
+            if constexpr (TRAIN) wf_rec_load(a, slot, pc.rec);
             int px, py;
             wf_pixel_of(slot, a.tilesX, &px, &py);
             Isect si;
@@ -887,6 +932,11 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs 
                     }
                     if (term) kind = EV_TERMINATE;
                     else if (!selectSurface) {
+                        if constexpr (TRAIN) {  // :798-802 (transmittanceWeight starts every path-loop iteration at 1, :317)
+                            const Spec tw = sp(1.f) * ((sel_num * factor) / sel_den);
+                            pc.rec.add_transmittance_weight(tw);
+                            pc.rec.new_segment(sel_p, true);
+                        }
                         kind = EV_SCATTER;
                         vx.volume = true;
                         vx.p = sel_p;
@@ -904,6 +954,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs 
             if (!alive) {
                 wf_finish_path(a, slot, st, isg);
                 pc.path();
+                wf_rec_finish(a, slot, pc.rec);
             } else {
                 // ---- li_segment_b up to the shadow ray's transmittance estimate -----------------------------------
                 P.set3(WF_VXP, slot, vx.p);
@@ -963,6 +1014,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs 
                     }
                 }
                 P.f(WF_SURV, slot) = survivalProb;
+                wf_rec_store(a, slot, pc.rec);
                 wf_store_path<G>(P, slot, st, sampler, ch, isg, extra);
             }
         }
