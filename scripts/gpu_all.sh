@@ -9,4 +9,6 @@ TAILN=1 step 400 ${T}_bench_default.json python bench.py
 TAILN=1 step 300 ${T}_bench_cloud.json python bench.py --workload cloud --steps 8 --warmup 2
 TAILN=1 step 300 ${T}_bench_cloud_nvdb.json python bench.py --workload cloud-nvdb --steps 8 --warmup 2
 TAILN=1 step 300 ${T}_bench_fog_guided.json python bench.py --workload fog-guided --steps 16 --warmup 2
+TAILN=1 step 300 ${T}_bench_cloud_guided.json python bench.py --workload cloud-guided --steps 8 --warmup 2 --train-waves 8
+TAILN=1 step 300 ${T}_bench_cloud_nvdb_guided.json python bench.py --workload cloud-nvdb-guided --steps 8 --warmup 2 --train-waves 8
 exit 0
