@@ -194,6 +194,31 @@ def test_scene_file_render_equals_the_api_scene(host_build, gpu_pkg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_scene_file_cloud_sky_with_default_guiding(host_build, tmp_path):
+    """The same scene with the reference's DEFAULT integrator options (directional guiding trained in the loop for 128 waves,
+    then queried; secondary-ray VSP) -- sky + sun + triangle ground + placed cloud used to be outside the guided kernels' scope.
+    Unbiased: the guided picture has the unguided picture's mean."""
+    exe = os.path.join(host_build, "vspg_pbrt")
+    text = open(os.path.join(SCENES, "cloud_sky.pbrt")).read()
+    start = text.index('Integrator "guidedvolpathvspg"')
+    end = text.index("WorldBegin")
+    guided = text[:start] + 'Integrator "guidedvolpathvspg" "integer maxdepth" 4 "string lightsampler" "uniform"\n' + text[end:]
+    gs = tmp_path / "cloud_sky_guided.pbrt"
+    gs.write_text(guided)
+    imgs = {}
+    for name, scene in (("plain", os.path.join(SCENES, "cloud_sky.pbrt")), ("guided", str(gs))):
+        out = tmp_path / (name + ".pfm")
+        a = subprocess.run([exe, scene, "--outfile", str(out), "--spp", "192"], capture_output=True, text=True)
+        assert a.returncode == 0, a.stdout + a.stderr
+        imgs[name] = read_pfm(str(out))
+    assert np.isfinite(imgs["guided"]).all()
+    mp, mg = imgs["plain"].mean(), imgs["guided"].mean()
+    print("cloud_sky mean radiance: plain %.4f guided %.4f" % (mp, mg))
+    assert abs(mg / mp - 1) < 0.03
+    assert not np.array_equal(imgs["plain"], imgs["guided"])
+
+
+@pytest.mark.gpu
 def test_scene_file_cloud_sky_renders(host_build, gpu_pkg, tmp_path):
     """The placed cloud under sky + sun over a triangle-mesh ground, from the scene file: deterministic, lit, and the
     same picture (up to the CTM's float composition) as the scene assembled in Python."""
