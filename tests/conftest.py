@@ -73,3 +73,18 @@ def libm_shim():
         getattr(lib, n).argtypes = [C.c_int, dp, dp]
     lib.libm_neg_log1m.argtypes = [C.c_int, fp, fp]
     return lib
+
+
+@pytest.fixture(autouse=True)
+def _debug_build_checks(request):
+    """With a diagnostic build of the library (csrc built with -DVSPG_WF_DEBUG, selected through VSPG_LIB) every GPU test
+    also asserts that the kernels' own index checks never fired (path-pool slots, list entries: vspg_dbg_read)."""
+    yield
+    if os.environ.get("VSPG_DBG_CHECK") and request.node.get_closest_marker("gpu"):
+        import ctypes as C
+        pkg = load_package()
+        lib = pkg.load()
+        if hasattr(lib, "vspg_dbg_read"):
+            out = (C.c_uint * 8)()
+            assert lib.vspg_dbg_read(out) == 0
+            assert list(out)[:2] == [0, 0], "device-side index check fired: %s" % list(out)

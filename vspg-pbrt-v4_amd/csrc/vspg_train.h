@@ -63,7 +63,10 @@ struct PathRecorder {
     int n, cur;  // cur: the reference's pathSegmentData pointer, -1 = nullptr
     uint32_t cur_flags;     // flags of record `cur`
     float scat_r, scat_g, scat_b;  // its accumulated scattered direct light
-    VDEV float &at(int seg, int f) const { return base[(size_t)(seg * SG_FLOATS + f) * (size_t)stride]; }
+    VDEV float &at(int seg, int f) const {
+        VSPG_DBG_CHECK(seg >= 0 && seg < max_seg && f >= 0 && f < SG_FLOATS, 3);
+        return base[(size_t)(seg * SG_FLOATS + f) * (size_t)stride];
+    }
     VDEV uint32_t &flags(int seg) const { return reinterpret_cast<uint32_t &>(at(seg, SG_FLAGS)); }
     VDEV void set3(int seg, int f, float x, float y, float z) const { at(seg, f) = x; at(seg, f + 1) = y; at(seg, f + 2) = z; }
     VDEV void reset() { n = 0; cur = -1; cur_flags = 0; scat_r = scat_g = scat_b = 0.f; }
