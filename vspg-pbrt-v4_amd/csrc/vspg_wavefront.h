@@ -456,10 +456,19 @@ VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out) {
 // kernels
 // =====================================================================================================================
 constexpr int kWfBlock = 256;
-constexpr int kWfWalkWavesPerSimd = 4;  // launch bound of the walk kernels (register budget 128)
-constexpr int kWfShadowWavesPerSimd = 5;  // the shadow walk carries less state (<= 96 registers)
+#ifndef VSPG_WF_WALK_WAVES
+#define VSPG_WF_WALK_WAVES 4
+#endif
+#ifndef VSPG_WF_SHADOW_WAVES
+#define VSPG_WF_SHADOW_WAVES 5
+#endif
+constexpr int kWfWalkWavesPerSimd = VSPG_WF_WALK_WAVES;  // launch bound of the walk kernels (register budget 128)
+constexpr int kWfShadowWavesPerSimd = VSPG_WF_SHADOW_WAVES;  // the shadow walk carries less state (<= 96 registers)
 constexpr int kWfRefill = 16;
-constexpr int kWfClaim = 128;  // jobs a walk wavefront claims per returning atomic  // a walk wavefront refills its idle lanes once this many are idle
+#ifndef VSPG_WF_CLAIM
+#define VSPG_WF_CLAIM 128
+#endif
+constexpr int kWfClaim = VSPG_WF_CLAIM;  // jobs a walk wavefront claims per returning atomic  // a walk wavefront refills its idle lanes once this many are idle
 
 template <class REC>
 struct WfCountersT : PathCountersT<REC> {
@@ -667,10 +676,37 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
 // claim: lanes with `want` set receive the next jobs of list[0, n) (slot in *slot_out, returns true); the wavefront keeps a
 // local range [next, end) claimed kWfClaim jobs at a time with one returning atomic (64 at a time put 32 k returning
 // atomics per launch on one word: a third of the kernel's time).
+// Claim size.  The job cursor is ONE hot word (~88 returning atomics per microsecond on this part), so claims are large; but a
+// launch ends on the wavefronts still working through their last claim, and the later path-loop iterations have a tenth of
+// the first one's jobs.  Per launch: jobs / (4 * resident wavefronts), clamped to [32, 256] -- 126 for the first iteration of a
+// 1080p wave (the fixed 128 this replaced), 32 for the short lists, which then spread over every wavefront.  Measured on the
+// 256^3 cloud (scripts/gpu_variants_wl.sh, same box): fixed 128: 11.7 ms; fixed 256 / 512: 11.6-12.2 / 12.5; this rule: 11.1-11.7;
+// shrinking claims towards the end of a list (guided self-scheduling, mode 2): 13.4 -- the atomics cost more than the tail.
+#ifndef VSPG_WF_CLAIM_MODE
+#define VSPG_WF_CLAIM_MODE 1   // 0: fixed kWfClaim; 1: per launch (above); 2: of the jobs LEFT
+#endif
+#ifndef VSPG_WF_CLAIM_DIV
+#define VSPG_WF_CLAIM_DIV 4
+#endif
+#ifndef VSPG_WF_CLAIM_MIN
+#define VSPG_WF_CLAIM_MIN 32
+#endif
+#ifndef VSPG_WF_CLAIM_MAX
+#define VSPG_WF_CLAIM_MAX 256
+#endif
 struct WfClaim {
     unsigned next, end;
     bool exhausted;
+    unsigned seen;   // the list position of this wavefront's latest claim (an estimate of the global cursor)
 };
+VDEV unsigned wf_claim_size(unsigned n, unsigned seen) {
+    if (VSPG_WF_CLAIM_MODE == 0) return (unsigned)kWfClaim;
+    const unsigned waves = gridDim.x * (blockDim.x >> 6);
+    const unsigned left = VSPG_WF_CLAIM_MODE == 2 ? (n > seen ? n - seen : 0u) : n;
+    unsigned sz = left / (waves * (unsigned)VSPG_WF_CLAIM_DIV);
+    sz = sz < (unsigned)VSPG_WF_CLAIM_MIN ? (unsigned)VSPG_WF_CLAIM_MIN : sz;
+    return sz > (unsigned)VSPG_WF_CLAIM_MAX ? (unsigned)VSPG_WF_CLAIM_MAX : sz;
+}
 VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, unsigned int *head, unsigned *slot_out) {
     const int lane = threadIdx.x & 63;
     const unsigned long long need = __ballot(want);
@@ -681,12 +717,14 @@ VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, 
     while (served < cnt) {
         if (c.next >= c.end) {
             if (c.exhausted) break;
+            const unsigned sz = wf_claim_size(n, c.seen);
             unsigned base = 0;
-            if (lane == 0) base = atomicAdd(head, (unsigned)kWfClaim);
+            if (lane == 0) base = atomicAdd(head, sz);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= n) { c.exhausted = true; break; }
             c.next = base;
-            c.end = base + (unsigned)kWfClaim < n ? base + (unsigned)kWfClaim : n;
+            c.end = base + sz < n ? base + sz : n;
+            c.seen = c.end;
         }
         const unsigned avail = c.end - c.next;
         const unsigned take = cnt - served < avail ? cnt - served : avail;
@@ -710,7 +748,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     const unsigned n = I->n_walk;
     WfCounters pc;
     pc.zero();
-    WfClaim claim{0u, 0u, false};
+    WfClaim claim{0u, 0u, false, 0u};
     bool active = false, result = false;  // result: a finished walk whose result is still in registers
     unsigned slot = 0;
     WalkState<Medium> w;
@@ -1038,7 +1076,7 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
     const WfPool &P = a.P;
     WfIter *I = &a.iters[it];
     const unsigned n = I->n_shadow;
-    WfClaim claim{0u, 0u, false};
+    WfClaim claim{0u, 0u, false, 0u};
     bool active = false, result = false;
     unsigned slot = 0;
     WalkState<Medium> w;
