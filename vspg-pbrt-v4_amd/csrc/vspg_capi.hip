@@ -1637,7 +1637,10 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
 }
 
 // One pass of the wavefront pipeline: sample index `sample` of every pixel.
-template <class Medium, bool GUIDED = false, bool TRAIN = false>
+// WalkMedium: the instantiation the two walk kernels run -- the grey one whenever the medium's coefficients are bitwise grey
+// (a third of the per-channel divisions / FastExp of a tracking step), also under the guided dense kernels, which have no
+// grey instantiation of their own: the walks read and write none of the fields whose layout depends on it.
+template <class Medium, bool GUIDED = false, bool TRAIN = false, class WalkMedium = Medium>
 static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
     const size_t items = (size_t)tilesX * tilesY * 64;
@@ -1678,7 +1681,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     }
     {   // tuning knobs (defaults measured on the 256^3 cloud stand-in)
         const char *e1 = getenv("VSPG_WF_ROUNDS"), *e2 = getenv("VSPG_WF_REFILL");
-        a.walk_rounds = e1 ? atoi(e1) : Medium::kAdvanceRounds;
+        a.walk_rounds = e1 ? atoi(e1) : WalkMedium::kAdvanceRounds;
         a.walk_refill = e2 ? atoi(e2) : kWfRefill;
         if (a.walk_rounds < 1) a.walk_rounds = 1;
         if (a.walk_refill < 1) a.walk_refill = 1;
@@ -1693,9 +1696,9 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     if (swalk > max_blocks) swalk = max_blocks;
     for (int it = 0; it <= r->prm.maxdepth; ++it) {
         hipLaunchKernelGGL((k_wf_advance<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
-        hipLaunchKernelGGL(k_wf_dist_walk<Medium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
+        hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
         hipLaunchKernelGGL((k_wf_seg_end<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
-        if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<Medium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
+        if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
     }
     HIPCHK(hipGetLastError());
     if (TRAIN) {
@@ -2124,7 +2127,8 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (uses_wf_pipeline(r)) {
         if (guided && r->training) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided,train>" : "k_wf_dist_walk<GridMedium,guided,train>";
         if (guided) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided>" : "k_wf_dist_walk<GridMedium,guided>";
-        return nvdb ? "k_wf_dist_walk<NanoDenseMedium>" : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
+        return nvdb ? (r->medium_grey ? "k_wf_dist_walk<NanoDenseMediumGrey>" : "k_wf_dist_walk<NanoDenseMedium>")
+                    : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
     }
     if (uses_wg_guided(r)) return "k_render_wave_wg<HomogeneousMedium,guided>";
     if (uses_wg_kernel(r)) {
@@ -2186,13 +2190,15 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         for (int k = 0; k < 6; ++k) before[k] = checksum(bufs[k], sizes[k]);
 #endif
         for (int w = first; w < wave_end; w += sc > 1 ? sc : 1) {
-            const int rc = guided && r->training ? (nvdb ? wf_render_pass<NanoDenseMedium, true, true>(r, w, (hipStream_t)stream)
-                                                         : wf_render_pass<GridMedium, true, true>(r, w, (hipStream_t)stream))
-                           : guided ? (nvdb ? wf_render_pass<NanoDenseMedium, true>(r, w, (hipStream_t)stream)
-                                            : wf_render_pass<GridMedium, true>(r, w, (hipStream_t)stream))
-                           : nvdb ? wf_render_pass<NanoDenseMedium>(r, w, (hipStream_t)stream)
-                                  : (r->medium_grey ? wf_render_pass<GridMediumGrey>(r, w, (hipStream_t)stream)
-                                                    : wf_render_pass<GridMedium>(r, w, (hipStream_t)stream));
+            const hipStream_t hs = (hipStream_t)stream;
+            const bool grey = r->medium_grey, tr = r->training;
+            int rc;
+            if (guided && nvdb) rc = tr ? (grey ? wf_render_pass<NanoDenseMedium, true, true, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true, true>(r, w, hs))
+                                        : (grey ? wf_render_pass<NanoDenseMedium, true, false, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true>(r, w, hs));
+            else if (guided) rc = tr ? (grey ? wf_render_pass<GridMedium, true, true, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true, true>(r, w, hs))
+                                     : (grey ? wf_render_pass<GridMedium, true, false, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true>(r, w, hs));
+            else if (nvdb) rc = grey ? wf_render_pass<NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium>(r, w, hs);
+            else rc = grey ? wf_render_pass<GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium>(r, w, hs);
             if (rc) return rc;
         }
 #ifdef VSPG_WF_DEBUG

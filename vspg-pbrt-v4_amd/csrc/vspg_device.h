@@ -1191,6 +1191,7 @@ struct GridMediumT {
 using GridMedium = GridMediumT<false>;
 using GridMediumGrey = GridMediumT<false, true>;
 using NanoDenseMedium = GridMediumT<true>;
+using NanoDenseMediumGrey = GridMediumT<true, true>;
 template <bool NVDB, bool GREY>
 VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
     return GridMediumT<NVDB, GREY>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
