@@ -231,10 +231,18 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    # VSPG_BENCH_REHEARSE=1 (1-GPU boxes only; never a benchmark number): every rank on device 0, collectives over gloo -- walks
+    # the whole N-rank code path (self-launch, sharded steps with the statistics exchange, film all-reduce) where one card exists
+    rehearse = world > 1 and os.environ.get("VSPG_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = load_package()
     pkg.load()
