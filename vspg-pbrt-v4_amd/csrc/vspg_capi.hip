@@ -2794,6 +2794,15 @@ int vspg_dbg_read(unsigned int *out8) {  // diagnostic build only
     return 0;
 }
 #endif
+#ifdef VSPG_WF_STATS
+int vspg_wf_stats_read(unsigned long long *out16) {  // diagnostic build only: read and clear
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wf_stats), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wf_stats), z, sizeof z));
+    return 0;
+}
+#endif
 #ifdef VSPG_PROFILE
 // diagnostic build only: dump and clear the per-section counters
 int vspg_prof_read(unsigned long long *out /* PS_COUNT*3 */, int *n_sections) {

@@ -455,6 +455,18 @@ VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out) {
 // =====================================================================================================================
 // kernels
 // =====================================================================================================================
+#ifdef VSPG_WF_STATS  // diagnostic build: where the lanes of the distance walk are (scripts/wf_stats.py reads them back)
+// [0] loop iterations  [1] lanes with a job  [2] advance rounds run  [3] lanes in them  [4] collision steps run
+// [5] lanes in them  [6] refills
+__device__ unsigned long long g_wf_stats[16];
+#define VSPG_WF_STAT(k, i, v) st_[(i)] += (unsigned long long)(v)
+#define VSPG_WF_STAT_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define VSPG_WF_STAT_FLUSH(k) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_wf_stats[(k) * 8 + i_], st_[i_]); } while (0)
+#else
+#define VSPG_WF_STAT(k, i, v)
+#define VSPG_WF_STAT_DECL
+#define VSPG_WF_STAT_FLUSH(k)
+#endif
 constexpr int kWfBlock = 256;
 #ifndef VSPG_WF_WALK_WAVES
 #define VSPG_WF_WALK_WAVES 4
@@ -676,6 +688,13 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
 // claim: lanes with `want` set receive the next jobs of list[0, n) (slot in *slot_out, returns true); the wavefront keeps a
 // local range [next, end) claimed kWfClaim jobs at a time with one returning atomic (64 at a time put 32 k returning
 // atomics per launch on one word: a third of the kernel's time).
+// Job order.  Tried (round 2): longest-processing-time-first -- the distance-walk jobs bucketed by the ray's majorant optical
+// depth (the expected number of tentative collisions, known from the segment's pre-pass), thickest bucket first, so that a launch
+// does not end on a few long walks.  With four buckets the lanes holding a job rose from 44.6 to 52.2 of 64 and the loop iterations
+// fell by 15 % (scripts/wf_stats.py) -- and the wave got 5 % SLOWER (11.7 -> 12.3 ms): jobs in list order are jobs in slot order,
+// so a wavefront's claim reads and writes neighbouring records (whole cache lines); bucketed, every 16-byte group of a job's
+// record is its own line.  Two buckets (only the thickest 10-15 % pulled forward) were within +-0.5 %.  Dropped.
+//
 // Claim size.  The job cursor is ONE hot word (~88 returning atomics per microsecond on this part), so claims are large; but a
 // launch ends on the wavefronts still working through their last claim, and the later path-loop iterations have a tenth of
 // the first one's jobs.  Per launch: jobs / (4 * resident wavefronts), clamped to [32, 256] -- 126 for the first iteration of a
@@ -752,6 +771,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     bool active = false, result = false;  // result: a finished walk whose result is still in registers
     unsigned slot = 0;
     WalkState<Medium> w;
+    VSPG_WF_STAT_DECL;
     w.iter = medium.empty_iter();
     w.sigma_maj = sp(0.f); w.seg_tMax = w.tMin = 0.f; w.T_maj = sp(1.f); w.u = 0.f; w.rng.state = w.rng.inc = 0; w.count = 0; w.in_seg = false;
     V3 ro = mk(0, 0, 0), rdn = mk(0, 0, 1);
@@ -780,6 +800,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
                 result = false;
             }
             unsigned ns = 0;
+            VSPG_WF_STAT(0, 6, 1);
             if (wf_claim(claim, !active, a.list_walk, n, &I->walk_head, &ns)) {
                 slot = ns;
                 w.iter = wf_load_iter(P, slot, medium);
@@ -804,6 +825,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
         // ---- one tracking step ------------------------------------------------------------------------------------
         float t = 0.f;
         int r = WALK_MOVED;
+        VSPG_WF_STAT(0, 0, 1); VSPG_WF_STAT(0, 1, __popcll(__ballot(active))); VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(active)));
         if (active) {
             r = walk_advance<Medium, true>(w, ch, scale, &t);
         }
@@ -812,8 +834,10 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
         for (int rr = 1; rr < a.walk_rounds; ++rr) {
             const bool again = active && r == WALK_MOVED;
             if (__popcll(__ballot(again)) < 8) break;
+            VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(again)));
             if (again) r = walk_advance<Medium, true>(w, ch, scale, &t);
         }
+        VSPG_WF_STAT(0, 4, __ballot(active && r == WALK_COLLISION) != 0ull); VSPG_WF_STAT(0, 5, __popcll(__ballot(active && r == WALK_COLLISION)));
         if (active && r == WALK_COLLISION) {
             w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
             const V3 p = ro + rdn * t;
@@ -845,6 +869,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
             result = true;
         }
     }
+    VSPG_WF_STAT_FLUSH(0);
     wf_flush_counters(pc, a.counters);
 }
 
