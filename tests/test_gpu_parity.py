@@ -793,6 +793,90 @@ def test_tr_buffer_and_nds_plus_vs_oracle(gpu_pkg, medium):
     g0.close(); g.close(); c.close()
 
 
+CLOUD_SWEEP = [
+    dict(),                                                      # baseline
+    dict(usenee=0), dict(maxdepth=0), dict(maxdepth=1), dict(maxdepth=9, minrrdepth=3),
+    dict(vspguiding=0), dict(vspmisratio=1.0), dict(vspmisratio=0.0), dict(vspcriterion=0),
+    dict(_sigma=(0.5, 0.0)),                                     # pure absorber: no scattering event is ever selected
+    dict(_sigma=((0.3, 0.1, 0.02), (0.2, 0.9, 1.6))),            # chromatic: the generic (non-grey) walk instantiations
+    dict(_dens="zero"),                                          # every brick empty: no density storage at all
+    dict(_dens="one_voxel"),                                     # a single non-zero voxel in an otherwise empty grid
+    dict(_dens="tiny"),                                          # a 1 x 1 x 1 grid
+    dict(_dens="slab"),                                          # 5 x 9 x 3: partial bricks on every axis
+    dict(_res=(1, 1)), dict(_res=(9, 7)),                        # less than one tile; ragged tiles
+    dict(_kind="nvdb"), dict(_kind="nvdb", usenee=0), dict(_kind="nvdb", _dens="slab"),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CLOUD_SWEEP)))
+def test_cloud_parameter_sweep_vs_oracle(gpu_pkg, case):
+    """The heterogeneous path's options and degenerate inputs one at a time: the wavefront pipeline and the per-lane kernel
+    render the same film bit for bit over 3 waves (with the VSP-buffer updates), the film equals the oracle's up to the
+    float-vs-double accumulation, and replayed paths are the oracle's bit for bit."""
+    from scenes import cloud_density, grid_scene, nvdb_scene
+    P = gpu_pkg
+    kw = dict(CLOUD_SWEEP[case])
+    W, H = kw.pop("_res", (48, 32))
+    dens_kind = kw.pop("_dens", "cloud")
+    if dens_kind == "cloud":
+        dens, n = cloud_density(24), (24, 24, 24)
+    elif dens_kind == "zero":
+        dens, n = np.zeros(20 * 20 * 20, dtype=np.float32), (20, 20, 20)
+    elif dens_kind == "one_voxel":
+        d = np.zeros((20, 20, 20), dtype=np.float32)   # [z][y][x]
+        d[11, 9, 10] = 3.0
+        dens, n = d.reshape(-1), (20, 20, 20)
+    elif dens_kind == "tiny":
+        dens, n = np.array([0.8], dtype=np.float32), (1, 1, 1)
+    else:
+        rng = np.random.default_rng(5)
+        dens, n = rng.random(5 * 9 * 3).astype(np.float32), (5, 9, 3)
+    sa, ss = kw.pop("_sigma", (0.08, 7.9))
+    kind = kw.pop("_kind", "grid")
+    if kind == "grid":
+        scene = grid_scene(dens, n, sa, ss, g=0.6, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    else:
+        vox = tuple(1.6 / n[k] for k in range(3))
+        scene = nvdb_scene(dens, n, sa, ss, g=0.6, index_min=(-2, 1, 0), voxel=vox, origin=(-0.75 + 2 * vox[0], -0.8 - vox[1], -0.5),
+                           density_offset=0.01, majorant_scale=1.1, W=W, H=H)
+    prm = P.app_f_params()
+    for k, v in kw.items():
+        setattr(prm, k, v)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=case)
+    films, names = [], set()
+    for kernel in (None, "lane"):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            g = P.Renderer(scene, prm, W, H, seed=case)
+            names.add(g.kernel_name())
+            for w in range(3):
+                g.render_wave(w, w + 1)
+                g.post_process_wave()
+            films.append(g.film())
+            if kernel is None:
+                rng = np.random.default_rng(case)
+                pix = np.stack([rng.integers(0, W, 3000), rng.integers(0, H, 3000)], axis=1).astype(np.int32)
+                si = rng.integers(0, 64, 3000).astype(np.int32)
+                Lg, sg = g.trace_paths(pix, si)
+            g.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    assert len(names) == 2 and any(k.startswith("k_wf_") for k in names), names
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+    for w in range(3):
+        c.render_wave(w, w + 1)
+        c.post_process_wave()
+    fc = c.film()
+    assert np.array_equal(films[0][..., 3], fc[..., 3])
+    ig, ic = films[0][..., :3] / films[0][..., 3:4], fc[..., :3] / fc[..., 3:4]
+    assert np.mean((ig - ic) ** 2 / (ic ** 2 + 1e-4)) <= 1e-10
+    Lc, sc = c.trace_paths(pix, si)
+    assert np.array_equal(sg, sc)
+    assert np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    c.close()
+
+
 @pytest.mark.parametrize("lescale", ["grid", "default"])
 def test_emissive_grid_vs_oracle(gpu_pkg, lescale):
     """GridMedium emission (media.h:326-342): Le = LeScale.Lookup(p) * Le_spec, picked up by the delta-tracking
@@ -1466,6 +1550,74 @@ def test_guided_wavefront_pipeline_equals_per_lane_kernel(gpu_pkg, kind):
     assert np.array_equal(fa[..., 3], fc[..., 3])
     ia, ic = fa[..., :3] / fa[..., 3:4], fc[..., :3] / fc[..., 3:4]
     assert np.mean(np.all(np.abs(ia - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
+
+
+GUIDED_CLOUD_SWEEP = [
+    dict(maxdepth=1),                                   # two records per path (pss->Reserve(2 * maxdepth))
+    dict(maxdepth=0),                                   # thirty records reserved, none used past the first vertex
+    dict(maxdepth=8, minrrdepth=4),
+    dict(usenee=0),
+    dict(surfaceguiding=0), dict(volumeguiding=0),
+    dict(surfaceguidingtype=0, volumeguidingtype=1),    # surface MIS, volume RIS
+    dict(vspsecondaryguiding=0), dict(vspguiding=0),
+    dict(vspcriterion=0),
+]
+
+
+@pytest.mark.parametrize("case", range(len(GUIDED_CLOUD_SWEEP)))
+def test_cloud_guided_sweep_vs_oracle(gpu_pkg, case):
+    """Guiding options one at a time over the heterogeneous medium.  Query side (field uploaded): the wavefront pipeline's film
+    equals the per-lane guided kernel's bit for bit and replayed paths are the oracle's.  Training side: the samples the
+    pipeline records in two passes are the oracle's as a multiset."""
+    import scenes
+    P = gpu_pkg
+    W, H = 48, 32
+    kw = dict(GUIDED_CLOUD_SWEEP[case])
+    scene = scenes.grid_scene(scenes.cloud_density(24), (24, 24, 24), 0.08, 7.9, g=0.6, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    prm = P.default_params()
+    for k, v in kw.items():
+        setattr(prm, k, v)
+    field = scenes.light_field(P, n=4)
+    wants = prm.surfaceguiding or prm.volumeguiding or (prm.vspguiding and prm.vspsecondaryguiding)
+    films, names = [], set()
+    for kernel in (None, "lane"):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            g = P.Renderer(scene, prm, W, H, seed=20 + case)
+            if wants:
+                g.set_guiding_field(field, field)
+            names.add(g.kernel_name())
+            if kernel is None:  # (before any wave: the replay sees the image-space VSP buffer's state, and the oracle below is fresh)
+                rng = np.random.default_rng(case)
+                pix = np.stack([rng.integers(0, W, 3000), rng.integers(0, H, 3000)], axis=1).astype(np.int32)
+                si = rng.integers(0, 64, 3000).astype(np.int32)
+                Lg, sg = g.trace_paths(pix, si)
+            for w in range(3):
+                g.render_wave(w, w + 1); g.post_process_wave()
+            films.append(g.film())
+            g.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    assert len(names) == 2, names
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=20 + case)
+    if wants:
+        c.set_guiding_field(field, field)
+    Lc, sc = c.trace_paths(pix, si)
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    c.close()
+    if not wants:
+        return
+    g = P.Renderer(scene, prm, W, H, seed=20 + case)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=20 + case)
+    assert "train" in g.kernel_name() and g.kernel_name().startswith("k_wf_")
+    g.render_wave(0, 2)
+    c.render_wave(0, 2)
+    tg, tc = g.training_stats(), c.training_stats()
+    assert tg["n_samples"] == tc["n_samples"] and tg["n_zero"] == tc["n_zero"] and tg["n_dropped"] == tc["n_dropped"]
+    assert _sorted_samples(g.train_samples()).tobytes() == _sorted_samples(c.train_samples()).tobytes()
+    g.close(); c.close()
 
 
 def test_config5_standin_vs_oracle(gpu_pkg):
