@@ -634,14 +634,25 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                     const float tM = tMax * len(st.rd);
                     const V3 rdn = normalize(st.rd);
                     const auto iter = medium.sample_ray(st.ro, rdn, tM);
-                    auto pre = iter;
+                    // The pre-pass (media_sampleTMaj.h:153-168) serves the VSP-guided case (majorantScale, the zero-candidate
+                    // compensation); otherwise all it decides is the early return for a ray whose majorants are all zero.  For
+                    // a grey medium the traversal itself gives that ray the same result -- every cell multiplies T_maj by
+                    // FastExp(-0) == 1, no callback runs, no sampler dimension is drawn -- so unguided segments (every segment past
+                    // the camera ray when only the primary VSP guides) skip the DDA sweep and go straight to the walk.  (Chromatic
+                    // media keep it: with a zero majorant in the hero channel only, the early return and the traversal differ in
+                    // the other channels of T_maj.)
                     float totalLength = 0.f;
-                    while (true) {
-                        MajSeg seg;
-                        if (!pre.next(&seg)) break;
-                        const float smaj = ch_of(seg.sigma_maj, ch);
-                        if (smaj == 0) continue;
-                        totalLength += smaj * (seg.tMax - seg.tMin);
+                    if (guide || !Medium::kGrey) {
+                        auto pre = iter;
+                        while (true) {
+                            MajSeg seg;
+                            if (!pre.next(&seg)) break;
+                            const float smaj = ch_of(seg.sigma_maj, ch);
+                            if (smaj == 0) continue;
+                            totalLength += smaj * (seg.tMax - seg.tMin);
+                        }
+                    } else if (iter.tMin < iter.tMax) {
+                        totalLength = 1.f;  // (only its being non-zero matters below)
                     }
                     if (guide) extra |= WFL_GUIDE;
                     P.f(WF_VSPG, slot) = vsp;
