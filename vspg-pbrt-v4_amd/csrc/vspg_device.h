@@ -331,6 +331,9 @@ VDEV int sample_discrete2(float w0, float w1, float u) {  // sampling.h:79-113, 
 // a4: Henyey-Greenstein, frames, direction sampling
 // ---------------------------------------------------------------------------------------
 VDEV float henyey_greenstein(float cosTheta, float g) {  // scattering.h:50-59
+    // isotropic media (g == 0, the benchmark's fog): denom = 1 + 0 + 2 * 0 * cosTheta is exactly 1 for every finite cosTheta,
+    // so the expression below is kInv4Pi * 1 / (1 * 1) = kInv4Pi bit for bit -- without its square root and division
+    if (g == 0.f && __builtin_fabsf(cosTheta) < kInf) return kInv4Pi;
     g = clampf(g, (float)-.99, (float).99);
     float denom = 1 + sqr(g) + 2 * g * cosTheta;
     return kInv4Pi * (1 - sqr(g)) / (denom * safe_sqrt(denom));

@@ -235,6 +235,15 @@ struct Intr {
     V3 wo;
     float g;
 };
+// v * (T_maj / T_maj[ch]) (:1083-1084, :1236-1238, :723-724).  In a grey medium every channel of T_maj IS T_maj[ch] (built from
+// one value, HomogeneousMediumT / GridMediumT): the quotient is x / x -- exactly 1 for every finite non-zero x -- and v * 1 is v.
+// The division only runs where that is not so (a FastExp underflow to 0: 0 / 0, as in the reference).
+template <int GREY>
+VDEV Spec mul_tmaj_ratio(Spec v, Spec T_maj, int ch) {
+    const float tm = ch_of(T_maj, ch);
+    if (GREY >= 1 && tm > 0.f && tm < kInf) return v;
+    return v * (T_maj / tm);
+}
 template <class Medium, class PC, class GD = GDist>
 VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, const Bsdf *bsdf, int ch,
                     Sampler &sampler, Spec r_p, PC &pc, const GD *gd = nullptr, bool use_gd = false) {
@@ -323,10 +332,9 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
                                           if (!nonzero(T_ray)) return false;
                                           return true;
                                       });
-            float tm = ch_of(T_maj, ch);
-            T_ray = T_ray * (T_maj / tm);
-            r_l = r_l * (T_maj / tm);
-            r_u = r_u * (T_maj / tm);
+            T_ray = mul_tmaj_ratio<Medium::kGrey>(T_ray, T_maj, ch);
+            r_l = mul_tmaj_ratio<Medium::kGrey>(r_l, T_maj, ch);
+            r_u = mul_tmaj_ratio<Medium::kGrey>(r_u, T_maj, ch);
         }
         if (!nonzero(T_ray)) return sp(0.f);
     }
@@ -457,9 +465,8 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 trRatioEst = trRatioEst * (sigma_n / sigma_maj);
                 return true;
             });
-        float tm = ch_of(T_maj, ch);
-        beta_rs = beta_rs * (T_maj / tm);
-        r_u_rs = r_u_rs * (T_maj / tm);
+        beta_rs = mul_tmaj_ratio<Medium::kGrey>(beta_rs, T_maj, ch);
+        r_u_rs = mul_tmaj_ratio<Medium::kGrey>(r_u_rs, T_maj, ch);
         if (st.depth == 0 && S.tr_calc && !(vsp_ready & VSP_NO_FEED)) {  // trBuffer->AddSample (:727-728, trbuffer.h:40-45)
             // one lane owns the pixel for the whole launch and runs its samples in order (k_render_wave)
             const size_t pix = (size_t)py * S.xres + px;
@@ -607,14 +614,13 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
     // terminated is set by the tail, or beta / r_u is zero)
     bool multiply_T_maj = ev.kind == EV_PASS && nonzero(st.beta) && nonzero(st.r_u);
     if (multiply_T_maj) {
-        float tm = ch_of(T_maj, ch);
-        st.beta = st.beta * (T_maj / tm);
-        st.r_u = st.r_u * (T_maj / tm);
-        st.r_l = st.r_l * (T_maj / tm);
+        st.beta = mul_tmaj_ratio<Medium::kGrey>(st.beta, T_maj, ch);
+        st.r_u = mul_tmaj_ratio<Medium::kGrey>(st.r_u, T_maj, ch);
+        st.r_l = mul_tmaj_ratio<Medium::kGrey>(st.r_l, T_maj, ch);
         st.r_u = st.r_u * r_u_factor;
         st.r_l = st.r_l * r_u_factor;
         if constexpr (kRec) {  // :1085, :1090
-            tw = tw * (T_maj / tm);
+            tw = mul_tmaj_ratio<Medium::kGrey>(tw, T_maj, ch);
             tw = tw * (sp(1.f) / ch_of(r_u_factor, ch));
         }
     }
@@ -843,8 +849,9 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
         float pdf;
         V3 wi = hg_post(-st.rd, vg, a0, a1, sinA, cosA, &pdf);  // gphase.Sample_p(-ray.d, u)
         if (pdf == 0) return false;
-        float w = pdf / pdf;  // ps->p / ps->pdf
-        st.beta = st.beta * w;
+        // ps->p / ps->pdf: the phase function's value IS its pdf, so the weight is x / x -- exactly 1 for every finite non-zero
+        // x (pdf == 0 returned above), and beta * 1 is beta; the division only runs where it is not (an infinite or NaN pdf)
+        if (!(pdf < kInf)) st.beta = st.beta * (pdf / pdf);
         st.r_l = st.r_u / pdf;
         st.prevCtx.p = vp;
         st.prevCtx.quad = -1;
@@ -864,7 +871,7 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
     if (!nonzero(f) || pdf == 0 || wl.z == 0) return false;
     V3 wi = bsdf.frame.from_local(wl);
     st.lastVertexVolume = false;
-    st.rr_correction *= pdf / pdf;  // bs->pdf / bs->bsdfPdf
+    if (!(pdf < kInf)) st.rr_correction *= pdf / pdf;  // bs->pdf / bs->bsdfPdf == x / x == 1 for finite non-zero x (pdf == 0 returned above)
     Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
     st.beta = st.beta * bsdfWeight;
     st.r_l = st.r_u / pdf;  // misPdf == pdf without guiding

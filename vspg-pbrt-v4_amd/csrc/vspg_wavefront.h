@@ -384,12 +384,12 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *
     return r;
 }
 // ... and from the estimate on (:1233-1251).  walked: the medium block ran (T_maj is the walk's residual majorant transmittance)
+template <int GREY = 0>
 VDEV Spec sample_Ld_end(bool walked, bool delta_light, Spec T_ray, Spec r_l, Spec r_u, Spec T_maj, int ch, Spec f_hat, Spec Ll, float p_l, float scatterPDF, Spec r_p) {
     if (walked) {
-        float tm = ch_of(T_maj, ch);
-        T_ray = T_ray * (T_maj / tm);
-        r_l = r_l * (T_maj / tm);
-        r_u = r_u * (T_maj / tm);
+        T_ray = mul_tmaj_ratio<GREY>(T_ray, T_maj, ch);
+        r_l = mul_tmaj_ratio<GREY>(r_l, T_maj, ch);
+        r_u = mul_tmaj_ratio<GREY>(r_u, T_maj, ch);
     }
     if (!nonzero(T_ray)) return sp(0.f);
     r_l = r_l * (r_p * p_l);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
                             T_ray = P.sp3(WF_TRAY, slot); r_l = P.sp3(WF_SRL, slot); r_u = P.sp3(WF_SRU, slot);
                             T_maj = P.sp3(WF_STMAJ, slot);
                         }
-                        Ld = sample_Ld_end(walked, (fl & WFL_DELTA) != 0, T_ray, r_l, r_u, T_maj, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
+                        Ld = sample_Ld_end<G>(walked, (fl & WFL_DELTA) != 0, T_ray, r_l, r_u, T_maj, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
                                            P.f(WF_SPDF, slot), st.r_u);
                     }
                     st.L = st.L + beta_nee * Ld;
@@ -959,9 +959,8 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs 
                     P.load_rng(WF_RNG, slot, sampler.rng);  // the traversal drew one sampler dimension per candidate (:702)
                 }
                 float sel_sTTr = sel_wi;
-                const float tm = ch_of(T_maj, ch);
-                beta_rs = beta_rs * (T_maj / tm);
-                r_u_rs = r_u_rs * (T_maj / tm);
+                beta_rs = mul_tmaj_ratio<G>(beta_rs, T_maj, ch);
+                r_u_rs = mul_tmaj_ratio<G>(r_u_rs, T_maj, ch);
                 if (st.depth == 0 && S.tr_calc) {  // trBuffer->AddSample (:727-728, trbuffer.h:40-45); one sample per pixel per pass, passes in order
                     const size_t pix = (size_t)py * S.xres + px;
                     const int ns = S.tr_spp[pix] + 1;
