@@ -1420,6 +1420,8 @@ VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float
             continue;
         }
         float tMin = seg.tMin;
+        // (grey medium: this is x / x == 1; selecting the constant instead of dividing measured 0.7 % SLOWER on the headline
+        //  kernel -- the select keeps both operands alive across the block -- so the division stays)
         Spec nMaj = seg.sigma_maj / smaj;
         // a medium with ONE majorant segment never carries a remaining optical distance into a next
         // segment: the block below is dead for it and the loop body runs once

@@ -575,7 +575,8 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 pc.volume_scatter();
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
                 st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
-                st.r_u = st.r_u * (T_maj * sigma_t / pdf);
+                // grey medium: T_maj * sigma_t is, channel by channel, the very product pdf is -- x / x == 1 (see mul_tmaj_ratio)
+                if (!(Medium::kGrey >= 1 && pdf > 0.f && pdf < kInf)) st.r_u = st.r_u * (T_maj * sigma_t / pdf);
                 if (NDS_plus) st.r_u = st.r_u * (sigma_maj * pScatter / sigma_t);  // :975-976
                 st.r_u = st.r_u * r_u_factor;
                 if constexpr (kRec) {  // :978-986 (beta_factor is 1)
