@@ -11,8 +11,9 @@ out = (C.c_ulonglong * 16)()
 r.render_wave(0, 1); lib.vspg_wf_stats_read(out)
 r.render_wave(1, 2); lib.vspg_wf_stats_read(out)
 s = list(out)[:8]
-it, act, rounds, rl, cs, cl, rf, _ = s
-print(wl, "iterations %d  lanes with a job %.1f  advance rounds/iteration %.2f  lanes per round %.1f  collision steps/iteration %.2f  lanes per collision step %.1f  refills/iteration %.3f"
-      % (it, act / it, rounds / it, rl / rounds, cs / it, cl / max(cs, 1), rf / it))
+it, act, rounds, rl, cs, cl, dl, dr = s
+print(wl, "iterations %d  lanes with a job %.1f  advance rounds/iteration %.2f  lanes per round %.1f  collision steps/iteration %.2f  lanes per collision step %.1f"
+      % (it, act / it, rounds / it, rl / rounds, cs / it, cl / max(cs, 1)))
+print("draining iterations (no job left to claim): %.1f %% of all, %.1f lanes with a job; the others: %.1f lanes" % (100.0 * dr / it, dl / max(dr, 1), (act - dl) / max(it - dr, 1)))
 print("collisions per iteration-lane %.3f" % (cl / (64.0 * it)))
 r.close()

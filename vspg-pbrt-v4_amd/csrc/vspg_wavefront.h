@@ -457,7 +457,7 @@ VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out) {
 // =====================================================================================================================
 #ifdef VSPG_WF_STATS  // diagnostic build: where the lanes of the distance walk are (scripts/wf_stats.py reads them back)
 // [0] loop iterations  [1] lanes with a job  [2] advance rounds run  [3] lanes in them  [4] collision steps run
-// [5] lanes in them  [6] refills
+// [5] lanes in them  [6] lanes with a job in draining iterations  [7] draining iterations (the wavefront has no job left to claim)
 __device__ unsigned long long g_wf_stats[16];
 #define VSPG_WF_STAT(k, i, v) st_[(i)] += (unsigned long long)(v)
 #define VSPG_WF_STAT_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -706,6 +706,13 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
 // so a wavefront's claim reads and writes neighbouring records (whole cache lines); bucketed, every 16-byte group of a job's
 // record is its own line.  Two buckets (only the thickest 10-15 % pulled forward) were within +-0.5 %.  Dropped.
 //
+// Draining.  30 % of the distance walk's loop iterations on the 256^3 cloud are run by wavefronts that have no job left to claim,
+// with 14.6 of 64 lanes still walking (NanoVDB semantics: 40 %, 10.2 lanes; the others run 57.7 lanes).  Tried (round 2): a
+// draining wavefront down to 16 / 24 / 32 / 48 lanes PARKS its walks -- full tracking state into the record -- and a second
+// launch resumes them packed, 64 to a wavefront; bit-identical, and 12-15 % SLOWER (11.1 -> 12.4-13.0 ms; 16.3 -> 17.5): the
+// draining iterations run on a mostly empty chip and are cheap in time, the park / resume traffic and the second launch's own
+// ramp and tail are not.  Dropped.
+//
 // Claim size.  The job cursor is ONE hot word (~88 returning atomics per microsecond on this part), so claims are large; but a
 // launch ends on the wavefronts still working through their last claim, and the later path-loop iterations have a tenth of
 // the first one's jobs.  Per launch: jobs / (4 * resident wavefronts), clamped to [32, 256] -- 126 for the first iteration of a
@@ -811,7 +818,6 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
                 result = false;
             }
             unsigned ns = 0;
-            VSPG_WF_STAT(0, 6, 1);
             if (wf_claim(claim, !active, a.list_walk, n, &I->walk_head, &ns)) {
                 slot = ns;
                 w.iter = wf_load_iter(P, slot, medium);
@@ -837,6 +843,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
         float t = 0.f;
         int r = WALK_MOVED;
         VSPG_WF_STAT(0, 0, 1); VSPG_WF_STAT(0, 1, __popcll(__ballot(active))); VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(active)));
+        if (claim.exhausted && claim.next >= claim.end) { VSPG_WF_STAT(0, 7, 1); VSPG_WF_STAT(0, 6, __popcll(__ballot(active))); }  // draining: no job left to claim
         if (active) {
             r = walk_advance<Medium, true>(w, ch, scale, &t);
         }
