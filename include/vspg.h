@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSPG_ABI_VERSION 4
+#define VSPG_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define VSPG_OK 0
@@ -315,6 +315,19 @@ int vspg_post_process_wave(VspgRenderer *r, void *stream);
  * statistics).  vspg_post_process_wave(r, s) == vspg_post_process_step(r, 1, NULL, s). */
 int vspg_isg_update_due(VspgRenderer *r, int n_waves);
 int vspg_post_process_step(VspgRenderer *r, int n_waves, const float *isg_stats_sum, void *stream);
+
+/* Sharded guiding-field training ("all-reduce guiding samples / statistics per wave").  Field::Update (:239) fits
+ * the field from sufficient statistics accumulated over the step's radiance samples.  With an exchange hook installed, the
+ * update sums those statistics over the ranks at its accumulation points -- the sample count and weight, then per field the
+ * position statistics before the split, after it, and the EM step's: eight in-place sum all-reduces of at most 1.2 MB per
+ * training step -- and continues from the sums, so EVERY rank fits the SAME field from ALL ranks' samples: N ranks stepping
+ * this way train what one renderer trains that renders [w, w + N) per step (up to float summation order; the ranks' fields
+ * are bit-identical to each other when the all-reduce hands every rank the same bits, as RCCL's and gloo's do).
+ * `fn` sums n_floats floats at dev_ptr in place over the ranks, enqueued on `stream`; it returns 0 or an error code that
+ * vspg_post_process_step passes on.  Every rank must install a hook (or none): the hook is called the same number of times
+ * on every rank -- the decision to update is taken on the summed sample count.  NULL removes it. */
+typedef int (*VspgExchangeFn)(float *dev_ptr, size_t n_floats, void *stream, void *user);
+int vspg_renderer_set_exchange(VspgRenderer *r, VspgExchangeFn fn, void *user);
 
 /* Name of the kernel instantiation vspg_render_wave launches for this renderer as it stands (bench / profile
  * bookkeeping; static storage). */

@@ -28,6 +28,9 @@ int vspg_rccl_destroy(void *comm);
 int vspg_rccl_post_process_step(VspgRenderer *r, int world, void *comm, void *stream);
 /* frame end: in-place sum of the film over the ranks */
 int vspg_rccl_allreduce_film(VspgRenderer *r, void *comm, void *stream);
+/* guiding-field training over all ranks' samples: installs vspg_renderer_set_exchange(r, <ncclAllReduce sum on comm>), so that
+ * every rank's Field::Update fits the same field (include/vspg.h).  Call once after vspg_renderer_create, on every rank. */
+int vspg_rccl_enable_training_exchange(VspgRenderer *r, void *comm);
 /* sum of the path counters over the ranks (host values) */
 int vspg_rccl_sum_counters(VspgRenderer *r, void *comm, void *stream, VspgCounters *out);
 

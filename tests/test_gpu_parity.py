@@ -1720,6 +1720,96 @@ def test_training_update_matches_oracle(gpu_pkg):
     c.close()
 
 
+@pytest.mark.parametrize("medium", ["homogeneous", "grid"])
+def test_sharded_training_fits_one_field_from_all_samples(gpu_pkg, medium):
+    """SURVEY 8e for the guiding field: two shards (two renderers, two host threads standing in for two ranks) with the exchange
+    hook installed -- Field::Update sums its sufficient statistics over the shards -- fit the SAME field, bit for bit, and that
+    field is the one ONE renderer fits that renders both sample indices in a step (the oracle's field_update on the union of
+    the samples), up to float summation order."""
+    import threading
+    import scenes
+    P = gpu_pkg
+    # device <-> host copies through the HIP runtime the library itself is bound to (dlsym on its handle searches its dependencies;
+    # a second runtime in the process -- torch bundles one -- could not open the device)
+    lib = P.load()
+    lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib.hipMemcpy.restype = C.c_int
+    lib.hipDeviceSynchronize.restype = C.c_int
+    W, H = 48, 40
+    if medium == "grid":
+        scene = scenes.grid_scene(scenes.cloud_density(16), (16, 16, 16), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5,
+                                  bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    else:
+        scene = P.fog_box_scene(W, H)
+        scene.medium.g = 0.3
+    prm = P.default_params()
+    shards = [P.Renderer(scene, prm, W, H, seed=3, shard_index=k, shard_count=2) for k in range(2)]
+    barrier = threading.Barrier(2)
+    slots, calls, errors = {}, [0, 0], []
+
+    def make_hook(k):
+        def hook(ptr, n, stream):
+            calls[k] += 1
+            slots[k] = (ptr, n)
+            assert lib.hipDeviceSynchronize() == 0
+            barrier.wait(timeout=60)
+            if k == 0:   # "rank 0" sums the two shards' buffers and hands the sum to both
+                assert slots[0][1] == slots[1][1]
+                a, b = np.empty(n, np.float32), np.empty(n, np.float32)
+                assert lib.hipMemcpy(a.ctypes.data, slots[0][0], 4 * n, 2) == 0 and lib.hipMemcpy(b.ctypes.data, slots[1][0], 4 * n, 2) == 0
+                t = a + b
+                assert lib.hipMemcpy(slots[0][0], t.ctypes.data, 4 * n, 1) == 0 and lib.hipMemcpy(slots[1][0], t.ctypes.data, 4 * n, 1) == 0
+            barrier.wait(timeout=60)
+        return hook
+
+    for k in range(2):
+        shards[k].set_exchange(make_hook(k))
+        shards[k].render_wave(0, 2)          # shard k renders sample index k of the step
+
+    def step(k):
+        try:
+            shards[k].post_process_step(2)
+        except Exception as e:  # noqa
+            errors.append(e)
+            barrier.abort()
+    th = [threading.Thread(target=step, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errors, errors
+    assert calls[0] == calls[1] == 8        # count, weight sum, 3 accumulation points x 2 fields
+    st0, st1 = shards[0].training_stats(), shards[1].training_stats()
+    assert st0["iteration"] == st1["iteration"] == 1 and st0["n_nodes"] == st1["n_nodes"] and st0["n_regions"] == st1["n_regions"]
+    # one renderer stepping two waves: the oracle
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
+    c.render_wave(0, 2)
+    c.post_process_step(2, None)
+    sc = c.training_stats()
+    assert sc["iteration"] == 1 and sc["n_nodes"] == st0["n_nodes"] and sc["n_regions"] == st0["n_regions"]
+    assert st0["n_samples"] + st1["n_samples"] == sc["n_samples"]   # the shards' samples are the union renderer's
+    for vol in (0, 1):
+        n0, r0, nn0, nr0 = shards[0].get_guiding_field(vol)
+        n1, r1, nn1, nr1 = shards[1].get_guiding_field(vol)
+        assert (nn0, nr0) == (nn1, nr1)
+        assert bytes(n0)[:nn0 * C.sizeof(P.VspgKdNode)] == bytes(n1)[:nn1 * C.sizeof(P.VspgKdNode)]          # the two shards' fields:
+        assert bytes(r0)[:nr0 * C.sizeof(P.VspgFieldRegion)] == bytes(r1)[:nr1 * C.sizeof(P.VspgFieldRegion)]  # the same bits
+        nc, rc, nnc, nrc = c.get_guiding_field(vol)
+        assert (nn0, nr0) == (nnc, nrc)
+        for i in range(nn0):
+            assert n0[i].packed == nc[i].packed and abs(n0[i].split - nc[i].split) <= 1e-5
+        fg, fc = _field_arrays(P, r0, nr0), _field_arrays(P, rc, nrc)
+        assert np.array_equal(fg["n_lobes"], fc["n_lobes"])
+        assert np.allclose(fg["pivot"], fc["pivot"], atol=1e-4)
+        assert np.allclose(fg["weight"], fc["weight"], rtol=2e-3, atol=1e-5)
+        assert np.allclose(fg["mu"], fc["mu"], atol=2e-3)
+        assert np.allclose(fg["kappa"], fc["kappa"], rtol=1e-2)
+        assert np.allclose(fg["vsp"], fc["vsp"], atol=2e-3)
+    for r in shards:
+        r.close()
+    c.close()
+
+
 def test_training_in_loop_unbiased_and_useful(gpu_pkg):
     """Train + query in-loop (cfg 5).  With NEE the trained-guided render has the unguided mean (the field
     only changes sampling densities); without NEE -- where finding the small light is the whole problem --

@@ -145,6 +145,7 @@ class VspgTmajResult(C.Structure):
 # every symbol include/vspg.h declares: (name, restype, argtypes)
 _P = C.POINTER
 _vp = C.c_void_p
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)   # VspgExchangeFn
 SYMBOLS = [
     ("vspg_abi_version", C.c_int, []),
     ("vspg_last_error", C.c_char_p, []),
@@ -158,6 +159,7 @@ SYMBOLS = [
     ("vspg_post_process_wave", C.c_int, [_vp, _vp]),
     ("vspg_isg_update_due", C.c_int, [_vp, C.c_int]),
     ("vspg_post_process_step", C.c_int, [_vp, C.c_int, _vp, _vp]),
+    ("vspg_renderer_set_exchange", C.c_int, [_vp, _vp, _vp]),
     ("vspg_renderer_kernel_name", C.c_char_p, [_vp]),
     ("vspg_film_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("vspg_film_read", C.c_int, [_vp, _P(C.c_float), _vp]),
@@ -369,6 +371,25 @@ class Renderer:
         """PostProcessWave after a step of n_waves sample indices; isg_stats_sum_ptr = device pointer (int) to the
         all-reduced statistics or None."""
         _check(self.lib, self.lib.vspg_post_process_step(self.h, int(n_waves), _vp(isg_stats_sum_ptr or 0), _vp(stream or 0)))
+
+    def set_exchange(self, fn):
+        """Sharded guiding-field training: fn(dev_ptr: int, n_floats: int, stream: int) sums the floats in place over the
+        ranks (VspgExchangeFn); None removes the hook.  Exceptions in fn surface as an error of post_process_step."""
+        if fn is None:
+            self._exchange_cb = None
+            _check(self.lib, self.lib.vspg_renderer_set_exchange(self.h, None, None))
+            return
+
+        def _cb(ptr, n, stream, _user):
+            try:
+                fn(int(ptr or 0), int(n), int(stream or 0))
+                return 0
+            except Exception:  # the C side turns a non-zero return into an error code
+                import traceback
+                traceback.print_exc()
+                return VSPG_EHIP
+        self._exchange_cb = EXCHANGE_FN(_cb)   # keep the thunk alive as long as the renderer may call it
+        _check(self.lib, self.lib.vspg_renderer_set_exchange(self.h, C.cast(self._exchange_cb, _vp), None))
 
     def kernel_name(self):
         return (self.lib.vspg_renderer_kernel_name(self.h) or b"").decode()

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void k_train_estep(const DScene *__restrict
     const DScene &S = *Sp;
     vspg_libm::stage_logf_tab_lds();
     __syncthreads();
-    const float wmax = kTrainWeightClamp * (*sumw / (float)n);
+    const float wmax = kTrainWeightClamp * (sumw[0] / sumw[1]);  // mean sample weight: sum / count, both over ALL ranks' samples (train_update)
     unsigned int lo, hi;
     train_piece(*n_sorted, &lo, &hi);
     RunAccumulator<8 * GK> R;
@@ -1234,7 +1234,9 @@ struct VspgRenderer {
     unsigned long long *train_counters = nullptr;  // [0] samples, [1] zero-valued, [2..3] spare
     RegionStats *rstats[2] = {nullptr, nullptr};
     float *train_acc = nullptr;               // kTrainCapRegions x kStatFloats accumulators of one pass
-    float *train_sumw = nullptr;
+    float *train_sumw = nullptr;        // [0] sum of sample weights, [1] sample count (as a float, for the cross-rank sum)
+    VspgExchangeFn exchange = nullptr;  // sharded training: sums a device buffer over the ranks (vspg_renderer_set_exchange)
+    void *exchange_user = nullptr;
     int *train_reg = nullptr;                 // region of every sample of the batch (field being updated)
     unsigned int *train_order = nullptr;      // sample indices sorted by region
     unsigned int *train_hist = nullptr, *train_cursor = nullptr, *train_nsorted = nullptr;
@@ -2016,7 +2018,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         CK(hipMalloc(&r->train_counters, 4 * sizeof(unsigned long long)));
         CK(hipMemset(r->train_counters, 0, 4 * sizeof(unsigned long long)));
         CK(hipMalloc(&r->train_acc, (size_t)kTrainCapRegions * kStatFloats * sizeof(float)));
-        CK(hipMalloc(&r->train_sumw, sizeof(float)));
+        CK(hipMalloc(&r->train_sumw, 2 * sizeof(float)));
         CK(hipMalloc(&r->train_reg, r->sample_capacity * sizeof(int)));
         CK(hipMalloc(&r->train_order, r->sample_capacity * sizeof(unsigned int)));
         CK(hipMalloc(&r->train_hist, (size_t)kTrainCapRegions * sizeof(unsigned int)));
@@ -2311,9 +2313,29 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
     HIPCHK(hipMemcpyAsync(cnt, r->train_counters, sizeof cnt, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const unsigned long long n = cnt[0] < r->sample_capacity ? cnt[0] : r->sample_capacity;
-    if (n > kTrainMinUpdateSamples) {
+    // sharded training: `xchg` sums a device buffer over the ranks (no-op without a hook); the decision to update is taken
+    // on the SUMMED sample count, so every rank takes it alike and the hook runs the same number of times everywhere
+    const auto xchg = [&](float *p, size_t nf) -> int {
+        if (!r->exchange) return 0;
+        const int rc = r->exchange(p, nf, (void *)s, r->exchange_user);
+        return rc ? fail(rc, "the exchange hook of the sharded guiding-field update failed") : 0;
+    };
+    double n_all = (double)n;
+    {
+        float nf = (float)n;  // train_sumw[1]: the sample count the E-step divides the weight sum by
+        HIPCHK(hipMemcpyAsync(r->train_sumw + 1, &nf, sizeof nf, hipMemcpyHostToDevice, s));
+        if (r->exchange) {
+            if (int rc = xchg(r->train_sumw + 1, 1)) return rc;
+            HIPCHK(hipMemcpyAsync(&nf, r->train_sumw + 1, sizeof nf, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            n_all = (double)nf;
+        }
+    }
+    if (n_all > (double)kTrainMinUpdateSamples) {
         const size_t acc_bytes = (size_t)kTrainCapRegions * kStatFloats * sizeof(float);
+        const size_t acc_floats = (size_t)kTrainCapRegions * kStatFloats;
         unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+        if (grid < 1u) grid = 1u;  // (a rank whose own samples ran dry still takes part in the sums)
         if (grid > (unsigned)r->num_cus * 16u) grid = (unsigned)r->num_cus * 16u;
         const unsigned rgrid = (kTrainCapRegions + kBlock - 1) / kBlock;
         // counting sort: few, long chunks -- every workgroup flushes one atomic per bin its chunk touched
@@ -2322,6 +2344,7 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
         const unsigned agrid = grid < (unsigned)r->num_cus * 4u ? grid : (unsigned)r->num_cus * 4u;
         HIPCHK(hipMemsetAsync(r->train_sumw, 0, sizeof(float), s));
         hipLaunchKernelGGL(k_train_sum_weight, dim3(sgrid), dim3(kBlock), 0, s, r->samples, n, r->train_sumw);
+        if (int rc = xchg(r->train_sumw, 1)) return rc;
         const size_t hist_bytes = (size_t)kTrainCapRegions * sizeof(unsigned int);
         auto sort_by_region = [&](int f) -> int {  // reg_of, order, n_sorted for field f as the tree stands now
             HIPCHK(hipMemsetAsync(r->train_hist, 0, hist_bytes, s));
@@ -2336,16 +2359,19 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
             HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
             hipLaunchKernelGGL((k_train_pos<true>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order,
                                r->train_nsorted, r->train_acc);
+            if (int rc = xchg(r->train_acc, acc_floats)) return rc;
             hipLaunchKernelGGL(k_train_split, dim3(1), dim3(kSplitBlock), 0, s, r->dscene, f, r->rstats[f], r->train_acc, r->fnodes[f],
                                r->fregions[f]);
             if (int rc = sort_by_region(f)) return rc;  // the split changed the leaves
             HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
             hipLaunchKernelGGL((k_train_pos<false>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order,
                                r->train_nsorted, r->train_acc);
+            if (int rc = xchg(r->train_acc, acc_floats)) return rc;
             hipLaunchKernelGGL(k_train_init_regions, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->fregions[f]);
             HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
             hipLaunchKernelGGL(k_train_estep, dim3(agrid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_reg, r->train_order,
                                r->train_nsorted, r->train_sumw, r->train_acc);
+            if (int rc = xchg(r->train_acc, acc_floats)) return rc;
             hipLaunchKernelGGL(k_train_mstep, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->rstats[f],
                                r->fregions[f]);
             hipLaunchKernelGGL(k_field_aux, dim3(rgrid * 2), dim3(kBlock), 0, s, r->dscene, f, r->fregions[f], r->faux[f]);
@@ -2404,6 +2430,12 @@ int vspg_post_process_step(VspgRenderer *r, int n_waves, const float *isg_stats_
     return 0;
 }
 int vspg_post_process_wave(VspgRenderer *r, void *stream) { return vspg_post_process_step(r, 1, nullptr, stream); }
+int vspg_renderer_set_exchange(VspgRenderer *r, VspgExchangeFn fn, void *user) {
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    r->exchange = fn;
+    r->exchange_user = user;
+    return 0;
+}
 
 int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
     if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");

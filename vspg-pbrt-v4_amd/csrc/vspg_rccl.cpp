@@ -117,6 +117,19 @@ int vspg_rccl_post_process_step(VspgRenderer *r, int world, void *comm, void *st
     return vspg_post_process_step(r, world, sum, stream);
 }
 
+static int rccl_exchange(float *p, size_t n, void *stream, void *user) {
+    const ncclResult_t nr = ncclAllReduce(p, p, n, ncclFloat, ncclSum, (ncclComm_t)user, (hipStream_t)stream);
+    if (nr != ncclSuccess) {
+        std::fprintf(stderr, "vspg_rccl: training exchange: %s\n", ncclGetErrorString(nr));
+        return VSPG_EHIP;
+    }
+    return 0;
+}
+int vspg_rccl_enable_training_exchange(VspgRenderer *r, void *comm) {
+    if (!r) return VSPG_EINVAL;
+    return vspg_renderer_set_exchange(r, comm ? rccl_exchange : nullptr, comm);
+}
+
 int vspg_rccl_allreduce_film(VspgRenderer *r, void *comm, void *stream) {
     if (!r) return VSPG_EINVAL;
     float *film = nullptr;

@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
         cfg.xres = sd->xres; cfg.yres = sd->yres; cfg.spp = sd->pixelSamples; cfg.seed = sd->seed;
         cfg.shard_index = rank; cfg.shard_count = world; cfg.device = local;
         if (vspg_renderer_create(&sd->scene, &prm, &cfg, &r) != 0) throw vspg::Error(vspg_last_error());
+        if (world > 1 && vspg_rccl_enable_training_exchange(r, comm) != 0) throw vspg::Error("training exchange set-up failed");
         const int steps = (sd->pixelSamples + world - 1) / world;
         for (int s = 0; s < steps; ++s) {
             const int w0 = s * world, w1 = (s + 1) * world < sd->pixelSamples ? (s + 1) * world : sd->pixelSamples;

@@ -54,6 +54,29 @@ class ShardSync:
         self.dist, self.r, self.world, self.torch, self.device = dist, renderer, world, torch, device
         self._stats = None
         self._sum = None
+        # guiding-field training: the HIP renderer's Field::Update sums its sufficient statistics over the ranks
+        # through this hook (vspg_renderer_set_exchange), so every rank fits the same field from all ranks' samples
+        if world > 1 and hasattr(renderer, "set_exchange"):
+            renderer.set_exchange(self._exchange)
+
+    def _exchange(self, ptr, n, stream):
+        torch = self.torch
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        t = torch.as_tensor(_Dev(), device=self.device)
+        # the update's kernels run on `stream`; collectives are issued on torch's current stream: order the two
+        if stream == torch.cuda.current_stream(self.device).cuda_stream:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        elif stream:
+            ext = torch.cuda.ExternalStream(stream, device=self.device)
+            torch.cuda.current_stream(self.device).wait_stream(ext)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            ext.wait_stream(torch.cuda.current_stream(self.device))
+        else:
+            torch.cuda.synchronize(self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            torch.cuda.synchronize(self.device)
 
     def _stats_tensor(self):
         if hasattr(self.r, "isg_stats_tensor"):       # CPU oracle: a fresh host copy per call
