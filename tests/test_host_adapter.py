@@ -194,6 +194,20 @@ def test_scene_file_render_equals_the_api_scene(host_build, gpu_pkg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_wave_log_lines(host_build, tmp_path):
+    """--wave-log: one JSON line per wave with the wave's wall time, its path / segment counts and the kernel that served it."""
+    import json
+    exe = os.path.join(host_build, "vspg_pbrt")
+    log = tmp_path / "waves.jsonl"
+    a = subprocess.run([exe, os.path.join(SCENES, "cloud_sky.pbrt"), "--outfile", str(tmp_path / "o.pfm"), "--spp", "5", "--wave-log", str(log)],
+                       capture_output=True, text=True, env=dict(os.environ, VSPG_ROCTX="1"))   # (markers on: must not disturb anything)
+    assert a.returncode == 0, a.stdout + a.stderr
+    lines = [json.loads(x) for x in open(log)]
+    assert [x["wave"] for x in lines] == [0, 1, 2, 3, 4]
+    assert all(x["paths"] == 48 * 32 and x["segments"] >= x["paths"] and x["ms"] > 0 and x["kernel"].startswith("k_wf_") for x in lines)
+
+
+@pytest.mark.gpu
 def test_scene_file_cloud_sky_with_default_guiding(host_build, tmp_path):
     """The same scene with the reference's DEFAULT integrator options (directional guiding trained in the loop for 128 waves,
     then queried; secondary-ray VSP) -- sky + sun + triangle ground + placed cloud used to be outside the guided kernels' scope.

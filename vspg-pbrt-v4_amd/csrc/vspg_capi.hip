@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see csrc/Makefile).
 // No CPU fallback lives here: every compute entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -1710,6 +1711,33 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     return 0;
 }
 
+// Profiling markers (trace ranges): with VSPG_ROCTX=1 in the environment every vspg_render_wave / vspg_post_process_step
+// call is a roctx range (rocprofv3 --marker-trace shows waves and post-processing on the timeline).  libroctx64 is looked up at
+// run time, so the library carries no link dependency on it and costs nothing when the variable is unset.
+namespace {
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char *e = getenv("VSPG_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        // rocprofv3 listens to the rocprofiler-sdk's roctx; roctracer's libroctx64 (same entry points) serves older tools
+        void *h = nullptr;
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const RoctxApi g_roctx;
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { if (g_roctx.push) g_roctx.push(name); }
+    ~RoctxRange() { if (g_roctx.pop) g_roctx.pop(); }
+};
+}  // namespace
+
 extern "C" {
 
 int vspg_abi_version(void) { return VSPG_ABI_VERSION; }
@@ -2148,6 +2176,7 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
 }
 
 int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream) {
+    const RoctxRange range("vspg_render_wave");
     if (!r) return fail(VSPG_EINVAL, "null renderer");
     if (wave_end < wave_start || wave_start < 0) return fail(VSPG_EINVAL, "bad wave range");
     if (wave_end == wave_start) return 0;
@@ -2396,6 +2425,7 @@ int vspg_isg_update_due(VspgRenderer *r, int n_waves) {
 
 int vspg_post_process_step(VspgRenderer *r, int n_waves, const float *isg_stats_sum, void *stream) {
     // PostProcessWave (guidedvolpathvspgintegrator.cpp:230-260) after a step that covered n_waves sample indices
+    const RoctxRange range("vspg_post_process_step");
     if (!r) return fail(VSPG_EINVAL, "null renderer");
     if (n_waves < 1) return fail(VSPG_EINVAL, "n_waves must be >= 1");
     const bool due = isg_update_due(r, n_waves);

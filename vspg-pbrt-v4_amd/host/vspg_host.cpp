@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 
@@ -570,9 +571,23 @@ GuidingCache GuidingCache::Read(const std::string &filename) {
 void GuidedVolPathVSPGIntegrator::Render() {
     // ImageTileIntegrator::Render (integrators.cpp:123-239): waves of 1 spp, PostProcessWave each
     int waveStart = 0, waveEnd = 1, nextWaveSize = 1;
+    VspgCounters before;
+    std::memset(&before, 0, sizeof before);
     while (waveStart < spp) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const std::string kernel = waveLog ? vspg_renderer_kernel_name(renderer) : "";
         if (vspg_render_wave(renderer, waveStart, waveEnd, nullptr) != 0) throw Error(vspg_last_error());
         PostProcessWave();
+        if (waveLog) {  // one JSON line per wave: the counter read synchronises the stream, so `ms` is the wave's wall time
+            VspgCounters c;
+            if (vspg_get_counters(renderer, &c, nullptr) != 0) throw Error(vspg_last_error());
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(waveLog, "{\"wave\": %d, \"ms\": %.4f, \"paths\": %llu, \"segments\": %llu, \"density_queries\": %llu, \"kernel\": \"%s\"}\n", waveStart, ms,
+                         (unsigned long long)(c.paths - before.paths), (unsigned long long)(c.segments - before.segments),
+                         (unsigned long long)(c.density_queries - before.density_queries), kernel.c_str());
+            std::fflush(waveLog);
+            before = c;
+        }
         waveStart = waveEnd;
         waveEnd = std::min(spp, waveEnd + nextWaveSize);
     }

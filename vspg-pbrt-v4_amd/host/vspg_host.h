@@ -12,6 +12,7 @@
 // vspg::Error with the same trigger conditions so an embedding application can decide.
 #pragma once
 #include <map>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -166,8 +167,11 @@ class GuidedVolPathVSPGIntegrator : public Integrator {
     TrBuffer GetTrBuffer();              // the transmittance buffer as it stands (recorded or loaded)
     VspBuffer GetVspBuffer();            // the image-space VSP estimate as it stands
     const VspgIntegratorParams &Params() const { return params; }
+    // one JSON line per wave while rendering: {wave, ms, paths, segments, density_queries, kernel} (not owned; NULL = off)
+    void SetWaveLog(std::FILE *f) { waveLog = f; }
 
   private:
+    std::FILE *waveLog = nullptr;
     VspgIntegratorParams params;
     VspgRenderConfig cfg;
     VspgRenderer *renderer = nullptr;

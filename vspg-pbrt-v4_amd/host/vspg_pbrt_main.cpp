@@ -1,5 +1,5 @@
 // vspg_pbrt -- render a pbrt-v4 scene file (the subset of vspg_scenefile.h) with the MI355X-native GuidedVolPathVSPG path.
-//   vspg_pbrt scene.pbrt [--spp N] [--outfile image.pfm] [--seed S] [--device D] [--parse-only]
+//   vspg_pbrt scene.pbrt [--spp N] [--outfile image.pfm] [--seed S] [--device D] [--wave-log waves.jsonl] [--parse-only]
 // The counterpart of `pbrt scene.pbrt` for this integrator (cmd/pbrt.cpp -> RenderCPU, cpu/render.cpp:56-57); the image is
 // written as PFM (RGBFilm::WriteImage's EXR needs OpenEXR, an absent submodule).
 #include <cstdio>
@@ -12,6 +12,7 @@
 int main(int argc, char **argv) {
     std::string scene, out;
     int spp = -1, seed = -1, device = 0;
+    std::string waveLogPath;
     bool parseOnly = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -20,11 +21,12 @@ int main(int argc, char **argv) {
         else if (a == "--outfile") out = next();
         else if (a == "--seed") seed = std::atoi(next());
         else if (a == "--device") device = std::atoi(next());
+        else if (a == "--wave-log") waveLogPath = next();
         else if (a == "--parse-only") parseOnly = true;
         else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
         else scene = a;
     }
-    if (scene.empty()) { std::fprintf(stderr, "usage: vspg_pbrt scene.pbrt [--spp N] [--outfile image.pfm] [--seed S] [--device D] [--parse-only]\n"); return 2; }
+    if (scene.empty()) { std::fprintf(stderr, "usage: vspg_pbrt scene.pbrt [--spp N] [--outfile image.pfm] [--seed S] [--device D] [--wave-log waves.jsonl] [--parse-only]\n"); return 2; }
     try {
         auto sd = vspg::ParseSceneFile(scene);
         if (spp > 0) sd->pixelSamples = spp;
@@ -37,8 +39,15 @@ int main(int argc, char **argv) {
         if (parseOnly) return 0;
         auto integrator = vspg::CreateIntegrator(*sd, device);
         std::printf("%s\n", integrator->ToString().c_str());
-        integrator->Render();
         auto *vi = static_cast<vspg::GuidedVolPathVSPGIntegrator *>(integrator.get());
+        std::FILE *wl = nullptr;
+        if (!waveLogPath.empty()) {
+            wl = std::fopen(waveLogPath.c_str(), "w");
+            if (!wl) throw vspg::Error("cannot open " + waveLogPath);
+            vi->SetWaveLog(wl);
+        }
+        integrator->Render();
+        if (wl) { vi->SetWaveLog(nullptr); std::fclose(wl); }
         vspg::Film film = vi->GetFilm();
         film.WritePFM(sd->filmFilename);
         VspgCounters c = vi->Counters();
