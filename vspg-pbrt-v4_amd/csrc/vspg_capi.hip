@@ -1462,9 +1462,25 @@ struct Builder {
     std::vector<Box> tbox;
     std::vector<float> cen;         // 3 per triangle
     std::vector<DBvhNode> nodes;
+    std::vector<signed char> split_axis;   // per node: the axis its children were separated along (inner nodes)
+    // The traversal has no stack: its order is the array's.  So the tree is laid out EIGHT times, once per sign pattern of a ray
+    // direction: at every inner node the child on the side the ray comes from goes first (near-first traversal, which lets the
+    // running closest distance cull the far child), each layout with its own skip links.  A ray walks the layout of its octant.
+    void emit(int node, int oct, std::vector<DBvhNode> &out) const {
+        const int idx = (int)out.size();
+        out.push_back(nodes[node]);
+        if (nodes[node].leaf < 0) {
+            const int left = node + 1, right = nodes[left].skip;   // (base layout: left subtree first)
+            const bool right_first = (oct >> split_axis[node]) & 1;  // the ray runs towards -axis: the upper child is nearer
+            emit(right_first ? right : left, oct, out);
+            emit(right_first ? left : right, oct, out);
+        }
+        out[idx].skip = (int)out.size();
+    }
     void build(int lo, int hi) {
         const int me = (int)nodes.size();
         nodes.push_back(DBvhNode{});
+        split_axis.push_back(0);
         Box b = empty_box(), cb = empty_box();
         for (int i = lo; i < hi; ++i) { merge(b, tbox[order[i]]); grow(cb, &cen[3 * order[i]]); }
         for (int k = 0; k < 3; ++k) { nodes[me].bmin[k] = b.lo[k]; nodes[me].bmax[k] = b.hi[k]; }
@@ -1500,6 +1516,7 @@ struct Builder {
         }
         if (mid > lo && mid < hi) {
             nodes[me].leaf = -1;
+            split_axis[me] = (signed char)axis;
             build(lo, mid);
             build(mid, hi);
         } else {
@@ -1969,8 +1986,16 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             for (size_t i = 0; i < all.size(); ++i) sorted[i] = all[B.order[i]];
             CK(hipMalloc(&r->tris, sorted.size() * sizeof(DTri)));
             CK(hipMemcpy(r->tris, sorted.data(), sorted.size() * sizeof(DTri), hipMemcpyHostToDevice));
-            CK(hipMalloc(&r->bvh, B.nodes.size() * sizeof(DBvhNode)));
-            CK(hipMemcpy(r->bvh, B.nodes.data(), B.nodes.size() * sizeof(DBvhNode), hipMemcpyHostToDevice));
+            std::vector<DBvhNode> layouts;   // eight direction-ordered layouts, back to back (see Builder::emit)
+            layouts.reserve(8 * B.nodes.size());
+            for (int oct = 0; oct < 8; ++oct) {
+                std::vector<DBvhNode> one;
+                one.reserve(B.nodes.size());
+                B.emit(0, oct, one);
+                layouts.insert(layouts.end(), one.begin(), one.end());
+            }
+            CK(hipMalloc(&r->bvh, layouts.size() * sizeof(DBvhNode)));
+            CK(hipMemcpy(r->bvh, layouts.data(), layouts.size() * sizeof(DBvhNode), hipMemcpyHostToDevice));
             r->hscene.n_tris = (int32_t)sorted.size();
             r->hscene.n_bvh_nodes = (int32_t)B.nodes.size();
             r->hscene.tris = r->tris;
@@ -2215,7 +2240,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         };
         const size_t nb = (size_t)r->hscene.bnx * r->hscene.bny * r->hscene.bnz;
         const void *bufs[6] = {r->tris, r->bvh, r->brick_index, r->octets, r->dscene, r->majorant};
-        const size_t sizes[6] = {(size_t)r->hscene.n_tris * sizeof(DTri), (size_t)r->hscene.n_bvh_nodes * sizeof(DBvhNode), nb * 4, r->n_bricks * 512 * 32,
+        const size_t sizes[6] = {(size_t)r->hscene.n_tris * sizeof(DTri), (size_t)r->hscene.n_bvh_nodes * 8 * sizeof(DBvhNode), nb * 4, r->n_bricks * 512 * 32,
                                  sizeof(DScene), (size_t)16 * 16 * 16 * 4};
         unsigned long long before[6];
         for (int k = 0; k < 6; ++k) before[k] = checksum(bufs[k], sizes[k]);

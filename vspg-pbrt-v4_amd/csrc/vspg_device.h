@@ -478,7 +478,8 @@ struct DTri {
     int32_t pad;
 };
 // BVH in depth-first order (own builder, vspg_capi.hip): an inner node's first child is the next node; `skip` is where
-// the traversal continues when the node is missed or its subtree is done -- no stack, no per-lane scratch.
+// the traversal continues when the node is missed or its subtree is done -- no stack, no per-lane scratch.  S.bvh holds
+// EIGHT layouts of the same tree, n_bvh_nodes each, one per sign pattern of a ray direction (near child first).
 struct DBvhNode {
     float bmin[3];
     int32_t skip;
@@ -743,8 +744,10 @@ VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, Tri
     int best_id = 0x7fffffff;
     float limit = tMax;
     int i = 0;
+    // the layout of the ray's octant: near child first at every inner node (vspg_capi.hip, bvhbuild::Builder::emit)
+    const DBvhNode *const nodes = S.bvh + (size_t)((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) * (size_t)S.n_bvh_nodes;
     while (i < S.n_bvh_nodes) {
-        const float4 *nd = reinterpret_cast<const float4 *>(S.bvh + i);
+        const float4 *nd = reinterpret_cast<const float4 *>(nodes + i);
         const float4 lo = nd[0], hi = nd[1];
         const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
         // cull with slack: the box may touch the triangle exactly where it is hit
@@ -776,8 +779,9 @@ VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, Tri
 VDEV bool bvh_any(const DScene &S, V3 o, V3 d, float tMax) {
     const V3 inv = V3{1 / d.x, 1 / d.y, 1 / d.z};
     int i = 0;
+    const DBvhNode *const nodes = S.bvh + (size_t)((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) * (size_t)S.n_bvh_nodes;
     while (i < S.n_bvh_nodes) {
-        const float4 *nd = reinterpret_cast<const float4 *>(S.bvh + i);
+        const float4 *nd = reinterpret_cast<const float4 *>(nodes + i);
         const float4 lo = nd[0], hi = nd[1];
         const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
         if (bvh_box_hit(lo, hi, o, inv, tMax)) {
