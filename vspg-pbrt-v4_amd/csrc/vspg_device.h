@@ -676,16 +676,30 @@ VDEV bool quad_intersect(const DQuad &q, V3 o, V3 d, float tMax, float *tHit, V3
 struct TriHit { float t, b0, b1, b2; };
 VDEV V3 permute3(V3 v, int kx, int ky, int kz) { return V3{comp(v, kx), comp(v, ky), comp(v, kz)}; }
 VDEV float max3abs(float a, float b, float c) { return fmax_(fmax_(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)); }
-VDEV bool tri_intersect(V3 o, V3 d, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit) {
-    if (len2(cross(p2 - p0, p1 - p0)) == 0) return false;
-    V3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+// the part of IntersectTriangle that depends on the ray only (shapes.cpp:180-197: the permutation that makes |d.z| the largest
+// component and the shear that aligns d with +z): computed ONCE per ray by the traversals instead of once per triangle test --
+// three IEEE divisions (~150 SIMD-cycles) per test otherwise; the same operations on the same operands, so the same bits
+struct TriRay {
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+};
+VDEV TriRay tri_ray(V3 d) {
+    TriRay R;
     const V3 ad = vabs(d);
-    const int kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxComponentIndex (vecmath.h:454-456)
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    const V3 dp = permute3(d, kx, ky, kz);
+    R.kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxComponentIndex (vecmath.h:454-456)
+    R.kx = R.kz + 1; if (R.kx == 3) R.kx = 0;
+    R.ky = R.kx + 1; if (R.ky == 3) R.ky = 0;
+    const V3 dp = permute3(d, R.kx, R.ky, R.kz);
+    R.Sx = -dp.x / dp.z; R.Sy = -dp.y / dp.z; R.Sz = 1 / dp.z;
+    return R;
+}
+// (the degenerate-triangle test of :172-173 runs when the soup is uploaded -- derive_triangle, same expression: such triangles
+//  never reach the device array)
+VDEV bool tri_intersect(V3 o, const TriRay &R, float tMax, V3 p0, V3 p1, V3 p2, TriHit *hit) {
+    V3 p0t = p0 - o, p1t = p1 - o, p2t = p2 - o;
+    const int kx = R.kx, ky = R.ky, kz = R.kz;
     p0t = permute3(p0t, kx, ky, kz); p1t = permute3(p1t, kx, ky, kz); p2t = permute3(p2t, kx, ky, kz);
-    const float Sx = -dp.x / dp.z, Sy = -dp.y / dp.z, Sz = 1 / dp.z;
+    const float Sx = R.Sx, Sy = R.Sy, Sz = R.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -742,6 +756,7 @@ VDEV bool bvh_box_hit(const float4 &lo, const float4 &hi, V3 o, V3 inv, float tL
 // closest distance -- the test's acceptance would then depend on the visiting order), candidates compare by (t, id)
 VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, TriHit *best) {
     const V3 inv = V3{1 / d.x, 1 / d.y, 1 / d.z};
+    const TriRay R = tri_ray(d);
     bool found = false;
     int best_id = 0x7fffffff;
     float limit = tMax;
@@ -759,7 +774,7 @@ VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, Tri
                 for (int k = 0; k < cnt; ++k) {
                     const DTri &T = S.tris[first + k];
                     TriHit h;
-                    if (tri_intersect(o, d, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax &&
+                    if (tri_intersect(o, R, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax &&
                         (!found || h.t < best->t || (h.t == best->t && T.id < best_id))) {
                         found = true;
                         *best = h;
@@ -780,6 +795,7 @@ VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, Tri
 }
 VDEV bool bvh_any(const DScene &S, V3 o, V3 d, float tMax) {
     const V3 inv = V3{1 / d.x, 1 / d.y, 1 / d.z};
+    const TriRay R = tri_ray(d);
     int i = 0;
     const DBvhNode *const nodes = S.bvh + (size_t)((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) * (size_t)S.n_bvh_nodes;
     while (i < S.n_bvh_nodes) {
@@ -792,7 +808,7 @@ VDEV bool bvh_any(const DScene &S, V3 o, V3 d, float tMax) {
                 for (int k = 0; k < cnt; ++k) {
                     const DTri &T = S.tris[first + k];
                     TriHit h;
-                    if (tri_intersect(o, d, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax) return true;
+                    if (tri_intersect(o, R, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax) return true;
                 }
                 i = skip;
             } else {
