@@ -160,12 +160,37 @@ def test_scene_files_parse(host_build):
     assert "0 rectangles, 4 triangles, 2 infinite lights, medium type 2 (placed), film 48x32 @ 2 spp" in b.stdout
 
 
+def test_scene_file_include(host_build, tmp_path):
+    """Include: as a directive (pbrt's) and inside a parameter list -- the block the reference's nanovdb2pbrt prints for a grid
+    (cmd/nanovdb2pbrt.cpp:117-126) kept in its own file next to the scene.  The parsed scene is the inline one's."""
+    exe = os.path.join(host_build, "vspg_pbrt")
+    src = open(os.path.join(SCENES, "cloud_sky.pbrt")).read()
+    i, j = src.index('"integer nx" 2'), src.index('"rgb sigma_a"')
+    (tmp_path / "sub").mkdir()
+    (tmp_path / "sub" / "grid.pbrt").write_text('"integer nx" 2 "integer ny" 2  "integer nz" 2\n\t"point3 p0" [ -1.000000 -1.000000 -1.000000 ] '
+                                                '"point3 p1" [ 1.000000 1.000000 1.000000 ]\n\t"float density" [\n0.200000 1.000000 0.700000 0.100000 0.900000 0.400000 1.000000 0.600000 ]\n')
+    k = src.index("LightSource")
+    (tmp_path / "lights.pbrt").write_text(src[k:src.index("Material")])
+    scene = src[:i] + 'Include "sub/grid.pbrt"\n      ' + src[j:k] + 'Include "lights.pbrt"\n' + src[src.index("Material"):]
+    (tmp_path / "scene.pbrt").write_text(scene)
+    r = subprocess.run([exe, str(tmp_path / "scene.pbrt"), "--parse-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "0 rectangles, 4 triangles, 2 infinite lights, medium type 2 (placed), film 48x32 @ 2 spp" in r.stdout
+    (tmp_path / "loop.pbrt").write_text('Include "loop.pbrt"\n')
+    r = subprocess.run([exe, str(tmp_path / "loop.pbrt"), "--parse-only"], capture_output=True, text=True)
+    assert r.returncode == 1 and "nested deeper" in r.stderr
+    (tmp_path / "missing.pbrt").write_text('Include "nope.pbrt"\n')
+    r = subprocess.run([exe, str(tmp_path / "missing.pbrt"), "--parse-only"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+
+
 @pytest.mark.parametrize("bad,needle", [
     ('Shape "sphere" "float radius" 1', 'Shape "sphere"'),
     ('Texture "t" "spectrum" "checkerboard"', 'directive "Texture"'),
     ('Material "diffuse" "rgb reflectance" [ .5 .5 .5 ] "float bogus" 1', "unused parameter"),
     ('Material "conductor"', 'Material "conductor"'),
     ('LightSource "spot"', 'LightSource "spot"'),
+    ('MakeNamedMedium "c" "string type" "nanovdb" "string filename" "cloud.nvdb"\nMediumInterface "" "c"\nCamera "perspective"', "nanovdb2pbrt"),
 ])
 def test_scene_file_errors(host_build, tmp_path, bad, needle):
     exe = os.path.join(host_build, "vspg_pbrt")

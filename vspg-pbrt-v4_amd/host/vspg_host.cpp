@@ -213,7 +213,10 @@ VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p, s
     std::memset(&m, 0, sizeof m);
     if (name == "uniformgrid") return CreateGridMedium(p, densityStorage, leScaleStorage);
     if (name != "homogeneous")
-        throw Error("medium \"" + name + "\": only \"homogeneous\" and \"uniformgrid\" are inside this build's scope");
+        throw Error("medium \"" + name + "\": only \"homogeneous\" and \"uniformgrid\" are inside this build's scope" +
+                    (name == "nanovdb" ? std::string(" -- a .nvdb grid comes in through the reference's own converter: `nanovdb2pbrt file.nvdb > grid.pbrt` prints the "
+                                                     "\"integer nx ny nz\" \"point3 p0 p1\" \"float density\" parameters of a \"uniformgrid\" medium (INTEGRATION.md 2)")
+                                       : std::string()));
     // HomogeneousMedium::Create (media.cpp:167-206)
     if (!p.GetOneString("preset", "").empty()) throw Error("medium \"preset\" tables are outside this build's scope");
     float sa[3] = {1.f, 1.f, 1.f}, ss[3] = {1.f, 1.f, 1.f}, le[3] = {0, 0, 0};  // defaults: ConstantSpectrum(1)

@@ -114,7 +114,7 @@ struct NamedMedium {
 
 class Parser {
   public:
-    explicit Parser(const std::string &text) : tok(tokenize(text)) {}
+    explicit Parser(const std::string &text, const std::string &baseDir = "") : tok(tokenize(text)), baseDir(baseDir) {}
     std::unique_ptr<SceneDescription> run() {
         sd = std::make_unique<SceneDescription>();
         std::memset(&sd->scene, 0, sizeof sd->scene);
@@ -125,6 +125,8 @@ class Parser {
 
   private:
     std::vector<Token> tok;
+    std::string baseDir;   // directory of the scene file: Include and relative file names resolve against it
+    int includeDepth = 0;
     size_t pos = 0;
     std::unique_ptr<SceneDescription> sd;
     GraphicsState gs;
@@ -158,12 +160,33 @@ class Parser {
     // re-assembled for ParameterDictionary::Parse
     ParameterDictionary params_with_bare_bools() {
         std::string text;
-        while (pos < tok.size() && (tok[pos].kind != Token::Word || tok[pos].text == "true" || tok[pos].text == "false")) {
+        while (pos < tok.size()) {
+            if (tok[pos].kind == Token::Word && tok[pos].text == "Include" && pos + 1 < tok.size() && tok[pos + 1].kind == Token::String) {
+                // beyond pbrt (whose Include is a directive only): an Include INSIDE a parameter list splices the file's parameters in,
+                // so that the block `nanovdb2pbrt` prints can stay in its own file: MakeNamedMedium "c" "string type" "uniformgrid" Include "grid.pbrt"
+                ++pos;
+                splice_include();
+                continue;
+            }
+            if (!(tok[pos].kind != Token::Word || tok[pos].text == "true" || tok[pos].text == "false")) break;
             const Token &t = tok[pos++];
             if (t.kind == Token::String) text += "\"" + t.text + "\" ";
             else text += t.text + " ";
         }
         return ParameterDictionary::Parse(text);
+    }
+    // pbrt's Include (parser.cpp): the named file's tokens take the directive's place.  Relative names resolve against the
+    // including scene file's directory.
+    void splice_include() {
+        std::string name = str();
+        if (!name.empty() && name[0] != '/' && !baseDir.empty()) name = baseDir + "/" + name;
+        if (++includeDepth > 16) fail("Include nested deeper than 16 files");
+        std::ifstream f(name);
+        if (!f) fail("Include \"" + name + "\": cannot open");
+        std::stringstream ss;
+        ss << f.rdbuf();
+        const std::vector<Token> inc = tokenize(ss.str());
+        tok.insert(tok.begin() + (std::ptrdiff_t)pos, inc.begin(), inc.end());
     }
     void concat(const M4 &t) { gs.ctm = mul(gs.ctm, t); }
 
@@ -282,6 +305,8 @@ class Parser {
             const std::string type = str();
             ParameterDictionary p = params_with_bare_bools();
             shape(type, p);
+        } else if (d == "Include") {
+            splice_include();
         } else {
             fail("directive \"" + d + "\" is outside this build's scope");
         }
@@ -417,7 +442,8 @@ std::unique_ptr<SceneDescription> ParseSceneFile(const std::string &filename) {
     if (!f) throw Error(filename + ": cannot open");
     std::stringstream ss;
     ss << f.rdbuf();
-    return ParseSceneString(ss.str());
+    const size_t slash = filename.find_last_of('/');
+    return Parser(ss.str(), slash == std::string::npos ? std::string(".") : filename.substr(0, slash)).run();
 }
 std::unique_ptr<Integrator> CreateIntegrator(const SceneDescription &sd, int device) {
     return Integrator::Create(sd.integratorName, sd.integratorParams, sd.scene, sd.xres, sd.yres, sd.pixelSamples, sd.seed, device);

@@ -12,6 +12,7 @@
 // Identity, Translate, Scale, Rotate, Transform, ConcatTransform, ReverseOrientation, Material "diffuse" (reflectance),
 // MakeNamedMaterial / NamedMaterial ("diffuse"), AreaLightSource "diffuse" (L, scale, twosided), LightSource "infinite"
 // (L, scale; no image) / "distant" (L, scale, from, to), MakeNamedMedium ("homogeneous", "uniformgrid"), MediumInterface,
+// Include (as a directive, and -- beyond pbrt -- inside a parameter list, for the block the reference's nanovdb2pbrt prints),
 // Shape "bilinearmesh" (one patch: a parallelogram becomes a rectangle, anything else two triangles) / "trianglemesh"
 // (P, indices).  Anything else is an Error naming the directive: nothing is silently dropped.
 //
