@@ -1395,8 +1395,10 @@ def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
     prm = P.default_params()
     field = scenes.light_field(P, n=4)
     films = {}
-    for kernel in ("wg", "lane"):
+    for kernel, nogrey in (("wg", ""), ("lane", ""), ("lane", "1")):
         os.environ["VSPG_KERNEL"] = kernel
+        if nogrey:
+            os.environ["VSPG_NO_GREY_GUIDED"] = nogrey
         try:
             r = P.Renderer(scene, prm, W, H, seed=2)
             r.set_guiding_field(field, field)
@@ -1408,9 +1410,12 @@ def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
             r.close()
         finally:
             os.environ.pop("VSPG_KERNEL", None)
-    assert sorted(films) == ["k_render_wave<HomogeneousMedium,guided>", "k_render_wave_wg<HomogeneousMedium,guided>"], sorted(films)
-    a, b = films.values()
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            os.environ.pop("VSPG_NO_GREY_GUIDED", None)
+    # the per-lane kernel's grey / zero-null-coefficient instantiation (the fog box qualifies), its generic one, the workgroup kernel
+    assert sorted(films) == ["k_render_wave<HomogeneousMedium,guided>", "k_render_wave<HomogeneousMediumT<2,true>,guided>",
+                             "k_render_wave_wg<HomogeneousMedium,guided>"], sorted(films)
+    a, b, c3 = films.values()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c3.view(np.uint32))
 
 
 @pytest.mark.parametrize("stype,vtype", [(1, 0), (0, 1)])  # (ris, mis) = reference defaults; (mis, ris)
@@ -1483,7 +1488,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     g = P.Renderer(scene, prm, W, H, seed=3)
     c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
     # grid media record on the wavefront pipeline (recorder state travels in the path record), homogeneous ones on the per-lane kernel
-    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave<HomogeneousMedium,guided,train>")
+    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave<HomogeneousMediumT<2,true>,guided,train>")
     g.render_wave(0, 2)
     c.render_wave(0, 2)
     sg, sc = g.training_stats(), c.training_stats()

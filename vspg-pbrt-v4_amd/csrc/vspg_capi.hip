@@ -2164,6 +2164,12 @@ static bool uses_wg_guided(const VspgRenderer *r) {
     return wants_guiding(r->prm) && !r->training && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
            r->hscene.n_tris == 0 && r->hscene.n_inf == 0;
 }
+// guided renders over a homogeneous medium: the grey / zero-null-coefficient / rectangle-scene instantiation of the per-lane
+// kernel (the segment half of the loop sheds the same per-channel work as the headline kernel's instantiation)
+static bool guided_grey_simple(const VspgRenderer *r) {
+    return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS && r->medium_grey && r->surfaces_grey && r->null_zero && r->hscene.n_tris == 0 &&
+           r->hscene.n_inf == 0 && !getenv("VSPG_NO_GREY_GUIDED");
+}
 static bool uses_wg_kernel(const VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
@@ -2211,6 +2217,7 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (nvdb) return guided ? (train ? "k_render_wave<NanoDenseMedium,guided,train>" : "k_render_wave<NanoDenseMedium,guided>") : "k_render_wave<NanoDenseMedium>";
     if (grid) return guided ? (train ? "k_render_wave<GridMedium,guided,train>" : "k_render_wave<GridMedium,guided>")
                             : (r->medium_grey ? "k_render_wave<GridMediumGrey>" : "k_render_wave<GridMedium>");
+    if (guided && guided_grey_simple(r)) return train ? "k_render_wave<HomogeneousMediumT<2,true>,guided,train>" : "k_render_wave<HomogeneousMediumT<2,true>,guided>";
     return guided ? (train ? "k_render_wave<HomogeneousMedium,guided,train>" : "k_render_wave<HomogeneousMedium,guided>") : "k_render_wave<HomogeneousMedium>";
 }
 
@@ -2362,6 +2369,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);
     else if (grid && r->medium_grey) VSPG_LAUNCH_RENDER(GridMediumGrey, false);
     else if (grid) VSPG_LAUNCH_RENDER(GridMedium, false);
+    else if (guided && guided_grey_simple(r)) VSPG_LAUNCH_RENDER(HomogeneousMediumGreySceneNullZero, true);
     else if (guided) VSPG_LAUNCH_RENDER(HomogeneousMedium, true);
     else VSPG_LAUNCH_RENDER(HomogeneousMedium, false);
 #undef VSPG_LAUNCH_RENDER
