@@ -1427,13 +1427,29 @@ static float light_pdf_li(const rquad_t *q, const lsctx_t *ctx, v3 wi) {
 /* ------------------------------------------------------------------------------------ */
 #define GK VSPG_FIELD_LOBES
 #define TWO_PI_F 6.28318530717958647692f
+/* Round 3: the arithmetic behind the OpenPGL calls was re-laid for the device (own design, still PARITY UNPINNED; the wrapper
+ * logic above it -- guiding.h's MIS / RIS flows -- is untouched).  Same model as before -- parallax-re-aimed vMF lobes, closed-form
+ * product with one vMF, responsibility-weighted VSP -- with the evaluation organised so that a lobe costs 3 IEEE divisions
+ * and 2 square roots at Init (was 8 and 2) and keeps 7 floats of state (was 9):
+ *   raw_k      the region's lobe k re-aimed at the query point (normalised with ONE reciprocal),
+ *   b_k        weight_k * vmf_norm(kappa_k)                  (per region, cached per field update: DField::aux on the device)
+ *   product with (m2, k2):  s = raw_k kappa_k + m2 k2,  kp = |s|,  kc = clamp(kp),
+ *   a_k        (b_k * vmf_norm(k2)) * FastExp((kp - kappa_k) - k2)        the product lobe's density weight, un-normalised
+ *   wo_k       a_k * ((2 pi (1 - FastExp(-2 kc))) / kc)                     its mass (= a_k / vmf_norm(kc)),  sum = SUM wo_k
+ *   c1_k, c2_k kappa_k / kp, k2 / kp:   mu_k . w == c1_k (raw_k . w) + c2_k (m2 . w)   -- the product's mean is never formed
+ *   PDF(w)     = (SUM_k a_k FastExp(kc_k (mu_k . w - 1))) * (1 / sum)
+ *   IncomingRadiancePDF(w) = SUM_k b_k FastExp(kappa_k (raw_k . w - 1));   VolumeScatterProbability(w) = SUM e_k vsp_k / SUM e_k
+ * with e_k the terms of the IncomingRadiancePDF sum (so its denominator IS that PDF).  Without a product lobe (isotropic
+ * phase function) a_k = b_k, wo_k = weight_k, c1 = 1, c2 = 0. */
 typedef struct {
     int ok;            /* Init() succeeded */
     int field, region; /* which field / leaf */
     v3 p;              /* query position (parallax) */
-    int n;             /* lobes of the PRODUCT mixture */
-    float w[GK], kappa[GK];
-    v3 mu[GK];
+    int n;             /* lobes */
+    v3 m2;             /* the product lobe's axis (unused when c2 == 0) */
+    float isum;        /* 1 / SUM wo */
+    v3 raw[GK];
+    float a[GK], kc[GK], c1[GK], c2[GK], wn[GK]; /* wn = wo * isum: the normalised masses (lobe selection) */
 } gdist_t;
 
 static float vmf_norm(float kappa) { /* kappa / (2 pi (1 - e^{-2 kappa})) */
@@ -1465,45 +1481,48 @@ static v3 lobe_dir(const VspgFieldRegion *R, int k, v3 p) {
     v3 t = v_sub(src, p);
     float l2 = v_len2(t);
     if (!(l2 > 0)) return mu;
-    return v_normalize(t);
+    float inv = 1.0f / sqrtf(l2);
+    return v_scale(t, inv);
 }
-/* product of lobe (mu,kappa,w) with a vMF (m2,k2): closed form (App. E.2) */
-static void lobe_product(v3 mu, float kappa, float w, v3 m2, float k2, v3 *mo, float *ko, float *wo) {
-    v3 s = v_add(v_scale(mu, kappa), v_scale(m2, k2));
-    float kp = v_len(s);
-    if (!(kp > 1e-6f)) { /* lobes cancel: nearly uniform */
-        *mo = mu; *ko = 1e-2f; *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(1e-2f)) * oracle_fast_exp(1e-2f - kappa - k2);
-        return;
-    }
-    float kc = kappa_clamp(kp);
-    *mo = V3(s.x / kp, s.y / kp, s.z / kp);
-    *ko = kc;
-    *wo = w * (vmf_norm(kappa) * vmf_norm(k2) / vmf_norm(kc)) * oracle_fast_exp(kp - kappa - k2);
-}
+static float lobe_b(const VspgFieldRegion *R, int k) { return R->weight[k] * vmf_norm(kappa_clamp(R->kappa[k])); }
 /* {Surface,Volume}SamplingDistribution::Init + Apply*Product */
 static gdist_t gdist_init(const OracleRenderer *r, int f, v3 p, int have_product, v3 m2, float k2) {
     gdist_t d;
     memset(&d, 0, sizeof d);
-    d.field = f; d.p = p;
+    d.field = f; d.p = p; d.m2 = m2;
     d.region = field_lookup(r, f, p);
     if (d.region < 0) return d;
     const VspgFieldRegion *R = &r->field[f].regions[d.region];
     if (R->n_lobes <= 0) return d;
     d.ok = 1;
     d.n = R->n_lobes < GK ? R->n_lobes : GK;
+    const float nk2 = have_product ? vmf_norm(k2) : 0.f;
+    float wo[GK];
     float sum = 0;
     for (int k = 0; k < d.n; ++k) {
-        v3 mu = lobe_dir(R, k, p);
-        float kap = kappa_clamp(R->kappa[k]);
-        if (have_product) lobe_product(mu, kap, R->weight[k], m2, k2, &d.mu[k], &d.kappa[k], &d.w[k]);
-        else { d.mu[k] = mu; d.kappa[k] = kap; d.w[k] = R->weight[k]; }
-        sum += d.w[k];
+        d.raw[k] = lobe_dir(R, k, p);
+        const float kr = kappa_clamp(R->kappa[k]), b = lobe_b(R, k);
+        if (have_product) {
+            v3 s = v_add(v_scale(d.raw[k], kr), v_scale(m2, k2));
+            float kp = sqrtf(v_len2(s));
+            float kpinv = kp > 1e-6f ? 1.0f / kp : 0.f; /* lobes cancel: c1 = c2 = 0, i.e. mu . w := 0 under kc = 0.01 -- nearly uniform */
+            float kc = kappa_clamp(kp);
+            float E = oracle_fast_exp(-2 * kc);
+            d.a[k] = (b * nk2) * oracle_fast_exp((kp - kr) - k2);
+            wo[k] = d.a[k] * ((TWO_PI_F * (1 - E)) / kc);
+            d.kc[k] = kc; d.c1[k] = kr * kpinv; d.c2[k] = k2 * kpinv;
+        } else {
+            d.a[k] = b; wo[k] = R->weight[k]; d.kc[k] = kr; d.c1[k] = 1.f; d.c2[k] = 0.f;
+        }
+        sum += wo[k];
     }
     if (sum > 0 && !isinf(sum)) {
-        for (int k = 0; k < d.n; ++k) d.w[k] = d.w[k] / sum;
+        d.isum = 1.0f / sum;
     } else { /* degenerate product: fall back to the incident-radiance mixture */
-        for (int k = 0; k < d.n; ++k) { d.mu[k] = lobe_dir(R, k, p); d.kappa[k] = kappa_clamp(R->kappa[k]); d.w[k] = R->weight[k]; }
+        d.isum = 1.f;
+        for (int k = 0; k < d.n; ++k) { d.a[k] = lobe_b(R, k); wo[k] = R->weight[k]; d.kc[k] = kappa_clamp(R->kappa[k]); d.c1[k] = 1.f; d.c2[k] = 0.f; }
     }
+    for (int k = 0; k < d.n; ++k) d.wn[k] = wo[k] * d.isum;
     return d;
 }
 #define COSINE_LOBE_KAPPA 2.18853f /* vMF fit of the clamped cosine (App. E.2) */
@@ -1520,15 +1539,19 @@ static gdist_t gdist_init_volume(const OracleRenderer *r, v3 p, v3 dir, float g)
     return gdist_init(r, 1, p, 1, v_normalize(axis), kg);
 }
 static float gdist_pdf(const gdist_t *d, v3 w) {
+    const float x2 = v_dot(d->m2, w);
     float s = 0;
-    for (int k = 0; k < d->n; ++k) s += d->w[k] * vmf_eval(d->mu[k], d->kappa[k], w);
-    return s;
+    for (int k = 0; k < d->n; ++k) {
+        const float dp = d->c1[k] * v_dot(d->raw[k], w) + d->c2[k] * x2;
+        s += d->a[k] * oracle_fast_exp(d->kc[k] * (dp - 1));
+    }
+    return s * d->isum;
 }
 /* incident-radiance mixture (before the product) */
 static float gdist_incoming_pdf(const OracleRenderer *r, const gdist_t *d, v3 w) {
     const VspgFieldRegion *R = &r->field[d->field].regions[d->region];
     float s = 0;
-    for (int k = 0; k < d->n; ++k) s += R->weight[k] * vmf_eval(lobe_dir(R, k, d->p), kappa_clamp(R->kappa[k]), w);
+    for (int k = 0; k < d->n; ++k) s += lobe_b(R, k) * oracle_fast_exp(kappa_clamp(R->kappa[k]) * (v_dot(d->raw[k], w) - 1));
     return s;
 }
 /* VolumeScatterProbability(wi): responsibility-weighted per-lobe estimate */
@@ -1537,7 +1560,7 @@ static float gdist_vsp(const OracleRenderer *r, int f, int region, v3 p, v3 w) {
     int n = R->n_lobes < GK ? R->n_lobes : GK;
     float num = 0, den = 0;
     for (int k = 0; k < n; ++k) {
-        float e = R->weight[k] * vmf_eval(lobe_dir(R, k, p), kappa_clamp(R->kappa[k]), w);
+        float e = lobe_b(R, k) * oracle_fast_exp(kappa_clamp(R->kappa[k]) * (v_dot(lobe_dir(R, k, p), w) - 1));
         num += e * R->vsp[k];
         den += e;
     }
@@ -1546,22 +1569,23 @@ static float gdist_vsp(const OracleRenderer *r, int f, int region, v3 p, v3 w) {
 }
 /* SamplePDF(u2, &wi) */
 static float gdist_sample(const gdist_t *d, float u0, float u1, v3 *wi) {
-    /* lobe selection by CDF walk over the weights, u0 rescaled inside the chosen lobe */
+    /* lobe selection by CDF walk over the normalised masses, u0 rescaled inside the chosen lobe */
     int k = 0;
     float acc = 0;
     for (; k < d->n - 1; ++k) {
-        if (u0 < acc + d->w[k]) break;
-        acc += d->w[k];
+        if (u0 < acc + d->wn[k]) break;
+        acc += d->wn[k];
     }
-    float uw = d->w[k] > 0 ? (u0 - acc) / d->w[k] : 0.f;
+    float uw = d->wn[k] > 0 ? (u0 - acc) / d->wn[k] : 0.f;
     uw = uw < 0 ? 0 : (uw > ONE_MINUS_EPS ? ONE_MINUS_EPS : uw);
-    float kap = d->kappa[k];
+    float kap = d->kc[k];
     float W = 1 + logf(uw + (1 - uw) * oracle_fast_exp(-2 * kap)) / kap;
     W = clampf(W, -1, 1);
     float sinT = safe_sqrt(1 - W * W);
     float phi = TWO_PI_F * u1;
     frame_t fr;
-    fr.z = d->mu[k];
+    /* the product lobe's mean, (raw kappa + m2 k2) / kp; the bare lobe where there is no product or the two cancel */
+    fr.z = d->c1[k] == 0.f && d->c2[k] == 0.f ? d->raw[k] : v_add(v_scale(d->raw[k], d->c1[k]), v_scale(d->m2, d->c2[k]));
     coordinate_system(fr.z, &fr.x, &fr.y);
     *wi = frame_from_local(&fr, V3(sinT * cosf(phi), sinT * sinf(phi), W));
     return gdist_pdf(d, *wi);

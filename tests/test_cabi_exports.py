@@ -36,8 +36,9 @@ def test_rccl_library_exports_every_declared_symbol(pkg):
     lib = C.CDLL(os.path.join(csrc, "libvspg_rccl.so"))
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vspg_rccl.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(vspg_rccl_[a-z0-9_]+)\s*\(", src)))
-    assert names == ["vspg_rccl_allreduce_film", "vspg_rccl_destroy", "vspg_rccl_enable_training_exchange", "vspg_rccl_init_from_env",
-                     "vspg_rccl_post_process_step", "vspg_rccl_sum_counters"]
+    assert names == ["vspg_rccl_allreduce_film", "vspg_rccl_destroy", "vspg_rccl_enable_training_exchange", "vspg_rccl_forget",
+                     "vspg_rccl_init_from_env", "vspg_rccl_post_process_step", "vspg_rccl_post_process_step_n", "vspg_rccl_ranks_seen",
+                     "vspg_rccl_sum_counters"]
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
     assert lib.vspg_rccl_post_process_step(None, 2, None, None) == pkg.VSPG_EINVAL   # argument check only

@@ -1418,6 +1418,43 @@ def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c3.view(np.uint32))
 
 
+@pytest.mark.parametrize("g,stype,vtype,sg,vg,maxdepth", [(0.0, 1, 0, 1, 1, 5),   # isotropic phase function: no product lobe at volume vertices
+                                                          (0.4, 0, 1, 1, 1, 5),   # surfaces MIS, volumes RIS
+                                                          (-0.6, 1, 1, 1, 1, 8),  # both RIS, backward scattering, deeper paths
+                                                          (0.4, 1, 0, 0, 0, 5),   # secondary-ray VSP only: the field is asked for nothing else
+                                                          (0.0, 0, 0, 1, 0, 5)])  # surfaces guided (MIS), volumes not
+def test_guided_workgroup_vertex_flavours_equal_per_lane_kernel(gpu_pkg, g, stype, vtype, sg, vg, maxdepth):
+    """The workgroup kernel's guided vertex (vspg_guided_wg.h: the mixture built once, every sum that does not depend on its own
+    sample taken in that pass, the NEE's shadow ray after it) against the per-lane kernel's straight flow, over the flavours
+    the reference's options select: films bit for bit."""
+    import scenes
+    P = gpu_pkg
+    W, H = 192, 128
+    scene = P.fog_box_scene(W, H)
+    scene.medium.g = g
+    prm = P.default_params()
+    prm.surfaceguidingtype, prm.volumeguidingtype = stype, vtype
+    prm.surfaceguiding, prm.volumeguiding, prm.maxdepth = sg, vg, maxdepth
+    field = scenes.light_field(P, n=4)
+    films = []
+    for kernel in ("wg", "lane"):
+        os.environ["VSPG_KERNEL"] = kernel
+        os.environ["VSPG_NO_GREY_GUIDED"] = "1"
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=11)
+            r.set_guiding_field(field, field)
+            for w in range(3):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            assert ("_wg" in r.kernel_name()) == (kernel == "wg"), r.kernel_name()
+            films.append(r.film())
+            assert r.counters()["paths"] == 3 * W * H
+            r.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+            os.environ.pop("VSPG_NO_GREY_GUIDED", None)
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))
+
+
 @pytest.mark.parametrize("stype,vtype", [(1, 0), (0, 1)])  # (ris, mis) = reference defaults; (mis, ris)
 def test_guided_paths_and_film_vs_oracle(gpu_pkg, stype, vtype):
     import scenes

@@ -331,3 +331,99 @@ def test_sharded_cpp_render_world_one_equals_unsharded(host_build, gpu_pkg, tmp_
     assert r2.returncode == 0, r2.stdout + r2.stderr
     assert "ranks 1: paths %d" % (64 * 48 * 6) in r2.stdout
     assert np.array_equal(read_pfm(str(a)).view(np.uint32), read_pfm(str(b)).view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def rehearse_build(host_build):
+    """vspg_pbrt_sharded linked against the one-card rehearsal transport (tests/rehearse/, test infrastructure) instead of
+    libvspg_rccl.so: same rendezvous, same stepping code (csrc/vspg_rendezvous.h, csrc/vspg_rccl_steps.h), host shared
+    memory where RCCL would be -- RCCL refuses two ranks on one device."""
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    csrc = os.path.join(ROOT, "vspg-pbrt-v4_amd", "csrc")
+    lib = os.path.join(out, "libvspg_rccl_rehearse.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-Wall", "-x", "hip", "--offload-arch=gfx950", "-shared", "-o", lib,
+                           os.path.join(ROOT, "tests", "rehearse", "vspg_rccl_rehearse.cpp"), "-L" + csrc, "-lvspg_hip", "-lrt",
+                           "-Wl,-rpath," + csrc])
+    exe = os.path.join(out, "vspg_pbrt_sharded_rehearse")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(host_build, "vspg_pbrt_sharded_main.cpp"),
+                           "-L" + host_build, "-lvspg_host", "-L" + csrc, "-lvspg_hip", "-L" + out, "-lvspg_rccl_rehearse",
+                           "-Wl,-rpath," + host_build, "-Wl,-rpath," + csrc, "-Wl,-rpath," + out, "-Wl,-rpath-link,/opt/rocm/lib"])
+    return exe
+
+
+def _run_ranks(exe, scene, out, spp, world, port, extra_env=None):
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([exe, scene, "--outfile", out, "--spp", str(spp)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hung (rendezvous / collective)")
+        outs.append(o)
+        assert p.returncode == 0, o
+    return outs
+
+
+@pytest.mark.gpu
+def test_sharded_cpp_render_two_ranks_on_one_card(rehearse_build, gpu_pkg, tmp_path):
+    """The all-C++ multi-GPU host with TWO ranks (both on the one card, collectives through the rehearsal transport): the
+    rendezvous survives a stale id file of a dead earlier run AND two runs back to back on the same port; the frame -- an odd
+    sample count, so the last step is ragged (one rank renders nothing, the wave counter advances by 1) -- equals two
+    renderers stepped by hand through the C-ABI with the statistics summed where the buffer updates, bit for bit."""
+    import glob
+    import torch
+    P = gpu_pkg
+    scene = os.path.join(SCENES, "fog_box.pbrt")
+    W, H, spp, world, port = 64, 48, 5, 2, 29653
+    # what a run that died before its clean-up leaves behind: a record under this launcher's name that is NOT this run's
+    # (old magic), and a syntactically valid one for another rank count
+    nonce = "ppid%d" % os.getpid()
+    stale = "/tmp/vspg_rccl_id.%d.%s" % (port, nonce)
+    with open(stale, "wb") as f:
+        f.write(b"\x01" * 160)
+    a, b = tmp_path / "run1.pfm", tmp_path / "run2.pfm"
+    o1 = _run_ranks(rehearse_build, scene, str(a), spp, world, port)
+    assert not os.path.exists(stale), "rank 0 must retire the record after the collective join"
+    o2 = _run_ranks(rehearse_build, scene, str(b), spp, world, port)      # same port, same launcher, straight after
+    assert not glob.glob("/tmp/vspg_rccl_id.%d.*" % port)
+    assert any("ranks 2: paths %d" % (W * H * spp) in o for o in o1 + o2), o1
+    f1, f2 = read_pfm(str(a)), read_pfm(str(b))
+    assert np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+
+    # the same frame by hand: two shards in this process
+    sd = P.fog_box_scene(W, H)
+    prm = P.app_f_params()
+    g = [P.Renderer(sd, prm, W, H, shard_index=i, shard_count=world) for i in range(world)]
+
+    def dev_stats(r):
+        ptr, n = r.isg_stats_ptr()
+
+        class Dev:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(Dev(), device="cuda:0")
+
+    for step in range((spp + world - 1) // world):
+        w0, w1 = step * world, min((step + 1) * world, spp)
+        for r in g:
+            r.render_wave(w0, w1)
+        due = g[0].isg_update_due(w1 - w0)
+        tot = None
+        if due:
+            torch.cuda.synchronize()
+            tot = dev_stats(g[0]) + dev_stats(g[1])
+        for r in g:
+            r.post_process_step(w1 - w0, tot.data_ptr() if due else None)
+        torch.cuda.synchronize()
+    film = g[0].film() + g[1].film()
+    assert np.all(film[..., 3] == spp)
+    ref = (film[..., :3] / film[..., 3:4]).astype(np.float32)
+    assert np.array_equal(f1.view(np.uint32), ref.view(np.uint32))
+    for r in g:
+        r.close()

@@ -16,6 +16,7 @@
 
 #include "vspg_path.h"
 #include "vspg_wg_kernel.h"
+#include "vspg_guided_wg.h"
 #include "vspg_wavefront.h"
 
 using namespace vspg;
@@ -241,15 +242,22 @@ __global__ __launch_bounds__(kBlock) void k_propagate(TrainArgs train, int max_s
         if (base + j < train.capacity) train.samples[base + j] = sink.stage[j];
 }
 
-// DField::aux of regions [0, n_regions): the per-lobe constants every mixture evaluation needs
+// DField::aux / DField::lobes of regions [0, n_regions): the per-lobe constants every mixture evaluation needs, and the
+// region records re-laid as arrays of lobes (vspg_guided_wg.h)
 __global__ __launch_bounds__(kBlock) void k_field_aux(const DScene *__restrict__ Sp, int f, const VspgFieldRegion *__restrict__ regs,
-                                                      float *__restrict__ aux) {
+                                                      float *__restrict__ aux, float4 *__restrict__ lobes) {
     const int n = Sp->field[f].n_regions * GK;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const int r = i / GK, k = i - r * GK;
-        const float kc = kappa_clamp(regs[r].kappa[k]);
-        aux[(size_t)r * (2 * GK) + k] = vmf_norm(kc);
+        const VspgFieldRegion &R = regs[r];
+        const float kc = kappa_clamp(R.kappa[k]);
+        const float b = R.weight[k] * vmf_norm(kc);  // b_k (vspg_guiding.h)
+        aux[(size_t)r * (2 * GK) + k] = b;
         aux[(size_t)r * (2 * GK) + GK + k] = kc;
+        float4 *L = lobes + (size_t)r * kRegionLobeQuads;
+        if (k == 0) L[0] = make_float4(R.pivot[0], R.pivot[1], R.pivot[2], __builtin_bit_cast(float, (int)R.n_lobes));
+        L[1 + 2 * k] = make_float4(R.mu[0][k], R.mu[1][k], R.mu[2][k], R.distance[k]);
+        L[2 + 2 * k] = make_float4(R.weight[k], b, kc, R.vsp[k]);
     }
 }
 
@@ -633,7 +641,13 @@ constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 384;
 #ifndef VSPG_WG_POOLG
 #define VSPG_WG_POOLG 0
 #endif
-constexpr int kWgWavesGuided = 2, kWgBlockGuided = 256, kWgPoolGuided = VSPG_WGG_NP;  // guided vertices: ~250 registers, 40-dword records
+#ifndef VSPG_WGG_WAVES
+#define VSPG_WGG_WAVES 2
+#endif
+#ifndef VSPG_WGG_BLOCK
+#define VSPG_WGG_BLOCK 256
+#endif
+constexpr int kWgWavesGuided = VSPG_WGG_WAVES, kWgBlockGuided = VSPG_WGG_BLOCK, kWgPoolGuided = VSPG_WGG_NP;  // guided vertices: 40-dword records
 constexpr bool kWgPoolGlobalHomog = VSPG_WG_POOLG != 0, kWgPoolGlobalGuided = VSPG_WGG_POOLG != 0;
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
@@ -969,6 +983,253 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     if (threadIdx.x < CNT_COUNT) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_counters[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_render_wave_wg2 (round 3): the same pool / phase design with the scheduler's serial pieces taken out.
+//   * work assignment is STATIC and INTERLEAVED: workgroup b owns the pixel tiles b, b + G, b + 2G, ... (G = grid size), so
+//     every workgroup samples the whole image (no systematic difference in path length between workgroups) and a fresh
+//     chunk's work items are pure index arithmetic -- no global work head, no assignment phase, no s_item array;
+//   * a finished path of a one-sample-per-pixel launch stores {L, ISG code} into a per-launch SAMPLE BUFFER with one 16-byte
+//     fire-and-forget store; k_film_resolve adds the buffer to the film and the ISG statistics afterwards (a streaming
+//     kernel, ~0.04 ms at 1080p).  The film flush of k_render_wave_wg -- a read-modify-write whose load latency sat between
+//     two workgroup barriers of every iteration -- is gone, and with it the third barrier: [segment] barrier [vertex] barrier.
+//     Per pixel and channel it is still the one IEEE addition `film += L` of RGBFilm::AddSample: same bits.
+//   Measured (profiles/r03_*): per-section wave timers of k_render_wave_wg showed 28 % of the wave cycles in the three
+//   barriers and ~20 % in assignment / flush; the SIMDs issued 44 % of the time (scripts/microbench/issue.hip prices).
+// Multi-sample launches keep the no-return atomics at the point where a path ends (several samples of a pixel per launch).
+enum { D_NFREE = 0, D_A0 = 2, D_A1 = 4, D_CURA = 6, D_BV = 8, D_BS = 10, D_CURB = 12, D_LNEXT = 14, D_COUNT = 15 };
+// ISG code of a finished sample, one float: 0 = no ISG record, +q = volume event, -q = surface event, q = the VSP the primary
+// segment used (or 0.5): q lies in [0.001, 0.999], so the sign is free and nothing is rounded
+VDEV float isg_code(const IsgSample &isg) {
+    if (!isg.valid) return 0.f;
+    const float q = isg.vsp_used >= 0.f ? isg.vsp_used : 0.5f;
+    return isg.surface_event ? -q : q;
+}
+template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd>
+__global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
+    const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
+    int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int tiles_magic,
+    float4 *__restrict__ wave_samples, unsigned long long *__restrict__ counters) {
+    const DScene &S = *Sp;
+    const int W = S.xres, H = S.yres;
+    const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
+    const unsigned n_tiles = (unsigned)(tilesX * tilesY);
+    const int lane = threadIdx.x & 63;
+    const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
+    // this workgroup's items: local item j = pixel (j & 63) of tile (j >> 6) * gridDim.x + blockIdx.x
+    const unsigned local_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+    const unsigned local_total = local_tiles * 64u;
+
+    constexpr int NF = GUIDED ? (int)PF_COUNT_GUIDED : (int)PF_GS;
+    __shared__ float s_pool[NF * NP];
+    __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
+    __shared__ unsigned int s_cnt[D_COUNT + 1];
+    const Pool P{s_pool, NP};
+    static_assert(Medium::kSingleSegment, "k_render_wave_wg2 serves homogeneous media (grid media: the wavefront pipeline)");
+    const Medium medium = MediumMaker<Medium>::make(S, nullptr);
+    float *glds = nullptr;
+    if constexpr (GUIDED) {  // the upper levels of the two kd-trees (north star: "LDS-staged kd-tree nodes")
+        __shared__ VspgKdNode s_kd[2][kKdLdsNodes];
+        for (int f = 0; f < 2; ++f) {
+            const int nl = S.field[f].n_nodes < kKdLdsNodes ? S.field[f].n_nodes : kKdLdsNodes;
+            for (int i = threadIdx.x; i < nl; i += kWgBlock) s_kd[f][i] = S.field[f].nodes[i];
+        }
+        glds = reinterpret_cast<float *>(&s_kd[0][0]);
+    }
+    __shared__ unsigned int s_counters[CNT_COUNT];
+    struct LaneCounters : PathCounters { uint32_t paths; VDEV void path() { paths++; } } pc;
+    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = pc.paths = 0;
+
+    stage_scene_lds(S);
+    if (threadIdx.x < CNT_COUNT) s_counters[threadIdx.x] = 0;
+    if (threadIdx.x <= D_COUNT) s_cnt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < NP; i += kWgBlock) s_free[0][i] = (unsigned short)i;
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt[D_NFREE] = NP;
+    __syncthreads();
+
+    // a path ends: its sample leaves the kernel
+    auto emit = [&](int pxy, Spec Lraw, const IsgSample &isg) {
+        const Spec L = finish_radiance(Lraw);
+        const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
+        if (single_sample) {
+            wave_samples[pidx] = make_float4(L.r, L.g, L.b, isg_code(isg));
+        } else {
+            film_add_sample(film + pidx, L);
+            isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
+        }
+    };
+
+    VSPG_PROF(PS_WG_TOTAL);
+    for (int k = 0;; ++k) {
+        const int par = k & 1, nxt = par ^ 1;
+        const unsigned nFree = s_cnt[D_NFREE + par], nA0 = s_cnt[D_A0 + par], nA1 = s_cnt[D_A1 + par], lnext = s_cnt[D_LNEXT];
+        const unsigned left = local_total - lnext;
+        const unsigned nFresh = nFree < left ? nFree : left;
+        const unsigned nPrim = nFresh + nA0, nA = nPrim + nA1;
+        if (nA == 0) break;  // nothing in flight and nothing left to start (free slots exist whenever nothing is in flight)
+        // the vertex-list counters of the PREVIOUS iteration (other parity) are free again: nobody reads them before the
+        // segment phase of the next iteration pushes into them, two barriers from here
+        if (threadIdx.x == 0) { s_cnt[D_BV + nxt] = 0; s_cnt[D_BS + nxt] = 0; s_cnt[D_CURB + nxt] = 0; }
+
+        // ---- S: camera ray + primary segment for new paths, one secondary segment for the others ------
+        while (true) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[D_CURA + par], 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= nA) break;
+            VSPG_PROF(PS_WG_A);
+            const unsigned i = base + (unsigned)lane;
+            bool toV = false, toS = false, restart = false, freed = false;
+            int slot = 0;
+            if (i < nA) {
+                Sampler sampler;
+                PathState st;
+                IsgSample isg;
+                int ch = 0, pxy = 0;
+                Vertex vx;
+                bool alive = false, valid = true;
+                if (i < nPrim) {
+                    int px, py, smp;
+                    if (i < nFresh) {
+                        slot = s_free[par][i];
+                        const unsigned item = lnext + i;
+                        const unsigned tile = (item >> 6) * gridDim.x + blockIdx.x, l = item & 63u;
+                        unsigned ty = tilesX == 1 ? tile : __umulhi(tile, tiles_magic);
+                        unsigned tx = tile - ty * (unsigned)tilesX;
+                        while (tx >= (unsigned)tilesX) { tx -= (unsigned)tilesX; ty++; }
+                        px = (int)(tx * 8u + (l & 7u));
+                        py = (int)(ty * 8u + (l >> 3));
+                        pxy = px | (py << 16);
+                        smp = first_sample;
+                        valid = tile < n_tiles;
+                    } else {
+                        slot = s_listA[par][i - nFresh];
+                        pxy = P.i(PF_PIXEL, slot);
+                        smp = P.i(PF_SAMPLE, slot);
+                        px = pxy & 0xffff;
+                        py = (int)((unsigned)pxy >> 16);
+                    }
+                    valid = valid && px < W && py < H && smp < wave_end;  // tile padding: the slot stays free
+                    if (valid) {
+                        if (single_sample)
+                            start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
+                        else
+                            start_path(S, vsp_buf, vsp_ready, px, py, smp, sampler, st, &ch, isg);
+                        P.i(PF_PIXEL, slot) = pxy;
+                        P.i(PF_SAMPLE, slot) = smp;
+                        alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
+                                                                          isg, pc, vx);
+                        if (alive) {
+                            pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
+                            pool_store_vertex<GUIDED>(P, slot, vx);
+                        }
+                    } else {
+                        freed = true;
+                    }
+                } else {
+                    slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
+                    const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
+                    pxy = P.i(PF_PIXEL, slot);
+                    const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
+                    alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
+                                                                        isg, pc, vx);
+                    if (alive) pool_store_a<Medium::kGrey, GUIDED>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                }
+                if (alive) {
+                    toV = vx.volume;
+                    toS = !vx.volume;
+                } else if (valid) {
+                    emit(pxy, st.L, isg);
+                    pc.path();
+                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
+                    P.i(PF_SAMPLE, slot) = s2;
+                    restart = s2 < wave_end;
+                    freed = !restart;
+                }
+            }
+            list_push(toV, slot, s_listB, &s_cnt[D_BV + par]);
+            list_push_back(toS, slot, s_listB + NP - 1, &s_cnt[D_BS + par]);
+            list_push(restart, slot, s_listA[nxt], &s_cnt[D_A0 + nxt]);
+            list_push(freed, slot, s_free[nxt], &s_cnt[D_NFREE + nxt]);
+        }
+        { VSPG_PROF(PS_WG_BAR_A); __syncthreads(); }
+        // the segment phase's inputs are consumed (every wave read the counts before it entered the phase)
+        if (threadIdx.x == 0) {
+            s_cnt[D_LNEXT] = lnext + nFresh;
+            s_cnt[D_NFREE + par] = 0; s_cnt[D_A0 + par] = 0; s_cnt[D_A1 + par] = 0; s_cnt[D_CURA + par] = 0;
+        }
+
+        // ---- V: vertex processing (NEE, Russian roulette, new direction) ----------------------------
+        const unsigned nBV = s_cnt[D_BV + par], nB = nBV + s_cnt[D_BS + par];
+        while (true) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[D_CURB + par], 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= nB) break;
+            VSPG_PROF(PS_WG_B);
+            const unsigned i = base + (unsigned)lane;
+            bool cont = false, restart = false, freed = false;
+            int slot = 0;
+            if (i < nB) {
+                slot = i < nBV ? s_listB[i] : s_listB[NP - 1 - (int)(i - nBV)];
+                Sampler sampler;
+                PathState st;
+                IsgSample isg;
+                int ch;
+                bool alive;
+                if constexpr (GUIDED) {  // the guided vertex works on the pool record directly (vspg_guided_wg.h)
+                    const uint32_t fl = P.u(PF_FLAGS, slot);
+                    alive = li_vertex_guided_wg<Medium>(S, medium, P, slot, fl, pc, reinterpret_cast<const VspgKdNode *>(glds), &st.L, &isg);
+                    if (!alive) {
+                        isg.valid = (fl & FL_ISG_VALID) != 0;
+                        isg.surface_event = (fl & FL_ISG_SURF) != 0;
+                        isg.vsp_used = P.f(PF_VSP, slot);  // (depth >= 1 at a vertex: the slot holds isg.vsp_used)
+                    }
+                } else {
+                    const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
+                    const Vertex vx = pool_load_vertex<GUIDED>(P, slot, fl);
+                    alive = li_segment_b<Medium, GUIDED, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock);
+                    if (alive) pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE);
+                }
+                if (alive) {
+                    cont = true;
+                } else {
+                    emit(P.i(PF_PIXEL, slot), st.L, isg);
+                    pc.path();
+                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
+                    P.i(PF_SAMPLE, slot) = s2;
+                    restart = s2 < wave_end;
+                    freed = !restart;
+                }
+            }
+            list_push_back(cont, slot, s_listA[nxt] + NP - 1, &s_cnt[D_A1 + nxt]);
+            list_push(restart, slot, s_listA[nxt], &s_cnt[D_A0 + nxt]);
+            list_push(freed, slot, s_free[nxt], &s_cnt[D_NFREE + nxt]);
+        }
+        { VSPG_PROF(PS_WG_BAR_B); __syncthreads(); }
+    }
+    atomicAdd(&s_counters[CNT_PATHS], pc.paths); atomicAdd(&s_counters[CNT_SEGMENTS], pc.segments);
+    atomicAdd(&s_counters[CNT_VOLUME_SCATTERS], pc.volume_scatters); atomicAdd(&s_counters[CNT_SURFACE_HITS], pc.surface_hits);
+    atomicAdd(&s_counters[CNT_DENSITY_QUERIES], pc.density_queries); atomicAdd(&s_counters[CNT_SHADOW_RAYS], pc.shadow_rays);
+    __syncthreads();
+    if (threadIdx.x < CNT_COUNT) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_counters[threadIdx.x]);
+}
+
+// film += the launch's sample buffer; ISG statistics likewise (the same read-modify-write forms the in-kernel flush used)
+__global__ __launch_bounds__(kBlock) void k_film_resolve(size_t npix, const float4 *__restrict__ wave_samples, float4 *__restrict__ film,
+                                                         float *__restrict__ isg_stats) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= npix) return;
+    const float4 s = wave_samples[i];
+    const Spec L = Spec{s.x, s.y, s.z};
+    film_add_sample_rmw(film + i, L);
+    IsgSample isg;
+    isg.valid = s.w != 0.f;
+    isg.surface_event = s.w < 0.f;
+    isg.vsp_used = __builtin_fabsf(s.w);
+    isg_add_sample_rmw(isg_stats + i * VSPG_ISG_STATS, L, isg);
+}
+
 template <class Medium, bool GUIDED>
 __global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict__ Sp, const float *__restrict__ vsp_buf,
                                                         int vsp_ready, int n, const int32_t *__restrict__ pixel_xy,
@@ -1220,6 +1481,7 @@ struct VspgRenderer {
     VspgKdNode *fnodes[2] = {nullptr, nullptr};        // guiding fields (device copies)
     VspgFieldRegion *fregions[2] = {nullptr, nullptr};
     float *faux[2] = {nullptr, nullptr};               // DField::aux
+    float4 *flobes[2] = {nullptr, nullptr};            // DField::lobes
     bool field_set = false;
     bool medium_grey = false;   // homogeneous medium with bitwise-grey sigma_a, sigma_s, Le
     bool surfaces_grey = false; // every rectangle's (clamped) Kd bitwise grey
@@ -1252,6 +1514,7 @@ struct VspgRenderer {
     // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
     float *wf_pool = nullptr;
     float *wg_gpool = nullptr;   // k_render_wave_wg<..., POOLG>: the workgroups' path pools in global memory
+    float4 *wave_samples = nullptr;  // k_render_wave_wg2: one {L, ISG code} per pixel of a one-sample launch (k_film_resolve adds it in)
     size_t wg_gpool_floats = 0;
     unsigned int *wf_lists = nullptr;   // 4 x n_items: active, vertex, walk, shadow
     WfIter *wf_iters = nullptr;
@@ -2069,7 +2332,9 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             CK(hipMemcpy(r->fnodes[f], &root, sizeof root, hipMemcpyHostToDevice));
             CK(hipMalloc(&r->faux[f], sizeof(float) * 2 * GK * kTrainCapRegions));
             CK(hipMemset(r->faux[f], 0, sizeof(float) * 2 * GK * kTrainCapRegions));
-            r->hscene.field[f] = DField{1, 1, r->fnodes[f], r->fregions[f], r->faux[f]};
+            CK(hipMalloc(&r->flobes[f], sizeof(float4) * kRegionLobeQuads * kTrainCapRegions));
+            CK(hipMemset(r->flobes[f], 0, sizeof(float4) * kRegionLobeQuads * kTrainCapRegions));
+            r->hscene.field[f] = DField{1, 1, r->fnodes[f], r->fregions[f], r->faux[f], r->flobes[f]};
         }
         CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
     }
@@ -2113,6 +2378,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
         if (r->fnodes[f]) (void)hipFree(r->fnodes[f]);
         if (r->fregions[f]) (void)hipFree(r->fregions[f]);
         if (r->faux[f]) (void)hipFree(r->faux[f]);
+        if (r->flobes[f]) (void)hipFree(r->flobes[f]);
     }
     for (int f = 0; f < 2; ++f)
         if (r->rstats[f]) (void)hipFree(r->rstats[f]);
@@ -2130,6 +2396,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->tris) (void)hipFree(r->tris);
     if (r->bvh) (void)hipFree(r->bvh);
     if (r->wg_gpool) (void)hipFree(r->wg_gpool);
+    if (r->wave_samples) (void)hipFree(r->wave_samples);
     if (r->wf_pool) (void)hipFree(r->wf_pool);
     if (r->wf_lists) (void)hipFree(r->wf_lists);
     if (r->wf_iters) (void)hipFree(r->wf_iters);
@@ -2334,6 +2601,29 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                 r->wg_gpool_floats = need;
             }
         }
+        // round 3: the two-barrier scheduler (k_render_wave_wg2) serves the homogeneous instantiations; VSPG_WG_SCHED=1 keeps
+        // the round-2 scheduler (three barriers, global work head, in-kernel film flush) for A/B runs and the tests that compare
+        const char *sched_env = getenv("VSPG_WG_SCHED");
+        const bool sched2 = !grid && !(sched_env && sched_env[0] == '1');
+        if (sched2) {
+            if (!r->wave_samples) HIPCHK(hipMalloc(&r->wave_samples, r->npix * sizeof(float4)));
+            const long long n_tiles = (long long)tilesX * tilesY;
+            if (wblocks > n_tiles) wblocks = n_tiles;
+#define VSPG_LAUNCH_WG2(M, G, NPOOL, BLK, WV)                                                                                         \
+    hipLaunchKernelGGL((k_render_wave_wg2<M, G, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,        \
+                       r->wave_samples, r->counters)
+            if (gwg) VSPG_LAUNCH_WG2(HomogeneousMediumSimple, true, kWgPoolGuided, kWgBlockGuided, kWgWavesGuided);
+            else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
+            else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGreyScene, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
+            else if (r->medium_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGrey, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
+            else VSPG_LAUNCH_WG2(HomogeneousMediumSimple, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
+#undef VSPG_LAUNCH_WG2
+            HIPCHK(hipGetLastError());
+            if (n_samples == 1)
+                hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((r->npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                                   r->npix, r->wave_samples, r->film, r->isg_stats);
+        } else
         if (gwg)
             hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, true, kWgPoolGuided, kWgBlockGuided, kWgWavesGuided, kWgPoolGlobalGuided>),
                                dim3((unsigned)wblocks), dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film,
@@ -2450,7 +2740,7 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
             if (int rc = xchg(r->train_acc, acc_floats)) return rc;
             hipLaunchKernelGGL(k_train_mstep, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->rstats[f],
                                r->fregions[f]);
-            hipLaunchKernelGGL(k_field_aux, dim3(rgrid * 2), dim3(kBlock), 0, s, r->dscene, f, r->fregions[f], r->faux[f]);
+            hipLaunchKernelGGL(k_field_aux, dim3(rgrid * 2), dim3(kBlock), 0, s, r->dscene, f, r->fregions[f], r->faux[f], r->flobes[f]);
         }
         HIPCHK(hipGetLastError());
         r->field_iteration++;
@@ -2707,7 +2997,8 @@ static int upload_field(VspgRenderer *r, int f, const VspgField *src, hipStream_
     if (r->fnodes[f]) { (void)hipFree(r->fnodes[f]); r->fnodes[f] = nullptr; }
     if (r->fregions[f]) { (void)hipFree(r->fregions[f]); r->fregions[f] = nullptr; }
     if (r->faux[f]) { (void)hipFree(r->faux[f]); r->faux[f] = nullptr; }
-    r->hscene.field[f] = DField{0, 0, nullptr, nullptr, nullptr};
+    if (r->flobes[f]) { (void)hipFree(r->flobes[f]); r->flobes[f] = nullptr; }
+    r->hscene.field[f] = DField{0, 0, nullptr, nullptr, nullptr, nullptr};
     if (!src || src->n_nodes <= 0 || src->n_regions <= 0) return 0;
     if (!src->nodes || !src->regions) return fail(VSPG_EINVAL, "guiding field without node / region arrays");
     for (int i = 0; i < src->n_nodes; ++i) {  // structural check: children after their parent, leaves in range
@@ -2723,7 +3014,8 @@ static int upload_field(VspgRenderer *r, int f, const VspgField *src, hipStream_
     HIPCHK(hipMemcpyAsync(r->fnodes[f], src->nodes, sizeof(VspgKdNode) * src->n_nodes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(r->fregions[f], src->regions, sizeof(VspgFieldRegion) * src->n_regions, hipMemcpyHostToDevice, s));
     HIPCHK(hipMalloc(&r->faux[f], sizeof(float) * 2 * GK * src->n_regions));
-    r->hscene.field[f] = DField{src->n_nodes, src->n_regions, r->fnodes[f], r->fregions[f], r->faux[f]};
+    HIPCHK(hipMalloc(&r->flobes[f], sizeof(float4) * kRegionLobeQuads * src->n_regions));
+    r->hscene.field[f] = DField{src->n_nodes, src->n_regions, r->fnodes[f], r->fregions[f], r->faux[f], r->flobes[f]};
     return 0;
 }
 
@@ -2742,7 +3034,7 @@ int vspg_renderer_set_guiding_field(VspgRenderer *r, const VspgField *surface_fi
     for (int f = 0; f < 2; ++f)
         if (r->faux[f])
             hipLaunchKernelGGL(k_field_aux, dim3((r->hscene.field[f].n_regions * GK + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene,
-                               f, r->fregions[f], r->faux[f]);
+                               f, r->fregions[f], r->faux[f], r->flobes[f]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     r->field_set = true;

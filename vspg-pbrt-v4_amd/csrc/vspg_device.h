@@ -460,10 +460,13 @@ struct DField {
     int32_t n_nodes, n_regions;
     const VspgKdNode *nodes;
     const VspgFieldRegion *regions;
-    // per region 2 x VSPG_FIELD_LOBES floats: vmf_norm(kappa_clamp(kappa[k])) then kappa_clamp(kappa[k]) -- functions of
+    // per region 2 x VSPG_FIELD_LOBES floats: b_k = weight[k] * vmf_norm(kappa_clamp(kappa[k])) then kappa_clamp(kappa[k]) -- functions of
     // the stored lobes only, evaluated once per field update by the same device code the queries would run
     // (k_field_aux) instead of once per lobe per mixture evaluation (an IEEE division and a FastExp each)
     const float *aux;
+    // per region 1 + 2 x VSPG_FIELD_LOBES float4: the same region as an array of lobes, for the workgroup kernel's guided vertex
+    // (vspg_guided_wg.h: region_lobes): {pivot, n_lobes}, then per lobe {mu, distance} {weight, b, kappa (clamped), vsp}
+    const float4 *lobes;
 };
 // Triangle geometry.  DTri: the three vertices plus what Triangle::InteractionFromIntersection
 // (shapes.h:883-1010) derives from them alone -- n = Normalize(Cross(p0 - p2, p1 - p2)) and the normalised dpdu of the

@@ -9,10 +9,10 @@
 //   ApplyCosineProduct(n)                 closed-form product with a kappa = 2.18853 vMF around n
 //   ApplySingleLobeHenyeyGreensteinProduct closed-form product with a vMF of mean cosine |g|
 //   PDF / SamplePDF / IncomingRadiancePDF / VolumeScatterProbability
-// Layout: kd nodes (8 B) and regions (240 B) in HBM, read through L2; the per-lane PRODUCT mixture
-// (5 floats x 8 lobes) lives in LDS for the lifetime of a vertex, strided by the workgroup size so
-// that lanes hit distinct banks.  Arithmetic uses +,-,*,/,sqrt, FastExp and the host-exact
-// logf/sinf/cosf only, in the same order as the CPU checker, so results are bit-identical.
+// Layout: kd nodes (8 B) and regions (240 B) in HBM, read through L2; the per-lane mixture (8 floats x 8 lobes) lives in LDS for
+// the lifetime of a vertex in the per-lane kernels, strided by the workgroup size so that lanes hit distinct banks, and in
+// registers in the workgroup kernel.  Arithmetic uses +,-,*,/,sqrt, FastExp and the host-exact logf/sinf/cosf only, in the
+// same order as the CPU checker, so results are bit-identical.
 #pragma once
 #include "vspg_device.h"
 
@@ -50,50 +50,32 @@ VDEV int field_lookup(const DField &F, V3 p, const VspgKdNode *lds = nullptr, in
 static_assert(sizeof(VspgFieldRegion) % 16 == 0 && offsetof(VspgFieldRegion, weight) % 16 == 0 && GK % 4 == 0, "16-byte rows");
 VDEV float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 VDEV float c4(float4 v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }  // j is a compile-time constant after unrolling
+// the region's lobe re-aimed at the query point; normalised with ONE reciprocal (round 3: was three IEEE divisions)
 VDEV V3 lobe_dir(V3 pivot, V3 mu, float d, V3 p) {
     if (!(d > 0) || isinf_(d)) return mu;
     V3 src = pivot + mu * d;
     V3 t = src - p;
     float l2 = len2(t);
     if (!(l2 > 0)) return mu;
-    return normalize(t);
-}
-// nk = vmf_norm(kappa), nk2 = vmf_norm(k2) (the caller has them); *no = vmf_norm(*ko)
-VDEV void lobe_product(V3 mu, float kappa, float nk, float w, V3 m2, float k2, float nk2, V3 *mo, float *ko, float *wo, float *no) {
-    V3 s = mu * kappa + m2 * k2;
-    float kp = len(s);
-    if (!(kp > 1e-6f)) {
-        *mo = mu;
-        *ko = 1e-2f;
-        *no = vmf_norm(1e-2f);
-        *wo = w * (nk * nk2 / *no) * fast_exp(1e-2f - kappa - k2);
-        return;
-    }
-    float kc = kappa_clamp(kp);
-    *mo = V3{s.x / kp, s.y / kp, s.z / kp};
-    *ko = kc;
-    *no = vmf_norm(kc);
-    *wo = w * (nk * nk2 / *no) * fast_exp(kp - kappa - k2);
+    const float inv = 1.0f / __builtin_sqrtf(l2);
+    return t * inv;
 }
 
-// Per-lane guiding scratch in LDS, element e of lobe k at lds[(e * GK + k) * stride]:
-//   e 0-4  the product mixture (weight, kappa, mean direction),  e 5  vmf_norm of the product kappa,
-//   e 6-8  the region's raw, parallax-re-aimed lobe directions at the query point.
-// Everything a later evaluation at the same point would otherwise recompute per lobe (a normalisation with three
-// IEEE divisions, a division + FastExp for the normalisation constant) is computed once in gdist_init and read back:
-// same operations on the same inputs, so the same bits.  The scratch of a lane stays valid until the lane's next
-// gdist_init -- in particular for the VolumeScatterProbability query of the NEXT segment (fetch_vsp).
-constexpr int kGFloats = 9 * GK;
+// ---- the mixture a vertex works with (round 3 layout; arithmetic: oracle/vspg_oracle.c "a14", the comment above gdist_t) ----
+// Per lobe k, 8 floats:  e 0-2 raw_k (the region's lobe re-aimed at the query point),  e 3 a_k (density weight of the product
+// lobe, un-normalised),  e 4 kc_k (its concentration),  e 5-6 c1_k, c2_k (mu_k . w == c1 (raw_k . w) + c2 (m2 . w): the product's
+// mean direction is never formed),  e 7 wn_k (normalised mass: lobe selection).  Per vertex: m2 and isum = 1 / SUM wo_k.
+// DField::aux holds, per region, b_k = weight_k * vmf_norm(kappa_k) and the clamped kappa_k (k_field_aux, once per field update).
+// Two homes for the per-lobe floats, same contents:
+//   GStoreLds  per-lane columns of s_gmix, element e of lobe k at lds[(e * GK + k) * stride] (the per-lane kernels: a path lives in
+//              a lane's registers for its whole life and has none to spare); a lane's column stays valid until its next gdist_init;
+//   GStoreReg  registers (every loop over lobes fully unrolled with `k < n` predicates: constant indices).
+constexpr int kGElems = 8;
+constexpr int kGFloats = kGElems * GK;
 constexpr int kGuideBlock = 256;  // threads per block of every kernel that keeps the guided scratch in LDS
 __shared__ float s_gmix[kGuideBlock * kGFloats];
 VDEV float *guide_lds() { return s_gmix + threadIdx.x; }
 VDEV const float *region_aux(const DField &F, int region) { return F.aux + (size_t)region * (2 * GK); }
-// Two homes for the scratch, same contents:
-//   GStoreLds  per-lane columns of s_gmix (the per-lane kernels: a path lives in a lane's registers for its whole life and
-//              has none to spare);
-//   GStoreReg  72 registers (the workgroup kernel's vertex phase: a path's registers exist only inside a phase, and the LDS
-//              belongs to the path pool).  Every loop over lobes is fully unrolled with `k < n` predicates, so all indices are
-//              compile-time constants and the array never leaves the register file.
 struct GStoreLds {
     float *lds;
     int stride;
@@ -109,32 +91,53 @@ template <class ST>
 struct GDistT {
     bool ok;
     int field, region, n;
-    V3 p;
+    V3 p, m2;
+    float isum;
     ST st;
-    VDEV float w(int k) const { return st.get(0, k); }
-    VDEV void set_w(int k, float v) { st.set(0, k, v); }
-    VDEV float kappa(int k) const { return st.get(1, k); }
-    VDEV void set_kappa(int k, float v) { st.set(1, k, v); }
-    VDEV V3 mu(int k) const { return V3{st.get(2, k), st.get(3, k), st.get(4, k)}; }
-    VDEV void set_mu(int k, V3 m) { st.set(2, k, m.x); st.set(3, k, m.y); st.set(4, k, m.z); }
-    VDEV float pnorm(int k) const { return st.get(5, k); }
-    VDEV void set_pnorm(int k, float v) { st.set(5, k, v); }
-    VDEV V3 raw(int k) const { return V3{st.get(6, k), st.get(7, k), st.get(8, k)}; }
-    VDEV void set_raw(int k, V3 m) { st.set(6, k, m.x); st.set(7, k, m.y); st.set(8, k, m.z); }
+    VDEV V3 raw(int k) const { return V3{st.get(0, k), st.get(1, k), st.get(2, k)}; }
+    VDEV void set_raw(int k, V3 m) { st.set(0, k, m.x); st.set(1, k, m.y); st.set(2, k, m.z); }
+    VDEV float a(int k) const { return st.get(3, k); }
+    VDEV float kc(int k) const { return st.get(4, k); }
+    VDEV float c1(int k) const { return st.get(5, k); }
+    VDEV float c2(int k) const { return st.get(6, k); }
+    VDEV float wn(int k) const { return st.get(7, k); }
+    VDEV void set_lobe(int k, float a_, float kc_, float c1_, float c2_, float wo_) {
+        st.set(3, k, a_); st.set(4, k, kc_); st.set(5, k, c1_); st.set(6, k, c2_); st.set(7, k, wo_);
+    }
+    VDEV void set_wn(int k, float v) { st.set(7, k, v); }
 };
 using GDist = GDistT<GStoreLds>;
 using GDistReg = GDistT<GStoreReg>;
 VDEV GStoreLds gstore_lds(float *lds, int stride) { return GStoreLds{lds, stride}; }
 
+// the product of one re-aimed lobe with the vMF (m2, k2): density weight a, mass wo, concentration kc, and the two
+// coefficients that stand for its mean direction (b = weight * vmf_norm(kr), nk2 = vmf_norm(k2))
+VDEV void lobe_product(V3 raw, float kr, float b, V3 m2, float k2, float nk2, float *a, float *wo, float *kc, float *c1, float *c2) {
+    const V3 s = raw * kr + m2 * k2;
+    const float kp = __builtin_sqrtf(len2(s));
+    const float kpinv = kp > 1e-6f ? 1.0f / kp : 0.f;  // the lobes cancel: mu . w := 0 under kc = 0.01, nearly uniform
+    *kc = kappa_clamp(kp);
+    const float E = fast_exp(-2 * *kc);
+    *a = (b * nk2) * fast_exp((kp - kr) - k2);
+    *wo = *a * ((kTwoPi * (1 - E)) / *kc);
+    *c1 = kr * kpinv;
+    *c2 = k2 * kpinv;
+}
+
 // fills `d` in place (d.st is set by the caller for the LDS home; the register home is never copied: a by-value copy of the
-// 72-float array would pin it in scratch memory)
-constexpr int kKdLdsNodes = 1024;  // nodes per field staged in LDS by the workgroup kernel (8 KB per field)
+// array would pin it in scratch memory)
+#ifndef VSPG_KD_LDS
+#define VSPG_KD_LDS 1024
+#endif
+constexpr int kKdLdsNodes = VSPG_KD_LDS;  // nodes per field staged in LDS by the workgroup kernel (8 B each)
 template <class ST>
 VDEV void gdist_init(GDistT<ST> &d, const DField *fields, int f, V3 p, bool have_product, V3 m2, float k2,
                      const VspgKdNode *kd_lds = nullptr) {
     d.ok = false;
     d.field = f;
     d.p = p;
+    d.m2 = m2;
+    d.isum = 1.f;
     d.n = 0;
     // f differs per lane when a wavefront holds volume and surface vertices: select between the two (scalar-loaded)
     // field records instead of indexing the array per lane
@@ -151,7 +154,7 @@ VDEV void gdist_init(GDistT<ST> &d, const DField *fields, int f, V3 p, bool have
     if (R.n_lobes <= 0) return;
     d.ok = true;
     d.n = R.n_lobes < GK ? R.n_lobes : GK;
-    const float *ax = region_aux(F, d.region);  // [k] vmf_norm(kappa_clamp(kappa[k])), [GK + k] kappa_clamp(kappa[k])
+    const float *ax = region_aux(F, d.region);  // [k] b_k = weight_k * vmf_norm(kappa_k), [GK + k] kappa_k (clamped)
     const float nk2 = have_product ? vmf_norm(k2) : 0.f;
     const V3 pivot = ld3(R.pivot);
     float sum = 0;
@@ -159,40 +162,32 @@ VDEV void gdist_init(GDistT<ST> &d, const DField *fields, int f, V3 p, bool have
     for (int h = 0; h < GK; h += 4) {
         if (h < d.n) {
             const float4 w4 = ld4(R.weight + h), mx4 = ld4(R.mu[0] + h), my4 = ld4(R.mu[1] + h), mz4 = ld4(R.mu[2] + h),
-                         d4 = ld4(R.distance + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+                         d4 = ld4(R.distance + h), b4 = ld4(ax + h), k4 = ld4(ax + GK + h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = h + j;
                 if (k < d.n) {
-                    V3 mu = lobe_dir(pivot, V3{c4(mx4, j), c4(my4, j), c4(mz4, j)}, c4(d4, j), p);
-                    d.set_raw(k, mu);
-                    float kap = c4(k4, j);
-                    V3 mo = mu;
-                    float ko = kap, wo = c4(w4, j), no = c4(n4, j);
-                    if (have_product) lobe_product(mu, kap, c4(n4, j), c4(w4, j), m2, k2, nk2, &mo, &ko, &wo, &no);
-                    d.set_mu(k, mo);
-                    d.set_kappa(k, ko);
-                    d.set_pnorm(k, no);
-                    d.set_w(k, wo);
+                    const V3 raw = lobe_dir(pivot, V3{c4(mx4, j), c4(my4, j), c4(mz4, j)}, c4(d4, j), p);
+                    d.set_raw(k, raw);
+                    float a = c4(b4, j), wo = c4(w4, j), kc = c4(k4, j), c1 = 1.f, c2 = 0.f;
+                    if (have_product) lobe_product(raw, c4(k4, j), c4(b4, j), m2, k2, nk2, &a, &wo, &kc, &c1, &c2);
+                    d.set_lobe(k, a, kc, c1, c2, wo);
                     sum += wo;
                 }
             }
         }
     }
     if (sum > 0 && !isinf_(sum)) {
+        d.isum = 1.0f / sum;
+    } else {  // degenerate product: fall back to the incident-radiance mixture
+        d.isum = 1.f;
 #pragma unroll
         for (int k = 0; k < GK; ++k)
-            if (k < d.n) d.set_w(k, d.w(k) / sum);
-    } else {
-#pragma unroll
-        for (int k = 0; k < GK; ++k)
-            if (k < d.n) {
-                d.set_mu(k, d.raw(k));
-                d.set_kappa(k, ax[GK + k]);
-                d.set_pnorm(k, ax[k]);
-                d.set_w(k, R.weight[k]);
-            }
+            if (k < d.n) d.set_lobe(k, ax[k], ax[GK + k], 1.f, 0.f, R.weight[k]);
     }
+#pragma unroll
+    for (int k = 0; k < GK; ++k)
+        if (k < d.n) d.set_wn(k, d.wn(k) * d.isum);
 }
 // The product lobe of GuidedPhaseFunction::init as data (so that one gdist_init call serves both vertex kinds)
 VDEV void volume_product_lobe(V3 dir, float g, bool *have_product, V3 *m2, float *k2) {
@@ -228,27 +223,30 @@ VDEV GDist gdist_init_volume(const DField *fields, V3 p, V3 dir, float g, float 
 }
 template <class ST>
 VDEV float gdist_pdf(const GDistT<ST> &d, V3 w) {
+    const float x2 = dot(d.m2, w);
     float s = 0;
 #pragma unroll
     for (int k = 0; k < GK; ++k)
-        if (k < d.n) s += d.w(k) * (d.pnorm(k) * fast_exp(d.kappa(k) * (dot(d.mu(k), w) - 1)));  // w * vmf_eval
-    return s;
+        if (k < d.n) {
+            const float dp = d.c1(k) * dot(d.raw(k), w) + d.c2(k) * x2;
+            s += d.a(k) * fast_exp(d.kc(k) * (dp - 1));
+        }
+    return s * d.isum;
 }
 template <class ST>
 VDEV float gdist_incoming_pdf(const DField *fields, const GDistT<ST> &d, V3 w) {
     DField F = fields[0];
     if (d.field) F = fields[1];
-    const VspgFieldRegion &R = F.regions[d.region];
     const float *ax = region_aux(F, d.region);
     float s = 0;
 #pragma unroll
     for (int h = 0; h < GK; h += 4) {
         if (h < d.n) {
-            const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+            const float4 b4 = ld4(ax + h), k4 = ld4(ax + GK + h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = h + j;
-                if (k < d.n) s += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(d.raw(k), w) - 1)));
+                if (k < d.n) s += c4(b4, j) * fast_exp(c4(k4, j) * (dot(d.raw(k), w) - 1));
             }
         }
     }
@@ -260,20 +258,19 @@ template <class ST>
 VDEV void gdist_incoming_pdf2(const DField *fields, const GDistT<ST> &d, bool want0, V3 w0, V3 w1, float *inc0, float *inc1) {
     DField F = fields[0];
     if (d.field) F = fields[1];
-    const VspgFieldRegion &R = F.regions[d.region];
     const float *ax = region_aux(F, d.region);
     float s0 = 0, s1 = 0;
 #pragma unroll
     for (int h = 0; h < GK; h += 4) {
         if (h < d.n) {
-            const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h);
+            const float4 b4 = ld4(ax + h), k4 = ld4(ax + GK + h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = h + j;
                 if (k < d.n) {
                     const V3 dir = d.raw(k);
-                    if (want0) s0 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w0) - 1)));
-                    s1 += c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(dir, w1) - 1)));
+                    if (want0) s0 += c4(b4, j) * fast_exp(c4(k4, j) * (dot(dir, w0) - 1));
+                    s1 += c4(b4, j) * fast_exp(c4(k4, j) * (dot(dir, w1) - 1));
                 }
             }
         }
@@ -293,12 +290,12 @@ VDEV float gdist_vsp(const DField *fields, int f, int region, const GDistT<ST> &
 #pragma unroll
     for (int h = 0; h < GK; h += 4) {
         if (h < n) {
-            const float4 w4 = ld4(R.weight + h), n4 = ld4(ax + h), k4 = ld4(ax + GK + h), v4 = ld4(R.vsp + h);
+            const float4 b4 = ld4(ax + h), k4 = ld4(ax + GK + h), v4 = ld4(R.vsp + h);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = h + j;
                 if (k < n) {
-                    float e = c4(w4, j) * (c4(n4, j) * fast_exp(c4(k4, j) * (dot(d.raw(k), w) - 1)));
+                    float e = c4(b4, j) * fast_exp(c4(k4, j) * (dot(d.raw(k), w) - 1));
                     num += e * c4(v4, j);
                     den += e;
                 }
@@ -308,33 +305,8 @@ VDEV float gdist_vsp(const DField *fields, int f, int region, const GDistT<ST> &
     if (!(den > 0)) return -1.f;
     return num / den;
 }
-template <class ST>
-VDEV float gdist_sample(const GDistT<ST> &d, float u0, float u1, V3 *wi) {
-    // the lobe: `for (k = 0; k < n - 1; ++k) { if (u0 < acc + w_k) break; acc += w_k; }` as a predicated scan (constant indices)
-    bool scanning = true;
-    int ks = 0;
-    float acc = 0;
-#pragma unroll
-    for (int j = 0; j < GK - 1; ++j) {
-        if (scanning && j < d.n - 1) {
-            const float wj = d.w(j);
-            if (u0 < acc + wj) {
-                scanning = false;
-            } else {
-                acc += wj;
-                ks = j + 1;
-            }
-        }
-    }
-    float wk = 0, kap = 0;
-    V3 mz = mk(0, 0, 1);
-#pragma unroll
-    for (int j = 0; j < GK; ++j)
-        if (j == ks) {
-            wk = d.w(j);
-            kap = d.kappa(j);
-            mz = d.mu(j);
-        }
+// the direction SamplePDF draws once the lobe is chosen: acc = the masses before it, wk its own
+VDEV V3 vmf_sample_dir(float u0, float u1, float acc, float wk, float kap, V3 mz) {
     float uw = wk > 0 ? (u0 - acc) / wk : 0.f;
     uw = uw < 0 ? 0 : (uw > kOneMinusEps ? kOneMinusEps : uw);
     float W = 1 + logf_(uw + (1 - uw) * fast_exp(-2 * kap)) / kap;
@@ -344,7 +316,40 @@ VDEV float gdist_sample(const GDistT<ST> &d, float u0, float u1, V3 *wi) {
     Frame fr;
     fr.z = mz;
     coordinate_system(fr.z, &fr.x, &fr.y);
-    *wi = fr.from_local(V3{sinT * cosf_(phi), sinT * sinf_(phi), W});
+    return fr.from_local(V3{sinT * cosf_(phi), sinT * sinf_(phi), W});
+}
+template <class ST>
+VDEV float gdist_sample(const GDistT<ST> &d, float u0, float u1, V3 *wi) {
+    // the lobe: `for (k = 0; k < n - 1; ++k) { if (u0 < acc + wn_k) break; acc += wn_k; }` as a predicated scan (constant indices)
+    bool scanning = true;
+    int ks = 0;
+    float acc = 0;
+#pragma unroll
+    for (int j = 0; j < GK - 1; ++j) {
+        if (scanning && j < d.n - 1) {
+            const float wj = d.wn(j);
+            if (u0 < acc + wj) {
+                scanning = false;
+            } else {
+                acc += wj;
+                ks = j + 1;
+            }
+        }
+    }
+    float wk = 0, kap = 0, c1 = 0, c2 = 0;
+    V3 raw = mk(0, 0, 1);
+#pragma unroll
+    for (int j = 0; j < GK; ++j)
+        if (j == ks) {
+            wk = d.wn(j);
+            kap = d.kc(j);
+            c1 = d.c1(j);
+            c2 = d.c2(j);
+            raw = d.raw(j);
+        }
+    // the product lobe's mean, (raw kappa + m2 k2) / kp; the bare lobe where there is no product or the two cancel
+    const V3 mz = c1 == 0.f && c2 == 0.f ? raw : raw * c1 + d.m2 * c2;
+    *wi = vmf_sample_dir(u0, u1, acc, wk, kap, mz);
     return gdist_pdf(d, *wi);
 }
 

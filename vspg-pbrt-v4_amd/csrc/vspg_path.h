@@ -244,49 +244,13 @@ VDEV Spec mul_tmaj_ratio(Spec v, Spec T_maj, int ch) {
     if (GREY >= 1 && tm > 0.f && tm < kInf) return v;
     return v * (T_maj / tm);
 }
-template <class Medium, class PC, class GD = GDist>
-VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, const Bsdf *bsdf, int ch,
-                    Sampler &sampler, Spec r_p, PC &pc, const GD *gd = nullptr, bool use_gd = false) {
-    // (use_gd separate from the pointer: a `cond ? &gd : nullptr` argument keeps a register-resident distribution in scratch)
-    V3 ctxp = intr.pi.mid();
-    if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
-    float u = sampler.get1d();
-    // UniformLightSampler::Sample (lightsamplers.h:33-38) over the emissive rectangles followed by the infinite lights
+// sample_Ld from the shadow ray on (:1190-1251): lightRay = intr.SpawnRayTo(ls->pLight), the ratio-tracked transmittance,
+// the estimate.  (Its own function since round 3: the workgroup kernel's guided vertex runs the two halves of sample_Ld at
+// different times, vspg_guided_wg.h.)
+template <class Medium, class PC>
+VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &intr, int ch, const LightLi &ls, Spec f_hat, float p_l,
+                           float scatterPDF, Spec r_p, PC &pc, bool delta_light = false) {
     constexpr bool kFull = !Medium::kSimpleScene;
-    const int n_all = kFull ? S.n_lights + S.n_inf : S.n_lights;
-    bool have_light = n_all > 0;
-    int lightIndex = 0;
-    float lightPmf = 0;
-    if (have_light) {
-        int li = (int)(u * (float)n_all);
-        lightIndex = li < n_all - 1 ? li : n_all - 1;
-        lightPmf = 1.f / (float)n_all;
-    }
-    float ul0 = sampler.get1d(), ul1 = sampler.get1d();
-    if (!have_light) return sp(0.f);
-    LightLi ls;
-    bool delta_light = false;
-    if (!sample_light<kFull>(S, lightIndex, ctxp, ul0, ul1, &ls, &delta_light)) return sp(0.f);
-    float p_l = lightPmf * ls.pdf;
-
-    float scatterPDF;
-    Spec f_hat;
-    V3 wo = intr.wo, wi = ls.wi;
-    // GuidedBSDF::PDF / GuidedPhaseFunction::PDF (guiding.h:271-289, 542-558); gd != nullptr iff useGuiding
-    if (intr.is_surface) {
-        f_hat = bsdf_f(*bsdf, wo, wi) * absdot(wi, intr.n);
-        float bsdfPDF = bsdf_pdf(*bsdf, wo, wi);
-        if (use_gd) bsdfPDF = ((1.0f - kGuidingProbability) * bsdfPDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
-        scatterPDF = 1.0f * bsdfPDF;
-    } else {
-        float p = henyey_greenstein(dot(wo, wi), intr.g);
-        f_hat = sp(p);
-        float phasePDF = p;
-        if (use_gd) phasePDF = ((1.0f - kGuidingProbability) * phasePDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
-        scatterPDF = 1.0f * phasePDF;
-    }
-    if (!nonzero(f_hat)) return sp(0.f);
-
     // lightRay = intr.SpawnRayTo(ls->pLight) (interaction.h:111-115, ray.h:103-108)
     V3 pf = offset_ray_origin(intr.pi, intr.n, ls.pLight.mid() - intr.pi.mid());
     V3 pt = offset_ray_origin(ls.pLight, ls.nLight, pf - ls.pLight.mid());
@@ -342,6 +306,52 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     r_u = r_u * (r_p * scatterPDF);
     if (kFull && delta_light) return f_hat * T_ray * ls.L / avg(r_l);  // IsDeltaLight (:1248-1249)
     return f_hat * T_ray * ls.L / avg(r_l + r_u);
+}
+
+template <class Medium, class PC, class GD = GDist>
+VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, const Bsdf *bsdf, int ch,
+                    Sampler &sampler, Spec r_p, PC &pc, const GD *gd = nullptr, bool use_gd = false) {
+    // (use_gd separate from the pointer: a `cond ? &gd : nullptr` argument keeps a register-resident distribution in scratch)
+    V3 ctxp = intr.pi.mid();
+    if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
+    float u = sampler.get1d();
+    // UniformLightSampler::Sample (lightsamplers.h:33-38) over the emissive rectangles followed by the infinite lights
+    constexpr bool kFull = !Medium::kSimpleScene;
+    const int n_all = kFull ? S.n_lights + S.n_inf : S.n_lights;
+    bool have_light = n_all > 0;
+    int lightIndex = 0;
+    float lightPmf = 0;
+    if (have_light) {
+        int li = (int)(u * (float)n_all);
+        lightIndex = li < n_all - 1 ? li : n_all - 1;
+        lightPmf = 1.f / (float)n_all;
+    }
+    float ul0 = sampler.get1d(), ul1 = sampler.get1d();
+    if (!have_light) return sp(0.f);
+    LightLi ls;
+    bool delta_light = false;
+    if (!sample_light<kFull>(S, lightIndex, ctxp, ul0, ul1, &ls, &delta_light)) return sp(0.f);
+    float p_l = lightPmf * ls.pdf;
+
+    float scatterPDF;
+    Spec f_hat;
+    V3 wo = intr.wo, wi = ls.wi;
+    // GuidedBSDF::PDF / GuidedPhaseFunction::PDF (guiding.h:271-289, 542-558); gd != nullptr iff useGuiding
+    if (intr.is_surface) {
+        f_hat = bsdf_f(*bsdf, wo, wi) * absdot(wi, intr.n);
+        float bsdfPDF = bsdf_pdf(*bsdf, wo, wi);
+        if (use_gd) bsdfPDF = ((1.0f - kGuidingProbability) * bsdfPDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        scatterPDF = 1.0f * bsdfPDF;
+    } else {
+        float p = henyey_greenstein(dot(wo, wi), intr.g);
+        f_hat = sp(p);
+        float phasePDF = p;
+        if (use_gd) phasePDF = ((1.0f - kGuidingProbability) * phasePDF) + (kGuidingProbability * gdist_pdf(*gd, wi));
+        scatterPDF = 1.0f * phasePDF;
+    }
+    if (!nonzero(f_hat)) return sp(0.f);
+
+    return sample_Ld_shadow<Medium>(S, medium, intr, ch, ls, f_hat, p_l, scatterPDF, r_p, pc, delta_light);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "vspg_host.h"
+#include "vspg_scenefile.h"
 
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
@@ -162,6 +163,29 @@ int main() {
         IsgBufferSettings is;
         (void)ParseIntegratorParams(ParameterDictionary().Bool("loadISGBuffer", true).String("isgBufferFileName", "v.pfm"), nullptr, nullptr, &is);
         CHECK(is.load && !is.store && is.fileName == "v.pfm");
+    }
+    // scene-file reader: index / orientation / medium checks (round-2 review; no device calls: ParseSceneString only)
+    {
+        const std::string head = "Camera \"perspective\"\nSampler \"halton\" \"integer pixelsamples\" 2\nFilm \"rgb\" \"integer xresolution\" 8 \"integer yresolution\" 8\n"
+                                 "Integrator \"guidedvolpathvspg\"\nWorldBegin\n";
+        const std::string quadP = "\"point3 P\" [ 0 0 0  1 0 0  0 1 0  1 1 0 ]";
+        CHECK(throws([&] { (void)ParseSceneString(head + "Shape \"bilinearmesh\" " + quadP + " \"integer indices\" [ 0 1 2 500000000 ]\n"); }));
+        CHECK(throws([&] { (void)ParseSceneString(head + "Shape \"bilinearmesh\" " + quadP + " \"integer indices\" [ 0 1 2 -7 ]\n"); }));
+        CHECK(throws([&] { (void)ParseSceneString(head + "Shape \"bilinearmesh\" \"point3 P\" [ 0 0 0  1 0 0  0 1 0  1 1 0  5 ]\n"); }));
+        CHECK(throws([&] { (void)ParseSceneString(head + "Shape \"trianglemesh\" \"point3 P\" [ 0 0 0  1 0 0  0 1 0 ] \"integer indices\" [ 0 1 3 ]\n"); }));
+        {  // a mirroring CTM turns a patch over: reverseOrientation ^ transformSwapsHandedness (shapes.h:1163-1164)
+            auto a = ParseSceneString(head + "AreaLightSource \"diffuse\" \"rgb L\" [1 1 1]\nShape \"bilinearmesh\" " + quadP + "\n");
+            auto b = ParseSceneString(head + "Scale -1 1 1\nAreaLightSource \"diffuse\" \"rgb L\" [1 1 1]\nShape \"bilinearmesh\" " + quadP + "\n");
+            auto c2 = ParseSceneString(head + "Scale -1 1 1\nReverseOrientation\nAreaLightSource \"diffuse\" \"rgb L\" [1 1 1]\nShape \"bilinearmesh\" " + quadP + "\n");
+            CHECK(a->scene.n_quads == 1 && a->scene.quads[0].reverse_orientation == 0);
+            CHECK(b->scene.n_quads == 1 && b->scene.quads[0].reverse_orientation == 1);
+            CHECK(c2->scene.n_quads == 1 && c2->scene.quads[0].reverse_orientation == 0);
+            bool warned = false;
+            for (const auto &w : a->warnings) warned = warned || w.find("halton") != std::string::npos;
+            CHECK(warned);  // every sampler runs as "independent", and says so
+        }
+        // a shape that bounds two media, neither of them the camera's: refused, not rendered wrongly
+        CHECK(throws([&] { (void)ParseSceneString(head + "MakeNamedMedium \"m\" \"string type\" \"homogeneous\"\nMediumInterface \"m\" \"m\"\nShape \"bilinearmesh\" " + quadP + "\n"); }));
     }
     std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: ok\n", fails);
     return fails ? 1 : 0;

@@ -41,12 +41,15 @@ int main(int argc, char **argv) {
         cfg.xres = sd->xres; cfg.yres = sd->yres; cfg.spp = sd->pixelSamples; cfg.seed = sd->seed;
         cfg.shard_index = rank; cfg.shard_count = world; cfg.device = local;
         if (vspg_renderer_create(&sd->scene, &prm, &cfg, &r) != 0) throw vspg::Error(vspg_last_error());
+        int seen = 0;
+        if (vspg_rccl_ranks_seen(comm, nullptr, &seen) != 0 || seen != world) throw vspg::Error("RCCL launch check: " + std::to_string(seen) + " of " + std::to_string(world) + " ranks answered");
         if (world > 1 && vspg_rccl_enable_training_exchange(r, comm) != 0) throw vspg::Error("training exchange set-up failed");
         const int steps = (sd->pixelSamples + world - 1) / world;
         for (int s = 0; s < steps; ++s) {
             const int w0 = s * world, w1 = (s + 1) * world < sd->pixelSamples ? (s + 1) * world : sd->pixelSamples;
             if (vspg_render_wave(r, w0, w1, nullptr) != 0) throw vspg::Error(vspg_last_error());   // this rank's index of the step
-            if (vspg_rccl_post_process_step(r, world, comm, nullptr) != 0) throw vspg::Error(std::string("post-process step: ") + vspg_last_error());
+            // the last step of a frame whose sample count is not a multiple of the rank count covers w1 - w0 < world indices
+            if (vspg_rccl_post_process_step_n(r, w1 - w0, world, comm, nullptr) != 0) throw vspg::Error(std::string("post-process step: ") + vspg_last_error());
         }
         if (vspg_rccl_allreduce_film(r, comm, nullptr) != 0) throw vspg::Error("film all-reduce failed");
         VspgCounters c;
@@ -63,7 +66,7 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "rank %d error: %s\n", rank, e.what());
         code = 1;
     }
-    if (r) vspg_renderer_destroy(r);
+    if (r) { vspg_rccl_forget(r); vspg_renderer_destroy(r); }
     if (comm) vspg_rccl_destroy(comm);
     return code;
 }

@@ -1,6 +1,7 @@
 // vspg_scenefile.cpp -- see vspg_scenefile.h
 #include "vspg_scenefile.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -209,7 +210,8 @@ class Parser {
             haveCamera = true;
             cameraMedium = gs.outsideMedium;  // the camera takes the current OUTSIDE medium (scene.cpp:153-155, 664-665)
         } else if (d == "Sampler") {
-            (void)str();  // every sampler name is run as "independent": the path's parity is defined on it (samplers.h:442-476)
+            const std::string sname = str();  // every sampler is run as "independent": the path's parity is defined on it (samplers.h:442-476)
+            if (sname != "independent") sd->warnings.push_back("Sampler \"" + sname + "\" runs as \"independent\"");
             ParameterDictionary p = params_with_bare_bools();
             sd->pixelSamples = p.GetOneInt("pixelsamples", 16);
             sd->seed = p.GetOneInt("seed", 0);
@@ -355,8 +357,24 @@ class Parser {
             for (int k = 0; k < 3; ++k) sd->triP.push_back(v[i][k]);
         for (int k = 0; k < 3; ++k) sd->triKd.push_back(gs.Kd[k]);
     }
+    static bool swaps_handedness(const M4 &m) {  // Transform::SwapsHandedness (util/transform.cpp): det of the upper 3x3 < 0
+        const float det = m.m[0][0] * (m.m[1][1] * m.m[2][2] - m.m[1][2] * m.m[2][1]) - m.m[0][1] * (m.m[1][0] * m.m[2][2] - m.m[1][2] * m.m[2][0]) +
+                          m.m[0][2] * (m.m[1][0] * m.m[2][1] - m.m[1][1] * m.m[2][0]);
+        return det < 0;
+    }
     void shape(const std::string &type, ParameterDictionary &p) {
         if (!world) fail("Shape before WorldBegin");
+        // One medium fills the scene in this build (the camera's).  Every surface here is opaque, so a shape's two media never
+        // meet along a ray: a shape is consistent with that as long as ONE of its sides is the camera's medium (the floor under
+        // a cloud: MediumInterface "" "cloud").  A shape that bounds two OTHER media would render wrongly without a word -- refuse
+        // it (interaction.h:117-121 picks the medium per side in the reference); a one-sided match is accepted with a warning.
+        if (gs.insideMedium != cameraMedium && gs.outsideMedium != cameraMedium)
+            fail("Shape with MediumInterface \"" + gs.insideMedium + "\" \"" + gs.outsideMedium + "\": this build renders ONE medium filling the scene, the camera's (\"" +
+                 cameraMedium + "\"); media bounded by shapes are outside its scope");
+        if (gs.insideMedium != gs.outsideMedium) {
+            const std::string w = "MediumInterface \"" + gs.insideMedium + "\" \"" + gs.outsideMedium + "\" on a shape: the camera's medium (\"" + cameraMedium + "\") is used on both sides";
+            if (std::find(sd->warnings.begin(), sd->warnings.end(), w) == sd->warnings.end()) sd->warnings.push_back(w);
+        }
         std::vector<float> P = p.GetPoint3Array("P");
         if (p.Has("N") || p.Has("uv") || p.Has("S")) fail("shading normals / tangents / (u,v) on meshes are outside this build's scope");
         std::vector<float> W(P.size());
@@ -365,7 +383,11 @@ class Parser {
             std::vector<int> idx = p.GetIntArray("indices");
             p.ReportUnused();
             if (idx.empty()) idx = {0, 1, 2, 3};
+            if (P.size() % 3) fail("bilinearmesh: \"P\" must hold whole points (a multiple of three floats)");
             if (idx.size() != 4 || W.size() < 12) fail("bilinearmesh: one patch of four points is supported");
+            const int nv = (int)(W.size() / 3);
+            for (int k = 0; k < 4; ++k)
+                if (idx[k] < 0 || idx[k] >= nv) fail("bilinearmesh: vertex index out of range");
             const float *p00 = &W[3 * idx[0]], *p10 = &W[3 * idx[1]], *p01 = &W[3 * idx[2]], *p11 = &W[3 * idx[3]];
             float e1[3], e2[3];
             bool parallelogram = true;
@@ -380,15 +402,20 @@ class Parser {
                 std::memset(&q, 0, sizeof q);
                 for (int k = 0; k < 3; ++k) { q.p00[k] = p00[k]; q.e1[k] = e1[k]; q.e2[k] = e2[k]; q.Kd[k] = gs.Kd[k]; q.Le[k] = gs.areaLight ? gs.Le[k] : 0.f; }
                 q.two_sided = gs.twoSided;
-                q.reverse_orientation = gs.reverseOrientation;
+                // BilinearPatch flips n when reverseOrientation ^ transformSwapsHandedness (shapes.h:1163-1164, shapes.cpp:1267-1270):
+                // a mirroring CTM turns the patch's parametrisation over
+                q.reverse_orientation = gs.reverseOrientation != swaps_handedness(gs.ctm);
                 quads.push_back(q);
             } else {
                 add_triangle(p00, p10, p11);
                 add_triangle(p00, p11, p01);
             }
         } else if (type == "trianglemesh") {
+            // (a triangle's orientation -- reverseOrientation ^ transformSwapsHandedness, shapes.h:925-927 -- has no effect here:
+            // triangles carry a diffuse BSDF and no emission, and both are symmetric in the sign of n)
             std::vector<int> idx = p.GetIntArray("indices");
             p.ReportUnused();
+            if (P.size() % 3) fail("trianglemesh: \"P\" must hold whole points (a multiple of three floats)");
             const int nv = (int)(W.size() / 3);
             if (idx.empty()) { if (nv != 3) fail("trianglemesh without indices must have exactly three points"); idx = {0, 1, 2}; }
             if (idx.size() % 3) fail("trianglemesh: indices come in threes");

@@ -59,35 +59,43 @@ class ShardSync:
         if world > 1 and hasattr(renderer, "set_exchange"):
             renderer.set_exchange(self._exchange)
 
+    def _ordered(self, stream, fn):
+        """Run fn() -- work issued on torch's current stream -- ordered after what `stream` holds and before what it gets
+        next (the renderer's kernels run on `stream`; torch.distributed issues collectives on the current stream)."""
+        torch = self.torch
+        if not hasattr(torch, "cuda") or self.device is None or not torch.cuda.is_available():
+            return fn()                                  # gloo / CPU oracle: nothing to order
+        cur = torch.cuda.current_stream(self.device)
+        if stream == cur.cuda_stream:
+            return fn()
+        if stream:
+            ext = torch.cuda.ExternalStream(stream, device=self.device)
+            cur.wait_stream(ext)
+            out = fn()
+            ext.wait_stream(cur)
+            return out
+        torch.cuda.synchronize(self.device)              # the null stream: no handle to wait on
+        out = fn()
+        torch.cuda.synchronize(self.device)
+        return out
+
     def _exchange(self, ptr, n, stream):
         torch = self.torch
 
         class _Dev:
             __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
         t = torch.as_tensor(_Dev(), device=self.device)
-        # the update's kernels run on `stream`; collectives are issued on torch's current stream: order the two
-        if stream == torch.cuda.current_stream(self.device).cuda_stream:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        elif stream:
-            ext = torch.cuda.ExternalStream(stream, device=self.device)
-            torch.cuda.current_stream(self.device).wait_stream(ext)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-            ext.wait_stream(torch.cuda.current_stream(self.device))
-        else:
-            torch.cuda.synchronize(self.device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-            torch.cuda.synchronize(self.device)
+        self._ordered(stream, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
 
     def _stats_tensor(self):
         if hasattr(self.r, "isg_stats_tensor"):       # CPU oracle: a fresh host copy per call
             return self.r.isg_stats_tensor(self.torch)
         if self._stats is None:                       # HIP renderer: wrap the device pointer once (no copy)
-            if True:
-                ptr, n = self.r.isg_stats_ptr()
+            ptr, n = self.r.isg_stats_ptr()
 
-                class _Dev:
-                    __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-                self._stats = self.torch.as_tensor(_Dev(), device=self.device)
+            class _Dev:
+                __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+            self._stats = self.torch.as_tensor(_Dev(), device=self.device)
         return self._stats
 
     def post_process_step(self, stream=None):
@@ -102,8 +110,15 @@ class ShardSync:
             st = self._stats_tensor()
             if self._sum is None:
                 self._sum = self.torch.empty_like(st)
-            self._sum.copy_(st)
-            self.dist.all_reduce(self._sum, op=self.dist.ReduceOp.SUM)
+
+            def _sum_over_ranks():
+                self._sum.copy_(st)
+                self.dist.all_reduce(self._sum, op=self.dist.ReduceOp.SUM)
+            # the wave that filled `st` ran on `stream`, and the update that reads the sum runs there next
+            if hasattr(self.r, "isg_stats_tensor"):
+                _sum_over_ranks()
+            else:
+                self._ordered(stream, _sum_over_ranks)
             total = self._sum
         if hasattr(self.r, "isg_stats_tensor"):
             self.r.post_process_step(self.world, total)
