@@ -1477,8 +1477,7 @@ static v3 lobe_dir(const VspgFieldRegion *R, int k, v3 p) {
     v3 mu = V3(R->mu[0][k], R->mu[1][k], R->mu[2][k]);
     float d = R->distance[k];
     if (!(d > 0) || isinf(d)) return mu;
-    v3 src = v_add(v3_from(R->pivot), v_scale(mu, d));
-    v3 t = v_sub(src, p);
+    v3 t = v_add(v_sub(v3_from(R->pivot), p), v_scale(mu, d)); /* (pivot - p) + mu d: the lobe's source seen from p */
     float l2 = v_len2(t);
     if (!(l2 > 0)) return mu;
     float inv = 1.0f / sqrtf(l2);

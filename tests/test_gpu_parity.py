@@ -366,6 +366,39 @@ def test_grey_specialisations_are_bit_identical(gpu_pkg):
     assert not np.array_equal(films[0], films[1])
 
 
+@pytest.mark.parametrize("W,H", [(96, 64), (50, 37)])
+def test_workgroup_schedulers_are_bit_identical(gpu_pkg, W, H):
+    """The two schedulers of the workgroup kernel -- k_render_wave_wg (global work head, film flush between the phases) and
+    k_render_wave_wg2 (static interleaved tiles, sample buffer + k_film_resolve, two barriers; the guided default) -- over
+    the four homogeneous instantiations, with one-sample launches, a multi-sample launch (restarts, film atomics) and the
+    image-space buffer updating in between: same films, same VSP buffers, same counters."""
+    P = gpu_pkg
+    scene = P.fog_box_scene(W, H)
+    for env in ({"VSPG_NO_GREY": "1"}, {"VSPG_NO_GREY_KD": "1"}, {"VSPG_NO_NULLZERO": "1"}, {}):
+        out = []
+        for sched in ("1", "2"):
+            os.environ.update(env)
+            os.environ["VSPG_WG_SCHED"] = sched
+            try:
+                r = P.Renderer(scene, P.app_f_params(), W, H, seed=3)
+                for w in range(3):
+                    r.render_wave(w, w + 1)
+                    r.post_process_wave()
+                r.render_wave(3, 6)
+                for _ in range(3):
+                    r.post_process_wave()
+                r.render_wave(6, 7)
+                out.append((r.film(), r.vsp_buffer()[0], r.counters()))
+                r.close()
+            finally:
+                os.environ.pop("VSPG_WG_SCHED", None)
+                for k in env:
+                    os.environ.pop(k, None)
+        assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), env
+        assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), env
+        assert out[0][2] == out[1][2] and out[0][2]["paths"] == 7 * W * H, (env, out[0][2], out[1][2])
+
+
 def test_grey_grid_medium_film_equals_replayed_paths(gpu_pkg):
     """A grid medium with grey sigma_a / sigma_s renders through the broadcast-spectrum instantiation of the
     per-lane kernel; the path replay (k_trace_paths) uses the generic one: same pixels bit for bit, and the
@@ -1385,7 +1418,8 @@ def test_guiding_query_vs_oracle(guided_pair, is_volume, gg):
 
 def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
     """The reference-default guided configuration (surface RIS + volume MIS + secondary VSP) with a field in place: the
-    workgroup kernel (mixture scratch in registers, vertices compacted by kind) and the per-lane kernel (scratch in LDS)
+    workgroup kernel (the default since round 3: lobes in registers, vertices compacted by kind, four waves per SIMD) in its
+    grey / zero-null-coefficient and generic instantiations and the per-lane kernel (scratch in LDS) in both of its own
     render the same film bit for bit, at a size with many workgroups."""
     import scenes
     P = gpu_pkg
@@ -1395,8 +1429,9 @@ def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
     prm = P.default_params()
     field = scenes.light_field(P, n=4)
     films = {}
-    for kernel, nogrey in (("wg", ""), ("lane", ""), ("lane", "1")):
-        os.environ["VSPG_KERNEL"] = kernel
+    for kernel, nogrey in ((None, ""), ("wg", "1"), ("lane", ""), ("lane", "1")):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
         if nogrey:
             os.environ["VSPG_NO_GREY_GUIDED"] = nogrey
         try:
@@ -1411,11 +1446,11 @@ def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
         finally:
             os.environ.pop("VSPG_KERNEL", None)
             os.environ.pop("VSPG_NO_GREY_GUIDED", None)
-    # the per-lane kernel's grey / zero-null-coefficient instantiation (the fog box qualifies), its generic one, the workgroup kernel
     assert sorted(films) == ["k_render_wave<HomogeneousMedium,guided>", "k_render_wave<HomogeneousMediumT<2,true>,guided>",
-                             "k_render_wave_wg<HomogeneousMedium,guided>"], sorted(films)
-    a, b, c3 = films.values()
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c3.view(np.uint32))
+                             "k_render_wave_wg2<HomogeneousMedium,guided>", "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>"], sorted(films)
+    a = next(iter(films.values()))
+    for name, f in films.items():
+        assert np.array_equal(a.view(np.uint32), f.view(np.uint32)), name
 
 
 @pytest.mark.parametrize("g,stype,vtype,sg,vg,maxdepth", [(0.0, 1, 0, 1, 1, 5),   # isotropic phase function: no product lobe at volume vertices

@@ -635,29 +635,45 @@ constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 384;
 #ifndef VSPG_WGG_NP
 #define VSPG_WGG_NP 320
 #endif
-#ifndef VSPG_WGG_POOLG
-#define VSPG_WGG_POOLG 0
-#endif
-#ifndef VSPG_WG_POOLG
-#define VSPG_WG_POOLG 0
-#endif
 #ifndef VSPG_WGG_WAVES
-#define VSPG_WGG_WAVES 2
+#define VSPG_WGG_WAVES 4
 #endif
 #ifndef VSPG_WGG_BLOCK
-#define VSPG_WGG_BLOCK 256
+#define VSPG_WGG_BLOCK 512
 #endif
-constexpr int kWgWavesGuided = VSPG_WGG_WAVES, kWgBlockGuided = VSPG_WGG_BLOCK, kWgPoolGuided = VSPG_WGG_NP;  // guided vertices: 40-dword records
-constexpr bool kWgPoolGlobalHomog = VSPG_WG_POOLG != 0, kWgPoolGlobalGuided = VSPG_WGG_POOLG != 0;
+// guided vertices on the workgroup kernel (round 3, vspg_guided_wg.h): 128 registers, four waves per SIMD like the unguided kernel
+constexpr int kWgWavesGuided = VSPG_WGG_WAVES, kWgBlockGuided = VSPG_WGG_BLOCK, kWgPoolGuided = VSPG_WGG_NP;
+// Paths per pool: what fits the 80 KB a workgroup may use when two share a CU -- the record (PoolLayout::COUNT dwords), the
+// lists' entries per path, and `other` bytes of fixed LDS (scene records, tables, counters, staged kd nodes); a multiple of 32.
+template <class LY>
+constexpr int wg_pool_paths(int list_bytes_per_path, int other_bytes) {
+    return (81920 - other_bytes) / (LY::COUNT * 4 + list_bytes_per_path) / 32 * 32;
+}
+#ifndef VSPG_WG_OTHER
+#define VSPG_WG_OTHER 5500
+#endif
+// The unguided kernels run eight waves per workgroup over 64-entry chunks: 512 paths give every wave one chunk per phase, and a
+// pool that is not a multiple of that leaves a second round of partly filled chunks behind (608 paths: 0.849 against 0.804 ms per
+// 1080p wave) -- so the records the grey instantiations save are not spent on more paths there.
+template <int GREY> constexpr int kWgPoolHomogT = wg_pool_paths<PoolLayout<false, GREY>>(14, VSPG_WG_OTHER) < 512 ? wg_pool_paths<PoolLayout<false, GREY>>(14, VSPG_WG_OTHER) : 512;  // k_render_wave_wg: + s_item
+template <int GREY> constexpr int kWg2PoolHomogT = wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) < 512 ? wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) : 512;
+// guided: every path counts (320 -> 384 -> 416 paths: 2.14 -> 1.86 -> 1.78 ms per trained 1080p wave)
+#ifndef VSPG_WGG_NP_G0
+#define VSPG_WGG_NP_G0 wg_pool_paths<PoolLayout<true, 0>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8)
+#endif
+#ifndef VSPG_WGG_NP_G2
+#define VSPG_WGG_NP_G2 wg_pool_paths<PoolLayout<true, 2>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8)
+#endif
+template <int GREY> constexpr int kWg2PoolGuidedT = GREY >= 2 ? (VSPG_WGG_NP_G2) : (VSPG_WGG_NP_G0);
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
 
-template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd, bool POOLG = false>
+template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd>
 __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
     int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int tiles_magic,
-    unsigned int *__restrict__ work_head, unsigned long long *__restrict__ counters, float *__restrict__ gpool = nullptr) {
+    unsigned int *__restrict__ work_head, unsigned long long *__restrict__ counters) {
     // tiles_magic = ceil(2^32 / tilesX): the one integer division of the kernel (tile index -> tile row, once
     // per claimed chunk) is a multiply-high by it plus a fix-up; pixels travel as packed (x | y << 16)
     const DScene &S = *Sp;
@@ -668,19 +684,12 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
     reset_sibling_head(work_head);
 
-    constexpr int NF = GUIDED ? (int)PF_COUNT_GUIDED : (int)PF_GS;
-    // POOLG (build-time experiment, -DVSPG_WG_POOLG=1 / -DVSPG_WGG_POOLG=1; off): the pool in the workgroup's own piece of
-    // GLOBAL memory instead of LDS -- the segment-streaming layout SURVEY 8d's byte model describes.  It lifts the LDS bound
-    // on NP (long lists, many chunks per wavefront and phase) at the price of the records' round trips; measured on the
-    // 1080p fog wave (scripts/gpu_poolg.sh): 0.82 ms (LDS, 512 paths) -> 2.49 / 3.39 / 2.95 ms (global, 1024 / 2048 / 4096
-    // paths); guided instantiation 2.93 ms (LDS, 320 paths) -> 4.21 / 5.59 ms (global, 1024 / 2048).  The state belongs on chip.
-    float *pool_base;
-    if constexpr (POOLG) {
-        pool_base = gpool + (size_t)blockIdx.x * ((size_t)NF * NP);
-    } else {
-        __shared__ float s_pool[NF * NP];
-        pool_base = s_pool;
-    }
+    using LY = PoolLayout<GUIDED, Medium::kGrey>;
+    constexpr int NF = LY::COUNT;
+    // (Tried in round 2 and dropped: the pool in the workgroup's own piece of GLOBAL memory instead of LDS -- the segment-streaming
+    // layout SURVEY 8d's byte model describes -- 0.82 ms (LDS, 512 paths) -> 2.49 / 3.39 / 2.95 ms with 1024 / 2048 / 4096 paths.)
+    __shared__ float s_pool[NF * NP];
+    float *const pool_base = s_pool;
     __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
     __shared__ unsigned int s_item[NP];
     __shared__ unsigned int s_cnt[C_COUNT];
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     if (threadIdx.x < C_COUNT) s_cnt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < NP; i += kWgBlock) {
         s_free[0][i] = (unsigned short)i;
-        P.u(PF_FLAGS, i) = 0;
+        P.u(LY::FLAGS, i) = 0;
     }
     __syncthreads();
     if (threadIdx.x == 0) s_cnt[C_NFREE] = NP;
@@ -790,18 +799,18 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 const unsigned i = base + (unsigned)lane;
                 if (i < n_free) {
                     const int slot = s_free[par][i];
-                    const uint32_t fl = P.u(PF_FLAGS, slot);
+                    const uint32_t fl = P.u(LY::FLAGS, slot);
                     if (fl & FL_DONE) {
-                        const int pxy = P.i(PF_PIXEL, slot);
+                        const int pxy = P.i(LY::PIXEL, slot);
                         const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
-                        const Spec L = P.sp3(PF_L, slot);
+                        const Spec L = P.sp3(LY::L, slot);
                         IsgSample isg;
                         isg.valid = (fl & FL_ISG_VALID) != 0;
                         isg.surface_event = (fl & FL_ISG_SURF) != 0;
-                        isg.vsp_used = P.f(PF_VSP, slot);
+                        isg.vsp_used = P.f(LY::VSP, slot);
                         film_add_sample_rmw(film + pidx, L);
                         isg_add_sample_rmw(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
-                        P.u(PF_FLAGS, slot) = 0;
+                        P.u(LY::FLAGS, slot) = 0;
                     }
                 }
             }
@@ -817,8 +826,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
             __syncthreads();
             for (unsigned j = threadIdx.x; j < nA1; j += (unsigned)kWgBlock) {
                 const int slot = s_listA[par][NP - 1 - (int)j];
-                const V3 ro = P.v3(PF_RO, slot), rd = P.v3(PF_RD, slot);
-                const int ch = (int)((P.u(PF_FLAGS, slot) >> FL_CH_SHIFT) & 3u);
+                const V3 ro = P.v3(LY::RO, slot), rd = P.v3(LY::RD, slot);
+                const int ch = (int)((P.u(LY::FLAGS, slot) >> FL_CH_SHIFT) & 3u);
                 const Isect si = scene_intersect(S, ro, rd, kInf);
                 float tau = 0.f;
                 if (si.hit && S.medium_type != VSPG_MEDIUM_NONE) tau = majorant_optical_depth(medium, ro, rd, si.t, ch);
@@ -864,8 +873,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                         smp = first_sample;
                     } else {
                         slot = s_listA[par][i - nFresh];
-                        pxy = P.i(PF_PIXEL, slot);
-                        smp = P.i(PF_SAMPLE, slot);
+                        pxy = P.i(LY::PIXEL, slot);
+                        smp = P.i(LY::SAMPLE, slot);
                     }
                     px = pxy & 0xffff;
                     py = (int)((unsigned)pxy >> 16);
@@ -875,13 +884,13 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                             start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
                         else
                             start_path(S, vsp_buf, vsp_ready, px, py, smp, sampler, st, &ch, isg);
-                        P.i(PF_PIXEL, slot) = pxy;
-                        P.i(PF_SAMPLE, slot) = smp;
+                        P.i(LY::PIXEL, slot) = pxy;
+                        P.i(LY::SAMPLE, slot) = smp;
                         alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                           isg, pc, vx);
                         if (alive) {
                             pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
-                            pool_store_vertex<GUIDED>(P, slot, vx);
+                            pool_store_vertex<GUIDED, Medium::kGrey>(P, slot, vx);
                         }
                     } else {
                         freed = true;
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                     if constexpr (kSortWalks) slot = s_order[i - nPrim];
                     else slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
                     const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
-                    pxy = P.i(PF_PIXEL, slot);
+                    pxy = P.i(LY::PIXEL, slot);
                     const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
                     alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                         isg, pc, vx);
@@ -903,17 +912,17 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                     const Spec L = finish_radiance(st.L);
                     const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
                     if (single_sample) {  // parked for the film flush at the top of the next iteration
-                        P.sets(PF_L, slot, L);
-                        P.i(PF_PIXEL, slot) = pxy;
-                        P.f(PF_VSP, slot) = isg.vsp_used;
-                        P.u(PF_FLAGS, slot) = (uint32_t)FL_DONE | (isg.valid ? (uint32_t)FL_ISG_VALID : 0u) | (isg.surface_event ? (uint32_t)FL_ISG_SURF : 0u);
+                        P.sets(LY::L, slot, L);
+                        P.i(LY::PIXEL, slot) = pxy;
+                        P.f(LY::VSP, slot) = isg.vsp_used;
+                        P.u(LY::FLAGS, slot) = (uint32_t)FL_DONE | (isg.valid ? (uint32_t)FL_ISG_VALID : 0u) | (isg.surface_event ? (uint32_t)FL_ISG_SURF : 0u);
                     } else {
                         film_add_sample(film + pidx, L);
                         isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
                     }
                     pc.path();
-                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
-                    P.i(PF_SAMPLE, slot) = s2;
+                    const int s2 = P.i(LY::SAMPLE, slot) + sample_step;
+                    P.i(LY::SAMPLE, slot) = s2;
                     restart = s2 < wave_end;
                     freed = !restart;
                 }
@@ -943,26 +952,26 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
                 IsgSample isg;
                 int ch;
                 const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
-                const Vertex vx = pool_load_vertex<GUIDED>(P, slot, fl);
+                const Vertex vx = pool_load_vertex<GUIDED, Medium::kGrey>(P, slot, fl);
                 if (li_segment_b<Medium, GUIDED, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock)) {
                     pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE);
                     cont = true;
                 } else {
-                    const int pxy = P.i(PF_PIXEL, slot);
+                    const int pxy = P.i(LY::PIXEL, slot);
                     const size_t pidx = (size_t)((unsigned)pxy >> 16) * W + (pxy & 0xffff);
                     const Spec L = finish_radiance(st.L);
                     if (single_sample) {  // parked for the film flush at the top of the next iteration
-                        P.sets(PF_L, slot, L);
-                        P.i(PF_PIXEL, slot) = pxy;
-                        P.f(PF_VSP, slot) = isg.vsp_used;
-                        P.u(PF_FLAGS, slot) = (uint32_t)FL_DONE | (isg.valid ? (uint32_t)FL_ISG_VALID : 0u) | (isg.surface_event ? (uint32_t)FL_ISG_SURF : 0u);
+                        P.sets(LY::L, slot, L);
+                        P.i(LY::PIXEL, slot) = pxy;
+                        P.f(LY::VSP, slot) = isg.vsp_used;
+                        P.u(LY::FLAGS, slot) = (uint32_t)FL_DONE | (isg.valid ? (uint32_t)FL_ISG_VALID : 0u) | (isg.surface_event ? (uint32_t)FL_ISG_SURF : 0u);
                     } else {
                         film_add_sample(film + pidx, L);
                         isg_add_sample_atomic(isg_stats + pidx * VSPG_ISG_STATS, L, isg);
                     }
                     pc.path();
-                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
-                    P.i(PF_SAMPLE, slot) = s2;
+                    const int s2 = P.i(LY::SAMPLE, slot) + sample_step;
+                    P.i(LY::SAMPLE, slot) = s2;
                     restart = s2 < wave_end;
                     freed = !restart;
                 }
@@ -1019,7 +1028,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     const unsigned local_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
     const unsigned local_total = local_tiles * 64u;
 
-    constexpr int NF = GUIDED ? (int)PF_COUNT_GUIDED : (int)PF_GS;
+    using LY = PoolLayout<GUIDED, Medium::kGrey>;
+    constexpr int NF = LY::COUNT;
     __shared__ float s_pool[NF * NP];
     __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
     __shared__ unsigned int s_cnt[D_COUNT + 1];
@@ -1027,8 +1037,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     static_assert(Medium::kSingleSegment, "k_render_wave_wg2 serves homogeneous media (grid media: the wavefront pipeline)");
     const Medium medium = MediumMaker<Medium>::make(S, nullptr);
     float *glds = nullptr;
-    if constexpr (GUIDED) {  // the upper levels of the two kd-trees (north star: "LDS-staged kd-tree nodes")
-        __shared__ VspgKdNode s_kd[2][kKdLdsNodes];
+    if constexpr (GUIDED && kKdLdsNodes > 0) {  // the upper levels of the two kd-trees (north star: "LDS-staged kd-tree nodes")
+        __shared__ VspgKdNode s_kd[2][kKdLdsNodes > 0 ? kKdLdsNodes : 1];
         for (int f = 0; f < 2; ++f) {
             const int nl = S.field[f].n_nodes < kKdLdsNodes ? S.field[f].n_nodes : kKdLdsNodes;
             for (int i = threadIdx.x; i < nl; i += kWgBlock) s_kd[f][i] = S.field[f].nodes[i];
@@ -1036,8 +1046,13 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
         glds = reinterpret_cast<float *>(&s_kd[0][0]);
     }
     __shared__ unsigned int s_counters[CNT_COUNT];
-    struct LaneCounters : PathCounters { uint32_t paths; VDEV void path() { paths++; } } pc;
-    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = pc.paths = 0;
+    // counters: per lane in registers (six of them; the unguided instantiations have them to spare), per workgroup in LDS through
+    // a ballot and one atomic per count in the guided instantiation, whose vertex phase needs every register it can get
+    struct LaneCounters : PathCounters { uint32_t paths; VDEV void path() { paths++; } };
+    typename std::conditional<GUIDED, const WaveCounters, LaneCounters>::type pc = [&] {
+        if constexpr (GUIDED) return WaveCounters{s_counters};
+        else { LaneCounters c; c.segments = c.volume_scatters = c.surface_hits = c.density_queries = c.shadow_rays = c.paths = 0; return c; }
+    }();
 
     stage_scene_lds(S);
     if (threadIdx.x < CNT_COUNT) s_counters[threadIdx.x] = 0;
@@ -1104,8 +1119,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                         valid = tile < n_tiles;
                     } else {
                         slot = s_listA[par][i - nFresh];
-                        pxy = P.i(PF_PIXEL, slot);
-                        smp = P.i(PF_SAMPLE, slot);
+                        pxy = P.i(LY::PIXEL, slot);
+                        smp = P.i(LY::SAMPLE, slot);
                         px = pxy & 0xffff;
                         py = (int)((unsigned)pxy >> 16);
                     }
@@ -1115,13 +1130,13 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                             start_path(S, vsp_buf, vsp_ready, px, py, jump, sampler, st, &ch, isg);
                         else
                             start_path(S, vsp_buf, vsp_ready, px, py, smp, sampler, st, &ch, isg);
-                        P.i(PF_PIXEL, slot) = pxy;
-                        P.i(PF_SAMPLE, slot) = smp;
+                        P.i(LY::PIXEL, slot) = pxy;
+                        P.i(LY::SAMPLE, slot) = smp;
                         alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                           isg, pc, vx);
                         if (alive) {
                             pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
-                            pool_store_vertex<GUIDED>(P, slot, vx);
+                            pool_store_vertex<GUIDED, Medium::kGrey>(P, slot, vx);
                         }
                     } else {
                         freed = true;
@@ -1129,7 +1144,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                 } else {
                     slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
                     const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
-                    pxy = P.i(PF_PIXEL, slot);
+                    pxy = P.i(LY::PIXEL, slot);
                     const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
                     alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                         isg, pc, vx);
@@ -1141,8 +1156,8 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                 } else if (valid) {
                     emit(pxy, st.L, isg);
                     pc.path();
-                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
-                    P.i(PF_SAMPLE, slot) = s2;
+                    const int s2 = P.i(LY::SAMPLE, slot) + sample_step;
+                    P.i(LY::SAMPLE, slot) = s2;
                     restart = s2 < wave_end;
                     freed = !restart;
                 }
@@ -1178,26 +1193,26 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                 int ch;
                 bool alive;
                 if constexpr (GUIDED) {  // the guided vertex works on the pool record directly (vspg_guided_wg.h)
-                    const uint32_t fl = P.u(PF_FLAGS, slot);
+                    const uint32_t fl = P.u(LY::FLAGS, slot);
                     alive = li_vertex_guided_wg<Medium>(S, medium, P, slot, fl, pc, reinterpret_cast<const VspgKdNode *>(glds), &st.L, &isg);
                     if (!alive) {
                         isg.valid = (fl & FL_ISG_VALID) != 0;
                         isg.surface_event = (fl & FL_ISG_SURF) != 0;
-                        isg.vsp_used = P.f(PF_VSP, slot);  // (depth >= 1 at a vertex: the slot holds isg.vsp_used)
+                        isg.vsp_used = P.f(LY::VSP, slot);  // (depth >= 1 at a vertex: the slot holds isg.vsp_used)
                     }
                 } else {
                     const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
-                    const Vertex vx = pool_load_vertex<GUIDED>(P, slot, fl);
+                    const Vertex vx = pool_load_vertex<GUIDED, Medium::kGrey>(P, slot, fl);
                     alive = li_segment_b<Medium, GUIDED, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock);
                     if (alive) pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE);
                 }
                 if (alive) {
                     cont = true;
                 } else {
-                    emit(P.i(PF_PIXEL, slot), st.L, isg);
+                    emit(P.i(LY::PIXEL, slot), st.L, isg);
                     pc.path();
-                    const int s2 = P.i(PF_SAMPLE, slot) + sample_step;
-                    P.i(PF_SAMPLE, slot) = s2;
+                    const int s2 = P.i(LY::SAMPLE, slot) + sample_step;
+                    P.i(LY::SAMPLE, slot) = s2;
                     restart = s2 < wave_end;
                     freed = !restart;
                 }
@@ -1208,9 +1223,11 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
         }
         { VSPG_PROF(PS_WG_BAR_B); __syncthreads(); }
     }
-    atomicAdd(&s_counters[CNT_PATHS], pc.paths); atomicAdd(&s_counters[CNT_SEGMENTS], pc.segments);
-    atomicAdd(&s_counters[CNT_VOLUME_SCATTERS], pc.volume_scatters); atomicAdd(&s_counters[CNT_SURFACE_HITS], pc.surface_hits);
-    atomicAdd(&s_counters[CNT_DENSITY_QUERIES], pc.density_queries); atomicAdd(&s_counters[CNT_SHADOW_RAYS], pc.shadow_rays);
+    if constexpr (!GUIDED) {
+        atomicAdd(&s_counters[CNT_PATHS], pc.paths); atomicAdd(&s_counters[CNT_SEGMENTS], pc.segments);
+        atomicAdd(&s_counters[CNT_VOLUME_SCATTERS], pc.volume_scatters); atomicAdd(&s_counters[CNT_SURFACE_HITS], pc.surface_hits);
+        atomicAdd(&s_counters[CNT_DENSITY_QUERIES], pc.density_queries); atomicAdd(&s_counters[CNT_SHADOW_RAYS], pc.shadow_rays);
+    }
     __syncthreads();
     if (threadIdx.x < CNT_COUNT) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_counters[threadIdx.x]);
 }
@@ -1513,9 +1530,7 @@ struct VspgRenderer {
     DBvhNode *bvh = nullptr;
     // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
     float *wf_pool = nullptr;
-    float *wg_gpool = nullptr;   // k_render_wave_wg<..., POOLG>: the workgroups' path pools in global memory
     float4 *wave_samples = nullptr;  // k_render_wave_wg2: one {L, ISG code} per pixel of a one-sample launch (k_film_resolve adds it in)
-    size_t wg_gpool_floats = 0;
     unsigned int *wf_lists = nullptr;   // 4 x n_items: active, vertex, walk, shadow
     WfIter *wf_iters = nullptr;
     size_t wf_items = 0;
@@ -2395,7 +2410,6 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_nsorted) (void)hipFree(r->train_nsorted);
     if (r->tris) (void)hipFree(r->tris);
     if (r->bvh) (void)hipFree(r->bvh);
-    if (r->wg_gpool) (void)hipFree(r->wg_gpool);
     if (r->wave_samples) (void)hipFree(r->wave_samples);
     if (r->wf_pool) (void)hipFree(r->wf_pool);
     if (r->wf_lists) (void)hipFree(r->wf_lists);
@@ -2426,8 +2440,11 @@ static const char *kernel_env() {
     return e && *e ? e : nullptr;
 }
 static bool uses_wg_guided(const VspgRenderer *r) {
+    // round 3: the workgroup kernel's guided vertex (vspg_guided_wg.h, four waves per SIMD) is the DEFAULT for a trained or
+    // loaded field over a homogeneous medium in a rectangle scene; VSPG_KERNEL=lane selects the per-lane kernel (tests compare
+    // the two).  Training waves (segment recording), guided Russian roulette, triangles / infinite lights stay per-lane.
     const char *kenv = kernel_env();
-    if (!kenv || strcmp(kenv, "wg") != 0) return false;
+    if (kenv && strcmp(kenv, "wg") != 0) return false;
     return wants_guiding(r->prm) && !r->training && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
            r->hscene.n_tris == 0 && r->hscene.n_inf == 0;
 }
@@ -2472,7 +2489,7 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
         return nvdb ? (r->medium_grey ? "k_wf_dist_walk<NanoDenseMediumGrey>" : "k_wf_dist_walk<NanoDenseMedium>")
                     : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
     }
-    if (uses_wg_guided(r)) return "k_render_wave_wg<HomogeneousMedium,guided>";
+    if (uses_wg_guided(r)) return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>" : "k_render_wave_wg2<HomogeneousMedium,guided>";
     if (uses_wg_kernel(r)) {
         if (grid) return "k_render_wave_wg<GridMedium>";
         if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg<HomogeneousMediumT<2,true>>";
@@ -2592,68 +2609,42 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         long long wblocks = (long long)r->num_cus * (wwaves * 4 / (wblock / 64));
         const long long wmax = (items + kWgChunk - 1) / kWgChunk;
         if (wblocks > wmax) wblocks = wmax;
-        if ((gwg && kWgPoolGlobalGuided) || (!gwg && !grid && kWgPoolGlobalHomog)) {
-            const size_t need = (size_t)wblocks * (gwg ? (size_t)PF_COUNT_GUIDED * kWgPoolGuided : (size_t)PF_GS * kWgPoolHomog);
-            if (need > r->wg_gpool_floats) {
-                if (r->wg_gpool) HIPCHK(hipFree(r->wg_gpool));
-                r->wg_gpool = nullptr;
-                HIPCHK(hipMalloc(&r->wg_gpool, need * sizeof(float)));
-                r->wg_gpool_floats = need;
-            }
-        }
-        // round 3: the two-barrier scheduler (k_render_wave_wg2) serves the homogeneous instantiations; VSPG_WG_SCHED=1 keeps
-        // the round-2 scheduler (three barriers, global work head, in-kernel film flush) for A/B runs and the tests that compare
+        const int single = n_samples == 1 ? 1 : 0;
+        // Two schedulers: k_render_wave_wg (global work head, film flush between the phases, three barriers) and
+        // k_render_wave_wg2 (static interleaved tiles, sample buffer + k_film_resolve, two barriers).  Unguided renders default to
+        // the first (measured faster there: its flush hides behind the assignment), guided ones run the second;
+        // VSPG_WG_SCHED=1|2 overrides for the unguided instantiations (tests compare the two).
         const char *sched_env = getenv("VSPG_WG_SCHED");
-        const bool sched2 = !grid && !(sched_env && sched_env[0] == '1');
+        const bool sched2 = !grid && (gwg || (sched_env && sched_env[0] == '2'));
         if (sched2) {
             if (!r->wave_samples) HIPCHK(hipMalloc(&r->wave_samples, r->npix * sizeof(float4)));
             const long long n_tiles = (long long)tilesX * tilesY;
             if (wblocks > n_tiles) wblocks = n_tiles;
 #define VSPG_LAUNCH_WG2(M, G, NPOOL, BLK, WV)                                                                                         \
     hipLaunchKernelGGL((k_render_wave_wg2<M, G, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
-                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,        \
-                       r->wave_samples, r->counters)
-            if (gwg) VSPG_LAUNCH_WG2(HomogeneousMediumSimple, true, kWgPoolGuided, kWgBlockGuided, kWgWavesGuided);
-            else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
-            else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGreyScene, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
-            else if (r->medium_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGrey, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
-            else VSPG_LAUNCH_WG2(HomogeneousMediumSimple, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog);
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, r->wave_samples, r->counters)
+            if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, true, kWg2PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided);
+            else if (gwg) VSPG_LAUNCH_WG2(HomogeneousMediumSimple, true, kWg2PoolGuidedT<0>, kWgBlockGuided, kWgWavesGuided);
+            else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, false, kWg2PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);
+            else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGreyScene, false, kWg2PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);
+            else if (r->medium_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGrey, false, kWg2PoolHomogT<1>, kWgBlockHomog, kWgWavesHomog);
+            else VSPG_LAUNCH_WG2(HomogeneousMediumSimple, false, kWg2PoolHomogT<0>, kWgBlockHomog, kWgWavesHomog);
 #undef VSPG_LAUNCH_WG2
             HIPCHK(hipGetLastError());
-            if (n_samples == 1)
+            if (single)
                 hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((r->npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
                                    r->npix, r->wave_samples, r->film, r->isg_stats);
-        } else
-        if (gwg)
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, true, kWgPoolGuided, kWgBlockGuided, kWgWavesGuided, kWgPoolGlobalGuided>),
-                               dim3((unsigned)wblocks), dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters, r->wg_gpool);
-        else if (grid)
-            hipLaunchKernelGGL((k_render_wave_wg<GridMedium, false, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid>),
-                               dim3((unsigned)wblocks), dim3(kWgBlockGrid), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters);
-        else if (r->medium_grey && r->surfaces_grey && r->null_zero)  // ... and the null-collision coefficient is exactly 0
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreySceneNullZero, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
-                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters, r->wg_gpool);
-        else if (r->medium_grey && r->surfaces_grey)  // ... and every Kd bitwise grey: beta is grey by construction too
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGreyScene, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
-                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters, r->wg_gpool);
-        else if (r->medium_grey)  // sigma_a, sigma_s, Le bitwise grey: the broadcast-spectrum instantiation
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumGrey, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
-                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters, r->wg_gpool);
-        else
-            hipLaunchKernelGGL((k_render_wave_wg<HomogeneousMediumSimple, false, kWgPoolHomog, kWgBlockHomog, kWgWavesHomog, kWgPoolGlobalHomog>),
-                               dim3((unsigned)wblocks), dim3(kWgBlockHomog), 0, (hipStream_t)stream, r->dscene, r->film,
-                               r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, n_samples == 1 ? 1 : 0, jump, tiles_magic,
-                               work_head, r->counters, r->wg_gpool);
+        } else {
+#define VSPG_LAUNCH_WG(M, NPOOL, BLK, WV)                                                                                            \
+    hipLaunchKernelGGL((k_render_wave_wg<M, false, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, work_head, r->counters)
+            if (grid) VSPG_LAUNCH_WG(GridMedium, kWgPoolGrid, kWgBlockGrid, kWgWavesGrid);
+            else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG(HomogeneousMediumGreySceneNullZero, kWgPoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);  // ... and the null-collision coefficient is exactly 0
+            else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG(HomogeneousMediumGreyScene, kWgPoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);  // ... and every Kd bitwise grey: beta is grey by construction too
+            else if (r->medium_grey) VSPG_LAUNCH_WG(HomogeneousMediumGrey, kWgPoolHomogT<1>, kWgBlockHomog, kWgWavesHomog);  // sigma_a, sigma_s, Le bitwise grey: the broadcast-spectrum instantiation
+            else VSPG_LAUNCH_WG(HomogeneousMediumSimple, kWgPoolHomogT<0>, kWgBlockHomog, kWgWavesHomog);
+#undef VSPG_LAUNCH_WG
+        }
     } else if (nvdb && guided) VSPG_LAUNCH_RENDER(NanoDenseMedium, true);
     else if (nvdb) VSPG_LAUNCH_RENDER(NanoDenseMedium, false);
     else if (grid && guided) VSPG_LAUNCH_RENDER(GridMedium, true);

@@ -23,7 +23,14 @@ namespace vspg {
 
 // DField::lobes, per region 1 + 2 GK float4:  [0] {pivot, n_lobes (int bits)}   [1 + 2k] {mu_k, distance_k}   [2 + 2k] {weight_k, b_k, kappa_k (clamped), vsp_k}
 constexpr int kRegionLobeQuads = 1 + 2 * GK;
-VDEV const float4 *region_lobes(const DField &F, int region) { return F.lobes + (size_t)region * kRegionLobeQuads; }
+// The records are read through a GLOBAL-address-space pointer: through the generic pointer a kernel argument's member is,
+// the compiler emits flat loads and waits for each one where it stands (seen in the ISA: sixteen exposed L2 round trips per
+// vertex); global loads can be issued ahead -- the loops below fetch lobe k + 1 while lobe k is being worked on.
+struct GlobalQuads {
+    const float4 *p;
+    VDEV float4 operator[](int i) const { return ld4_global(p + i); }
+};
+VDEV GlobalQuads region_lobes(const DField &F, int region) { return GlobalQuads{F.lobes + (size_t)region * kRegionLobeQuads}; }
 
 // light.SampleLi for the light the NEE picked: everything sample_Ld derives from (lightIndex, ul0, ul1) at this vertex
 struct NeePick {
@@ -39,20 +46,20 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
                               const VspgKdNode *kd_lds, Spec *L_out, IsgSample *isg_out) {
     constexpr bool kFull = !Medium::kSimpleScene;
     static_assert(!kFull, "the workgroup kernel's homogeneous instantiations are rectangle scenes with area lights");
+    constexpr int G = Medium::kGrey;
+    using LY = PoolLayout<true, G>;
     const bool volume_vertex = (fl & FL_VX_VOLUME) != 0;
     const int depth = (int)(fl & FL_DEPTH_MASK);
     const int ch = (int)((fl >> FL_CH_SHIFT) & 3u);
     const bool specularBounce = (fl & FL_SPECULAR) != 0;
     Sampler sampler;
-    sampler.rng.state = (uint64_t)P.u(PF_RNG + 0, slot) | ((uint64_t)P.u(PF_RNG + 1, slot) << 32);
-    sampler.rng.inc = (uint64_t)P.u(PF_RNG + 2, slot) | ((uint64_t)P.u(PF_RNG + 3, slot) << 32);
-    const Vertex vx = pool_load_vertex<true>(P, slot, fl);
+    pool_load_rng<LY>(P, slot, sampler);
+    const Vertex vx = pool_load_vertex<true, G>(P, slot, fl);
     PathState st;  // only ro / rd are read below (vertex_setup, the query point)
-    st.ro = P.v3(PF_RO, slot);
-    st.rd = P.v3(PF_RD, slot);
+    st.ro = P.v3(LY::RO, slot);
+    st.rd = P.v3(LY::RD, slot);
     VertexCtx c;
-    vertex_setup<false, false>(S, st, vx, c);
-    const V3 wo = -st.rd;
+    vertex_setup<(G >= 2), false>(S, st, vx, c);
     const float vg = vx.g;
 
     (void)sampler.get1d();  // v (the stochastic-lookup sample of Init)
@@ -72,21 +79,24 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
         ginit = c.bsdf.has_lobes;
         gprod = true;
         gm2 = c.si.n;
-        if (dot(wo, c.si.n) < 0.f) gm2 = -gm2;
+        if (dot(-st.rd, c.si.n) < 0.f) gm2 = -gm2;
         gk2 = kCosineLobeKappa;
     }
     DField F = S.field[0];
     if (gfield) F = S.field[1];
     int region = -1, n = 0;
-    const float4 *RL = nullptr;
-    V3 pivot = mk(0, 0, 0);
+    GlobalQuads RL = region_lobes(F, 0);
+    float4 q0n = make_float4(0, 0, 0, 0), q1n = q0n;  // the next lobe's two quads, in flight
+    V3 pp = mk(0, 0, 0);  // pivot - query point
     if (ginit) {
         const int nl = F.n_nodes < kKdLdsNodes ? F.n_nodes : kKdLdsNodes;
         region = field_lookup(F, gpoint, kd_lds + (gfield ? kKdLdsNodes : 0), nl);
         if (region >= 0) {
             RL = region_lobes(F, region);
             const float4 h = RL[0];
-            pivot = V3{h.x, h.y, h.z};
+            q0n = RL[1];  // lobe 0, issued with the header (every region record holds GK lobes, set or not)
+            q1n = RL[2];
+            pp = V3{h.x, h.y, h.z} - gpoint;
             n = __builtin_bit_cast(int, h.w);
             n = n < GK ? n : GK;
         }
@@ -98,7 +108,7 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
     // ---- survival probability of a volume vertex, BEFORE the NEE (:817-830) ---------------------------------------------
     float survivalProb = 1.f;
     if (volume_vertex && depth > S.prm.minrrdepth) {
-        const Spec rrw = (P.sp3(PF_BETA, slot) / avg(P.sp3(PF_RU, slot))) * P.f(PF_RRC, slot);
+        const Spec rrw = (pool_load_beta<LY, G>(P, slot) / avg(pool_load_ru<LY, G>(P, slot))) * P.f(LY::RRC, slot);
         survivalProb = specularBounce ? 0.95f : standard_throughput_rr(rrw);
     }
 
@@ -109,9 +119,9 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
     nee.ul0 = nee.ul1 = nee.sfPDF = 0.f;
     nee.wi = mk(0, 0, 0);
     const bool do_nee = S.prm.usenee && (volume_vertex || c.bsdf.has_lobes);
-    V3 ctxp = c.intr.pi.mid();
-    if (c.intr.is_surface && c.bsdf.has_lobes) ctxp = offset_ray_origin(c.intr.pi, c.intr.n, c.intr.wo);  // :1147-1149
     if (do_nee) {
+        V3 ctxp = c.intr.pi.mid();
+        if (c.intr.is_surface && c.bsdf.has_lobes) ctxp = offset_ray_origin(c.intr.pi, c.intr.n, c.intr.wo);  // :1147-1149
         const float u = sampler.get1d();
         const int n_all = S.n_lights;
         nee.ul0 = sampler.get1d();
@@ -173,13 +183,13 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
             if (volume_vertex) {
                 ang = hg_pre(vg, ua, ub, &a0, &a1);
             } else {
-                a1 = c.bsdf.frame.to_local(wo).z;
+                a1 = c.bsdf.frame.to_local(-st.rd).z;
                 okf = !(a1 == 0 || !c.bsdf.has_lobes);
                 ang = cos_hemi_pre(ua, ub, &a0, &degenerate);
             }
             const float sinA = sinf_(ang), cosA = cosf_(ang);
             if (volume_vertex) {
-                w0 = hg_post(wo, vg, a0, a1, sinA, cosA, &sf0);
+                w0 = hg_post(-st.rd, vg, a0, a1, sinA, cosA, &sf0);
                 ok0 = true;
             } else if (okf) {
                 V3 wl = cos_hemi_post(a0, degenerate, sinA, cosA);
@@ -199,6 +209,13 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
             s1 = sampler.get1d();
         }
     }
+    // the sampler and the NEE's pick wait in the pool while the lobes hold the registers: the record's RNG field (the state is
+    // written back at the end anyway) and the previous-vertex context (dead during a vertex: the tail below rewrites it)
+    pool_store_rng<LY>(P, slot, sampler);
+    P.i(LY::PCQ, slot) = nee.lightIndex;
+    P.f(LY::PCP + 0, slot) = nee.ul0;
+    P.f(LY::PCP + 1, slot) = nee.ul1;
+    P.f(LY::PCP + 2, slot) = nee.sfPDF;
     const bool cand1 = !dead && useGuiding && (ris || !sampleSF);
     const bool want_g_nee = nee.ok && useGuiding;                       // gdist_pdf at the NEE direction
     const bool want_g0 = !dead && useGuiding && ok0 && (ris || sampleSF);  // gdist_pdf at candidate 0
@@ -216,8 +233,12 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
         for (int k = 0; k < GK; ++k) {
             lr[k][0] = lr[k][1] = lr[k][2] = la[k] = lkc[k] = lc1[k] = lc2[k] = lwo[k] = 0.f;
             if (k < n) {
-                const float4 q0 = RL[1 + 2 * k], q1 = RL[2 + 2 * k];  // {mu, distance}, {weight, b, kappa, vsp}
-                const V3 raw = lobe_dir(pivot, V3{q0.x, q0.y, q0.z}, q0.w, gpoint);
+                const float4 q0 = q0n, q1 = q1n;  // {mu, distance}, {weight, b, kappa, vsp}
+                if (k + 1 < GK) {
+                    q0n = RL[3 + 2 * k];
+                    q1n = RL[4 + 2 * k];
+                }
+                const V3 raw = lobe_dir(pp, V3{q0.x, q0.y, q0.z}, q0.w);
                 float a = q1.y, wo_k = q1.x, kc = q1.z, c1 = 1.f, c2 = 0.f;
                 if (useGuiding && gprod) lobe_product(raw, q1.z, q1.y, gm2, gk2, nk2, &a, &wo_k, &kc, &c1, &c2);
                 lr[k][0] = raw.x; lr[k][1] = raw.y; lr[k][2] = raw.z;
@@ -281,17 +302,28 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
                     raw = V3{lr[j][0], lr[j][1], lr[j][2]};
                 }
             const V3 mz = c1 == 0.f && c2 == 0.f ? raw : raw * c1 + gm2 * c2;
+            const bool want_e1 = ris || useScatterGuiding;
+            float4 q1nn = q1n;
+            if (want_e1) {  // pass 2's first two region quads travel while the direction is being computed
+                q1n = RL[2];
+                q1nn = RL[4];  // (unconditional: a region record holds GK lobes, set or not -- no control flow around a load in flight)
+                __builtin_amdgcn_sched_barrier(0);
+            }
             w1 = vmf_sample_dir(s0, s1, acc, wk, kap, mz);
             const float x21 = dot(gm2, w1);
-            const bool want_e1 = ris || useScatterGuiding;
             float p1 = 0;
 #pragma unroll
             for (int k = 0; k < GK; ++k)
                 if (k < n) {
+                    const float4 q1 = q1n;
+                    q1n = q1nn;
+                    if (want_e1) {  // two lobes ahead: a lobe of this pass is ~50 instructions, an L2 round trip several hundred cycles
+                        if (k + 2 < GK) q1nn = RL[6 + 2 * k];
+                        __builtin_amdgcn_sched_barrier(0);  // (the load stays HERE, ahead of this lobe's arithmetic)
+                    }
                     const float x1 = dot(V3{lr[k][0], lr[k][1], lr[k][2]}, w1);
                     p1 += la[k] * fast_exp(lkc[k] * ((lc1[k] * x1 + lc2[k] * x21) - 1));
                     if (want_e1) {
-                        const float4 q1 = RL[2 + 2 * k];
                         const float e = q1.y * fast_exp(q1.z * (x1 - 1));
                         num1 += e * q1.w;
                         den1 += e;
@@ -301,8 +333,26 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
         }
     }
 
+    // ---- the vertex again: Interaction / BSDF are rebuilt from the pool record rather than carried across the lobes (the same
+    // function of the same inputs: same bits; `slot_b` is an opaque copy of the slot index so that the compiler does not
+    // merge the two evaluations into ~40 registers that live through both passes over the lobes)
+    int slot_b = slot;
+    asm volatile("" : "+v"(slot_b));
+    pool_load_rng<LY>(P, slot_b, sampler);
+    nee.lightIndex = P.i(LY::PCQ, slot_b);
+    nee.ul0 = P.f(LY::PCP + 0, slot_b);
+    nee.ul1 = P.f(LY::PCP + 1, slot_b);
+    nee.sfPDF = P.f(LY::PCP + 2, slot_b);
+    st.ro = P.v3(LY::RO, slot_b);
+    st.rd = P.v3(LY::RD, slot_b);
+    const Vertex vxb = pool_load_vertex<true, G>(P, slot_b, P.u(LY::FLAGS, slot_b));
+    vertex_setup<(G >= 2), false>(S, st, vxb, c);
+    const V3 wo = -st.rd;
+    V3 ctxp = c.intr.pi.mid();
+    if (c.intr.is_surface && c.bsdf.has_lobes) ctxp = offset_ray_origin(c.intr.pi, c.intr.n, c.intr.wo);
+
     // ---- NEE, second half: shadow ray, transmittance, the estimate (sample_Ld :1190-1251); L += beta * Ld ----------------
-    Spec L = P.sp3(PF_L, slot);
+    Spec L = P.sp3(LY::L, slot);
     if (nee.ok) {
         LightLi ls;
         (void)light_sample_li(light_quad_at(nee.lightIndex), ctxp, nee.ul0, nee.ul1, &ls);  // the same sample again: same bits
@@ -313,9 +363,12 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
         else f_hat = sp(nee.sfPDF);
         if (useGuiding) sfp = ((1.0f - kGuidingProbability) * sfp) + (kGuidingProbability * g_nee);
         const float scatterPDF = 1.0f * sfp;
-        const Spec r_p = P.sp3(PF_RU, slot);
+        const Spec r_p = pool_load_ru<LY, G>(P, slot);
         const Spec Ld = sample_Ld_shadow<Medium>(S, medium, c.intr, ch, ls, f_hat, p_l, scatterPDF, r_p, pc);
-        L = L + P.sp3(PF_BETA, slot) * Ld;
+        L = L + pool_load_beta<LY, G>(P, slot) * Ld;
+        pc.rec.add_scattered_direct_light(Ld);  // :485 / :838
+    } else if (do_nee) {
+        pc.rec.add_scattered_direct_light(sp(0.f));  // SampleLd ran and returned nothing: the hook is still called
     }
     if (dead) {
         *L_out = L;
@@ -399,11 +452,11 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
     }
 
     // ---- the path moves on (li_vertex_guided_impl's tail) ------------------------------------------------------------------
-    Spec beta = P.sp3(PF_BETA, slot);
+    Spec beta = pool_load_beta<LY, G>(P, slot);
     if (volume_vertex && rr_q > 0.f) beta = beta / (1 - rr_q);  // (:849; survivalProb < 1 <=> rr_q > 0)
-    const Spec r_u = P.sp3(PF_RU, slot);
+    const Spec r_u = pool_load_ru<LY, G>(P, slot);
     bool cont = false;
-    float rr_correction = P.f(PF_RRC, slot);
+    float rr_correction = P.f(LY::RRC, slot);
     V3 ro = mk(0, 0, 0);
     Spec r_l = sp(0.f);
     if (volume_vertex) {
@@ -412,6 +465,8 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
             beta = beta * w;
             r_l = r_u / pdf;
             ro = vx.p;
+            // guiding_addVolumeData(..., phaseFunctionWeight, ps->wi, ps->pdf, ps->meanCosine, survivalProb) (:871)
+            pc.rec.add_scatter_data(true, sp(w), wi, pdf, 1.0f - __builtin_fabsf(vg), survivalProb);
             cont = true;
         }
     } else if (have) {
@@ -431,6 +486,8 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
                 if (sampler.get1d() < qq) cont = false;
                 else beta = beta / (1 - qq);
             }
+            // guiding_addSurfaceData(..., bsdfWeight, bs->wi, bs->eta, bs->sampledRoughness, bs->pdf, survivalProb) (:608)
+            if (cont) pc.rec.add_scatter_data(false, bsdfWeight, wi, pdf, 1.0f, survivalProb);
         }
     }
     if (!cont) {
@@ -444,25 +501,25 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
         vsp_next = den > 0 ? num / den : -1.f;
     }
     // ---- what the vertex changed goes back to the pool (pool_store_full's fields, minus the ones it left alone) ----------
-    P.set3(PF_RO, slot, ro);
-    P.set3(PF_RD, slot, wi);
-    P.sets(PF_L, slot, L);
-    P.sets(PF_BETA, slot, beta);
-    P.sets(PF_RL, slot, r_l);
+    P.set3(LY::RO, slot, ro);
+    P.set3(LY::RD, slot, wi);
+    P.sets(LY::L, slot, L);
+    pool_store_beta<LY, G>(P, slot, beta);
+    pool_store_rl<LY, G>(P, slot, r_l);
     if (volume_vertex) {
-        P.set3(PF_PCP, slot, vx.p);
-        P.i(PF_PCQ, slot) = -1;
+        P.set3(LY::PCP, slot, vx.p);
+        P.i(LY::PCQ, slot) = -1;
     } else {
-        P.set3(PF_PCP, slot, c.si.p);
-        P.i(PF_PCQ, slot) = vx.quad;
+        P.set3(LY::PCP, slot, c.si.p);
+        P.i(LY::PCQ, slot) = vx.quad;
     }
-    pool_store_rng(P, slot, sampler);
-    P.f(PF_GS, slot) = vsp_next;
+    pool_store_rng<LY>(P, slot, sampler);
+    P.f(LY::GS, slot) = vsp_next;
     // depth / channel / ISG bits are unchanged by a vertex; specularBounce is cleared, lastVertexVolume set to the vertex kind
     uint32_t nfl = (fl & (FL_DEPTH_MASK | (3u << FL_CH_SHIFT) | FL_ISG_VALID | FL_ISG_SURF)) | FL_LIVE;
     if (volume_vertex) nfl |= FL_LASTVOL;
-    P.u(PF_FLAGS, slot) = nfl;
-    P.f(PF_RRC, slot) = rr_correction;
+    P.u(LY::FLAGS, slot) = nfl;
+    P.f(LY::RRC, slot) = rr_correction;
     (void)isg_out;
     return true;
 }

@@ -24,6 +24,15 @@ constexpr float kCosineLobeKappa = 2.18853f;
 constexpr float kGuidingProbability = 0.5f;  // guiding.h:348, 628
 constexpr float kUniformIncomingRadiancePDF = (float)(1.0f / (4.0f * 3.14159265358979323846));  // guiding.h:179
 
+#define VSPG_AS1 __attribute__((address_space(1)))
+typedef float vspg_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int vspg_v2u __attribute__((ext_vector_type(2)));
+// 16-byte / 8-byte loads through a global-address-space pointer (builtin vector types: a class type cannot be copied out of
+// another address space)
+VDEV float4 ld4_global(const void *p) {
+    const vspg_v4f v = *(const vspg_v4f VSPG_AS1 *)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 VDEV float vmf_norm(float kappa) { return kappa / (kTwoPi * (1 - fast_exp(-2 * kappa))); }
 VDEV float vmf_eval(V3 mu, float kappa, V3 w) { return vmf_norm(kappa) * fast_exp(kappa * (dot(mu, w) - 1)); }
 VDEV float kappa_clamp(float k) { return k < 1e-2f ? 1e-2f : (k > 1e4f ? 1e4f : k); }
@@ -35,7 +44,13 @@ VDEV int field_lookup(const DField &F, V3 p, const VspgKdNode *lds = nullptr, in
     if (!F.nodes || F.n_nodes <= 0) return -1;
     uint32_t node = 0;
     for (int depth = 0; depth < 64; ++depth) {
-        VspgKdNode nd = (int)node < n_lds ? lds[node] : F.nodes[node];
+        VspgKdNode nd;
+        if ((int)node < n_lds) nd = lds[node];
+        else {
+            const vspg_v2u v = *(const vspg_v2u VSPG_AS1 *)(F.nodes + node);
+            nd.split = __builtin_bit_cast(float, v.x);
+            nd.packed = v.y;
+        }
         uint32_t axis = nd.packed & 3u, idx = nd.packed >> 2;
         if (axis == 3u) return (int)idx < F.n_regions ? (int)idx : -1;
         float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
@@ -48,13 +63,18 @@ VDEV int field_lookup(const DField &F, V3 p, const VspgKdNode *lds = nullptr, in
 // are 32 bytes, 16-byte aligned): the lanes of a wavefront sit in unrelated regions, so every load instruction
 // costs one cache-line lookup per lane whatever its width -- the guided kernels were bound by exactly that.
 static_assert(sizeof(VspgFieldRegion) % 16 == 0 && offsetof(VspgFieldRegion, weight) % 16 == 0 && GK % 4 == 0, "16-byte rows");
-VDEV float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// (field data is read through GLOBAL-address-space pointers: through the generic pointers a kernel argument's members are, the
+//  compiler emits flat loads and waits for each where it stands)
+VDEV float4 ld4(const float *p) { return ld4_global(p); }
+VDEV float ld1g(const float *p) { return *(const float VSPG_AS1 *)p; }
+VDEV int ld1g(const int32_t *p) { return *(const int32_t VSPG_AS1 *)p; }
+VDEV V3 ld3g(const float *p) { return V3{ld1g(p), ld1g(p + 1), ld1g(p + 2)}; }
 VDEV float c4(float4 v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }  // j is a compile-time constant after unrolling
 // the region's lobe re-aimed at the query point; normalised with ONE reciprocal (round 3: was three IEEE divisions)
-VDEV V3 lobe_dir(V3 pivot, V3 mu, float d, V3 p) {
+// pp = pivot - p (one subtraction per vertex, not per lobe)
+VDEV V3 lobe_dir(V3 pp, V3 mu, float d) {
     if (!(d > 0) || isinf_(d)) return mu;
-    V3 src = pivot + mu * d;
-    V3 t = src - p;
+    V3 t = pp + mu * d;
     float l2 = len2(t);
     if (!(l2 > 0)) return mu;
     const float inv = 1.0f / __builtin_sqrtf(l2);
@@ -127,7 +147,7 @@ VDEV void lobe_product(V3 raw, float kr, float b, V3 m2, float k2, float nk2, fl
 // fills `d` in place (d.st is set by the caller for the LDS home; the register home is never copied: a by-value copy of the
 // array would pin it in scratch memory)
 #ifndef VSPG_KD_LDS
-#define VSPG_KD_LDS 1024
+#define VSPG_KD_LDS 256
 #endif
 constexpr int kKdLdsNodes = VSPG_KD_LDS;  // nodes per field staged in LDS by the workgroup kernel (8 B each)
 template <class ST>
@@ -151,12 +171,13 @@ VDEV void gdist_init(GDistT<ST> &d, const DField *fields, int f, V3 p, bool have
     }
     if (d.region < 0) return;
     const VspgFieldRegion &R = F.regions[d.region];
-    if (R.n_lobes <= 0) return;
+    const int n_lobes = ld1g(&R.n_lobes);
+    if (n_lobes <= 0) return;
     d.ok = true;
-    d.n = R.n_lobes < GK ? R.n_lobes : GK;
+    d.n = n_lobes < GK ? n_lobes : GK;
     const float *ax = region_aux(F, d.region);  // [k] b_k = weight_k * vmf_norm(kappa_k), [GK + k] kappa_k (clamped)
     const float nk2 = have_product ? vmf_norm(k2) : 0.f;
-    const V3 pivot = ld3(R.pivot);
+    const V3 pp = ld3g(R.pivot) - p;
     float sum = 0;
 #pragma unroll
     for (int h = 0; h < GK; h += 4) {
@@ -167,7 +188,7 @@ VDEV void gdist_init(GDistT<ST> &d, const DField *fields, int f, V3 p, bool have
             for (int j = 0; j < 4; ++j) {
                 const int k = h + j;
                 if (k < d.n) {
-                    const V3 raw = lobe_dir(pivot, V3{c4(mx4, j), c4(my4, j), c4(mz4, j)}, c4(d4, j), p);
+                    const V3 raw = lobe_dir(pp, V3{c4(mx4, j), c4(my4, j), c4(mz4, j)}, c4(d4, j));
                     d.set_raw(k, raw);
                     float a = c4(b4, j), wo = c4(w4, j), kc = c4(k4, j), c1 = 1.f, c2 = 0.f;
                     if (have_product) lobe_product(raw, c4(k4, j), c4(b4, j), m2, k2, nk2, &a, &wo, &kc, &c1, &c2);
@@ -183,7 +204,7 @@ VDEV void gdist_init(GDistT<ST> &d, const DField *fields, int f, V3 p, bool have
         d.isum = 1.f;
 #pragma unroll
         for (int k = 0; k < GK; ++k)
-            if (k < d.n) d.set_lobe(k, ax[k], ax[GK + k], 1.f, 0.f, R.weight[k]);
+            if (k < d.n) d.set_lobe(k, ld1g(ax + k), ld1g(ax + GK + k), 1.f, 0.f, ld1g(R.weight + k));
     }
 #pragma unroll
     for (int k = 0; k < GK; ++k)
@@ -285,7 +306,8 @@ VDEV float gdist_vsp(const DField *fields, int f, int region, const GDistT<ST> &
     if (f) F = fields[1];
     const VspgFieldRegion &R = F.regions[region];
     const float *ax = region_aux(F, region);
-    int n = R.n_lobes < GK ? R.n_lobes : GK;
+    const int n_lobes = ld1g(&R.n_lobes);
+    int n = n_lobes < GK ? n_lobes : GK;
     float num = 0, den = 0;
 #pragma unroll
     for (int h = 0; h < GK; h += 4) {

@@ -22,34 +22,36 @@
 namespace vspg {
 
 // ---- LDS pool record (field-major SoA: field f of slot s at base[f * NP + s]) ----------------
-enum {
-    PF_RO = 0,        // 3
-    PF_RD = 3,        // 3
-    PF_L = 6,         // 3
-    PF_BETA = 9,      // 3
-    PF_RU = 12,       // 3
-    PF_RL = 15,       // 3
-    PF_PCP = 18,      // 3  previous light-sample context: raw point
-    PF_PCQ = 21,      // 1  ... its rectangle (int), -1 = medium vertex (exact point, n = 0)
-    PF_RNG = 22,      // 4  sampler PCG state / inc (2 x u64)
-    PF_FLAGS = 26,    // 1  packed: depth, ch, bools, life cycle
-    PF_RRC = 27,      // 1  rr_correction
-    PF_PIXEL = 28,    // 1  pixel index (int)
-    PF_SAMPLE = 29,   // 1  sample index (int)
-    PF_VSP = 30,      // 1  isg.vsp_used (the primary VSP itself never leaves the primary phase)
-    PF_VXG = 31,      // 1  vertex: volume: g; surface: rectangle index (int)
-    PF_VXT = 32,      // 1  vertex: surface tHit
-    PF_GS = 33,       // 4  guided builds: gs.vsp_next (1 used)
-    PF_COUNT = 37,
-    // The vertex position lives only from the segment phase to the vertex phase, the ray origin only
-    // from the vertex phase to the next segment phase (the unguided vertex code never reads the old
-    // origin): they share three dwords.  480 -> 512 paths fit the 80 KB a workgroup may use.
-    PF_VXP = PF_RO,
-    // guided builds: gbsdf.init queries the cache at ray.o + tHit * ray.d (guiding.h:85), so the origin must survive
-    PF_VXP_GUIDED = 37,  // 3
-    PF_COUNT_GUIDED = 40
+// The record is laid out per kernel instantiation (round 3): a grey medium parks ONE channel of r_u / r_l (GREY >= 1) and, with
+// grey surfaces, of beta (GREY >= 2) -- see HomogeneousMediumT -- and the fields those instantiations do not store take no
+// room, so more paths fit the LDS a workgroup may use (the pool's size is what the phases' list lengths, i.e. the wavefronts'
+// occupancy with work, hang on: 320 -> 384 paths took the guided kernel from 2.14 to 1.86 ms per wave).
+//   unguided: 33 dwords generic, 29 with a grey medium, 27 with grey surfaces too;  guided: 37 / 33 / 31.
+template <bool GUIDED, int GREY>
+struct PoolLayout {
+    static constexpr int RO = 0;                                  // 3
+    static constexpr int RD = 3;                                  // 3
+    static constexpr int L = 6;                                   // 3
+    static constexpr int BETA = 9;                                // 3 (1 with grey surfaces)
+    static constexpr int RU = BETA + (GREY >= 2 ? 1 : 3);         // 3 (1 in a grey medium)
+    static constexpr int RL = RU + (GREY >= 1 ? 1 : 3);           // 3 (1)
+    static constexpr int PCP = RL + (GREY >= 1 ? 1 : 3);          // 3  previous light-sample context: raw point
+    static constexpr int PCQ = PCP + 3;                           // 1  ... its rectangle (int), -1 = medium vertex (exact point, n = 0)
+    static constexpr int RNG = PCQ + 1;                           // 4  sampler PCG state / inc (2 x u64)
+    static constexpr int FLAGS = RNG + 4;                         // 1  packed: depth, ch, bools, life cycle
+    static constexpr int RRC = FLAGS + 1;                         // 1  rr_correction
+    static constexpr int PIXEL = RRC + 1;                         // 1  pixel (x | y << 16)
+    static constexpr int SAMPLE = PIXEL + 1;                      // 1  sample index (int)
+    static constexpr int VSP = SAMPLE + 1;                        // 1  isg.vsp_used (the primary VSP itself never leaves the primary phase)
+    static constexpr int VXG = VSP + 1;                           // 1  vertex: volume: g; surface: rectangle index (int)
+    static constexpr int VXT = VXG + 1;                           // 1  vertex: surface tHit
+    static constexpr int GS = VXT + 1;                            // 1  guided builds: gs.vsp_next
+    // The vertex position lives only from the segment phase to the vertex phase, the ray origin only from the vertex phase to
+    // the next segment phase (the unguided vertex code never reads the old origin): they share three dwords.  Guided builds:
+    // gbsdf.init queries the cache at ray.o + tHit * ray.d (guiding.h:85), so the origin must survive.
+    static constexpr int VXP = GUIDED ? GS + 1 : RO;              // 3
+    static constexpr int COUNT = GUIDED ? VXP + 3 : GS;
 };
-template <bool GUIDED> struct PoolVx { static constexpr int kField = GUIDED ? (int)PF_VXP_GUIDED : (int)PF_VXP; };
 enum {
     FL_DEPTH_MASK = 0xff,
     FL_CH_SHIFT = 8,            // 2 bits
@@ -85,105 +87,125 @@ VDEV uint32_t pool_pack_flags(const PathState &st, int ch, const IsgSample &isg,
     if (isg.surface_event) fl |= FL_ISG_SURF;
     return fl;
 }
+template <class LY>
 VDEV void pool_store_rng(const Pool &P, int slot, const Sampler &sampler) {
-    P.u(PF_RNG + 0, slot) = (uint32_t)sampler.rng.state;
-    P.u(PF_RNG + 1, slot) = (uint32_t)(sampler.rng.state >> 32);
-    P.u(PF_RNG + 2, slot) = (uint32_t)sampler.rng.inc;
-    P.u(PF_RNG + 3, slot) = (uint32_t)(sampler.rng.inc >> 32);
+    P.u(LY::RNG + 0, slot) = (uint32_t)sampler.rng.state;
+    P.u(LY::RNG + 1, slot) = (uint32_t)(sampler.rng.state >> 32);
+    P.u(LY::RNG + 2, slot) = (uint32_t)sampler.rng.inc;
+    P.u(LY::RNG + 3, slot) = (uint32_t)(sampler.rng.inc >> 32);
+}
+template <class LY>
+VDEV void pool_load_rng(const Pool &P, int slot, Sampler &sampler) {
+    sampler.rng.state = (uint64_t)P.u(LY::RNG + 0, slot) | ((uint64_t)P.u(LY::RNG + 1, slot) << 32);
+    sampler.rng.inc = (uint64_t)P.u(LY::RNG + 2, slot) | ((uint64_t)P.u(LY::RNG + 3, slot) << 32);
 }
 
 // everything a path carries into its next segment (after the primary segment and after a vertex)
 // GREY (grey medium, see HomogeneousMediumT): r_u and r_l are grey by construction -- one channel is parked
 // and broadcast on load, which also tells the compiler that the three channels are one value
-template <int GREY>
-VDEV void pool_store_beta(const Pool &P, int slot, const PathState &st) {
-    if constexpr (GREY >= 2) P.f(PF_BETA, slot) = st.beta.r;
-    else P.sets(PF_BETA, slot, st.beta);
+template <class LY, int GREY>
+VDEV void pool_store_beta(const Pool &P, int slot, Spec beta) {
+    if constexpr (GREY >= 2) P.f(LY::BETA, slot) = beta.r;
+    else P.sets(LY::BETA, slot, beta);
 }
-template <int GREY>
+template <class LY, int GREY>
+VDEV Spec pool_load_beta(const Pool &P, int slot) { return GREY >= 2 ? sp(P.f(LY::BETA, slot)) : P.sp3(LY::BETA, slot); }
+template <class LY, int GREY>
+VDEV Spec pool_load_ru(const Pool &P, int slot) { return GREY >= 1 ? sp(P.f(LY::RU, slot)) : P.sp3(LY::RU, slot); }
+template <class LY, int GREY>
+VDEV void pool_store_rl(const Pool &P, int slot, Spec r_l) {
+    if constexpr (GREY >= 1) P.f(LY::RL, slot) = r_l.r;
+    else P.sets(LY::RL, slot, r_l);
+}
+template <class LY, int GREY>
 VDEV void pool_store_ru_rl(const Pool &P, int slot, const PathState &st) {
     if constexpr (GREY >= 1) {
-        P.f(PF_RU, slot) = st.r_u.r;
-        P.f(PF_RL, slot) = st.r_l.r;
+        P.f(LY::RU, slot) = st.r_u.r;
+        P.f(LY::RL, slot) = st.r_l.r;
     } else {
-        P.sets(PF_RU, slot, st.r_u);
-        P.sets(PF_RL, slot, st.r_l);
+        P.sets(LY::RU, slot, st.r_u);
+        P.sets(LY::RL, slot, st.r_l);
     }
 }
 template <bool GUIDED, int GREY = 0>
 VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                           uint32_t keep_flags) {
-    P.set3(PF_RO, slot, st.ro);
-    P.set3(PF_RD, slot, st.rd);
-    P.sets(PF_L, slot, st.L);
-    pool_store_beta<GREY>(P, slot, st);
-    pool_store_ru_rl<GREY>(P, slot, st);
-    P.set3(PF_PCP, slot, st.prevCtx.p);
-    P.i(PF_PCQ, slot) = st.prevCtx.quad;
-    pool_store_rng(P, slot, sampler);
+    using LY = PoolLayout<GUIDED, GREY>;
+    P.set3(LY::RO, slot, st.ro);
+    P.set3(LY::RD, slot, st.rd);
+    P.sets(LY::L, slot, st.L);
+    pool_store_beta<LY, GREY>(P, slot, st.beta);
+    pool_store_ru_rl<LY, GREY>(P, slot, st);
+    P.set3(LY::PCP, slot, st.prevCtx.p);
+    P.i(LY::PCQ, slot) = st.prevCtx.quad;
+    pool_store_rng<LY>(P, slot, sampler);
     uint32_t fl = pool_pack_flags(st, ch, isg, keep_flags);
     if constexpr (GUIDED) {
-        P.f(PF_GS, slot) = st.gs.vsp_next;
+        P.f(LY::GS, slot) = st.gs.vsp_next;
     }
-    P.u(PF_FLAGS, slot) = fl;
-    P.f(PF_RRC, slot) = st.rr_correction;
-    P.f(PF_VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
+    P.u(LY::FLAGS, slot) = fl;
+    P.f(LY::RRC, slot) = st.rr_correction;
+    P.f(LY::VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
 }
 
-template <bool GUIDED = false>
+template <bool GUIDED = false, int GREY = 0>
 VDEV void pool_store_vertex(const Pool &P, int slot, const Vertex &vx) {
-    P.set3(PoolVx<GUIDED>::kField, slot, vx.p);
-    if (vx.volume) P.f(PF_VXG, slot) = vx.g; else P.i(PF_VXG, slot) = vx.quad;
-    P.f(PF_VXT, slot) = vx.t;
+    using LY = PoolLayout<GUIDED, GREY>;
+    P.set3(LY::VXP, slot, vx.p);
+    if (vx.volume) P.f(LY::VXG, slot) = vx.g; else P.i(LY::VXG, slot) = vx.quad;
+    P.f(LY::VXT, slot) = vx.t;
 }
 // after li_segment_a: only what that half changes (L, beta, r_u, r_l, sampler, depth / ISG flags) plus
 // the vertex it stopped at; ray, previous context, rr_correction and guiding state are untouched
 template <int GREY = 0, bool GUIDED = false>
 VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                        const Vertex &vx, uint32_t keep_flags) {
-    P.sets(PF_L, slot, st.L);
-    pool_store_beta<GREY>(P, slot, st);
-    pool_store_ru_rl<GREY>(P, slot, st);
-    pool_store_rng(P, slot, sampler);
+    using LY = PoolLayout<GUIDED, GREY>;
+    P.sets(LY::L, slot, st.L);
+    pool_store_beta<LY, GREY>(P, slot, st.beta);
+    pool_store_ru_rl<LY, GREY>(P, slot, st);
+    pool_store_rng<LY>(P, slot, sampler);
     uint32_t fl = pool_pack_flags(st, ch, isg, keep_flags);
     if (vx.volume) fl |= FL_VX_VOLUME;
-    P.u(PF_FLAGS, slot) = fl;
-    P.f(PF_VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
-    pool_store_vertex<GUIDED>(P, slot, vx);
+    P.u(LY::FLAGS, slot) = fl;
+    P.f(LY::VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
+    pool_store_vertex<GUIDED, GREY>(P, slot, vx);
 }
-template <bool GUIDED = false>
+template <bool GUIDED = false, int GREY = 0>
 VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
+    using LY = PoolLayout<GUIDED, GREY>;
     Vertex vx;
     vx.volume = (fl & FL_VX_VOLUME) != 0;
-    vx.p = P.v3(PoolVx<GUIDED>::kField, slot);
-    vx.g = vx.volume ? P.f(PF_VXG, slot) : 0.f;
-    vx.quad = vx.volume ? -1 : P.i(PF_VXG, slot);
+    vx.p = P.v3(LY::VXP, slot);
+    vx.g = vx.volume ? P.f(LY::VXG, slot) : 0.f;
+    vx.quad = vx.volume ? -1 : P.i(LY::VXG, slot);
     __builtin_assume(vx.quad >= -1);
-    vx.t = P.f(PF_VXT, slot);
+    vx.t = P.f(LY::VXT, slot);
     vx.perr = vx.volume ? mk(0, 0, 0) : ld3(quad_at(vx.quad).perr);
     return vx;
 }
 
 template <bool GUIDED, int GREY = 0>
 VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st, Sampler &sampler, int *ch, IsgSample &isg) {
-    st.ro = P.v3(PF_RO, slot);
-    st.rd = P.v3(PF_RD, slot);
-    st.L = P.sp3(PF_L, slot);
-    st.beta = GREY >= 2 ? sp(P.f(PF_BETA, slot)) : P.sp3(PF_BETA, slot);
+    using LY = PoolLayout<GUIDED, GREY>;
+    st.ro = P.v3(LY::RO, slot);
+    st.rd = P.v3(LY::RD, slot);
+    st.L = P.sp3(LY::L, slot);
+    st.beta = GREY >= 2 ? sp(P.f(LY::BETA, slot)) : P.sp3(LY::BETA, slot);
     if constexpr (GREY >= 1) {
-        st.r_u = sp(P.f(PF_RU, slot));
-        st.r_l = sp(P.f(PF_RL, slot));
+        st.r_u = sp(P.f(LY::RU, slot));
+        st.r_l = sp(P.f(LY::RL, slot));
     } else {
-        st.r_u = P.sp3(PF_RU, slot);
-        st.r_l = P.sp3(PF_RL, slot);
+        st.r_u = P.sp3(LY::RU, slot);
+        st.r_l = P.sp3(LY::RL, slot);
     }
-    st.prevCtx.p = P.v3(PF_PCP, slot);
-    st.prevCtx.quad = P.i(PF_PCQ, slot);
+    st.prevCtx.p = P.v3(LY::PCP, slot);
+    st.prevCtx.quad = P.i(LY::PCQ, slot);
     st.prevCtx.perr = mk(0, 0, 0);  // (triangle scenes run the per-lane / wavefront kernels)
     __builtin_assume(st.prevCtx.quad >= -1);
-    sampler.rng.state = (uint64_t)P.u(PF_RNG + 0, slot) | ((uint64_t)P.u(PF_RNG + 1, slot) << 32);
-    sampler.rng.inc = (uint64_t)P.u(PF_RNG + 2, slot) | ((uint64_t)P.u(PF_RNG + 3, slot) << 32);
-    const uint32_t fl = P.u(PF_FLAGS, slot);
+    sampler.rng.state = (uint64_t)P.u(LY::RNG + 0, slot) | ((uint64_t)P.u(LY::RNG + 1, slot) << 32);
+    sampler.rng.inc = (uint64_t)P.u(LY::RNG + 2, slot) | ((uint64_t)P.u(LY::RNG + 3, slot) << 32);
+    const uint32_t fl = P.u(LY::FLAGS, slot);
     st.depth = (int)(fl & FL_DEPTH_MASK);
     *ch = (int)((fl >> FL_CH_SHIFT) & 3u);
     st.specularBounce = (fl & FL_SPECULAR) != 0;
@@ -191,13 +213,13 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     st.lastVertexVolume = (fl & FL_LASTVOL) != 0;
     isg.valid = (fl & FL_ISG_VALID) != 0;
     isg.surface_event = (fl & FL_ISG_SURF) != 0;
-    st.rr_correction = P.f(PF_RRC, slot);
+    st.rr_correction = P.f(LY::RRC, slot);
     st.etaScale = 1;
-    const float v = P.f(PF_VSP, slot);
+    const float v = P.f(LY::VSP, slot);
     st.vsp0 = v;
     isg.vsp_used = st.depth == 0 ? -1.f : v;
     if constexpr (GUIDED) {
-        st.gs.vsp_next = P.f(PF_GS, slot);
+        st.gs.vsp_next = P.f(LY::GS, slot);
         st.pce = 0.f;        // (guided RR is served by the per-lane kernels)
         st.guideRR = false;
     } else {
