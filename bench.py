@@ -28,6 +28,12 @@ The JSON line carries
                  difference, and the relMSE of each against a 16x-spp render (noise floor).
   generic_instantiation : the same workload through the kernel instantiation a chromatic medium
                  takes (no grey-spectrum / zero-null-coefficient specialisation), untimed for `value`.
+  reference_defaults : the same scene with the reference's DEFAULT integrator options (surface RIS + volume MIS
+                 guiding, primary + secondary VSP: the cache query in the loop) -- trained-wave Mpaths/s, training-wave
+                 ms and the effective rate of a 256-spp frame whose first 128 waves train; untimed for `value`.
+  roofline.issue_bound / roofline.traffic : counters of THIS run -- bench.py profiles itself first (three short
+                 `rocprofv3 --pmc` child runs of the same workload, before this process touches the GPU): vector
+                 instructions per launch, lane utilisation, the issue fraction they price to, HBM bytes per launch.
 """
 import argparse
 import ctypes as C
@@ -81,6 +87,51 @@ def pmc_traffic_bytes(workload, W, H):
             # WRITE_SIZE is exact for 16-B-per-lane and dword stores.  Both KiB per launch.
             best = (2.0 * pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
     return best
+
+
+PMC_GROUPS = (["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES"], ["FETCH_SIZE"], ["WRITE_SIZE"])
+# scripts/microbench/issue.hip on MI355X (profiles/r03_microbench_issue.txt): SIMD cycles one wave-instruction of a path-kernel-like
+# mix costs with four waves per SIMD issuing (the hardware floor is 2: MI355X_MICROARCH.md, wave scheduling), and the clock the chip held
+ISSUE_CYCLES_PER_INST = 2.47
+ISSUE_CLOCK_GHZ = 2.38
+
+
+def live_pmc(args):
+    """Counters of this run's workload: rocprofv3 --pmc child runs of `bench.py --pmc-child` (own passes per counter group:
+    FETCH_SIZE and WRITE_SIZE do not share one, MI355X_MICROARCH.md), started BEFORE this process touches the GPU.  Returns
+    {kernel name: {counter: mean per launch}} over the workload's path kernels, or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not found"
+    if args.workload.endswith("-guided"):
+        return None, "live counters are taken for the unguided workloads (a guided run mixes training and trained launches)"
+    agg = {}
+    for group in PMC_GROUPS:
+        d = tempfile.mkdtemp(prefix="vspg_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc"] + group + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+               "--workload", args.workload, "--xres", str(args.xres), "--yres", str(args.yres), "--grid", str(args.grid), "--steps", "3", "--warmup", "2",
+               "--train-waves", str(min(args.train_waves, 8))]
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        except Exception as e:  # noqa: BLE001
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 child: %s" % e
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if res.returncode != 0 or not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 child rc=%d: %s" % (res.returncode, res.stdout[-300:])
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                k = row["Kernel_Name"]
+                if "k_render_wave" not in k and "k_wf_" not in k:
+                    continue
+                agg.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in agg.items()}, None
 
 
 class DevArray:
@@ -206,6 +257,9 @@ def parse_args():
                     help="DIAGNOSTIC ONLY (not the benchmark config): override maxdepth to time parts of the path")
     ap.add_argument("--train-waves", type=int, default=16, help="fog-guided: in-loop training waves before the timed region")
     ap.add_argument("--grid", type=int, default=256, help="voxels per axis of the cloud workload's density grid")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the self-profiling child runs (roofline.issue_bound / live traffic)")
+    ap.add_argument("--no-reference-defaults", action="store_true", help="skip the reference-default-options leg of the default line")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 watches: waves only, no output
     return ap.parse_args()
 
 
@@ -219,6 +273,11 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
+
+    # self-profiling (rank 0 of a 1-GPU run): child processes, before anything here has touched the GPU
+    pmc, pmc_note = None, "skipped"
+    if not args.pmc_child and not args.no_pmc and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.diag_maxdepth is None:
+        pmc, pmc_note = live_pmc(args)
 
     import torch
     import torch.distributed as dist
@@ -286,6 +345,17 @@ def main():
         step0 = args.train_waves
     for i in range(args.warmup):
         step(step0 + i)
+    if args.pmc_child:  # the waves rocprofv3 counts: the timed loop's launches, nothing else
+        for i in range(args.steps):
+            step(step0 + args.warmup + i)
+        torch.cuda.synchronize()
+        r.close()
+        return
+    ranks_seen = None
+    if world > 1:  # launch check: every rank of the communicator answers (an all-reduce of ones)
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if rehearse else torch.device("cuda", local_rank))
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
     # untimed: first use of the communicator at the film's size (RCCL sets up channels / buffers lazily)
     sh.frame_end_allreduce(dist, film, world)
     torch.cuda.synchronize()
@@ -321,12 +391,42 @@ def main():
     r.close()
 
     if rank == 0:
-        traffic_bytes = pmc_traffic_bytes(args.workload, W, H)
         kbar = segs_rank / max(1, paths_rank)
         dq_rank = cnt["density_queries"] if not fog else 0
         bytes_per_launch = (segs_rank * B_SEGMENT + paths_rank * B_PATH_FIXED + dq_rank * B_DENSITY_QUERY) / max(1, args.steps)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         diag = args.diag_maxdepth is not None
+        pipeline = not fog  # heterogeneous media: the four-kernel wavefront pipeline, kern_ms spans all its launches of a wave
+        # ---- this run's counters (live_pmc): per WAVE over the workload's path kernels
+        traffic_bytes, traffic_src, issue = None, None, None
+        if pmc:
+            def per_wave(counter):
+                tot, seen = 0.0, False
+                for cs in pmc.values():
+                    if counter in cs:
+                        mean, n = cs[counter]
+                        tot += mean * n / 5.0   # the child ran 2 warm-up + 3 timed waves; a pipeline kernel launches several times per wave
+                        seen = True
+                return tot if seen else None
+            fs, ws = per_wave("FETCH_SIZE"), per_wave("WRITE_SIZE")
+            if fs is not None and ws is not None:
+                # gfx950 correction of the microarch guide: FETCH_SIZE tallies 128-B read requests at 64 B -> x2; both in KiB
+                traffic_bytes = (2.0 * fs + ws) * 1024.0
+                traffic_src = "this run: rocprofv3 --pmc child passes (FETCH_SIZE x2 + WRITE_SIZE), per wave over the path kernels"
+            insts, act, thr = per_wave("SQ_INSTS_VALU"), per_wave("SQ_ACTIVE_INST_VALU"), per_wave("SQ_THREAD_CYCLES_VALU")
+            if insts and act and thr and kern_ms > 0:
+                n_simd = torch.cuda.get_device_properties(local_rank).multi_processor_count * 4
+                cyc = kern_ms * 1e-3 * ISSUE_CLOCK_GHZ * 1e9
+                issue = {"valu_insts_per_launch": insts, "lane_util": thr / (64.0 * act),
+                         "est_issue_frac": insts / n_simd * ISSUE_CYCLES_PER_INST / cyc,
+                         "est_issue_frac_at_2_cycle_floor": insts / n_simd * 2.0 / cyc,
+                         "cycles_per_wave_inst": ISSUE_CYCLES_PER_INST, "clock_ghz": ISSUE_CLOCK_GHZ, "simds": n_simd,
+                         "note": "vector wave-instructions of one wave's launches (SQ_INSTS_VALU) / SIMDs x the measured price of a path-kernel-like "
+                                 "mix at four waves per SIMD (profiles/r03_microbench_issue.txt) / kernel cycles: the fraction of the time the vector "
+                                 "pipes issue.  lane_util = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU).  This, not HBM, is what bounds the kernel"}
+        if traffic_bytes is None:
+            traffic_bytes = pmc_traffic_bytes(args.workload, W, H)
+            traffic_src = "committed profile taken on these kernel sources (profiles/*_pmc_*.json)" if traffic_bytes else None
         if args.workload == "fog":
             metric = "Mpaths/sec on 1920x1080 homogeneous fog; relMSE vs CPU ref at equal spp"
             wl = "fog-box %dx%d, guidedvolpathvspg vspguiding=true (primary-ray VSP; App. F options)" % (W, H)
@@ -341,6 +441,13 @@ def main():
             if guided:  # config 5's shape: secondary-ray VSP + cache train + query on a heterogeneous medium
                 wl += ("; the reference's default options (surface RIS + volume MIS guiding, primary + secondary VSP), field trained "
                        "in-loop for %d waves before the timed region" % args.train_waves)
+        if pipeline:
+            note = ("achieved = ALGORITHMIC bytes (SURVEY 8d: 256 B per segment + 76 B per path + 36 B per density query) / the time of one "
+                    "wave's launches of the wavefront pipeline (k_wf_advance, k_wf_dist_walk, k_wf_seg_end, k_wf_shadow_walk x (maxdepth + 2) "
+                    "iterations; the path records live in HBM): `kernel` names the pipeline by its walk kernel, `kernel_ms` is the whole wave")
+        else:
+            note = ("achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time: the path state lives in LDS, so this is a notional rate -- the "
+                    "kernel is bound by vector issue and latency (issue_bound), not by HBM")
         out = {
             "metric": metric,
             "value": paths_total / elapsed / 1e6,
@@ -361,13 +468,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic_bytes / (kern_ms * 1e-3) / 1e9) if traffic_bytes and kern_ms > 0 else None,
-                         "traffic_bytes_per_launch": traffic_bytes,
-                         "kernel": kernel_name, "kernel_ms": kern_ms, "density_queries_per_path": dq_rank / max(1, paths_rank),
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time: the path state lives in LDS, so this is a notional "
-                                 "rate; traffic = measured HBM bytes (PMC FETCH_SIZE x2 + WRITE_SIZE) of the committed profile taken on "
-                                 "these kernel sources, null when the sources changed since"},
+                         "traffic_bytes_per_launch": traffic_bytes, "traffic_source": traffic_src,
+                         "issue_bound": issue, "pmc_note": pmc_note,
+                         "kernel": ("wavefront pipeline: " if pipeline else "") + kernel_name, "kernel_ms": kern_ms,
+                         "density_queries_per_path": dq_rank / max(1, paths_rank),
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "note": note},
         }
+        if ranks_seen is not None:
+            out["rccl_ranks_seen"] = ranks_seen
         if train_ms is not None:
             out["training"] = {"waves": args.train_waves, "ms_per_wave": train_ms,
                                "note": "render with segment recording + PropagateSamples + Field::Update, host-timed, untimed for value"}
@@ -395,6 +503,49 @@ def main():
             out["generic_instantiation"] = {"value": g.counters()["paths"] / tg / 1e6, "unit": "Mpaths/s", "steps": 16,
                                             "kernel_ms": sum(a.elapsed_time(b) for a, b in gev) / 16, "kernel": g.kernel_name(),
                                             "note": "same scene through the instantiation a chromatic medium / coloured walls take"}
+            g.close()
+        if args.workload == "fog" and not args.no_reference_defaults and world == 1 and not diag:
+            # the configuration a `guidedvolpathvspg` user gets by default (:1263-1319): directional guiding + secondary-ray VSP,
+            # i.e. the cache query in the loop.  The field trains in-loop for the first waves, like the reference's first 128.
+            dprm = pkg.default_params()
+            n_train, n_meas = 32, 16
+            dprm.guide_num_training_waves = n_train
+            g = pkg.Renderer(scene, dprm, W, H, spp=n_train + 4 + n_meas, seed=0, device=local_rank)
+            train_kernel = g.kernel_name()
+            tms = []
+            for i in range(n_train):
+                torch.cuda.synchronize()
+                tt = time.perf_counter()
+                g.render_wave(i, i + 1, stream)
+                g.post_process_wave(stream)
+                torch.cuda.synchronize()
+                tms.append((time.perf_counter() - tt) * 1e3)
+            for i in range(4):
+                g.render_wave(n_train + i, n_train + i + 1, stream)
+                g.post_process_wave(stream)
+            g.reset_counters(stream)
+            gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_meas)]
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for i in range(n_meas):
+                gev[i][0].record()
+                g.render_wave(n_train + 4 + i, n_train + 5 + i, stream)
+                gev[i][1].record()
+                g.post_process_wave(stream)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            gcnt = g.counters()
+            trained_ms = tg / n_meas * 1e3
+            train_ms_late = sum(tms[n_train // 2:]) / (n_train - n_train // 2)
+            out["reference_defaults"] = {
+                "value": gcnt["paths"] / tg / 1e6, "unit": "Mpaths/s (trained waves)", "steps": n_meas, "ms_per_trained_wave": trained_ms,
+                "kernel_ms": sum(a.elapsed_time(b) for a, b in gev) / n_meas, "kernel": g.kernel_name(),
+                "training": {"waves": n_train, "ms_per_wave": train_ms_late, "kernel": train_kernel,
+                             "note": "render with segment recording + PropagateSamples + Field::Update, host-timed; mean of the last %d" % (n_train - n_train // 2)},
+                "effective_256spp": {"value": W * H * 256 / ((128 * train_ms_late + 128 * trained_ms) * 1e-3) / 1e6, "unit": "Mpaths/s",
+                                     "note": "a 256-spp frame with guidenumtrainingwaves 128 (the reference's default): 128 training + 128 trained waves"},
+                "mean_segments_per_path": gcnt["segments"] / max(1, gcnt["paths"]),
+                "note": "same scene, the reference's default options (surface RIS + volume MIS guiding, primary + secondary VSP): untimed for `value`"}
             g.close()
         if not args.no_cpu_baseline and world == 1:
             # the relMSE leg needs the same waves on both sides: at least 4 spp (training waves would make the oracle

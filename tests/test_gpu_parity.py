@@ -1559,8 +1559,9 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
             scene.medium.sigma_s[k] = 1.5
     g = P.Renderer(scene, prm, W, H, seed=3)
     c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
-    # grid media record on the wavefront pipeline (recorder state travels in the path record), homogeneous ones on the per-lane kernel
-    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave<HomogeneousMediumT<2,true>,guided,train>")
+    # grid media record on the wavefront pipeline, homogeneous ones on the workgroup kernel (round 3): either way the recorder's
+    # state travels in the path record
+    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>")
     g.render_wave(0, 2)
     c.render_wave(0, 2)
     sg, sc = g.training_stats(), c.training_stats()
@@ -1570,16 +1571,22 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     assert a.tobytes() == b.tobytes()
     assert set(np.unique(a["flags"])) <= {0, 1, 2, 3} and (a["flags"] & 1).any() and (~a["flags"] & 1).any()
     g.close()
-    if medium == "grid":  # ... and the per-lane training kernel records the same samples
-        os.environ["VSPG_KERNEL"] = "lane"
+    # ... and the other kernels that serve the configuration record the same samples: the per-lane training kernel, and for
+    # homogeneous media the workgroup kernel's generic instantiation
+    others = [({"VSPG_KERNEL": "lane"}, "k_render_wave<GridMedium,guided,train>" if medium == "grid" else "k_render_wave<HomogeneousMediumT<2,true>,guided,train>")]
+    if medium != "grid":
+        others.append(({"VSPG_NO_GREY_GUIDED": "1"}, "k_render_wave_wg2<HomogeneousMedium,guided,train>"))
+    for env, name in others:
+        os.environ.update(env)
         try:
             g2 = P.Renderer(scene, prm, W, H, seed=3)
-            assert g2.kernel_name() == "k_render_wave<GridMedium,guided,train>"
+            assert g2.kernel_name() == name
             g2.render_wave(0, 2)
-            assert _sorted_samples(g2.train_samples()).tobytes() == b.tobytes()
+            assert _sorted_samples(g2.train_samples()).tobytes() == b.tobytes(), name
             g2.close()
         finally:
-            os.environ.pop("VSPG_KERNEL", None)
+            for k in env:
+                os.environ.pop(k, None)
     c.close()
 
 

@@ -665,6 +665,7 @@ template <int GREY> constexpr int kWg2PoolHomogT = wg_pool_paths<PoolLayout<fals
 #define VSPG_WGG_NP_G2 wg_pool_paths<PoolLayout<true, 2>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8)
 #endif
 template <int GREY> constexpr int kWg2PoolGuidedT = GREY >= 2 ? (VSPG_WGG_NP_G2) : (VSPG_WGG_NP_G0);
+template <int GREY> constexpr int kWg2PoolTrainT = wg_pool_paths<PoolLayout<true, GREY, true>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8);  // + the recorder's state
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
@@ -1013,11 +1014,11 @@ VDEV float isg_code(const IsgSample &isg) {
     const float q = isg.vsp_used >= 0.f ? isg.vsp_used : 0.5f;
     return isg.surface_event ? -q : q;
 }
-template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd>
+template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd, bool TRAIN = false>
 __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
     int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int tiles_magic,
-    float4 *__restrict__ wave_samples, unsigned long long *__restrict__ counters) {
+    float4 *__restrict__ wave_samples, unsigned long long *__restrict__ counters, TrainArgs train = TrainArgs{nullptr, nullptr, nullptr, nullptr, 0, 0}) {
     const DScene &S = *Sp;
     const int W = S.xres, H = S.yres;
     const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3;
@@ -1028,8 +1029,9 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     const unsigned local_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
     const unsigned local_total = local_tiles * 64u;
 
-    using LY = PoolLayout<GUIDED, Medium::kGrey>;
+    using LY = PoolLayout<GUIDED, Medium::kGrey, TRAIN>;
     constexpr int NF = LY::COUNT;
+    static_assert(!TRAIN || GUIDED, "segment recording belongs to the guided instantiations");
     __shared__ float s_pool[NF * NP];
     __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
     __shared__ unsigned int s_cnt[D_COUNT + 1];
@@ -1049,10 +1051,26 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     // counters: per lane in registers (six of them; the unguided instantiations have them to spare), per workgroup in LDS through
     // a ballot and one atomic per count in the guided instantiation, whose vertex phase needs every register it can get
     struct LaneCounters : PathCounters { uint32_t paths; VDEV void path() { paths++; } };
-    typename std::conditional<GUIDED, const WaveCounters, LaneCounters>::type pc = [&] {
-        if constexpr (GUIDED) return WaveCounters{s_counters};
+    using Rec = typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type;
+    typename std::conditional<GUIDED, WaveCountersT<Rec>, LaneCounters>::type pc = [&] {
+        if constexpr (GUIDED) { WaveCountersT<Rec> c; c.c = s_counters; return c; }
         else { LaneCounters c; c.segments = c.volume_scatters = c.surface_hits = c.density_queries = c.shadow_rays = c.paths = 0; return c; }
     }();
+    // a18, training launches (one sample per pixel): a path's records go to ITS column of the wave's record buffer -- the
+    // column of its work item, which the pixel names (tile-ordered items: vspg_render_wave sizes the buffer by them)
+    const auto rec_bind = [&](int pxy) {
+        if constexpr (TRAIN) {
+            const unsigned px = (unsigned)pxy & 0xffffu, py = (unsigned)pxy >> 16;
+            const unsigned item = ((py >> 3) * (unsigned)tilesX + (px >> 3)) * 64u + ((py & 7u) << 3) + (px & 7u);
+            pc.rec.base = train.segbuf + item;
+            pc.rec.stride = (int)train.n_items;
+            pc.rec.max_seg = train_rec_capacity(S.prm.maxdepth);
+            return item;
+        } else {
+            (void)pxy;
+            return 0u;
+        }
+    };
 
     stage_scene_lds(S);
     if (threadIdx.x < CNT_COUNT) s_counters[threadIdx.x] = 0;
@@ -1132,11 +1150,13 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                             start_path(S, vsp_buf, vsp_ready, px, py, smp, sampler, st, &ch, isg);
                         P.i(LY::PIXEL, slot) = pxy;
                         P.i(LY::SAMPLE, slot) = smp;
+                        if constexpr (TRAIN) { (void)rec_bind(pxy); pc.rec.reset(); }
                         alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                           isg, pc, vx);
                         if (alive) {
                             pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
                             pool_store_vertex<GUIDED, Medium::kGrey>(P, slot, vx);
+                            if constexpr (TRAIN) pool_store_rec<LY>(P, slot, pc.rec);
                         }
                     } else {
                         freed = true;
@@ -1146,15 +1166,20 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                     const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
                     pxy = P.i(LY::PIXEL, slot);
                     const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
+                    if constexpr (TRAIN) { (void)rec_bind(pxy); pool_load_rec<LY>(P, slot, pc.rec); }
                     alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
                                                                         isg, pc, vx);
-                    if (alive) pool_store_a<Medium::kGrey, GUIDED>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                    if (alive) {
+                        pool_store_a<Medium::kGrey, GUIDED>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                        if constexpr (TRAIN) pool_store_rec<LY>(P, slot, pc.rec);
+                    }
                 }
                 if (alive) {
                     toV = vx.volume;
                     toS = !vx.volume;
                 } else if (valid) {
                     emit(pxy, st.L, isg);
+                    if constexpr (TRAIN) train.seg_count[rec_bind(pxy)] = pc.rec.n;  // PropagateSamples (:627) follows in k_propagate
                     pc.path();
                     const int s2 = P.i(LY::SAMPLE, slot) + sample_step;
                     P.i(LY::SAMPLE, slot) = s2;
@@ -1194,7 +1219,9 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                 bool alive;
                 if constexpr (GUIDED) {  // the guided vertex works on the pool record directly (vspg_guided_wg.h)
                     const uint32_t fl = P.u(LY::FLAGS, slot);
+                    if constexpr (TRAIN) { (void)rec_bind(P.i(LY::PIXEL, slot)); pool_load_rec<LY>(P, slot, pc.rec); }
                     alive = li_vertex_guided_wg<Medium>(S, medium, P, slot, fl, pc, reinterpret_cast<const VspgKdNode *>(glds), &st.L, &isg);
+                    if constexpr (TRAIN) { if (alive) pool_store_rec<LY>(P, slot, pc.rec); }
                     if (!alive) {
                         isg.valid = (fl & FL_ISG_VALID) != 0;
                         isg.surface_event = (fl & FL_ISG_SURF) != 0;
@@ -1210,6 +1237,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                     cont = true;
                 } else {
                     emit(P.i(LY::PIXEL, slot), st.L, isg);
+                    if constexpr (TRAIN) train.seg_count[rec_bind(P.i(LY::PIXEL, slot))] = pc.rec.n;
                     pc.path();
                     const int s2 = P.i(LY::SAMPLE, slot) + sample_step;
                     P.i(LY::SAMPLE, slot) = s2;
@@ -2445,7 +2473,7 @@ static bool uses_wg_guided(const VspgRenderer *r) {
     // the two).  Training waves (segment recording), guided Russian roulette, triangles / infinite lights stay per-lane.
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wg") != 0) return false;
-    return wants_guiding(r->prm) && !r->training && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
+    return wants_guiding(r->prm) && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
            r->hscene.n_tris == 0 && r->hscene.n_inf == 0;
 }
 // guided renders over a homogeneous medium: the grey / zero-null-coefficient / rectangle-scene instantiation of the per-lane
@@ -2489,7 +2517,10 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
         return nvdb ? (r->medium_grey ? "k_wf_dist_walk<NanoDenseMediumGrey>" : "k_wf_dist_walk<NanoDenseMedium>")
                     : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
     }
-    if (uses_wg_guided(r)) return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>" : "k_render_wave_wg2<HomogeneousMedium,guided>";
+    if (uses_wg_guided(r)) {
+        if (r->training) return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>" : "k_render_wave_wg2<HomogeneousMedium,guided,train>";
+        return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>" : "k_render_wave_wg2<HomogeneousMedium,guided>";
+    }
     if (uses_wg_kernel(r)) {
         if (grid) return "k_render_wave_wg<GridMedium>";
         if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg<HomogeneousMediumT<2,true>>";
@@ -2623,7 +2654,15 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
 #define VSPG_LAUNCH_WG2(M, G, NPOOL, BLK, WV)                                                                                         \
     hipLaunchKernelGGL((k_render_wave_wg2<M, G, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
                        r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, r->wave_samples, r->counters)
-            if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, true, kWg2PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided);
+            if (gwg && train && guided_grey_simple(r))
+                hipLaunchKernelGGL((k_render_wave_wg2<HomogeneousMediumGreySceneNullZero, true, kWg2PoolTrainT<2>, kWgBlockGuided, kWgWavesGuided, true>), dim3((unsigned)wblocks),
+                                   dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump,
+                                   tiles_magic, r->wave_samples, r->counters, targs);
+            else if (gwg && train)
+                hipLaunchKernelGGL((k_render_wave_wg2<HomogeneousMediumSimple, true, kWg2PoolTrainT<0>, kWgBlockGuided, kWgWavesGuided, true>), dim3((unsigned)wblocks),
+                                   dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump,
+                                   tiles_magic, r->wave_samples, r->counters, targs);
+            else if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, true, kWg2PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided);
             else if (gwg) VSPG_LAUNCH_WG2(HomogeneousMediumSimple, true, kWg2PoolGuidedT<0>, kWgBlockGuided, kWgWavesGuided);
             else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, false, kWg2PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);
             else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGreyScene, false, kWg2PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);

@@ -185,9 +185,10 @@ struct PathCountersT {
     VDEV void shadow_ray() { shadow_rays++; }
 };
 using PathCounters = PathCountersT<NullRecorder>;
-struct WaveCounters {
+template <class REC>
+struct WaveCountersT {
     unsigned int *c;  // LDS, CNT_COUNT entries
-    NullRecorder rec;
+    REC rec;
     VDEV void add(int k) const {
         const unsigned long long m = __ballot(1);
         if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(c + k, (unsigned int)__popcll(m));
@@ -199,6 +200,7 @@ struct WaveCounters {
     VDEV void density_query() const { add(CNT_DENSITY_QUERIES); }
     VDEV void shadow_ray() const { add(CNT_SHADOW_RAYS); }
 };
+using WaveCounters = WaveCountersT<NullRecorder>;
 
 struct IsgSample {
     bool valid, surface_event;

@@ -27,7 +27,7 @@ namespace vspg {
 // room, so more paths fit the LDS a workgroup may use (the pool's size is what the phases' list lengths, i.e. the wavefronts'
 // occupancy with work, hang on: 320 -> 384 paths took the guided kernel from 2.14 to 1.86 ms per wave).
 //   unguided: 33 dwords generic, 29 with a grey medium, 27 with grey surfaces too;  guided: 37 / 33 / 31.
-template <bool GUIDED, int GREY>
+template <bool GUIDED, int GREY, bool TRAIN = false>
 struct PoolLayout {
     static constexpr int RO = 0;                                  // 3
     static constexpr int RD = 3;                                  // 3
@@ -50,7 +50,11 @@ struct PoolLayout {
     // the next segment phase (the unguided vertex code never reads the old origin): they share three dwords.  Guided builds:
     // gbsdf.init queries the cache at ray.o + tHit * ray.d (guiding.h:85), so the origin must survive.
     static constexpr int VXP = GUIDED ? GS + 1 : RO;              // 3
-    static constexpr int COUNT = GUIDED ? VXP + 3 : GS;
+    // (appended LAST: every other field sits at the same offset with and without it, so the helpers below need not know)
+    // training launches (a18): the recorder's state between phases -- record count, current record, its flags word, its
+    // accumulated scattered direct light (PathRecorder, vspg_train.h); the records themselves go straight to HBM
+    static constexpr int REC = GUIDED ? VXP + 3 : GS;             // 6
+    static constexpr int COUNT = REC + (TRAIN ? 6 : 0);
 };
 enum {
     FL_DEPTH_MASK = 0xff,
@@ -79,6 +83,26 @@ struct Pool {
     VDEV void sets(int field, int slot, Spec v) const { f(field, slot) = v.r; f(field + 1, slot) = v.g; f(field + 2, slot) = v.b; }
 };
 
+template <class LY>
+VDEV void pool_store_rec(const Pool &P, int slot, const PathRecorder &rec) {
+    P.i(LY::REC + 0, slot) = rec.n;
+    P.i(LY::REC + 1, slot) = rec.cur;
+    P.u(LY::REC + 2, slot) = rec.cur_flags;
+    P.f(LY::REC + 3, slot) = rec.scat_r;
+    P.f(LY::REC + 4, slot) = rec.scat_g;
+    P.f(LY::REC + 5, slot) = rec.scat_b;
+}
+template <class LY>
+VDEV void pool_load_rec(const Pool &P, int slot, PathRecorder &rec) {
+    rec.n = P.i(LY::REC + 0, slot);
+    rec.cur = P.i(LY::REC + 1, slot);
+    rec.cur_flags = P.u(LY::REC + 2, slot);
+    rec.scat_r = P.f(LY::REC + 3, slot);
+    rec.scat_g = P.f(LY::REC + 4, slot);
+    rec.scat_b = P.f(LY::REC + 5, slot);
+}
+VDEV void pool_store_rec(const Pool &, int, const NullRecorder &) {}
+VDEV void pool_load_rec(const Pool &, int, NullRecorder &) {}
 VDEV uint32_t pool_pack_flags(const PathState &st, int ch, const IsgSample &isg, uint32_t keep_flags) {
     uint32_t fl = keep_flags | (uint32_t)(st.depth & FL_DEPTH_MASK) | ((uint32_t)ch << FL_CH_SHIFT);
     if (st.specularBounce) fl |= FL_SPECULAR;
