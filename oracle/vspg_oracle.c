@@ -503,7 +503,10 @@ typedef struct {
     float g; /* HG phase */
 } medium_props_t; /* MediumProperties, media.h:77-82 */
 
+typedef struct lightsampler lightsampler_t; /* "light samplers" section below */
 struct OracleRenderer {
+    lightsampler_t *lsamp; /* LightSampler::Create(prm.lightsampler, lights) (lightsamplers.cpp:49-64), built with the renderer */
+    int light_of_quad[VSPG_MAX_QUADS]; /* rectangle -> index into the light list, -1: not a light */
     VspgScene scene;
     VspgIntegratorParams prm;
     VspgRenderConfig cfg;
@@ -1645,6 +1648,423 @@ typedef struct {
 #define GUIDING_PROBABILITY 0.5f /* guiding.h:348, 628 */
 
 /* ------------------------------------------------------------------------------------ */
+/* Light samplers (round 3): PowerLightSampler (lightsamplers.h:63-98, lightsamplers.cpp:76-99) and BVHLightSampler    */
+/* (lightsamplers.h:100-430, lightsamplers.cpp:108-262) -- "bvh" is the reference's default (:1318).  Built once per      */
+/* renderer from the light list {emissive rectangles in rectangle order, then the infinite lights}; the node records keep  */
+/* what CompactLightBounds' accessors return (the quantised box / cosines / octahedral axis, de-quantised once).          */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { v3 bmin, bmax; float phi; v3 w; float cosTheta_o, cosTheta_e; int twoSided; } lightbounds_t; /* LightBounds (lights.h:104-135) */
+typedef struct {
+    v3 bmin, bmax, w;              /* CompactLightBounds::Bounds(allb), Vector3f(w) */
+    float phi, cosTheta_o, cosTheta_e;
+    int32_t twoSided;
+    uint32_t child_or_light;       /* interior: second child (the first is node + 1); leaf: index into the light list */
+    int32_t is_leaf;
+} lbvh_node_t;
+#define LBVH_MAX_LIGHTS (VSPG_MAX_QUADS + VSPG_MAX_INFINITE_LIGHTS)
+struct lightsampler {
+    int n_nodes, n_inf;                       /* nodes.size(), infiniteLights.size() */
+    lbvh_node_t nodes[2 * LBVH_MAX_LIGHTS];
+    int inf_light[VSPG_MAX_INFINITE_LIGHTS];  /* infiniteLights[k] as an index into the light list */
+    uint32_t bit_trail[LBVH_MAX_LIGHTS];      /* lightToBitTrail; 0xffffffff: not in the tree (infinite, or phi == 0) */
+    /* PowerLightSampler's AliasTable (util/sampling.cpp:563-646) */
+    int n_alias;
+    float alias_p[LBVH_MAX_LIGHTS], alias_q[LBVH_MAX_LIGHTS];
+    int alias_i[LBVH_MAX_LIGHTS];
+};
+
+static float safe_asin_f(float x) { return asinf(clampf(x, -1, 1)); }
+static float safe_acos_f(float x) { return acosf(clampf(x, -1, 1)); }
+static float angle_between(v3 a, v3 b) { /* vecmath.h:972-977 */
+    if (v_dot(a, b) < 0) return PI_F - 2 * safe_asin_f(v_len(v_add(a, b)) / 2);
+    return 2 * safe_asin_f(v_len(v_sub(b, a)) / 2);
+}
+typedef struct { v3 w; float cosTheta; } dircone_t; /* DirectionCone (vecmath.h:1785-1808); cosTheta == INFINITY: empty */
+static dircone_t dircone(v3 w, float c) { dircone_t d; d.w = v_normalize(w); d.cosTheta = c; return d; }
+static dircone_t dircone_union(dircone_t a, dircone_t b) { /* vecmath.cpp:56-83 */
+    if (isinf(a.cosTheta)) return b;
+    if (isinf(b.cosTheta)) return a;
+    float theta_a = safe_acos_f(a.cosTheta), theta_b = safe_acos_f(b.cosTheta);
+    float theta_d = angle_between(a.w, b.w);
+    if (fminf(theta_d + theta_b, PI_F) <= theta_a) return a;
+    if (fminf(theta_d + theta_a, PI_F) <= theta_b) return b;
+    float theta_o = (theta_a + theta_d + theta_b) / 2;
+    if (theta_o >= PI_F) return dircone(V3(0, 0, 1), -1);
+    float theta_r = theta_o - theta_a;
+    v3 wr = v_cross(a.w, b.w);
+    if (v_len2(wr) == 0) return dircone(V3(0, 0, 1), -1);
+    /* Rotate(Degrees(theta_r), wr)(a.w) (transform.h:220-247): sin / cos of Radians(Degrees(theta_r)) */
+    float deg = (180 / PI_F) * theta_r, rad = (PI_F / 180) * deg;
+    float sinT = sinf(rad), cosT = cosf(rad);
+    v3 ax = v_normalize(wr);
+    float m[3][3];
+    m[0][0] = ax.x * ax.x + (1 - ax.x * ax.x) * cosT; m[0][1] = ax.x * ax.y * (1 - cosT) - ax.z * sinT; m[0][2] = ax.x * ax.z * (1 - cosT) + ax.y * sinT;
+    m[1][0] = ax.x * ax.y * (1 - cosT) + ax.z * sinT; m[1][1] = ax.y * ax.y + (1 - ax.y * ax.y) * cosT; m[1][2] = ax.y * ax.z * (1 - cosT) - ax.x * sinT;
+    m[2][0] = ax.x * ax.z * (1 - cosT) - ax.y * sinT; m[2][1] = ax.y * ax.z * (1 - cosT) + ax.x * sinT; m[2][2] = ax.z * ax.z + (1 - ax.z * ax.z) * cosT;
+    v3 w = V3(m[0][0] * a.w.x + m[0][1] * a.w.y + m[0][2] * a.w.z, m[1][0] * a.w.x + m[1][1] * a.w.y + m[1][2] * a.w.z,
+              m[2][0] * a.w.x + m[2][1] * a.w.y + m[2][2] * a.w.z); /* Transform::operator()(Vector3f), transform.h:351-356 */
+    return dircone(w, cosf(theta_o));
+}
+static lightbounds_t lb_empty(void) { lightbounds_t b; memset(&b, 0, sizeof b); b.bmin = V3(INFINITY, INFINITY, INFINITY); b.bmax = V3(-INFINITY, -INFINITY, -INFINITY); return b; }
+static v3 v_min3(v3 a, v3 b) { return V3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+static v3 v_max3(v3 a, v3 b) { return V3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+static lightbounds_t lb_union(lightbounds_t a, lightbounds_t b) { /* lights.h:137-153 */
+    if (a.phi == 0) return b;
+    if (b.phi == 0) return a;
+    dircone_t ca, cb; ca.w = a.w; ca.cosTheta = a.cosTheta_o; cb.w = b.w; cb.cosTheta = b.cosTheta_o;
+    ca.w = v_normalize(ca.w); cb.w = v_normalize(cb.w); /* DirectionCone(w, cosTheta) normalises */
+    dircone_t cone = dircone_union(ca, cb);
+    lightbounds_t r;
+    r.bmin = v_min3(a.bmin, b.bmin); r.bmax = v_max3(a.bmax, b.bmax);
+    r.w = v_normalize(cone.w);
+    r.phi = a.phi + b.phi;
+    r.cosTheta_o = cone.cosTheta;
+    r.cosTheta_e = fminf(a.cosTheta_e, b.cosTheta_e);
+    r.twoSided = a.twoSided | b.twoSided;
+    return r;
+}
+static v3 lb_centroid(const lightbounds_t *b) { return v_scale(v_add(b->bmin, b->bmax), 0.5f); } /* (pMin + pMax) / 2 */
+static float vcomp(v3 v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
+/* CompactLightBounds(lb, allb) and back through its accessors (lightsamplers.h:100-142, 212-242; vecmath.h:1733-1782) */
+static float quantize_bounds(float c, float mn, float mx) { return mn == mx ? 0.f : 65535.f * clampf((c - mn) / (mx - mn), 0, 1); }
+static float lerpf(float t, float a, float b) { return (1 - t) * a + t * b; }
+static uint16_t oct_encode(float f) { return (uint16_t)roundf(clampf((f + 1) / 2, 0, 1) * 65535.f); }
+static void compact_node(lbvh_node_t *nd, const lightbounds_t *lb, v3 amin, v3 amax) {
+    /* OctahedralVector(Normalize(lb.w)) -> Vector3f */
+    v3 v = v_normalize(lb->w);
+    float l1 = fabsf(v.x) + fabsf(v.y) + fabsf(v.z);
+    v = V3(v.x / l1, v.y / l1, v.z / l1);
+    uint16_t ox, oy;
+    if (v.z >= 0) { ox = oct_encode(v.x); oy = oct_encode(v.y); }
+    else { ox = oct_encode((1 - fabsf(v.y)) * copysignf(1.f, v.x)); oy = oct_encode((1 - fabsf(v.x)) * copysignf(1.f, v.y)); }
+    v3 d;
+    d.x = -1 + 2 * (ox / 65535.f);
+    d.y = -1 + 2 * (oy / 65535.f);
+    d.z = 1 - (fabsf(d.x) + fabsf(d.y));
+    if (d.z < 0) { float xo = d.x; d.x = (1 - fabsf(d.y)) * copysignf(1.f, xo); d.y = (1 - fabsf(xo)) * copysignf(1.f, d.y); }
+    nd->w = v_normalize(d);
+    nd->phi = lb->phi;
+    unsigned qo = (unsigned)floorf(32767.f * ((lb->cosTheta_o + 1) / 2)), qe = (unsigned)floorf(32767.f * ((lb->cosTheta_e + 1) / 2));
+    nd->cosTheta_o = 2 * (qo / 32767.f) - 1;
+    nd->cosTheta_e = 2 * (qe / 32767.f) - 1;
+    nd->twoSided = lb->twoSided;
+    float lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) {
+        uint16_t q0 = (uint16_t)floorf(quantize_bounds(vcomp(lb->bmin, c), vcomp(amin, c), vcomp(amax, c)));
+        uint16_t q1 = (uint16_t)ceilf(quantize_bounds(vcomp(lb->bmax, c), vcomp(amin, c), vcomp(amax, c)));
+        lo[c] = lerpf(q0 / 65535.f, vcomp(amin, c), vcomp(amax, c));
+        hi[c] = lerpf(q1 / 65535.f, vcomp(amin, c), vcomp(amax, c));
+    }
+    nd->bmin = V3(lo[0], lo[1], lo[2]); nd->bmax = V3(hi[0], hi[1], hi[2]);
+}
+static float lb_evaluate_cost(const lightbounds_t *b, v3 bdiag, int dim) { /* lightsamplers.h:398-411 */
+    float theta_o = acosf(b->cosTheta_o), theta_e = acosf(b->cosTheta_e);
+    float theta_w = fminf(theta_o + theta_e, PI_F);
+    float sinTheta_o = safe_sqrt(1 - sqr(b->cosTheta_o));
+    float M_omega = 2 * PI_F * (1 - b->cosTheta_o) +
+                    PI_F / 2 * (2 * theta_w * sinTheta_o - cosf(theta_o - 2 * theta_w) - 2 * theta_o * sinTheta_o + b->cosTheta_o);
+    float Kr = fmaxf(bdiag.x, fmaxf(bdiag.y, bdiag.z)) / vcomp(bdiag, dim);
+    v3 d = v_sub(b->bmax, b->bmin);
+    float area = 2 * (d.x * d.y + d.x * d.z + d.y * d.z); /* Bounds3::SurfaceArea */
+    return b->phi * M_omega * Kr * area;
+}
+typedef struct { int light; lightbounds_t lb; } lbvh_item_t;
+static int lbvh_bucket(const lightbounds_t *lb, v3 cmin, v3 cmax, int dim) { /* nBuckets * centroidBounds.Offset(pc)[dim], 12 buckets */
+    float pc = vcomp(lb_centroid(lb), dim), mn = vcomp(cmin, dim), mx = vcomp(cmax, dim);
+    float o = pc - mn;
+    if (mx > mn) o /= mx - mn;
+    int b = (int)(12 * o);
+    return b == 12 ? 11 : b;
+}
+static int lbvh_build(lightsampler_t *ls, lbvh_item_t *it, int start, int end, uint32_t bitTrail, int depth, v3 amin, v3 amax, lightbounds_t *out) {
+    if (end - start == 1) {
+        int nodeIndex = ls->n_nodes++;
+        compact_node(&ls->nodes[nodeIndex], &it[start].lb, amin, amax);
+        ls->nodes[nodeIndex].child_or_light = (uint32_t)it[start].light;
+        ls->nodes[nodeIndex].is_leaf = 1;
+        ls->bit_trail[it[start].light] = bitTrail;
+        *out = it[start].lb;
+        return nodeIndex;
+    }
+    v3 bmin = V3(INFINITY, INFINITY, INFINITY), bmax = V3(-INFINITY, -INFINITY, -INFINITY), cmin = bmin, cmax = bmax;
+    for (int i = start; i < end; ++i) {
+        bmin = v_min3(bmin, it[i].lb.bmin); bmax = v_max3(bmax, it[i].lb.bmax);
+        v3 c = lb_centroid(&it[i].lb);
+        cmin = v_min3(cmin, c); cmax = v_max3(cmax, c);
+    }
+    float minCost = INFINITY;
+    int minCostSplitBucket = -1, minCostSplitDim = -1;
+    const v3 bdiag = v_sub(bmax, bmin);
+    for (int dim = 0; dim < 3; ++dim) {
+        if (vcomp(cmax, dim) == vcomp(cmin, dim)) continue;
+        lightbounds_t bucket[12];
+        for (int b = 0; b < 12; ++b) bucket[b] = lb_empty();
+        for (int i = start; i < end; ++i) {
+            int b = lbvh_bucket(&it[i].lb, cmin, cmax, dim);
+            bucket[b] = lb_union(bucket[b], it[i].lb);
+        }
+        float cost[11];
+        for (int i = 0; i < 11; ++i) {
+            lightbounds_t b0 = lb_empty(), b1 = lb_empty();
+            for (int j = 0; j <= i; ++j) b0 = lb_union(b0, bucket[j]);
+            for (int j = i + 1; j < 12; ++j) b1 = lb_union(b1, bucket[j]);
+            cost[i] = lb_evaluate_cost(&b0, bdiag, dim) + lb_evaluate_cost(&b1, bdiag, dim);
+        }
+        for (int i = 1; i < 11; ++i)
+            if (cost[i] > 0 && cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; minCostSplitDim = dim; }
+    }
+    int mid;
+    if (minCostSplitDim == -1) mid = (start + end) / 2;
+    else {
+        /* std::partition (libstdc++, forward-iterator form is not used for pointers: the bidirectional algorithm) */
+        int first = start, last = end;
+        while (1) {
+            while (1) {
+                if (first == last) goto done;
+                if (lbvh_bucket(&it[first].lb, cmin, cmax, minCostSplitDim) <= minCostSplitBucket) ++first; else break;
+            }
+            --last;
+            while (1) {
+                if (first == last) goto done;
+                if (!(lbvh_bucket(&it[last].lb, cmin, cmax, minCostSplitDim) <= minCostSplitBucket)) --last; else break;
+            }
+            lbvh_item_t t = it[first]; it[first] = it[last]; it[last] = t;
+            ++first;
+        }
+    done:
+        mid = first;
+        if (mid == start || mid == end) mid = (start + end) / 2;
+    }
+    int nodeIndex = ls->n_nodes++;
+    lightbounds_t l0, l1;
+    lbvh_build(ls, it, start, mid, bitTrail, depth + 1, amin, amax, &l0);
+    int child1 = lbvh_build(ls, it, mid, end, bitTrail | (1u << depth), depth + 1, amin, amax, &l1);
+    lightbounds_t lb = lb_union(l0, l1);
+    compact_node(&ls->nodes[nodeIndex], &lb, amin, amax);
+    ls->nodes[nodeIndex].child_or_light = (uint32_t)child1;
+    ls->nodes[nodeIndex].is_leaf = 0;
+    *out = lb;
+    return nodeIndex;
+}
+/* DiffuseAreaLight::Bounds on a rectangle (lights.cpp:845-864; BilinearPatch::Bounds / NormalBounds, shapes.cpp:1070-1126) */
+static lightbounds_t quad_light_bounds(const rquad_t *q, int reverse_orientation) {
+    lightbounds_t lb;
+    lb.bmin = v_min3(v_min3(q->p00, q->p01), v_min3(q->p10, q->p11));
+    lb.bmax = v_max3(v_max3(q->p00, q->p01), v_max3(q->p10, q->p11));
+    v3 n00 = v_normalize(v_cross(v_sub(q->p10, q->p00), v_sub(q->p01, q->p00)));
+    v3 n10 = v_normalize(v_cross(v_sub(q->p11, q->p10), v_sub(q->p00, q->p10)));
+    v3 n01 = v_normalize(v_cross(v_sub(q->p00, q->p01), v_sub(q->p11, q->p01)));
+    v3 n11 = v_normalize(v_cross(v_sub(q->p01, q->p11), v_sub(q->p10, q->p11)));
+    if (reverse_orientation) { n00 = v_neg(n00); n10 = v_neg(n10); n01 = v_neg(n01); n11 = v_neg(n11); }
+    v3 n = v_normalize(v_add(v_add(n00, n10), v_add(n01, n11)));
+    float cosTheta = fminf(fminf(v_dot(n, n00), v_dot(n, n01)), fminf(v_dot(n, n10), v_dot(n, n11)));
+    dircone_t nb = dircone(n, clampf(cosTheta, -1, 1));
+    float phi = fmaxf(q->Le.c[0], fmaxf(q->Le.c[1], q->Le.c[2])); /* Lemit->MaxValue(), RGB rendering mode (spectrum.h:772-779) */
+    phi *= 1.f * q->area * PI_F;                                     /* scale * area * Pi */
+    lb.w = v_normalize(nb.w);
+    lb.phi = phi;
+    lb.cosTheta_o = nb.cosTheta;
+    lb.cosTheta_e = cosf(PI_F / 2);
+    lb.twoSided = q->two_sided;
+    return lb;
+}
+static void lightsampler_build(OracleRenderer *r, lightsampler_t *ls) {
+    memset(ls, 0, sizeof *ls);
+    const int n_all = r->n_lights + r->n_inf;
+    for (int i = 0; i < LBVH_MAX_LIGHTS; ++i) ls->bit_trail[i] = 0xffffffffu;
+    /* BVHLightSampler (lightsamplers.cpp:108-136) */
+    lbvh_item_t items[LBVH_MAX_LIGHTS];
+    int n_items = 0;
+    v3 amin = V3(INFINITY, INFINITY, INFINITY), amax = V3(-INFINITY, -INFINITY, -INFINITY);
+    for (int i = 0; i < n_all; ++i) {
+        if (i >= r->n_lights) { ls->inf_light[ls->n_inf++] = i; continue; } /* Bounds() == {} */
+        const int qi = r->light_quads[i];
+        lightbounds_t lb = quad_light_bounds(&r->quads[qi], r->scene.quads[qi].reverse_orientation);
+        if (lb.phi > 0) {
+            items[n_items].light = i; items[n_items].lb = lb; n_items++;
+            amin = v_min3(amin, lb.bmin); amax = v_max3(amax, lb.bmax);
+        }
+    }
+    if (n_items > 0) { lightbounds_t root; lbvh_build(ls, items, 0, n_items, 0, 0, amin, amax, &root); }
+    /* PowerLightSampler (lightsamplers.cpp:76-99): phi = SafeDiv(light.Phi(lambda), lambda.PDF()).Average() for
+     * lambda = SampledWavelengths::SampleVisible(0.5f) (spectrum.h:367-386, sampling.h SampleVisibleWavelengths / VisibleWavelengthsPDF) */
+    if (n_all > 0) {
+        float pdf[3], power[LBVH_MAX_LIGHTS], acc0 = 0.f;
+        for (int i = 0; i < 3; ++i) {
+            float up = 0.5f + (float)i / 3;
+            if (up > 1) up -= 1;
+            float lambda = 538 - 138.888889f * atanhf(0.85691062f - 1.82750197f * up);
+            pdf[i] = lambda < 360 || lambda > 830 ? 0.f : 0.0039398042f / sqr(coshf(0.0072f * (lambda - 538)));
+        }
+        for (int i = 0; i < n_all; ++i) {
+            spec L; float k;
+            if (i < r->n_lights) {
+                const rquad_t *q = &r->quads[r->light_quads[i]];
+                L = q->Le; k = PI_F * (q->two_sided ? 2 : 1) * q->area; /* DiffuseAreaLight::Phi (lights.cpp:826-843) */
+            } else {
+                const VspgInfiniteLight *il = &r->scene.infinite_lights[i - r->n_lights];
+                L = s_from(il->L);
+                k = il->type == VSPG_LIGHT_DISTANT ? PI_F * sqr(r->scene_radius)              /* lights.cpp:251-253 */
+                                                    : 4 * PI_F * PI_F * sqr(r->scene_radius);  /* lights.cpp:1038-1040 */
+            }
+            float s = 0.f;
+            for (int c = 0; c < 3; ++c) s += pdf[c] != 0 ? (k * L.c[c]) / pdf[c] : 0.f;
+            power[i] = s / 3;
+            acc0 += power[i];
+        }
+        if (acc0 == 0.f) for (int i = 0; i < n_all; ++i) power[i] = 1.f;
+        /* AliasTable (util/sampling.cpp:563-618) */
+        double sum = 0.;
+        for (int i = 0; i < n_all; ++i) sum += power[i];
+        const float fsum = (float)sum;
+        ls->n_alias = n_all;
+        struct { float pHat; int index; } under[LBVH_MAX_LIGHTS], over[LBVH_MAX_LIGHTS];
+        int nu = 0, no = 0;
+        for (int i = 0; i < n_all; ++i) {
+            ls->alias_p[i] = power[i] / fsum;
+            float pHat = ls->alias_p[i] * n_all;
+            if (pHat < 1) { under[nu].pHat = pHat; under[nu].index = i; nu++; } else { over[no].pHat = pHat; over[no].index = i; no++; }
+        }
+        while (nu > 0 && no > 0) {
+            float upH = under[nu - 1].pHat, ovH = over[no - 1].pHat;
+            int ui = under[nu - 1].index, oi = over[no - 1].index;
+            nu--; no--;
+            ls->alias_q[ui] = upH; ls->alias_i[ui] = oi;
+            float pExcess = upH + ovH - 1;
+            if (pExcess < 1) { under[nu].pHat = pExcess; under[nu].index = oi; nu++; } else { over[no].pHat = pExcess; over[no].index = oi; no++; }
+        }
+        while (no > 0) { no--; ls->alias_q[over[no].index] = 1; ls->alias_i[over[no].index] = -1; }
+        while (nu > 0) { nu--; ls->alias_q[under[nu].index] = 1; ls->alias_i[under[nu].index] = -1; }
+    }
+}
+/* CompactLightBounds::Importance (lightsamplers.h:144-206) on the de-quantised node */
+static float lbvh_importance(const lbvh_node_t *nd, v3 p, v3 n) {
+    v3 pc = v_scale(v_add(nd->bmin, nd->bmax), 0.5f);
+    v3 dd = v_sub(p, pc);
+    float d2 = v_len2(dd);
+    d2 = fmaxf(d2, v_len(v_sub(nd->bmax, nd->bmin)) / 2);
+    v3 wi = v_normalize(v_sub(p, pc));
+    float cosTheta_w = v_dot(nd->w, wi);
+    if (nd->twoSided) cosTheta_w = fabsf(cosTheta_w);
+    float sinTheta_w = safe_sqrt(1 - sqr(cosTheta_w));
+    /* BoundSubtendedDirections(bounds, p).cosTheta (vecmath.h:1815-1828) */
+    float cosTheta_b;
+    {
+        int inside = pc.x >= nd->bmin.x && pc.x <= nd->bmax.x && pc.y >= nd->bmin.y && pc.y <= nd->bmax.y && pc.z >= nd->bmin.z && pc.z <= nd->bmax.z;
+        float radius = inside ? v_len(v_sub(pc, nd->bmax)) : 0.f;
+        if (v_len2(v_sub(p, pc)) < sqr(radius)) cosTheta_b = -1.f;
+        else {
+            float sin2ThetaMax = sqr(radius) / v_len2(v_sub(pc, p));
+            cosTheta_b = safe_sqrt(1 - sin2ThetaMax);
+        }
+    }
+    float sinTheta_b = safe_sqrt(1 - sqr(cosTheta_b));
+    float cosTheta_o = nd->cosTheta_o, cosTheta_e = nd->cosTheta_e;
+    float sinTheta_o = safe_sqrt(1 - sqr(cosTheta_o));
+    /* cosSubClamped / sinSubClamped */
+    float cosTheta_x = cosTheta_w > cosTheta_o ? 1.f : cosTheta_w * cosTheta_o + sinTheta_w * sinTheta_o;
+    float sinTheta_x = cosTheta_w > cosTheta_o ? 0.f : sinTheta_w * cosTheta_o - cosTheta_w * sinTheta_o;
+    float cosThetap = cosTheta_x > cosTheta_b ? 1.f : cosTheta_x * cosTheta_b + sinTheta_x * sinTheta_b;
+    if (cosThetap <= cosTheta_e) return 0;
+    float importance = nd->phi * cosThetap / d2;
+    if (!(n.x == 0 && n.y == 0 && n.z == 0)) {
+        float cosTheta_i = v_absdot(wi, n);
+        float sinTheta_i = safe_sqrt(1 - sqr(cosTheta_i));
+        float cosThetap_i = cosTheta_i > cosTheta_b ? 1.f : cosTheta_i * cosTheta_b + sinTheta_i * sinTheta_b;
+        importance *= cosThetap_i;
+    }
+    return fmaxf(importance, 0);
+}
+/* lightSampler.Sample(ctx, u): light index into the light list and its pmf; 0 = no light */
+static int lightsampler_sample(const OracleRenderer *r, const lightsampler_t *ls, v3 p, v3 n, float u, int *lightIndex, float *pmf) {
+    const int n_all = r->n_lights + r->n_inf;
+    if (r->prm.lightsampler == VSPG_LIGHTSAMPLER_UNIFORM) { /* lightsamplers.h:33-38 */
+        if (n_all == 0) return 0;
+        int li = (int)(u * (float)n_all);
+        *lightIndex = li < n_all - 1 ? li : n_all - 1;
+        *pmf = 1.f / (float)n_all;
+        return 1;
+    }
+    if (r->prm.lightsampler == VSPG_LIGHTSAMPLER_POWER) { /* AliasTable::Sample (sampling.cpp:620-646) */
+        if (!ls->n_alias) return 0;
+        int offset = (int)(u * (float)ls->n_alias);
+        if (offset > ls->n_alias - 1) offset = ls->n_alias - 1;
+        float up = fminf(u * (float)ls->n_alias - (float)offset, ONE_MINUS_EPS);
+        if (up < ls->alias_q[offset]) { *lightIndex = offset; *pmf = ls->alias_p[offset]; }
+        else { *lightIndex = ls->alias_i[offset]; *pmf = ls->alias_p[ls->alias_i[offset]]; }
+        return 1;
+    }
+    /* BVHLightSampler::Sample (lightsamplers.h:283-342) */
+    const float pInfinite = (float)ls->n_inf / (float)(ls->n_inf + (ls->n_nodes == 0 ? 0 : 1));
+    if (u < pInfinite) {
+        u /= pInfinite;
+        int index = (int)(u * (float)ls->n_inf);
+        if (index > ls->n_inf - 1) index = ls->n_inf - 1;
+        *pmf = pInfinite / (float)ls->n_inf;
+        *lightIndex = ls->inf_light[index];
+        return 1;
+    }
+    if (ls->n_nodes == 0) return 0;
+    u = fminf((u - pInfinite) / (1 - pInfinite), ONE_MINUS_EPS);
+    int nodeIndex = 0;
+    float pm = 1 - pInfinite;
+    while (1) {
+        const lbvh_node_t *node = &ls->nodes[nodeIndex];
+        if (!node->is_leaf) {
+            float ci[2] = {lbvh_importance(&ls->nodes[nodeIndex + 1], p, n), lbvh_importance(&ls->nodes[node->child_or_light], p, n)};
+            if (ci[0] == 0 && ci[1] == 0) return 0;
+            /* SampleDiscrete(ci, u, &nodePMF, &u) (sampling.h:79-113) */
+            float sumW = 0; sumW += ci[0]; sumW += ci[1];
+            float up = u * sumW;
+            if (up == sumW) up = next_float_down(up);
+            int offset = 0; float sum = 0;
+            while (sum + ci[offset] <= up) sum += ci[offset++];
+            float nodePMF = ci[offset] / sumW;
+            u = fminf((up - sum) / ci[offset], ONE_MINUS_EPS);
+            pm *= nodePMF;
+            nodeIndex = offset == 0 ? nodeIndex + 1 : (int)node->child_or_light;
+        } else {
+            if (nodeIndex > 0 || lbvh_importance(node, p, n) > 0) { *lightIndex = (int)node->child_or_light; *pmf = pm; return 1; }
+            return 0;
+        }
+    }
+}
+/* lightSampler.PMF(ctx, light) */
+static float lightsampler_pmf(const OracleRenderer *r, const lightsampler_t *ls, v3 p, v3 n, int lightIndex) {
+    const int n_all = r->n_lights + r->n_inf;
+    if (r->prm.lightsampler == VSPG_LIGHTSAMPLER_UNIFORM) return n_all ? 1.f / (float)n_all : 0.f;
+    if (r->prm.lightsampler == VSPG_LIGHTSAMPLER_POWER) return ls->n_alias ? ls->alias_p[lightIndex] : 0.f;
+    /* BVHLightSampler::PMF (lightsamplers.h:344-381) */
+    if (ls->bit_trail[lightIndex] == 0xffffffffu) return 1.f / (float)(ls->n_inf + (ls->n_nodes == 0 ? 0 : 1));
+    uint32_t bitTrail = ls->bit_trail[lightIndex];
+    const float pInfinite = (float)ls->n_inf / (float)(ls->n_inf + (ls->n_nodes == 0 ? 0 : 1));
+    float pm = 1 - pInfinite;
+    int nodeIndex = 0;
+    while (1) {
+        const lbvh_node_t *node = &ls->nodes[nodeIndex];
+        if (node->is_leaf) return pm;
+        float ci[2] = {lbvh_importance(&ls->nodes[nodeIndex + 1], p, n), lbvh_importance(&ls->nodes[node->child_or_light], p, n)};
+        pm *= ci[bitTrail & 1] / (ci[0] + ci[1]);
+        nodeIndex = (bitTrail & 1) ? (int)node->child_or_light : nodeIndex + 1;
+        bitTrail >>= 1;
+    }
+}
+
+/* lightSampler.Sample(ctx, u) / PMF(ctx, light) for n contexts {p, ns} (tests/test_oracle_lightsamplers.py) */
+int oracle_light_sample_batch(OracleRenderer *r, int n, const float *p, const float *ns, const float *u, int32_t *out_light, float *out_pmf) {
+    for (int i = 0; i < n; ++i) {
+        int li = -1; float pm = 0;
+        if (!lightsampler_sample(r, r->lsamp, v3_from(p + 3 * i), v3_from(ns + 3 * i), u[i], &li, &pm)) { li = -1; pm = 0; }
+        out_light[i] = li; out_pmf[i] = pm;
+    }
+    return 0;
+}
+int oracle_light_pmf_batch(OracleRenderer *r, int n, const float *p, const float *ns, const int32_t *light, float *out_pmf) {
+    for (int i = 0; i < n; ++i) out_pmf[i] = lightsampler_pmf(r, r->lsamp, v3_from(p + 3 * i), v3_from(ns + 3 * i), light[i]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* a15: SampleLd (guidedvolpathvspgintegrator.cpp:1136-1252), guiding distributions        */
 /* inactive (field untrained => GuidedBSDF/GuidedPhaseFunction fall through to the plain   */
 /* BSDF / phase function, guiding.h:115-118,271-289,400-402,542-558)                       */
@@ -1694,16 +2114,10 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
         if (intr->bsdf->has_lobes) ctxp = offset_ray_origin(intr->pi, intr->n, intr->wo);
     }
     float u = sampler_get1d(sampler);
-    /* UniformLightSampler::Sample (lightsamplers.h:33-38) */
-    const int n_all = r->n_lights + r->n_inf;
-    int have_light = n_all > 0;
+    /* lightSampler.Sample(ctx, u) (:1157): uniform / power / bvh; ctx.p() is the (offset) point, ctx.ns the surface normal (0 in a medium) */
     int lightIndex = 0;
     float lightPmf = 0;
-    if (have_light) {
-        int li = (int)(u * (float)n_all);
-        lightIndex = li < n_all - 1 ? li : n_all - 1;
-        lightPmf = 1.f / (float)n_all;
-    }
+    const int have_light = lightsampler_sample(r, r->lsamp, ctxp, intr->is_surface ? intr->n : V3(0, 0, 0), u, &lightIndex, &lightPmf);
     float ul0 = sampler_get1d(sampler), ul1 = sampler_get1d(sampler);
     if (!have_light) return S1(0.f);
     lightli_t ls;
@@ -2310,7 +2724,6 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         }
         rec_add_transmittance_weight(rec, transmittanceWeight); /* :350 */
         if (!si.hit) { /* :353-374: contributions from infinite light sources (this fork lists DeltaDirection lights there too, integrators.h:79) */
-            const int n_all = r->n_lights + r->n_inf;
             for (int k = 0; k < r->n_inf; ++k) {
                 const VspgInfiniteLight *il = &r->scene.infinite_lights[k];
                 spec Le = s_from(il->L); /* UniformInfiniteLight::Le / DistantLight::Le (lights.cpp:1014-1017, lights.h:291-293) */
@@ -2320,7 +2733,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
                     rec_add_infinite_light_emission(rec, ro, rd, Le, 1.0f); /* :361 */
                 } else {
                     /* lightSampler.PMF * light.PDF_Li(prevIntrContext, ray.d, true): both light types return 0 for the incomplete PDF */
-                    float lightPDF = (1.f / (float)n_all) * 0.f;
+                    float lightPDF = lightsampler_pmf(r, r->lsamp, p3i_mid(prevIntrCtx.pi), prevIntrCtx.ns, r->n_lights + k) * 0.f;
                     r_l = s_scale(r_l, lightPDF);
                     float w_b = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.f;
                     L = s_add(L, s_mul(s_scale(beta, w_b), Le));
@@ -2343,7 +2756,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
                 w_direct = 1.0f;
             } else {
                 DBG(lastVertexVolume ? 2 : 4);
-                float lightPDF = (1.f / (float)(r->n_lights + r->n_inf)) * light_pdf_li(q, &prevIntrCtx, rd);
+                float lightPDF = lightsampler_pmf(r, r->lsamp, p3i_mid(prevIntrCtx.pi), prevIntrCtx.ns, r->light_of_quad[si.quad]) * light_pdf_li(q, &prevIntrCtx, rd);
                 r_l = s_scale(r_l, lightPDF);
                 float w_l = r->prm.usenee ? 1.0f / s_avg(s_add(r_u, r_l)) : 1.0f;
                 L = s_add(L, s_mul(s_scale(beta, w_l), Le));
@@ -3021,7 +3434,8 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
     r->n_quads = scene->n_quads;
     for (int i = 0; i < r->n_quads; ++i) {
         quad_init(&r->quads[i], &scene->quads[i]);
-        if (r->quads[i].is_light) r->light_quads[r->n_lights++] = i;
+        r->light_of_quad[i] = -1;
+        if (r->quads[i].is_light) { r->light_of_quad[i] = r->n_lights; r->light_quads[r->n_lights++] = i; }
     }
     if (scene->n_triangles > 0 && scene->tri_p) { /* f1: what InteractionFromIntersection derives per triangle (shapes.h:888-938) */
         r->tris = (rtri_t *)calloc((size_t)scene->n_triangles, sizeof(rtri_t));
@@ -3076,6 +3490,8 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
             r->scene_radius = sqrtf(dx * dx + dy * dy + dz * dz); /* Distance(center, pMax) */
         }
     }
+    r->lsamp = (lightsampler_t *)calloc(1, sizeof(lightsampler_t));
+    lightsampler_build(r, r->lsamp);
     if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;
         size_t n = (size_t)m->nx * m->ny * m->nz;
@@ -3131,7 +3547,7 @@ void oracle_renderer_destroy(OracleRenderer *r) {
     free_field(r, 0); free_field(r, 1);
     free(r->samples);
     free(r->trbuf); free(r->tr_spp); free(r->le_scale); free(r->contrib);
-    free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r->tris); free(r);
+    free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r->tris); free(r->lsamp); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {
     size_t n = (size_t)r->cfg.xres * r->cfg.yres * 4;

@@ -100,6 +100,9 @@ int oracle_sample_tmaj_batch(OracleRenderer *r, int variant, int n, const VspgTm
 
 int oracle_renderer_set_guiding_field(OracleRenderer *r, const VspgField *surface_field,
                                       const VspgField *volume_field);
+/* lightSampler.Sample(ctx, u) / PMF(ctx, light) of the renderer's light sampler (prm.lightsampler) for n contexts {p, ns} */
+int oracle_light_sample_batch(OracleRenderer *r, int n, const float *p, const float *ns, const float *u, int32_t *out_light, float *out_pmf);
+int oracle_light_pmf_batch(OracleRenderer *r, int n, const float *p, const float *ns, const int32_t *light, float *out_pmf);
 int oracle_guiding_query_batch(OracleRenderer *r, int is_volume, float g, int n, const float *p,
                                const float *n_or_wo, const float *wi, const float *u, int32_t *out_ok,
                                float *out_pdf, float *out_incoming_pdf, float *out_vsp, float *out_ws,

@@ -46,6 +46,8 @@ def load():
         "oracle_apply_inverse_point": (None, [C.c_float * 16, f3, f3]),
         "oracle_bounds3": (C.c_int, [f3, f3, f3, f3, C.c_float, C.POINTER(C.c_float * 2), f3]),
         "oracle_independent_sampler": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, p(C.c_float)]),
+        "oracle_light_sample_batch": (C.c_int, [vp, C.c_int, p(C.c_float), p(C.c_float), p(C.c_float), p(C.c_int32), p(C.c_float)]),
+        "oracle_light_pmf_batch": (C.c_int, [vp, C.c_int, p(C.c_float), p(C.c_float), p(C.c_int32), p(C.c_float)]),
         "oracle_renderer_create": (C.c_int, [p(P.VspgScene), p(P.VspgIntegratorParams), p(P.VspgRenderConfig), p(vp)]),
         "oracle_renderer_destroy": (None, [vp]),
         "oracle_render_wave": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
@@ -244,6 +246,25 @@ class OracleRenderer:
 
     def guiding_query_batch(self, is_volume, g, p, n_or_wo, wi, u):
         return guiding_query(self.lib.oracle_guiding_query_batch, self.h, is_volume, g, p, n_or_wo, wi, u, None)
+
+    def light_sample_batch(self, p, ns, u):
+        """lightSampler.Sample(ctx, u) per context: (light index into {emissive rectangles, infinite lights}, -1 = none; pmf)"""
+        fp = C.POINTER(C.c_float)
+        p, ns, u = (np.ascontiguousarray(x, dtype=np.float32) for x in (p, ns, u))
+        li = np.zeros(len(u), dtype=np.int32)
+        pmf = np.zeros(len(u), dtype=np.float32)
+        self.lib.oracle_light_sample_batch(self.h, len(u), p.ctypes.data_as(fp), ns.ctypes.data_as(fp), u.ctypes.data_as(fp),
+                                           li.ctypes.data_as(C.POINTER(C.c_int32)), pmf.ctypes.data_as(fp))
+        return li, pmf
+
+    def light_pmf_batch(self, p, ns, light):
+        fp = C.POINTER(C.c_float)
+        p, ns = (np.ascontiguousarray(x, dtype=np.float32) for x in (p, ns))
+        light = np.ascontiguousarray(light, dtype=np.int32)
+        pmf = np.zeros(len(light), dtype=np.float32)
+        self.lib.oracle_light_pmf_batch(self.h, len(light), p.ctypes.data_as(fp), ns.ctypes.data_as(fp),
+                                        light.ctypes.data_as(C.POINTER(C.c_int32)), pmf.ctypes.data_as(fp))
+        return pmf
 
 
 def guiding_query(fn, handle, is_volume, g, p, n_or_wo, wi, u, stream):

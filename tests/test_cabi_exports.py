@@ -84,7 +84,10 @@ def test_parameter_validation_and_no_cpu_fallback(pkg):
     prm.lightsampler = pkg.LIGHTSAMPLER_POWER
     two_lights = pkg.fog_box_scene(32, 32)
     two_lights.quads[0].Le[0] = two_lights.quads[0].Le[1] = two_lights.quads[0].Le[2] = 1.0   # a second emitter
-    assert lib.vspg_renderer_create(C.byref(two_lights), C.byref(prm), C.byref(cfg), C.byref(h)) == pkg.VSPG_ESCOPE
+    rc = lib.vspg_renderer_create(C.byref(two_lights), C.byref(prm), C.byref(cfg), C.byref(h))
+    assert rc in (0, pkg.VSPG_ENODEVICE)   # (round 3: "power" / "bvh" serve any number of lights; without a GPU the create call stops at the device)
+    if rc == 0:
+        lib.vspg_renderer_destroy(h)
     prm = pkg.app_f_params()
     prm.vspmisratio = 1.5
     assert create(prm, cfg) == pkg.VSPG_EINVAL

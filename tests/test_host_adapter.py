@@ -241,7 +241,7 @@ def test_scene_file_cloud_sky_with_default_guiding(host_build, tmp_path):
     text = open(os.path.join(SCENES, "cloud_sky.pbrt")).read()
     start = text.index('Integrator "guidedvolpathvspg"')
     end = text.index("WorldBegin")
-    guided = text[:start] + 'Integrator "guidedvolpathvspg" "integer maxdepth" 4 "string lightsampler" "uniform"\n' + text[end:]
+    guided = text[:start] + 'Integrator "guidedvolpathvspg" "integer maxdepth" 4\n' + text[end:]
     gs = tmp_path / "cloud_sky_guided.pbrt"
     gs.write_text(guided)
     imgs = {}
@@ -304,7 +304,6 @@ def test_scene_file_cloud_sky_renders(host_build, gpu_pkg, tmp_path):
     P.add_infinite_light(s, P.LIGHT_DISTANT, (9, 8, 6.5), (0.3, 1, -0.4))
     prm = P.app_f_params()
     prm.maxdepth = 4
-    prm.lightsampler = P.LIGHTSAMPLER_UNIFORM
     r = P.Renderer(s, prm, W, H)
     for w in range(16):
         r.render_wave(w, w + 1)

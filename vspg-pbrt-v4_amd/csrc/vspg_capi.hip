@@ -1602,6 +1602,298 @@ static PcgJump pcg_jump(unsigned long long delta) {
     return PcgJump{accMult, accPlus};
 }
 
+// ---- light samplers: host-side build (lightsamplers.cpp:76-99 PowerLightSampler, :108-262 BVHLightSampler::buildBVH) ----------
+// The reference's construction restated: LightBounds of every bounded light (DiffuseAreaLight::Bounds on a rectangle), the
+// modified-SAH split over 12 buckets per axis, CompactLightBounds' quantisation.  The CPU checker states the same thing in C
+// (oracle/vspg_oracle.c, "light samplers"); both run the same float operations on the same libm, so the trees are equal.
+namespace lsb {
+struct v3 { float x, y, z; };
+static inline v3 V3(float x, float y, float z) { return v3{x, y, z}; }
+static inline v3 v_add(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline v3 v_sub(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline v3 v_scale(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
+static inline v3 v_neg(v3 a) { return v3{-a.x, -a.y, -a.z}; }
+static inline float v_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float v_len2(v3 a) { return v_dot(a, a); }
+static inline float v_len(v3 a) { return sqrtf(v_len2(a)); }
+static inline v3 v_normalize(v3 a) { float l = v_len(a); return v3{a.x / l, a.y / l, a.z / l}; }
+static inline float dop(float a, float b, float c, float d) { return hostmath::dop(a, b, c, d); }
+static inline v3 v_cross(v3 v, v3 w) { return v3{dop(v.y, w.z, v.z, w.y), dop(v.z, w.x, v.x, w.z), dop(v.x, w.y, v.y, w.x)}; }
+static inline float sqr(float x) { return x * x; }
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float safe_sqrt(float x) { return sqrtf(x > 0 ? x : 0.f); }
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr int LBVH_MAX_LIGHTS = kMaxLights;
+struct lightbounds_t { v3 bmin, bmax; float phi; v3 w; float cosTheta_o, cosTheta_e; int twoSided; };
+static float safe_asin_f(float x) { return asinf(clampf(x, -1, 1)); }
+static float safe_acos_f(float x) { return acosf(clampf(x, -1, 1)); }
+static float angle_between(v3 a, v3 b) { /* vecmath.h:972-977 */
+    if (v_dot(a, b) < 0) return PI_F - 2 * safe_asin_f(v_len(v_add(a, b)) / 2);
+    return 2 * safe_asin_f(v_len(v_sub(b, a)) / 2);
+}
+typedef struct { v3 w; float cosTheta; } dircone_t; /* DirectionCone (vecmath.h:1785-1808); cosTheta == INFINITY: empty */
+static dircone_t dircone(v3 w, float c) { dircone_t d; d.w = v_normalize(w); d.cosTheta = c; return d; }
+static dircone_t dircone_union(dircone_t a, dircone_t b) { /* vecmath.cpp:56-83 */
+    if (std::isinf(a.cosTheta)) return b;
+    if (std::isinf(b.cosTheta)) return a;
+    float theta_a = safe_acos_f(a.cosTheta), theta_b = safe_acos_f(b.cosTheta);
+    float theta_d = angle_between(a.w, b.w);
+    if (fminf(theta_d + theta_b, PI_F) <= theta_a) return a;
+    if (fminf(theta_d + theta_a, PI_F) <= theta_b) return b;
+    float theta_o = (theta_a + theta_d + theta_b) / 2;
+    if (theta_o >= PI_F) return dircone(V3(0, 0, 1), -1);
+    float theta_r = theta_o - theta_a;
+    v3 wr = v_cross(a.w, b.w);
+    if (v_len2(wr) == 0) return dircone(V3(0, 0, 1), -1);
+    /* Rotate(Degrees(theta_r), wr)(a.w) (transform.h:220-247): sin / cos of Radians(Degrees(theta_r)) */
+    float deg = (180 / PI_F) * theta_r, rad = (PI_F / 180) * deg;
+    float sinT = sinf(rad), cosT = cosf(rad);
+    v3 ax = v_normalize(wr);
+    float m[3][3];
+    m[0][0] = ax.x * ax.x + (1 - ax.x * ax.x) * cosT; m[0][1] = ax.x * ax.y * (1 - cosT) - ax.z * sinT; m[0][2] = ax.x * ax.z * (1 - cosT) + ax.y * sinT;
+    m[1][0] = ax.x * ax.y * (1 - cosT) + ax.z * sinT; m[1][1] = ax.y * ax.y + (1 - ax.y * ax.y) * cosT; m[1][2] = ax.y * ax.z * (1 - cosT) - ax.x * sinT;
+    m[2][0] = ax.x * ax.z * (1 - cosT) - ax.y * sinT; m[2][1] = ax.y * ax.z * (1 - cosT) + ax.x * sinT; m[2][2] = ax.z * ax.z + (1 - ax.z * ax.z) * cosT;
+    v3 w = V3(m[0][0] * a.w.x + m[0][1] * a.w.y + m[0][2] * a.w.z, m[1][0] * a.w.x + m[1][1] * a.w.y + m[1][2] * a.w.z,
+              m[2][0] * a.w.x + m[2][1] * a.w.y + m[2][2] * a.w.z); /* Transform::operator()(Vector3f), transform.h:351-356 */
+    return dircone(w, cosf(theta_o));
+}
+static lightbounds_t lb_empty(void) { lightbounds_t b; std::memset(&b, 0, sizeof b); b.bmin = V3(INFINITY, INFINITY, INFINITY); b.bmax = V3(-INFINITY, -INFINITY, -INFINITY); return b; }
+static v3 v_min3(v3 a, v3 b) { return V3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+static v3 v_max3(v3 a, v3 b) { return V3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+static lightbounds_t lb_union(lightbounds_t a, lightbounds_t b) { /* lights.h:137-153 */
+    if (a.phi == 0) return b;
+    if (b.phi == 0) return a;
+    dircone_t ca, cb; ca.w = a.w; ca.cosTheta = a.cosTheta_o; cb.w = b.w; cb.cosTheta = b.cosTheta_o;
+    ca.w = v_normalize(ca.w); cb.w = v_normalize(cb.w); /* DirectionCone(w, cosTheta) normalises */
+    dircone_t cone = dircone_union(ca, cb);
+    lightbounds_t r;
+    r.bmin = v_min3(a.bmin, b.bmin); r.bmax = v_max3(a.bmax, b.bmax);
+    r.w = v_normalize(cone.w);
+    r.phi = a.phi + b.phi;
+    r.cosTheta_o = cone.cosTheta;
+    r.cosTheta_e = fminf(a.cosTheta_e, b.cosTheta_e);
+    r.twoSided = a.twoSided | b.twoSided;
+    return r;
+}
+static v3 lb_centroid(const lightbounds_t *b) { return v_scale(v_add(b->bmin, b->bmax), 0.5f); } /* (pMin + pMax) / 2 */
+static float vcomp(v3 v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
+/* CompactLightBounds(lb, allb) and back through its accessors (lightsamplers.h:100-142, 212-242; vecmath.h:1733-1782) */
+static float quantize_bounds(float c, float mn, float mx) { return mn == mx ? 0.f : 65535.f * clampf((c - mn) / (mx - mn), 0, 1); }
+static float lerpf(float t, float a, float b) { return (1 - t) * a + t * b; }
+static uint16_t oct_encode(float f) { return (uint16_t)std::round(clampf((f + 1) / 2, 0, 1) * 65535.f); }
+static void compact_node(DLightNode *nd, const lightbounds_t *lb, v3 amin, v3 amax) {
+    /* OctahedralVector(Normalize(lb.w)) -> Vector3f */
+    v3 v = v_normalize(lb->w);
+    float l1 = fabsf(v.x) + fabsf(v.y) + fabsf(v.z);
+    v = V3(v.x / l1, v.y / l1, v.z / l1);
+    uint16_t ox, oy;
+    if (v.z >= 0) { ox = oct_encode(v.x); oy = oct_encode(v.y); }
+    else { ox = oct_encode((1 - fabsf(v.y)) * copysignf(1.f, v.x)); oy = oct_encode((1 - fabsf(v.x)) * copysignf(1.f, v.y)); }
+    v3 d;
+    d.x = -1 + 2 * (ox / 65535.f);
+    d.y = -1 + 2 * (oy / 65535.f);
+    d.z = 1 - (fabsf(d.x) + fabsf(d.y));
+    if (d.z < 0) { float xo = d.x; d.x = (1 - fabsf(d.y)) * copysignf(1.f, xo); d.y = (1 - fabsf(xo)) * copysignf(1.f, d.y); }
+    { const v3 wn = v_normalize(d); nd->w[0] = wn.x; nd->w[1] = wn.y; nd->w[2] = wn.z; }
+    nd->phi = lb->phi;
+    unsigned qo = (unsigned)floorf(32767.f * ((lb->cosTheta_o + 1) / 2)), qe = (unsigned)floorf(32767.f * ((lb->cosTheta_e + 1) / 2));
+    nd->cosTheta_o = 2 * (qo / 32767.f) - 1;
+    nd->cosTheta_e = 2 * (qe / 32767.f) - 1;
+    nd->twoSided = lb->twoSided;
+    float lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) {
+        uint16_t q0 = (uint16_t)floorf(quantize_bounds(vcomp(lb->bmin, c), vcomp(amin, c), vcomp(amax, c)));
+        uint16_t q1 = (uint16_t)ceilf(quantize_bounds(vcomp(lb->bmax, c), vcomp(amin, c), vcomp(amax, c)));
+        lo[c] = lerpf(q0 / 65535.f, vcomp(amin, c), vcomp(amax, c));
+        hi[c] = lerpf(q1 / 65535.f, vcomp(amin, c), vcomp(amax, c));
+    }
+    for (int c = 0; c < 3; ++c) { nd->bmin[c] = lo[c]; nd->bmax[c] = hi[c]; }
+}
+static float lb_evaluate_cost(const lightbounds_t *b, v3 bdiag, int dim) { /* lightsamplers.h:398-411 */
+    float theta_o = acosf(b->cosTheta_o), theta_e = acosf(b->cosTheta_e);
+    float theta_w = fminf(theta_o + theta_e, PI_F);
+    float sinTheta_o = safe_sqrt(1 - sqr(b->cosTheta_o));
+    float M_omega = 2 * PI_F * (1 - b->cosTheta_o) +
+                    PI_F / 2 * (2 * theta_w * sinTheta_o - cosf(theta_o - 2 * theta_w) - 2 * theta_o * sinTheta_o + b->cosTheta_o);
+    float Kr = fmaxf(bdiag.x, fmaxf(bdiag.y, bdiag.z)) / vcomp(bdiag, dim);
+    v3 d = v_sub(b->bmax, b->bmin);
+    float area = 2 * (d.x * d.y + d.x * d.z + d.y * d.z); /* Bounds3::SurfaceArea */
+    return b->phi * M_omega * Kr * area;
+}
+typedef struct { int light; lightbounds_t lb; } lbvh_item_t;
+static int lbvh_bucket(const lightbounds_t *lb, v3 cmin, v3 cmax, int dim) { /* nBuckets * centroidBounds.Offset(pc)[dim], 12 buckets */
+    float pc = vcomp(lb_centroid(lb), dim), mn = vcomp(cmin, dim), mx = vcomp(cmax, dim);
+    float o = pc - mn;
+    if (mx > mn) o /= mx - mn;
+    int b = (int)(12 * o);
+    return b == 12 ? 11 : b;
+}
+static int lbvh_build(DLightSampler *ls, lbvh_item_t *it, int start, int end, uint32_t bitTrail, int depth, v3 amin, v3 amax, lightbounds_t *out) {
+    if (end - start == 1) {
+        int nodeIndex = ls->n_nodes++;
+        compact_node(&ls->nodes[nodeIndex], &it[start].lb, amin, amax);
+        ls->nodes[nodeIndex].child_or_light = (uint32_t)it[start].light;
+        ls->nodes[nodeIndex].is_leaf = 1;
+        ls->bit_trail[it[start].light] = bitTrail;
+        *out = it[start].lb;
+        return nodeIndex;
+    }
+    v3 bmin = V3(INFINITY, INFINITY, INFINITY), bmax = V3(-INFINITY, -INFINITY, -INFINITY), cmin = bmin, cmax = bmax;
+    for (int i = start; i < end; ++i) {
+        bmin = v_min3(bmin, it[i].lb.bmin); bmax = v_max3(bmax, it[i].lb.bmax);
+        v3 c = lb_centroid(&it[i].lb);
+        cmin = v_min3(cmin, c); cmax = v_max3(cmax, c);
+    }
+    float minCost = INFINITY;
+    int minCostSplitBucket = -1, minCostSplitDim = -1;
+    const v3 bdiag = v_sub(bmax, bmin);
+    for (int dim = 0; dim < 3; ++dim) {
+        if (vcomp(cmax, dim) == vcomp(cmin, dim)) continue;
+        lightbounds_t bucket[12];
+        for (int b = 0; b < 12; ++b) bucket[b] = lb_empty();
+        for (int i = start; i < end; ++i) {
+            int b = lbvh_bucket(&it[i].lb, cmin, cmax, dim);
+            bucket[b] = lb_union(bucket[b], it[i].lb);
+        }
+        float cost[11];
+        for (int i = 0; i < 11; ++i) {
+            lightbounds_t b0 = lb_empty(), b1 = lb_empty();
+            for (int j = 0; j <= i; ++j) b0 = lb_union(b0, bucket[j]);
+            for (int j = i + 1; j < 12; ++j) b1 = lb_union(b1, bucket[j]);
+            cost[i] = lb_evaluate_cost(&b0, bdiag, dim) + lb_evaluate_cost(&b1, bdiag, dim);
+        }
+        for (int i = 1; i < 11; ++i)
+            if (cost[i] > 0 && cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; minCostSplitDim = dim; }
+    }
+    int mid;
+    if (minCostSplitDim == -1) mid = (start + end) / 2;
+    else {
+        /* std::partition (libstdc++, forward-iterator form is not used for pointers: the bidirectional algorithm) */
+        int first = start, last = end;
+        while (1) {
+            while (1) {
+                if (first == last) goto done;
+                if (lbvh_bucket(&it[first].lb, cmin, cmax, minCostSplitDim) <= minCostSplitBucket) ++first; else break;
+            }
+            --last;
+            while (1) {
+                if (first == last) goto done;
+                if (!(lbvh_bucket(&it[last].lb, cmin, cmax, minCostSplitDim) <= minCostSplitBucket)) --last; else break;
+            }
+            lbvh_item_t t = it[first]; it[first] = it[last]; it[last] = t;
+            ++first;
+        }
+    done:
+        mid = first;
+        if (mid == start || mid == end) mid = (start + end) / 2;
+    }
+    int nodeIndex = ls->n_nodes++;
+    lightbounds_t l0, l1;
+    lbvh_build(ls, it, start, mid, bitTrail, depth + 1, amin, amax, &l0);
+    int child1 = lbvh_build(ls, it, mid, end, bitTrail | (1u << depth), depth + 1, amin, amax, &l1);
+    lightbounds_t lb = lb_union(l0, l1);
+    compact_node(&ls->nodes[nodeIndex], &lb, amin, amax);
+    ls->nodes[nodeIndex].child_or_light = (uint32_t)child1;
+    ls->nodes[nodeIndex].is_leaf = 0;
+    *out = lb;
+    return nodeIndex;
+}
+static lightbounds_t quad_light_bounds(const DQuad &q, int reverse_orientation) {  // lights.cpp:845-864; shapes.cpp:1070-1126
+    const v3 p00 = V3(q.p00[0], q.p00[1], q.p00[2]), p10 = V3(q.p10[0], q.p10[1], q.p10[2]), p01 = V3(q.p01[0], q.p01[1], q.p01[2]),
+             p11 = V3(q.p11[0], q.p11[1], q.p11[2]);
+    lightbounds_t lb;
+    lb.bmin = v_min3(v_min3(p00, p01), v_min3(p10, p11));
+    lb.bmax = v_max3(v_max3(p00, p01), v_max3(p10, p11));
+    v3 n00 = v_normalize(v_cross(v_sub(p10, p00), v_sub(p01, p00)));
+    v3 n10 = v_normalize(v_cross(v_sub(p11, p10), v_sub(p00, p10)));
+    v3 n01 = v_normalize(v_cross(v_sub(p00, p01), v_sub(p11, p01)));
+    v3 n11 = v_normalize(v_cross(v_sub(p01, p11), v_sub(p10, p11)));
+    if (reverse_orientation) { n00 = v_neg(n00); n10 = v_neg(n10); n01 = v_neg(n01); n11 = v_neg(n11); }
+    v3 n = v_normalize(v_add(v_add(n00, n10), v_add(n01, n11)));
+    float cosTheta = fminf(fminf(v_dot(n, n00), v_dot(n, n01)), fminf(v_dot(n, n10), v_dot(n, n11)));
+    dircone_t nb = dircone(n, clampf(cosTheta, -1, 1));
+    float phi = fmaxf(q.Le[0], fmaxf(q.Le[1], q.Le[2]));  // Lemit->MaxValue(), RGB rendering mode (spectrum.h:772-779)
+    phi *= 1.f * q.area * PI_F;                           // scale * area * Pi
+    lb.w = v_normalize(nb.w);
+    lb.phi = phi;
+    lb.cosTheta_o = nb.cosTheta;
+    lb.cosTheta_e = cosf(PI_F / 2);
+    lb.twoSided = q.two_sided;
+    return lb;
+}
+static void build(const VspgScene &sc, const VspgIntegratorParams &prm, DScene *D) {
+    DLightSampler *ls = &D->lsamp;
+    std::memset(ls, 0, sizeof *ls);
+    const int n_all = D->n_lights + D->n_inf;
+    for (int i = 0; i < kMaxLights; ++i) ls->bit_trail[i] = 0xffffffffu;
+    for (int i = 0; i < VSPG_MAX_QUADS; ++i) ls->light_of_quad[i] = -1;
+    for (int i = 0; i < D->n_lights; ++i) ls->light_of_quad[D->light_quads[i]] = i;
+    // every sampler picks a scene's only light with pmf 1: the two-line uniform pick serves (and keeps the workgroup kernels)
+    ls->mode = n_all > 1 ? prm.lightsampler : VSPG_LIGHTSAMPLER_UNIFORM;
+    lbvh_item_t items[LBVH_MAX_LIGHTS];
+    int n_items = 0;
+    v3 amin = V3(INFINITY, INFINITY, INFINITY), amax = V3(-INFINITY, -INFINITY, -INFINITY);
+    for (int i = 0; i < n_all; ++i) {
+        if (i >= D->n_lights) { ls->inf_light[ls->n_inf++] = i; continue; }  // Bounds() == {}
+        const int qi = D->light_quads[i];
+        lightbounds_t lb = quad_light_bounds(D->quads[qi], sc.quads[qi].reverse_orientation);
+        if (lb.phi > 0) {
+            items[n_items].light = i; items[n_items].lb = lb; n_items++;
+            amin = v_min3(amin, lb.bmin); amax = v_max3(amax, lb.bmax);
+        }
+    }
+    if (n_items > 0) { lightbounds_t root; lbvh_build(ls, items, 0, n_items, 0, 0, amin, amax, &root); }
+    // PowerLightSampler: phi = SafeDiv(light.Phi(lambda), lambda.PDF()).Average(), lambda = SampledWavelengths::SampleVisible(0.5f)
+    if (n_all > 0) {
+        float pdf[3], power[LBVH_MAX_LIGHTS], acc0 = 0.f;
+        for (int i = 0; i < 3; ++i) {
+            float up = 0.5f + (float)i / 3;
+            if (up > 1) up -= 1;
+            float lambda = 538 - 138.888889f * atanhf(0.85691062f - 1.82750197f * up);
+            pdf[i] = lambda < 360 || lambda > 830 ? 0.f : 0.0039398042f / sqr(coshf(0.0072f * (lambda - 538)));
+        }
+        for (int i = 0; i < n_all; ++i) {
+            float L[3], k;
+            if (i < D->n_lights) {
+                const DQuad &q = D->quads[D->light_quads[i]];
+                for (int c = 0; c < 3; ++c) L[c] = q.Le[c];
+                k = PI_F * (q.two_sided ? 2 : 1) * q.area;  // DiffuseAreaLight::Phi (lights.cpp:826-843)
+            } else {
+                const int j = i - D->n_lights;
+                for (int c = 0; c < 3; ++c) L[c] = D->inf_L[j][c];
+                k = D->inf_type[j] == VSPG_LIGHT_DISTANT ? PI_F * sqr(D->scene_radius) : 4 * PI_F * PI_F * sqr(D->scene_radius);
+            }
+            float s = 0.f;
+            for (int c = 0; c < 3; ++c) s += pdf[c] != 0 ? (k * L[c]) / pdf[c] : 0.f;
+            power[i] = s / 3;
+            acc0 += power[i];
+        }
+        if (acc0 == 0.f) for (int i = 0; i < n_all; ++i) power[i] = 1.f;
+        double sum = 0.;  // AliasTable (util/sampling.cpp:563-618)
+        for (int i = 0; i < n_all; ++i) sum += power[i];
+        const float fsum = (float)sum;
+        ls->n_alias = n_all;
+        struct { float pHat; int index; } under[LBVH_MAX_LIGHTS], over[LBVH_MAX_LIGHTS];
+        int nu = 0, no = 0;
+        for (int i = 0; i < n_all; ++i) {
+            ls->alias_p[i] = power[i] / fsum;
+            float pHat = ls->alias_p[i] * n_all;
+            if (pHat < 1) { under[nu].pHat = pHat; under[nu].index = i; nu++; } else { over[no].pHat = pHat; over[no].index = i; no++; }
+        }
+        while (nu > 0 && no > 0) {
+            float upH = under[nu - 1].pHat, ovH = over[no - 1].pHat;
+            int ui = under[nu - 1].index, oi = over[no - 1].index;
+            nu--; no--;
+            ls->alias_q[ui] = upH; ls->alias_i[ui] = oi;
+            float pExcess = upH + ovH - 1;
+            if (pExcess < 1) { under[nu].pHat = pExcess; under[nu].index = oi; nu++; } else { over[no].pHat = pExcess; over[no].index = oi; no++; }
+        }
+        while (no > 0) { no--; ls->alias_q[over[no].index] = 1; ls->alias_i[over[no].index] = -1; }
+        while (nu > 0) { nu--; ls->alias_q[under[nu].index] = 1; ls->alias_i[under[nu].index] = -1; }
+    }
+}
+}  // namespace lsb
+
 static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T);
 static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, const VspgRenderConfig &cfg, DScene *D) {
     using namespace hostmath;
@@ -1718,6 +2010,7 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
     D->seed = cfg.seed;
     D->shard_index = cfg.shard_index;
     D->shard_count = cfg.shard_count < 1 ? 1 : cfg.shard_count;
+    lsb::build(sc, prm, D);  // LightSampler::Create(prm.lightsampler, lights) (lightsamplers.cpp:49-64)
 }
 
 // GridMedium constructor: majorantGrid.Set(x,y,z, densityGrid.MaxValue(VoxelBounds(x,y,z)))
@@ -1969,10 +2262,7 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     int nl = scene->n_infinite_lights;
     for (int i = 0; i < scene->n_quads; ++i)
         if (scene->quads[i].Le[0] != 0 || scene->quads[i].Le[1] != 0 || scene->quads[i].Le[2] != 0) nl++;
-    if (p->lightsampler == VSPG_LIGHTSAMPLER_BVH && nl > 1)
-        return fail(VSPG_ESCOPE, "lightsampler \"bvh\" with more than one light is outside scope: use \"uniform\"");
-    if (p->lightsampler == VSPG_LIGHTSAMPLER_POWER && nl > 1)
-        return fail(VSPG_ESCOPE, "lightsampler \"power\" with more than one light is outside scope: use \"uniform\"");
+    (void)nl;  // (round 3: "power" and "bvh" serve any number of lights -- vspg_lightsampler.h)
     return 0;
 }
 
@@ -2474,13 +2764,13 @@ static bool uses_wg_guided(const VspgRenderer *r) {
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wg") != 0) return false;
     return wants_guiding(r->prm) && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
-           r->hscene.n_tris == 0 && r->hscene.n_inf == 0;
+           r->hscene.n_tris == 0 && r->hscene.n_inf == 0 && r->hscene.lsamp.mode == VSPG_LIGHTSAMPLER_UNIFORM;
 }
 // guided renders over a homogeneous medium: the grey / zero-null-coefficient / rectangle-scene instantiation of the per-lane
 // kernel (the segment half of the loop sheds the same per-channel work as the headline kernel's instantiation)
 static bool guided_grey_simple(const VspgRenderer *r) {
     return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS && r->medium_grey && r->surfaces_grey && r->null_zero && r->hscene.n_tris == 0 &&
-           r->hscene.n_inf == 0 && !getenv("VSPG_NO_GREY_GUIDED");
+           r->hscene.n_inf == 0 && r->hscene.lsamp.mode == VSPG_LIGHTSAMPLER_UNIFORM && !getenv("VSPG_NO_GREY_GUIDED");
 }
 static bool uses_wg_kernel(const VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
@@ -2493,6 +2783,7 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
     // triangle hits carry a per-hit error bound the LDS pool record has no room for, and the kernel's homogeneous instantiations
     // are built for rectangle scenes with area lights only (HomogeneousMediumT::kSimpleScene)
     if (r->hscene.n_tris > 0 || r->hscene.n_inf > 0) return false;
+    if (r->hscene.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM) return false;  // power / BVH picks of a multi-light scene: the full-scene kernels
     return !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
 }
 // "wf" = the multi-kernel wavefront pipeline (vspg_wavefront.h): heterogeneous media whose every segment runs the

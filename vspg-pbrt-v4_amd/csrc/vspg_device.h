@@ -468,6 +468,26 @@ struct DField {
     // (vspg_guided_wg.h: region_lobes): {pivot, n_lobes}, then per lobe {mu, distance} {weight, b, kappa (clamped), vsp}
     const float4 *lobes;
 };
+// Light samplers beyond the uniform pick (vspg_lightsampler.h): the BVH light sampler's nodes as CompactLightBounds' accessors
+// return them, the light -> bit-trail map of its PMF, the power sampler's alias table.  Built on the host with the renderer.
+constexpr int kMaxLights = VSPG_MAX_QUADS + VSPG_MAX_INFINITE_LIGHTS;
+struct DLightNode {
+    float bmin[3], bmax[3], w[3];
+    float phi, cosTheta_o, cosTheta_e;
+    int32_t twoSided;
+    uint32_t child_or_light;  // interior: second child (the first is node + 1); leaf: index into the light list
+    int32_t is_leaf;
+};
+struct DLightSampler {
+    int32_t mode;             // VSPG_LIGHTSAMPLER_*; scenes with at most one light are given UNIFORM (the same pick, pmf 1)
+    int32_t n_nodes, n_inf, n_alias;
+    DLightNode nodes[2 * kMaxLights];
+    int32_t inf_light[VSPG_MAX_INFINITE_LIGHTS];
+    uint32_t bit_trail[kMaxLights];
+    float alias_p[kMaxLights], alias_q[kMaxLights];
+    int32_t alias_i[kMaxLights];
+    int32_t light_of_quad[VSPG_MAX_QUADS];  // rectangle -> index into the light list (-1: not a light)
+};
 // Triangle geometry.  DTri: the three vertices plus what Triangle::InteractionFromIntersection
 // (shapes.h:883-1010) derives from them alone -- n = Normalize(Cross(p0 - p2, p1 - p2)) and the normalised dpdu of the
 // default (u,v) parameterisation -- computed once on the host with the same float operations.  80 bytes = five 16-byte loads.
@@ -550,6 +570,8 @@ struct DScene {
     // ImageSpaceGuidingBuffer::GetContributionEstimate), refreshed with the VSP buffer
     const float *contrib;
     int32_t contrib_ready;
+    // LightSampler::Create(prm.lightsampler, lights): lsamp.mode is UNIFORM wherever the pick is trivial
+    DLightSampler lsamp;
 };
 // vsp_ready as handed to the path functions: bit 0 = the VSP buffer holds estimates; bit 1 = a debug path trace
 // (vspg_trace_paths), which does not feed the per-pixel buffers

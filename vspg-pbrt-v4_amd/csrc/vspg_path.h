@@ -5,6 +5,7 @@
 
 #include "vspg_device.h"
 #include "vspg_guiding.h"
+#include "vspg_lightsampler.h"
 #include "vspg_train.h"
 
 namespace vspg {
@@ -317,13 +318,16 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     V3 ctxp = intr.pi.mid();
     if (intr.is_surface && bsdf->has_lobes) ctxp = offset_ray_origin(intr.pi, intr.n, intr.wo);  // :1147-1149
     float u = sampler.get1d();
-    // UniformLightSampler::Sample (lightsamplers.h:33-38) over the emissive rectangles followed by the infinite lights
+    // lightSampler.Sample(ctx, u) (:1157) over the emissive rectangles followed by the infinite lights: UniformLightSampler
+    // (lightsamplers.h:33-38) inline; the power / BVH samplers of multi-light scenes (vspg_lightsampler.h) in the full-scene kernels
     constexpr bool kFull = !Medium::kSimpleScene;
     const int n_all = kFull ? S.n_lights + S.n_inf : S.n_lights;
     bool have_light = n_all > 0;
     int lightIndex = 0;
     float lightPmf = 0;
-    if (have_light) {
+    if (kFull && S.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM) {
+        have_light = light_sampler_sample(S, ctxp, intr.is_surface ? intr.n : mk(0, 0, 0), u, &lightIndex, &lightPmf);
+    } else if (have_light) {
         int li = (int)(u * (float)n_all);
         lightIndex = li < n_all - 1 ? li : n_all - 1;
         lightPmf = 1.f / (float)n_all;
@@ -675,7 +679,9 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
                 if constexpr (kRec) pc.rec.add_infinite_light_emission(st.ro + st.rd * kGuidingInfiniteLightDistance, Le, 1.0f);  // :361
             } else {
                 // lightSampler.PMF * light.PDF_Li(prevIntrContext, ray.d, true): both light types return 0 for the incomplete PDF
-                const float lightPDF = (1.f / (float)n_all) * 0.f;
+                const float pmf = S.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM ? light_sampler_pmf(S, st.prevCtx.template expand<FULL>(S).pi.mid(), st.prevCtx.template expand<FULL>(S).n, S.n_lights + k)
+                                                                            : 1.f / (float)n_all;
+                const float lightPDF = pmf * 0.f;
                 st.r_l = st.r_l * lightPDF;
                 const float w_b = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.f;
                 st.L = st.L + st.beta * w_b * Le;
@@ -693,7 +699,10 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
             st.L = st.L + st.beta * Le / avg(st.r_u);
             w_direct = 1.0f;
         } else {
-            float lightPDF = (1.f / (float)(FULL ? S.n_lights + S.n_inf : S.n_lights)) * light_pdf_li(q, st.prevCtx.template expand<FULL>(S), st.rd);
+            const LsCtx pctx = st.prevCtx.template expand<FULL>(S);
+            const float pmf = FULL && S.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM ? light_sampler_pmf(S, pctx.pi.mid(), pctx.n, S.lsamp.light_of_quad[si.quad])
+                                                                                 : 1.f / (float)(FULL ? S.n_lights + S.n_inf : S.n_lights);
+            float lightPDF = pmf * light_pdf_li(q, pctx, st.rd);
             st.r_l = st.r_l * lightPDF;
             float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
             st.L = st.L + st.beta * w_l * Le;

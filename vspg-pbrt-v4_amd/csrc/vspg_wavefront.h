@@ -337,7 +337,9 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *
     bool have_light = n_all > 0;
     int lightIndex = 0;
     float lightPmf = 0;
-    if (have_light) {  // UniformLightSampler::Sample (lightsamplers.h:33-38)
+    if (S.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM) {  // power / BVH sampler of a multi-light scene (vspg_lightsampler.h)
+        have_light = light_sampler_sample(S, ctxp, intr.is_surface ? intr.n : mk(0, 0, 0), u, &lightIndex, &lightPmf);
+    } else if (have_light) {  // UniformLightSampler::Sample (lightsamplers.h:33-38)
         int li = (int)(u * (float)n_all);
         lightIndex = li < n_all - 1 ? li : n_all - 1;
         lightPmf = 1.f / (float)n_all;
