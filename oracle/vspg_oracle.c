@@ -2219,7 +2219,7 @@ static float standard_throughput_rr(spec w) {
 /* a18: path-segment recording -- the guiding_* hooks of src/pbrt/cpu/guiding.h:682-832.   */
 /* A segment is openpgl::cpp::PathSegment reduced to what PropagateSamples reads.          */
 /* ------------------------------------------------------------------------------------ */
-#define TRAIN_MAX_SEG 32
+#define TRAIN_MAX_SEG 64 /* records a path keeps: min(2 * maxdepth, 64); beyond it NextSegment() == nullptr (vspg_train.h) */
 typedef struct {
     v3 p, wi;
     int has_wi, volume, is_delta;
@@ -3535,7 +3535,6 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
      * true); this build trains iff the field will be queried. */
     r->training = params->surfaceguiding || params->volumeguiding || params->vspsecondaryguiding;
     if (r->training) {
-        if ((params->maxdepth >= 1 ? params->maxdepth * 2 : 30) > TRAIN_MAX_SEG) { oracle_renderer_destroy(r); return VSPG_ESCOPE; }
         field_alloc(r, 0);
         field_alloc(r, 1);
     }

@@ -1661,7 +1661,7 @@ def _sorted_samples(a):
     return a[key]
 
 
-@pytest.mark.parametrize("medium", ["homogeneous", "grid", "homogeneous-deep"])
+@pytest.mark.parametrize("medium", ["homogeneous", "grid", "homogeneous-deep", "homogeneous-capped"])
 def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     """Wave 0 of a training run (field still empty -> unguided paths): the radiance samples the device
     records and propagates are the oracle's, bit for bit, as a multiset; so is the dropped-sample count.
@@ -1676,9 +1676,11 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
         scene = P.fog_box_scene(W, H)
         scene.medium.g = 0.3
     prm = P.default_params()
-    if medium == "homogeneous-deep":
-        prm.maxdepth = 9
-        prm.minrrdepth = 8   # no Russian roulette before depth 9: long paths
+    if medium in ("homogeneous-deep", "homogeneous-capped"):
+        # long paths; "capped": deeper than the 64 records a path keeps (2 * maxdepth = 80): recording stops there (NextSegment() ==
+        # nullptr), the path renders on, and the propagation kernel's staging area overflows into its flush path
+        prm.maxdepth = 9 if medium == "homogeneous-deep" else 40
+        prm.minrrdepth = prm.maxdepth - 1   # no Russian roulette before the last vertex
         for k in range(3):
             scene.medium.sigma_a[k] = 0.01
             scene.medium.sigma_s[k] = 1.5
@@ -1687,8 +1689,10 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     # grid media record on the wavefront pipeline, homogeneous ones on the workgroup kernel (round 3): either way the recorder's
     # state travels in the path record
     assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>")
-    g.render_wave(0, 2)
-    c.render_wave(0, 2)
+    # (the sample buffer holds one wave's worth -- pixels x (maxdepth + 1) -- between two updates: the capped case fills it with one)
+    n_waves = 1 if medium == "homogeneous-capped" else 2
+    g.render_wave(0, n_waves)
+    c.render_wave(0, n_waves)
     sg, sc = g.training_stats(), c.training_stats()
     assert sg["training"] == sc["training"] == 1
     assert sg["n_samples"] == sc["n_samples"] > 1000 and sg["n_zero"] == sc["n_zero"]
@@ -1706,7 +1710,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
         try:
             g2 = P.Renderer(scene, prm, W, H, seed=3)
             assert g2.kernel_name() == name
-            g2.render_wave(0, 2)
+            g2.render_wave(0, n_waves)
             assert _sorted_samples(g2.train_samples()).tobytes() == b.tobytes(), name
             g2.close()
         finally:

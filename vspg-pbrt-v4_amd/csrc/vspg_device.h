@@ -439,6 +439,7 @@ VDEV V3 offset_ray_origin(P3i pi, V3 n, V3 w) {
 // ---------------------------------------------------------------------------------------
 // device-resident scene (uploaded once; uniform accesses become scalar loads)
 // ---------------------------------------------------------------------------------------
+#define VSPG_GLOBAL_AS __attribute__((address_space(1)))
 struct DQuad {
     float p00[3], p10[3], p01[3], p11[3], e1[3], e2[3];
     float n[3], dpdu_n[3], perr[3];
@@ -1068,14 +1069,20 @@ struct GridMediumT {
         const int ox = ix + 1, oy = iy + 1, oz = iz + 1;
         Octet o{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if ((unsigned)ox <= (unsigned)nx && (unsigned)oy <= (unsigned)ny && (unsigned)oz <= (unsigned)nz) {
-            const int b = brick_index[((oz >> 3) * bny + (oy >> 3)) * bnx + (ox >> 3)];
-            VSPG_DBG_CHECK(b < 1 << 20, 1);
+            // brick_index == nullptr: every brick is stored, in grid order (round 3, "dense bricks") -- the slot is arithmetic and
+            // a density query is ONE memory round trip instead of two dependent ones (index, then octet).  Both arrays are read
+            // through global-address-space pointers (flat loads wait on two counters and are issued where they stand).
+            const int cell = ((oz >> 3) * bny + (oy >> 3)) * bnx + (ox >> 3);
+            int b = cell;
+            if (brick_index) b = *(const int VSPG_GLOBAL_AS *)(brick_index + cell);
+            VSPG_DBG_CHECK(b < 1 << 20 || !brick_index, 1);
 #ifdef VSPG_WF_DEBUG
-            if (b >= 1 << 20) return o;
+            if (brick_index && b >= 1 << 20) return o;
 #endif
             if (b >= 0) {
-                const float4 *q = octets + ((size_t)b * 512u + (size_t)((ox & 7) + 8 * ((oy & 7) + 8 * (oz & 7)))) * 2u;
-                const float4 lo = q[0], hi = q[1];
+                typedef float v4f_ __attribute__((ext_vector_type(4)));
+                const v4f_ VSPG_GLOBAL_AS *q = (const v4f_ VSPG_GLOBAL_AS *)(octets + ((size_t)b * 512u + (size_t)((ox & 7) + 8 * ((oy & 7) + 8 * (oz & 7)))) * 2u);
+                const v4f_ lo = q[0], hi = q[1];
                 o = Octet{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             }
         }

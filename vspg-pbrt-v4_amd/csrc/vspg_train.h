@@ -36,8 +36,10 @@ struct NullRecorder {  // every hook compiles to nothing
     VDEV void add_infinite_light_emission(V3, Spec, float) const {}
 };
 // pss->Reserve(maxDepth >= 1 ? maxDepth * 2 : 30) (guidedvolpathvspgintegrator.cpp:135-138): the records a path may keep;
-// NextSegment() returns nullptr beyond it (what OpenPGL's storage does then is restated, not pinned: the library is absent)
-constexpr int kTrainMaxSeg = 32;
+// NextSegment() returns nullptr beyond it (what OpenPGL's storage does then is restated, not pinned: the library is absent).
+// The record buffer of a wave holds min(2 * maxdepth, 64) records per path (88 B each, one column per pixel: 11.7 GB at 1080p
+// when all 64 are in use); a deeper path keeps rendering and stops recording there -- no configuration is refused for its depth.
+constexpr int kTrainMaxSeg = 64;
 __host__ __device__ inline int train_rec_capacity(int maxdepth) {
     const int c = maxdepth >= 1 ? maxdepth * 2 : 30;
     return c < kTrainMaxSeg ? c : kTrainMaxSeg;
