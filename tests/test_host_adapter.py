@@ -190,7 +190,7 @@ def test_scene_file_include(host_build, tmp_path):
     ('Material "diffuse" "rgb reflectance" [ .5 .5 .5 ] "float bogus" 1', "unused parameter"),
     ('Material "conductor"', 'Material "conductor"'),
     ('LightSource "spot"', 'LightSource "spot"'),
-    ('MakeNamedMedium "c" "string type" "nanovdb" "string filename" "cloud.nvdb"\nMediumInterface "" "c"\nCamera "perspective"', "nanovdb2pbrt"),
+    ('MakeNamedMedium "c" "string type" "nanovdb" "string filename" "cloud.nvdb"\nMediumInterface "" "c"\nCamera "perspective"', "cloud.nvdb: cannot open"),
 ])
 def test_scene_file_errors(host_build, tmp_path, bad, needle):
     exe = os.path.join(host_build, "vspg_pbrt")

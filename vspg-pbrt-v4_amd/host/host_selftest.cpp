@@ -41,7 +41,8 @@ int main() {
     CHECK(m.type == VSPG_MEDIUM_HOMOGENEOUS && m.sigma_a[1] == .4f && m.sigma_s[2] == 6.f && m.g == .5f && m.Le[0] == 0);
     VspgMedium md = CreateMedium("homogeneous", ParameterDictionary());
     CHECK(md.sigma_a[0] == 1.f && md.sigma_s[0] == 1.f && md.g == 0.f);  // ConstantSpectrum(1) defaults
-    CHECK(throws([] { CreateMedium("nanovdb", ParameterDictionary()); }));
+    CHECK(throws([] { CreateMedium("nanovdb", ParameterDictionary()); }));  // Must supply "filename" (media.cpp:685)
+    CHECK(throws([] { std::vector<float> d, t; CreateMedium("nanovdb", ParameterDictionary().String("filename", "/nonexistent/x.nvdb"), &d, &t); }));
     CHECK(throws([] { CreateMedium("homogeneous", ParameterDictionary().Float("bogus", 1)); }));
     // registry names (integrators.cpp:3739-3764)
     VspgScene scene;

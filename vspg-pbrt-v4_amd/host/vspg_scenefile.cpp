@@ -441,6 +441,10 @@ class Parser {
             if (it == media.end()) throw Error("medium \"" + cameraMedium + "\" (the camera's) is not defined");
             ParameterDictionary p = it->second.params;
             (void)p.GetOneString("type", "");
+            if (it->second.type == "nanovdb") {  // ResolveFilename (media.cpp:686): relative to the scene file's directory
+                const std::string fn = p.GetOneString("filename", "");
+                if (!fn.empty() && fn[0] != '/' && !baseDir.empty()) p.String("filename", baseDir + "/" + fn);
+            }
             s.medium = CreateMedium(it->second.type, p, &sd->density, &sd->leScale);
             if (!is_identity(it->second.ctm)) {
                 if (s.medium.type == VSPG_MEDIUM_HOMOGENEOUS) { /* a homogeneous medium has no frame */ }
