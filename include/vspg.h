@@ -318,9 +318,9 @@ int vspg_post_process_step(VspgRenderer *r, int n_waves, const float *isg_stats_
 
 /* Sharded guiding-field training ("all-reduce guiding samples / statistics per wave").  Field::Update (:239) fits
  * the field from sufficient statistics accumulated over the step's radiance samples.  With an exchange hook installed, the
- * update sums those statistics over the ranks at its accumulation points -- the sample count and weight, then per field the
- * position statistics before the split, after it, and the EM step's: eight in-place sum all-reduces of at most 1.2 MB per
- * training step -- and continues from the sums, so EVERY rank fits the SAME field from ALL ranks' samples: N ranks stepping
+ * update sums those statistics over the ranks at its accumulation points -- the sample count and weight, then (both fields
+ * in one buffer) the position statistics before the split, after it, and the EM step's: five in-place sum all-reduces of at
+ * most 2.3 MB per training step -- and continues from the sums, so EVERY rank fits the SAME field from ALL ranks' samples: N ranks stepping
  * this way train what one renderer trains that renders [w, w + N) per step (up to float summation order; the ranks' fields
  * are bit-identical to each other when the all-reduce hands every rank the same bits, as RCCL's and gloo's do).
  * `fn` sums n_floats floats at dev_ptr in place over the ranks, enqueued on `stream`; it returns 0 or an error code that

@@ -14,14 +14,14 @@ for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
     if "k_train" not in k: continue
     name = k[k.index("k_train_") + 8:].split("(")[0][:12]
-    if name.startswith("sum_weight"): cur = collections.OrderedDict(); ups.append(cur)
+    if name.startswith("decay"): cur = collections.OrderedDict(); ups.append(cur)   # first kernel of an update
     if cur is None: continue
     cur[name] = cur.get(name, 0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 ren = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
     if "k_render_wave" in k or "k_propagate" in k or "k_field_aux" in k:
-        name = ("render<train>" if "true, true" in k else "render<guided>") if "k_render_wave" in k else k.split("::")[-1].split("(")[0]
+        name = ("render<train>" if ", true>(" in k else "render<guided>") if "k_render_wave" in k else k.split("::")[-1].split("(")[0]
         ren[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 for k, v in ren.items(): print("%-16s n=%d mean %.3f ms" % (k, len(v), sum(v) / len(v)))
 for i, u in enumerate(ups):

@@ -5,9 +5,9 @@ import torch
 import __graft_entry__ as g
 P = g.load_package(); P.load()
 W, H = 1920, 1080
-prm = P.default_params(); prm.guide_num_training_waves = 12
+prm = P.default_params(); prm.guide_num_training_waves = int(os.environ.get('VSPG_TT_TRAIN', '24'))
 r = P.Renderer(P.fog_box_scene(W, H), prm, W, H)
-for w in range(20):
+for w in range(int(os.environ.get('VSPG_TT_TRAIN', '24')) + 6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     r.render_wave(w, w + 1); torch.cuda.synchronize(); t1 = time.perf_counter()
     r.post_process_wave(); torch.cuda.synchronize(); t2 = time.perf_counter()

@@ -1991,7 +1991,7 @@ def test_sharded_training_fits_one_field_from_all_samples(gpu_pkg, medium):
     for t in th:
         t.join(120)
     assert not errors, errors
-    assert calls[0] == calls[1] == 8        # count, weight sum, 3 accumulation points x 2 fields
+    assert calls[0] == calls[1] == 5        # count, weight sum, 3 accumulation points (both fields in each)
     st0, st1 = shards[0].training_stats(), shards[1].training_stats()
     assert st0["iteration"] == st1["iteration"] == 1 and st0["n_nodes"] == st1["n_nodes"] and st0["n_regions"] == st1["n_regions"]
     # one renderer stepping two waves: the oracle

@@ -213,9 +213,9 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
 }
 
 // PathSegmentStorage::PropagateSamples (:627) for every path of a training wave: one thread per work item
-constexpr int kStagePerLane = 6;  // samples a lane can stage (maxdepth 5: at most maxdepth + 1 samples per path)
+constexpr int kStagePerLane = 3;  // samples staged per lane on average (2.5 at the defaults); a wavefront that collects more flushes early (StageSink)
 __global__ __launch_bounds__(kBlock) void k_propagate(TrainArgs train, int max_seg) {
-    __shared__ VspgTrainSample s_stage[kBlock * kStagePerLane];  // 61 KB
+    __shared__ VspgTrainSample s_stage[kBlock * kStagePerLane];  // 31 KB: five workgroups per CU
     __shared__ unsigned int s_wcount[kBlock / 64];
     __shared__ unsigned long long s_base;
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
@@ -262,88 +262,102 @@ __global__ __launch_bounds__(kBlock) void k_field_aux(const DScene *__restrict__
 }
 
 // ---- a18: Field::Update stand-in (definitions in vspg_train.h / oracle "Field::Update") --------------
-// Every kernel sees the batch through (samples, n); `f` selects the surface (0) or volume (1) field.
-__device__ __forceinline__ bool train_sample_region(const DScene &S, int f, const VspgTrainSample &sm, int *region) {
-    if (((sm.flags & VSPG_SAMPLE_VOLUME) != 0) != (f == 1)) return false;
-    *region = field_lookup(S.field[f], ld3(sm.p));
-    return *region >= 0;
-}
-__global__ __launch_bounds__(kBlock) void k_train_sum_weight(const VspgTrainSample *__restrict__ samples, unsigned long long n,
-                                                             float *__restrict__ sumw) {
-    float x = 0;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kBlock)
-        x += samples[i].weight;
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-    if ((threadIdx.x & 63) == 0 && x != 0.f) atomicAdd(sumw, x);
-}
-__global__ __launch_bounds__(kBlock) void k_train_decay(const DScene *__restrict__ Sp, int f, RegionStats *__restrict__ stats) {
-    const int n = Sp->field[f].n_regions * kStatFloats;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const int r = i / kStatFloats, k = i - r * kStatFloats;
-        (&stats[r].n)[k] *= kTrainDecay;
+// The surface (0) and the volume (1) field are updated TOGETHER: a sample belongs to exactly one of them (its VOLUME flag),
+// the two updates are independent, and every pass over the batch is bound by reading the samples -- so each pass serves both
+// fields under the sort key  field * kTrainCapRegions + region  (vspg_train.h: kTrainKeys).
+struct TrainFields {
+    RegionStats *stats[2];
+    VspgFieldRegion *regs[2];
+    VspgKdNode *nodes[2];
+};
+__global__ __launch_bounds__(kBlock) void k_train_decay(const DScene *__restrict__ Sp, TrainFields tf) {
+    for (int f = 0; f < 2; ++f) {
+        const int n = Sp->field[f].n_regions * kStatFloats;
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+            const int r = i / kStatFloats, k = i - r * kStatFloats;
+            (&tf.stats[f][r].n)[k] *= kTrainDecay;
+        }
     }
 }
-// ---- counting sort of the batch by region ----------------------------------------------------------------
+// ---- counting sort of the batch by key -----------------------------------------------------------------
 // Histograms are built per workgroup in LDS over a contiguous chunk of the batch and flushed with one global
 // atomic per non-empty bin: device-scope atomics on a handful of hot addresses (few regions in the first
 // iterations) cost ~300 ns each when issued per wavefront.
+constexpr int kSortBlock = 1024;  // one workgroup per CU: half the flushes of two 512-thread ones at the same occupancy
 __device__ __forceinline__ void train_chunk(unsigned long long n, unsigned long long *lo, unsigned long long *hi) {
     unsigned long long per = (n + gridDim.x - 1) / gridDim.x;
-    per = (per + kBlock - 1) / kBlock * kBlock;
+    per = (per + kSortBlock - 1) / kSortBlock * kSortBlock;
     *lo = (unsigned long long)blockIdx.x * per < n ? (unsigned long long)blockIdx.x * per : n;
     *hi = *lo + per < n ? *lo + per : n;
 }
-// s_bins[region] += 1 for every lane with region >= 0; returns the lane's rank within the bin before the add.
+// s_bins[key] += 1 for every lane with key >= 0; returns the bin's value before the lane's own add.
 // A few ballot rounds serve the popular bins with one LDS atomic each, the tail goes lane by lane.
-__device__ __forceinline__ unsigned int lds_bin_add(unsigned int *s_bins, int region) {
+__device__ __forceinline__ unsigned int lds_bin_add(unsigned int *s_bins, int key) {
     const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(region >= 0);
+    unsigned long long todo = __ballot(key >= 0);
     unsigned int rank = 0;
     for (int round = 0; todo != 0ull && round < 4; ++round) {
         const int leader = __ffsll((long long)todo) - 1;
-        const int lreg = __shfl(region, leader);
-        const unsigned long long same = __ballot(region == lreg) & todo;
+        const int lkey = __shfl(key, leader);
+        const unsigned long long same = __ballot(key == lkey) & todo;
         unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(&s_bins[lreg], (unsigned int)__popcll(same));
+        if (lane == leader) base = atomicAdd(&s_bins[lkey], (unsigned int)__popcll(same));
         base = __shfl(base, leader);
         if ((same >> lane) & 1ull) rank = base + (unsigned int)__popcll(same & ((1ull << lane) - 1ull));
         todo &= ~same;
     }
-    if ((todo >> lane) & 1ull) rank = atomicAdd(&s_bins[region], 1u);
+    if ((todo >> lane) & 1ull) rank = atomicAdd(&s_bins[key], 1u);
     return rank;
 }
-// region of every sample of field f (-1: other field / outside) + histogram
-__global__ __launch_bounds__(kBlock) void k_train_lookup(const DScene *__restrict__ Sp, int f, const VspgTrainSample *__restrict__ samples,
-                                                         unsigned long long n, int *__restrict__ reg_of, unsigned int *__restrict__ hist) {
-    __shared__ unsigned int s_hist[kTrainCapRegions];
+// key of every sample (-1: outside its field's tree) + histogram; the first of an update's two sorts also sums the sample
+// weights (sumw != nullptr).  `redo`: the second sort runs only if the split pass changed a tree (*redo != 0); otherwise
+// key_of / order / n_sorted of the first sort still stand.
+constexpr int kTrainLdsNodes = 512;  // upper kd-tree levels per field staged in LDS for the descent (field_lookup)
+__global__ __launch_bounds__(kSortBlock) void k_train_lookup(const DScene *__restrict__ Sp, const VspgTrainSample *__restrict__ samples,
+                                                         unsigned long long n, int *__restrict__ key_of, unsigned int *__restrict__ hist,
+                                                         float *__restrict__ sumw, const int *__restrict__ redo) {
+    __shared__ unsigned int s_hist[kTrainKeys];
+    __shared__ VspgKdNode s_nodes[2 * kTrainLdsNodes];
+    if (redo && *redo == 0) return;
     const DScene &S = *Sp;
-    const int nreg = S.field[f].n_regions;
-    for (int b = threadIdx.x; b < nreg; b += kBlock) s_hist[b] = 0;
+    int nl[2];
+    for (int f = 0; f < 2; ++f) {
+        nl[f] = S.field[f].n_nodes < kTrainLdsNodes ? S.field[f].n_nodes : kTrainLdsNodes;
+        for (int i = threadIdx.x; i < nl[f]; i += kSortBlock) s_nodes[f * kTrainLdsNodes + i] = S.field[f].nodes[i];
+    }
+    for (int b = threadIdx.x; b < kTrainKeys; b += kSortBlock) s_hist[b] = 0;
     __syncthreads();
     unsigned long long lo, hi;
     train_chunk(n, &lo, &hi);
-    for (unsigned long long i0 = lo; i0 < hi; i0 += kBlock) {
+    float wsum = 0;
+    for (unsigned long long i0 = lo; i0 < hi; i0 += kSortBlock) {
         const unsigned long long i = i0 + threadIdx.x;
-        int region = -1;
+        int key = -1;
         if (i < hi) {
             const VspgTrainSample sm = samples[i];
-            int rg;
-            if (train_sample_region(S, f, sm, &rg)) region = rg;
-            reg_of[i] = region;
+            const int f = (sm.flags & VSPG_SAMPLE_VOLUME) ? 1 : 0;
+            const int region = field_lookup(S.field[f], ld3(sm.p), s_nodes + f * kTrainLdsNodes, nl[f]);
+            if (region >= 0) key = f * kTrainCapRegions + region;
+            key_of[i] = key;
+            wsum += sm.weight;
         }
-        lds_bin_add(s_hist, region);
+        lds_bin_add(s_hist, key);
+    }
+    if (sumw) {
+        for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
+        if ((threadIdx.x & 63) == 0 && wsum != 0.f) atomicAdd(sumw, wsum);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nreg; b += kBlock)
+    for (int b = threadIdx.x; b < kTrainKeys; b += kSortBlock)
         if (s_hist[b]) atomicAdd(&hist[b], s_hist[b]);
 }
 // exclusive scan of the histogram -> start offsets (one block); cursor = copy for the scatter; total -> *n_sorted
-__global__ __launch_bounds__(kBlock) void k_train_scan(const DScene *__restrict__ Sp, int f, const unsigned int *__restrict__ hist,
-                                                       unsigned int *__restrict__ cursor, unsigned int *__restrict__ n_sorted) {
+__global__ __launch_bounds__(kBlock) void k_train_scan(const unsigned int *__restrict__ hist, unsigned int *__restrict__ cursor,
+                                                       unsigned int *__restrict__ n_sorted, const int *__restrict__ redo) {
     __shared__ unsigned int s_part[kBlock];
-    const int nreg = Sp->field[f].n_regions;
-    const int per = (nreg + kBlock - 1) / kBlock;
-    const int lo = threadIdx.x * per < nreg ? threadIdx.x * per : nreg, hi = lo + per < nreg ? lo + per : nreg;
+    if (redo && *redo == 0) return;
+    constexpr int per = (kTrainKeys + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * per < kTrainKeys ? threadIdx.x * per : kTrainKeys, hi = lo + per < kTrainKeys ? lo + per : kTrainKeys;
     unsigned int sum = 0;
     for (int i = lo; i < hi; ++i) sum += hist[i];
     s_part[threadIdx.x] = sum;
@@ -358,31 +372,29 @@ __global__ __launch_bounds__(kBlock) void k_train_scan(const DScene *__restrict_
     for (int i = lo; i < hi; ++i) { cursor[i] = run; run += hist[i]; }
 }
 // a workgroup recounts its chunk, reserves one range per non-empty bin, then places its samples
-__global__ __launch_bounds__(kBlock) void k_train_scatter(const DScene *__restrict__ Sp, int f, const int *__restrict__ reg_of,
-                                                          unsigned long long n, unsigned int *__restrict__ cursor,
-                                                          unsigned int *__restrict__ order) {
-    __shared__ unsigned int s_hist[kTrainCapRegions], s_base[kTrainCapRegions];
-    const int nreg = Sp->field[f].n_regions;
-    for (int b = threadIdx.x; b < nreg; b += kBlock) s_hist[b] = 0;
+__global__ __launch_bounds__(kSortBlock) void k_train_scatter(const int *__restrict__ key_of, unsigned long long n, unsigned int *__restrict__ cursor,
+                                                          unsigned int *__restrict__ order, const int *__restrict__ redo) {
+    __shared__ unsigned int s_cur[kTrainKeys];
+    if (redo && *redo == 0) return;
+    for (int b = threadIdx.x; b < kTrainKeys; b += kSortBlock) s_cur[b] = 0;
     __syncthreads();
     unsigned long long lo, hi;
     train_chunk(n, &lo, &hi);
-    for (unsigned long long i0 = lo; i0 < hi; i0 += kBlock) {
+    for (unsigned long long i0 = lo; i0 < hi; i0 += kSortBlock) {
         const unsigned long long i = i0 + threadIdx.x;
-        lds_bin_add(s_hist, i < hi ? reg_of[i] : -1);
+        lds_bin_add(s_cur, i < hi ? key_of[i] : -1);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nreg; b += kBlock) {
-        const unsigned int c = s_hist[b];
-        s_base[b] = c ? atomicAdd(&cursor[b], c) : 0u;
-        s_hist[b] = 0;
+    for (int b = threadIdx.x; b < kTrainKeys; b += kSortBlock) {
+        const unsigned int c = s_cur[b];
+        s_cur[b] = c ? atomicAdd(&cursor[b], c) : 0u;  // from a count to the chunk's first slot of the bin
     }
     __syncthreads();
-    for (unsigned long long i0 = lo; i0 < hi; i0 += kBlock) {
+    for (unsigned long long i0 = lo; i0 < hi; i0 += kSortBlock) {
         const unsigned long long i = i0 + threadIdx.x;
-        const int region = i < hi ? reg_of[i] : -1;
-        const unsigned int rank = lds_bin_add(s_hist, region);
-        if (region >= 0) order[s_base[region] + rank] = (unsigned int)i;
+        const int key = i < hi ? key_of[i] : -1;
+        const unsigned int slot = lds_bin_add(s_cur, key);
+        if (key >= 0) order[slot] = (unsigned int)i;
     }
 }
 // every wavefront takes a contiguous piece of the sorted order
@@ -393,11 +405,13 @@ __device__ __forceinline__ void train_piece(unsigned int n_sorted, unsigned int 
     *lo = w * per < n_sorted ? w * per : n_sorted;
     *hi = *lo + per < n_sorted ? *lo + per : n_sorted;
 }
-// position statistics {n, sum p, [sum p^2]} of the batch per region -> acc
+// position statistics {n, sum p, [sum p^2]} of the batch per key -> acc
+// (`need`: the pass after the split serves k_train_init_regions only -- it runs when a region without lobes exists, flags[1] of k_train_split)
 template <bool WITH_P2>
-__global__ __launch_bounds__(kBlock) void k_train_pos(const VspgTrainSample *__restrict__ samples, const int *__restrict__ reg_of,
+__global__ __launch_bounds__(kBlock) void k_train_pos(const VspgTrainSample *__restrict__ samples, const int *__restrict__ key_of,
                                                       const unsigned int *__restrict__ order, const unsigned int *__restrict__ n_sorted,
-                                                      float *__restrict__ acc) {
+                                                      float *__restrict__ acc, const int *__restrict__ need) {
+    if (need && *need == 0) return;
     unsigned int lo, hi;
     train_piece(*n_sorted, &lo, &hi);
     constexpr int NV = WITH_P2 ? 7 : 4;
@@ -406,36 +420,44 @@ __global__ __launch_bounds__(kBlock) void k_train_pos(const VspgTrainSample *__r
     for (unsigned int j0 = lo; j0 < hi; j0 += 64u) {
         const unsigned int j = j0 + (threadIdx.x & 63);
         const bool valid = j < hi;
-        float v[NV];
-        int region = -1;
-        for (int k = 0; k < NV; ++k) v[k] = 0.f;
+        float v[RunAccumulator<NV>::P];
+        int key = -1;
+        for (int k = 0; k < RunAccumulator<NV>::P; ++k) v[k] = 0.f;
         if (valid) {
             const unsigned int i = order[j];
-            region = reg_of[i];
+            key = key_of[i];
             const VspgTrainSample sm = samples[i];
             v[0] = 1.f; v[1] = sm.p[0]; v[2] = sm.p[1]; v[3] = sm.p[2];
             if constexpr (WITH_P2) { v[4] = sm.p[0] * sm.p[0]; v[5] = sm.p[1] * sm.p[1]; v[6] = sm.p[2] * sm.p[2]; }
         }
-        R.add(valid, region, v);
+        R.add(valid, key, v);
     }
     R.flush();
 }
-// spatial refinement, ONE thread: sequential like the CPU definition so node / region numbering is the same
+// spatial refinement: one workgroup per field, sequential in meaning like the CPU definition so node / region numbering is the same
 constexpr int kSplitBlock = 1024;
-__global__ __launch_bounds__(kSplitBlock) void k_train_split(DScene *Sp, int f, RegionStats *stats, const float *acc, VspgKdNode *nodes,
-                                                             VspgFieldRegion *regs) {
+// flags[0] += regions created (the second sort runs only then), flags[1] |= a region without lobes exists (k_train_init_regions has work)
+__global__ __launch_bounds__(kSplitBlock) void k_train_split(DScene *Sp, TrainFields tf, const float *acc_all, int *flags) {
     // The definition is sequential over the nodes (oracle/vspg_oracle.c:field_update_one): a leaf that wants to
     // split takes the next two node slots and the next region slot, until a capacity runs out.  Slots only grow,
     // so "rank among the wanting leaves" (a prefix sum) reproduces the sequential numbering exactly.
-    __shared__ unsigned int s_cnt[kSplitBlock];
+    __shared__ unsigned int s_wave[kSplitBlock / 64];
     __shared__ int s_n_nodes, s_n_regions;
+    const int f = blockIdx.x;
     DField &F = Sp->field[f];
+    RegionStats *stats = tf.stats[f];
+    VspgFieldRegion *regs = tf.regs[f];
+    VspgKdNode *nodes = tf.nodes[f];
+    const float *acc = acc_all + (size_t)f * kTrainCapRegions * kStatFloats;
     const int n_reg0 = F.n_regions, n_nodes0 = F.n_nodes;
+    bool bare = false;
     for (int i = threadIdx.x; i < n_reg0; i += kSplitBlock) {
         const float *a = acc + (size_t)i * kStatFloats;
         stats[i].n += a[0];
         for (int k = 0; k < 3; ++k) { stats[i].sum_p[k] += a[1 + k]; stats[i].sum_p2[k] += a[4 + k]; }
+        bare = bare || regs[i].n_lobes == 0;  // (the regions a split creates are copies of these)
     }
+    if (__ballot(bare) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
     __syncthreads();
     constexpr int kPer = (kTrainCapNodes + kSplitBlock - 1) / kSplitBlock;
     const int first = threadIdx.x * kPer;
@@ -459,21 +481,33 @@ __global__ __launch_bounds__(kSplitBlock) void k_train_split(DScene *Sp, int f, 
         axis_of[j] = axis;
         split_of[j] = mean[axis];
     }
-    s_cnt[threadIdx.x] = (unsigned int)__popc(want);
+    // exclusive prefix sum of popc(want) over the threads: within the wavefront by shuffles, across wavefronts through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int mine = (unsigned int)__popc(want);
+    unsigned int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
+    unsigned int before = 0, total = 0;
+    for (int w = 0; w < kSplitBlock / 64; ++w) {
+        const unsigned int c = s_wave[w];
+        if (w < wave) before += c;
+        total += c;
+    }
     if (threadIdx.x == 0) {
-        unsigned int run = 0;
-        for (int t = 0; t < kSplitBlock; ++t) { const unsigned int v = s_cnt[t]; s_cnt[t] = run; run += v; }
-        // how many of the `run` candidates fit: both capacities
-        int fit = (int)run;
+        // how many of the `total` candidates fit: both capacities
+        int fit = (int)total;
         if (fit > (kTrainCapNodes - n_nodes0) / 2) fit = (kTrainCapNodes - n_nodes0) / 2;
         if (fit > kTrainCapRegions - n_reg0) fit = kTrainCapRegions - n_reg0;
         if (fit < 0) fit = 0;
         s_n_nodes = n_nodes0 + 2 * fit;
         s_n_regions = n_reg0 + fit;
+        if (fit) atomicAdd(&flags[0], fit);
     }
-    __syncthreads();
-    int rank = (int)s_cnt[threadIdx.x];
+    int rank = (int)(before + incl - mine);
     for (int j = 0; j < kPer; ++j) {
         if (!((want >> j) & 1u)) continue;
         const int left = n_nodes0 + 2 * rank, newreg = n_reg0 + rank;
@@ -495,20 +529,22 @@ __global__ __launch_bounds__(kSplitBlock) void k_train_split(DScene *Sp, int f, 
     __syncthreads();
     if (threadIdx.x == 0) { F.n_nodes = s_n_nodes; F.n_regions = s_n_regions; }
 }
-__global__ __launch_bounds__(kBlock) void k_train_init_regions(const DScene *__restrict__ Sp, int f, const float *__restrict__ acc,
-                                                               VspgFieldRegion *__restrict__ regs) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kBlock) void k_train_init_regions(const DScene *__restrict__ Sp, TrainFields tf, const float *__restrict__ acc) {
+    const int key = blockIdx.x * kBlock + threadIdx.x;
+    if (key >= kTrainKeys) return;
+    const int f = key >= kTrainCapRegions ? 1 : 0, i = key - f * kTrainCapRegions;
     if (i >= Sp->field[f].n_regions) return;
-    const float *a = acc + (size_t)i * kStatFloats;
-    if (regs[i].n_lobes == 0 && a[0] > 0) {
-        for (int k = 0; k < 3; ++k) regs[i].pivot[k] = a[1 + k] / a[0];
-        region_init_lobes(regs[i]);
+    const float *a = acc + (size_t)key * kStatFloats;
+    VspgFieldRegion &R = tf.regs[f][i];
+    if (R.n_lobes == 0 && a[0] > 0) {
+        for (int k = 0; k < 3; ++k) R.pivot[k] = a[1 + k] / a[0];
+        region_init_lobes(R);
     }
 }
-__global__ __launch_bounds__(kBlock) void k_train_estep(const DScene *__restrict__ Sp, int f, const VspgTrainSample *__restrict__ samples,
-                                                        unsigned long long n, const int *__restrict__ reg_of,
-                                                        const unsigned int *__restrict__ order, const unsigned int *__restrict__ n_sorted,
-                                                        const float *__restrict__ sumw, float *__restrict__ acc) {
+__global__ __launch_bounds__(kBlock) void k_train_estep(const DScene *__restrict__ Sp, const VspgTrainSample *__restrict__ samples,
+                                                        const int *__restrict__ key_of, const unsigned int *__restrict__ order,
+                                                        const unsigned int *__restrict__ n_sorted, const float *__restrict__ sumw,
+                                                        float *__restrict__ acc) {
     const DScene &S = *Sp;
     vspg_libm::stage_logf_tab_lds();
     __syncthreads();
@@ -520,14 +556,15 @@ __global__ __launch_bounds__(kBlock) void k_train_estep(const DScene *__restrict
     for (unsigned int j0 = lo; j0 < hi; j0 += 64u) {
         const unsigned int j = j0 + (threadIdx.x & 63);
         bool valid = j < hi;
-        int region = -1;
+        int key = -1;
         float vals[8 * GK];  // S, R0, R1, R2, D, V, Qv, Qs -- the order of RegionStats
         for (int k = 0; k < 8 * GK; ++k) vals[k] = 0.f;
         if (valid) {
             const unsigned int i = order[j];
-            region = reg_of[i];
+            key = key_of[i];
             const VspgTrainSample sm = samples[i];
-            const VspgFieldRegion &Rg = S.field[f].regions[region];
+            const int f = key >= kTrainCapRegions ? 1 : 0;
+            const VspgFieldRegion &Rg = S.field[f].regions[key - f * kTrainCapRegions];
             const int nl = Rg.n_lobes < GK ? Rg.n_lobes : GK;
             valid = nl > 0;
             if (valid) {
@@ -554,19 +591,20 @@ __global__ __launch_bounds__(kBlock) void k_train_estep(const DScene *__restrict
                 }
             }
         }
-        R.add(valid, region, vals);
+        R.add(valid, key, vals);
     }
     R.flush();
 }
-__global__ __launch_bounds__(kBlock) void k_train_mstep(const DScene *__restrict__ Sp, int f, const float *__restrict__ acc,
-                                                        RegionStats *__restrict__ stats, VspgFieldRegion *__restrict__ regs) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kBlock) void k_train_mstep(const DScene *__restrict__ Sp, TrainFields tf, const float *__restrict__ acc) {
+    const int key = blockIdx.x * kBlock + threadIdx.x;
+    if (key >= kTrainKeys) return;
+    const int f = key >= kTrainCapRegions ? 1 : 0, i = key - f * kTrainCapRegions;
     if (i >= Sp->field[f].n_regions) return;
-    VspgFieldRegion &R = regs[i];
+    VspgFieldRegion &R = tf.regs[f][i];
     if (R.n_lobes <= 0) return;
     const int nl = R.n_lobes < GK ? R.n_lobes : GK;
-    RegionStats &s1 = stats[i];
-    const float *a = acc + (size_t)i * kStatFloats + 7;
+    RegionStats &s1 = tf.stats[f][i];
+    const float *a = acc + (size_t)key * kStatFloats + 7;
     float Stot = 0;
     for (int k = 0; k < nl; ++k) {
         s1.S[k] += a[0 * GK + k];
@@ -1548,6 +1586,7 @@ struct VspgRenderer {
     int *train_reg = nullptr;                 // region of every sample of the batch (field being updated)
     unsigned int *train_order = nullptr;      // sample indices sorted by region
     unsigned int *train_hist = nullptr, *train_cursor = nullptr, *train_nsorted = nullptr;
+    int *train_nsplit = nullptr;              // [0] regions the split pass of the running update created (both fields), [1] a region without lobes exists
     float *density = nullptr;   // GridMedium density samples (raw; released once the octet bricks are built)
     int32_t *brick_index = nullptr;
     float4 *octets = nullptr;
@@ -2690,12 +2729,13 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         CK(hipMalloc(&r->samples, r->sample_capacity * sizeof(VspgTrainSample)));
         CK(hipMalloc(&r->train_counters, 4 * sizeof(unsigned long long)));
         CK(hipMemset(r->train_counters, 0, 4 * sizeof(unsigned long long)));
-        CK(hipMalloc(&r->train_acc, (size_t)kTrainCapRegions * kStatFloats * sizeof(float)));
+        CK(hipMalloc(&r->train_acc, (size_t)kTrainKeys * kStatFloats * sizeof(float)));
         CK(hipMalloc(&r->train_sumw, 2 * sizeof(float)));
         CK(hipMalloc(&r->train_reg, r->sample_capacity * sizeof(int)));
         CK(hipMalloc(&r->train_order, r->sample_capacity * sizeof(unsigned int)));
-        CK(hipMalloc(&r->train_hist, (size_t)kTrainCapRegions * sizeof(unsigned int)));
-        CK(hipMalloc(&r->train_cursor, (size_t)kTrainCapRegions * sizeof(unsigned int)));
+        CK(hipMalloc(&r->train_hist, (size_t)kTrainKeys * sizeof(unsigned int)));
+        CK(hipMalloc(&r->train_cursor, (size_t)kTrainKeys * sizeof(unsigned int)));
+        CK(hipMalloc(&r->train_nsplit, 2 * sizeof(int)));
         CK(hipMalloc(&r->train_nsorted, sizeof(unsigned int)));
     }
 #undef CK
@@ -2734,6 +2774,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_hist) (void)hipFree(r->train_hist);
     if (r->train_cursor) (void)hipFree(r->train_cursor);
     if (r->train_nsorted) (void)hipFree(r->train_nsorted);
+    if (r->train_nsplit) (void)hipFree(r->train_nsplit);
     if (r->tris) (void)hipFree(r->tris);
     if (r->bvh) (void)hipFree(r->bvh);
     if (r->wave_samples) (void)hipFree(r->wave_samples);
@@ -3027,50 +3068,51 @@ static int train_update(VspgRenderer *r, hipStream_t s) {
         }
     }
     if (n_all > (double)kTrainMinUpdateSamples) {
-        const size_t acc_bytes = (size_t)kTrainCapRegions * kStatFloats * sizeof(float);
-        const size_t acc_floats = (size_t)kTrainCapRegions * kStatFloats;
+        const size_t acc_floats = (size_t)kTrainKeys * kStatFloats, acc_bytes = acc_floats * sizeof(float);
         unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
         if (grid < 1u) grid = 1u;  // (a rank whose own samples ran dry still takes part in the sums)
         if (grid > (unsigned)r->num_cus * 16u) grid = (unsigned)r->num_cus * 16u;
-        const unsigned rgrid = (kTrainCapRegions + kBlock - 1) / kBlock;
+        const unsigned rgrid = (kTrainKeys + kBlock - 1) / kBlock;
         // counting sort: few, long chunks -- every workgroup flushes one atomic per bin its chunk touched
-        const unsigned sgrid = grid < (unsigned)r->num_cus * 2u ? grid : (unsigned)r->num_cus * 2u;
+        unsigned sgrid = (unsigned)((n + kSortBlock - 1) / kSortBlock);
+        if (sgrid < 1u) sgrid = 1u;
+        if (sgrid > (unsigned)r->num_cus) sgrid = (unsigned)r->num_cus;
         // accumulation passes: every wavefront flushes its running sums at least once, so no more wavefronts than fill the chip
         const unsigned agrid = grid < (unsigned)r->num_cus * 4u ? grid : (unsigned)r->num_cus * 4u;
-        HIPCHK(hipMemsetAsync(r->train_sumw, 0, sizeof(float), s));
-        hipLaunchKernelGGL(k_train_sum_weight, dim3(sgrid), dim3(kBlock), 0, s, r->samples, n, r->train_sumw);
-        if (int rc = xchg(r->train_sumw, 1)) return rc;
-        const size_t hist_bytes = (size_t)kTrainCapRegions * sizeof(unsigned int);
-        auto sort_by_region = [&](int f) -> int {  // reg_of, order, n_sorted for field f as the tree stands now
+        const TrainFields tf{{r->rstats[0], r->rstats[1]}, {r->fregions[0], r->fregions[1]}, {r->fnodes[0], r->fnodes[1]}};
+        const size_t hist_bytes = (size_t)kTrainKeys * sizeof(unsigned int);
+        // key_of, order, n_sorted for both fields as the trees stand now; the second sort (redo) only if a tree changed
+        auto sort_by_key = [&](float *sumw, const int *redo) -> int {
             HIPCHK(hipMemsetAsync(r->train_hist, 0, hist_bytes, s));
-            hipLaunchKernelGGL(k_train_lookup, dim3(sgrid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_reg, r->train_hist);
-            hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(kBlock), 0, s, r->dscene, f, r->train_hist, r->train_cursor, r->train_nsorted);
-            hipLaunchKernelGGL(k_train_scatter, dim3(sgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_reg, n, r->train_cursor, r->train_order);
+            hipLaunchKernelGGL(k_train_lookup, dim3(sgrid), dim3(kSortBlock), 0, s, r->dscene, r->samples, n, r->train_reg, r->train_hist, sumw, redo);
+            hipLaunchKernelGGL(k_train_scan, dim3(1), dim3(kBlock), 0, s, r->train_hist, r->train_cursor, r->train_nsorted, redo);
+            hipLaunchKernelGGL(k_train_scatter, dim3(sgrid), dim3(kSortBlock), 0, s, r->train_reg, n, r->train_cursor, r->train_order, redo);
             return 0;
         };
-        for (int f = 0; f < 2; ++f) {
-            hipLaunchKernelGGL(k_train_decay, dim3(rgrid * 8), dim3(kBlock), 0, s, r->dscene, f, r->rstats[f]);
-            if (int rc = sort_by_region(f)) return rc;
-            HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
-            hipLaunchKernelGGL((k_train_pos<true>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order,
-                               r->train_nsorted, r->train_acc);
-            if (int rc = xchg(r->train_acc, acc_floats)) return rc;
-            hipLaunchKernelGGL(k_train_split, dim3(1), dim3(kSplitBlock), 0, s, r->dscene, f, r->rstats[f], r->train_acc, r->fnodes[f],
-                               r->fregions[f]);
-            if (int rc = sort_by_region(f)) return rc;  // the split changed the leaves
-            HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
-            hipLaunchKernelGGL((k_train_pos<false>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order,
-                               r->train_nsorted, r->train_acc);
-            if (int rc = xchg(r->train_acc, acc_floats)) return rc;
-            hipLaunchKernelGGL(k_train_init_regions, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->fregions[f]);
-            HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
-            hipLaunchKernelGGL(k_train_estep, dim3(agrid), dim3(kBlock), 0, s, r->dscene, f, r->samples, n, r->train_reg, r->train_order,
-                               r->train_nsorted, r->train_sumw, r->train_acc);
-            if (int rc = xchg(r->train_acc, acc_floats)) return rc;
-            hipLaunchKernelGGL(k_train_mstep, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, f, r->train_acc, r->rstats[f],
-                               r->fregions[f]);
-            hipLaunchKernelGGL(k_field_aux, dim3(rgrid * 2), dim3(kBlock), 0, s, r->dscene, f, r->fregions[f], r->faux[f], r->flobes[f]);
-        }
+        HIPCHK(hipMemsetAsync(r->train_sumw, 0, sizeof(float), s));
+        HIPCHK(hipMemsetAsync(r->train_nsplit, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(k_train_decay, dim3(rgrid * 4), dim3(kBlock), 0, s, r->dscene, tf);
+        if (int rc = sort_by_key(r->train_sumw, nullptr)) return rc;
+        if (int rc = xchg(r->train_sumw, 1)) return rc;
+        HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
+        hipLaunchKernelGGL((k_train_pos<true>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order, r->train_nsorted,
+                           r->train_acc, (const int *)nullptr);
+        if (int rc = xchg(r->train_acc, acc_floats)) return rc;
+        hipLaunchKernelGGL(k_train_split, dim3(2), dim3(kSplitBlock), 0, s, r->dscene, tf, r->train_acc, r->train_nsplit);
+        if (int rc = sort_by_key(nullptr, r->train_nsplit)) return rc;  // the split changed the leaves
+        HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
+        hipLaunchKernelGGL((k_train_pos<false>), dim3(agrid), dim3(kBlock), 0, s, r->samples, r->train_reg, r->train_order, r->train_nsorted,
+                           r->train_acc, (const int *)(r->train_nsplit + 1));
+        if (int rc = xchg(r->train_acc, acc_floats)) return rc;
+        hipLaunchKernelGGL(k_train_init_regions, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, tf, r->train_acc);
+        HIPCHK(hipMemsetAsync(r->train_acc, 0, acc_bytes, s));
+        hipLaunchKernelGGL(k_train_estep, dim3(agrid), dim3(kBlock), 0, s, r->dscene, r->samples, r->train_reg, r->train_order, r->train_nsorted,
+                           r->train_sumw, r->train_acc);
+        if (int rc = xchg(r->train_acc, acc_floats)) return rc;
+        hipLaunchKernelGGL(k_train_mstep, dim3(rgrid), dim3(kBlock), 0, s, r->dscene, tf, r->train_acc);
+        for (int f = 0; f < 2; ++f)
+            hipLaunchKernelGGL(k_field_aux, dim3((kTrainCapRegions + kBlock - 1) / kBlock * 2), dim3(kBlock), 0, s, r->dscene, f, r->fregions[f],
+                               r->faux[f], r->flobes[f]);
         HIPCHK(hipGetLastError());
         r->field_iteration++;
         if (r->field_iteration >= r->prm.guide_num_training_waves) r->training = false;

@@ -171,6 +171,10 @@ struct StageSink {
 
 // PathSegmentStorage::PropagateSamples stand-in (see oracle/vspg_oracle.c:propagate_samples for the
 // definition): walk the path's records from the last vertex to the first, in lock step across the wave.
+// The kernel is bound by the latency of its record loads, so a record is loaded WHOLE (all 22 fields, whether the path
+// wrote the group or not -- the flags word selects afterwards; an unwritten field holds a stale value of an earlier wave,
+// never used) and the record below it is in flight while this one is processed: one round trip per record instead of
+// two dependent ones (flags, then the groups they name).
 VDEV void propagate_samples(const PathRecorder &rec, bool active, StageSink &sink) {
     const int n = active ? rec.n : 0;
     int nmax = n;
@@ -182,22 +186,33 @@ VDEV void propagate_samples(const PathRecorder &rec, bool active, StageSink &sin
     V3 p_next = mk(0, 0, 0);
     bool have_next = false, next_volume = false;
     unsigned int zero = 0;
+    float cur[SG_FLOATS], nxt[SG_FLOATS];
+#pragma unroll
+    for (int f = 0; f < SG_FLOATS; ++f) cur[f] = nxt[f] = 0.f;
+    if (nmax - 1 >= 0 && nmax - 1 < n) {
+#pragma unroll
+        for (int f = 0; f < SG_FLOATS; ++f) cur[f] = rec.at(nmax - 1, f);
+    }
     for (int i = nmax - 1; i >= 0; --i) {
+        if (i - 1 >= 0 && i - 1 < n) {
+#pragma unroll
+            for (int f = 0; f < SG_FLOATS; ++f) nxt[f] = rec.at(i - 1, f);
+        }
         bool emit = false;
         VspgTrainSample smp;
         if (i < n) {
-            const uint32_t fl = rec.flags(i);
+            const uint32_t fl = __builtin_bit_cast(uint32_t, cur[SG_FLAGS]);
             const bool has_wi = (fl & SGF_HAS_WI) != 0, volume = (fl & SGF_VOLUME) != 0, is_delta = (fl & SGF_DELTA) != 0;
-            const V3 p = V3{rec.at(i, SG_P), rec.at(i, SG_P + 1), rec.at(i, SG_P + 2)};
-            const Spec T = (fl & SGF_T) ? Spec{rec.at(i, SG_T), rec.at(i, SG_T + 1), rec.at(i, SG_T + 2)} : sp(1.f);
-            const float pdf = has_wi ? rec.at(i, SG_PDF) : 0.f;
+            const V3 p = V3{cur[SG_P], cur[SG_P + 1], cur[SG_P + 2]};
+            const Spec T = (fl & SGF_T) ? Spec{cur[SG_T], cur[SG_T + 1], cur[SG_T + 2]} : sp(1.f);
+            const float pdf = has_wi ? cur[SG_PDF] : 0.f;
             const Spec Lin = have_next ? T * Lout_next : sp(0.f);
             if (has_wi && !is_delta && have_next && pdf > 0) {
                 const float w = avg(Lin) / pdf;
                 if (w > 0 && !isinf_(w)) {
                     emit = true;
                     smp.p[0] = p.x; smp.p[1] = p.y; smp.p[2] = p.z;
-                    smp.dir[0] = rec.at(i, SG_WI); smp.dir[1] = rec.at(i, SG_WI + 1); smp.dir[2] = rec.at(i, SG_WI + 2);
+                    smp.dir[0] = cur[SG_WI]; smp.dir[1] = cur[SG_WI + 1]; smp.dir[2] = cur[SG_WI + 2];
                     smp.weight = w;
                     smp.pdf = pdf;
                     smp.distance = len(p_next - p);
@@ -207,13 +222,13 @@ VDEV void propagate_samples(const PathRecorder &rec, bool active, StageSink &sin
                 }
             }
             const bool has_direct = (fl & SGF_DIRECT) != 0;
-            const Spec direct = has_direct ? Spec{rec.at(i, SG_DIRECT), rec.at(i, SG_DIRECT + 1), rec.at(i, SG_DIRECT + 2)} : sp(0.f);
-            const float mi = has_direct ? rec.at(i, SG_MI) : 1.f;
-            const Spec scat = (fl & SGF_SCAT) ? Spec{rec.at(i, SG_SCAT), rec.at(i, SG_SCAT + 1), rec.at(i, SG_SCAT + 2)} : sp(0.f);
+            const Spec direct = has_direct ? Spec{cur[SG_DIRECT], cur[SG_DIRECT + 1], cur[SG_DIRECT + 2]} : sp(0.f);
+            const float mi = has_direct ? cur[SG_MI] : 1.f;
+            const Spec scat = (fl & SGF_SCAT) ? Spec{cur[SG_SCAT], cur[SG_SCAT + 1], cur[SG_SCAT + 2]} : sp(0.f);
             Spec Lout = direct * mi + scat;
             if (has_wi) {
-                const Spec sw = Spec{rec.at(i, SG_SW), rec.at(i, SG_SW + 1), rec.at(i, SG_SW + 2)};
-                Lout = Lout + (sw * Lin) / rec.at(i, SG_RR);
+                const Spec sw = Spec{cur[SG_SW], cur[SG_SW + 1], cur[SG_SW + 2]};
+                Lout = Lout + (sw * Lin) / cur[SG_RR];
             }
             Lout_next = Lout;
             p_next = p;
@@ -221,6 +236,8 @@ VDEV void propagate_samples(const PathRecorder &rec, bool active, StageSink &sin
             next_volume = volume;
         }
         sink.append(emit, smp);
+#pragma unroll
+        for (int f = 0; f < SG_FLOATS; ++f) cur[f] = nxt[f];
     }
     if (zero) atomicAdd(&sink.counters[1], (unsigned long long)zero);
 }
@@ -233,6 +250,7 @@ constexpr float kTrainWeightClamp = 32.0f;
 constexpr float kTrainKappaInit = 2.0f;
 constexpr unsigned long long kTrainMinUpdateSamples = 128;  // guidedvolpathvspgintegrator.cpp:238
 constexpr int kTrainCapNodes = 8192, kTrainCapRegions = 4097;
+constexpr int kTrainKeys = 2 * kTrainCapRegions;  // sort key of a sample in an update: field * kTrainCapRegions + region
 
 struct RegionStats {  // decayed sufficient statistics of one region
     float n;
@@ -243,43 +261,58 @@ struct RegionStats {  // decayed sufficient statistics of one region
 constexpr int kStatFloats = 7 + 8 * GK;  // every float member of RegionStats, in order
 static_assert(sizeof(RegionStats) == (kStatFloats + 1) * 4, "RegionStats layout");
 
-// Accumulation over samples SORTED by region (counting sort, k_train_lookup / k_train_scan / k_train_scatter):
+// Accumulation over samples SORTED by key (counting sort, k_train_lookup / k_train_scan / k_train_scatter):
 // a wavefront walks a contiguous piece of the sorted order, so almost every 64-sample group belongs to one
-// region.  The group's NV values are summed with a butterfly; value v's running sum lives in LANE v, and when
-// the region changes (or the piece ends) the wavefront flushes all of them with ONE atomic instruction (lane v
-// adds to statistic v).  Hot regions -- the whole field at iteration 0 -- thus cost one atomic per value per
-// wavefront piece instead of one per sample.
+// key.  The group's NV values are summed ACROSS the lanes by a transposing butterfly: at the step with lane distance o
+// a lane hands the half of its values its partner is responsible for to that partner and adds the half it receives --
+// P - 1 exchanges for P values instead of 6 P -- and ends up holding the group's total of ONE value (index lane >> kShift).
+// Each lane keeps the running sum of its value for the current key, and when the key changes (or the piece ends) the
+// wavefront flushes all of them with ONE atomic instruction.  Hot keys -- the whole field at iteration 0 -- thus cost one
+// atomic per value per wavefront piece instead of one per sample.
 template <int NV>
 struct RunAccumulator {
     static_assert(NV <= 64, "one lane per statistic");
-    float acc;      // lane v: running sum of statistic v for `region`
-    int region;     // wave-uniform
+    static constexpr int P = NV <= 1 ? 1 : NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;  // NV padded to a power of two
+    static constexpr int kShift = P == 1 ? 6 : P == 2 ? 5 : P == 4 ? 4 : P == 8 ? 3 : P == 16 ? 2 : P == 32 ? 1 : 0;
+    float acc;      // running sum of statistic (lane >> kShift) for `key` (the lanes sharing a statistic hold the same sum)
+    int key;        // wave-uniform
     float *dst;
     int first;
-    VDEV void init(float *d, int f) { acc = 0.f; region = -1; dst = d; first = f; }
+    VDEV void init(float *d, int f) { acc = 0.f; key = -1; dst = d; first = f; }
     VDEV void flush() {
-        const int lane = threadIdx.x & 63;
-        if (region >= 0 && lane < NV && acc != 0.f) atomicAdd(&dst[(size_t)region * kStatFloats + first + lane], acc);
+        const int lane = threadIdx.x & 63, v = lane >> kShift;
+        if (key >= 0 && (lane & ((1 << kShift) - 1)) == 0 && v < NV && acc != 0.f) atomicAdd(&dst[(size_t)key * kStatFloats + first + v], acc);
         acc = 0.f;
     }
-    // all lanes call; `valid` lanes contribute vals[] to their `reg`
-    VDEV void add(bool valid, int reg, const float (&vals)[NV]) {
+    // all lanes call; `valid` lanes contribute vals[0 .. NV) to their key `k` (vals[NV .. P) must be zero)
+    VDEV void add(bool valid, int k, const float (&vals)[P]) {
         const int lane = threadIdx.x & 63;
         unsigned long long todo = __ballot(valid);
         while (todo != 0ull) {
             const int leader = __ffsll((long long)todo) - 1;
-            const int lreg = __shfl(reg, leader);
-            const unsigned long long same = __ballot(valid && reg == lreg) & todo;
+            const int lkey = __shfl(k, leader);
+            const unsigned long long same = __ballot(valid && k == lkey) & todo;
             const bool mine = (same >> lane) & 1ull;
-            if (lreg != region) {
+            if (lkey != key) {
                 flush();
-                region = lreg;
+                key = lkey;
             }
-            for (int v = 0; v < NV; ++v) {
-                float x = mine ? vals[v] : 0.f;
-                for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-                if (lane == v) acc += x;
+            float x[P];
+#pragma unroll
+            for (int v = 0; v < P; ++v) x[v] = mine ? vals[v] : 0.f;
+            int o = 32;
+#pragma unroll
+            for (int c = P; c > 1; c >>= 1, o >>= 1) {
+                const bool upper = (lane & o) != 0;
+#pragma unroll
+                for (int j = 0; j < c / 2; ++j) {
+                    const float a = x[j], b = x[j + c / 2];
+                    x[j] = (upper ? b : a) + __shfl_xor(upper ? a : b, o);
+                }
             }
+            float t = x[0];
+            for (; o > 0; o >>= 1) t += __shfl_xor(t, o);
+            acc += t;
             todo &= ~same;
         }
     }
