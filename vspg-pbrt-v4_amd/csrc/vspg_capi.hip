@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
 constexpr int kStagePerLane = 3;  // samples staged per lane on average (2.5 at the defaults); a wavefront that collects more flushes early (StageSink)
 __global__ __launch_bounds__(kBlock) void k_propagate(TrainArgs train, int max_seg) {
     __shared__ VspgTrainSample s_stage[kBlock * kStagePerLane];  // 31 KB: five workgroups per CU
-    __shared__ unsigned int s_wcount[kBlock / 64];
+    __shared__ unsigned int s_wcount[kBlock / 64], s_wzero[kBlock / 64];
     __shared__ unsigned long long s_base;
     const unsigned i = blockIdx.x * kBlock + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -227,13 +227,15 @@ __global__ __launch_bounds__(kBlock) void k_propagate(TrainArgs train, int max_s
     rec.reset();
     rec.n = i < train.n_items ? train.seg_count[i] : 0;
     StageSink sink{s_stage + wave * 64 * kStagePerLane, 64u * kStagePerLane, 0u, train.samples, train.counters, train.capacity};
-    propagate_samples(rec, rec.n > 0, sink);
-    if (lane == 0) s_wcount[wave] = sink.count;
+    unsigned int zero = propagate_samples(rec, rec.n > 0, sink);
+    for (int off = 32; off > 0; off >>= 1) zero += __shfl_xor(zero, off);  // (one atomic per workgroup: the counters are single words)
+    if (lane == 0) { s_wcount[wave] = sink.count; s_wzero[wave] = zero; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned int total = 0;
-        for (int w = 0; w < kBlock / 64; ++w) total += s_wcount[w];
+        unsigned int total = 0, zeros = 0;
+        for (int w = 0; w < kBlock / 64; ++w) { total += s_wcount[w]; zeros += s_wzero[w]; }
         s_base = total ? atomicAdd(&train.counters[0], (unsigned long long)total) : 0ull;
+        if (zeros) atomicAdd(&train.counters[1], (unsigned long long)zeros);
     }
     __syncthreads();
     unsigned long long base = s_base;

@@ -171,33 +171,52 @@ struct StageSink {
 
 // PathSegmentStorage::PropagateSamples stand-in (see oracle/vspg_oracle.c:propagate_samples for the
 // definition): walk the path's records from the last vertex to the first, in lock step across the wave.
-// The kernel is bound by the latency of its record loads, so a record is loaded WHOLE (all 22 fields, whether the path
-// wrote the group or not -- the flags word selects afterwards; an unwritten field holds a stale value of an earlier wave,
-// never used) and the record below it is in flight while this one is processed: one round trip per record instead of
-// two dependent ones (flags, then the groups they name).
-VDEV void propagate_samples(const PathRecorder &rec, bool active, StageSink &sink) {
+// The kernel is bound by its record loads (1.1 GB per 1080p wave when every field of every record is read), so:
+//   * the flags words of the path's records are read first, all at once, and packed six bits apiece (records past the tenth
+//     count as "every group present"), so that
+//   * a record's groups are loaded only where the path wrote them, with no load depending on another, and
+//   * the record below is in flight while this one is processed (two register sets, the loop unrolled by two).
+struct SegRegs { float v[SG_FLOATS]; };
+VDEV unsigned int propagate_samples(const PathRecorder &rec, bool active, StageSink &sink) {  // returns the lane's zero-valued samples
     const int n = active ? rec.n : 0;
     int nmax = n;
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_xor(nmax, off);
         nmax = o > nmax ? o : nmax;
     }
+    constexpr int kPacked = 10;
+    unsigned long long packed = 0ull;
+    {
+        uint32_t f[kPacked];
+#pragma unroll
+        for (int i = 0; i < kPacked; ++i) f[i] = i < n ? rec.flags(i) : 0u;
+#pragma unroll
+        for (int i = 0; i < kPacked; ++i) packed |= (unsigned long long)(f[i] & 63u) << (6 * i);
+    }
     Spec Lout_next = sp(0.f);
     V3 p_next = mk(0, 0, 0);
     bool have_next = false, next_volume = false;
     unsigned int zero = 0;
-    float cur[SG_FLOATS], nxt[SG_FLOATS];
-#pragma unroll
-    for (int f = 0; f < SG_FLOATS; ++f) cur[f] = nxt[f] = 0.f;
-    if (nmax - 1 >= 0 && nmax - 1 < n) {
-#pragma unroll
-        for (int f = 0; f < SG_FLOATS; ++f) cur[f] = rec.at(nmax - 1, f);
-    }
-    for (int i = nmax - 1; i >= 0; --i) {
-        if (i - 1 >= 0 && i - 1 < n) {
-#pragma unroll
-            for (int f = 0; f < SG_FLOATS; ++f) nxt[f] = rec.at(i - 1, f);
+    const auto load = [&](SegRegs &R, int i) {
+        if (i < 0 || i >= n) return;
+        const uint32_t m = i < kPacked ? (uint32_t)(packed >> (6 * i)) & 63u : 63u;
+        R.v[SG_FLAGS] = i < kPacked ? __builtin_bit_cast(float, m) : rec.at(i, SG_FLAGS);
+        R.v[SG_P] = rec.at(i, SG_P); R.v[SG_P + 1] = rec.at(i, SG_P + 1); R.v[SG_P + 2] = rec.at(i, SG_P + 2);
+        if (m & SGF_HAS_WI) {
+            R.v[SG_WI] = rec.at(i, SG_WI); R.v[SG_WI + 1] = rec.at(i, SG_WI + 1); R.v[SG_WI + 2] = rec.at(i, SG_WI + 2);
+            R.v[SG_PDF] = rec.at(i, SG_PDF);
+            R.v[SG_SW] = rec.at(i, SG_SW); R.v[SG_SW + 1] = rec.at(i, SG_SW + 1); R.v[SG_SW + 2] = rec.at(i, SG_SW + 2);
+            R.v[SG_RR] = rec.at(i, SG_RR);
         }
+        if (m & SGF_T) { R.v[SG_T] = rec.at(i, SG_T); R.v[SG_T + 1] = rec.at(i, SG_T + 1); R.v[SG_T + 2] = rec.at(i, SG_T + 2); }
+        if (m & SGF_DIRECT) {
+            R.v[SG_DIRECT] = rec.at(i, SG_DIRECT); R.v[SG_DIRECT + 1] = rec.at(i, SG_DIRECT + 1); R.v[SG_DIRECT + 2] = rec.at(i, SG_DIRECT + 2);
+            R.v[SG_MI] = rec.at(i, SG_MI);
+        }
+        if (m & SGF_SCAT) { R.v[SG_SCAT] = rec.at(i, SG_SCAT); R.v[SG_SCAT + 1] = rec.at(i, SG_SCAT + 1); R.v[SG_SCAT + 2] = rec.at(i, SG_SCAT + 2); }
+    };
+    const auto process = [&](const SegRegs &R, int i) {
+        const float *cur = R.v;
         bool emit = false;
         VspgTrainSample smp;
         if (i < n) {
@@ -236,10 +255,21 @@ VDEV void propagate_samples(const PathRecorder &rec, bool active, StageSink &sin
             next_volume = volume;
         }
         sink.append(emit, smp);
+    };
+    SegRegs A, B;
 #pragma unroll
-        for (int f = 0; f < SG_FLOATS; ++f) cur[f] = nxt[f];
+    for (int f = 0; f < SG_FLOATS; ++f) A.v[f] = B.v[f] = 0.f;
+    int i = nmax - 1;
+    load(A, i);
+    while (i >= 0) {
+        load(B, i - 1);
+        process(A, i);
+        if (--i < 0) break;
+        load(A, i - 1);
+        process(B, i);
+        --i;
     }
-    if (zero) atomicAdd(&sink.counters[1], (unsigned long long)zero);
+    return zero;
 }
 
 // ---- Field::Update stand-in (definition: oracle/vspg_oracle.c "Field::Update") ------------------
