@@ -1088,41 +1088,18 @@ struct GridMediumT {
         }
         return o;
     }
-    static VDEV float interp_grid(const Octet &o, float dx, float dy, float dz) {  // the lerps of SampledGrid::Lookup(Point3f) (containers.h:810-818)
+    VDEV float lookup(V3 p) const {  // SampledGrid::Lookup(Point3f) (containers.h:804-819) over the octet of floor(p * n - .5)
+        float sx = p.x * nx - .5f, sy = p.y * ny - .5f, sz = p.z * nz - .5f;
+        float fx = __builtin_floorf(sx), fy = __builtin_floorf(sy), fz = __builtin_floorf(sz);
+        int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+        float dx = sx - (float)ix, dy = sy - (float)iy, dz = sz - (float)iz;
+        const Octet o = octet(ix, iy, iz);
         float d00 = (1 - dx) * o.v000 + dx * o.v100;
         float d10 = (1 - dx) * o.v010 + dx * o.v110;
         float d01 = (1 - dx) * o.v001 + dx * o.v101;
         float d11 = (1 - dx) * o.v011 + dx * o.v111;
         float a = (1 - dy) * d00 + dy * d10, b = (1 - dy) * d01 + dy * d11;
         return (1 - dz) * a + dz * b;
-    }
-    static VDEV float interp_nvdb(const Octet &o, float u, float v, float w) {  // TrilinearSampler: lerp(a, b, w) = a + w (b - a) along z, then y, then x
-        const float v000 = o.v000, v001 = o.v001, v010 = o.v010, v011 = o.v011, v100 = o.v100, v101 = o.v101, v110 = o.v110, v111 = o.v111;
-        const float a00 = v000 + w * (v001 - v000), a01 = v010 + w * (v011 - v010);
-        const float a10 = v100 + w * (v101 - v100), a11 = v110 + w * (v111 - v110);
-        const float b0 = a00 + v * (a01 - a00), b1 = a10 + v * (a11 - a10);
-        return b0 + u * (b1 - b0);
-    }
-    // base voxel + fractions of a query: SampledGrid::Lookup(Point3f) over the octet of floor(p * n - .5) (p in [0,1]^3) ...
-    VDEV void cell_grid(V3 p, int *ix, int *iy, int *iz, float *dx, float *dy, float *dz) const {
-        float sx = p.x * nx - .5f, sy = p.y * ny - .5f, sz = p.z * nz - .5f;
-        float fx = __builtin_floorf(sx), fy = __builtin_floorf(sy), fz = __builtin_floorf(sz);
-        *ix = (int)fx; *iy = (int)fy; *iz = (int)fz;
-        *dx = sx - (float)*ix; *dy = sy - (float)*iy; *dz = sz - (float)*iz;
-    }
-    // ... and nanovdb::SampleFromVoxels<Tree, 1, false> over the dense copy: ijk = floor(x), uvw = x - ijk (x in index space)
-    VDEV void cell_nvdb(V3 x, int *ix, int *iy, int *iz, float *u, float *v, float *w) const {
-        const float fx = __builtin_floorf(x.x), fy = __builtin_floorf(x.y), fz = __builtin_floorf(x.z);
-        // a query far outside the grid must not wrap the int conversion into the valid range: clamp (any such octet is zero)
-        const float cx = fmax_(fmin_(fx, 1e9f), -1e9f), cy = fmax_(fmin_(fy, 1e9f), -1e9f), cz = fmax_(fmin_(fz, 1e9f), -1e9f);
-        *ix = (int)cx - imx; *iy = (int)cy - imy; *iz = (int)cz - imz;  // accessor.getValue: background 0 outside the index bounding box
-        *u = x.x - fx; *v = x.y - fy; *w = x.z - fz;
-    }
-    VDEV float lookup(V3 p) const {
-        int ix, iy, iz;
-        float dx, dy, dz;
-        cell_grid(p, &ix, &iy, &iz, &dx, &dy, &dz);
-        return interp_grid(octet(ix, iy, iz), dx, dy, dz);
     }
     static VDEV float at(const float *data, int nx, int ny, int nz, int x, int y, int z) {  // SampledGrid::Lookup(Point3i) (containers.h:830-835)
         if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
@@ -1228,16 +1205,32 @@ struct GridMediumT {
         axis_setup(gi.z, gd.z, 4, &it.vz, &it.dtz, &it.ncz);
         return it;
     }
+    // nanovdb::SampleFromVoxels<Tree, 1, false> over the dense copy: ijk = floor(x), uvw = x - ijk, corner values
+    // with background 0, lerp(a, b, w) = a + w (b - a) along z, then y, then x
     VDEV float lookup_index(V3 x) const {
-        int ix, iy, iz;
-        float u, v, w;
-        cell_nvdb(x, &ix, &iy, &iz, &u, &v, &w);
-        return interp_nvdb(octet(ix, iy, iz), u, v, w);
+        const float fx = __builtin_floorf(x.x), fy = __builtin_floorf(x.y), fz = __builtin_floorf(x.z);
+        // a query far outside the grid must not wrap the int conversion into the valid range: clamp (any such octet is zero)
+        const float cx = fmax_(fmin_(fx, 1e9f), -1e9f), cy = fmax_(fmin_(fy, 1e9f), -1e9f), cz = fmax_(fmin_(fz, 1e9f), -1e9f);
+        const int i = (int)cx, j = (int)cy, k = (int)cz;
+        const float u = x.x - fx, v = x.y - fy, w = x.z - fz;
+        const Octet o = octet(i - imx, j - imy, k - imz);  // accessor.getValue: background 0 outside the index bounding box
+        const float v000 = o.v000, v001 = o.v001, v010 = o.v010, v011 = o.v011, v100 = o.v100, v101 = o.v101, v110 = o.v110, v111 = o.v111;
+        const float a00 = v000 + w * (v001 - v000), a01 = v010 + w * (v011 - v010);
+        const float a10 = v100 + w * (v101 - v100), a11 = v110 + w * (v111 - v110);
+        const float b0 = a00 + v * (a01 - a00), b1 = a10 + v * (a11 - a10);
+        return b0 + u * (b1 - b0);
     }
-    VDEV V3 index_of(V3 p) const { return V3{(p.x - origin.x) * inv_voxel.x, (p.y - origin.y) * inv_voxel.y, (p.z - origin.z) * inv_voxel.z}; }
-    VDEV MediumProps props_of(float d, V3 po) const {
+    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703 (temperature grids are out of scope)
+        float d;
         Spec le = sp(0.f);
-        if constexpr (!NVDB) {
+        p = to_medium(p);  // renderFromMedium.ApplyInverse(p) (media.h:322 / :693)
+        if constexpr (NVDB) {
+            const V3 xi = V3{(p.x - origin.x) * inv_voxel.x, (p.y - origin.y) * inv_voxel.y, (p.z - origin.z) * inv_voxel.z};
+            d = lookup_index(xi);
+            d += density_offset;
+        } else {
+            const V3 po = offset(p);
+            d = lookup(po);
             if (le_scale) {  // isEmissive (wave-uniform): Le = scale * Le_spec where the LeScale grid is positive (:326-342)
                 const float scale = lookup(le_scale, lnx, lny, lnz, po);
                 if (scale > 0) le = Le * scale;
@@ -1245,57 +1238,6 @@ struct GridMediumT {
         }
         Spec sa = sigma_a * d, ss = sigma_s * d;
         return MediumProps{sa, ss, le, g, ss + sa};
-    }
-    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703 (temperature grids are out of scope)
-        p = to_medium(p);  // renderFromMedium.ApplyInverse(p) (media.h:322 / :693)
-        if constexpr (NVDB) {
-            float d = lookup_index(index_of(p));
-            d += density_offset;
-            return props_of(d, p);
-        } else {
-            const V3 po = offset(p);
-            return props_of(lookup(po), po);
-        }
-    }
-    // The same query in two phases, for the batched distance walk (vspg_wavefront.h): point_fetch issues the query's loads with no
-    // branch around them -- an out-of-range or empty-brick query reads slot 0 and is zeroed afterwards -- so that several queries
-    // of a lane are in flight together; point_finish(p, point_fetch(p)) == sample_point(p) bit for bit (same functions, same order).
-    VDEV Octet octet_nb(int ix, int iy, int iz) const {
-        typedef float v4f_ __attribute__((ext_vector_type(4)));
-        const int ox = ix + 1, oy = iy + 1, oz = iz + 1;
-        const bool in = (unsigned)ox <= (unsigned)nx && (unsigned)oy <= (unsigned)ny && (unsigned)oz <= (unsigned)nz;
-        const int cell = in ? ((oz >> 3) * bny + (oy >> 3)) * bnx + (ox >> 3) : 0;
-        int b = cell;
-        if (brick_index) b = *(const int VSPG_GLOBAL_AS *)(brick_index + cell);
-        const bool have = in && b >= 0;
-        const size_t slot = have ? (size_t)b * 512u + (size_t)((ox & 7) + 8 * ((oy & 7) + 8 * (oz & 7))) : (size_t)0;
-        const v4f_ VSPG_GLOBAL_AS *q = (const v4f_ VSPG_GLOBAL_AS *)(octets + slot * 2u);
-        const v4f_ lo = q[0], hi = q[1];
-        return Octet{have ? lo.x : 0.f, have ? lo.y : 0.f, have ? lo.z : 0.f, have ? lo.w : 0.f, have ? hi.x : 0.f, have ? hi.y : 0.f, have ? hi.z : 0.f, have ? hi.w : 0.f};
-    }
-    VDEV bool can_fetch_unconditionally() const { return octets != nullptr; }  // (an all-zero grid stores no brick at all)
-    VDEV Octet point_fetch(V3 p) const {
-        int ix, iy, iz;
-        float a, b, c;
-        p = to_medium(p);
-        if constexpr (NVDB) cell_nvdb(index_of(p), &ix, &iy, &iz, &a, &b, &c);
-        else cell_grid(offset(p), &ix, &iy, &iz, &a, &b, &c);
-        return octet_nb(ix, iy, iz);
-    }
-    VDEV MediumProps point_finish(V3 p, const Octet &o) const {
-        int ix, iy, iz;
-        float a, b, c;
-        p = to_medium(p);
-        if constexpr (NVDB) {
-            cell_nvdb(index_of(p), &ix, &iy, &iz, &a, &b, &c);
-            float d = interp_nvdb(o, a, b, c);
-            d += density_offset;
-            return props_of(d, p);
-        } else {
-            const V3 po = offset(p);
-            cell_grid(po, &ix, &iy, &iz, &a, &b, &c);
-            return props_of(interp_grid(o, a, b, c), po);
-        }
     }
     VDEV Spec sigma_n(const MediumProps &mp, Spec sigma_maj) const { return clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s); }
     VDEV bool is_homogeneous() const { return false; }

@@ -778,22 +778,6 @@ VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, 
 }
 
 // ---- SampleT_maj_Resampling's traversal (media_sampleTMaj.h:178-247) + the reservoir callback (:691-719) --------------
-// The callback "never stops the traversal" and draws from the SAMPLER, not from the walk's private RNG: where the tentative
-// collisions of a ray fall depends on the majorants and that RNG alone.  So a lane runs AHEAD of its callbacks: a tentative
-// collision is queued (position, T_maj up to it, the segment's majorant -- kWfPend entries per lane) and the traversal goes on;
-// when most lanes' queues are full the wavefront runs the callbacks, every lane its own queue in order, with the density
-// fetches of all queued collisions issued together (GridMediumT::point_fetch: no branch around the loads).  Per lane the
-// operations and their order are unchanged (bit-identical results); what changes is that the collision code runs with full
-// queues instead of the 35 of 64 lanes that happened to draw a collision in the same step, the traversal steps run without
-// waiting for it, and a lane has kWfPend memory round trips in flight instead of one.
-#ifndef VSPG_WF_PEND
-#define VSPG_WF_PEND 2
-#endif
-#ifndef VSPG_WF_PEND_READY
-#define VSPG_WF_PEND_READY 40
-#endif
-constexpr int kWfPend = VSPG_WF_PEND;             // queued tentative collisions per lane
-constexpr int kWfPendReady = VSPG_WF_PEND_READY;  // the callbacks run once this many lanes have a full queue (or a finished walk with entries left)
 template <class Medium>
 __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(WfArgs a, int it) {
     const DScene &S = *a.scene;
@@ -805,7 +789,6 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     pc.zero();
     WfClaim claim{0u, 0u, false, 0u};
     bool active = false, result = false;  // result: a finished walk whose result is still in registers
-    bool ended = false;                   // the traversal has reached the end of the ray (queued collisions may remain)
     unsigned slot = 0;
     WalkState<Medium> w;
     VSPG_WF_STAT_DECL;
@@ -820,16 +803,6 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     float weightSum = 0, sel_wi = 0;
     Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f), sel_num = sp(0.f), sel_den = sp(0.f);
     V3 sel_p = mk(0, 0, 0);
-    // the queue: a grey medium's spectra have three equal channels, one is kept
-    using PV = typename std::conditional<Medium::kGrey != 0, float, Spec>::type;
-    const auto pack = [](Spec x) -> PV { if constexpr (Medium::kGrey != 0) return x.r; else return x; };
-    const auto unpack = [](PV x) -> Spec { if constexpr (Medium::kGrey != 0) return sp(x); else return x; };
-    V3 q_p[kWfPend];
-    PV q_T[kWfPend], q_s[kWfPend];
-    int npend = 0;
-#pragma unroll
-    for (int k = 0; k < kWfPend; ++k) { q_p[k] = mk(0, 0, 0); q_T[k] = pack(sp(1.f)); q_s[k] = pack(sp(0.f)); }
-    const bool batched = medium.can_fetch_unconditionally();  // (wave-uniform)
     while (true) {
         const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
         if (n_idle == 64u || (n_idle >= (unsigned)a.walk_refill && !(claim.exhausted && claim.next >= claim.end))) {
@@ -865,73 +838,53 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
                 sel_num = sel_den = sp(0.f);
                 sel_p = mk(0, 0, 0);
                 active = true;
-                ended = false;
-                npend = 0;
-#pragma unroll
-                for (int k = 0; k < kWfPend; ++k) q_p[k] = ro;  // (an unused entry is fetched too: any point will do)
             }
             if (__ballot(active) == 0ull) break;  // nothing in flight and the list has run out
         }
-        // ---- one tracking step for every lane with room in its queue ------------------------------------------------
-        const bool room = active && !ended && npend < kWfPend;
-        VSPG_WF_STAT(0, 0, 1); VSPG_WF_STAT(0, 1, __popcll(__ballot(active))); VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(room)));
+        // ---- one tracking step ------------------------------------------------------------------------------------
+        float t = 0.f;
+        int r = WALK_MOVED;
+        VSPG_WF_STAT(0, 0, 1); VSPG_WF_STAT(0, 1, __popcll(__ballot(active))); VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(active)));
         if (claim.exhausted && claim.next >= claim.end) { VSPG_WF_STAT(0, 7, 1); VSPG_WF_STAT(0, 6, __popcll(__ballot(active))); }  // draining: no job left to claim
-        if (room) {
-            float t = 0.f;
-            const int r = walk_advance<Medium, true>(w, ch, scale, &t);
-            if (r == WALK_COLLISION) {
-                const Spec T = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
-                const V3 p = ro + rdn * t;
-#pragma unroll
-                for (int k = 0; k < kWfPend; ++k)
-                    if (npend == k) { q_p[k] = p; q_T[k] = pack(T); q_s[k] = pack(w.sigma_maj); }
-                ++npend;
-                w.T_maj = sp(1.f);
-                w.tMin = t;
-            } else if (r == WALK_END) {
-                ended = true;
-            }
+        if (active) {
+            r = walk_advance<Medium, true>(w, ch, scale, &t);
         }
-        // ---- the callbacks of the queued collisions (:691-719), every lane its own queue in order ---------------------
-        const bool ready = active && npend > 0 && (npend == kWfPend || ended);
-        const unsigned n_ready = (unsigned)__popcll(__ballot(ready));
-        const unsigned n_room = (unsigned)__popcll(__ballot(active && !ended && npend < kWfPend));
-        if (n_ready >= (unsigned)kWfPendReady || (n_ready > 0u && n_room < 8u)) {
-            VSPG_WF_STAT(0, 4, 1); VSPG_WF_STAT(0, 5, __popcll(__ballot(active && npend > 0)));
-            typename Medium::Octet oc[kWfPend];
-            if (batched) {
-#pragma unroll
-                for (int k = 0; k < kWfPend; ++k) oc[k] = medium.point_fetch(q_p[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < kWfPend; ++k) {
-                if (active && k < npend) {
-                    const V3 p = q_p[k];
-                    const MediumProps mp = batched ? medium.point_finish(p, oc[k]) : medium.sample_point(p);
-                    pc.density_query();
-                    const Spec sigma_maj = unpack(q_s[k]), T_maj = unpack(q_T[k]);
-                    const Spec sigma_t = mp.sigma_t;
-                    const Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
-                    const float wi = ch_of(sigma_t / sigma_maj * trRatioEst, ch);
-                    if (wi > 0) {
-                        weightSum += wi;
-                        if (sampler.get1d() < wi / weightSum) {
-                            const float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
-                            sel_num = beta_rs * T_maj * mp.sigma_s / pdf;
-                            sel_den = r_u_rs * T_maj * sigma_t / pdf;
-                            sel_p = p;
-                            sel_wi = wi;
-                        }
-                    }
-                    const float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
-                    beta_rs = beta_rs * (T_maj * sigma_n / pdf);
-                    r_u_rs = r_u_rs * (T_maj * sigma_n / pdf);
-                    trRatioEst = trRatioEst * (sigma_n / sigma_maj);
+        // lanes that only moved (crossed into the next majorant cell, skipped an empty one) try again before the wavefront
+        // enters the collision code, so that code runs with most lanes: up to walk_rounds tries while >= 8 lanes would sit idle
+        for (int rr = 1; rr < a.walk_rounds; ++rr) {
+            const bool again = active && r == WALK_MOVED;
+            if (__popcll(__ballot(again)) < 8) break;
+            VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(again)));
+            if (again) r = walk_advance<Medium, true>(w, ch, scale, &t);
+        }
+        VSPG_WF_STAT(0, 4, __ballot(active && r == WALK_COLLISION) != 0ull); VSPG_WF_STAT(0, 5, __popcll(__ballot(active && r == WALK_COLLISION)));
+        if (active && r == WALK_COLLISION) {
+            w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
+            const V3 p = ro + rdn * t;
+            const MediumProps mp = medium.sample_point(p);
+            // the resampling callback (:691-719); it never stops the traversal
+            pc.density_query();
+            const Spec sigma_maj = w.sigma_maj, T_maj = w.T_maj;
+            const Spec sigma_t = mp.sigma_t;
+            const Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
+            const float wi = ch_of(sigma_t / sigma_maj * trRatioEst, ch);
+            if (wi > 0) {
+                weightSum += wi;
+                if (sampler.get1d() < wi / weightSum) {
+                    const float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
+                    sel_num = beta_rs * T_maj * mp.sigma_s / pdf;
+                    sel_den = r_u_rs * T_maj * sigma_t / pdf;
+                    sel_p = p;
+                    sel_wi = wi;
                 }
             }
-            npend = 0;
-        }
-        if (active && ended && npend == 0) {
+            const float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
+            beta_rs = beta_rs * (T_maj * sigma_n / pdf);
+            r_u_rs = r_u_rs * (T_maj * sigma_n / pdf);
+            trRatioEst = trRatioEst * (sigma_n / sigma_maj);
+            w.T_maj = sp(1.f);
+            w.tMin = t;
+        } else if (active && r == WALK_END) {
             active = false;
             result = true;
         }
