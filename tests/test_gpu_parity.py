@@ -1722,7 +1722,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
 @pytest.mark.parametrize("kind", ["grid", "nvdb"])
 def test_guided_wavefront_pipeline_equals_per_lane_kernel(gpu_pkg, kind):
     """The reference-default guided configuration over a heterogeneous medium with a field in place (config 5's query side):
-    the wavefront pipeline -- whole guided vertex in k_wf_seg_end, NEE result added by the next k_wf_advance -- renders the
+    the wavefront pipeline -- whole guided vertex in k_wf_vertex, a shadow-walked NEE result added by the next k_wf_vertex -- renders the
     per-lane guided kernel's film bit for bit, and both agree with the oracle's."""
     import scenes
     P = gpu_pkg
@@ -1774,6 +1774,8 @@ GUIDED_CLOUD_SWEEP = [
     dict(surfaceguidingtype=0, volumeguidingtype=1),    # surface MIS, volume RIS
     dict(vspsecondaryguiding=0), dict(vspguiding=0),
     dict(vspcriterion=0),
+    dict(rrguiding=1, maxdepth=8, minrrdepth=1),        # guided Russian roulette on the pipeline (contribution estimate ready from wave 1 on)
+    dict(rrguiding=1, surfacerrguiding=0),
 ]
 
 

@@ -1600,7 +1600,9 @@ struct VspgRenderer {
     // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
     float *wf_pool = nullptr;
     float4 *wave_samples = nullptr;  // k_render_wave_wg2: one {L, ISG code} per pixel of a one-sample launch (k_film_resolve adds it in)
-    unsigned int *wf_lists = nullptr;   // 4 x n_items: active, vertex, walk, shadow
+    unsigned int *wf_lists = nullptr;   // 4 x n_items: active (even / odd iterations), walk, shadow
+    hipStream_t wf_stream2 = nullptr;   // the shadow walks' stream (wf_render_pass)
+    hipEvent_t wf_ev_vertex = nullptr, wf_ev_shadow = nullptr;
     WfIter *wf_iters = nullptr;
     size_t wf_items = 0;
     int num_cus = 0;
@@ -2337,7 +2339,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     a.n_items = (unsigned)items;
     a.tilesX = (unsigned)tilesX;
     a.list_active = r->wf_lists;
-    a.list_vertex = r->wf_lists + items;
+    a.list_active2 = r->wf_lists + items;
     a.list_walk = r->wf_lists + 2 * items;
     a.list_shadow = r->wf_lists + 3 * items;
     a.iters = r->wf_iters;
@@ -2363,11 +2365,30 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     unsigned swalk = (unsigned)r->num_cus * (unsigned)kWfShadowWavesPerSimd;
     if (walk > max_blocks) walk = max_blocks;
     if (swalk > max_blocks) swalk = max_blocks;
+    // The shadow walk of iteration i runs beside the distance walk of iteration i + 1, on the renderer's second stream; the
+    // vertex kernel of iteration i + 1 waits for both (it adds the shadow walk's result first thing).  VSPG_WF_SERIAL=1 keeps
+    // everything on the caller's stream (same results; for A/B runs and debugging).
+    static const bool serial = [] { const char *e = getenv("VSPG_WF_SERIAL"); return e && *e && *e != '0'; }();
+    if (!serial && !r->wf_stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&r->wf_stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&r->wf_ev_vertex, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&r->wf_ev_shadow, hipEventDisableTiming));
+    }
+    const hipStream_t s2 = serial ? s : r->wf_stream2;
+    hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a);
     for (int it = 0; it <= r->prm.maxdepth; ++it) {
-        hipLaunchKernelGGL((k_wf_advance<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
         hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
-        hipLaunchKernelGGL((k_wf_seg_end<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
-        if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
+        if (it > 0 && !serial) HIPCHK(hipStreamWaitEvent(s, r->wf_ev_shadow, 0));
+        hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
+        if (it < r->prm.maxdepth) {
+            if (!serial) {
+                HIPCHK(hipEventRecord(r->wf_ev_vertex, s));
+                HIPCHK(hipStreamWaitEvent(s2, r->wf_ev_vertex, 0));
+            }
+            hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s2, a, it);
+            if (!serial) HIPCHK(hipEventRecord(r->wf_ev_shadow, s2));
+            if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it + 1);
+        }
     }
     HIPCHK(hipGetLastError());
     if (TRAIN) {
@@ -2783,6 +2804,9 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->wf_pool) (void)hipFree(r->wf_pool);
     if (r->wf_lists) (void)hipFree(r->wf_lists);
     if (r->wf_iters) (void)hipFree(r->wf_iters);
+    if (r->wf_ev_vertex) (void)hipEventDestroy(r->wf_ev_vertex);
+    if (r->wf_ev_shadow) (void)hipEventDestroy(r->wf_ev_shadow);
+    if (r->wf_stream2) (void)hipStreamDestroy(r->wf_stream2);
     if (r->density) (void)hipFree(r->density);
     if (r->brick_index) (void)hipFree(r->brick_index);
     if (r->octets) (void)hipFree(r->octets);
@@ -2844,9 +2868,8 @@ static bool uses_wf_pipeline(const VspgRenderer *r) {
     const bool het = r->scene.medium.type == VSPG_MEDIUM_GRID || r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wf") != 0) return false;
-    // guided builds too, training passes included (segment recording in the dense kernels); guided Russian roulette stays on
-    // the per-lane kernel
-    if (wants_guiding(r->prm) && r->prm.rrguiding) return false;
+    // guided builds too, training passes included (segment recording in the dense kernels), and guided Russian roulette (round 3:
+    // the vertex kernel reads the pixel's contribution estimate)
     return het && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
 }
 const char *vspg_renderer_kernel_name(VspgRenderer *r) {

@@ -6,22 +6,31 @@
 // walk: 18 % of the vector lanes did useful work on the 256^3 cloud (round 1, profiles/r01_pmc_wave_state_cloud.txt).
 //
 // Here the frame's paths live in HBM as a field-major SoA (one column per pixel of the wave: this part has 288 GB, the
-// ~400 B per path of a 4K wave are 3.3 GB) and every path-loop iteration (:309-609) is cut at its two walks:
+// ~600 B per path of a 4K wave are 5 GB) and every path-loop iteration (:309-609) is cut at its two walks:
 //
-//   k_wf_advance     dense   vertex end of the previous iteration (NEE result, Russian roulette, new direction :842-874 /
-//                            :487-606) fused with the next segment's begin (scene intersection, RNG seeding :323-325, the
-//                            resampling routine's majorant pre-pass, media_sampleTMaj.h:150-176); survivors are compacted
-//                            into the next list with a wave ballot + prefix count + one atomic per wavefront
+//   k_wf_start       dense   camera rays + the first segment's begin (once per pass)
 //   k_wf_dist_walk   WALK    SampleT_maj_Resampling's traversal + the reservoir callback (:691-719) -- one JOB per path
-//   k_wf_seg_end     dense   candidate selection (:721-771), surface emission / depth test (:350-412), vertex setup, the
-//                            NEE's light sample and shadow-ray set-up (:1136-1200)
+//   k_wf_vertex      dense   [the previous vertex's NEE result, if a shadow walk was out for it] candidate selection
+//                            (:721-771), surface emission / depth test (:350-412), the vertex -- NEE light sample and
+//                            shadow-ray set-up (:1136-1200), Russian roulette, new direction (:842-874 / :487-606) -- and the
+//                            NEXT segment's begin (scene intersection, RNG seeding :323-325, the resampling routine's majorant
+//                            pre-pass, media_sampleTMaj.h:150-176); survivors are compacted into the next list with a wave
+//                            ballot + prefix count + one atomic per workgroup per four rounds
 //   k_wf_shadow_walk WALK    the shadow ray's ratio-tracking transmittance (:1205-1232) -- one JOB per unoccluded NEE
+//   (guided pipelines: the next segment's begin is its own dense kernel, k_wf_begin -- the guided vertex fills the register file)
+//
+// Nothing at a vertex after the NEE's set-up depends on the shadow ray's transmittance -- it only scales what is added to L --
+// so the vertex does not wait for it (round 3): k_wf_vertex goes on to the next segment, the shadow walk of iteration i runs
+// CONCURRENTLY with the distance walk of iteration i + 1 (own stream, own job fields), and its result is added first thing in
+// the next k_wf_vertex, before anything else touches L (the additions to L keep the reference's order).  A path that ends at
+// the vertex with a shadow walk still out stays on the list as WFL_DEAD for that one addition.  An NEE that needs no walk is
+// added on the spot.  Per iteration the path record crosses HBM once (it used to be twice: k_wf_seg_end, then k_wf_advance).
 //
 // The WALK kernels are persistent: a lane runs one job at a time and a wavefront refills its idle lanes from the job
 // list once a quarter of them are idle (one returning atomic per 64 jobs), so the lanes of a wavefront are at DIFFERENT
 // jobs but always in the SAME loop -- one tracking step per iteration: majorant-cell advance, then the tentative-collision
 // draw, then the collision itself (8-voxel fetch + callback) for the lanes that drew one.  Path state crosses a kernel
-// boundary once per walk, as coalesced 4-byte-per-lane SoA accesses.
+// boundary once per walk, as 16-byte-per-lane group accesses.
 //
 // Per path the operations and their order are those of li_segment_a / li_segment_b / sample_distance / sample_Ld /
 // sample_T_maj*: the film is bit-identical to the per-lane kernel's (and to the oracle's paths).
@@ -53,7 +62,7 @@ enum {
     WF_RNG = 28,      // 4  sampler PCG state / inc
     WF_VXP = 32,      // 3  vertex position (surface: re-projected hit point; volume: selected candidate) | +3: WF_VXG
     WF_VXG = 35,      // 1  surface: rectangle (int); volume: g
-    // walk job (distance walk, later re-used by the shadow walk of the same iteration)
+    // distance-walk job
     WF_IT = 36,       // 9 (+3 below)  DDA iterator at the start of the ray: tMin, tMax, nextCrossingT[3], deltaT[3], packed voxel | step signs
     WF_VXT = 45,      // 1  surface tHit
     WF_WU = 46,       // 1  first uniform of the walk
@@ -89,18 +98,21 @@ enum {
     WF_RECN = 124,    // 1  records written so far
     WF_RECCUR = 125,  // 1  current record (-1: none)
     WF_RECFL = 126,   // 1  its flags word
-    WF_COUNT = 128
+    // shadow-walk job (own fields: the shadow walk of iteration i runs beside the distance walk of iteration i + 1)
+    WF_SIT = 128,     // 9  DDA iterator of the shadow ray (as WF_IT)
+    WF_SWU = 137,     // 1  first uniform of the shadow walk
+    WF_SRDN = 140,    // 3  normalised shadow-ray direction
+    WF_SWRNG = 144,   // 4  the shadow ray's private PCG (:1193)
+    WF_COUNT = 148
 };
 enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_NODIST = 1 << 20,    // no SampleDistance this segment (no medium / the ray escapes)
     WFL_NOWALK = 1 << 21,    // the resampling routine returned before its traversal (tau == 0)
     WFL_GUIDE = 1 << 22,     // the segment is VSP-guided
-    WFL_SHADOW_WALK = 1 << 23,   // NEE: a ratio-tracking walk was queued
-    WFL_SHADOW_CLEAR = 1 << 24,  // NEE: contributes without a walk (T_ray = 1)
+    WFL_SHADOW_WALK = 1 << 23,   // NEE of the previous vertex: a ratio-tracking walk is out; its result is added by the next k_wf_vertex
     WFL_HIT = 1 << 25,       // the segment's ray hit a surface
-    WFL_NEE = 1 << 26,       // SampleLd ran at the vertex (its result is added even when it is zero, :483 / :836)
-    WFL_DELTA = 1 << 27,     // NEE sampled a delta light (DistantLight)
-    WFL_DEAD = 1 << 28,      // guided pipeline: the vertex code ended the path; only its NEE result is still to be added
+    WFL_DELTA = 1 << 27,     // that NEE sampled a delta light (DistantLight)
+    WFL_DEAD = 1 << 28,      // the path ended at the previous vertex; only that NEE result is still to be added
 };
 
 struct WfPool {
@@ -131,8 +143,8 @@ struct WfPool {
 
 // per-iteration control block (one per path-loop iteration, zeroed once per launch of the pipeline)
 struct WfIter {
-    unsigned int n_active;       // paths with a segment in this iteration (k_wf_advance -> k_wf_seg_end)
-    unsigned int n_vertex;       // paths standing at a vertex after it (k_wf_seg_end -> the next k_wf_advance)
+    unsigned int n_active;       // list entries of this iteration: paths with a segment in flight (+ WFL_DEAD ones awaiting their NEE)
+    unsigned int n_unused;
     unsigned int n_walk;         // distance-walk jobs
     unsigned int n_shadow;       // shadow-walk jobs
     unsigned int walk_head;      // job cursors of the two walk kernels
@@ -150,8 +162,8 @@ struct WfArgs {
     PcgJump jump;                // PCG skip-ahead for sample * 65536
     unsigned int n_items;        // tiles * 64
     unsigned int tilesX;
-    unsigned int *list_active;   // slots with a segment in flight
-    unsigned int *list_vertex;   // slots standing at a vertex
+    unsigned int *list_active;   // slots with a segment in flight, even iterations
+    unsigned int *list_active2;  // ... odd iterations (k_wf_vertex reads one and writes the other)
     unsigned int *list_walk;
     unsigned int *list_shadow;
     WfIter *iters;               // [maxdepth + 2]
@@ -162,7 +174,7 @@ struct WfArgs {
     int rec_cap;                 // records a path may keep (train_rec_capacity)
 };
 // the recorder of a path between two kernels of a training pass: records go straight to the path's column of the wave's
-// buffer; n / cur / flags travel in the path record.  (scat_*: a record sees at most one NEE, added by k_wf_advance.)
+// buffer; n / cur / flags travel in the path record.  (scat_*: a record sees at most one NEE.)
 VDEV void wf_rec_load(const WfArgs &a, unsigned slot, PathRecorder &rec) {
     rec.base = a.train.segbuf + slot;
     rec.stride = (int)a.train.n_items;
@@ -282,19 +294,19 @@ VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sample
 
 // DDA iterator <-> 9 dwords
 template <class Iter>
-VDEV void wf_store_iter(const WfPool &P, unsigned slot, const Iter &it) {
-    P.f(WF_IT + 0, slot) = it.tMin; P.f(WF_IT + 1, slot) = it.tMax;
-    P.f(WF_IT + 2, slot) = it.ncx; P.f(WF_IT + 3, slot) = it.ncy; P.f(WF_IT + 4, slot) = it.ncz;
-    P.f(WF_IT + 5, slot) = it.dtx; P.f(WF_IT + 6, slot) = it.dty; P.f(WF_IT + 7, slot) = it.dtz;
-    P.u(WF_IT + 8, slot) = (uint32_t)it.vx | ((uint32_t)it.vy << 7) | ((uint32_t)it.vz << 14) | ((uint32_t)it.neg << 21);
+VDEV void wf_store_iter(const WfPool &P, unsigned slot, const Iter &it, int F = WF_IT) {
+    P.f(F + 0, slot) = it.tMin; P.f(F + 1, slot) = it.tMax;
+    P.f(F + 2, slot) = it.ncx; P.f(F + 3, slot) = it.ncy; P.f(F + 4, slot) = it.ncz;
+    P.f(F + 5, slot) = it.dtx; P.f(F + 6, slot) = it.dty; P.f(F + 7, slot) = it.dtz;
+    P.u(F + 8, slot) = (uint32_t)it.vx | ((uint32_t)it.vy << 7) | ((uint32_t)it.vz << 14) | ((uint32_t)it.neg << 21);
 }
 template <class Medium>
-VDEV typename Medium::Iter wf_load_iter(const WfPool &P, unsigned slot, const Medium &medium) {
+VDEV typename Medium::Iter wf_load_iter(const WfPool &P, unsigned slot, const Medium &medium, int F = WF_IT) {
     typename Medium::Iter it = medium.empty_iter();
-    it.tMin = P.f(WF_IT + 0, slot); it.tMax = P.f(WF_IT + 1, slot);
-    it.ncx = P.f(WF_IT + 2, slot); it.ncy = P.f(WF_IT + 3, slot); it.ncz = P.f(WF_IT + 4, slot);
-    it.dtx = P.f(WF_IT + 5, slot); it.dty = P.f(WF_IT + 6, slot); it.dtz = P.f(WF_IT + 7, slot);
-    const uint32_t pk = P.u(WF_IT + 8, slot);
+    it.tMin = P.f(F + 0, slot); it.tMax = P.f(F + 1, slot);
+    it.ncx = P.f(F + 2, slot); it.ncy = P.f(F + 3, slot); it.ncz = P.f(F + 4, slot);
+    it.dtx = P.f(F + 5, slot); it.dty = P.f(F + 6, slot); it.dtz = P.f(F + 7, slot);
+    const uint32_t pk = P.u(F + 8, slot);
     it.vx = (int)(pk & 127u); it.vy = (int)((pk >> 7) & 127u); it.vz = (int)((pk >> 14) & 127u); it.neg = (int)(pk >> 21);
     return it;
 }
@@ -479,6 +491,9 @@ constexpr int kWfBlock = 256;
 constexpr int kWfWalkWavesPerSimd = VSPG_WF_WALK_WAVES;  // launch bound of the walk kernels (register budget 128)
 constexpr int kWfShadowWavesPerSimd = VSPG_WF_SHADOW_WAVES;  // the shadow walk carries less state (<= 96 registers)
 constexpr int kWfRefill = 16;
+#ifndef VSPG_WF_VERTEX_WAVES
+#define VSPG_WF_VERTEX_WAVES 3   // launch bound of the unguided vertex kernel (waves per SIMD)
+#endif
 #ifndef VSPG_WF_CLAIM
 #define VSPG_WF_CLAIM 128
 #endif
@@ -522,19 +537,138 @@ VDEV Medium wf_block_medium(const DScene &S) {
     return MediumMaker<Medium>::make(S, maj_ptr);
 }
 
-// ---- vertex end of iteration it-1 + segment begin of iteration it ---------------------------------------------------
-// GUIDED (a trained / loaded guiding field being queried): k_wf_seg_end has run the WHOLE vertex (li_vertex_guided_impl); what is
-// left of it here is adding the NEE's result, with the throughput the NEE saw (WF_BNEE), before the next segment begins.
-// TRAIN (a18, with GUIDED): the pass records path segments; here the NEE's result reaches its record (guiding_addScatteredDirectLight)
-template <class Medium, bool GUIDED = false, bool TRAIN = false>
-__global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
+// ---- the begin of a segment: li_segment_a up to the traversal ----------------------------------------------------------
+// Scene intersection, the segment's RNG, VSP fetch, the resampling routine's prologue; stores the path (with `extra` flags: what
+// the caller still has to say about the PREVIOUS vertex) and, if the traversal has anything to do, the distance-walk job.
+template <class Medium, bool GUIDED, class PC>
+VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &medium, unsigned slot, PathState &st, Sampler &sampler, int ch,
+                           IsgSample &isg, PC &pc, uint32_t extra, bool *walk) {
+    const WfPool &P = a.P;
+    constexpr int G = Medium::kGrey;
+    // ---- li_segment_a up to the traversal (:312-325, sample_distance / SampleT_maj_Resampling prologue) --
+    pc.segment();
+    const Isect si = scene_intersect(S, st.ro, st.rd, kInf);
+    const float tMax = si.hit ? si.t : kInf;
+    extra |= FL_LIVE | (si.hit ? (uint32_t)WFL_HIT : 0u);
+    P.set3(WF_VXP, slot, si.p);
+    P.i(WF_VXG, slot) = si.quad;
+    P.f(WF_VXT, slot) = si.t;
+    if (is_tri(si.quad)) P.set3(WF_VXE, slot, si.perr);
+    if (S.medium_type != VSPG_MEDIUM_NONE) {
+        Rng rng;
+        {
+            uint64_t hash0 = hash_float(sampler.get1d());
+            uint64_t hash1 = hash_float(sampler.get1d());
+            rng.set_sequence(hash0, hash1);
+        }
+        bool guide = false;
+        const float vsp = fetch_vsp<GUIDED>(S, st, &guide);
+        if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
+        const float u = sampler.get1d();
+        const float tM = tMax * len(st.rd);
+        const V3 rdn = normalize(st.rd);
+        const auto iter = medium.sample_ray(st.ro, rdn, tM);
+        // The pre-pass (media_sampleTMaj.h:153-168) serves the VSP-guided case (majorantScale, the zero-candidate
+        // compensation); otherwise all it decides is the early return for a ray whose majorants are all zero.  For
+        // a grey medium the traversal itself gives that ray the same result -- every cell multiplies T_maj by
+        // FastExp(-0) == 1, no callback runs, no sampler dimension is drawn -- so unguided segments (every segment past
+        // the camera ray when only the primary VSP guides) skip the DDA sweep and go straight to the walk.  (Chromatic
+        // media keep it: with a zero majorant in the hero channel only, the early return and the traversal differ in
+        // the other channels of T_maj.)
+        float totalLength = 0.f;
+        if (guide || !Medium::kGrey) {
+            auto pre = iter;
+            while (true) {
+                MajSeg seg;
+                if (!pre.next(&seg)) break;
+                const float smaj = ch_of(seg.sigma_maj, ch);
+                if (smaj == 0) continue;
+                totalLength += smaj * (seg.tMax - seg.tMin);
+            }
+        } else if (iter.tMin < iter.tMax) {
+            totalLength = 1.f;  // (only its being non-zero matters below)
+        }
+        if (guide) extra |= WFL_GUIDE;
+        P.f(WF_VSPG, slot) = vsp;
+        if (totalLength == 0.f) {
+            extra |= WFL_NOWALK;
+        } else {
+            float majorantScale = 1.0f, vrc = vsp;
+            if (guide) {
+                float minTotalLength = -logf_(1 - vsp);
+                if (minTotalLength > totalLength) {
+                    majorantScale = minTotalLength / totalLength;
+                    totalLength = minTotalLength;
+                }
+                float expNegTotalLength = fast_exp(-totalLength);
+                vrc = vsp / (1 - expNegTotalLength);
+            }
+            wf_store_iter(P, slot, iter);
+            P.set3(WF_RDN, slot, rdn);
+            P.store_rng(WF_WRNG, slot, rng);
+            P.f(WF_WU, slot) = u;
+            P.f(WF_MSCALE, slot) = majorantScale;
+            P.f(WF_VRC, slot) = vrc;
+            *walk = true;
+        }
+    } else {
+        extra |= WFL_NODIST;
+    }
+    wf_store_path<G>(P, slot, st, sampler, ch, isg, extra);
+}
+
+// ---- the next segment's begin as its own kernel (guided pipelines) -----------------------------------------------------------
+// The guided vertex keeps its product mixture in registers and fills the register file on its own.  Inlined behind it, the
+// segment's begin (BVH walk, DDA pre-pass) pushed the allocator into spilling inside the mixture loops (cloud-guided 11.0 -> 11.4
+// ms per wave); as a real call it cost more still (12.4: the path goes through the stack).  So guided pipelines keep the two
+// apart: k_wf_vertex parks the path, this kernel walks the same list and begins the segments.
+template <class Medium, bool GUIDED = true, bool TRAIN = false>
+__global__ __launch_bounds__(kWfBlock, 3) void k_wf_begin(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
     const WfPool &P = a.P;
     constexpr int G = Medium::kGrey;
-    const bool first = it == 0;
-    const unsigned n = first ? a.n_items : a.iters[it - 1].n_vertex;
     WfIter *I = &a.iters[it];
+    const unsigned n = I->n_active;
+    const unsigned int *list = (it & 1) ? a.list_active2 : a.list_active;
+    WfCountersT<typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type> pc;
+    pc.zero();
+    __shared__ unsigned int s_stage[kWfStageRounds * kWfBlock], s_cnt, s_gbase;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const WfStage stB{s_stage, &s_cnt};
+    int round = 0;
+    for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
+        const unsigned idx = base + threadIdx.x;
+        bool walk = false;
+        unsigned slot = 0;
+        if (idx < n) {
+            slot = list[idx];
+            const uint32_t fl0 = P.u(WF_FLAGS, slot);
+            if (!(fl0 & WFL_DEAD)) {
+                PathState st;
+                Sampler sampler;
+                IsgSample isg;
+                int ch;
+                const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
+                st.gs.vsp_next = P.f(WF_GSVSP, slot);
+                wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, fl & (uint32_t)(WFL_SHADOW_WALK | WFL_DELTA), &walk);
+            }
+        }
+        stB.push(walk, slot);
+        if ((round % kWfStageRounds) == kWfStageRounds - 1) stB.flush(a.list_walk, &I->n_walk, &s_gbase);
+    }
+    stB.flush(a.list_walk, &I->n_walk, &s_gbase);
+    wf_flush_counters(pc, a.counters);
+}
+
+// ---- camera rays + the first segment's begin -----------------------------------------------------------------------------
+template <class Medium, bool GUIDED = false, bool TRAIN = false>
+__global__ __launch_bounds__(kWfBlock, 3) void k_wf_start(WfArgs a) {
+    const DScene &S = *a.scene;
+    const Medium medium = wf_block_medium<Medium>(S);
+    const unsigned n = a.n_items;
+    WfIter *I = &a.iters[0];
     WfCountersT<typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type> pc;
     pc.zero();
     __shared__ unsigned int s_stage[2][kWfStageRounds * kWfBlock], s_cnt[2], s_gbase[2];
@@ -543,146 +677,24 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_advance(WfArgs a, int it) {
     const WfStage stA{s_stage[0], &s_cnt[0]}, stB{s_stage[1], &s_cnt[1]};
     int round = 0;
     for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
-        const unsigned idx = base + threadIdx.x;
+        const unsigned slot = base + threadIdx.x;
         bool alive = false, walk = false;
-        unsigned slot = 0;
-        if (idx < n) {
-            slot = first ? idx : a.list_vertex[idx];
-            PathState st;
-            Sampler sampler;
-            IsgSample isg;
-            int ch = 0;
-            if (first) {
-                int px, py;
-                wf_pixel_of(slot, a.tilesX, &px, &py);
-                if (px < S.xres && py < S.yres) {
-                    start_path(S, a.vsp_buf, a.vsp_ready, px, py, a.jump, sampler, st, &ch, isg);
-                    alive = true;
-                    if constexpr (TRAIN) {
-                        wf_rec_load(a, slot, pc.rec);
-                        pc.rec.reset();
-                        wf_rec_store(a, slot, pc.rec);
-                    }
+        if (slot < n) {
+            int px, py;
+            wf_pixel_of(slot, a.tilesX, &px, &py);
+            if (px < S.xres && py < S.yres) {
+                PathState st;
+                Sampler sampler;
+                IsgSample isg;
+                int ch = 0;
+                start_path(S, a.vsp_buf, a.vsp_ready, px, py, a.jump, sampler, st, &ch, isg);
+                alive = true;
+                if constexpr (TRAIN) {
+                    wf_rec_load(a, slot, pc.rec);
+                    pc.rec.reset();
+                    wf_rec_store(a, slot, pc.rec);
                 }
-            } else {
-                // ---- li_segment_b from the NEE estimate on (:483 / :836, :842-874 / :487-606) --------------------
-                const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
-                Vertex vx;
-                VertexCtx c;
-                Spec beta_nee = st.beta;
-                if constexpr (GUIDED) {
-                    beta_nee = P.sp3(WF_BNEE, slot);
-                    st.gs.vsp_next = P.f(WF_GSVSP, slot);
-                } else {
-                    vx.volume = (fl & FL_VX_VOLUME) != 0;
-                    vx.p = P.v3(WF_VXP, slot);
-                    vx.g = vx.volume ? P.f(WF_VXG, slot) : 0.f;
-                    vx.quad = vx.volume ? -1 : P.i(WF_VXG, slot);
-                    vx.t = P.f(WF_VXT, slot);
-                    vx.perr = vx.volume ? mk(0, 0, 0) : (is_tri(vx.quad) ? P.v3(WF_VXE, slot) : ld3(quad_at(vx.quad).perr));
-                    vertex_setup<false>(S, st, vx, c);
-                }
-                if (fl & WFL_NEE) {
-                    Spec Ld = sp(0.f);
-                    if (fl & (WFL_SHADOW_WALK | WFL_SHADOW_CLEAR)) {
-                        const bool walked = (fl & WFL_SHADOW_WALK) != 0;
-                        Spec T_ray = sp(1.f), r_l = sp(1.f), r_u = sp(1.f), T_maj = sp(1.f);
-                        if (walked) {
-                            T_ray = P.sp3(WF_TRAY, slot); r_l = P.sp3(WF_SRL, slot); r_u = P.sp3(WF_SRU, slot);
-                            T_maj = P.sp3(WF_STMAJ, slot);
-                        }
-                        Ld = sample_Ld_end<G>(walked, (fl & WFL_DELTA) != 0, T_ray, r_l, r_u, T_maj, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
-                                           P.f(WF_SPDF, slot), st.r_u);
-                    }
-                    st.L = st.L + beta_nee * Ld;
-                    if constexpr (TRAIN) {  // :485 / :838 (the flags word is order-independent: add_scatter_data keeps the SCAT bit)
-                        wf_rec_load(a, slot, pc.rec);
-                        pc.rec.add_scattered_direct_light(Ld);
-                        wf_rec_store(a, slot, pc.rec);
-                    }
-                }
-                if constexpr (GUIDED) alive = !(fl & WFL_DEAD);
-                else alive = vertex_tail(S, st, sampler, vx, c, P.f(WF_SURV, slot));
-                if (!alive) {
-                    wf_finish_path(a, slot, st, isg);
-                    pc.path();
-                    if constexpr (TRAIN) {
-                        if (!(fl & WFL_NEE)) wf_rec_load(a, slot, pc.rec);
-                        wf_rec_finish(a, slot, pc.rec);
-                    }
-                }
-            }
-            if (alive) {
-                // ---- li_segment_a up to the traversal (:312-325, sample_distance / SampleT_maj_Resampling prologue) --
-                pc.segment();
-                const Isect si = scene_intersect(S, st.ro, st.rd, kInf);
-                const float tMax = si.hit ? si.t : kInf;
-                uint32_t extra = FL_LIVE | (si.hit ? (uint32_t)WFL_HIT : 0u);
-                P.set3(WF_VXP, slot, si.p);
-                P.i(WF_VXG, slot) = si.quad;
-                P.f(WF_VXT, slot) = si.t;
-                if (is_tri(si.quad)) P.set3(WF_VXE, slot, si.perr);
-                if (S.medium_type != VSPG_MEDIUM_NONE) {
-                    Rng rng;
-                    {
-                        uint64_t hash0 = hash_float(sampler.get1d());
-                        uint64_t hash1 = hash_float(sampler.get1d());
-                        rng.set_sequence(hash0, hash1);
-                    }
-                    bool guide = false;
-                    const float vsp = fetch_vsp<GUIDED>(S, st, &guide);
-                    if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
-                    const float u = sampler.get1d();
-                    const float tM = tMax * len(st.rd);
-                    const V3 rdn = normalize(st.rd);
-                    const auto iter = medium.sample_ray(st.ro, rdn, tM);
-                    // The pre-pass (media_sampleTMaj.h:153-168) serves the VSP-guided case (majorantScale, the zero-candidate
-                    // compensation); otherwise all it decides is the early return for a ray whose majorants are all zero.  For
-                    // a grey medium the traversal itself gives that ray the same result -- every cell multiplies T_maj by
-                    // FastExp(-0) == 1, no callback runs, no sampler dimension is drawn -- so unguided segments (every segment past
-                    // the camera ray when only the primary VSP guides) skip the DDA sweep and go straight to the walk.  (Chromatic
-                    // media keep it: with a zero majorant in the hero channel only, the early return and the traversal differ in
-                    // the other channels of T_maj.)
-                    float totalLength = 0.f;
-                    if (guide || !Medium::kGrey) {
-                        auto pre = iter;
-                        while (true) {
-                            MajSeg seg;
-                            if (!pre.next(&seg)) break;
-                            const float smaj = ch_of(seg.sigma_maj, ch);
-                            if (smaj == 0) continue;
-                            totalLength += smaj * (seg.tMax - seg.tMin);
-                        }
-                    } else if (iter.tMin < iter.tMax) {
-                        totalLength = 1.f;  // (only its being non-zero matters below)
-                    }
-                    if (guide) extra |= WFL_GUIDE;
-                    P.f(WF_VSPG, slot) = vsp;
-                    if (totalLength == 0.f) {
-                        extra |= WFL_NOWALK;
-                    } else {
-                        float majorantScale = 1.0f, vrc = vsp;
-                        if (guide) {
-                            float minTotalLength = -logf_(1 - vsp);
-                            if (minTotalLength > totalLength) {
-                                majorantScale = minTotalLength / totalLength;
-                                totalLength = minTotalLength;
-                            }
-                            float expNegTotalLength = fast_exp(-totalLength);
-                            vrc = vsp / (1 - expNegTotalLength);
-                        }
-                        wf_store_iter(P, slot, iter);
-                        P.set3(WF_RDN, slot, rdn);
-                        P.store_rng(WF_WRNG, slot, rng);
-                        P.f(WF_WU, slot) = u;
-                        P.f(WF_MSCALE, slot) = majorantScale;
-                        P.f(WF_VRC, slot) = vrc;
-                        walk = true;
-                    }
-                } else {
-                    extra |= WFL_NODIST;
-                }
-                wf_store_path<G>(P, slot, st, sampler, ch, isg, extra);
+                wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
             }
         }
         stA.push(alive, slot);
@@ -893,173 +905,190 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     wf_flush_counters(pc, a.counters);
 }
 
-// ---- candidate selection, surface emission, depth test, vertex setup, NEE light sample + shadow-ray set-up -------------
+// ---- the vertex kernel: [deferred NEE result] + segment end + vertex + the next segment's begin ----------------------------
 // GUIDED: the vertex code is li_vertex_guided_impl -- cache init, NEE set-up with the guided PDF, Russian roulette, MIS / RIS
 // direction sampling, the next segment's VSP -- with the product mixture in registers (GStoreReg; ~240 VGPRs: 2 waves per SIMD)
+// TRAIN (a18, with GUIDED): the pass records path segments (the NEE's result reaches its record when it is added to L)
 template <class Medium, bool GUIDED = false, bool TRAIN = false>
-__global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs a, int it) {
+__global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k_wf_vertex(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
     const WfPool &P = a.P;
     constexpr int G = Medium::kGrey;
-    WfIter *I = &a.iters[it];
+    WfIter *I = &a.iters[it], *In = &a.iters[it + 1];
     const unsigned n = I->n_active;
+    const unsigned int *list_in = (it & 1) ? a.list_active2 : a.list_active;
+    unsigned int *list_out = (it & 1) ? a.list_active : a.list_active2;
     WfCountersT<typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type> pc;
     pc.zero();
-    __shared__ unsigned int s_stage[2][kWfStageRounds * kWfBlock], s_cnt[2], s_gbase[2];
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __shared__ unsigned int s_stage[3][kWfStageRounds * kWfBlock], s_cnt[3], s_gbase[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const WfStage stA{s_stage[0], &s_cnt[0]}, stB{s_stage[1], &s_cnt[1]};
+    const WfStage stA{s_stage[0], &s_cnt[0]}, stB{s_stage[1], &s_cnt[1]}, stC{s_stage[2], &s_cnt[2]};
     int round = 0;
     for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
         const unsigned idx = base + threadIdx.x;
-        bool alive = false, shadow = false;
+        bool next = false, walk = false, shadow = false;  // next: the slot goes onto the next iteration's list
         unsigned slot = 0;
         if (idx < n) {
-            slot = a.list_active[idx];
+            slot = list_in[idx];
             PathState st;
             Sampler sampler;
             IsgSample isg;
             int ch;
             const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
             if constexpr (TRAIN) wf_rec_load(a, slot, pc.rec);
-            int px, py;
-            wf_pixel_of(slot, a.tilesX, &px, &py);
-            Isect si;
-            si.hit = (fl & WFL_HIT) != 0;
-            si.quad = P.i(WF_VXG, slot);
-            si.t = P.f(WF_VXT, slot);
-            si.p = P.v3(WF_VXP, slot);
-            if (is_tri(si.quad)) {
-                const DTri &T = S.tris[tri_of(si.quad)];
-                si.n = V3{T.nx, T.ny, T.nz};
-                si.perr = P.v3(WF_VXE, slot);
-            } else {
-                const DQuad &q = quad_at(si.quad);
-                si.n = ld3(q.n);
-                si.perr = ld3(q.perr);
+            bool alive = false;
+            // ---- the previous vertex's NEE, if its shadow walk was out (:483 / :836 from the estimate on) ----------------
+            if (fl & WFL_SHADOW_WALK) {
+                const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, P.sp3(WF_TRAY, slot), P.sp3(WF_SRL, slot), P.sp3(WF_SRU, slot),
+                                                 P.sp3(WF_STMAJ, slot), ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
+                                                 P.f(WF_SPDF, slot), st.r_u);  // (the vertex code after the NEE leaves r_u alone)
+                st.L = st.L + P.sp3(WF_BNEE, slot) * Ld;
+                if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);  // :485 / :838 (add_scatter_data keeps the SCAT bit)
             }
             Vertex vx;
-            vx.volume = false;
-            vx.p = si.p;
-            vx.g = 0;
-            vx.quad = si.quad;
-            vx.t = si.t;
-            vx.perr = si.perr;
             int kind = EV_PASS;
-            if (!(fl & WFL_NODIST)) {
-                // ---- sample_distance after the traversal (:721-802) ---------------------------------------------
-                const bool guide = (fl & WFL_GUIDE) != 0;
-                const float vsp = P.f(WF_VSPG, slot);
-                float weightSum = 0, sel_wi = 0, vrc = 0;
-                Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f), sel_num = sp(0.f), sel_den = sp(0.f), T_maj = sp(1.f);
-                V3 sel_p = mk(0, 0, 0);
-                if (!(fl & WFL_NOWALK)) {
-                    T_maj = P.sp3(WF_TMAJ, slot);
-                    weightSum = P.f(WF_WSUM, slot);
-                    trRatioEst = P.sp3(WF_TRR, slot);
-                    beta_rs = P.sp3(WF_BRS, slot);
-                    r_u_rs = P.sp3(WF_RURS, slot);
-                    sel_p = P.v3(WF_SELP, slot);
-                    sel_wi = P.f(WF_SELW, slot);
-                    sel_num = P.sp3(WF_SELNUM, slot);
-                    sel_den = P.sp3(WF_SELDEN, slot);
-                    vrc = P.f(WF_VRC, slot);
-                    P.load_rng(WF_RNG, slot, sampler.rng);  // the traversal drew one sampler dimension per candidate (:702)
-                }
-                float sel_sTTr = sel_wi;
-                beta_rs = mul_tmaj_ratio<G>(beta_rs, T_maj, ch);
-                r_u_rs = mul_tmaj_ratio<G>(r_u_rs, T_maj, ch);
-                if (st.depth == 0 && S.tr_calc) {  // trBuffer->AddSample (:727-728, trbuffer.h:40-45); one sample per pixel per pass, passes in order
-                    const size_t pix = (size_t)py * S.xres + px;
-                    const int ns = S.tr_spp[pix] + 1;
-                    S.tr_spp[pix] = ns;
-                    const float alpha = 1.f / (float)ns;
-                    float *tb = S.tr_rgb + pix * 3;
-                    tb[0] = (1.f - alpha) * tb[0] + alpha * trRatioEst.r;
-                    tb[1] = (1.f - alpha) * tb[1] + alpha * trRatioEst.g;
-                    tb[2] = (1.f - alpha) * tb[2] + alpha * trRatioEst.b;
-                }
-                const float trScalar = ch_of(trRatioEst, ch);
-                float surf_wi = trScalar;
-                if (guide && trScalar < 1 && trScalar > 0 && weightSum > 0) {
-                    float volRatio = vrc * S.prm.vspmisratio + (1 - trScalar) * (1 - S.prm.vspmisratio);
-                    float surfRatio = 1 - volRatio;
-                    surf_wi = surfRatio / volRatio * weightSum;
-                }
-                weightSum += surf_wi;
-                if (weightSum != 0) {
-                    bool selectSurface = false;
-                    if (sampler.get1d() < surf_wi / weightSum) {
-                        sel_wi = surf_wi;
-                        sel_sTTr = trScalar;
-                        sel_num = beta_rs;
-                        sel_den = r_u_rs;
-                        selectSurface = true;
-                    }
-                    const float factor = weightSum * sel_sTTr / sel_wi;
-                    bool term = false;
-                    if (!selectSurface) {
-                        if (st.depth == 0) {
-                            isg.valid = true;
-                            isg.surface_event = false;
-                        }
-                        if (st.depth++ >= S.prm.maxdepth) term = true;
-                        else pc.volume_scatter();
-                    }
-                    if (!term) {
-                        st.beta = st.beta * (sel_num * factor);
-                        st.r_u = st.r_u * sel_den;
-                        if (has_nan(st.beta) || has_nan(st.r_u) || has_inf(st.beta) || has_inf(st.r_u)) term = true;
-                    }
-                    if (term) kind = EV_TERMINATE;
-                    else if (!selectSurface) {
-                        if constexpr (TRAIN) {  // :798-802 (transmittanceWeight starts every path-loop iteration at 1, :317)
-                            const Spec tw = sp(1.f) * ((sel_num * factor) / sel_den);
-                            pc.rec.add_transmittance_weight(tw);
-                            pc.rec.new_segment(sel_p, true);
-                        }
-                        kind = EV_SCATTER;
-                        vx.volume = true;
-                        vx.p = sel_p;
-                        vx.g = medium.g;
-                    }
-                }
-            }
-            if (kind == EV_TERMINATE || (!(fl & WFL_NODIST) && (!nonzero(st.beta) || !nonzero(st.r_u)))) {  // :343-344
-                alive = false;
-            } else if (kind == EV_SCATTER) {
-                alive = true;
+            if (fl & WFL_DEAD) {
+                // the path ended at the previous vertex; that addition was all it waited for
             } else {
-                alive = li_surface_pre(S, st, isg, pc, si, sp(1.f));
+                int px, py;
+                wf_pixel_of(slot, a.tilesX, &px, &py);
+                Isect si;
+                si.hit = (fl & WFL_HIT) != 0;
+                si.quad = P.i(WF_VXG, slot);
+                si.t = P.f(WF_VXT, slot);
+                si.p = P.v3(WF_VXP, slot);
+                if (is_tri(si.quad)) {
+                    const DTri &T = S.tris[tri_of(si.quad)];
+                    si.n = V3{T.nx, T.ny, T.nz};
+                    si.perr = P.v3(WF_VXE, slot);
+                } else {
+                    const DQuad &q = quad_at(si.quad);
+                    si.n = ld3(q.n);
+                    si.perr = ld3(q.perr);
+                }
+                vx.volume = false;
+                vx.p = si.p;
+                vx.g = 0;
+                vx.quad = si.quad;
+                vx.t = si.t;
+                vx.perr = si.perr;
+                if (!(fl & WFL_NODIST)) {
+                    // ---- sample_distance after the traversal (:721-802) ---------------------------------------------
+                    const bool guide = (fl & WFL_GUIDE) != 0;
+                    const float vsp = P.f(WF_VSPG, slot);
+                    float weightSum = 0, sel_wi = 0, vrc = 0;
+                    Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f), sel_num = sp(0.f), sel_den = sp(0.f), T_maj = sp(1.f);
+                    V3 sel_p = mk(0, 0, 0);
+                    if (!(fl & WFL_NOWALK)) {
+                        T_maj = P.sp3(WF_TMAJ, slot);
+                        weightSum = P.f(WF_WSUM, slot);
+                        trRatioEst = P.sp3(WF_TRR, slot);
+                        beta_rs = P.sp3(WF_BRS, slot);
+                        r_u_rs = P.sp3(WF_RURS, slot);
+                        sel_p = P.v3(WF_SELP, slot);
+                        sel_wi = P.f(WF_SELW, slot);
+                        sel_num = P.sp3(WF_SELNUM, slot);
+                        sel_den = P.sp3(WF_SELDEN, slot);
+                        vrc = P.f(WF_VRC, slot);
+                        P.load_rng(WF_RNG, slot, sampler.rng);  // the traversal drew one sampler dimension per candidate (:702)
+                    }
+                    float sel_sTTr = sel_wi;
+                    beta_rs = mul_tmaj_ratio<G>(beta_rs, T_maj, ch);
+                    r_u_rs = mul_tmaj_ratio<G>(r_u_rs, T_maj, ch);
+                    if (st.depth == 0 && S.tr_calc) {  // trBuffer->AddSample (:727-728, trbuffer.h:40-45); one sample per pixel per pass, passes in order
+                        const size_t pix = (size_t)py * S.xres + px;
+                        const int ns = S.tr_spp[pix] + 1;
+                        S.tr_spp[pix] = ns;
+                        const float alpha = 1.f / (float)ns;
+                        float *tb = S.tr_rgb + pix * 3;
+                        tb[0] = (1.f - alpha) * tb[0] + alpha * trRatioEst.r;
+                        tb[1] = (1.f - alpha) * tb[1] + alpha * trRatioEst.g;
+                        tb[2] = (1.f - alpha) * tb[2] + alpha * trRatioEst.b;
+                    }
+                    const float trScalar = ch_of(trRatioEst, ch);
+                    float surf_wi = trScalar;
+                    if (guide && trScalar < 1 && trScalar > 0 && weightSum > 0) {
+                        float volRatio = vrc * S.prm.vspmisratio + (1 - trScalar) * (1 - S.prm.vspmisratio);
+                        float surfRatio = 1 - volRatio;
+                        surf_wi = surfRatio / volRatio * weightSum;
+                    }
+                    weightSum += surf_wi;
+                    if (weightSum != 0) {
+                        bool selectSurface = false;
+                        if (sampler.get1d() < surf_wi / weightSum) {
+                            sel_wi = surf_wi;
+                            sel_sTTr = trScalar;
+                            sel_num = beta_rs;
+                            sel_den = r_u_rs;
+                            selectSurface = true;
+                        }
+                        const float factor = weightSum * sel_sTTr / sel_wi;
+                        bool term = false;
+                        if (!selectSurface) {
+                            if (st.depth == 0) {
+                                isg.valid = true;
+                                isg.surface_event = false;
+                            }
+                            if (st.depth++ >= S.prm.maxdepth) term = true;
+                            else pc.volume_scatter();
+                        }
+                        if (!term) {
+                            st.beta = st.beta * (sel_num * factor);
+                            st.r_u = st.r_u * sel_den;
+                            if (has_nan(st.beta) || has_nan(st.r_u) || has_inf(st.beta) || has_inf(st.r_u)) term = true;
+                        }
+                        if (term) kind = EV_TERMINATE;
+                        else if (!selectSurface) {
+                            if constexpr (TRAIN) {  // :798-802 (transmittanceWeight starts every path-loop iteration at 1, :317)
+                                const Spec tw = sp(1.f) * ((sel_num * factor) / sel_den);
+                                pc.rec.add_transmittance_weight(tw);
+                                pc.rec.new_segment(sel_p, true);
+                            }
+                            kind = EV_SCATTER;
+                            vx.volume = true;
+                            vx.p = sel_p;
+                            vx.g = medium.g;
+                        }
+                    }
+                }
+                if (kind == EV_TERMINATE || (!(fl & WFL_NODIST) && (!nonzero(st.beta) || !nonzero(st.r_u)))) {  // :343-344
+                    alive = false;
+                } else if (kind == EV_SCATTER) {
+                    alive = true;
+                } else {
+                    alive = li_surface_pre(S, st, isg, pc, si, sp(1.f));
+                }
             }
             if (!alive) {
                 wf_finish_path(a, slot, st, isg);
                 pc.path();
                 wf_rec_finish(a, slot, pc.rec);
             } else {
-                // ---- li_segment_b up to the shadow ray's transmittance estimate -----------------------------------
-                P.set3(WF_VXP, slot, vx.p);
-                if (vx.volume) P.f(WF_VXG, slot) = vx.g; else P.i(WF_VXG, slot) = vx.quad;
+                // ---- li_segment_b: the vertex --------------------------------------------------------------------------------
                 VertexCtx c;
                 vertex_setup<false>(S, st, vx, c);
                 float survivalProb = 1.f;
-                uint32_t extra = FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u);
+                uint32_t extra = 0u;
                 ShadowSetup ss;
                 ss.status = 0;
-                bool nee = false;
+                bool nee = false, cont = true;
+                Spec beta_nee = st.beta;
                 if constexpr (GUIDED) {
-                    Spec beta_nee = st.beta;
-                    const bool cont = li_vertex_guided_impl<Medium, true, true>(
+                    {   // guided RR (:274-285): the pixel's contribution estimate, once the image-space buffer is ready
+                        int qx, qy;
+                        wf_pixel_of(slot, a.tilesX, &qx, &qy);
+                        st.guideRR = S.prm.rrguiding && S.contrib_ready;
+                        st.pce = st.guideRR ? S.contrib[(size_t)qy * S.xres + qx] : 0.f;
+                    }
+                    cont = li_vertex_guided_impl<Medium, true, true>(
                         S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, nullptr, 0, [&](const auto &gd, bool use_gd) {
                             nee = true;
                             beta_nee = st.beta;
                             ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc, &gd, use_gd);
                             return sp(0.f);
                         });
-                    P.sets(WF_BNEE, slot, beta_nee);
-                    P.f(WF_GSVSP, slot) = st.gs.vsp_next;
-                    if (!cont) extra |= WFL_DEAD;
                 } else {
                     survivalProb = vertex_pre(S, st, sampler, vx);
                     if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833
@@ -1068,47 +1097,71 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : 3) void k_wf_seg_end(WfArgs 
                     }
                 }
                 if (nee) {
-                    extra |= WFL_NEE;
-                    if (ss.status != 0) {
-                        if (ss.delta_light) extra |= WFL_DELTA;
-                        P.sets(WF_FHAT, slot, ss.f_hat);
-                        P.sets(WF_LSL, slot, ss.L);
-                        P.f(WF_PL, slot) = ss.p_l;
-                        P.f(WF_SPDF, slot) = ss.scatterPDF;
-                    }
                     if (ss.status == 1) {
                         const float tM = (1 - kShadowEps) * len(ss.ld);
                         const V3 rdn = normalize(ss.ld);
                         const auto iter = medium.sample_ray(ss.lo, rdn, tM);
                         if (iter.tMin >= iter.tMax) {
-                            extra |= WFL_SHADOW_CLEAR;  // the ray misses the medium's bounds: the walk would return T_maj = 1 at once
+                            ss.status = 2;  // the ray misses the medium's bounds: the walk would return T_maj = 1 at once
                         } else {
-                            wf_store_iter(P, slot, iter);
-                            P.set3(WF_RDN, slot, rdn);
+                            wf_store_iter(P, slot, iter, WF_SIT);
+                            P.set3(WF_SRDN, slot, rdn);
                             P.set3(WF_SLO, slot, ss.lo);
-                            P.store_rng(WF_WRNG, slot, ss.rng);
-                            P.f(WF_WU, slot) = ss.us;
-                            extra |= WFL_SHADOW_WALK;
+                            P.store_rng(WF_SWRNG, slot, ss.rng);
+                            P.f(WF_SWU, slot) = ss.us;
+                            P.sets(WF_FHAT, slot, ss.f_hat);
+                            P.sets(WF_LSL, slot, ss.L);
+                            P.f(WF_PL, slot) = ss.p_l;
+                            P.f(WF_SPDF, slot) = ss.scatterPDF;
+                            P.sets(WF_BNEE, slot, beta_nee);
+                            extra |= WFL_SHADOW_WALK | (ss.delta_light ? (uint32_t)WFL_DELTA : 0u);
                             shadow = true;
                         }
-                    } else if (ss.status == 2) {
-                        extra |= WFL_SHADOW_CLEAR;
+                    }
+                    if (!shadow) {  // no walk to wait for: the estimate's tail (:1233-1251) and the addition (:483 / :836) here
+                        Spec Ld = sp(0.f);
+                        if (ss.status == 2)
+                            Ld = sample_Ld_end<G>(false, ss.delta_light, sp(1.f), sp(1.f), sp(1.f), sp(1.f), ch, ss.f_hat, ss.L, ss.p_l, ss.scatterPDF, st.r_u);
+                        st.L = st.L + beta_nee * Ld;
+                        if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);
                     }
                 }
-                P.f(WF_SURV, slot) = survivalProb;
-                wf_rec_store(a, slot, pc.rec);
-                wf_store_path<G>(P, slot, st, sampler, ch, isg, extra);
+                // ---- Russian roulette + new direction (:842-874 / :487-606); the guided vertex has done both ------------------
+                if constexpr (!GUIDED) cont = vertex_tail(S, st, sampler, vx, c, survivalProb);
+                if (!cont) {
+                    if (shadow) {  // its shadow walk is out: the slot stays listed for that one addition
+                        wf_rec_store(a, slot, pc.rec);
+                        wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE | WFL_DEAD);
+                        next = true;
+                    } else {
+                        wf_finish_path(a, slot, st, isg);
+                        pc.path();
+                        wf_rec_finish(a, slot, pc.rec);
+                    }
+                } else {
+                    wf_rec_store(a, slot, pc.rec);
+                    if constexpr (GUIDED) {  // k_wf_begin takes it from here
+                        P.f(WF_GSVSP, slot) = st.gs.vsp_next;
+                        wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE);
+                    } else {
+                        wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, extra, &walk);
+                    }
+                    next = true;
+                }
             }
         }
-        stA.push(alive, slot);
-        stB.push(shadow, slot);
+        stA.push(next, slot);
+        stB.push(walk, slot);
+        stC.push(shadow, slot);
         if ((round % kWfStageRounds) == kWfStageRounds - 1) {
-            stA.flush(a.list_vertex, &I->n_vertex, &s_gbase[0]);
-            stB.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
+            stA.flush(list_out, &In->n_active, &s_gbase[0]);
+            stB.flush(a.list_walk, &In->n_walk, &s_gbase[1]);
+            stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[2]);
         }
     }
-    stA.flush(a.list_vertex, &I->n_vertex, &s_gbase[0]);
-    stB.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
+    stA.flush(list_out, &In->n_active, &s_gbase[0]);
+    stB.flush(a.list_walk, &In->n_walk, &s_gbase[1]);
+    stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[2]);
     wf_flush_counters(pc, a.counters);
 }
 
@@ -1142,13 +1195,13 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
             unsigned ns = 0;
             if (wf_claim(claim, !active, a.list_shadow, n, &I->shadow_head, &ns)) {
                 slot = ns;
-                w.iter = wf_load_iter(P, slot, medium);
+                w.iter = wf_load_iter(P, slot, medium, WF_SIT);
                 w.in_seg = false;
                 w.T_maj = sp(1.f);
-                w.u = P.f(WF_WU, slot);
-                P.load_rng(WF_WRNG, slot, w.rng);
+                w.u = P.f(WF_SWU, slot);
+                P.load_rng(WF_SWRNG, slot, w.rng);
                 ro = P.v3(WF_SLO, slot);
-                rdn = P.v3(WF_RDN, slot);
+                rdn = P.v3(WF_SRDN, slot);
                 ch = (int)((P.u(WF_FLAGS, slot) >> FL_CH_SHIFT) & 3u);
                 T_ray = r_l = r_u = sp(1.f);
                 active = true;
