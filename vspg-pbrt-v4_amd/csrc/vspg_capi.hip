@@ -2360,9 +2360,13 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     }
     // persistent grids: the dense kernels stride over their list, the walk kernels pull jobs
     const unsigned max_blocks = (unsigned)((items + kWfBlock - 1) / kWfBlock);
-    unsigned dense = (unsigned)r->num_cus * 8u, walk = (unsigned)r->num_cus * (unsigned)kWfWalkWavesPerSimd;
+    // (the two walk kernels of neighbouring iterations run side by side: VSPG_WF_WALK_BLOCKS / VSPG_WF_SHADOW_BLOCKS = resident
+    // workgroups per CU of each, within their launch bounds)
+    static const int walk_blocks = [] { const char *e = getenv("VSPG_WF_WALK_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= kWfWalkWavesPerSimd ? v : kWfWalkWavesPerSimd; }();
+    static const int shadow_blocks = [] { const char *e = getenv("VSPG_WF_SHADOW_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= kWfShadowWavesPerSimd ? v : kWfShadowWavesPerSimd; }();
+    unsigned dense = (unsigned)r->num_cus * 8u, walk = (unsigned)r->num_cus * (unsigned)walk_blocks;
     if (dense > max_blocks) dense = max_blocks;
-    unsigned swalk = (unsigned)r->num_cus * (unsigned)kWfShadowWavesPerSimd;
+    unsigned swalk = (unsigned)r->num_cus * (unsigned)shadow_blocks;
     if (walk > max_blocks) walk = max_blocks;
     if (swalk > max_blocks) swalk = max_blocks;
     // The shadow walk of iteration i runs beside the distance walk of iteration i + 1, on the renderer's second stream; the
