@@ -1719,6 +1719,39 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c.close()
 
 
+@pytest.mark.parametrize("guided", [False, True])
+def test_wavefront_pipeline_concurrent_walks_equal_single_stream_order(gpu_pkg, guided):
+    """The shadow walk of iteration i runs on a second stream beside the distance walk of iteration i + 1 (own job fields, its
+    result added by the next vertex kernel).  The same pass with every kernel on ONE stream (VSPG_WF_SERIAL=1) must give the
+    same film and counters bit for bit -- at 1080p, where the two kernels really overlap -- twice in a row (a race between the
+    two would not repeat)."""
+    P = gpu_pkg
+    W, H = 1920, 1080
+    scene = P.cloud_box_scene(W, H, 64)
+    prm = P.default_params() if guided else P.app_f_params()
+    field = None
+    if guided:
+        import scenes
+        field = scenes.light_field(P, n=4)
+    results = []
+    for serial in ("0", "1", "0"):
+        os.environ["VSPG_WF_SERIAL"] = serial
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=4)
+            if field is not None:
+                r.set_guiding_field(field, field)
+            assert r.kernel_name().startswith("k_wf_")
+            for w in range(2):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            results.append((r.film(), r.counters()))
+            r.close()
+        finally:
+            os.environ.pop("VSPG_WF_SERIAL", None)
+    for f, c in results[1:]:
+        assert c == results[0][1]
+        assert np.array_equal(f.view(np.uint32), results[0][0].view(np.uint32))
+
+
 @pytest.mark.parametrize("kind", ["grid", "nvdb"])
 def test_guided_wavefront_pipeline_equals_per_lane_kernel(gpu_pkg, kind):
     """The reference-default guided configuration over a heterogeneous medium with a field in place (config 5's query side):

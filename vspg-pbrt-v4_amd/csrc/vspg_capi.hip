@@ -2321,7 +2321,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
         if (r->wf_lists) (void)hipFree(r->wf_lists);
         if (r->wf_iters) (void)hipFree(r->wf_iters);
         r->wf_pool = nullptr; r->wf_lists = nullptr; r->wf_iters = nullptr;
-        HIPCHK(hipMalloc(&r->wf_pool, (size_t)WF_COUNT * items * sizeof(float)));
+        HIPCHK(hipMalloc(&r->wf_pool, (size_t)kWfPoolFloats * items * sizeof(float)));
         HIPCHK(hipMalloc(&r->wf_lists, 4 * items * sizeof(unsigned int)));
         HIPCHK(hipMalloc(&r->wf_iters, (size_t)n_iters * sizeof(WfIter)));
         r->wf_items = items;
@@ -2372,7 +2372,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     // The shadow walk of iteration i runs beside the distance walk of iteration i + 1, on the renderer's second stream; the
     // vertex kernel of iteration i + 1 waits for both (it adds the shadow walk's result first thing).  VSPG_WF_SERIAL=1 keeps
     // everything on the caller's stream (same results; for A/B runs and debugging).
-    static const bool serial = [] { const char *e = getenv("VSPG_WF_SERIAL"); return e && *e && *e != '0'; }();
+    const bool serial = [] { const char *e = getenv("VSPG_WF_SERIAL"); return e && *e && *e != '0'; }();  // (read per pass: a test flips it)
     if (!serial && !r->wf_stream2) {
         HIPCHK(hipStreamCreateWithFlags(&r->wf_stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_vertex, hipEventDisableTiming));
@@ -2968,7 +2968,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             for (int k = 0; k < 6; ++k)
                 if (checksum(bufs[k], sizes[k]) != before[k]) fprintf(stderr, "VSPG_WF_DEBUG: the pipeline changed %s (%zu bytes at %p)\n", names[k], sizes[k], bufs[k]);
             fprintf(stderr, "VSPG_WF_DEBUG: pool %p..%p lists %p film %p isg %p tris %p bvh %p\n", (void *)r->wf_pool,
-                    (void *)((char *)r->wf_pool + (size_t)WF_COUNT * r->wf_items * 4), (void *)r->wf_lists, (void *)r->film, (void *)r->isg_stats, (void *)r->tris, (void *)r->bvh);
+                    (void *)((char *)r->wf_pool + (size_t)kWfPoolFloats * r->wf_items * 4), (void *)r->wf_lists, (void *)r->film, (void *)r->isg_stats, (void *)r->tris, (void *)r->bvh);
         }
 #endif
         return 0;

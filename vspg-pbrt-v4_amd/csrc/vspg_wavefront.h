@@ -40,10 +40,17 @@
 
 namespace vspg {
 
-// ---- path record: groups of four floats, group-major ("AoSoA-4"): field f of slot s at base[((f >> 2) * n + s) * 4 + (f & 3)] --
-// A 3-vector / spectrum / RNG state sits inside ONE 16-byte group, so a lane moves it with one dwordx3 / dwordx4 access and a
-// wavefront over consecutive slots touches whole cache lines (as 4-byte-per-lane SoA the dense kernels sat at ~3 TB/s on
-// ~110 memory instructions per path).
+// ---- path record: groups of kWfGroup floats, group-major: field f of slot s at base[((f / kWfGroup) * n + s) * kWfGroup + f % kWfGroup] --
+// A 3-vector / spectrum / RNG state sits inside ONE 16-byte quad, so a lane moves it with one dwordx3 / dwordx4 access.  With
+// groups of one quad a wavefront over consecutive slots touches whole cache lines; wider groups keep a lane's quads of a group in
+// one line however thin the lists get, but coalesce consecutive slots worse.  Measured (same box, ms per wave, groups of
+// 4 / 8 / 16 / 32 floats): cloud 9.9 / 10.1 / 11.0 / 11.4; NanoVDB semantics 14.4 / 14.5 / 15.1 / 15.4; guided cloud 11.65 / 11.1 /
+// 11.1 / 11.4.  Quads stay (a width chosen at run time per pipeline costs far more in address arithmetic than it returns:
+// 12.6 / 16.6 ms -- the field offsets must fold at compile time).
+#ifndef VSPG_WF_GROUP
+#define VSPG_WF_GROUP 4
+#endif
+constexpr int kWfGroup = VSPG_WF_GROUP;
 enum {
     WF_RO = 0,        // 3  ray origin            | +3: WF_VSP
     WF_VSP = 3,       // 1  isg.vsp_used
@@ -105,6 +112,7 @@ enum {
     WF_SWRNG = 144,   // 4  the shadow ray's private PCG (:1193)
     WF_COUNT = 148
 };
+constexpr int kWfPoolFloats = (WF_COUNT + kWfGroup - 1) / kWfGroup * kWfGroup;  // floats per path in the pool (whole groups)
 enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_NODIST = 1 << 20,    // no SampleDistance this segment (no medium / the ray escapes)
     WFL_NOWALK = 1 << 21,    // the resampling routine returned before its traversal (tau == 0)
@@ -122,7 +130,7 @@ struct WfPool {
 #ifdef VSPG_WF_DEBUG
         if (slot >= n) { atomicOr(&g_dbg_err[0], 1u); atomicMax(&g_dbg_err[1], slot); slot = 0; }
 #endif
-        return ((size_t)(field >> 2) * n + slot) * 4u + (size_t)(field & 3);
+        return ((size_t)(field / kWfGroup) * n + slot) * (size_t)kWfGroup + (size_t)(field % kWfGroup);
     }
     VDEV float &f(int field, unsigned slot) const { return base[at(field, slot)]; }
     VDEV int &i(int field, unsigned slot) const { return reinterpret_cast<int *>(base)[at(field, slot)]; }

@@ -51,10 +51,9 @@ struct PoolLayout {
     // gbsdf.init queries the cache at ray.o + tHit * ray.d (guiding.h:85), so the origin must survive.
     static constexpr int VXP = GUIDED ? GS + 1 : RO;              // 3
     // (appended LAST: every other field sits at the same offset with and without it, so the helpers below need not know)
-    // training launches (a18): the recorder's state between phases -- record count, current record, its flags word, its
-    // accumulated scattered direct light (PathRecorder, vspg_train.h); the records themselves go straight to HBM
-    static constexpr int REC = GUIDED ? VXP + 3 : GS;             // 6
-    static constexpr int COUNT = REC + (TRAIN ? 6 : 0);
+    // training launches (a18): the recorder's state between phases, packed (pool_store_rec); the records themselves go straight to HBM
+    static constexpr int REC = GUIDED ? VXP + 3 : GS;             // 1 (pool_store_rec)
+    static constexpr int COUNT = REC + (TRAIN ? 1 : 0);
 };
 enum {
     FL_DEPTH_MASK = 0xff,
@@ -83,23 +82,20 @@ struct Pool {
     VDEV void sets(int field, int slot, Spec v) const { f(field, slot) = v.r; f(field + 1, slot) = v.g; f(field + 2, slot) = v.b; }
 };
 
+// The recorder's state between phases in ONE dword: records written (<= 64), whether a current record exists (it is always the
+// last one: new_segment sets cur = n++, and NextSegment() == nullptr leaves none), its six flag bits.  The accumulated scattered
+// direct light is not parked: a record sees at most one NEE, inside one vertex phase, and new_segment zeroes the sum.
 template <class LY>
 VDEV void pool_store_rec(const Pool &P, int slot, const PathRecorder &rec) {
-    P.i(LY::REC + 0, slot) = rec.n;
-    P.i(LY::REC + 1, slot) = rec.cur;
-    P.u(LY::REC + 2, slot) = rec.cur_flags;
-    P.f(LY::REC + 3, slot) = rec.scat_r;
-    P.f(LY::REC + 4, slot) = rec.scat_g;
-    P.f(LY::REC + 5, slot) = rec.scat_b;
+    P.u(LY::REC, slot) = (uint32_t)rec.n | (rec.cur >= 0 ? 128u : 0u) | (rec.cur_flags << 8);
 }
 template <class LY>
 VDEV void pool_load_rec(const Pool &P, int slot, PathRecorder &rec) {
-    rec.n = P.i(LY::REC + 0, slot);
-    rec.cur = P.i(LY::REC + 1, slot);
-    rec.cur_flags = P.u(LY::REC + 2, slot);
-    rec.scat_r = P.f(LY::REC + 3, slot);
-    rec.scat_g = P.f(LY::REC + 4, slot);
-    rec.scat_b = P.f(LY::REC + 5, slot);
+    const uint32_t w = P.u(LY::REC, slot);
+    rec.n = (int)(w & 127u);
+    rec.cur = (w & 128u) ? rec.n - 1 : -1;
+    rec.cur_flags = w >> 8;
+    rec.scat_r = rec.scat_g = rec.scat_b = 0.f;
 }
 VDEV void pool_store_rec(const Pool &, int, const NullRecorder &) {}
 VDEV void pool_load_rec(const Pool &, int, NullRecorder &) {}
