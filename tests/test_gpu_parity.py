@@ -399,6 +399,58 @@ def test_workgroup_schedulers_are_bit_identical(gpu_pkg, W, H):
         assert out[0][2] == out[1][2] and out[0][2]["paths"] == 7 * W * H, (env, out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("guided", [False, True])
+def test_parked_samples_reach_the_film_whoever_asks_first(gpu_pkg, guided):
+    """A one-sample launch of k_render_wave_wg2 parks its samples; the NEXT such launch resolves them as it starts each pixel, and
+    whatever else touches the film or the image-space statistics first -- a film read, the buffer update of PostProcessWave, a
+    multi-sample launch, a film clear, the device-pointer getters of the sharded step -- makes them enter before it looks.  The
+    same call sequence with VSPG_WG2_DEFER=0 (every launch resolves its own samples at once) gives the same bits at every step."""
+    P = gpu_pkg
+    W, H = 100, 70
+    scene = P.fog_box_scene(W, H)
+    prm = P.default_params() if guided else P.app_f_params()
+    field = None
+    if guided:
+        from scenes import light_field
+        field = light_field(P, n=4)
+    logs = []
+    for defer in ("1", "0"):
+        os.environ["VSPG_WG2_DEFER"] = defer
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=9)
+            if field is not None:
+                r.set_guiding_field(field, field)
+            assert r.kernel_name().startswith("k_render_wave_wg2<")
+            log = []
+            r.render_wave(0, 1)
+            log.append(r.film())                       # a read right after a launch
+            r.post_process_wave()                      # wave counter 1: the buffer updates from the statistics (parked ones included)
+            log.append(r.vsp_buffer()[0])
+            r.render_wave(1, 2); r.post_process_wave() # update at 2
+            r.render_wave(2, 3); r.post_process_wave() # no update: stays parked
+            r.render_wave(3, 4); r.post_process_wave() # update at 4, two launches' samples behind it
+            log.append(r.vsp_buffer()[0])
+            r.render_wave(4, 7)                        # multi-sample launch: film atomics, after the parked samples
+            log.append(r.film())
+            r.render_wave(7, 8)
+            r.film_clear()                             # the parked samples are not resurrected by the next launch
+            r.render_wave(8, 9)
+            r.render_wave(9, 10)
+            log.append(r.film())
+            log.append(np.array(sorted(r.counters().items()), dtype=object))
+            logs.append(log)
+            r.close()
+        finally:
+            os.environ.pop("VSPG_WG2_DEFER", None)
+    for a, b in zip(*logs):
+        if a.dtype == object:
+            assert (a == b).all()
+        else:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    f = logs[0][4]
+    assert np.all(f[..., 3] == 2.0)    # two samples per pixel since the clear
+
+
 def test_grey_grid_medium_film_equals_replayed_paths(gpu_pkg):
     """A grid medium with grey sigma_a / sigma_s renders through the broadcast-spectrum instantiation of the
     per-lane kernel; the path replay (k_trace_paths) uses the generic one: same pixels bit for bit, and the

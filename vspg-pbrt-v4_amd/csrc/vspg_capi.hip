@@ -1054,10 +1054,22 @@ VDEV float isg_code(const IsgSample &isg) {
     const float q = isg.vsp_used >= 0.f ? isg.vsp_used : 0.5f;
     return isg.surface_event ? -q : q;
 }
+// one parked sample {L, ISG code} into the film and the image-space statistics (RGBFilm::AddSample + ISG AddSample, the
+// read-modify-write forms: one writer per pixel)
+__device__ __forceinline__ void resolve_sample(float4 s, float4 *film_px, float *isg_px) {
+    const Spec L = Spec{s.x, s.y, s.z};
+    film_add_sample_rmw(film_px, L);
+    IsgSample isg;
+    isg.valid = s.w != 0.f;
+    isg.surface_event = s.w < 0.f;
+    isg.vsp_used = __builtin_fabsf(s.w);
+    isg_add_sample_rmw(isg_px, L, isg);
+}
 template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd, bool TRAIN = false>
 __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
     int vsp_ready, int wave_end, int first_sample, int single_sample, PcgJump jump, unsigned int tiles_magic,
+    unsigned int static_tiles, unsigned int *__restrict__ work_head, const float4 *__restrict__ prev_samples,
     float4 *__restrict__ wave_samples, unsigned long long *__restrict__ counters, TrainArgs train = TrainArgs{nullptr, nullptr, nullptr, nullptr, 0, 0}) {
     const DScene &S = *Sp;
     const int W = S.xres, H = S.yres;
@@ -1065,9 +1077,14 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     const unsigned n_tiles = (unsigned)(tilesX * tilesY);
     const int lane = threadIdx.x & 63;
     const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
-    // this workgroup's items: local item j = pixel (j & 63) of tile (j >> 6) * gridDim.x + blockIdx.x
-    const unsigned local_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
+    // this workgroup's items: local item j = pixel (j & 63) of tile (j >> 6) * gridDim.x + blockIdx.x, over the first static_tiles
+    // tiles; the REST of the frame is handed out tile by tile from a global head once a workgroup has started all of its own --
+    // the workgroups finish their static shares at different times (a share's cost follows what its pixels see), and without the
+    // shared tail every one of them ended on its own slowest tiles
+    const unsigned n_static = static_tiles < n_tiles ? static_tiles : n_tiles;
+    const unsigned local_tiles = blockIdx.x < n_static ? (n_static - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
     const unsigned local_total = local_tiles * 64u;
+    reset_sibling_head(work_head);
 
     using LY = PoolLayout<GUIDED, Medium::kGrey, TRAIN>;
     constexpr int NF = LY::COUNT;
@@ -1075,6 +1092,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     __shared__ float s_pool[NF * NP];
     __shared__ unsigned short s_listA[2][NP], s_listB[NP], s_free[2][NP];
     __shared__ unsigned int s_cnt[D_COUNT + 1];
+    __shared__ unsigned int s_dyn[2], s_dyn_done[2];  // the tiles claimed for this iteration (first tile, items); the shared tail has run out
     const Pool P{s_pool, NP};
     static_assert(Medium::kSingleSegment, "k_render_wave_wg2 serves homogeneous media (grid media: the wavefront pipeline)");
     const Medium medium = MediumMaker<Medium>::make(S, nullptr);
@@ -1115,6 +1133,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     stage_scene_lds(S);
     if (threadIdx.x < CNT_COUNT) s_counters[threadIdx.x] = 0;
     if (threadIdx.x <= D_COUNT) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 2) { s_dyn[threadIdx.x] = 0; s_dyn_done[threadIdx.x] = 0; }
     for (int i = threadIdx.x; i < NP; i += kWgBlock) s_free[0][i] = (unsigned short)i;
     __syncthreads();
     if (threadIdx.x == 0) s_cnt[D_NFREE] = NP;
@@ -1137,23 +1156,44 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
         const int par = k & 1, nxt = par ^ 1;
         const unsigned nFree = s_cnt[D_NFREE + par], nA0 = s_cnt[D_A0 + par], nA1 = s_cnt[D_A1 + par], lnext = s_cnt[D_LNEXT];
         const unsigned left = local_total - lnext;
-        const unsigned nFresh = nFree < left ? nFree : left;
-        const unsigned nPrim = nFresh + nA0, nA = nPrim + nA1;
-        if (nA == 0) break;  // nothing in flight and nothing left to start (free slots exist whenever nothing is in flight)
         // the vertex-list counters of the PREVIOUS iteration (other parity) are free again: nobody reads them before the
         // segment phase of the next iteration pushes into them, two barriers from here
-        if (threadIdx.x == 0) { s_cnt[D_BV + nxt] = 0; s_cnt[D_BS + nxt] = 0; s_cnt[D_CURB + nxt] = 0; }
+        if (threadIdx.x == 0) { s_cnt[D_BV + nxt] = 0; s_cnt[D_BS + nxt] = 0; s_cnt[D_CURB + nxt] = 0; s_dyn_done[nxt] = s_dyn_done[par]; }
+        // own share started: whole tiles from the shared tail for the free slots (one returning atomic per claim).  Every thread
+        // takes this branch or none: its condition reads values written at least one barrier ago (the done flag travels by parity).
+        unsigned dynBase = 0, nDyn = 0;
+        if (left == 0u && nFree >= 64u && n_static < n_tiles && !s_dyn_done[par]) {
+            if (threadIdx.x == 0) {
+                const unsigned m = nFree >> 6, n_dyn = n_tiles - n_static;
+                const unsigned b = atomicAdd(work_head, m);
+                const unsigned got = b < n_dyn ? (m < n_dyn - b ? m : n_dyn - b) : 0u;
+                s_dyn[0] = n_static + b;
+                s_dyn[1] = got * 64u;
+                if (got < m) s_dyn_done[nxt] = 1u;
+            }
+            __syncthreads();
+            dynBase = s_dyn[0];
+            nDyn = s_dyn[1];
+        }
+        const unsigned nFresh = left > 0u ? (nFree < left ? nFree : left) : nDyn;
+        const unsigned nPrim = nFresh + nA0, nA = nPrim + nA1;
+        if (nA == 0) break;  // nothing in flight and nothing left to start (free slots exist whenever nothing is in flight)
+        const unsigned nSpare = nFree - nFresh;  // carried over to the next iteration's free list (the shared tail will want them)
 
         // ---- S: camera ray + primary segment for new paths, one secondary segment for the others ------
         while (true) {
             unsigned base = 0;
             if (lane == 0) base = atomicAdd(&s_cnt[D_CURA + par], 64u);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= nA) break;
+            if (base >= nA + nSpare) break;
             VSPG_PROF(PS_WG_A);
             const unsigned i = base + (unsigned)lane;
             bool toV = false, toS = false, restart = false, freed = false;
             int slot = 0;
+            if (i >= nA && i < nA + nSpare) {  // a free slot no new path took this iteration: it stays free
+                slot = s_free[par][nFresh + (i - nA)];
+                freed = true;
+            }
             if (i < nA) {
                 Sampler sampler;
                 PathState st;
@@ -1166,7 +1206,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                     if (i < nFresh) {
                         slot = s_free[par][i];
                         const unsigned item = lnext + i;
-                        const unsigned tile = (item >> 6) * gridDim.x + blockIdx.x, l = item & 63u;
+                        const unsigned tile = left > 0u ? (item >> 6) * gridDim.x + blockIdx.x : dynBase + (i >> 6), l = (left > 0u ? item : i) & 63u;
                         unsigned ty = tilesX == 1 ? tile : __umulhi(tile, tiles_magic);
                         unsigned tx = tile - ty * (unsigned)tilesX;
                         while (tx >= (unsigned)tilesX) { tx -= (unsigned)tilesX; ty++; }
@@ -1174,7 +1214,13 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                         py = (int)(ty * 8u + (l >> 3));
                         pxy = px | (py << 16);
                         smp = first_sample;
-                        valid = tile < n_tiles;
+                        valid = tile < (left > 0u ? n_static : n_tiles);
+                        // the PREVIOUS one-sample launch parked this pixel's sample (vspg_render_wave: deferred resolve): it enters
+                        // the film now, before this launch's sample of the pixel can (same order of additions as ever)
+                        if (prev_samples != nullptr && valid && px < W && py < H) {
+                            const size_t pidx = (size_t)py * W + px;
+                            resolve_sample(prev_samples[pidx], film + pidx, isg_stats + pidx * VSPG_ISG_STATS);
+                        }
                     } else {
                         slot = s_listA[par][i - nFresh];
                         pxy = P.i(LY::PIXEL, slot);
@@ -1235,7 +1281,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
         { VSPG_PROF(PS_WG_BAR_A); __syncthreads(); }
         // the segment phase's inputs are consumed (every wave read the counts before it entered the phase)
         if (threadIdx.x == 0) {
-            s_cnt[D_LNEXT] = lnext + nFresh;
+            s_cnt[D_LNEXT] = lnext + (left > 0u ? nFresh : 0u);
             s_cnt[D_NFREE + par] = 0; s_cnt[D_A0 + par] = 0; s_cnt[D_A1 + par] = 0; s_cnt[D_CURA + par] = 0;
         }
 
@@ -1305,14 +1351,7 @@ __global__ __launch_bounds__(kBlock) void k_film_resolve(size_t npix, const floa
                                                          float *__restrict__ isg_stats) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= npix) return;
-    const float4 s = wave_samples[i];
-    const Spec L = Spec{s.x, s.y, s.z};
-    film_add_sample_rmw(film + i, L);
-    IsgSample isg;
-    isg.valid = s.w != 0.f;
-    isg.surface_event = s.w < 0.f;
-    isg.vsp_used = __builtin_fabsf(s.w);
-    isg_add_sample_rmw(isg_stats + i * VSPG_ISG_STATS, L, isg);
+    resolve_sample(wave_samples[i], film + i, isg_stats + i * VSPG_ISG_STATS);
 }
 
 template <class Medium, bool GUIDED>
@@ -1599,7 +1638,13 @@ struct VspgRenderer {
     DBvhNode *bvh = nullptr;
     // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
     float *wf_pool = nullptr;
-    float4 *wave_samples = nullptr;  // k_render_wave_wg2: one {L, ISG code} per pixel of a one-sample launch (k_film_resolve adds it in)
+    // k_render_wave_wg2: one {L, ISG code} per pixel of a one-sample launch.  The samples of launch w enter the film at the start of
+    // launch w + 1 (inside the kernel, as each pixel's new path begins) or, when anything else wants the film or the statistics
+    // first, through k_film_resolve (flush_parked_samples): two buffers, `ws_parked` says the other one holds unresolved samples.
+    float4 *wave_samples[2] = {nullptr, nullptr};
+    int ws_cur = 0;
+    bool ws_parked = false;
+    hipStream_t ws_stream = nullptr;  // the stream of the launch that parked them
     unsigned int *wf_lists = nullptr;   // 4 x n_items: active (even / odd iterations), walk, shadow
     hipStream_t wf_stream2 = nullptr;   // the shadow walks' stream (wf_render_pass)
     hipEvent_t wf_ev_vertex = nullptr, wf_ev_shadow = nullptr;
@@ -2804,7 +2849,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->train_nsplit) (void)hipFree(r->train_nsplit);
     if (r->tris) (void)hipFree(r->tris);
     if (r->bvh) (void)hipFree(r->bvh);
-    if (r->wave_samples) (void)hipFree(r->wave_samples);
+    for (int k = 0; k < 2; ++k) if (r->wave_samples[k]) (void)hipFree(r->wave_samples[k]);
     if (r->wf_pool) (void)hipFree(r->wf_pool);
     if (r->wf_lists) (void)hipFree(r->wf_lists);
     if (r->wf_iters) (void)hipFree(r->wf_iters);
@@ -2876,6 +2921,31 @@ static bool uses_wf_pipeline(const VspgRenderer *r) {
     // the vertex kernel reads the pixel's contribution estimate)
     return het && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
 }
+// Which scheduler of the workgroup kernel: k_render_wave_wg2 (tiles from a global head, samples parked and
+// resolved by the next launch, two barriers) serves every homogeneous configuration since round 3 -- with the shared tile head it
+// beat k_render_wave_wg (film flush between the phases, three barriers) on the unguided workload too (0.776 against 0.808 ms);
+// VSPG_WG_SCHED=1 selects k_render_wave_wg for the unguided instantiations (tests compare the two), grid media under
+// VSPG_KERNEL=wg stay on it.
+static bool uses_wg2(const VspgRenderer *r) {
+    if (!uses_wg_kernel(r) || r->scene.medium.type == VSPG_MEDIUM_GRID) return false;
+    if (uses_wg_guided(r)) return true;
+    const char *e = getenv("VSPG_WG_SCHED");
+    return !(e && e[0] == '1');
+}
+// The samples a one-sample wg2 launch parked are resolved by the next such launch; anything else that reads or writes the film or
+// the image-space statistics calls this first (VSPG_WG2_DEFER=0: every launch resolves its own samples at once).
+static bool wg2_defer_enabled() {  // (read per launch: a test flips it)
+    const char *e = getenv("VSPG_WG2_DEFER");
+    return !(e && e[0] == '0');
+}
+static int flush_parked_samples(VspgRenderer *r, hipStream_t s) {
+    if (!r->ws_parked) return 0;
+    hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((r->npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, r->npix,
+                       r->wave_samples[r->ws_cur ^ 1], r->film, r->isg_stats);
+    HIPCHK(hipGetLastError());
+    r->ws_parked = false;
+    return 0;
+}
 const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (!r) return "";
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
@@ -2889,6 +2959,12 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (uses_wg_guided(r)) {
         if (r->training) return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>" : "k_render_wave_wg2<HomogeneousMedium,guided,train>";
         return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>" : "k_render_wave_wg2<HomogeneousMedium,guided>";
+    }
+    if (uses_wg_kernel(r) && uses_wg2(r)) {
+        if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg2<HomogeneousMediumT<2,true>>";
+        if (r->medium_grey && r->surfaces_grey) return "k_render_wave_wg2<HomogeneousMediumT<2,false>>";
+        if (r->medium_grey) return "k_render_wave_wg2<HomogeneousMediumT<1,false>>";
+        return "k_render_wave_wg2<HomogeneousMediumT<0,false>>";
     }
     if (uses_wg_kernel(r)) {
         if (grid) return "k_render_wave_wg<GridMedium>";
@@ -2932,6 +3008,10 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (guided && !r->field_set) return fail(VSPG_ESCOPE, "guiding enabled but the renderer holds no guiding field");
+    // a one-sample launch of k_render_wave_wg2 resolves the samples its predecessor parked; every other launch adds to the film
+    // itself, so the parked samples go in first
+    const bool defer = !uses_wf_pipeline(r) && uses_wg2(r) && n_samples == 1 && wg2_defer_enabled();
+    if (!defer) { const int rc = flush_parked_samples(r, (hipStream_t)stream); if (rc) return rc; }
     if (uses_wf_pipeline(r)) {  // one pass per sample index of this shard, in order
 #ifdef VSPG_WF_DEBUG
         auto checksum = [&](const void *dptr, size_t bytes) -> unsigned long long {
@@ -3010,27 +3090,32 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         const long long wmax = (items + kWgChunk - 1) / kWgChunk;
         if (wblocks > wmax) wblocks = wmax;
         const int single = n_samples == 1 ? 1 : 0;
-        // Two schedulers: k_render_wave_wg (global work head, film flush between the phases, three barriers) and
-        // k_render_wave_wg2 (static interleaved tiles, sample buffer + k_film_resolve, two barriers).  Unguided renders default to
-        // the first (measured faster there: its flush hides behind the assignment), guided ones run the second;
-        // VSPG_WG_SCHED=1|2 overrides for the unguided instantiations (tests compare the two).
-        const char *sched_env = getenv("VSPG_WG_SCHED");
-        const bool sched2 = !grid && (gwg || (sched_env && sched_env[0] == '2'));
+        // Two schedulers (uses_wg2): k_render_wave_wg2 (tiles from a global head, parked samples, two barriers) by default,
+        // k_render_wave_wg (film flush between the phases, three barriers) for grid media and under VSPG_WG_SCHED=1.
+        const bool sched2 = uses_wg2(r);
         if (sched2) {
-            if (!r->wave_samples) HIPCHK(hipMalloc(&r->wave_samples, r->npix * sizeof(float4)));
+            for (int k = 0; k < 2; ++k)
+                if (!r->wave_samples[k]) HIPCHK(hipMalloc(&r->wave_samples[k], r->npix * sizeof(float4)));
+            float4 *const ws_out = r->wave_samples[r->ws_cur];
+            const float4 *const ws_prev = defer && r->ws_parked ? r->wave_samples[r->ws_cur ^ 1] : nullptr;
             const long long n_tiles = (long long)tilesX * tilesY;
             if (wblocks > n_tiles) wblocks = n_tiles;
+            // the share of the frame handed out from the global head, in 64ths (VSPG_WG2_TAIL; the rest is dealt to the workgroups
+            // up front, interleaved).  Measured on the reference-default guided workload / the unguided one (ms per 1080p wave):
+            // 0: 1.59 / 0.887, 8: 1.50 / 0.829, 16: 1.46 / 0.800, 32: 1.47 / 0.790, 64 (all of it): 1.454 / 0.775.
+            static const int tail64 = [] { const char *e = getenv("VSPG_WG2_TAIL"); const int v = e ? atoi(e) : 64; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+            const unsigned static_tiles = (unsigned)((n_tiles * (64 - tail64) / 64) / wblocks * wblocks);
 #define VSPG_LAUNCH_WG2(M, G, NPOOL, BLK, WV)                                                                                         \
     hipLaunchKernelGGL((k_render_wave_wg2<M, G, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
-                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, r->wave_samples, r->counters)
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, static_tiles, work_head, ws_prev, ws_out, r->counters)
             if (gwg && train && guided_grey_simple(r))
                 hipLaunchKernelGGL((k_render_wave_wg2<HomogeneousMediumGreySceneNullZero, true, kWg2PoolTrainT<2>, kWgBlockGuided, kWgWavesGuided, true>), dim3((unsigned)wblocks),
                                    dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump,
-                                   tiles_magic, r->wave_samples, r->counters, targs);
+                                   tiles_magic, static_tiles, work_head, ws_prev, ws_out, r->counters, targs);
             else if (gwg && train)
                 hipLaunchKernelGGL((k_render_wave_wg2<HomogeneousMediumSimple, true, kWg2PoolTrainT<0>, kWgBlockGuided, kWgWavesGuided, true>), dim3((unsigned)wblocks),
                                    dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump,
-                                   tiles_magic, r->wave_samples, r->counters, targs);
+                                   tiles_magic, static_tiles, work_head, ws_prev, ws_out, r->counters, targs);
             else if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, true, kWg2PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided);
             else if (gwg) VSPG_LAUNCH_WG2(HomogeneousMediumSimple, true, kWg2PoolGuidedT<0>, kWgBlockGuided, kWgWavesGuided);
             else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, false, kWg2PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);
@@ -3039,9 +3124,12 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             else VSPG_LAUNCH_WG2(HomogeneousMediumSimple, false, kWg2PoolHomogT<0>, kWgBlockHomog, kWgWavesHomog);
 #undef VSPG_LAUNCH_WG2
             HIPCHK(hipGetLastError());
-            if (single)
-                hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((r->npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
-                                   r->npix, r->wave_samples, r->film, r->isg_stats);
+            if (single) {  // this launch's samples are parked in ws_out (its predecessor's, if any were, have just been resolved)
+                r->ws_cur ^= 1;
+                r->ws_parked = true;
+                r->ws_stream = (hipStream_t)stream;
+                if (!defer) { const int rc = flush_parked_samples(r, (hipStream_t)stream); if (rc) return rc; }
+            }
         } else {
 #define VSPG_LAUNCH_WG(M, NPOOL, BLK, WV)                                                                                            \
     hipLaunchKernelGGL((k_render_wave_wg<M, false, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
@@ -3180,6 +3268,7 @@ int vspg_post_process_step(VspgRenderer *r, int n_waves, const float *isg_stats_
         const bool do_contrib = r->prm.rrguiding != 0;  // cfg.EnableContributionEstimate(guideRR) (:164-168)
         if (do_vsp || do_contrib) {
             HIPCHK(hipSetDevice(r->cfg.device));
+            { const int rc = flush_parked_samples(r, (hipStream_t)stream); if (rc) return rc; }  // the statistics of every wave so far
             int blocks = (int)((r->npix + kBlock - 1) / kBlock);
             hipLaunchKernelGGL(k_isg_update, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, r->cfg.xres, r->cfg.yres,
                                r->prm.vspcriterion, isg_stats_sum ? isg_stats_sum : r->isg_stats, do_vsp ? r->vsp : nullptr,
@@ -3206,6 +3295,12 @@ int vspg_renderer_set_exchange(VspgRenderer *r, VspgExchangeFn fn, void *user) {
 
 int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
     if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
+    if (r->ws_parked) {  // the caller reads the film on a stream of its own: the parked samples go in, and are in, before it gets the pointer
+        HIPCHK(hipSetDevice(r->cfg.device));
+        const hipStream_t s = r->ws_stream;
+        if (const int rc = flush_parked_samples(r, s)) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+    }
     *dev_ptr = reinterpret_cast<float *>(r->film);
     *n_floats = r->npix * 4;
     return 0;
@@ -3213,6 +3308,7 @@ int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
 int vspg_film_read(VspgRenderer *r, float *host, void *stream) {
     if (!r || !host) return fail(VSPG_EINVAL, "null argument");
     HIPCHK(hipSetDevice(r->cfg.device));
+    if (const int rc = flush_parked_samples(r, (hipStream_t)stream)) return rc;
     HIPCHK(hipMemcpyAsync(host, r->film, r->npix * sizeof(float4), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return 0;
@@ -3220,6 +3316,7 @@ int vspg_film_read(VspgRenderer *r, float *host, void *stream) {
 int vspg_film_clear(VspgRenderer *r, void *stream) {
     if (!r) return fail(VSPG_EINVAL, "null renderer");
     HIPCHK(hipSetDevice(r->cfg.device));
+    if (const int rc = flush_parked_samples(r, (hipStream_t)stream)) return rc;  // (their statistics stay; the film is cleared after)
     HIPCHK(hipMemsetAsync(r->film, 0, r->npix * sizeof(float4), (hipStream_t)stream));
     return 0;
 }
@@ -3277,6 +3374,12 @@ int vspg_vsp_buffer_load(VspgRenderer *r, const float *host, void *stream) {
 }
 int vspg_isg_stats_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
     if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
+    if (r->ws_parked) {
+        HIPCHK(hipSetDevice(r->cfg.device));
+        const hipStream_t s = r->ws_stream;
+        if (const int rc = flush_parked_samples(r, s)) return rc;
+        HIPCHK(hipStreamSynchronize(s));
+    }
     *dev_ptr = r->isg_stats;
     *n_floats = r->npix * VSPG_ISG_STATS;
     return 0;
