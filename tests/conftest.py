@@ -43,7 +43,14 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu_pkg(pkg):
-    """The package with the HIP library loaded; fails loudly if the extension is missing."""
+    """The package with the HIP library loaded; fails loudly if the extension is missing.
+    torch bundles a HIP runtime of its own: it opens the device only if it does so BEFORE the system runtime behind
+    libvspg_hip.so has (two GPU tests hand device pointers to torch) -- so it goes first, whatever subset of the suite runs."""
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     pkg.load()
     return pkg
 
