@@ -335,7 +335,11 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r);
 
 /* Film access.  The film is W*H float4 {sum w*r, sum w*g, sum w*b, sum w} in HBM
  * (the accumulate contract of RGBFilm::AddSample, src/pbrt/film.h:251-267, in float).
- * vspg_film_device_ptr exposes it for the frame-end RCCL all-reduce. */
+ * vspg_film_device_ptr exposes it for the frame-end RCCL all-reduce.
+ * A one-sample vspg_render_wave may leave its samples parked beside the film until the next launch starts (it adds them as each
+ * pixel's new path begins, in the same order as ever); every call that reads or writes the film or the image-space statistics
+ * adds them first, on the stream it is given.  The two *_device_ptr getters have no stream: they add the parked samples on the
+ * stream of the launch that parked them and wait for that stream, so the pointer they return is good for any stream. */
 int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);
 int vspg_film_read(VspgRenderer *r, float *host_rgbw /* W*H*4 */, void *stream);
 int vspg_film_clear(VspgRenderer *r, void *stream);
