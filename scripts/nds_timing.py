@@ -8,7 +8,7 @@ P = g.load_package(); P.load()
 W, H = 1920, 1080
 for kind in ("grid", "nvdb"):
     scene = P.cloud_box_scene(W, H, 256) if kind == "grid" else P.nanovdb_box_scene(W, H, 256)
-    for kernel in ("lane", "wg"):
+    for kernel in ("lane", "wf"):
         os.environ["VSPG_KERNEL"] = kernel
         try:
             prm = P.app_f_params(); prm.vspsamplingmethod = P.VSP_NDS

@@ -1771,6 +1771,54 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c.close()
 
 
+@pytest.mark.parametrize("case", ["grid", "nvdb", "grid-guided", "grid-emissive", "grid-nds+"])
+def test_nds_on_the_pipeline_equals_per_lane_kernel(gpu_pkg, case):
+    """vspsamplingmethod "nds" over a heterogeneous medium: the pipeline's shape for it -- k_wf_segment_vertex (segment and vertex
+    in the lane) + k_wf_shadow_walk (the NEE's walk, regrouped, its result added by the next launch) -- renders the per-lane
+    kernel's film bit for bit; NDS+ (collisionProbabilityBias with a TrBuffer), an emissive grid and the reference's default
+    guiding options on top included.  (The per-lane kernel's paths are the oracle's: the NDS tests above.)"""
+    import scenes
+    P = gpu_pkg
+    W, H = 96, 64
+    dens = scenes.cloud_density(24)
+    if case == "nvdb":
+        scene = scenes.nvdb_scene(dens, (24, 24, 24), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5, index_min=(-3, 2, 0), voxel=(0.066, 0.0625, 0.058),
+                                  origin=(-0.6, -0.93, -0.5), density_offset=0.02, majorant_scale=1.25, W=W, H=H)
+    else:
+        scene = scenes.grid_scene(dens, (24, 24, 24), (0.05, 0.08, 0.1), (3.0, 2.6, 2.2), g=0.5, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    if case == "grid-emissive":
+        scene.medium.Le[:] = (2.5, 1.25, 0.4)
+    guided = case == "grid-guided"
+    prm = P.default_params() if guided else P.app_f_params()
+    prm.vspsamplingmethod = P.VSP_NDS
+    tr = None
+    if case == "grid-nds+":
+        prm.collisionProbabilityBias = 1
+        tr = np.random.default_rng(5).random((H, W, 3)).astype(np.float32) * 0.9 + 0.05
+    field = scenes.light_field(P, n=4) if guided else None
+    films = {}
+    for kernel in (None, "lane"):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=14)
+            if field is not None:
+                r.set_guiding_field(field, field)
+            if tr is not None:
+                r.set_tr_buffer(tr)
+            for w in range(4):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            films[r.kernel_name()] = (r.film(), r.counters())
+            r.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    print(case, sorted(films))
+    assert len(films) == 2 and any(k.startswith("k_wf_segment_vertex<") for k in films) and any(k.startswith("k_render_wave<") for k in films)
+    (fa, ca), (fb, cb) = films.values()
+    assert ca == cb
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+
+
 @pytest.mark.parametrize("guided", [False, True])
 def test_wavefront_pipeline_concurrent_walks_equal_single_stream_order(gpu_pkg, guided):
     """The shadow walk of iteration i runs on a second stream beside the distance walk of iteration i + 1 (own job fields, its

@@ -2424,6 +2424,18 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_shadow, hipEventDisableTiming));
     }
     const hipStream_t s2 = serial ? s : r->wf_stream2;
+    if (r->prm.vspsamplingmethod != VSPG_VSP_RESAMPLING) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
+        for (int it = 0; it <= r->prm.maxdepth; ++it) {
+            hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
+            if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
+        }
+        HIPCHK(hipGetLastError());
+        if (TRAIN) {
+            hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a.train, a.rec_cap);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
     hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a);
     for (int it = 0; it <= r->prm.maxdepth; ++it) {
         hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
@@ -2917,9 +2929,9 @@ static bool uses_wf_pipeline(const VspgRenderer *r) {
     const bool het = r->scene.medium.type == VSPG_MEDIUM_GRID || r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wf") != 0) return false;
-    // guided builds too, training passes included (segment recording in the dense kernels), and guided Russian roulette (round 3:
-    // the vertex kernel reads the pixel's contribution estimate)
-    return het && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING;
+    // guided builds too, training passes included (segment recording in the dense kernels), guided Russian roulette (round 3:
+    // the vertex kernel reads the pixel's contribution estimate) and, in its own shape, NDS / NDS+ (k_wf_segment_vertex)
+    return het;
 }
 // Which scheduler of the workgroup kernel: k_render_wave_wg2 (tiles from a global head, samples parked and
 // resolved by the next launch, two barriers) serves every homogeneous configuration since round 3 -- with the shared tile head it
@@ -2950,6 +2962,12 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (!r) return "";
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
+    if (uses_wf_pipeline(r) && r->prm.vspsamplingmethod != VSPG_VSP_RESAMPLING) {
+        if (guided && r->training) return nvdb ? "k_wf_segment_vertex<NanoDenseMedium,guided,train>" : "k_wf_segment_vertex<GridMedium,guided,train>";
+        if (guided) return nvdb ? "k_wf_segment_vertex<NanoDenseMedium,guided>" : "k_wf_segment_vertex<GridMedium,guided>";
+        return nvdb ? (r->medium_grey ? "k_wf_segment_vertex<NanoDenseMediumGrey>" : "k_wf_segment_vertex<NanoDenseMedium>")
+                    : (r->medium_grey ? "k_wf_segment_vertex<GridMediumGrey>" : "k_wf_segment_vertex<GridMedium>");
+    }
     if (uses_wf_pipeline(r)) {
         if (guided && r->training) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided,train>" : "k_wf_dist_walk<GridMedium,guided,train>";
         if (guided) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided>" : "k_wf_dist_walk<GridMedium,guided>";

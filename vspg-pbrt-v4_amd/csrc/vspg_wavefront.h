@@ -913,6 +913,96 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     wf_flush_counters(pc, a.counters);
 }
 
+// ---- the vertex of a pipeline path: li_segment_b with the NEE's shadow walk deferred ----------------------------------------
+// Vertex set-up, the NEE's light sample and shadow-ray set-up (queued as a shadow-walk job, or added on the spot when no walk
+// is needed), Russian roulette and the new direction (the guided vertex does all of it in li_vertex_guided_impl).  Returns what
+// became of the path: finished here (film written), ended but listed for its outstanding NEE (stored, WFL_DEAD), or going on
+// (`extra_out`: the flags of an outstanding shadow walk, for the caller's store).
+enum { WFV_FINISHED = 0, WFV_DEAD_LISTED = 1, WFV_CONTINUES = 2 };
+template <class Medium, bool GUIDED, bool TRAIN, class PC>
+VDEV int wf_vertex(const WfArgs &a, const DScene &S, const Medium &medium, unsigned slot, PathState &st, Sampler &sampler, int ch, IsgSample &isg,
+                   PC &pc, const Vertex &vx, uint32_t *extra_out, bool *shadow_out) {
+    const WfPool &P = a.P;
+    constexpr int G = Medium::kGrey;
+    bool shadow = false;
+    VertexCtx c;
+    vertex_setup<false>(S, st, vx, c);
+    float survivalProb = 1.f;
+    uint32_t extra = 0u;
+    ShadowSetup ss;
+    ss.status = 0;
+    bool nee = false, cont = true;
+    Spec beta_nee = st.beta;
+    if constexpr (GUIDED) {
+        {   // guided RR (:274-285): the pixel's contribution estimate, once the image-space buffer is ready
+            int qx, qy;
+            wf_pixel_of(slot, a.tilesX, &qx, &qy);
+            st.guideRR = S.prm.rrguiding && S.contrib_ready;
+            st.pce = st.guideRR ? S.contrib[(size_t)qy * S.xres + qx] : 0.f;
+        }
+        cont = li_vertex_guided_impl<Medium, true, true>(
+            S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, nullptr, 0, [&](const auto &gd, bool use_gd) {
+                nee = true;
+                beta_nee = st.beta;
+                ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc, &gd, use_gd);
+                return sp(0.f);
+            });
+    } else {
+        survivalProb = vertex_pre(S, st, sampler, vx);
+        if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833
+            nee = true;
+            ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc);
+        }
+    }
+    if (nee) {
+        if (ss.status == 1) {
+            const float tM = (1 - kShadowEps) * len(ss.ld);
+            const V3 rdn = normalize(ss.ld);
+            const auto iter = medium.sample_ray(ss.lo, rdn, tM);
+            if (iter.tMin >= iter.tMax) {
+                ss.status = 2;  // the ray misses the medium's bounds: the walk would return T_maj = 1 at once
+            } else {
+                wf_store_iter(P, slot, iter, WF_SIT);
+                P.set3(WF_SRDN, slot, rdn);
+                P.set3(WF_SLO, slot, ss.lo);
+                P.store_rng(WF_SWRNG, slot, ss.rng);
+                P.f(WF_SWU, slot) = ss.us;
+                P.sets(WF_FHAT, slot, ss.f_hat);
+                P.sets(WF_LSL, slot, ss.L);
+                P.f(WF_PL, slot) = ss.p_l;
+                P.f(WF_SPDF, slot) = ss.scatterPDF;
+                P.sets(WF_BNEE, slot, beta_nee);
+                extra |= WFL_SHADOW_WALK | (ss.delta_light ? (uint32_t)WFL_DELTA : 0u);
+                shadow = true;
+            }
+        }
+        if (!shadow) {  // no walk to wait for: the estimate's tail (:1233-1251) and the addition (:483 / :836) here
+            Spec Ld = sp(0.f);
+            if (ss.status == 2)
+                Ld = sample_Ld_end<G>(false, ss.delta_light, sp(1.f), sp(1.f), sp(1.f), sp(1.f), ch, ss.f_hat, ss.L, ss.p_l, ss.scatterPDF, st.r_u);
+            st.L = st.L + beta_nee * Ld;
+            if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);
+        }
+    }
+    // ---- Russian roulette + new direction (:842-874 / :487-606); the guided vertex has done both ------------------
+    if constexpr (!GUIDED) cont = vertex_tail(S, st, sampler, vx, c, survivalProb);
+    if (!cont) {
+        if (shadow) {  // its shadow walk is out: the slot stays listed for that one addition
+            wf_rec_store(a, slot, pc.rec);
+            wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE | WFL_DEAD);
+            *shadow_out = true;
+            return WFV_DEAD_LISTED;
+        }
+        wf_finish_path(a, slot, st, isg);
+        pc.path();
+        wf_rec_finish(a, slot, pc.rec);
+        return WFV_FINISHED;
+    }
+    *extra_out = extra;
+    *shadow_out = shadow;
+    return WFV_CONTINUES;
+}
+
 // ---- the vertex kernel: [deferred NEE result] + segment end + vertex + the next segment's begin ----------------------------
 // GUIDED: the vertex code is li_vertex_guided_impl -- cache init, NEE set-up with the guided PDF, Russian roulette, MIS / RIS
 // direction sampling, the next segment's VSP -- with the product mixture in registers (GStoreReg; ~240 VGPRs: 2 waves per SIMD)
@@ -1074,79 +1164,12 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                 pc.path();
                 wf_rec_finish(a, slot, pc.rec);
             } else {
-                // ---- li_segment_b: the vertex --------------------------------------------------------------------------------
-                VertexCtx c;
-                vertex_setup<false>(S, st, vx, c);
-                float survivalProb = 1.f;
+                // ---- li_segment_b: the vertex (wf_vertex), then the next segment's begin ---------------------------------------
                 uint32_t extra = 0u;
-                ShadowSetup ss;
-                ss.status = 0;
-                bool nee = false, cont = true;
-                Spec beta_nee = st.beta;
-                if constexpr (GUIDED) {
-                    {   // guided RR (:274-285): the pixel's contribution estimate, once the image-space buffer is ready
-                        int qx, qy;
-                        wf_pixel_of(slot, a.tilesX, &qx, &qy);
-                        st.guideRR = S.prm.rrguiding && S.contrib_ready;
-                        st.pce = st.guideRR ? S.contrib[(size_t)qy * S.xres + qx] : 0.f;
-                    }
-                    cont = li_vertex_guided_impl<Medium, true, true>(
-                        S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, nullptr, 0, [&](const auto &gd, bool use_gd) {
-                            nee = true;
-                            beta_nee = st.beta;
-                            ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc, &gd, use_gd);
-                            return sp(0.f);
-                        });
-                } else {
-                    survivalProb = vertex_pre(S, st, sampler, vx);
-                    if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833
-                        nee = true;
-                        ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc);
-                    }
-                }
-                if (nee) {
-                    if (ss.status == 1) {
-                        const float tM = (1 - kShadowEps) * len(ss.ld);
-                        const V3 rdn = normalize(ss.ld);
-                        const auto iter = medium.sample_ray(ss.lo, rdn, tM);
-                        if (iter.tMin >= iter.tMax) {
-                            ss.status = 2;  // the ray misses the medium's bounds: the walk would return T_maj = 1 at once
-                        } else {
-                            wf_store_iter(P, slot, iter, WF_SIT);
-                            P.set3(WF_SRDN, slot, rdn);
-                            P.set3(WF_SLO, slot, ss.lo);
-                            P.store_rng(WF_SWRNG, slot, ss.rng);
-                            P.f(WF_SWU, slot) = ss.us;
-                            P.sets(WF_FHAT, slot, ss.f_hat);
-                            P.sets(WF_LSL, slot, ss.L);
-                            P.f(WF_PL, slot) = ss.p_l;
-                            P.f(WF_SPDF, slot) = ss.scatterPDF;
-                            P.sets(WF_BNEE, slot, beta_nee);
-                            extra |= WFL_SHADOW_WALK | (ss.delta_light ? (uint32_t)WFL_DELTA : 0u);
-                            shadow = true;
-                        }
-                    }
-                    if (!shadow) {  // no walk to wait for: the estimate's tail (:1233-1251) and the addition (:483 / :836) here
-                        Spec Ld = sp(0.f);
-                        if (ss.status == 2)
-                            Ld = sample_Ld_end<G>(false, ss.delta_light, sp(1.f), sp(1.f), sp(1.f), sp(1.f), ch, ss.f_hat, ss.L, ss.p_l, ss.scatterPDF, st.r_u);
-                        st.L = st.L + beta_nee * Ld;
-                        if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);
-                    }
-                }
-                // ---- Russian roulette + new direction (:842-874 / :487-606); the guided vertex has done both ------------------
-                if constexpr (!GUIDED) cont = vertex_tail(S, st, sampler, vx, c, survivalProb);
-                if (!cont) {
-                    if (shadow) {  // its shadow walk is out: the slot stays listed for that one addition
-                        wf_rec_store(a, slot, pc.rec);
-                        wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE | WFL_DEAD);
-                        next = true;
-                    } else {
-                        wf_finish_path(a, slot, st, isg);
-                        pc.path();
-                        wf_rec_finish(a, slot, pc.rec);
-                    }
-                } else {
+                const int fate = wf_vertex<Medium, GUIDED, TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, vx, &extra, &shadow);
+                if (fate == WFV_DEAD_LISTED) {
+                    next = true;
+                } else if (fate == WFV_CONTINUES) {
                     wf_rec_store(a, slot, pc.rec);
                     if constexpr (GUIDED) {  // k_wf_begin takes it from here
                         P.f(WF_GSVSP, slot) = st.gs.vsp_next;
@@ -1170,6 +1193,104 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
     stA.flush(list_out, &In->n_active, &s_gbase[0]);
     stB.flush(a.list_walk, &In->n_walk, &s_gbase[1]);
     stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[2]);
+    wf_flush_counters(pc, a.counters);
+}
+
+// ---- vspsamplingmethod "nds" (NDS / NDS+) on grid media: the whole segment and the vertex in one dense kernel -----------------
+// SampleT_maj_OpticalDepthSpace's callback ENDS the segment (a real collision scatters or absorbs), and it draws from the same
+// RNG as the traversal: the walk cannot be cut out as a job the way the resampling routine's can.  So the segment runs in the
+// lane (li_segment_a: intersection, distance sampling with its delta-tracking walk, the event), then the vertex (wf_vertex);
+// what the pipeline still takes out of the lane is the NEE's ratio-tracking walk -- k_wf_shadow_walk, lanes regrouped over jobs
+// -- whose result the next launch adds first thing, as in the resampling pipeline.  One launch per path-loop iteration.
+template <class Medium, bool GUIDED = false, bool TRAIN = false>
+__global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int it) {
+    const DScene &S = *a.scene;
+    const Medium medium = wf_block_medium<Medium>(S);
+    const WfPool &P = a.P;
+    constexpr int G = Medium::kGrey;
+    const bool first = it == 0;
+    WfIter *I = &a.iters[it], *In = &a.iters[it + 1];
+    const unsigned n = first ? a.n_items : I->n_active;
+    const unsigned int *list_in = (it & 1) ? a.list_active2 : a.list_active;
+    unsigned int *list_out = (it & 1) ? a.list_active : a.list_active2;
+    WfCountersT<typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type> pc;
+    pc.zero();
+    __shared__ unsigned int s_stage[2][kWfStageRounds * kWfBlock], s_cnt[2], s_gbase[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const WfStage stA{s_stage[0], &s_cnt[0]}, stC{s_stage[1], &s_cnt[1]};
+    int round = 0;
+    for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
+        const unsigned idx = base + threadIdx.x;
+        bool next = false, shadow = false;
+        unsigned slot = 0;
+        if (idx < n) {
+            slot = first ? idx : list_in[idx];
+            int px, py;
+            wf_pixel_of(slot, a.tilesX, &px, &py);
+            PathState st;
+            Sampler sampler;
+            IsgSample isg;
+            int ch = 0;
+            bool run = false;
+            if (first) {
+                if (px < S.xres && py < S.yres) {
+                    start_path(S, a.vsp_buf, a.vsp_ready, px, py, a.jump, sampler, st, &ch, isg);
+                    if constexpr (TRAIN) {
+                        wf_rec_load(a, slot, pc.rec);
+                        pc.rec.reset();
+                    }
+                    run = true;
+                }
+            } else {
+                const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
+                if constexpr (TRAIN) wf_rec_load(a, slot, pc.rec);
+                if constexpr (GUIDED) st.gs.vsp_next = P.f(WF_GSVSP, slot);
+                if (fl & WFL_SHADOW_WALK) {  // the previous vertex's NEE (:483 / :836 from the estimate on)
+                    const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, P.sp3(WF_TRAY, slot), P.sp3(WF_SRL, slot), P.sp3(WF_SRU, slot),
+                                                     P.sp3(WF_STMAJ, slot), ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
+                                                     P.f(WF_SPDF, slot), st.r_u);
+                    st.L = st.L + P.sp3(WF_BNEE, slot) * Ld;
+                    if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);
+                }
+                if (fl & WFL_DEAD) {
+                    wf_finish_path(a, slot, st, isg);
+                    pc.path();
+                    wf_rec_finish(a, slot, pc.rec);
+                } else {
+                    run = true;
+                }
+            }
+            if (run) {
+                Vertex vx;
+                const bool alive = li_segment_a<Medium, GUIDED, SEG_ANY>(S, medium, a.vsp_buf, a.vsp_ready, px, py, st, ch, sampler, isg, pc, vx);
+                if (!alive) {
+                    wf_finish_path(a, slot, st, isg);
+                    pc.path();
+                    wf_rec_finish(a, slot, pc.rec);
+                } else {
+                    uint32_t extra = 0u;
+                    const int fate = wf_vertex<Medium, GUIDED, TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, vx, &extra, &shadow);
+                    if (fate == WFV_DEAD_LISTED) {
+                        next = true;
+                    } else if (fate == WFV_CONTINUES) {
+                        wf_rec_store(a, slot, pc.rec);
+                        if constexpr (GUIDED) P.f(WF_GSVSP, slot) = st.gs.vsp_next;
+                        wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE);
+                        next = true;
+                    }
+                }
+            }
+        }
+        stA.push(next, slot);
+        stC.push(shadow, slot);
+        if ((round % kWfStageRounds) == kWfStageRounds - 1) {
+            stA.flush(list_out, &In->n_active, &s_gbase[0]);
+            stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
+        }
+    }
+    stA.flush(list_out, &In->n_active, &s_gbase[0]);
+    stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
     wf_flush_counters(pc, a.counters);
 }
 
