@@ -369,7 +369,7 @@ def test_grey_specialisations_are_bit_identical(gpu_pkg):
 @pytest.mark.parametrize("W,H", [(96, 64), (50, 37)])
 def test_workgroup_schedulers_are_bit_identical(gpu_pkg, W, H):
     """The two schedulers of the workgroup kernel -- k_render_wave_wg (global work head, film flush between the phases) and
-    k_render_wave_wg2 (static interleaved tiles, sample buffer + k_film_resolve, two barriers; the guided default) -- over
+    k_render_wave_wg2 (tiles from a global head, parked samples, two barriers; the default) -- over
     the four homogeneous instantiations, with one-sample launches, a multi-sample launch (restarts, film atomics) and the
     image-space buffer updating in between: same films, same VSP buffers, same counters."""
     P = gpu_pkg

@@ -1035,14 +1035,18 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_render_wave_wg2 (round 3): the same pool / phase design with the scheduler's serial pieces taken out.
-//   * work assignment is STATIC and INTERLEAVED: workgroup b owns the pixel tiles b, b + G, b + 2G, ... (G = grid size), so
-//     every workgroup samples the whole image (no systematic difference in path length between workgroups) and a fresh
-//     chunk's work items are pure index arithmetic -- no global work head, no assignment phase, no s_item array;
-//   * a finished path of a one-sample-per-pixel launch stores {L, ISG code} into a per-launch SAMPLE BUFFER with one 16-byte
-//     fire-and-forget store; k_film_resolve adds the buffer to the film and the ISG statistics afterwards (a streaming
-//     kernel, ~0.04 ms at 1080p).  The film flush of k_render_wave_wg -- a read-modify-write whose load latency sat between
-//     two workgroup barriers of every iteration -- is gone, and with it the third barrier: [segment] barrier [vertex] barrier.
-//     Per pixel and channel it is still the one IEEE addition `film += L` of RGBFilm::AddSample: same bits.
+//   * work assignment: whole pixel tiles for the pool's free slots, claimed from a GLOBAL tile head with one returning atomic per
+//     claim (up to NP / 64 tiles at once); a fresh item's pixel is index arithmetic on the claimed tile -- no assignment phase, no
+//     s_item array.  (First version: static interleaved shares, workgroup b owning tiles b, b + G, ... -- every workgroup then
+//     ended on its own slowest tiles; handing the frame out from the head took the unguided wave from 0.887 to 0.775 ms and the
+//     reference-default guided one from 1.59 to 1.45.  VSPG_WG2_TAIL keeps the split adjustable: the share of the frame that
+//     comes from the head, in 64ths.)
+//   * a finished path of a one-sample-per-pixel launch PARKS {L, ISG code} in a per-pixel buffer with one 16-byte fire-and-forget
+//     store; the NEXT launch adds it to the film and the ISG statistics as it starts that pixel's new path (or k_film_resolve
+//     does, when something else wants the film first: flush_parked_samples).  The film flush of k_render_wave_wg -- a
+//     read-modify-write whose load latency sat between two workgroup barriers of every iteration -- is gone, and with it the
+//     third barrier: [segment] barrier [vertex] barrier.  Per pixel and channel it is still the one IEEE addition `film += L` of
+//     RGBFilm::AddSample, in the same order: same bits.
 //   Measured (profiles/r03_*): per-section wave timers of k_render_wave_wg showed 28 % of the wave cycles in the three
 //   barriers and ~20 % in assignment / flush; the SIMDs issued 44 % of the time (scripts/microbench/issue.hip prices).
 // Multi-sample launches keep the no-return atomics at the point where a path ends (several samples of a pixel per launch).
@@ -2896,7 +2900,7 @@ static const char *kernel_env() {
 static bool uses_wg_guided(const VspgRenderer *r) {
     // round 3: the workgroup kernel's guided vertex (vspg_guided_wg.h, four waves per SIMD) is the DEFAULT for a trained or
     // loaded field over a homogeneous medium in a rectangle scene; VSPG_KERNEL=lane selects the per-lane kernel (tests compare
-    // the two).  Training waves (segment recording), guided Russian roulette, triangles / infinite lights stay per-lane.
+    // the two).  Guided Russian roulette, triangles / infinite lights and non-uniform light samplers stay per-lane.
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wg") != 0) return false;
     return wants_guiding(r->prm) && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
