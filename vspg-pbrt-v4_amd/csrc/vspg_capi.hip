@@ -685,9 +685,15 @@ constexpr int kWgWavesGrid = 2, kWgBlockGrid = 256, kWgPoolGrid = 384;
 constexpr int kWgWavesGuided = VSPG_WGG_WAVES, kWgBlockGuided = VSPG_WGG_BLOCK, kWgPoolGuided = VSPG_WGG_NP;
 // Paths per pool: what fits the 80 KB a workgroup may use when two share a CU -- the record (PoolLayout::COUNT dwords), the
 // lists' entries per path, and `other` bytes of fixed LDS (scene records, tables, counters, staged kd nodes); a multiple of 32.
+#ifndef VSPG_WG_LDS_BUDGET
+#define VSPG_WG_LDS_BUDGET 81920
+#endif
+#ifndef VSPG_WG_NP_CAP
+#define VSPG_WG_NP_CAP 512
+#endif
 template <class LY>
 constexpr int wg_pool_paths(int list_bytes_per_path, int other_bytes) {
-    return (81920 - other_bytes) / (LY::COUNT * 4 + list_bytes_per_path) / 32 * 32;
+    return (VSPG_WG_LDS_BUDGET - other_bytes) / (LY::COUNT * 4 + list_bytes_per_path) / 32 * 32;
 }
 #ifndef VSPG_WG_OTHER
 #define VSPG_WG_OTHER 5500
@@ -696,7 +702,7 @@ constexpr int wg_pool_paths(int list_bytes_per_path, int other_bytes) {
 // pool that is not a multiple of that leaves a second round of partly filled chunks behind (608 paths: 0.849 against 0.804 ms per
 // 1080p wave) -- so the records the grey instantiations save are not spent on more paths there.
 template <int GREY> constexpr int kWgPoolHomogT = wg_pool_paths<PoolLayout<false, GREY>>(14, VSPG_WG_OTHER) < 512 ? wg_pool_paths<PoolLayout<false, GREY>>(14, VSPG_WG_OTHER) : 512;  // k_render_wave_wg: + s_item
-template <int GREY> constexpr int kWg2PoolHomogT = wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) < 512 ? wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) : 512;
+template <int GREY> constexpr int kWg2PoolHomogT = wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) < VSPG_WG_NP_CAP ? wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) : VSPG_WG_NP_CAP;
 // guided: every path counts (320 -> 384 -> 416 paths: 2.14 -> 1.86 -> 1.78 ms per trained 1080p wave)
 #ifndef VSPG_WGG_NP_G0
 #define VSPG_WGG_NP_G0 wg_pool_paths<PoolLayout<true, 0>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8)
