@@ -113,7 +113,7 @@ def live_pmc(args):
     for group in PMC_GROUPS:
         d = tempfile.mkdtemp(prefix="vspg_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc"] + group + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
-               "--workload", args.workload, "--xres", str(args.xres), "--yres", str(args.yres), "--grid", str(args.grid), "--steps", "3", "--warmup", "2",
+               "--workload", args.workload, "--xres", str(args.xres), "--yres", str(args.yres), "--grid", str(args.grid), "--cloud-shape", args.cloud_shape, "--steps", "3", "--warmup", "2",
                "--train-waves", str(min(args.train_waves, 8))]
         try:
             res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -257,6 +257,8 @@ def parse_args():
                     help="DIAGNOSTIC ONLY (not the benchmark config): override maxdepth to time parts of the path")
     ap.add_argument("--train-waves", type=int, default=16, help="fog-guided: in-loop training waves before the timed region")
     ap.add_argument("--grid", type=int, default=256, help="voxels per axis of the cloud workload's density grid")
+    ap.add_argument("--cloud-shape", choices=["noise", "blob"], default="noise",
+                    help="cloud workloads: value noise filling the medium's bounds (default) or the same noise inside a ball with empty space around it")
     ap.add_argument("--no-pmc", action="store_true", help="skip the self-profiling child runs (roofline.issue_bound / live traffic)")
     ap.add_argument("--no-reference-defaults", action="store_true", help="skip the reference-default-options leg of the default line")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 watches: waves only, no output
@@ -312,8 +314,8 @@ def main():
     W, H = args.xres, args.yres
     fog = args.workload in ("fog", "fog-guided")
     guided = args.workload.endswith("-guided")
-    scene = (pkg.fog_box_scene(W, H) if fog else pkg.cloud_box_scene(W, H, args.grid) if args.workload in ("cloud", "cloud-guided")
-             else pkg.nanovdb_box_scene(W, H, args.grid))
+    scene = (pkg.fog_box_scene(W, H) if fog else pkg.cloud_box_scene(W, H, args.grid, shape=args.cloud_shape) if args.workload in ("cloud", "cloud-guided")
+             else pkg.nanovdb_box_scene(W, H, args.grid, shape=args.cloud_shape))
     prm = pkg.app_f_params()
     if args.diag_maxdepth is not None:
         prm.maxdepth = args.diag_maxdepth
@@ -436,8 +438,9 @@ def main():
                   "primary + secondary VSP), field trained in-loop for %d waves before the timed region" % (W, H, args.train_waves))
         else:
             metric = "Mpaths/sec on a procedural %d^3 cloud grid (not BASELINE.json's metric workload)" % args.grid
-            wl = "cloud-box %dx%d, %s %d^3 value noise, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
-                W, H, "GridMedium" if args.workload in ("cloud", "cloud-guided") else "NanoVDBMedium (brick layout, 64^3 majorants)", args.grid)
+            wl = "cloud-box %dx%d, %s %d^3 value noise%s, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
+                W, H, "GridMedium" if args.workload in ("cloud", "cloud-guided") else "NanoVDBMedium (brick layout, 64^3 majorants)", args.grid,
+                " inside a ball (80 % empty voxels)" if args.cloud_shape == "blob" else "")
             if guided:  # config 5's shape: secondary-ray VSP + cache train + query on a heterogeneous medium
                 wl += ("; the reference's default options (surface RIS + volume MIS guiding, primary + secondary VSP), field trained "
                        "in-loop for %d waves before the timed region" % args.train_waves)

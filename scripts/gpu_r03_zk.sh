@@ -1,0 +1,15 @@
+#!/bin/bash
+# all-zero majorant cells crossed inside one walk_advance call: parity tests, then noise / blob clouds with and without it
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/r03zk
+mkdir -p $OUT; : > $OUT/ab.txt
+cd $REPO
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "grid or nvdb or cloud or wavefront or placed or config5 or nds" > $OUT/tests.log 2>&1
+echo "tests rc=$?"; tail -3 $OUT/tests.log
+grep -q "failed\|error" $OUT/tests.log && exit 1
+for rep in 1 2; do
+for wl in cloud cloud-nvdb; do
+for shape in noise blob; do
+for lib in "" build/variants/noskip.so; do
+  env ${lib:+VSPG_LIB=$PWD/$lib} timeout -k 10 300 python bench.py --workload $wl --cloud-shape $shape --steps 8 --warmup 2 --no-cpu-baseline --no-pmc 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('rep$rep $wl $shape ${lib:-default} ms %.3f value %.1f seg/path %.2f dq/path %.1f' % (d['ms_per_step'], d['value'], d['config']['mean_segments_per_path'], d['roofline']['density_queries_per_path']))" | tee -a $OUT/ab.txt
+done; done; done; done

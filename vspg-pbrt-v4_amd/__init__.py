@@ -234,10 +234,12 @@ def fog_box_scene(xres, yres):
     return s
 
 
-def procedural_cloud_density(n, seed=5):
+def procedural_cloud_density(n, seed=5, shape="noise"):
     """Seeded value noise, density in [0, ~1.3], ~25-30 % empty voxels, x fastest (the layout
     cmd/nanovdb2pbrt.cpp dumps for GridMedium): the heterogeneous stand-in of SURVEY.md 8d until a
-    Disney-cloud asset is supplied."""
+    Disney-cloud asset is supplied.  shape="blob": the same noise inside a soft-edged ball of radius 0.36 n around the
+    grid's centre and nothing outside it (~80 % empty voxels, empty majorant cells all around: what a real cloud in
+    its bounding box looks like to the majorant grid)."""
     import numpy as np
     rng = np.random.default_rng(seed)
     coarse = rng.random((n // 4 + 2,) * 3).astype(np.float32)
@@ -253,14 +255,18 @@ def procedural_cloud_density(n, seed=5):
 
     v = interp(interp(interp(coarse, 0), 1), 2)
     v = np.clip(v * 2.2 - 0.75, 0.0, None)
+    if shape == "blob":
+        c = (np.arange(n, dtype=np.float32) + 0.5) / n - 0.5
+        r = np.sqrt(c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2)
+        v = (v + 0.35) * np.clip((0.36 - r) / 0.06, 0.0, 1.0).astype(np.float32)
     return np.ascontiguousarray(v.transpose(2, 1, 0).reshape(-1).astype(np.float32))
 
 
-def cloud_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5):
+def cloud_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5, shape="noise"):
     """Fog-box geometry and light with the homogeneous fog replaced by a procedural n^3 GridMedium
     (sigma_t scale 8, albedo 0.99, g 0.877 -- SURVEY.md 8d's cloud-like choice)."""
     s = fog_box_scene(xres, yres)
-    dens = procedural_cloud_density(n, seed)
+    dens = procedural_cloud_density(n, seed, shape)
     m = s.medium
     m.type = MEDIUM_GRID
     m.sigma_a[:] = (sigma_t * (1 - albedo),) * 3
@@ -274,10 +280,10 @@ def cloud_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5
     return s
 
 
-def nanovdb_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5, density_offset=0.0, majorant_scale=1.0):
+def nanovdb_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5, density_offset=0.0, majorant_scale=1.0, shape="noise"):
     """Same cloud, handed over as a NanoVDBMedium (dense copy): index bbox [0, n-1]^3, cubic voxels, the world
     bounding box covers the voxel extents (what cmd/nanovdb2pbrt.cpp reads from the grid); 64^3 majorants."""
-    s = cloud_box_scene(xres, yres, n, sigma_t, albedo, g, seed)
+    s = cloud_box_scene(xres, yres, n, sigma_t, albedo, g, seed, shape)
     m = s.medium
     m.type = MEDIUM_NANOVDB
     ext = [m.bounds_max[k] - m.bounds_min[k] for k in range(3)]

@@ -441,13 +441,18 @@ template <class Medium, bool CAP>
 VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out) {
     if (!w.in_seg) {
         MajSeg seg;
+        // (An empty cell costs a whole tracking round here -- T_maj *= FastExp(-0) == 1 and nothing else.  Crossing a RUN of empty
+        // cells inside this call was tried: bit-identical, and up to 2x slower on a cloud with empty space around it -- the lanes in
+        // the run spin while the rest of the wavefront waits, where the round structure keeps everyone stepping.  HISTORY.)
         if (!w.iter.next(&seg)) return WALK_END;
         seg.sigma_maj = seg.sigma_maj * scale;
         const float smaj = ch_of(seg.sigma_maj, ch);
         if (smaj == 0) {
-            float dt = seg.tMax - seg.tMin;
-            if (isinf_(dt)) dt = kFltMax;
-            w.T_maj = w.T_maj * fast_exp(seg.sigma_maj * -dt);
+            if (nonzero(seg.sigma_maj)) {  // (zero in every channel: the factor is FastExp(-0) == 1 exactly, and x * 1 is x)
+                float dt = seg.tMax - seg.tMin;
+                if (isinf_(dt)) dt = kFltMax;
+                w.T_maj = w.T_maj * fast_exp(seg.sigma_maj * -dt);
+            }
             return WALK_MOVED;
         }
         w.sigma_maj = seg.sigma_maj;
