@@ -2452,13 +2452,15 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
         if (it > 0 && !serial) HIPCHK(hipStreamWaitEvent(s, r->wf_ev_shadow, 0));
         hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
         if (it < r->prm.maxdepth) {
+            // (guided: the next segments begin BEFORE the shadow walk starts -- launched after it, the dense begin kernel crawled in
+            // the slots the persistent walk left over and the next distance walk waited for it)
+            if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it + 1);
             if (!serial) {
                 HIPCHK(hipEventRecord(r->wf_ev_vertex, s));
                 HIPCHK(hipStreamWaitEvent(s2, r->wf_ev_vertex, 0));
             }
             hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s2, a, it);
             if (!serial) HIPCHK(hipEventRecord(r->wf_ev_shadow, s2));
-            if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it + 1);
         }
     }
     HIPCHK(hipGetLastError());

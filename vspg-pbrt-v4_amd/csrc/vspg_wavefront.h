@@ -589,7 +589,11 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
         // media keep it: with a zero majorant in the hero channel only, the early return and the traversal differ in
         // the other channels of T_maj.)
         float totalLength = 0.f;
+#ifdef VSPG_WF_EXPERIMENT_NO_PREPASS  // (timing experiment only, WRONG results: what does the sweep cost?)
+        if (false) {
+#else
         if (guide || !Medium::kGrey) {
+#endif
             auto pre = iter;
             while (true) {
                 MajSeg seg;
