@@ -152,7 +152,7 @@ struct WfPool {
 // per-iteration control block (one per path-loop iteration, zeroed once per launch of the pipeline)
 struct WfIter {
     unsigned int n_active;       // list entries of this iteration: paths with a segment in flight (+ WFL_DEAD ones awaiting their NEE)
-    unsigned int n_unused;
+    unsigned int dense_head;     // chunk cursor of this iteration's vertex kernel (VSPG_WF_DENSE_CLAIM)
     unsigned int n_walk;         // distance-walk jobs
     unsigned int n_shadow;       // shadow-walk jobs
     unsigned int walk_head;      // job cursors of the two walk kernels
@@ -215,6 +215,12 @@ VDEV void wf_pixel_of(unsigned slot, unsigned tilesX, int *px, int *py) {
 // kWfStageRounds rounds in LDS (wave ballot + prefix count + one LDS atomic per wavefront) and flushes them with ONE
 // global atomic.  List order is irrelevant: every path's result depends on its own state only.
 constexpr int kWfStageRounds = 4;
+// The dense kernels' list walk.  Static: workgroup b takes chunks b, b + G, ... (grid stride).  Claimed (VSPG_WF_DENSE_CLAIM, the
+// vertex kernel): chunks of one workgroup's width from a cursor, one returning atomic and one barrier per chunk -- a chunk's cost
+// follows what its paths do (ended, NEE or not, hit or escape), so static shares end on their slowest chunks.
+#ifndef VSPG_WF_DENSE_CLAIM
+#define VSPG_WF_DENSE_CLAIM 1
+#endif
 struct WfStage {
     unsigned int *buf;   // LDS, kWfStageRounds * block entries
     unsigned int *cnt;   // LDS
@@ -1033,7 +1039,16 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
     __syncthreads();
     const WfStage stA{s_stage[0], &s_cnt[0]}, stB{s_stage[1], &s_cnt[1]}, stC{s_stage[2], &s_cnt[2]};
     int round = 0;
+#if VSPG_WF_DENSE_CLAIM
+    __shared__ unsigned int s_chunk[2];
+    for (;; ++round) {
+        if (threadIdx.x == 0) s_chunk[round & 1] = atomicAdd(&I->dense_head, (unsigned)kWfBlock);
+        __syncthreads();  // (two slots: the next claim is written while a slow wavefront may still be reading this one)
+        const unsigned base = s_chunk[round & 1];
+        if (base >= n) break;
+#else
     for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
+#endif
         const unsigned idx = base + threadIdx.x;
         bool next = false, walk = false, shadow = false;  // next: the slot goes onto the next iteration's list
         unsigned slot = 0;
