@@ -1244,7 +1244,16 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
     __syncthreads();
     const WfStage stA{s_stage[0], &s_cnt[0]}, stC{s_stage[1], &s_cnt[1]};
     int round = 0;
+#if VSPG_WF_DENSE_CLAIM   // (here a chunk holds whole distance walks: their lengths differ by orders of magnitude)
+    __shared__ unsigned int s_chunk[2];
+    for (;; ++round) {
+        if (threadIdx.x == 0) s_chunk[round & 1] = atomicAdd(&I->dense_head, (unsigned)kWfBlock);
+        __syncthreads();
+        const unsigned base = s_chunk[round & 1];
+        if (base >= n) break;
+#else
     for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
+#endif
         const unsigned idx = base + threadIdx.x;
         bool next = false, shadow = false;
         unsigned slot = 0;
