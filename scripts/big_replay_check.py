@@ -43,5 +43,36 @@ P.add_infinite_light(tri, P.LIGHT_UNIFORM_INFINITE, (0.35, 0.5, 0.9))
 P.add_infinite_light(tri, P.LIGHT_DISTANT, (9.0, 8.0, 6.5), (0.3, 1.0, -0.4))
 prm = P.app_f_params(); prm.lightsampler = 0
 ok &= check("fog + 20k triangles + sky + sun", tri, prm, 60000)
+# round 3: five lights of very different power (dim floor, bright one-sided panel, two-sided panel, sky, sun) under the BVH and the
+# power light samplers, fog with the reference's default guiding on top
+def multi_light():
+    sc = P.fog_box_scene(W, H)
+    for k in range(3):
+        sc.medium.sigma_a[k] = 0.02; sc.medium.sigma_s[k] = 0.25
+    floor = type(sc.quads[0]).from_buffer_copy(sc.quads[0])
+    for i in range(P.VSPG_MAX_QUADS):
+        sc.quads[i] = type(floor)()
+    sc.quads[0] = floor
+    sc.quads[0].Le[:] = (0.25, 0.2, 0.15)
+
+    def panel(k, p00, e1, e2, Le, two_sided):
+        q = type(floor)()
+        q.p00[:], q.e1[:], q.e2[:] = p00, e1, e2
+        q.Kd[:] = (0.5, 0.5, 0.5); q.Le[:] = Le; q.two_sided = two_sided
+        sc.quads[k] = q
+    panel(1, (-0.15, 0.7, 0.1), (0.3, 0, 0), (0, 0, 0.3), (30.0, 24.0, 12.0), 0)
+    panel(2, (-0.75, -0.2, 0.4), (0, 0.5, 0), (0, 0, 0.4), (2.0, 4.0, 9.0), 1)
+    sc.n_quads = 3
+    t2, kd2 = scenes.heightfield_triangles(40, y=-0.75, amp=0.2)
+    P.set_triangles(sc, t2, kd2)
+    P.add_infinite_light(sc, P.LIGHT_UNIFORM_INFINITE, (0.35, 0.5, 0.9))
+    P.add_infinite_light(sc, P.LIGHT_DISTANT, (9.0, 8.0, 6.5), (0.3, 1.0, -0.4))
+    return sc
+ml = multi_light()
+for name, ls in (("bvh", P.LIGHTSAMPLER_BVH), ("power", P.LIGHTSAMPLER_POWER)):
+    prm = P.app_f_params(); prm.lightsampler = ls
+    ok &= check("five lights, %s light sampler" % name, ml, prm, 60000)
+prm = P.default_params(); prm.lightsampler = P.LIGHTSAMPLER_BVH
+ok &= check("five lights, bvh sampler, guided", ml, prm, 40000, scenes.light_field(P, n=4, light=(0.3, 5.0, -0.4)))
 print("ALL BIT-IDENTICAL" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
