@@ -1064,6 +1064,9 @@ VDEV float isg_code(const IsgSample &isg) {
     const float q = isg.vsp_used >= 0.f ? isg.vsp_used : 0.5f;
     return isg.surface_event ? -q : q;
 }
+#ifndef VSPG_WG2_UNIT_SHIFT
+#define VSPG_WG2_UNIT_SHIFT 6
+#endif
 // one parked sample {L, ISG code} into the film and the image-space statistics (RGBFilm::AddSample + ISG AddSample, the
 // read-modify-write forms: one writer per pixel)
 __device__ __forceinline__ void resolve_sample(float4 s, float4 *film_px, float *isg_px) {
@@ -1092,6 +1095,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     // the workgroups finish their static shares at different times (a share's cost follows what its pixels see), and without the
     // shared tail every one of them ended on its own slowest tiles
     const unsigned n_static = static_tiles < n_tiles ? static_tiles : n_tiles;
+    constexpr unsigned kUnitShift = VSPG_WG2_UNIT_SHIFT, kUnit = 1u << kUnitShift;
     const unsigned local_tiles = blockIdx.x < n_static ? (n_static - blockIdx.x + gridDim.x - 1) / gridDim.x : 0u;
     const unsigned local_total = local_tiles * 64u;
     reset_sibling_head(work_head);
@@ -1172,13 +1176,14 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
         // own share started: whole tiles from the shared tail for the free slots (one returning atomic per claim).  Every thread
         // takes this branch or none: its condition reads values written at least one barrier ago (the done flag travels by parity).
         unsigned dynBase = 0, nDyn = 0;
-        if (left == 0u && nFree >= 64u && n_static < n_tiles && !s_dyn_done[par]) {
+        // (the head counts UNITS of 2^kUnitShift work items -- a tile, or half / a quarter of one: smaller units leave fewer slots idle)
+        if (left == 0u && nFree >= kUnit && n_static < n_tiles && !s_dyn_done[par]) {
             if (threadIdx.x == 0) {
-                const unsigned m = nFree >> 6, n_dyn = n_tiles - n_static;
+                const unsigned m = nFree >> kUnitShift, n_dyn = (n_tiles - n_static) << (6 - kUnitShift);
                 const unsigned b = atomicAdd(work_head, m);
                 const unsigned got = b < n_dyn ? (m < n_dyn - b ? m : n_dyn - b) : 0u;
-                s_dyn[0] = n_static + b;
-                s_dyn[1] = got * 64u;
+                s_dyn[0] = (n_static << (6 - kUnitShift)) + b;
+                s_dyn[1] = got << kUnitShift;
                 if (got < m) s_dyn_done[nxt] = 1u;
             }
             __syncthreads();
@@ -1216,7 +1221,9 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                     if (i < nFresh) {
                         slot = s_free[par][i];
                         const unsigned item = lnext + i;
-                        const unsigned tile = left > 0u ? (item >> 6) * gridDim.x + blockIdx.x : dynBase + (i >> 6), l = (left > 0u ? item : i) & 63u;
+                        const unsigned unit = dynBase + (i >> kUnitShift);  // (claimed items only)
+                        const unsigned tile = left > 0u ? (item >> 6) * gridDim.x + blockIdx.x : unit >> (6 - kUnitShift);
+                        const unsigned l = left > 0u ? item & 63u : ((unit & ((1u << (6 - kUnitShift)) - 1u)) << kUnitShift) + (i & (kUnit - 1u));
                         unsigned ty = tilesX == 1 ? tile : __umulhi(tile, tiles_magic);
                         unsigned tx = tile - ty * (unsigned)tilesX;
                         while (tx >= (unsigned)tilesX) { tx -= (unsigned)tilesX; ty++; }
