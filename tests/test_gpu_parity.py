@@ -376,9 +376,11 @@ def test_workgroup_schedulers_are_bit_identical(gpu_pkg, W, H):
     scene = P.fog_box_scene(W, H)
     for env in ({"VSPG_NO_GREY": "1"}, {"VSPG_NO_GREY_KD": "1"}, {"VSPG_NO_NULLZERO": "1"}, {}):
         out = []
-        for sched in ("1", "2"):
+        for sched in ("1", "2", "2 mixed"):   # "mixed": 3/8 of the frame from the global tile head, the rest dealt out up front
             os.environ.update(env)
-            os.environ["VSPG_WG_SCHED"] = sched
+            os.environ["VSPG_WG_SCHED"] = sched[0]
+            if sched.endswith("mixed"):
+                os.environ["VSPG_WG2_TAIL"] = "24"
             try:
                 r = P.Renderer(scene, P.app_f_params(), W, H, seed=3)
                 for w in range(3):
@@ -392,11 +394,13 @@ def test_workgroup_schedulers_are_bit_identical(gpu_pkg, W, H):
                 r.close()
             finally:
                 os.environ.pop("VSPG_WG_SCHED", None)
+                os.environ.pop("VSPG_WG2_TAIL", None)
                 for k in env:
                     os.environ.pop(k, None)
-        assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), env
-        assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32)), env
-        assert out[0][2] == out[1][2] and out[0][2]["paths"] == 7 * W * H, (env, out[0][2], out[1][2])
+        for other in out[1:]:
+            assert np.array_equal(out[0][0].view(np.uint32), other[0].view(np.uint32)), env
+            assert np.array_equal(out[0][1].view(np.uint32), other[1].view(np.uint32)), env
+            assert out[0][2] == other[2] and out[0][2]["paths"] == 7 * W * H, (env, out[0][2], other[2])
 
 
 @pytest.mark.parametrize("guided", [False, True])

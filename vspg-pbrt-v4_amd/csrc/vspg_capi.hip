@@ -3032,7 +3032,9 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
     if (blocks > max_blocks) blocks = max_blocks;
     const long long n_waves = blocks * (kBlock / 64);
     // static slice per wavefront: 3/4 of the fair share, whole tiles
-    const unsigned static_per_wave = (unsigned)((items * 3 / 4 / n_waves) / 64 * 64);
+    // (VSPG_LANE_STATIC: the static share in 64ths, default 48 = 3/4)
+    static const int lane_static64 = [] { const char *e = getenv("VSPG_LANE_STATIC"); const int v = e ? atoi(e) : 48; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+    const unsigned static_per_wave = (unsigned)((items * lane_static64 / 64 / n_waves) / 64 * 64);
     const unsigned dyn_base = (unsigned)(static_per_wave * n_waves);
     // first sample index of this shard in the range, and how many it has
     const int sc = r->cfg.shard_count, si = r->cfg.shard_index;
@@ -3140,7 +3142,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             // the share of the frame handed out from the global head, in 64ths (VSPG_WG2_TAIL; the rest is dealt to the workgroups
             // up front, interleaved).  Measured on the reference-default guided workload / the unguided one (ms per 1080p wave):
             // 0: 1.59 / 0.887, 8: 1.50 / 0.829, 16: 1.46 / 0.800, 32: 1.47 / 0.790, 64 (all of it): 1.454 / 0.775.
-            static const int tail64 = [] { const char *e = getenv("VSPG_WG2_TAIL"); const int v = e ? atoi(e) : 64; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+            const int tail64 = [] { const char *e = getenv("VSPG_WG2_TAIL"); const int v = e ? atoi(e) : 64; return v < 0 ? 0 : (v > 64 ? 64 : v); }();  // (per launch: a test varies it)
             const unsigned static_tiles = (unsigned)((n_tiles * (64 - tail64) / 64) / wblocks * wblocks);
 #define VSPG_LAUNCH_WG2(M, G, NPOOL, BLK, WV)                                                                                         \
     hipLaunchKernelGGL((k_render_wave_wg2<M, G, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
