@@ -2408,6 +2408,10 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     a.counters = r->counters;
     a.train = TrainArgs{nullptr, nullptr, nullptr, nullptr, 0, 0};
     a.rec_cap = train_rec_capacity(r->prm.maxdepth);
+    {   // (VSPG_WF_COMPACT=0: the full layout for a grey medium too -- same results, for A/B runs)
+        const char *e = getenv("VSPG_WF_COMPACT");
+        a.compact_results = WalkMedium::kGrey != 0 && !(e && e[0] == '0') ? 1 : 0;
+    }
     if (TRAIN) {  // a18: the pass records path segments; PropagateSamples (k_propagate) follows it
         a.train = TrainArgs{r->segbuf, r->seg_count, r->samples, r->train_counters, r->sample_capacity, (unsigned)items};
         HIPCHK(hipMemsetAsync(r->seg_count, 0, items * sizeof(int), s));

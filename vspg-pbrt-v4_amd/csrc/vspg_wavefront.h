@@ -149,6 +149,65 @@ struct WfPool {
     }
 };
 
+// ---- what the walk kernels hand back, and where -----------------------------------------------------------------------------
+// A grey medium's walk (the walk kernels' kGrey instantiations) works on spectra with three equal channels: its results travel as
+// ONE float apiece, packed into two quads (+ the selected position's) instead of seven, and the shadow walk's four spectra into
+// one -- every quad a lane touches costs a line once the lists have thinned out (11 of the ~60 quad accesses of a path-loop
+// iteration).  `compact` (WfArgs::compact_results) is what both sides agree on: the host sets it from the walk medium's kGrey.
+struct WfWalkResult {
+    Spec T_maj, trRatioEst, beta_rs, r_u_rs, sel_num, sel_den;
+    float weightSum, sel_wi;
+    V3 sel_p;
+};
+VDEV void wf_store_walk_result(const WfPool &P, unsigned slot, bool compact, const WfWalkResult &r) {
+    if (compact) {
+        P.f(WF_TMAJ + 0, slot) = r.T_maj.r; P.f(WF_TMAJ + 1, slot) = r.trRatioEst.r; P.f(WF_TMAJ + 2, slot) = r.beta_rs.r; P.f(WF_WSUM, slot) = r.weightSum;
+        P.f(WF_TRR + 0, slot) = r.r_u_rs.r; P.f(WF_TRR + 1, slot) = r.sel_num.r; P.f(WF_TRR + 2, slot) = r.sel_den.r; P.f(WF_SELW, slot) = r.sel_wi;
+    } else {
+        P.sets(WF_TMAJ, slot, r.T_maj);
+        P.f(WF_WSUM, slot) = r.weightSum;
+        P.sets(WF_TRR, slot, r.trRatioEst);
+        P.sets(WF_BRS, slot, r.beta_rs);
+        P.sets(WF_RURS, slot, r.r_u_rs);
+        P.f(WF_SELW, slot) = r.sel_wi;
+        P.sets(WF_SELNUM, slot, r.sel_num);
+        P.sets(WF_SELDEN, slot, r.sel_den);
+    }
+    P.set3(WF_SELP, slot, r.sel_p);
+}
+VDEV WfWalkResult wf_load_walk_result(const WfPool &P, unsigned slot, bool compact) {
+    WfWalkResult r;
+    if (compact) {
+        r.T_maj = sp(P.f(WF_TMAJ + 0, slot)); r.trRatioEst = sp(P.f(WF_TMAJ + 1, slot)); r.beta_rs = sp(P.f(WF_TMAJ + 2, slot));
+        r.r_u_rs = sp(P.f(WF_TRR + 0, slot)); r.sel_num = sp(P.f(WF_TRR + 1, slot)); r.sel_den = sp(P.f(WF_TRR + 2, slot));
+    } else {
+        r.T_maj = P.sp3(WF_TMAJ, slot);
+        r.trRatioEst = P.sp3(WF_TRR, slot);
+        r.beta_rs = P.sp3(WF_BRS, slot);
+        r.r_u_rs = P.sp3(WF_RURS, slot);
+        r.sel_num = P.sp3(WF_SELNUM, slot);
+        r.sel_den = P.sp3(WF_SELDEN, slot);
+    }
+    r.weightSum = P.f(WF_WSUM, slot);
+    r.sel_wi = P.f(WF_SELW, slot);
+    r.sel_p = P.v3(WF_SELP, slot);
+    return r;
+}
+// (the VSP the segment is guided with sits in the selected position's quad then: one quad fewer for the vertex kernel)
+VDEV int wf_vspg_field(bool compact) { return compact ? WF_SELP + 3 : WF_VSPG; }
+struct WfShadowResult { Spec T_ray, r_l, r_u, T_res; };
+VDEV void wf_store_shadow_result(const WfPool &P, unsigned slot, bool compact, const WfShadowResult &r) {
+    if (compact) {
+        P.f(WF_TRAY + 0, slot) = r.T_ray.r; P.f(WF_TRAY + 1, slot) = r.r_l.r; P.f(WF_TRAY + 2, slot) = r.r_u.r; P.f(WF_TRAY + 3, slot) = r.T_res.r;
+    } else {
+        P.sets(WF_TRAY, slot, r.T_ray); P.sets(WF_SRL, slot, r.r_l); P.sets(WF_SRU, slot, r.r_u); P.sets(WF_STMAJ, slot, r.T_res);
+    }
+}
+VDEV WfShadowResult wf_load_shadow_result(const WfPool &P, unsigned slot, bool compact) {
+    if (compact) return WfShadowResult{sp(P.f(WF_TRAY + 0, slot)), sp(P.f(WF_TRAY + 1, slot)), sp(P.f(WF_TRAY + 2, slot)), sp(P.f(WF_TRAY + 3, slot))};
+    return WfShadowResult{P.sp3(WF_TRAY, slot), P.sp3(WF_SRL, slot), P.sp3(WF_SRU, slot), P.sp3(WF_STMAJ, slot)};
+}
+
 // per-iteration control block (one per path-loop iteration, zeroed once per launch of the pipeline)
 struct WfIter {
     unsigned int n_active;       // list entries of this iteration: paths with a segment in flight (+ WFL_DEAD ones awaiting their NEE)
@@ -180,6 +239,7 @@ struct WfArgs {
     int walk_refill;             // a walk wavefront refills its idle lanes once this many are idle
     TrainArgs train;             // training passes (a18): the wave's segment-record buffer; k_propagate runs after the pass
     int rec_cap;                 // records a path may keep (train_rec_capacity)
+    int compact_results;         // the walk kernels run a grey medium: their results travel packed (wf_store_walk_result)
 };
 // the recorder of a path between two kernels of a training pass: records go straight to the path's column of the wave's
 // buffer; n / cur / flags travel in the path record.  (scat_*: a record sees at most one NEE.)
@@ -612,7 +672,7 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
             totalLength = 1.f;  // (only its being non-zero matters below)
         }
         if (guide) extra |= WFL_GUIDE;
-        P.f(WF_VSPG, slot) = vsp;
+        P.f(wf_vspg_field(a.compact_results != 0), slot) = vsp;
         if (totalLength == 0.f) {
             extra |= WFL_NOWALK;
         } else {
@@ -842,15 +902,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
         const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
         if (n_idle == 64u || (n_idle >= (unsigned)a.walk_refill && !(claim.exhausted && claim.next >= claim.end))) {
             if (result) {  // park the finished walks' results
-                P.sets(WF_TMAJ, slot, w.T_maj);
-                P.f(WF_WSUM, slot) = weightSum;
-                P.sets(WF_TRR, slot, trRatioEst);
-                P.sets(WF_BRS, slot, beta_rs);
-                P.sets(WF_RURS, slot, r_u_rs);
-                P.set3(WF_SELP, slot, sel_p);
-                P.f(WF_SELW, slot) = sel_wi;
-                P.sets(WF_SELNUM, slot, sel_num);
-                P.sets(WF_SELDEN, slot, sel_den);
+                wf_store_walk_result(P, slot, a.compact_results != 0, WfWalkResult{w.T_maj, trRatioEst, beta_rs, r_u_rs, sel_num, sel_den, weightSum, sel_wi, sel_p});
                 P.store_rng(WF_RNG, slot, sampler.rng);
                 result = false;
             }
@@ -1063,8 +1115,9 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
             bool alive = false;
             // ---- the previous vertex's NEE, if its shadow walk was out (:483 / :836 from the estimate on) ----------------
             if (fl & WFL_SHADOW_WALK) {
-                const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, P.sp3(WF_TRAY, slot), P.sp3(WF_SRL, slot), P.sp3(WF_SRU, slot),
-                                                 P.sp3(WF_STMAJ, slot), ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
+                const WfShadowResult sr = wf_load_shadow_result(P, slot, a.compact_results != 0);
+                const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, sr.T_ray, sr.r_l, sr.r_u,
+                                                 sr.T_res, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
                                                  P.f(WF_SPDF, slot), st.r_u);  // (the vertex code after the NEE leaves r_u alone)
                 st.L = st.L + P.sp3(WF_BNEE, slot) * Ld;
                 if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);  // :485 / :838 (add_scatter_data keeps the SCAT bit)
@@ -1099,20 +1152,14 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                 if (!(fl & WFL_NODIST)) {
                     // ---- sample_distance after the traversal (:721-802) ---------------------------------------------
                     const bool guide = (fl & WFL_GUIDE) != 0;
-                    const float vsp = P.f(WF_VSPG, slot);
+                    const float vsp = P.f(wf_vspg_field(a.compact_results != 0), slot);
                     float weightSum = 0, sel_wi = 0, vrc = 0;
                     Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f), sel_num = sp(0.f), sel_den = sp(0.f), T_maj = sp(1.f);
                     V3 sel_p = mk(0, 0, 0);
                     if (!(fl & WFL_NOWALK)) {
-                        T_maj = P.sp3(WF_TMAJ, slot);
-                        weightSum = P.f(WF_WSUM, slot);
-                        trRatioEst = P.sp3(WF_TRR, slot);
-                        beta_rs = P.sp3(WF_BRS, slot);
-                        r_u_rs = P.sp3(WF_RURS, slot);
-                        sel_p = P.v3(WF_SELP, slot);
-                        sel_wi = P.f(WF_SELW, slot);
-                        sel_num = P.sp3(WF_SELNUM, slot);
-                        sel_den = P.sp3(WF_SELDEN, slot);
+                        const WfWalkResult wr = wf_load_walk_result(P, slot, a.compact_results != 0);
+                        T_maj = wr.T_maj; weightSum = wr.weightSum; trRatioEst = wr.trRatioEst; beta_rs = wr.beta_rs; r_u_rs = wr.r_u_rs;
+                        sel_p = wr.sel_p; sel_wi = wr.sel_wi; sel_num = wr.sel_num; sel_den = wr.sel_den;
                         vrc = P.f(WF_VRC, slot);
                         P.load_rng(WF_RNG, slot, sampler.rng);  // the traversal drew one sampler dimension per candidate (:702)
                     }
@@ -1280,8 +1327,9 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
                 if constexpr (TRAIN) wf_rec_load(a, slot, pc.rec);
                 if constexpr (GUIDED) st.gs.vsp_next = P.f(WF_GSVSP, slot);
                 if (fl & WFL_SHADOW_WALK) {  // the previous vertex's NEE (:483 / :836 from the estimate on)
-                    const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, P.sp3(WF_TRAY, slot), P.sp3(WF_SRL, slot), P.sp3(WF_SRU, slot),
-                                                     P.sp3(WF_STMAJ, slot), ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
+                    const WfShadowResult sr = wf_load_shadow_result(P, slot, a.compact_results != 0);
+                    const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, sr.T_ray, sr.r_l, sr.r_u,
+                                                     sr.T_res, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
                                                      P.f(WF_SPDF, slot), st.r_u);
                     st.L = st.L + P.sp3(WF_BNEE, slot) * Ld;
                     if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);
@@ -1348,10 +1396,7 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
         const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
         if (n_idle == 64u || (n_idle >= (unsigned)a.walk_refill && !(claim.exhausted && claim.next >= claim.end))) {
             if (result) {
-                P.sets(WF_TRAY, slot, T_ray);
-                P.sets(WF_SRL, slot, r_l);
-                P.sets(WF_SRU, slot, r_u);
-                P.sets(WF_STMAJ, slot, T_res);
+                wf_store_shadow_result(P, slot, a.compact_results != 0, WfShadowResult{T_ray, r_l, r_u, T_res});
                 result = false;
             }
             unsigned ns = 0;
