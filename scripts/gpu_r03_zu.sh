@@ -1,0 +1,10 @@
+#!/bin/bash
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/r03zu
+mkdir -p $OUT
+cd $REPO
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_nvdb_reader.py -x -q -m gpu -k "grid or nvdb or cloud or wavefront or placed or config5 or nds" > $OUT/tests.log 2>&1
+echo "tests rc=$?"; tail -3 $OUT/tests.log
+grep -q "failed\|error" $OUT/tests.log && exit 1
+WORKLOADS="cloud cloud-nvdb cloud-guided" bash scripts/gpu_variants_wl.sh
+cp gpurun_out/variants_wl.txt $OUT/

@@ -59,7 +59,7 @@ enum {
     WF_L = 8,         // 3                        | +3: WF_FLAGS
     WF_FLAGS = 11,    // 1  packed like the LDS pool's (vspg_wg_kernel.h) + WFL_* bits
     WF_BETA = 12,     // 3                        | +3: WF_SURV
-    WF_SURV = 15,     // 1  survivalProb of the vertex
+    WF_SURV = 15,     // 1  (was: survivalProb of the vertex) now WF_VRC: vsp / (1 - exp(-tau)) of the segment in flight (media_sampleTMaj.h:172)
     WF_RU = 16,       // 3                        | +3: WF_PL
     WF_PL = 19,       // 1  NEE: p_l
     WF_RL = 20,       // 3                        | +3: WF_SPDF
@@ -75,7 +75,7 @@ enum {
     WF_WU = 46,       // 1  first uniform of the walk
     WF_MSCALE = 47,   // 1  majorantScale
     WF_RDN = 48,      // 3  normalised direction  | +3: WF_VRC
-    WF_VRC = 51,      // 1  vsp / (1 - exp(-tau)) (media_sampleTMaj.h:172)
+    WF_VRC = 15,      // 1  in the throughput's quad, which the vertex kernel reads anyway (the walk has no use for it)
     WF_WRNG = 52,     // 4  the walk's private PCG (:323-325 / :1193)
     // distance-walk result
     WF_TMAJ = 56,     // 3                        | +3: WF_WSUM
@@ -83,7 +83,7 @@ enum {
     WF_TRR = 60,      // 3  trRatioEst            | +3: WF_SELW
     WF_SELW = 63,     // 1  selected candidate's weight (0: none selected)
     WF_BRS = 64,      // 3  beta_rs               | +3: WF_VSPG
-    WF_VSPG = 67,     // 1  the VSP the segment is guided with (-1: none)
+    WF_VSPG = 67,     // (unused: nothing downstream of the segment's begin reads the VSP itself, only WF_VRC)
     WF_RURS = 68,     // 3  r_u_rs
     WF_SELP = 72,     // 3  selected candidate: position
     WF_SELNUM = 76,   // 3
@@ -106,8 +106,8 @@ enum {
     WF_RECCUR = 125,  // 1  current record (-1: none)
     WF_RECFL = 126,   // 1  its flags word
     // shadow-walk job (own fields: the shadow walk of iteration i runs beside the distance walk of iteration i + 1)
-    WF_SIT = 128,     // 9  DDA iterator of the shadow ray (as WF_IT)
-    WF_SWU = 137,     // 1  first uniform of the shadow walk
+    WF_SIT = 128,     // 8  DDA iterator of the shadow ray (floats; its packed word: WF_SITP, in the direction's quad)
+    WF_SWU = 137,     // (unused: the shadow walk's first uniform sits in the origin's quad, WF_SWU2)
     WF_SRDN = 140,    // 3  normalised shadow-ray direction
     WF_SWRNG = 144,   // 4  the shadow ray's private PCG (:1193)
     WF_COUNT = 148
@@ -193,8 +193,6 @@ VDEV WfWalkResult wf_load_walk_result(const WfPool &P, unsigned slot, bool compa
     r.sel_p = P.v3(WF_SELP, slot);
     return r;
 }
-// (the VSP the segment is guided with sits in the selected position's quad then: one quad fewer for the vertex kernel)
-VDEV int wf_vspg_field(bool compact) { return compact ? WF_SELP + 3 : WF_VSPG; }
 struct WfShadowResult { Spec T_ray, r_l, r_u, T_res; };
 VDEV void wf_store_shadow_result(const WfPool &P, unsigned slot, bool compact, const WfShadowResult &r) {
     if (compact) {
@@ -309,6 +307,10 @@ struct WfStage {
     }
 };
 
+// With a grey medium r_u and r_l are one float each: they share ONE quad with the NEE's two pdfs -- {r_u, r_l, scatterPDF, p_l}
+// -- instead of two (every quad a lane touches is a line of its own once the lists have thinned out).
+template <int GREY> constexpr int wf_rl_field() { return GREY >= 1 ? WF_RU + 1 : WF_RL; }
+template <int GREY> constexpr int wf_spdf_field() { return GREY >= 1 ? WF_RU + 2 : WF_SPDF; }
 template <int GREY>
 VDEV void wf_store_path(const WfPool &P, unsigned slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                         uint32_t extra_flags) {
@@ -318,7 +320,7 @@ VDEV void wf_store_path(const WfPool &P, unsigned slot, const PathState &st, con
     P.sets(WF_BETA, slot, st.beta);
     if constexpr (GREY >= 1) {
         P.f(WF_RU, slot) = st.r_u.r;
-        P.f(WF_RL, slot) = st.r_l.r;
+        P.f(wf_rl_field<GREY>(), slot) = st.r_l.r;
     } else {
         P.sets(WF_RU, slot, st.r_u);
         P.sets(WF_RL, slot, st.r_l);
@@ -339,7 +341,7 @@ VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sample
     st.beta = P.sp3(WF_BETA, slot);
     if constexpr (GREY >= 1) {
         st.r_u = sp(P.f(WF_RU, slot));
-        st.r_l = sp(P.f(WF_RL, slot));
+        st.r_l = sp(P.f(wf_rl_field<GREY>(), slot));
     } else {
         st.r_u = P.sp3(WF_RU, slot);
         st.r_l = P.sp3(WF_RL, slot);
@@ -366,22 +368,27 @@ VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sample
     return fl;
 }
 
-// DDA iterator <-> 9 dwords
+// DDA iterator <-> 8 floats at F.. + one packed word at FP: voxel (3 x 7 bits), step signs (3 bits), and the path's hero channel
+// (2 bits: the walk kernels read it here instead of fetching the path's flags quad for it).  Distance walk: F = WF_IT, FP = WF_IT + 8
+// (the quad it shares with tHit, the first uniform and the majorant scale); shadow walk: F = WF_SIT, FP = WF_SRDN + 3 (the
+// direction's quad), its first uniform in the origin's quad (WF_SLO + 3) -- eight quads for a shadow job instead of nine.
+constexpr int WF_SITP = WF_SRDN + 3, WF_SWU2 = WF_SLO + 3;
 template <class Iter>
-VDEV void wf_store_iter(const WfPool &P, unsigned slot, const Iter &it, int F = WF_IT) {
+VDEV void wf_store_iter(const WfPool &P, unsigned slot, const Iter &it, int ch, int F = WF_IT, int FP = WF_IT + 8) {
     P.f(F + 0, slot) = it.tMin; P.f(F + 1, slot) = it.tMax;
     P.f(F + 2, slot) = it.ncx; P.f(F + 3, slot) = it.ncy; P.f(F + 4, slot) = it.ncz;
     P.f(F + 5, slot) = it.dtx; P.f(F + 6, slot) = it.dty; P.f(F + 7, slot) = it.dtz;
-    P.u(F + 8, slot) = (uint32_t)it.vx | ((uint32_t)it.vy << 7) | ((uint32_t)it.vz << 14) | ((uint32_t)it.neg << 21);
+    P.u(FP, slot) = (uint32_t)it.vx | ((uint32_t)it.vy << 7) | ((uint32_t)it.vz << 14) | ((uint32_t)it.neg << 21) | ((uint32_t)ch << 24);
 }
 template <class Medium>
-VDEV typename Medium::Iter wf_load_iter(const WfPool &P, unsigned slot, const Medium &medium, int F = WF_IT) {
+VDEV typename Medium::Iter wf_load_iter(const WfPool &P, unsigned slot, const Medium &medium, int *ch, int F = WF_IT, int FP = WF_IT + 8) {
     typename Medium::Iter it = medium.empty_iter();
     it.tMin = P.f(F + 0, slot); it.tMax = P.f(F + 1, slot);
     it.ncx = P.f(F + 2, slot); it.ncy = P.f(F + 3, slot); it.ncz = P.f(F + 4, slot);
     it.dtx = P.f(F + 5, slot); it.dty = P.f(F + 6, slot); it.dtz = P.f(F + 7, slot);
-    const uint32_t pk = P.u(F + 8, slot);
-    it.vx = (int)(pk & 127u); it.vy = (int)((pk >> 7) & 127u); it.vz = (int)((pk >> 14) & 127u); it.neg = (int)(pk >> 21);
+    const uint32_t pk = P.u(FP, slot);
+    it.vx = (int)(pk & 127u); it.vy = (int)((pk >> 7) & 127u); it.vz = (int)((pk >> 14) & 127u); it.neg = (int)((pk >> 21) & 7u);
+    *ch = (int)((pk >> 24) & 3u);
     return it;
 }
 
@@ -672,7 +679,6 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
             totalLength = 1.f;  // (only its being non-zero matters below)
         }
         if (guide) extra |= WFL_GUIDE;
-        P.f(wf_vspg_field(a.compact_results != 0), slot) = vsp;
         if (totalLength == 0.f) {
             extra |= WFL_NOWALK;
         } else {
@@ -686,7 +692,7 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
                 float expNegTotalLength = fast_exp(-totalLength);
                 vrc = vsp / (1 - expNegTotalLength);
             }
-            wf_store_iter(P, slot, iter);
+            wf_store_iter(P, slot, iter, ch);
             P.set3(WF_RDN, slot, rdn);
             P.store_rng(WF_WRNG, slot, rng);
             P.f(WF_WU, slot) = u;
@@ -909,7 +915,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
             unsigned ns = 0;
             if (wf_claim(claim, !active, a.list_walk, n, &I->walk_head, &ns)) {
                 slot = ns;
-                w.iter = wf_load_iter(P, slot, medium);
+                w.iter = wf_load_iter(P, slot, medium, &ch);
                 w.in_seg = false;
                 w.T_maj = sp(1.f);
                 w.u = P.f(WF_WU, slot);
@@ -918,7 +924,6 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
                 ro = P.v3(WF_RO, slot);
                 rdn = P.v3(WF_RDN, slot);
                 scale = P.f(WF_MSCALE, slot);
-                ch = (int)((P.u(WF_FLAGS, slot) >> FL_CH_SHIFT) & 3u);
                 P.load_rng(WF_RNG, slot, sampler.rng);
                 weightSum = 0; sel_wi = 0;
                 trRatioEst = beta_rs = r_u_rs = sp(1.f);
@@ -1029,15 +1034,15 @@ VDEV int wf_vertex(const WfArgs &a, const DScene &S, const Medium &medium, unsig
             if (iter.tMin >= iter.tMax) {
                 ss.status = 2;  // the ray misses the medium's bounds: the walk would return T_maj = 1 at once
             } else {
-                wf_store_iter(P, slot, iter, WF_SIT);
+                wf_store_iter(P, slot, iter, ch, WF_SIT, WF_SITP);
                 P.set3(WF_SRDN, slot, rdn);
                 P.set3(WF_SLO, slot, ss.lo);
                 P.store_rng(WF_SWRNG, slot, ss.rng);
-                P.f(WF_SWU, slot) = ss.us;
+                P.f(WF_SWU2, slot) = ss.us;
                 P.sets(WF_FHAT, slot, ss.f_hat);
                 P.sets(WF_LSL, slot, ss.L);
                 P.f(WF_PL, slot) = ss.p_l;
-                P.f(WF_SPDF, slot) = ss.scatterPDF;
+                P.f(wf_spdf_field<G>(), slot) = ss.scatterPDF;
                 P.sets(WF_BNEE, slot, beta_nee);
                 extra |= WFL_SHADOW_WALK | (ss.delta_light ? (uint32_t)WFL_DELTA : 0u);
                 shadow = true;
@@ -1118,7 +1123,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                 const WfShadowResult sr = wf_load_shadow_result(P, slot, a.compact_results != 0);
                 const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, sr.T_ray, sr.r_l, sr.r_u,
                                                  sr.T_res, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
-                                                 P.f(WF_SPDF, slot), st.r_u);  // (the vertex code after the NEE leaves r_u alone)
+                                                 P.f(wf_spdf_field<G>(), slot), st.r_u);  // (the vertex code after the NEE leaves r_u alone)
                 st.L = st.L + P.sp3(WF_BNEE, slot) * Ld;
                 if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);  // :485 / :838 (add_scatter_data keeps the SCAT bit)
             }
@@ -1152,7 +1157,6 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                 if (!(fl & WFL_NODIST)) {
                     // ---- sample_distance after the traversal (:721-802) ---------------------------------------------
                     const bool guide = (fl & WFL_GUIDE) != 0;
-                    const float vsp = P.f(wf_vspg_field(a.compact_results != 0), slot);
                     float weightSum = 0, sel_wi = 0, vrc = 0;
                     Spec trRatioEst = sp(1.f), beta_rs = sp(1.f), r_u_rs = sp(1.f), sel_num = sp(0.f), sel_den = sp(0.f), T_maj = sp(1.f);
                     V3 sel_p = mk(0, 0, 0);
@@ -1330,7 +1334,7 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
                     const WfShadowResult sr = wf_load_shadow_result(P, slot, a.compact_results != 0);
                     const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, sr.T_ray, sr.r_l, sr.r_u,
                                                      sr.T_res, ch, P.sp3(WF_FHAT, slot), P.sp3(WF_LSL, slot), P.f(WF_PL, slot),
-                                                     P.f(WF_SPDF, slot), st.r_u);
+                                                     P.f(wf_spdf_field<G>(), slot), st.r_u);
                     st.L = st.L + P.sp3(WF_BNEE, slot) * Ld;
                     if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);
                 }
@@ -1402,14 +1406,13 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
             unsigned ns = 0;
             if (wf_claim(claim, !active, a.list_shadow, n, &I->shadow_head, &ns)) {
                 slot = ns;
-                w.iter = wf_load_iter(P, slot, medium, WF_SIT);
+                w.iter = wf_load_iter(P, slot, medium, &ch, WF_SIT, WF_SITP);
                 w.in_seg = false;
                 w.T_maj = sp(1.f);
-                w.u = P.f(WF_SWU, slot);
+                w.u = P.f(WF_SWU2, slot);
                 P.load_rng(WF_SWRNG, slot, w.rng);
                 ro = P.v3(WF_SLO, slot);
                 rdn = P.v3(WF_SRDN, slot);
-                ch = (int)((P.u(WF_FLAGS, slot) >> FL_CH_SHIFT) & 3u);
                 T_ray = r_l = r_u = sp(1.f);
                 active = true;
             }
