@@ -3077,10 +3077,12 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             const hipStream_t hs = (hipStream_t)stream;
             const bool grey = r->medium_grey, tr = r->training;
             int rc;
-            if (guided && nvdb) rc = tr ? (grey ? wf_render_pass<NanoDenseMedium, true, true, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true, true>(r, w, hs))
-                                        : (grey ? wf_render_pass<NanoDenseMedium, true, false, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true>(r, w, hs));
-            else if (guided) rc = tr ? (grey ? wf_render_pass<GridMedium, true, true, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true, true>(r, w, hs))
-                                     : (grey ? wf_render_pass<GridMedium, true, false, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true>(r, w, hs));
+            // (a grey medium runs the kGrey instantiations of the dense kernels too, guided or not: r_u / r_l / the pdfs in one quad,
+            // no per-channel majorant ratios)
+            if (guided && nvdb) rc = tr ? (grey ? wf_render_pass<NanoDenseMediumGrey, true, true, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true, true>(r, w, hs))
+                                        : (grey ? wf_render_pass<NanoDenseMediumGrey, true, false, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true>(r, w, hs));
+            else if (guided) rc = tr ? (grey ? wf_render_pass<GridMediumGrey, true, true, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true, true>(r, w, hs))
+                                     : (grey ? wf_render_pass<GridMediumGrey, true, false, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true>(r, w, hs));
             else if (nvdb) rc = grey ? wf_render_pass<NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium>(r, w, hs);
             else rc = grey ? wf_render_pass<GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium>(r, w, hs);
             if (rc) return rc;
