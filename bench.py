@@ -107,8 +107,14 @@ def live_pmc(args):
 
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not found"
-    if args.workload.endswith("-guided"):
-        return None, "live counters are taken for the unguided workloads (a guided run mixes training and trained launches)"
+    # Never profile from inside a profiled run: the child would inherit the outer profiler's preloaded tool library, which
+    # initialises the GPU in rocprofv3's own `env python3` launcher hop before that hop execs -- the exec of a GPU-initialised
+    # process this pool forbids.  (Scripts that run bench.py under rocprofv3 also pass --no-pmc; this is the belt to that brace.)
+    outer = [k for k in os.environ if k.startswith(("ROCP", "ROCPROF"))]
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB")) or outer:
+        return None, "already under a profiler (%s): no self-profiling" % ", ".join(sorted(set(outer + [k for k in ("LD_PRELOAD", "HSA_TOOLS_LIB") if k in os.environ])))
+    child_env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB") and not k.startswith(("ROCP", "ROCPROF"))}
+    child_env["TMPDIR"] = "/tmp"
     agg = {}
     for group in PMC_GROUPS:
         d = tempfile.mkdtemp(prefix="vspg_pmc_", dir="/tmp")
@@ -116,7 +122,7 @@ def live_pmc(args):
                "--workload", args.workload, "--xres", str(args.xres), "--yres", str(args.yres), "--grid", str(args.grid), "--cloud-shape", args.cloud_shape, "--steps", "3", "--warmup", "2",
                "--train-waves", str(min(args.train_waves, 8))]
         try:
-            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            res = subprocess.run(cmd, cwd="/tmp", env=child_env, timeout=240, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         except Exception as e:  # noqa: BLE001
             shutil.rmtree(d, ignore_errors=True)
             return None, "rocprofv3 child: %s" % e
@@ -125,9 +131,13 @@ def live_pmc(args):
             shutil.rmtree(d, ignore_errors=True)
             return None, "rocprofv3 child rc=%d: %s" % (res.returncode, res.stdout[-300:])
         for f in files:
-            for row in csv.DictReader(open(f)):
+            rows = list(csv.DictReader(open(f)))
+            # a guided child trains its field first: only the launches BEHIND the last training kernel (k_propagate, k_train_*,
+            # in dispatch order) belong to the trained waves the line reports -- 2 warm-up + 3 timed ones, like the unguided child
+            last_train = max([int(r_["Dispatch_Id"]) for r_ in rows if "k_propagate" in r_["Kernel_Name"] or "k_train_" in r_["Kernel_Name"]], default=-1)
+            for row in rows:
                 k = row["Kernel_Name"]
-                if "k_render_wave" not in k and "k_wf_" not in k:
+                if int(row["Dispatch_Id"]) <= last_train or ("k_render_wave" not in k and "k_wf_" not in k):
                     continue
                 agg.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
@@ -359,7 +369,7 @@ def main():
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(ones.item())
     # untimed: first use of the communicator at the film's size (RCCL sets up channels / buffers lazily)
-    sh.frame_end_allreduce(dist, film, world)
+    sh.frame_end_allreduce(dist, film, world, r, stream)
     torch.cuda.synchronize()
     r.film_clear(stream)
     r.reset_counters(stream)
@@ -376,7 +386,9 @@ def main():
         r.render_wave(w0, w1, stream)
         ev[i][1].record()
         sync.post_process_step(stream)
-    sh.frame_end_allreduce(dist, film, world)  # frame-end film all-reduce over RCCL / xGMI
+    # frame end: the last wave's parked samples enter the film (vspg_flush: k_film_resolve on the render stream), then the film
+    # all-reduce over RCCL / xGMI -- both inside the timed region
+    sh.frame_end_allreduce(dist, film, world, r, stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -385,6 +397,9 @@ def main():
     elapsed = sh.max_over_ranks(dist, elapsed, world, "cuda")
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    # every pixel of the (summed) film holds exactly the frame's samples: `steps` per rank, every rank's last wave included
+    fw = film.view(-1, 4)[:, 3]
+    film_weight_ok = bool(((fw == float(args.steps * world)).all()).item())
     cnt = r.counters()
     paths_rank = cnt["paths"]
     segs_rank = cnt["segments"]
@@ -477,6 +492,7 @@ def main():
                          "density_queries_per_path": dq_rank / max(1, paths_rank),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "note": note},
         }
+        out["film_weight_ok"] = film_weight_ok
         if ranks_seen is not None:
             out["rccl_ranks_seen"] = ranks_seen
         if train_ms is not None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSPG_ABI_VERSION 5
+#define VSPG_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define VSPG_OK 0
@@ -338,8 +338,13 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r);
  * vspg_film_device_ptr exposes it for the frame-end RCCL all-reduce.
  * A one-sample vspg_render_wave may leave its samples parked beside the film until the next launch starts (it adds them as each
  * pixel's new path begins, in the same order as ever); every call that reads or writes the film or the image-space statistics
- * adds them first, on the stream it is given.  The two *_device_ptr getters have no stream: they add the parked samples on the
- * stream of the launch that parked them and wait for that stream, so the pointer they return is good for any stream. */
+ * adds them first, on the stream it is given (ordered behind the launch that parked them by an event when the streams differ).
+ * The two *_device_ptr getters have no stream: they add the parked samples on the stream of the launch that parked them and
+ * wait for that stream, so what the pointer shows is complete AT THE TIME OF THE CALL.  The pointer VALUE is fixed for the
+ * renderer's lifetime, the CONTENTS are not: a host that keeps the pointer across waves (to all-reduce the film or the
+ * statistics plane itself) must call vspg_flush(r, stream) -- asynchronous, no host wait -- after the last vspg_render_wave and
+ * before it reads through the pointer on `stream` (or on work ordered behind it); a no-op when nothing is parked. */
+int vspg_flush(VspgRenderer *r, void *stream);
 int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats);
 int vspg_film_read(VspgRenderer *r, float *host_rgbw /* W*H*4 */, void *stream);
 int vspg_film_clear(VspgRenderer *r, void *stream);

@@ -742,6 +742,146 @@ def test_sharded_steps_with_buffer_updates_vs_oracle_shards(gpu_pkg):
         r.close()
 
 
+class _ThreadDist:
+    """An in-process stand-in for torch.distributed: `world` threads, one per rank, meet in all_reduce and every one of them
+    leaves with the same sum (rank order, so the same bits).  Enough to drive vspg-pbrt-v4_amd/sharding.py -- the code
+    bench.py --gpus N runs -- with two HIP renderers on ONE card (RCCL refuses two ranks on a device)."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, world, torch):
+        import threading
+        self.world, self.torch = world, torch
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.tls = threading.local()
+        self.calls = 0
+
+    def all_reduce(self, t, op=None):
+        torch = self.torch
+        torch.cuda.synchronize()
+        self.slots[self.tls.rank] = t
+        self.barrier.wait()
+        total = self.slots[0].clone()
+        for k in range(1, self.world):
+            total += self.slots[k]
+        torch.cuda.synchronize()
+        self.barrier.wait()
+        t.copy_(total)
+        torch.cuda.synchronize()
+        if self.tls.rank == 0:
+            self.calls += 1
+        self.barrier.wait()
+
+
+def _run_shard_sync(P, scene, prm, W, H, steps, break_flush=False):
+    """Two HIP shards stepped by ShardSync itself (threads as ranks, own stream each); returns per rank the VSP buffer, the
+    summed statistics ShardSync handed the update at every due step, and the film after frame_end_allreduce."""
+    import importlib.util
+    import threading
+    import torch
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("vspg_sharding", os.path.join(ROOT, "vspg-pbrt-v4_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    world = 2
+    fake = _ThreadDist(world, torch)
+    dev = torch.device("cuda", 0)
+    out, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            fake.tls.rank = rank
+            torch.cuda.set_device(0)
+            r = P.Renderer(scene, prm, W, H, shard_index=rank, shard_count=world)
+            if break_flush:            # round 3's host: the pointer wrapped once, nobody resolves the parked wave
+                r.flush = lambda stream=None: None
+            ts = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(ts):
+                stream = ts.cuda_stream
+                fptr, fn = r.film_ptr()   # taken ONCE, before the first wave, as bench.py does
+
+                class Dev:
+                    __cuda_array_interface__ = {"shape": (fn,), "typestr": "<f4", "data": (fptr, False), "version": 2}
+                film = torch.as_tensor(Dev(), device=dev)
+                sync = sh.ShardSync(fake, r, world, torch, device=dev)
+                sums = []
+                for step in range(steps):
+                    w0, w1 = sh.step_wave_range(step, world)
+                    r.render_wave(w0, w1, stream)
+                    due = r.isg_update_due(world)
+                    sync.post_process_step(stream)
+                    if due:
+                        ts.synchronize()
+                        sums.append(sync._sum.cpu().numpy().copy())
+                sh.frame_end_allreduce(fake, film, world, r, stream)
+                ts.synchronize()
+                summed = film.cpu().numpy().reshape(H, W, 4).copy()
+            vsp, ready = r.vsp_buffer()
+            out[rank] = (vsp, ready, sums, summed)
+            r.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            fake.barrier.abort()
+    th = [threading.Thread(target=rank_main, args=(k,)) for k in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def test_shard_sync_on_the_hip_renderer_vs_oracle_shards(gpu_pkg):
+    """sharding.py (ShardSync.post_process_step + frame_end_allreduce: what `bench.py --gpus N` executes) driving TWO HIP
+    renderers on one card, against two oracle shards stepped the same way: the statistics every update ran on are
+    bit-identical to the oracle's sums, both ranks hold one VSP buffer, and every pixel of the all-reduced film carries
+    2 * steps samples -- each rank's LAST wave included (a one-sample wave parks its samples; vspg_flush).  The same
+    run with the flush taken out (round 3's host) must fail these checks: the test sees what it is there to see."""
+    P = gpu_pkg
+    W, H, steps = 96, 64, 6
+    scene = P.fog_box_scene(W, H)
+    prm = P.app_f_params()
+    c = [oracle_lib.OracleRenderer(scene, prm, W, H, shard_index=i, shard_count=2) for i in range(2)]
+    csums = []
+    for step in range(steps):
+        for r in c:
+            r.render_wave(2 * step, 2 * step + 2)
+        due = c[0].isg_update_due(2)
+        tc = None
+        if due:
+            tc = c[0].isg_stats().reshape(-1) + c[1].isg_stats().reshape(-1)
+            csums.append(tc.copy())
+        for r in c:
+            r.post_process_step(2, tc)
+    assert len(csums) == 3                    # the wave counter passes 2, 4, 8
+    vc, readyc = c[0].vsp_buffer()
+    fc = c[0].film() + c[1].film()
+    got = _run_shard_sync(P, scene, prm, W, H, steps)
+    for rank in range(2):
+        vsp, ready, sums, film = got[rank]
+        assert ready and readyc and len(sums) == 3
+        for k in range(3):
+            assert np.array_equal(sums[k].view(np.uint32), csums[k].view(np.uint32)), "update %d ran on other statistics than the oracle shards'" % k
+        assert np.mean(np.abs(vsp - vc) <= 1e-6) == 1.0
+        assert np.all(film[..., 3] == 2 * steps), "the all-reduced film lacks samples"
+        assert np.array_equal(film[..., 3], fc[..., 3])
+        ig, ic = film[..., :3] / film[..., 3:4], fc[..., :3] / fc[..., 3:4]
+        assert np.mean(np.all(np.abs(ig - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
+    assert np.array_equal(got[0][0], got[1][0]), "the two ranks hold different VSP buffers"
+    assert np.array_equal(got[0][3], got[1][3]), "the two ranks hold different films after the all-reduce"
+    print("ShardSync on HIP shards: VSP buffer bit-identical to the oracle shards' in %.4f of the pixels" % np.mean(got[0][0] == vc))
+    # ... and without the flush: stale statistics from the second update on, a film that lacks each rank's last wave
+    bad = _run_shard_sync(P, scene, prm, W, H, steps, break_flush=True)
+    stale = [not np.array_equal(bad[0][2][k].view(np.uint32), csums[k].view(np.uint32)) for k in range(3)]
+    assert stale[1] and stale[2], "the test would not have caught round 3's stale statistics"
+    assert not np.all(bad[0][3][..., 3] == 2 * steps), "the test would not have caught the film that lacks the last wave"
+    for r in c:
+        r.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # heterogeneous medium (GridMedium: DDA majorants, trilinear density, SampleT_maj_Resampling)
 # ---------------------------------------------------------------------------------------------

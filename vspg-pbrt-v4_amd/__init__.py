@@ -161,6 +161,7 @@ SYMBOLS = [
     ("vspg_post_process_step", C.c_int, [_vp, C.c_int, _vp, _vp]),
     ("vspg_renderer_set_exchange", C.c_int, [_vp, _vp, _vp]),
     ("vspg_renderer_kernel_name", C.c_char_p, [_vp]),
+    ("vspg_flush", C.c_int, [_vp, _vp]),
     ("vspg_film_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("vspg_film_read", C.c_int, [_vp, _P(C.c_float), _vp]),
     ("vspg_film_clear", C.c_int, [_vp, _vp]),
@@ -402,6 +403,11 @@ class Renderer:
 
     def post_process_wave(self, stream=None):
         _check(self.lib, self.lib.vspg_post_process_wave(self.h, _vp(stream or 0)))
+
+    def flush(self, stream=None):
+        """Adds the samples the last one-sample wave parked to the film and the image-space statistics (asynchronous on
+        `stream`): what a host that keeps film_ptr() / isg_stats_ptr() across waves calls before it reads through them."""
+        _check(self.lib, self.lib.vspg_flush(self.h, _vp(stream or 0)))
 
     def film_ptr(self):
         p, n = _vp(), C.c_size_t()

@@ -1662,6 +1662,7 @@ struct VspgRenderer {
     int ws_cur = 0;
     bool ws_parked = false;
     hipStream_t ws_stream = nullptr;  // the stream of the launch that parked them
+    hipEvent_t ws_event = nullptr;    // recorded behind that launch: whoever touches the parked samples on another stream waits on it
     unsigned int *wf_lists = nullptr;   // 4 x n_items: active (even / odd iterations), walk, shadow
     hipStream_t wf_stream2 = nullptr;   // the shadow walks' stream (wf_render_pass)
     hipEvent_t wf_ev_vertex = nullptr, wf_ev_shadow = nullptr;
@@ -2885,6 +2886,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->tris) (void)hipFree(r->tris);
     if (r->bvh) (void)hipFree(r->bvh);
     for (int k = 0; k < 2; ++k) if (r->wave_samples[k]) (void)hipFree(r->wave_samples[k]);
+    if (r->ws_event) (void)hipEventDestroy(r->ws_event);
     if (r->wf_pool) (void)hipFree(r->wf_pool);
     if (r->wf_lists) (void)hipFree(r->wf_lists);
     if (r->wf_iters) (void)hipFree(r->wf_iters);
@@ -2973,8 +2975,14 @@ static bool wg2_defer_enabled() {  // (read per launch: a test flips it)
     const char *e = getenv("VSPG_WG2_DEFER");
     return !(e && e[0] == '0');
 }
+// (the parking launch ran on ws_stream; work on any other stream that reads its samples is ordered behind it by ws_event)
+static int order_after_parking(VspgRenderer *r, hipStream_t s) {
+    if (r->ws_parked && r->ws_event && s != r->ws_stream) HIPCHK(hipStreamWaitEvent(s, r->ws_event, 0));
+    return 0;
+}
 static int flush_parked_samples(VspgRenderer *r, hipStream_t s) {
     if (!r->ws_parked) return 0;
+    if (const int rc = order_after_parking(r, s)) return rc;
     hipLaunchKernelGGL(k_film_resolve, dim3((unsigned)((r->npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, r->npix,
                        r->wave_samples[r->ws_cur ^ 1], r->film, r->isg_stats);
     HIPCHK(hipGetLastError());
@@ -3143,6 +3151,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                 if (!r->wave_samples[k]) HIPCHK(hipMalloc(&r->wave_samples[k], r->npix * sizeof(float4)));
             float4 *const ws_out = r->wave_samples[r->ws_cur];
             const float4 *const ws_prev = defer && r->ws_parked ? r->wave_samples[r->ws_cur ^ 1] : nullptr;
+            if (ws_prev) { const int rc = order_after_parking(r, (hipStream_t)stream); if (rc) return rc; }
             const long long n_tiles = (long long)tilesX * tilesY;
             if (wblocks > n_tiles) wblocks = n_tiles;
             // the share of the frame handed out from the global head, in 64ths (VSPG_WG2_TAIL; the rest is dealt to the workgroups
@@ -3173,6 +3182,8 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                 r->ws_cur ^= 1;
                 r->ws_parked = true;
                 r->ws_stream = (hipStream_t)stream;
+                if (!r->ws_event) HIPCHK(hipEventCreateWithFlags(&r->ws_event, hipEventDisableTiming));
+                HIPCHK(hipEventRecord(r->ws_event, (hipStream_t)stream));
                 if (!defer) { const int rc = flush_parked_samples(r, (hipStream_t)stream); if (rc) return rc; }
             }
         } else {
@@ -3338,6 +3349,12 @@ int vspg_renderer_set_exchange(VspgRenderer *r, VspgExchangeFn fn, void *user) {
     return 0;
 }
 
+int vspg_flush(VspgRenderer *r, void *stream) {
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    if (!r->ws_parked) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    return flush_parked_samples(r, (hipStream_t)stream);
+}
 int vspg_film_device_ptr(VspgRenderer *r, float **dev_ptr, size_t *n_floats) {
     if (!r || !dev_ptr || !n_floats) return fail(VSPG_EINVAL, "null argument");
     if (r->ws_parked) {  // the caller reads the film on a stream of its own: the parked samples go in, and are in, before it gets the pointer

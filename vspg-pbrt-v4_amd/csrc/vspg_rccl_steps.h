@@ -60,7 +60,9 @@ int vspg_rccl_post_process_step_n(VspgRenderer *r, int n_waves, int world, void 
     if (world == 1 || !vspg_isg_update_due(r, n_waves)) return vspg_post_process_step(r, n_waves, nullptr, stream);
     float *stats = nullptr;
     size_t n = 0;
-    int rc = vspg_isg_stats_device_ptr(r, &stats, &n);
+    int rc = vspg_flush(r, stream);  // this rank's latest wave enters the statistics on `stream` (no host wait), before the sum reads them
+    if (rc) return rc;
+    rc = vspg_isg_stats_device_ptr(r, &stats, &n);
     if (rc) return rc;
     float *sum = nullptr;
     {
@@ -95,7 +97,9 @@ int vspg_rccl_allreduce_film(VspgRenderer *r, void *comm, void *stream) {
     if (!r) return VSPG_EINVAL;
     float *film = nullptr;
     size_t n = 0;
-    int rc = vspg_film_device_ptr(r, &film, &n);
+    int rc = vspg_flush(r, stream);  // the frame's last wave enters the film before the sum
+    if (rc) return rc;
+    rc = vspg_film_device_ptr(r, &film, &n);
     if (rc) return rc;
     return VSPG_TRANSPORT::sum_f32(comm, film, film, n, (hipStream_t)stream);
 }

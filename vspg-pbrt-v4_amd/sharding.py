@@ -13,8 +13,16 @@ def step_wave_range(step, world):
     return step * world, (step + 1) * world
 
 
-def frame_end_allreduce(dist, film_tensor, world):
-    """Sum the per-rank film tiles {sum w*rgb, sum w} (RGBFilm accumulate contract, film.h:251-267)."""
+def frame_end_allreduce(dist, film_tensor, world, renderer=None, stream=None):
+    """Sum the per-rank film tiles {sum w*rgb, sum w} (RGBFilm accumulate contract, film.h:251-267).
+
+    `film_tensor` wraps the renderer's film pointer, which a host may keep for the renderer's lifetime -- but a one-sample
+    wave leaves its samples PARKED beside the film until the next launch (include/vspg.h, vspg_flush): the frame's last wave
+    is only in the film after `renderer.flush(stream)`.  Pass the HIP renderer and the stream its waves ran on (the stream
+    the collective is issued on must be that stream or ordered behind it) and the flush happens here, at world 1 too: a
+    frame end without the frame's film is not a frame end."""
+    if renderer is not None and hasattr(renderer, "flush"):
+        renderer.flush(stream)
     if world > 1:
         dist.all_reduce(film_tensor, op=dist.ReduceOp.SUM)
     return film_tensor
@@ -87,10 +95,15 @@ class ShardSync:
         t = torch.as_tensor(_Dev(), device=self.device)
         self._ordered(stream, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
 
-    def _stats_tensor(self):
+    def _stats_tensor(self, stream=None):
         if hasattr(self.r, "isg_stats_tensor"):       # CPU oracle: a fresh host copy per call
             return self.r.isg_stats_tensor(self.torch)
-        if self._stats is None:                       # HIP renderer: wrap the device pointer once (no copy)
+        # HIP renderer.  The pointer is fixed for the renderer's lifetime and wrapped once (no copy); what it shows is not:
+        # this rank's latest one-sample wave is still PARKED beside the statistics (vspg_flush, include/vspg.h) and enters
+        # them here, on the stream the wave ran on, before the sum below reads them.  (Round 3 wrapped the pointer once and
+        # never flushed: from the second update on the all-reduced statistics lacked every rank's latest wave.)
+        self.r.flush(stream)
+        if self._stats is None:
             ptr, n = self.r.isg_stats_ptr()
 
             class _Dev:
@@ -107,7 +120,7 @@ class ShardSync:
             return
         total = None
         if self.r.isg_update_due(self.world):
-            st = self._stats_tensor()
+            st = self._stats_tensor(stream)
             if self._sum is None:
                 self._sum = self.torch.empty_like(st)
 
