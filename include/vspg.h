@@ -46,6 +46,19 @@ extern "C" {
  * pbrt "bilinearmesh" rectangle with a "diffuse" material and, when Le != 0, a "diffuse"
  * area light (src/pbrt/shapes.cpp:1128-1143, src/pbrt/bxdfs.h:31-80,
  * src/pbrt/lights.cpp:796-820). */
+/* Medium boundaries (round 4).  A surface carries what pbrt's GeometricPrimitive hands the hit (src/pbrt/cpu/primitive.cpp:77): a material -- "diffuse", or NONE for `Material "interface"` (materials.cpp:736, scene.cpp:1340: a null
+ * Material; GetBSDF returns no BSDF and Li skips the hit, guidedvolpathvspgintegrator.cpp:399-404) -- and a MediumInterface
+ * {inside, outside} (base/medium.h:113-128; `MediumInterface "name_in" "name_out"`).  The library holds ONE medium
+ * (VspgScene.medium), so each side is "the medium" or "no medium": medium_interface is a pair of bits.  Only a TRANSITION
+ * (inside != outside, MediumInterface::IsMediumTransition) changes anything: Interaction::GetMedium(w) then returns the
+ * outside medium for Dot(w, n) > 0, the inside one otherwise (interaction.h:117-121), n being the surface's geometric
+ * normal after reverse_orientation; a surface that is not a transition leaves a ray in the medium it arrived in
+ * (SurfaceInteraction::SetIntersectionProperties, interaction.h:218-229). */
+enum { VSPG_MATERIAL_DIFFUSE = 0, VSPG_MATERIAL_INTERFACE = 1 };
+#define VSPG_IFACE_INSIDE 1   /* the scene's medium lies on the inside (behind the normal):  MediumInterface "m" ""  */
+#define VSPG_IFACE_OUTSIDE 2  /* ... on the outside (the side the normal points to):         MediumInterface ""  "m" */
+/* (0 and VSPG_IFACE_INSIDE | VSPG_IFACE_OUTSIDE: not a transition) */
+
 typedef struct VspgQuad {
     float p00[3];
     float e1[3];
@@ -54,7 +67,25 @@ typedef struct VspgQuad {
     float Le[3];                  /* emitted radiance (RGB); all zero = not a light */
     int32_t two_sided;            /* DiffuseAreaLight "twosided" */
     int32_t reverse_orientation;  /* flips the geometric normal normalize(e1 x e2) */
+    int32_t material;             /* VSPG_MATERIAL_* */
+    int32_t medium_interface;     /* VSPG_IFACE_* bits */
 } VspgQuad;
+
+/* Shape "sphere" (src/pbrt/shapes.h:107-330): the full sphere of `radius` around the object-space origin (partial spheres
+ * -- zmin / zmax / phimax -- are refused), placed by renderFromObject.  Both matrices of pbrt's Transform, row-major, as
+ * for VspgMedium (vspg_transform_inverse fills the inverse).  Intersection = Sphere::BasicIntersect with its interval
+ * arithmetic (shapes.h:147-229), interaction = InteractionFromIntersection + Transform::operator()(SurfaceInteraction)
+ * (shapes.h:237-284, transform.cpp:229-261).  Diffuse or interface; not a light. */
+#define VSPG_MAX_SPHERES 8
+typedef struct VspgSphere {
+    float render_from_object[16];
+    float object_from_render[16];
+    float radius;
+    float Kd[3];
+    int32_t reverse_orientation;
+    int32_t material;
+    int32_t medium_interface;
+} VspgSphere;
 
 /* Pinhole camera: raster point (x,y) -> camera-space point (sx*x+ox, sy*y+oy, 1),
  * normalised, then rotated into render space by the orthonormal frame (right, up, fwd).
@@ -68,7 +99,9 @@ typedef struct VspgCamera {
 
 enum { VSPG_MEDIUM_NONE = 0, VSPG_MEDIUM_HOMOGENEOUS = 1, VSPG_MEDIUM_GRID = 2, VSPG_MEDIUM_NANOVDB = 3 };
 
-/* The single medium filling the scene (ray.medium for every ray).
+/* The scene's one medium.  Without medium boundaries (no transition surface, camera_outside_medium == 0) it fills the
+ * scene -- ray.medium for every ray, rounds 1-3 -- otherwise a ray is in it or in no medium at all, as the camera and
+ * the MediumInterfaces it crossed say.
  * HOMOGENEOUS mirrors HomogeneousMedium (src/pbrt/media.h:221-283; parameters
  * src/pbrt/media.cpp:167-206): sigma_a/sigma_s are RGB, already multiplied by "scale";
  * Le already multiplied by "Lescale".
@@ -138,6 +171,12 @@ typedef struct VspgInfiniteLight {
     float w_light[3];
 } VspgInfiniteLight;
 
+/* tri_flags (optional, one int32 per triangle, HOST pointer; NULL = all 0): bit 0 = VSPG_MATERIAL_INTERFACE, bits 1-2 =
+ * the VSPG_IFACE_* bits, bit 3 = flip the geometric normal (the mesh's reverseOrientation ^ transformSwapsHandedness,
+ * shapes.h:934-936 -- only a medium transition can tell the two sides of a diffuse triangle apart). */
+#define VSPG_TRI_INTERFACE 1
+#define VSPG_TRI_IFACE_SHIFT 1
+#define VSPG_TRI_FLIP_NORMAL 8
 typedef struct VspgScene {
     int32_t n_quads;
     VspgQuad quads[VSPG_MAX_QUADS];
@@ -148,6 +187,13 @@ typedef struct VspgScene {
     const float *tri_kd;
     int32_t n_infinite_lights;
     VspgInfiniteLight infinite_lights[VSPG_MAX_INFINITE_LIGHTS];
+    /* round 4: medium boundaries */
+    const int32_t *tri_flags;
+    int32_t n_spheres;
+    VspgSphere spheres[VSPG_MAX_SPHERES];
+    /* the camera's medium (CameraBase::medium = the current OUTSIDE medium at the Camera directive, scene.cpp:153-155):
+     * 0 = the scene's medium (as ever), 1 = none -- the camera looks at the volume from outside */
+    int32_t camera_outside_medium;
 } VspgScene;
 
 /* ---- integrator parameters: same names and defaults as

@@ -431,6 +431,8 @@ typedef struct {
     float area;
     spec Kd, Le;
     int two_sided, is_light, has_bsdf_lobes;
+    int has_material; /* 0: Material "interface" (GetBSDF returns no BSDF, :399-404) */
+    int iface;        /* VSPG_IFACE_* bits when the surface is a medium TRANSITION, else 0 (interaction.h:218-229) */
 } rquad_t;
 
 typedef struct {
@@ -438,9 +440,15 @@ typedef struct {
     float t;
     int quad;   /* rectangle index, or -1 when `tri` names a triangle */
     int tri;    /* triangle (index into r->tris), -1 for a rectangle hit */
+    int sphere; /* sphere index, -1 otherwise */
     v3 p, n;
     v3 perr;    /* error bound of p */
+    p3i pi;     /* sphere hits: the interaction point as Transform::operator()(Point3fi) returned it (p = its midpoint) */
+    v3 dpdu_n;  /* sphere hits: Normalize(shading.dpdu) in render space (the BSDF frame's x) */
+    int has_material, iface; /* of the surface hit (see rquad_t) */
 } isect_t;
+/* SurfaceInteraction::pi of a hit */
+static inline p3i isect_pi(const isect_t *si) { return si->sphere >= 0 ? si->pi : p3i_from_err(si->p, si->perr); }
 
 /* f1: a triangle of the soup with what Triangle::InteractionFromIntersection derives from its vertices (shapes.h:888-938) */
 typedef struct {
@@ -450,8 +458,27 @@ typedef struct {
     spec Kd;
     int id;
     int has_bsdf_lobes;
+    int has_material, iface;
 } rtri_t;
 
+/* MediumInterface::IsMediumTransition (base/medium.h:124): inside != outside; anything else leaves the ray's medium alone */
+static int iface_transition(int bits) {
+    bits &= VSPG_IFACE_INSIDE | VSPG_IFACE_OUTSIDE;
+    return (bits == VSPG_IFACE_INSIDE || bits == VSPG_IFACE_OUTSIDE) ? bits : 0;
+}
+/* Dot(Vector3f, Normal3f) (vecmath.h:1064-1068): FMA(n.x, v.x, SumOfProducts(n.y, v.y, n.z, v.z)), math.h:577-583 */
+static inline float dot_vn(v3 v, v3 n) {
+    float cd = n.z * v.z;
+    float sop = fmaf(n.y, v.y, cd);
+    float err = fmaf(n.z, v.z, -cd);
+    return fmaf(n.x, v.x, sop + err);
+}
+/* Interaction::GetMedium(w) (interaction.h:117-121) with one medium: 1 = the scene's medium, 0 = none.  `medium` is the
+ * interaction's own `medium` member: the medium of the ray that hit a non-transition surface / of a medium interaction. */
+static inline int get_medium(int iface, v3 n, v3 w, int medium) {
+    if (iface) return dot_vn(w, n) > 0 ? ((iface & VSPG_IFACE_OUTSIDE) ? 1 : 0) : ((iface & VSPG_IFACE_INSIDE) ? 1 : 0);
+    return medium;
+}
 static void quad_init(rquad_t *q, const VspgQuad *in) {
     q->p00 = v3_from(in->p00);
     q->e1 = v3_from(in->e1);
@@ -475,6 +502,8 @@ static void quad_init(rquad_t *q, const VspgQuad *in) {
     q->two_sided = in->two_sided;
     q->is_light = s_nonzero(q->Le);
     q->has_bsdf_lobes = s_nonzero(q->Kd); /* DiffuseBxDF::Flags (bxdfs.h:82-84) */
+    q->has_material = in->material != VSPG_MATERIAL_INTERFACE;
+    q->iface = iface_transition(in->medium_interface);
 }
 
 /* ray / rectangle: plane hit, then parametric (u,v) test; the reported point is re-projected
@@ -496,6 +525,192 @@ static int quad_intersect(const rquad_t *q, v3 o, v3 d, float tMax, float *tHit,
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Shape "sphere" (round 4; shapes.h:107-330): Interval arithmetic (util/math.h:818-1010,  */
+/* CPU branches of the rounding helpers util/float.h:199-297), Sphere::BasicIntersect       */
+/* (shapes.h:147-229), InteractionFromIntersection (:237-284),                              */
+/* Transform::operator()(SurfaceInteraction) (transform.cpp:229-261).  Full spheres only.   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct { float lo, hi; } ivl;
+static inline float min_f(float a, float b) { return b < a ? b : a; } /* std::min */
+static inline float max_f(float a, float b) { return a < b ? b : a; } /* std::max */
+static inline ivl ivl_x(float v) { ivl r = {v, v}; return r; }
+static inline ivl ivl_mk(float a, float b) { ivl r = {min_f(a, b), max_f(a, b)}; return r; } /* Interval(low, high) */
+static inline float ivl_mid(ivl a) { return (a.lo + a.hi) / 2; }
+static inline ivl ivl_from_err(float v, float e) { ivl r; interval_from_value_and_error(v, e, &r.lo, &r.hi); return r; }
+static inline ivl ivl_add(ivl a, ivl b) { return ivl_mk(next_float_down(a.lo + b.lo), next_float_up(a.hi + b.hi)); }
+static inline ivl ivl_sub(ivl a, ivl b) { return ivl_mk(next_float_down(a.lo + -b.hi), next_float_up(a.hi + -b.lo)); }
+static inline float min4(const float *v) { float m = v[0]; for (int i = 1; i < 4; ++i) m = min_f(m, v[i]); return m; }
+static inline float max4(const float *v) { float m = v[0]; for (int i = 1; i < 4; ++i) m = max_f(m, v[i]); return m; }
+static inline ivl ivl_mul(ivl a, ivl b) {
+    float lp[4] = {next_float_down(a.lo * b.lo), next_float_down(a.hi * b.lo), next_float_down(a.lo * b.hi), next_float_down(a.hi * b.hi)};
+    float hp[4] = {next_float_up(a.lo * b.lo), next_float_up(a.hi * b.lo), next_float_up(a.lo * b.hi), next_float_up(a.hi * b.hi)};
+    return ivl_mk(min4(lp), max4(hp));
+}
+static inline int ivl_has(ivl i, float v) { return v >= i.lo && v <= i.hi; } /* InRange(v, i) */
+static inline ivl ivl_div(ivl a, ivl b) {
+    if (ivl_has(b, 0)) return ivl_mk(-INFINITY, INFINITY);
+    float lq[4] = {next_float_down(a.lo / b.lo), next_float_down(a.hi / b.lo), next_float_down(a.lo / b.hi), next_float_down(a.hi / b.hi)};
+    float hq[4] = {next_float_up(a.lo / b.lo), next_float_up(a.hi / b.lo), next_float_up(a.lo / b.hi), next_float_up(a.hi / b.hi)};
+    return ivl_mk(min4(lq), max4(hq));
+}
+static inline ivl ivl_sqr(ivl i) {
+    float alow = fabsf(i.lo), ahigh = fabsf(i.hi);
+    if (alow > ahigh) { float t = alow; alow = ahigh; ahigh = t; }
+    if (ivl_has(i, 0)) return ivl_mk(0, next_float_up(ahigh * ahigh));
+    return ivl_mk(next_float_down(alow * alow), next_float_up(ahigh * ahigh));
+}
+static inline ivl ivl_fmul(float f, ivl i) { /* operator*(Float, Interval) */
+    if (f > 0) return ivl_mk(next_float_down(f * i.lo), next_float_up(f * i.hi));
+    return ivl_mk(next_float_down(f * i.hi), next_float_up(f * i.lo));
+}
+static inline ivl ivl_sqrt(ivl i) { return ivl_mk(max_f(0.f, next_float_down(sqrtf(i.lo))), next_float_up(sqrtf(i.hi))); }
+
+typedef struct {
+    float m[16], mi[16]; /* renderFromObject: m and mInv, row-major */
+    float radius;
+    int flip;            /* reverseOrientation ^ transformSwapsHandedness */
+    float thetaZMin, thetaZMax, phiMax;
+    spec Kd;
+    int has_bsdf_lobes, has_material, iface;
+} rsphere_t;
+
+/* Transform::SwapsHandedness (transform.cpp:145-152) with Determinant(SquareMatrix<3>) (math.h:1419-1425) */
+static int swaps_handedness(const float *m) {
+    float minor12 = diff_of_products(m[5], m[10], m[6], m[9]);
+    float minor02 = diff_of_products(m[4], m[10], m[6], m[8]);
+    float minor01 = diff_of_products(m[4], m[9], m[5], m[8]);
+    return fmaf(m[2], minor01, diff_of_products(m[0], minor12, m[1], minor02)) < 0;
+}
+static int sphere_init(rsphere_t *S, const VspgSphere *in) {
+    memcpy(S->m, in->render_from_object, sizeof S->m);
+    memcpy(S->mi, in->object_from_render, sizeof S->mi);
+    if (!(in->radius > 0)) return VSPG_EINVAL;
+    for (int k = 0; k < 3; ++k) if (S->m[12 + k] != 0 || S->mi[12 + k] != 0) return VSPG_EINVAL; /* affine only */
+    if (S->m[15] != 1 || S->mi[15] != 1) return VSPG_EINVAL;
+    S->radius = in->radius;
+    S->flip = (in->reverse_orientation ? 1 : 0) ^ swaps_handedness(S->m);
+    /* zMin = -radius, zMax = radius, phiMax = 360 (the defaults, shapes.cpp:231-237) */
+    S->thetaZMin = acosf(clampf(min_f(-S->radius, S->radius) / S->radius, -1, 1));
+    S->thetaZMax = acosf(clampf(max_f(-S->radius, S->radius) / S->radius, -1, 1));
+    S->phiMax = (PI_F / 180) * clampf(360.f, 0, 360); /* Radians() (math.h:261-263); == fl(2 pi): the phi clip of :184, :200 never fires */
+    S->Kd = s_from(in->Kd);
+    for (int i = 0; i < 3; ++i) S->Kd.c[i] = clampf(S->Kd.c[i], 0, 1);
+    S->has_bsdf_lobes = s_nonzero(S->Kd);
+    S->has_material = in->material != VSPG_MATERIAL_INTERFACE;
+    S->iface = iface_transition(in->medium_interface);
+    return 0;
+}
+/* Sphere::BasicIntersect (shapes.h:147-229) for zMin = -radius, zMax = radius, phiMax = 2 pi (no clipping) */
+static int sphere_intersect(const rsphere_t *S, v3 ro, v3 rd, float tMax, float *tHit, v3 *pObj) {
+    const float *mi = S->mi;
+    const float g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS);
+    /* oi = (*objectFromRender)(Point3fi(r.o)): exact input (transform.h:133-175) */
+    ivl oi[3], di[3];
+    {
+        float x = ro.x, y = ro.y, z = ro.z;
+        for (int k = 0; k < 3; ++k) {
+            const float *row = mi + 4 * k;
+            float v = (row[0] * x + row[1] * y) + (row[2] * z + row[3]);
+            float e = g3 * (fabsf(row[0] * x) + fabsf(row[1] * y) + fabsf(row[2] * z) + fabsf(row[3]));
+            oi[k] = ivl_from_err(v, e);
+        }
+    }
+    { /* di = (*objectFromRender)(Vector3fi(r.d)) (transform.h:272-305) */
+        float x = rd.x, y = rd.y, z = rd.z;
+        for (int k = 0; k < 3; ++k) {
+            const float *row = mi + 4 * k;
+            float e = g3 * (fabsf(row[0] * x) + fabsf(row[1] * y) + fabsf(row[2] * z));
+            float v = row[0] * x + row[1] * y + row[2] * z;
+            di[k] = ivl_from_err(v, e);
+        }
+    }
+    ivl a = ivl_add(ivl_add(ivl_sqr(di[0]), ivl_sqr(di[1])), ivl_sqr(di[2]));
+    ivl b = ivl_fmul(2.f, ivl_add(ivl_add(ivl_mul(di[0], oi[0]), ivl_mul(di[1], oi[1])), ivl_mul(di[2], oi[2])));
+    ivl c = ivl_sub(ivl_add(ivl_add(ivl_sqr(oi[0]), ivl_sqr(oi[1])), ivl_sqr(oi[2])), ivl_sqr(ivl_x(S->radius)));
+    /* v = oi - b / (2 * a) * di; discrim = 4 a (radius + |v|)(radius - |v|) */
+    ivl f = ivl_div(b, ivl_fmul(2.f, a));
+    ivl v[3];
+    for (int k = 0; k < 3; ++k) v[k] = ivl_sub(oi[k], ivl_mul(f, di[k]));
+    ivl length = ivl_sqrt(ivl_add(ivl_add(ivl_sqr(v[0]), ivl_sqr(v[1])), ivl_sqr(v[2])));
+    ivl discrim = ivl_mul(ivl_mul(ivl_fmul(4.f, a), ivl_add(ivl_x(S->radius), length)), ivl_sub(ivl_x(S->radius), length));
+    if (discrim.lo < 0) return 0;
+    ivl rootDiscrim = ivl_sqrt(discrim);
+    ivl q;
+    if (ivl_mid(b) < 0) q = ivl_fmul(-.5f, ivl_sub(b, rootDiscrim));
+    else q = ivl_fmul(-.5f, ivl_add(b, rootDiscrim));
+    ivl t0 = ivl_div(q, a), t1 = ivl_div(c, q);
+    if (t0.lo > t1.lo) { ivl t = t0; t0 = t1; t1 = t; }
+    if (t0.hi > tMax || t1.lo <= 0) return 0;
+    ivl tShapeHit = t0;
+    if (tShapeHit.lo <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit.hi > tMax) return 0;
+    }
+    /* pHit = Point3f(oi) + (Float)tShapeHit * Vector3f(di); refined onto the sphere */
+    float ts = ivl_mid(tShapeHit);
+    v3 pHit = V3(ivl_mid(oi[0]) + ts * ivl_mid(di[0]), ivl_mid(oi[1]) + ts * ivl_mid(di[1]), ivl_mid(oi[2]) + ts * ivl_mid(di[2]));
+    float sc = S->radius / v_len(pHit); /* Distance(pHit, Point3f(0, 0, 0)) */
+    pHit = V3(pHit.x * sc, pHit.y * sc, pHit.z * sc);
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * S->radius;
+    /* (phi = atan2(y, x) feeds only the clip against phiMax -- never true for phiMax = fl(2 pi) -- and the (u, v)
+     *  parameterisation, which a diffuse / interface surface does not read) */
+    *tHit = ts;
+    *pObj = pHit;
+    return 1;
+}
+/* InteractionFromIntersection (shapes.h:237-284) carried to render space by Transform::operator()(SurfaceInteraction)
+ * (transform.cpp:229-261): pi, the geometric normal and Normalize(shading.dpdu) */
+static void sphere_interaction(const rsphere_t *S, v3 pHit, p3i *pi, v3 *n, v3 *dpdu_n) {
+    const float *m = S->m, *mi = S->mi;
+    float cosTheta = pHit.z / S->radius;
+    float zRadius = sqrtf(sqr(pHit.x) + sqr(pHit.y));
+    float cosPhi = pHit.x / zRadius, sinPhi = pHit.y / zRadius;
+    v3 dpdu = V3(-S->phiMax * pHit.y, S->phiMax * pHit.x, 0);
+    float sinTheta = safe_sqrt(1 - sqr(cosTheta));
+    float dth = S->thetaZMax - S->thetaZMin;
+    v3 dpdv = V3(dth * (pHit.z * cosPhi), dth * (pHit.z * sinPhi), dth * (-S->radius * sinTheta));
+    v3 no = v_normalize(v_cross(dpdu, dpdv));
+    if (S->flip) no = v_neg(no);
+    const float g5 = (5 * MACHINE_EPS) / (1 - 5 * MACHINE_EPS), g3 = (3 * MACHINE_EPS) / (1 - 3 * MACHINE_EPS);
+    v3 pErr = V3(g5 * fabsf(pHit.x), g5 * fabsf(pHit.y), g5 * fabsf(pHit.z));
+    /* t(si.pi): Point3fi with error bounds (transform.h:133-175, the approximate branch; exact when pError == 0) */
+    ivl pin[3] = {ivl_from_err(pHit.x, pErr.x), ivl_from_err(pHit.y, pErr.y), ivl_from_err(pHit.z, pErr.z)};
+    float x = ivl_mid(pin[0]), y = ivl_mid(pin[1]), z = ivl_mid(pin[2]);
+    float ex = (pin[0].hi - pin[0].lo) / 2, ey = (pin[1].hi - pin[1].lo) / 2, ez = (pin[2].hi - pin[2].lo) / 2;
+    int exact = (pin[0].hi - pin[0].lo) == 0 && (pin[1].hi - pin[1].lo) == 0 && (pin[2].hi - pin[2].lo) == 0;
+    float pv[3], pe[3];
+    for (int k = 0; k < 3; ++k) {
+        const float *row = m + 4 * k;
+        pv[k] = (row[0] * x + row[1] * y) + (row[2] * z + row[3]);
+        if (exact)
+            pe[k] = g3 * (fabsf(row[0] * x) + fabsf(row[1] * y) + fabsf(row[2] * z) + fabsf(row[3]));
+        else
+            pe[k] = (g3 + 1) * (fabsf(row[0]) * ex + fabsf(row[1]) * ey + fabsf(row[2]) * ez) +
+                    g3 * (fabsf(row[0] * x) + fabsf(row[1] * y) + fabsf(row[2] * z) + fabsf(row[3]));
+    }
+    *pi = p3i_from_err(V3(pv[0], pv[1], pv[2]), V3(pe[0], pe[1], pe[2]));
+    /* Normalize(t(si.n)): normals transform by the inverse transpose (transform.h:329-334) */
+    v3 nr = V3(mi[0] * no.x + mi[4] * no.y + mi[8] * no.z, mi[1] * no.x + mi[5] * no.y + mi[9] * no.z, mi[2] * no.x + mi[6] * no.y + mi[10] * no.z);
+    *n = v_normalize(nr);
+    /* shading.dpdu = t(dpdu) (Vector3 transform, transform.h:322-327); the BSDF frame takes Normalize() of it (bsdf.h:25-26) */
+    v3 du = V3(m[0] * dpdu.x + m[1] * dpdu.y + m[2] * dpdu.z, m[4] * dpdu.x + m[5] * dpdu.y + m[6] * dpdu.z, m[8] * dpdu.x + m[9] * dpdu.y + m[10] * dpdu.z);
+    *dpdu_n = v_normalize(du);
+}
+void oracle_sphere_intersect(const VspgSphere *sp, const float o[3], const float d[3], float tMax, int *hit, float *tHit, float p_lo[3], float p_hi[3],
+                             float n[3], float dpdu_n[3]) {
+    rsphere_t S;
+    *hit = 0;
+    if (sphere_init(&S, sp)) return;
+    v3 pObj;
+    if (!sphere_intersect(&S, v3_from(o), v3_from(d), tMax, tHit, &pObj)) return;
+    p3i pi; v3 nn, du;
+    sphere_interaction(&S, pObj, &pi, &nn, &du);
+    *hit = 1;
+    p_lo[0] = pi.lo.x; p_lo[1] = pi.lo.y; p_lo[2] = pi.lo.z; p_hi[0] = pi.hi.x; p_hi[1] = pi.hi.y; p_hi[2] = pi.hi.z;
+    n[0] = nn.x; n[1] = nn.y; n[2] = nn.z; dpdu_n[0] = du.x; dpdu_n[1] = du.y; dpdu_n[2] = du.z;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* renderer state                                                                         */
 /* ------------------------------------------------------------------------------------ */
 typedef struct {
@@ -514,6 +729,11 @@ struct OracleRenderer {
     rquad_t quads[VSPG_MAX_QUADS];
     rtri_t *tris; /* non-degenerate triangles of the soup, caller's order */
     int n_tris;
+    int n_spheres;
+    rsphere_t spheres[VSPG_MAX_SPHERES];
+    /* medium boundaries (round 4): has_medium = the scene holds a medium at all; has_boundaries = some surface is an
+     * interface material or a medium transition, or the camera sits outside the medium (else: the medium fills the scene) */
+    int has_medium, has_boundaries, camera_in_medium;
     /* infinite lights (lights.h:207-250 DistantLight, :554-601 UniformInfiniteLight); light order = emissive rectangles, then these */
     int n_inf;
     float scene_radius; /* Bounds3::BoundingSphere of the scene bounds (vecmath.h:1335-1338), light.Preprocess (integrators.h:74-81) */
@@ -637,6 +857,7 @@ static isect_t scene_intersect(const OracleRenderer *r, v3 o, v3 d, float tMax) 
     memset(&best, 0, sizeof best);
     best.t = tMax;
     best.tri = -1;
+    best.sphere = -1;
     for (int i = 0; i < r->n_quads; ++i) {
         float t;
         v3 p;
@@ -645,6 +866,8 @@ static isect_t scene_intersect(const OracleRenderer *r, v3 o, v3 d, float tMax) 
         }
     }
     best.perr = r->quads[best.quad].perr;
+    best.has_material = r->quads[best.quad].has_material;
+    best.iface = r->quads[best.quad].iface;
     if (r->n_tris > 0) {
         const float tRect = best.t;
         int found = 0, bi = -1;
@@ -665,6 +888,22 @@ static isect_t scene_intersect(const OracleRenderer *r, v3 o, v3 d, float tMax) 
             const float g7 = (7 * MACHINE_EPS) / (1 - 7 * MACHINE_EPS);
             best.perr = V3(g7 * sum.x, g7 * sum.y, g7 * sum.z); /* shapes.h:929-930 */
             best.n = T->n;
+            best.has_material = T->has_material;
+            best.iface = T->iface;
+        }
+    }
+    /* spheres: every one against the RAY's tMax (BasicIntersect rejects on interval bounds of t against the tMax it is
+     * given; with the running closest distance the outcome would depend on the visiting order), closest by t */
+    for (int i = 0; i < r->n_spheres; ++i) {
+        float t;
+        v3 pObj;
+        if (sphere_intersect(&r->spheres[i], o, d, tMax, &t, &pObj) && t < best.t) {
+            best.hit = 1; best.t = t; best.quad = -1; best.tri = -1; best.sphere = i;
+            sphere_interaction(&r->spheres[i], pObj, &best.pi, &best.n, &best.dpdu_n);
+            best.p = p3i_mid(best.pi);
+            best.perr = p3i_err(best.pi);
+            best.has_material = r->spheres[i].has_material;
+            best.iface = r->spheres[i].iface;
         }
     }
     return best;
@@ -679,6 +918,11 @@ static int scene_intersect_any(const OracleRenderer *r, v3 o, v3 d, float tMax) 
         float t, b[3];
         const rtri_t *T = &r->tris[i];
         if (tri_intersect(o, d, tMax, T->p0, T->p1, T->p2, &t, b) && t < tMax) return 1;
+    }
+    for (int i = 0; i < r->n_spheres; ++i) {
+        float t;
+        v3 pObj;
+        if (sphere_intersect(&r->spheres[i], o, d, tMax, &t, &pObj)) return 1;
     }
     return 0;
 }
@@ -1338,6 +1582,15 @@ static bsdf_t bsdf_make_tri(const rtri_t *T) {
     b.frame.y = v_cross(T->n, T->dpdu_n);
     b.R = T->Kd;
     b.has_lobes = T->has_bsdf_lobes;
+    return b;
+}
+static bsdf_t bsdf_make_sphere(const rsphere_t *S, const isect_t *si) {
+    bsdf_t b;
+    b.frame.x = si->dpdu_n;
+    b.frame.z = si->n;
+    b.frame.y = v_cross(si->n, si->dpdu_n);
+    b.R = S->Kd;
+    b.has_lobes = S->has_bsdf_lobes;
     return b;
 }
 static spec bsdf_f(const bsdf_t *b, v3 woR, v3 wiR) {
@@ -2103,6 +2356,8 @@ typedef struct {
     v3 wo;
     const bsdf_t *bsdf; /* surface */
     float g;            /* medium: HG */
+    int iface;          /* surface: its medium transition (0: none) */
+    int medium;         /* Interaction::medium: of the ray that hit a non-transition surface / of the medium interaction */
 } intr_t;
 
 static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t *gw, int ch, sampler_t *sampler,
@@ -2165,11 +2420,20 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
     rng_t rng;
     rng_set_sequence2(&rng, oracle_hash_point3(lo.x, lo.y, lo.z), oracle_hash_point3(ld.x, ld.y, ld.z));
     if (pc) pc->shadow_rays++;
-    if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
-        /* every surface in this scene has a material: any hit is an opaque blocker (:1197-1200) */
-        if (scene_intersect_any(r, lo, ld, 1 - SHADOW_EPS)) return S1(0.f);
-        if (r->scene.medium.type != VSPG_MEDIUM_NONE) {
-            float tMax = 1 - SHADOW_EPS;
+    int lmed = r->has_medium ? get_medium(intr->iface, intr->n, ld, intr->medium) : 0; /* r.medium = GetMedium(r.d) (interaction.h:111-115) */
+    while (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) { /* :1195-1244 */
+        /* Intersect(lightRay, 1 - ShadowEpsilon): a hit with a material blocks (:1197-1200); an interface hit ends the segment.
+         * Without boundaries every surface has a material: any hit decides, the closest need not be found. */
+        isect_t si;
+        memset(&si, 0, sizeof si);
+        if (r->has_boundaries) {
+            si = scene_intersect(r, lo, ld, 1 - SHADOW_EPS);
+            if (si.hit && si.has_material) return S1(0.f);
+        } else if (scene_intersect_any(r, lo, ld, 1 - SHADOW_EPS)) {
+            return S1(0.f);
+        }
+        if (lmed) {
+            float tMax = si.hit ? si.t : 1 - SHADOW_EPS;
             float us = rng_float(&rng);
             shadow_cb_ctx_t c;
             c.r = r; c.ch = ch; c.T_ray = T_ray; c.r_l = r_l; c.r_u = r_u; c.rng = &rng;
@@ -2180,6 +2444,10 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
             r_u = s_mul(r_u, s_divf(T_maj, T_maj.c[ch]));
         }
         if (!s_nonzero(T_ray)) return S1(0.f);
+        if (!si.hit) break;
+        /* lightRay = si->intr.SpawnRayTo(ls->pLight) (:1243): from the interface, in the medium its far side holds */
+        spawn_ray_to(isect_pi(&si), si.n, ls.pLight, ls.nLight, &lo, &ld);
+        lmed = get_medium(si.iface, si.n, ld, lmed);
     }
     r_l = s_mul(r_l, s_scale(r_p, p_l));
     r_u = s_mul(r_u, s_scale(r_p, scatterPDF));
@@ -2300,6 +2568,7 @@ typedef struct {
     isg_sample_t *isg;
     path_counters_t *pc;
     gwrap_t *gbsdf, *gphase; /* persist across the path loop like the GuidedBSDF / GuidedPhaseFunction objects (:287-288) */
+    int in_medium; /* ray.medium != nullptr (always 1 where SampleDistance runs, :318) */
 } sd_ctx_t;
 
 /* volume-scatter tail shared by both branches (:804-875 == :988-1058) */
@@ -2312,6 +2581,7 @@ static void scatter_tail(sd_ctx_t *c, v3 p, const medium_props_t *mp) {
         intr.pi = p3i_exact(p);
         intr.wo = v_neg(*c->ray_d);
         intr.g = mp->g;
+        intr.medium = c->in_medium; /* MediumInteraction(p, wo, time, ray.medium, phase) (:806 / :990) */
         float v = sampler_get1d(c->sampler);
         (void)v;
         /* gphase.init(&intr.phase, p, ray.d, v) (guiding.h:383-398) */
@@ -2696,12 +2966,15 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         guideRR = 1;
     }
 
+    /* ray.medium: the camera ray starts in the camera's medium (cameras.h CameraBase::medium, set from the graphics state's
+     * outside medium at the Camera directive, scene.cpp:153-155); every spawned ray takes GetMedium(direction) */
+    int in_medium = r->camera_in_medium;
     while (1) {
         pc->segments++;
         isect_t si = scene_intersect(r, ro, rd, INFINITY);
         float tMax = si.hit ? si.t : INFINITY;
         spec transmittanceWeight = S1(1.0f); /* :317 */
-        if (r->scene.medium.type != VSPG_MEDIUM_NONE) { /* ray.medium: one medium fills the scene (an escaping ray is sampled too, tMax = Infinity) */
+        if (in_medium && !isinf(tMax)) { /* :318 -- a ray that escapes the scene is not sampled (rounds 1-3 sampled it: wrong) */
             rng_t rng;
             uint64_t hash0 = oracle_hash_float(sampler_get1d(sampler));
             uint64_t hash1 = oracle_hash_float(sampler_get1d(sampler));
@@ -2718,6 +2991,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             c.isg = isg; c.pc = pc;
             c.gbsdf = &gbsdf; c.gphase = &gphase;
             c.rec = rec; c.transmittanceWeight = &transmittanceWeight;
+            c.in_medium = in_medium;
             sample_distance(&c, px, py, tMax);
             if (c.terminated || !s_nonzero(beta) || !s_nonzero(r_u)) break;
             if (c.scattered) continue;
@@ -2743,9 +3017,9 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             break;
         }
 
-        const rquad_t *q = &r->quads[si.tri >= 0 ? 0 : si.quad];
-        /* isect.Le(-ray.d) (:377-397); triangles carry no area light */
-        spec Le = si.tri < 0 && q->is_light ? light_L(q, si.n, v_neg(rd)) : S1(0.f);
+        const rquad_t *q = &r->quads[si.quad < 0 ? 0 : si.quad];
+        /* isect.Le(-ray.d) (:377-397); triangles and spheres carry no area light */
+        spec Le = si.quad >= 0 && q->is_light ? light_L(q, si.n, v_neg(rd)) : S1(0.f);
         int add_direct_contribution = 0;
         float w_direct = 0.f;
         if (s_nonzero(Le)) {
@@ -2763,7 +3037,13 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
                 w_direct = w_l;
             }
         }
-        bsdf_t bsdf = si.tri >= 0 ? bsdf_make_tri(&r->tris[si.tri]) : bsdf_make(q);
+        p3i pi = isect_pi(&si); /* SurfaceInteraction pi (shapes.h InteractionFromIntersection) */
+        if (!si.has_material) { /* :399-404: no BSDF -- a medium boundary.  isect.SkipIntersection(&ray, si->tHit) (interaction.cpp:91-97) */
+            ro = offset_ray_origin(pi, si.n, rd); /* SpawnRay(ray->d) (interaction.h:99-101) */
+            in_medium = r->has_medium ? get_medium(si.iface, si.n, rd, in_medium) : 0;
+            continue;
+        }
+        bsdf_t bsdf = si.tri >= 0 ? bsdf_make_tri(&r->tris[si.tri]) : (si.sphere >= 0 ? bsdf_make_sphere(&r->spheres[si.sphere], &si) : bsdf_make(q));
         rec_new_segment(rec, v_add(ro, v_scale(rd, si.t)), 0); /* guiding_newSurfacePathSegment (:406) */
         if (add_direct_contribution) rec_add_surface_emission(rec, Le, w_direct); /* :409-412 */
         if (depth == 0) {
@@ -2785,8 +3065,8 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         intr_t intr;
         memset(&intr, 0, sizeof intr);
         intr.is_surface = 1;
-        p3i pi = p3i_from_err(si.p, si.perr); /* SurfaceInteraction pi (shapes.h InteractionFromIntersection) */
         intr.pi = pi; intr.n = si.n;
+        intr.iface = si.iface; intr.medium = in_medium;
         intr.wo = v_normalize(v_neg(rd)); /* Interaction ctor normalises wo (interaction.h:31-32) */
         intr.bsdf = &bsdf;
         /* gbsdf.init(&bsdf, ray, si, v) (guiding.h:83-109): p = ray.o + tHit*ray.d, cosine product
@@ -2894,6 +3174,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
         anyNonSpecularBounces = 1;
         ro = offset_ray_origin(pi, si.n, wi); /* SpawnRay (interaction.h:99-101) */
         rd = wi;
+        in_medium = r->has_medium ? get_medium(si.iface, si.n, wi, in_medium) : 0; /* ... with GetMedium(wi) */
 
         if (!s_nonzero(beta)) break;
         if (!guideRR && depth > r->prm.minrrdepth) { /* :597-600 */
@@ -3405,6 +3686,7 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
     if (!scene || !p || !cfg) return VSPG_EINVAL;
     if (cfg->xres <= 0 || cfg->yres <= 0) return VSPG_EINVAL;
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return VSPG_EINVAL;
+    if (scene->n_spheres < 0 || scene->n_spheres > VSPG_MAX_SPHERES) return VSPG_EINVAL;
     if (medium_is_grid_like(scene->medium.type)) {
         const VspgMedium *m = &scene->medium;
         if (m->nx <= 0 || m->ny <= 0 || m->nz <= 0 || !m->density) return VSPG_EINVAL;
@@ -3463,9 +3745,24 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
                 T->Kd.c[k] = v < 0 ? 0 : (v > 1 ? 1 : v);
             }
             T->has_bsdf_lobes = T->Kd.c[0] != 0 || T->Kd.c[1] != 0 || T->Kd.c[2] != 0;
+            const int fl = scene->tri_flags ? scene->tri_flags[i] : 0;
+            T->has_material = !(fl & VSPG_TRI_INTERFACE);
+            T->iface = iface_transition(fl >> VSPG_TRI_IFACE_SHIFT);
+            if (fl & VSPG_TRI_FLIP_NORMAL) T->n = v_neg(T->n); /* reverseOrientation ^ transformSwapsHandedness (shapes.h:934-936) */
         }
-        r->scene.tri_p = NULL; r->scene.tri_kd = NULL;
+        r->scene.tri_p = NULL; r->scene.tri_kd = NULL; r->scene.tri_flags = NULL;
     }
+    r->n_spheres = scene->n_spheres;
+    for (int i = 0; i < r->n_spheres; ++i) {
+        rc = sphere_init(&r->spheres[i], &scene->spheres[i]);
+        if (rc) { free(r->tris); free(r); return rc; }
+    }
+    r->has_medium = scene->medium.type != VSPG_MEDIUM_NONE;
+    r->camera_in_medium = r->has_medium && !scene->camera_outside_medium;
+    r->has_boundaries = scene->camera_outside_medium != 0;
+    for (int i = 0; i < r->n_quads; ++i) r->has_boundaries |= !r->quads[i].has_material || r->quads[i].iface;
+    for (int i = 0; i < r->n_tris; ++i) r->has_boundaries |= !r->tris[i].has_material || r->tris[i].iface;
+    for (int i = 0; i < r->n_spheres; ++i) r->has_boundaries |= !r->spheres[i].has_material || r->spheres[i].iface;
     r->n_inf = scene->n_infinite_lights;
     { /* scene bounds = union of every primitive's bounds (the rectangles' corners, the triangles' vertices), BoundingSphere */
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -3481,6 +3778,17 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
             for (int j = 0; j < 3; ++j) {
                 const float q[3] = {c[j].x, c[j].y, c[j].z};
                 for (int k = 0; k < 3; ++k) { lo[k] = q[k] < lo[k] ? q[k] : lo[k]; hi[k] = q[k] > hi[k] ? q[k] : hi[k]; }
+            }
+        }
+        for (int i = 0; i < r->n_spheres; ++i) { /* Sphere::Bounds (shapes.cpp:33-36): the eight corners of the object-space box, transformed */
+            const rsphere_t *S = &r->spheres[i];
+            for (int c = 0; c < 8; ++c) {
+                const float x = (c & 1) ? S->radius : -S->radius, y = (c & 2) ? S->radius : -S->radius, z = (c & 4) ? S->radius : -S->radius;
+                for (int k = 0; k < 3; ++k) {
+                    const float *row = S->m + 4 * k;
+                    const float q = row[0] * x + row[1] * y + row[2] * z + row[3];
+                    lo[k] = q < lo[k] ? q : lo[k]; hi[k] = q > hi[k] ? q : hi[k];
+                }
             }
         }
         r->scene_radius = 0.f;

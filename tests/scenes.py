@@ -169,3 +169,103 @@ def box_wall_triangles():
     tris += quad((1, -1, -1), (0, 0, 2), (0, 2, 0))    # right
     tris = np.stack(tris).astype(np.float32)
     return tris, np.full((tris.shape[0], 3), 0.73, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# medium boundaries (round 4): camera outside the medium, interface surfaces, spheres
+# ---------------------------------------------------------------------------------------------
+def empty_scene(W, H, eye, look, up=(0, 1, 0), fov=40.0):
+    """No geometry, no medium, no light: camera only."""
+    P = load_package()
+    s = P.VspgScene()
+    lib = oracle_lib.load()
+    rc = lib.oracle_camera_look_at(C.byref(s.camera), P.f3(*eye), P.f3(*look), P.f3(*up), C.c_float(fov), W, H)
+    assert rc == 0
+    return s
+
+
+def add_quad(scene, p00, e1, e2, kd=(0.5, 0.5, 0.5), le=(0, 0, 0), material=0, iface=0, reverse=0, two_sided=0):
+    k = scene.n_quads
+    q = scene.quads[k]
+    q.p00[:] = p00
+    q.e1[:] = e1
+    q.e2[:] = e2
+    q.Kd[:] = kd
+    q.Le[:] = le
+    q.two_sided, q.reverse_orientation, q.material, q.medium_interface = two_sided, reverse, material, iface
+    scene.n_quads = k + 1
+    return scene
+
+
+def interface_box(scene, bmin, bmax, iface=None):
+    """Six interface-material rectangles around [bmin, bmax], normals pointing OUT, the scene's medium inside:
+    AttributeBegin MediumInterface "m" "" Material "interface" Shape ... AttributeEnd."""
+    P = load_package()
+    iface = P.IFACE_INSIDE if iface is None else iface
+    x0, y0, z0 = bmin
+    x1, y1, z1 = bmax
+    dx, dy, dz = x1 - x0, y1 - y0, z1 - z0
+    faces = [((x0, y0, z0), (0, 0, dz), (0, dy, 0)),   # x = x0, n = -x  (e1 x e2 = z x y = -x)
+             ((x1, y0, z0), (0, dy, 0), (0, 0, dz)),   # x = x1, n = +x
+             ((x0, y0, z0), (dx, 0, 0), (0, 0, dz)),   # y = y0, n = -y  (x x z = -y)
+             ((x0, y1, z0), (0, 0, dz), (dx, 0, 0)),   # y = y1, n = +y
+             ((x0, y0, z0), (0, dy, 0), (dx, 0, 0)),   # z = z0, n = -z  (y x x = -z)
+             ((x0, y0, z1), (dx, 0, 0), (0, dy, 0))]   # z = z1, n = +z
+    for p00, e1, e2 in faces:
+        add_quad(scene, p00, e1, e2, kd=(0, 0, 0), material=P.MATERIAL_INTERFACE, iface=iface)
+    return scene
+
+
+def add_sphere(scene, center, radius, material=0, iface=0, kd=(0.5, 0.5, 0.5), scale=(1, 1, 1), reverse=0):
+    """Shape "sphere" under Translate(center) * Scale(scale)."""
+    P = load_package()
+    k = scene.n_spheres
+    sp = scene.spheres[k]
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0], m[1, 1], m[2, 2] = scale
+    m[0, 3], m[1, 3], m[2, 3] = center
+    inv = np.linalg.inv(m.astype(np.float64)).astype(np.float32)
+    sp.render_from_object[:] = [float(x) for x in m.reshape(16)]
+    sp.object_from_render[:] = [float(x) for x in inv.reshape(16)]
+    sp.radius = radius
+    sp.Kd[:] = kd
+    sp.reverse_orientation, sp.material, sp.medium_interface = reverse, material, iface
+    scene.n_spheres = k + 1
+    return scene
+
+
+def cloud_scene(W, H, density, n, sigma_t=8.0, albedo=0.99, g=0.877, nvdb=False, sphere=True, ground=True, sun=True, sky=True):
+    """The shape of the reference's cloud scenes (BASELINE configs 3-5): camera in vacuum, the medium inside an
+    interface-material bounding shape (MediumInterface "cloud" "" + Material "interface"), a diffuse ground below, a
+    distant light and a uniform sky."""
+    P = load_package()
+    s = empty_scene(W, H, eye=(0.0, 0.6, -4.2), look=(0, 0.15, 0), fov=38.0)
+    m = s.medium
+    m.type = P.MEDIUM_NANOVDB if nvdb else P.MEDIUM_GRID
+    m.sigma_a[:] = (sigma_t * (1 - albedo),) * 3
+    m.sigma_s[:] = (sigma_t * albedo,) * 3
+    m.g = g
+    m.nx = m.ny = m.nz = n
+    m.bounds_min[:] = (-0.8, -0.5, -0.8)
+    m.bounds_max[:] = (0.8, 0.9, 0.8)
+    m.density = density.ctypes.data_as(C.POINTER(C.c_float))
+    s._density_keepalive = density
+    if nvdb:
+        for k in range(3):
+            m.index_min[k] = 0
+            m.voxel_size[k] = (m.bounds_max[k] - m.bounds_min[k]) / n
+            m.grid_origin[k] = m.bounds_min[k]
+        m.density_offset = 0.0
+        m.majorant_scale = 1.0
+    s.camera_outside_medium = 1
+    if sphere:   # radius sqrt(0.8^2 + 0.7^2 + 0.8^2) around the bounds' centre: the bounds fit inside
+        add_sphere(s, (0.0, 0.2, 0.0), 1.34, material=P.MATERIAL_INTERFACE, iface=P.IFACE_INSIDE)
+    else:
+        interface_box(s, (-0.8, -0.5, -0.8), (0.8, 0.9, 0.8))
+    if ground:
+        add_quad(s, (-6, -1.2, -6), (0, 0, 12), (12, 0, 0), kd=(0.4, 0.35, 0.3))   # n = +y
+    if sun:
+        P.add_infinite_light(s, P.LIGHT_DISTANT, (6.0, 5.5, 5.0), (0.4, 0.8, -0.3))
+    if sky:
+        P.add_infinite_light(s, P.LIGHT_UNIFORM_INFINITE, (0.25, 0.35, 0.5))
+    return s

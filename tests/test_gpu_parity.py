@@ -1686,7 +1686,7 @@ def test_guiding_with_triangles_and_infinite_lights_vs_oracle(gpu_pkg, medium):
     c.render_wave(0, 2)
     sg, sc = g.training_stats(), c.training_stats()
     assert sg["training"] == sc["training"] == 1
-    assert sg["n_samples"] == sc["n_samples"] > 1000 and sg["n_zero"] == sc["n_zero"]
+    assert sg["n_samples"] == sc["n_samples"] > 500 and sg["n_zero"] == sc["n_zero"]  # (an open scene: rays that escape are not sampled, :318)
     a, b = _sorted_samples(g.train_samples()), _sorted_samples(c.train_samples())
     assert a.tobytes() == b.tobytes()
     if medium == "cloud":  # (a homogeneous medium fills space: no ray ever escapes it)
@@ -1891,7 +1891,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c.render_wave(0, n_waves)
     sg, sc = g.training_stats(), c.training_stats()
     assert sg["training"] == sc["training"] == 1
-    assert sg["n_samples"] == sc["n_samples"] > 1000 and sg["n_zero"] == sc["n_zero"]
+    assert sg["n_samples"] == sc["n_samples"] > 500 and sg["n_zero"] == sc["n_zero"]  # (an open scene: rays that escape are not sampled, :318)
     a, b = _sorted_samples(g.train_samples()), _sorted_samples(c.train_samples())
     assert a.tobytes() == b.tobytes()
     assert set(np.unique(a["flags"])) <= {0, 1, 2, 3} and (a["flags"] & 1).any() and (~a["flags"] & 1).any()
@@ -2159,7 +2159,7 @@ def test_config5_standin_vs_oracle(gpu_pkg):
     c.render_wave(0, 2)
     sg, sc = g.training_stats(), c.training_stats()
     assert sg["training"] == sc["training"] == 1
-    assert sg["n_samples"] == sc["n_samples"] > 1000 and sg["n_zero"] == sc["n_zero"]
+    assert sg["n_samples"] == sc["n_samples"] > 500 and sg["n_zero"] == sc["n_zero"]  # (an open scene: rays that escape are not sampled, :318)
     a, b = _sorted_samples(g.train_samples()), _sorted_samples(c.train_samples())
     assert a.tobytes() == b.tobytes()
     g.close(); c.close()
@@ -2449,3 +2449,171 @@ def test_guided_russian_roulette_vs_oracle(gpu_pkg, guiding):
 def light_field_for(P):
     from scenes import light_field
     return light_field(P, n=4)
+
+
+# ---------------------------------------------------------------------------------------------
+# medium boundaries (round 4, row X3): MediumInterface + Material "interface" (:318, :399-404, :1196-1243,
+# interaction.h:117-121), Shape "sphere" (shapes.h:107-330) -- the HIP path against the oracle, bit for bit
+# ---------------------------------------------------------------------------------------------
+def _boundary_scene(P, name, W, H):
+    from scenes import add_quad, add_sphere, cloud_density, cloud_scene, empty_scene, interface_box, grid_scene
+    if name == "absorbing-sphere-sky":      # camera in vacuum, homogeneous medium inside an interface sphere, uniform sky
+        s = empty_scene(W, H, (0, 0, -4), (0, 0, 0), fov=35.0)
+        s.medium.type = P.MEDIUM_HOMOGENEOUS
+        s.medium.sigma_a[:] = (0.3, 0.5, 0.8)
+        s.medium.sigma_s[:] = (1.2, 1.0, 0.7)
+        s.medium.g = 0.4
+        s.camera_outside_medium = 1
+        add_sphere(s, (0.1, 0, 0), 1.0, material=P.MATERIAL_INTERFACE, iface=P.IFACE_INSIDE, scale=(1.2, 1.0, 0.9))
+        add_quad(s, (-6, -1.4, -6), (0, 0, 12), (12, 0, 0), kd=(0.5, 0.4, 0.3))
+        P.add_infinite_light(s, P.LIGHT_UNIFORM_INFINITE, (0.8, 0.9, 1.0))
+        P.add_infinite_light(s, P.LIGHT_DISTANT, (3.0, 2.8, 2.5), (0.3, 0.9, -0.2))
+        return s
+    if name in ("grid-box-shell", "grid-sphere-shell", "nvdb-sphere-shell"):   # closed diffuse shell with a light, a bounded grid medium
+        n = 16
+        dens = cloud_density(n)
+        s = empty_scene(W, H, (0, 0.1, -2.6), (0, 0, 0), fov=45.0)
+        m = s.medium
+        m.type = P.MEDIUM_NANOVDB if name.startswith("nvdb") else P.MEDIUM_GRID
+        m.sigma_a[:] = (0.4, 0.3, 0.2)
+        m.sigma_s[:] = (3.0, 3.2, 3.4)
+        m.g = 0.3
+        m.nx = m.ny = m.nz = n
+        m.bounds_min[:] = (-0.7, -0.7, -0.7)
+        m.bounds_max[:] = (0.7, 0.7, 0.7)
+        m.density = dens.ctypes.data_as(C.POINTER(C.c_float))
+        s._density_keepalive = dens
+        if name.startswith("nvdb"):
+            for k in range(3):
+                m.index_min[k] = 0
+                m.voxel_size[k] = 1.4 / n
+                m.grid_origin[k] = -0.7
+            m.majorant_scale = 1.0
+        for p00, e1, e2 in [((-3, -3, -3), (0, 0, 6), (6, 0, 0)), ((-3, 3, -3), (6, 0, 0), (0, 0, 6)), ((-3, -3, 3), (0, 6, 0), (6, 0, 0)),
+                            ((-3, -3, -3), (6, 0, 0), (0, 6, 0)), ((-3, -3, -3), (0, 6, 0), (0, 0, 6)), ((3, -3, -3), (0, 0, 6), (0, 6, 0))]:
+            add_quad(s, p00, e1, e2, kd=(0.6, 0.55, 0.5))
+        add_quad(s, (-0.8, 2.99, -0.8), (1.6, 0, 0), (0, 0, 1.6), le=(6, 6, 5), kd=(0, 0, 0))
+        s.camera_outside_medium = 1
+        if "box" in name:
+            interface_box(s, (-0.7, -0.7, -0.7), (0.7, 0.7, 0.7))
+        else:
+            add_sphere(s, (0, 0, 0), 1.25, material=P.MATERIAL_INTERFACE, iface=P.IFACE_INSIDE)
+        return s
+    if name in ("cloud-scene", "cloud-scene-nvdb", "cloud-scene-box"):         # the reference's cloud-scene shape
+        return cloud_scene(W, H, cloud_density(24), 24, nvdb=name.endswith("nvdb"), sphere=not name.endswith("box"))
+    if name == "fog-diffuse-sphere":        # the fog box with a DIFFUSE sphere in it: BSDF frame, NEE and MIS from a sphere vertex
+        s = P.fog_box_scene(W, H)
+        add_sphere(s, (0.3, -0.5, 0.2), 0.4, kd=(0.7, 0.5, 0.3), scale=(1.0, 1.3, 0.8))
+        return s
+    if name == "fog-hollow":                # the fog box with a vacuum bubble: MediumInterface "" "fog" on an interface sphere
+        s = P.fog_box_scene(W, H)
+        add_sphere(s, (0.0, 0.0, 0.3), 0.5, material=P.MATERIAL_INTERFACE, iface=P.IFACE_OUTSIDE)
+        return s
+    if name == "tri-interface-box":         # the bounded grid behind an interface box made of TRIANGLES, one side with flipped winding + flag
+        s = _boundary_scene(P, "grid-sphere-shell", W, H)
+        s.n_spheres = 0
+        lo, hi = np.float32([-0.7] * 3), np.float32([0.7] * 3)
+        tris, flags = [], []
+        for ax in range(3):
+            for side in (0, 1):
+                u, v = (ax + 1) % 3, (ax + 2) % 3
+                c = [np.zeros(3, np.float32) for _ in range(4)]
+                for k, (a, b) in enumerate([(0, 0), (1, 0), (1, 1), (0, 1)]):
+                    c[k][ax] = hi[ax] if side else lo[ax]
+                    c[k][u] = hi[u] if a else lo[u]
+                    c[k][v] = hi[v] if b else lo[v]
+                quad = [c[0], c[1], c[2], c[3]] if side else [c[0], c[3], c[2], c[1]]   # n = Normalize(Cross(p0 - p2, p1 - p2)): outward
+                t0, t1 = [quad[0], quad[1], quad[2]], [quad[0], quad[2], quad[3]]
+                fl = P.TRI_INTERFACE | (P.IFACE_INSIDE << P.TRI_IFACE_SHIFT)
+                if ax == 2:     # this pair is wound the other way round and says so
+                    t0, t1 = t0[::-1], t1[::-1]
+                    fl |= P.TRI_FLIP_NORMAL
+                tris += [t0, t1]
+                flags += [fl, fl]
+        P.set_triangles(s, np.array(tris, dtype=np.float32))
+        fa = np.array(flags, dtype=np.int32)
+        s.tri_flags = fa.ctypes.data_as(C.POINTER(C.c_int32))
+        s._tri_keepalive.append(fa)
+        return s
+    if name == "open-fog-sky":              # :318: a medium that fills an open scene -- rays that escape are not sampled
+        s = _boundary_scene(P, "absorbing-sphere-sky", W, H)
+        s.n_spheres = 0
+        s.camera_outside_medium = 0
+        return s
+    raise KeyError(name)
+
+
+BOUNDARY_SCENES = ["absorbing-sphere-sky", "grid-box-shell", "grid-sphere-shell", "nvdb-sphere-shell", "cloud-scene", "cloud-scene-nvdb",
+                   "cloud-scene-box", "fog-diffuse-sphere", "fog-hollow", "tri-interface-box", "open-fog-sky"]
+
+
+@pytest.mark.parametrize("name", BOUNDARY_SCENES)
+@pytest.mark.parametrize("options", ["app-f", "defaults", "nds"])
+def test_medium_boundaries_vs_oracle(gpu_pkg, name, options):
+    """Replayed paths bit-identical to the oracle's, the film of three waves (post-processed: the VSP buffer updates) equal to
+    the oracle's film, equal counters -- on every kernel that takes the scene."""
+    P = gpu_pkg
+    W, H = 64, 48
+    scene = _boundary_scene(P, name, W, H)
+    if options == "app-f":
+        prm = P.app_f_params()
+    elif options == "defaults":          # the reference's default options (surface RIS + volume MIS guiding, secondary VSP) over a hand-made
+        prm = P.default_params()         # field (scenes.light_field: stands in for a trained one; training has its own tests)
+        prm.lightsampler = P.LIGHTSAMPLER_UNIFORM if name == "fog-hollow" else prm.lightsampler
+    else:
+        prm = P.app_f_params()
+        prm.vspsamplingmethod = P.VSP_NDS
+    if options == "nds" and name == "fog-diffuse-sphere":
+        pytest.skip("one NDS case per medium kind is enough")
+    names = set()
+    rng = np.random.default_rng(11)
+    n = 6000
+    xy = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 64, n).astype(np.int32)
+    import scenes
+    field = scenes.light_field(P, n=2, bmin=(-3, -3, -3), bmax=(3, 3, 3), light=(0.0, 2.9, 0.0)) if options == "defaults" else None
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
+    if field:
+        c.set_guiding_field(field, field)
+    Lc, sc = c.trace_paths(xy, si)
+    def on_kernel(kernel):
+        g = P.Renderer(scene, prm, W, H, seed=3)
+        if field:
+            g.set_guiding_field(field, field)
+        kn = g.kernel_name()
+        if kn in names:
+            g.close()
+            return
+        names.add(kn)
+        Lg, sg = g.trace_paths(xy, si)
+        same = np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)
+        assert np.array_equal(sg, sc), (kn, np.flatnonzero(sg != sc)[:5])
+        assert same.all(), (kn, np.flatnonzero(~same)[:5], Lg[~same][:3], Lc[~same][:3])
+        cc = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
+        if field:
+            cc.set_guiding_field(field, field)
+        for w in range(3):
+            g.render_wave(w, w + 1)
+            g.post_process_wave()
+            cc.render_wave(w, w + 1)
+            cc.post_process_wave()
+        fg, fc = g.film(), cc.film()
+        assert np.array_equal(fg[..., 3], fc[..., 3])
+        assert np.allclose(fg[..., :3], fc[..., :3], rtol=2e-6, atol=1e-7), kn
+        cg, co = g.counters(), cc.counters()
+        assert cg == co, (kn, cg, co)
+        g.close(); cc.close()
+    for kernel in (None, "lane"):     # (the kernel is chosen per launch: the variable stays set while the renderer is used)
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            on_kernel(kernel)
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    het = scene.medium.type != P.MEDIUM_HOMOGENEOUS
+    assert len(names) == (2 if het else 1), names   # heterogeneous media: the wavefront pipeline AND the per-lane kernel
+    assert np.isfinite(Lc).all() and Lc.max() > 0
+    if name.startswith("cloud-scene"):
+        assert sc.max() >= 5      # paths that enter, scatter, leave and hit the ground: boundary crossings are iterations of the loop
+    c.close()
+    print(name, options, sorted(names))

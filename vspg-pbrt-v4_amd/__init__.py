@@ -32,7 +32,19 @@ f3 = C.c_float * 3
 
 class VspgQuad(C.Structure):
     _fields_ = [("p00", f3), ("e1", f3), ("e2", f3), ("Kd", f3), ("Le", f3),
-                ("two_sided", C.c_int32), ("reverse_orientation", C.c_int32)]
+                ("two_sided", C.c_int32), ("reverse_orientation", C.c_int32),
+                ("material", C.c_int32), ("medium_interface", C.c_int32)]
+
+
+VSPG_MAX_SPHERES = 8
+MATERIAL_DIFFUSE, MATERIAL_INTERFACE = 0, 1
+IFACE_INSIDE, IFACE_OUTSIDE = 1, 2
+TRI_INTERFACE, TRI_IFACE_SHIFT, TRI_FLIP_NORMAL = 1, 1, 8
+
+
+class VspgSphere(C.Structure):
+    _fields_ = [("render_from_object", C.c_float * 16), ("object_from_render", C.c_float * 16), ("radius", C.c_float),
+                ("Kd", f3), ("reverse_orientation", C.c_int32), ("material", C.c_int32), ("medium_interface", C.c_int32)]
 
 
 class VspgCamera(C.Structure):
@@ -64,7 +76,9 @@ class VspgScene(C.Structure):
     _fields_ = [("n_quads", C.c_int32), ("quads", VspgQuad * VSPG_MAX_QUADS),
                 ("camera", VspgCamera), ("medium", VspgMedium),
                 ("n_triangles", C.c_int32), ("tri_p", C.POINTER(C.c_float)), ("tri_kd", C.POINTER(C.c_float)),
-                ("n_infinite_lights", C.c_int32), ("infinite_lights", VspgInfiniteLight * VSPG_MAX_INFINITE_LIGHTS)]
+                ("n_infinite_lights", C.c_int32), ("infinite_lights", VspgInfiniteLight * VSPG_MAX_INFINITE_LIGHTS),
+                ("tri_flags", C.POINTER(C.c_int32)), ("n_spheres", C.c_int32), ("spheres", VspgSphere * VSPG_MAX_SPHERES),
+                ("camera_outside_medium", C.c_int32)]
 
 
 class VspgIntegratorParams(C.Structure):

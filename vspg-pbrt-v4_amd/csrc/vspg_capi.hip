@@ -2000,7 +2000,14 @@ static void build(const VspgScene &sc, const VspgIntegratorParams &prm, DScene *
 }
 }  // namespace lsb
 
-static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T);
+static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T, const int32_t *flags = nullptr);
+// SURF_* flags from the C-ABI's material / medium_interface pair: a MediumInterface only counts when it is a TRANSITION
+// (inside != outside, base/medium.h:124)
+static int32_t surf_flags_of(int material, int medium_interface) {
+    const int b = medium_interface & (VSPG_IFACE_INSIDE | VSPG_IFACE_OUTSIDE);
+    const int iface = (b == VSPG_IFACE_INSIDE || b == VSPG_IFACE_OUTSIDE) ? b : 0;
+    return (material == VSPG_MATERIAL_INTERFACE ? SURF_INTERFACE : 0) | (iface << SURF_IFACE_SHIFT);
+}
 static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, const VspgRenderConfig &cfg, DScene *D) {
     using namespace hostmath;
     memset(D, 0, sizeof *D);
@@ -2035,6 +2042,7 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
         q.two_sided = in.two_sided;
         q.is_light = light;
         q.has_lobes = lobes;
+        q.flags = surf_flags_of(in.material, in.medium_interface);
         // axis-aligned fast path: n, e1, e2 each have exactly one non-zero component
         auto single_axis = [](const float *v) {
             int nz = 0, ax = -1;
@@ -2070,6 +2078,23 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
             DTri T;
             if (derive_triangle(sc.tri_p + 9 * (size_t)i, nullptr, i, &T)) { grow(T.p0); grow(T.p1); grow(T.p2); }
         }
+        for (int i = 0; i < sc.n_spheres; ++i) {  // Sphere::Bounds (shapes.cpp:33-36): the corners of the object-space box, transformed
+            const float *m = sc.spheres[i].render_from_object, rr = sc.spheres[i].radius;
+            for (int c = 0; c < 8; ++c) {
+                const float x = (c & 1) ? rr : -rr, y = (c & 2) ? rr : -rr, z = (c & 4) ? rr : -rr;
+                float q[3];
+                for (int k = 0; k < 3; ++k) {
+                    volatile float a = m[4 * k] * x;  // volatile: one rounding per operation, as the oracle's -ffp-contract=off build
+                    volatile float b = m[4 * k + 1] * y;
+                    volatile float c2 = m[4 * k + 2] * z;
+                    volatile float sum = a + b;
+                    sum = sum + c2;
+                    sum = sum + m[4 * k + 3];
+                    q[k] = sum;
+                }
+                grow(q);
+            }
+        }
         D->scene_radius = 0.f;
         if (lo[0] <= hi[0]) {
             volatile float cx = (lo[0] + hi[0]) / 2, cy = (lo[1] + hi[1]) / 2, cz = (lo[2] + hi[2]) / 2;
@@ -2080,6 +2105,42 @@ static void build_dscene(const VspgScene &sc, const VspgIntegratorParams &prm, c
             D->scene_radius = std::sqrt(l2);
         }
     }
+    // Shape "sphere": the constants the Sphere constructor derives (shapes.h:117-128), full sphere
+    D->n_spheres = sc.n_spheres;
+    for (int i = 0; i < sc.n_spheres; ++i) {
+        const VspgSphere &in = sc.spheres[i];
+        DSphere &sp = D->spheres[i];
+        for (int k = 0; k < 12; ++k) { sp.m[k] = in.render_from_object[k]; sp.mi[k] = in.object_from_render[k]; }
+        sp.radius = in.radius;
+        const float *m = in.render_from_object;  // Transform::SwapsHandedness: Determinant(SquareMatrix<3>) < 0 (transform.cpp:145-152, math.h:1419-1425)
+        const float minor12 = dop(m[5], m[10], m[6], m[9]), minor02 = dop(m[4], m[10], m[6], m[8]), minor01 = dop(m[4], m[9], m[5], m[8]);
+        const bool swaps = std::fmaf(m[2], minor01, dop(m[0], minor12, m[1], minor02)) < 0;
+        sp.flip = (in.reverse_orientation ? 1 : 0) ^ (swaps ? 1 : 0);
+        auto clamp1 = [](float v) { return v < -1.f ? -1.f : (v > 1.f ? 1.f : v); };
+        sp.thetaZMin = std::acos(clamp1(-in.radius / in.radius));  // zMin = -radius, zMax = radius (the "sphere" defaults, shapes.cpp:231-237)
+        sp.thetaZMax = std::acos(clamp1(in.radius / in.radius));
+        {
+            volatile float rad = 3.14159265358979323846f / 180;  // Radians(360) (math.h:261-263) == fl(2 pi): no phi clipping
+            rad = rad * 360.f;
+            sp.phiMax = rad;
+        }
+        bool lobes = false;
+        for (int k = 0; k < 3; ++k) {
+            float kd = in.Kd[k];
+            kd = kd < 0 ? 0 : (kd > 1 ? 1 : kd);
+            sp.Kd[k] = kd;
+            lobes = lobes || kd != 0;
+        }
+        sp.has_lobes = lobes;
+        sp.flags = surf_flags_of(in.material, in.medium_interface);
+    }
+    // medium boundaries: anything that makes "the medium fills the scene" false
+    D->camera_in_medium = sc.medium.type != VSPG_MEDIUM_NONE && !sc.camera_outside_medium;
+    D->has_boundaries = sc.camera_outside_medium != 0;
+    for (int i = 0; i < D->n_quads; ++i) D->has_boundaries |= D->quads[i].flags != 0;
+    for (int i = 0; i < D->n_spheres; ++i) D->has_boundaries |= D->spheres[i].flags != 0;
+    for (int i = 0; i < sc.n_triangles && sc.tri_flags; ++i)
+        D->has_boundaries |= surf_flags_of(sc.tri_flags[i] & VSPG_TRI_INTERFACE, sc.tri_flags[i] >> VSPG_TRI_IFACE_SHIFT) != 0;
     D->cam = sc.camera;
     D->medium_type = sc.medium.type;
     for (int k = 0; k < 3; ++k) {
@@ -2247,7 +2308,7 @@ struct Builder {
 }  // namespace bvhbuild
 
 // what Triangle::InteractionFromIntersection derives from the vertices alone (shapes.h:888-938), same float operations
-static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T) {
+static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T, const int32_t *flags) {
     using namespace hostmath;
     const H3 p0 = ld(p9), p1 = ld(p9 + 3), p2 = ld(p9 + 6);
     auto sub = [](H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; };
@@ -2271,6 +2332,9 @@ static bool derive_triangle(const float *p9, const float *kd, int id, DTri *T) {
     stv(T->dpdu_n, normv(dpdu));
     T->id = id;
     for (int k = 0; k < 3; ++k) { float v = kd ? kd[3 * id + k] : 0.5f; T->Kd[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+    const int fl = flags ? flags[id] : 0;
+    T->flags = surf_flags_of(fl & VSPG_TRI_INTERFACE, fl >> VSPG_TRI_IFACE_SHIFT);
+    if (fl & VSPG_TRI_FLIP_NORMAL) { T->nx = -T->nx; T->ny = -T->ny; T->nz = -T->nz; }  // reverseOrientation ^ transformSwapsHandedness (shapes.h:934-936)
     return true;
 }
 
@@ -2322,6 +2386,14 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     if (cfg->xres <= 0 || cfg->yres <= 0) return fail(VSPG_EINVAL, "film resolution must be positive");
     if (cfg->xres > 32768 || cfg->yres > 32768) return fail(VSPG_EINVAL, "film resolution above 32768 (pixels travel as packed 16-bit pairs)");
     if (scene->n_quads < 0 || scene->n_quads > VSPG_MAX_QUADS) return fail(VSPG_EINVAL, "n_quads out of range");
+    if (scene->n_spheres < 0 || scene->n_spheres > VSPG_MAX_SPHERES) return fail(VSPG_EINVAL, "n_spheres out of range");
+    for (int i = 0; i < scene->n_spheres; ++i) {
+        const VspgSphere &sp = scene->spheres[i];
+        if (!(sp.radius > 0)) return fail(VSPG_EINVAL, "sphere radius must be positive");
+        const float *a = sp.render_from_object, *b = sp.object_from_render;
+        if (a[12] != 0 || a[13] != 0 || a[14] != 0 || a[15] != 1 || b[12] != 0 || b[13] != 0 || b[14] != 0 || b[15] != 1)
+            return fail(VSPG_EINVAL, "a sphere's renderFromObject must be affine (last row 0 0 0 1)");
+    }
     if (cfg->shard_count > 1 && (cfg->shard_index < 0 || cfg->shard_index >= cfg->shard_count))
         return fail(VSPG_EINVAL, "shard_index out of range");
     if (p->maxdepth < 0) return fail(VSPG_EINVAL, "maxdepth must be >= 0");
@@ -2378,7 +2450,13 @@ template <class Medium, bool GUIDED = false, bool TRAIN = false, class WalkMediu
 static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
     const size_t items = (size_t)tilesX * tilesY * 64;
-    const int n_iters = r->prm.maxdepth + 2;
+    // Path-loop iterations of a pass.  Without medium boundaries every iteration ends at a vertex and raises the depth: maxdepth + 1
+    // of them.  With boundaries an iteration may instead cross an interface (Li's `continue` at :399-404, depth unchanged): the loop
+    // runs until the list is empty -- a convex bounding shape costs at most two crossings per vertex -- under a generous cap.
+    const bool bnd = r->hscene.has_boundaries != 0;
+    const int base_iters = r->prm.maxdepth + 1;
+    const int max_iters = bnd ? 4 * (r->prm.maxdepth + 2) + 16 : base_iters;
+    const int n_iters = max_iters + 1;
     if (!r->wf_pool || r->wf_items != items) {
         if (r->wf_pool) (void)hipFree(r->wf_pool);
         if (r->wf_lists) (void)hipFree(r->wf_lists);
@@ -2446,12 +2524,33 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_shadow, hipEventDisableTiming));
     }
     const hipStream_t s2 = serial ? s : r->wf_stream2;
+    // (medium boundaries) has the list of iteration `it` run dry?  One small read-back per iteration past the ones every pass needs.
+    auto list_empty = [&](int it, bool *empty) -> int {
+        unsigned int na = 0;
+        HIPCHK(hipMemcpyAsync(&na, &r->wf_iters[it].n_active, sizeof na, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        *empty = na == 0;
+        return 0;
+    };
+    auto check_drained = [&]() -> int {
+        if (!bnd) return 0;
+        bool empty = true;
+        if (int rc = list_empty(max_iters, &empty)) return rc;
+        if (!empty) return fail(VSPG_ESCOPE, "paths still alive after the pipeline's iteration cap: more medium-boundary crossings per vertex than a pass provides for");
+        return 0;
+    };
     if (r->prm.vspsamplingmethod != VSPG_VSP_RESAMPLING) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
-        for (int it = 0; it <= r->prm.maxdepth; ++it) {
+        for (int it = 0; it < max_iters; ++it) {
+            if (bnd && it > base_iters) {
+                bool empty = false;
+                if (int rc = list_empty(it, &empty)) return rc;
+                if (empty) break;
+            }
             hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
-            if (it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
+            if (bnd || it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
         }
         HIPCHK(hipGetLastError());
+        if (int rc = check_drained()) return rc;
         if (TRAIN) {
             hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a.train, a.rec_cap);
             HIPCHK(hipGetLastError());
@@ -2459,11 +2558,16 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
         return 0;
     }
     hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a);
-    for (int it = 0; it <= r->prm.maxdepth; ++it) {
+    for (int it = 0; it < max_iters; ++it) {
+        if (bnd && it > base_iters) {
+            bool empty = false;
+            if (int rc = list_empty(it, &empty)) return rc;
+            if (empty) break;
+        }
         hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
         if (it > 0 && !serial) HIPCHK(hipStreamWaitEvent(s, r->wf_ev_shadow, 0));
         hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
-        if (it < r->prm.maxdepth) {
+        if (bnd || it < r->prm.maxdepth) {
             // (guided: the next segments begin BEFORE the shadow walk starts -- launched after it, the dense begin kernel crawled in
             // the slots the persistent walk left over and the next distance walk waited for it)
             if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it + 1);
@@ -2476,6 +2580,8 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
         }
     }
     HIPCHK(hipGetLastError());
+    if (bnd && !serial) HIPCHK(hipStreamWaitEvent(s, r->wf_ev_shadow, 0));  // (the last shadow walk finds an empty list; the caller's stream still waits for it)
+    if (int rc = check_drained()) return rc;
     if (TRAIN) {
         hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a.train, a.rec_cap);
         HIPCHK(hipGetLastError());
@@ -2731,7 +2837,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         all.reserve(scene->n_triangles);
         for (int i = 0; i < scene->n_triangles; ++i) {
             DTri T;
-            if (derive_triangle(scene->tri_p + 9 * (size_t)i, scene->tri_kd, i, &T)) all.push_back(T);
+            if (derive_triangle(scene->tri_p + 9 * (size_t)i, scene->tri_kd, i, &T, scene->tri_flags)) all.push_back(T);
         }
         if (!all.empty()) {
             bvhbuild::Builder B;
@@ -2768,6 +2874,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         }
         r->scene.tri_p = nullptr;  // the host arrays belong to the caller
         r->scene.tri_kd = nullptr;
+        r->scene.tri_flags = nullptr;
     }
     CK(hipMalloc(&r->dscene, sizeof(DScene)));
     CK(hipMemcpy(r->dscene, &r->hscene, sizeof(DScene), hipMemcpyHostToDevice));
@@ -2918,12 +3025,15 @@ static const char *kernel_env() {
     const char *e = getenv("VSPG_KERNEL");
     return e && *e ? e : nullptr;
 }
+// Medium boundaries, interface materials and spheres are served by the full-scene code paths (per-lane kernel, pipeline)
+static bool has_boundaries_or_spheres(const VspgRenderer *r) { return r->hscene.has_boundaries != 0 || r->hscene.n_spheres > 0; }
 static bool uses_wg_guided(const VspgRenderer *r) {
     // round 3: the workgroup kernel's guided vertex (vspg_guided_wg.h, four waves per SIMD) is the DEFAULT for a trained or
     // loaded field over a homogeneous medium in a rectangle scene; VSPG_KERNEL=lane selects the per-lane kernel (tests compare
     // the two).  Guided Russian roulette, triangles / infinite lights and non-uniform light samplers stay per-lane.
     const char *kenv = kernel_env();
     if (kenv && strcmp(kenv, "wg") != 0) return false;
+    if (has_boundaries_or_spheres(r)) return false;
     return wants_guiding(r->prm) && !r->prm.rrguiding && r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS &&
            r->hscene.n_tris == 0 && r->hscene.n_inf == 0 && r->hscene.lsamp.mode == VSPG_LIGHTSAMPLER_UNIFORM;
 }
@@ -2931,7 +3041,7 @@ static bool uses_wg_guided(const VspgRenderer *r) {
 // kernel (the segment half of the loop sheds the same per-channel work as the headline kernel's instantiation)
 static bool guided_grey_simple(const VspgRenderer *r) {
     return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS && r->medium_grey && r->surfaces_grey && r->null_zero && r->hscene.n_tris == 0 &&
-           r->hscene.n_inf == 0 && r->hscene.lsamp.mode == VSPG_LIGHTSAMPLER_UNIFORM && !getenv("VSPG_NO_GREY_GUIDED");
+           r->hscene.n_inf == 0 && r->hscene.lsamp.mode == VSPG_LIGHTSAMPLER_UNIFORM && !has_boundaries_or_spheres(r) && !getenv("VSPG_NO_GREY_GUIDED");
 }
 static bool uses_wg_kernel(const VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
@@ -2943,7 +3053,7 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
     // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
     // triangle hits carry a per-hit error bound the LDS pool record has no room for, and the kernel's homogeneous instantiations
     // are built for rectangle scenes with area lights only (HomogeneousMediumT::kSimpleScene)
-    if (r->hscene.n_tris > 0 || r->hscene.n_inf > 0) return false;
+    if (r->hscene.n_tris > 0 || r->hscene.n_inf > 0 || has_boundaries_or_spheres(r)) return false;
     if (r->hscene.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM) return false;  // power / BVH picks of a multi-light scene: the full-scene kernels
     return !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
 }

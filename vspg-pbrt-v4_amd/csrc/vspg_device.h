@@ -446,8 +446,12 @@ struct DQuad {
     float inv_l1, inv_l2, area;
     float Kd[3], Le[3];
     int32_t two_sided, is_light, has_lobes;
-    int32_t pad;
+    int32_t flags;  // SURF_* (medium boundaries)
 };
+// Medium boundaries (round 4; include/vspg.h VSPG_MATERIAL_* / VSPG_IFACE_*): what a surface hands a hit besides its BSDF --
+// bit 0: Material "interface" (no BSDF: Li skips the hit, :399-404); bits 1-2: the VSPG_IFACE_* bits of a medium TRANSITION
+// (MediumInterface with inside != outside), 0 for every other surface (the ray's medium carries on, interaction.h:218-229)
+enum { SURF_INTERFACE = 1, SURF_IFACE_SHIFT = 1 };
 // Packed per-rectangle intersection record: ONE 64-byte scalar load per test (s_load_dwordx16) with
 // no dependent address arithmetic.  kind 0: generic {n, p00, e1, e2, inv_l1, inv_l2}; kind 1: axis
 // aligned {nsign, pa = p00[axis], pu = p00[uaxis], pv = p00[vaxis], l1, l2, inv_l1, inv_l2}.
@@ -499,7 +503,15 @@ struct DTri {
     float dpdu_n[3];
     int32_t id;      // index in the caller's soup (the tie-break of equal hit distances)
     float Kd[3];
-    int32_t pad;
+    int32_t flags;   // SURF_* (nx, ny, nz already carry the VSPG_TRI_FLIP_NORMAL flip)
+};
+// Shape "sphere" (shapes.h:107-330; full spheres): rows 0..2 of renderFromObject's m and mInv, the constants the Sphere
+// constructor derives (computed on the host with the same libm calls), DiffuseMaterial reflectance or interface flags
+struct DSphere {
+    float m[12], mi[12];
+    float radius, thetaZMin, thetaZMax, phiMax;
+    float Kd[3];
+    int32_t flip, has_lobes, flags;
 };
 // BVH in depth-first order (own builder, vspg_capi.hip): an inner node's first child is the next node; `skip` is where
 // the traversal continues when the node is missed or its subtree is done -- no stack, no per-lane scratch.  S.bvh holds
@@ -513,6 +525,11 @@ struct DBvhNode {
 struct DScene {
     int32_t n_quads, n_lights;
     int32_t n_tris, n_bvh_nodes;
+    // medium boundaries: has_boundaries = some surface is an interface material or a medium transition, or the camera sits
+    // outside the medium (0: the medium fills the scene -- every boundary branch below is skipped, wave-uniformly);
+    // camera_in_medium = the camera ray's medium (1 = the scene's medium)
+    int32_t n_spheres, has_boundaries, camera_in_medium, pad_b;
+    DSphere spheres[VSPG_MAX_SPHERES];
     const DTri *tris;          // in BVH leaf order
     const DBvhNode *bvh;
     // infinite lights (light order: the emissive rectangles, then these); scene_radius: Bounds3::BoundingSphere of the scene bounds
@@ -621,6 +638,12 @@ struct Isect {
 };
 VDEV bool is_tri(int prim) { return prim <= -2; }
 VDEV int tri_of(int prim) { return -2 - prim; }
+// spheres: prim = kSpherePrim + index.  A sphere hit carries its OBJECT-SPACE hit point in `p` (Isect, Vertex, PrevCtx): the
+// interaction point with its error bounds, the normal and the shading frame are pure functions of it (sphere_interaction),
+// recomputed where they are read -- three floats name the hit, as (p, rectangle) does for a rectangle.
+constexpr int kSpherePrim = 32;
+VDEV bool is_sphere(int prim) { return prim >= kSpherePrim; }
+VDEV int sphere_of(int prim) { return prim - kSpherePrim; }
 
 // ray / rectangle (own geometry stand-in, contract in DESIGN.md): plane hit t = n.(p00-o)/n.d,
 // accepted when 0 < t < tMax and the parametric (u,v) of o+t*d lie in [0,1]^2; the reported point
@@ -847,6 +870,131 @@ VDEV bool bvh_any(const DScene &S, V3 o, V3 d, float tMax) {
     return false;
 }
 
+// ---------------------------------------------------------------------------------------
+// Shape "sphere" (round 4).  Interval arithmetic (util/math.h:818-1010 with the CPU branches of the rounding helpers,
+// util/float.h:199-297: NextFloatUp / NextFloatDown of the rounded-to-nearest result), Sphere::BasicIntersect
+// (shapes.h:147-229), InteractionFromIntersection (:237-284) carried to render space by
+// Transform::operator()(SurfaceInteraction) (transform.cpp:229-261).  Same operations as oracle/vspg_oracle.c.
+// ---------------------------------------------------------------------------------------
+struct Ivl { float lo, hi; };
+VDEV Ivl ivl_x(float v) { return Ivl{v, v}; }
+VDEV Ivl ivl_mk(float a, float b) { return Ivl{fmin_(a, b), fmax_(a, b)}; }  // Interval(low, high): std::min / std::max
+VDEV float ivl_mid(Ivl a) { return (a.lo + a.hi) / 2; }
+VDEV Ivl ivl_from_err(float v, float e) { Ivl r; interval_ve(v, e, &r.lo, &r.hi); return r; }
+VDEV Ivl ivl_add(Ivl a, Ivl b) { return ivl_mk(next_float_down(a.lo + b.lo), next_float_up(a.hi + b.hi)); }
+VDEV Ivl ivl_sub(Ivl a, Ivl b) { return ivl_mk(next_float_down(a.lo + -b.hi), next_float_up(a.hi + -b.lo)); }
+VDEV Ivl ivl_mul(Ivl a, Ivl b) {
+    const float p0 = a.lo * b.lo, p1 = a.hi * b.lo, p2 = a.lo * b.hi, p3 = a.hi * b.hi;
+    const float lo = fmin_(fmin_(fmin_(next_float_down(p0), next_float_down(p1)), next_float_down(p2)), next_float_down(p3));
+    const float hi = fmax_(fmax_(fmax_(next_float_up(p0), next_float_up(p1)), next_float_up(p2)), next_float_up(p3));
+    return ivl_mk(lo, hi);
+}
+VDEV bool ivl_has(Ivl i, float v) { return v >= i.lo && v <= i.hi; }
+VDEV Ivl ivl_div(Ivl a, Ivl b) {
+    if (ivl_has(b, 0.f)) return ivl_mk(-kInf, kInf);
+    const float q0 = a.lo / b.lo, q1 = a.hi / b.lo, q2 = a.lo / b.hi, q3 = a.hi / b.hi;
+    const float lo = fmin_(fmin_(fmin_(next_float_down(q0), next_float_down(q1)), next_float_down(q2)), next_float_down(q3));
+    const float hi = fmax_(fmax_(fmax_(next_float_up(q0), next_float_up(q1)), next_float_up(q2)), next_float_up(q3));
+    return ivl_mk(lo, hi);
+}
+VDEV Ivl ivl_sqr(Ivl i) {
+    float alow = __builtin_fabsf(i.lo), ahigh = __builtin_fabsf(i.hi);
+    if (alow > ahigh) { const float t = alow; alow = ahigh; ahigh = t; }
+    if (ivl_has(i, 0.f)) return ivl_mk(0.f, next_float_up(ahigh * ahigh));
+    return ivl_mk(next_float_down(alow * alow), next_float_up(ahigh * ahigh));
+}
+VDEV Ivl ivl_fmul(float f, Ivl i) {  // operator*(Float, Interval)
+    if (f > 0) return ivl_mk(next_float_down(f * i.lo), next_float_up(f * i.hi));
+    return ivl_mk(next_float_down(f * i.hi), next_float_up(f * i.lo));
+}
+VDEV Ivl ivl_sqrt(Ivl i) { return ivl_mk(fmax_(0.f, next_float_down(__builtin_sqrtf(i.lo))), next_float_up(__builtin_sqrtf(i.hi))); }
+
+// Sphere::BasicIntersect for zMin = -radius, zMax = radius, phiMax = fl(2 pi): the clip tests of :182-203 never fire
+VDEV bool sphere_intersect(const DSphere &S, V3 ro, V3 rd, float tMax, float *tHit, V3 *pObj) {
+    constexpr float g3 = (3 * kMachineEps) / (1 - 3 * kMachineEps);
+    Ivl oi[3], di[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // (*objectFromRender)(Point3fi(r.o)), (*objectFromRender)(Vector3fi(r.d)): exact inputs
+        const float *row = S.mi + 4 * k;
+        const float v = (row[0] * ro.x + row[1] * ro.y) + (row[2] * ro.z + row[3]);
+        const float e = g3 * (__builtin_fabsf(row[0] * ro.x) + __builtin_fabsf(row[1] * ro.y) + __builtin_fabsf(row[2] * ro.z) + __builtin_fabsf(row[3]));
+        oi[k] = ivl_from_err(v, e);
+        const float ev = g3 * (__builtin_fabsf(row[0] * rd.x) + __builtin_fabsf(row[1] * rd.y) + __builtin_fabsf(row[2] * rd.z));
+        const float vv = row[0] * rd.x + row[1] * rd.y + row[2] * rd.z;
+        di[k] = ivl_from_err(vv, ev);
+    }
+    const Ivl a = ivl_add(ivl_add(ivl_sqr(di[0]), ivl_sqr(di[1])), ivl_sqr(di[2]));
+    const Ivl b = ivl_fmul(2.f, ivl_add(ivl_add(ivl_mul(di[0], oi[0]), ivl_mul(di[1], oi[1])), ivl_mul(di[2], oi[2])));
+    const Ivl c = ivl_sub(ivl_add(ivl_add(ivl_sqr(oi[0]), ivl_sqr(oi[1])), ivl_sqr(oi[2])), ivl_sqr(ivl_x(S.radius)));
+    const Ivl f = ivl_div(b, ivl_fmul(2.f, a));
+    const Ivl v0 = ivl_sub(oi[0], ivl_mul(f, di[0])), v1 = ivl_sub(oi[1], ivl_mul(f, di[1])), v2 = ivl_sub(oi[2], ivl_mul(f, di[2]));
+    const Ivl length = ivl_sqrt(ivl_add(ivl_add(ivl_sqr(v0), ivl_sqr(v1)), ivl_sqr(v2)));
+    const Ivl discrim = ivl_mul(ivl_mul(ivl_fmul(4.f, a), ivl_add(ivl_x(S.radius), length)), ivl_sub(ivl_x(S.radius), length));
+    if (discrim.lo < 0) return false;
+    const Ivl rootDiscrim = ivl_sqrt(discrim);
+    Ivl q;
+    if (ivl_mid(b) < 0) q = ivl_fmul(-.5f, ivl_sub(b, rootDiscrim));
+    else q = ivl_fmul(-.5f, ivl_add(b, rootDiscrim));
+    Ivl t0 = ivl_div(q, a), t1 = ivl_div(c, q);
+    if (t0.lo > t1.lo) { const Ivl t = t0; t0 = t1; t1 = t; }
+    if (t0.hi > tMax || t1.lo <= 0) return false;
+    Ivl tShapeHit = t0;
+    if (tShapeHit.lo <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit.hi > tMax) return false;
+    }
+    const float ts = ivl_mid(tShapeHit);
+    V3 pHit = V3{ivl_mid(oi[0]) + ts * ivl_mid(di[0]), ivl_mid(oi[1]) + ts * ivl_mid(di[1]), ivl_mid(oi[2]) + ts * ivl_mid(di[2])};
+    const float sc = S.radius / len(pHit);  // pHit *= radius / Distance(pHit, Point3f(0, 0, 0))
+    pHit = V3{pHit.x * sc, pHit.y * sc, pHit.z * sc};
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * S.radius;
+    *tHit = ts;
+    *pObj = pHit;
+    return true;
+}
+// pi (render space, with error bounds), the geometric normal and Normalize(shading.dpdu) of the hit at object-space pHit
+struct SphereSurf {
+    P3i pi;
+    V3 n, dpdu_n;
+};
+template <bool WITH_DPDU = true>
+VDEV SphereSurf sphere_interaction(const DSphere &S, V3 pHit) {
+    SphereSurf r;
+    const float cosTheta = pHit.z / S.radius;
+    const float zRadius = __builtin_sqrtf(sqr(pHit.x) + sqr(pHit.y));
+    const float cosPhi = pHit.x / zRadius, sinPhi = pHit.y / zRadius;
+    const V3 dpdu = V3{-S.phiMax * pHit.y, S.phiMax * pHit.x, 0.f};
+    const float sinTheta = safe_sqrt(1 - sqr(cosTheta));
+    const float dth = S.thetaZMax - S.thetaZMin;
+    const V3 dpdv = V3{dth * (pHit.z * cosPhi), dth * (pHit.z * sinPhi), dth * (-S.radius * sinTheta)};
+    V3 no = normalize(cross(dpdu, dpdv));
+    if (S.flip) no = -no;
+    constexpr float g5 = (5 * kMachineEps) / (1 - 5 * kMachineEps), g3 = (3 * kMachineEps) / (1 - 3 * kMachineEps);
+    const Ivl px = ivl_from_err(pHit.x, g5 * __builtin_fabsf(pHit.x)), py = ivl_from_err(pHit.y, g5 * __builtin_fabsf(pHit.y)),
+              pz = ivl_from_err(pHit.z, g5 * __builtin_fabsf(pHit.z));
+    const float x = ivl_mid(px), y = ivl_mid(py), z = ivl_mid(pz);
+    const float ex = (px.hi - px.lo) / 2, ey = (py.hi - py.lo) / 2, ez = (pz.hi - pz.lo) / 2;
+    const bool exact = (px.hi - px.lo) == 0 && (py.hi - py.lo) == 0 && (pz.hi - pz.lo) == 0;
+    float pv[3], pe[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // Transform::operator()(Point3fi) (transform.h:133-175)
+        const float *row = S.m + 4 * k;
+        pv[k] = (row[0] * x + row[1] * y) + (row[2] * z + row[3]);
+        const float ea = g3 * (__builtin_fabsf(row[0] * x) + __builtin_fabsf(row[1] * y) + __builtin_fabsf(row[2] * z) + __builtin_fabsf(row[3]));
+        pe[k] = exact ? ea : (g3 + 1) * (__builtin_fabsf(row[0]) * ex + __builtin_fabsf(row[1]) * ey + __builtin_fabsf(row[2]) * ez) + ea;
+    }
+    r.pi = p3i_from_err(V3{pv[0], pv[1], pv[2]}, V3{pe[0], pe[1], pe[2]});
+    const float *mi = S.mi;  // normals: the inverse transpose (transform.h:329-334), then Normalize
+    r.n = normalize(V3{mi[0] * no.x + mi[4] * no.y + mi[8] * no.z, mi[1] * no.x + mi[5] * no.y + mi[9] * no.z, mi[2] * no.x + mi[6] * no.y + mi[10] * no.z});
+    if (WITH_DPDU) {
+        const float *m = S.m;
+        r.dpdu_n = normalize(V3{m[0] * dpdu.x + m[1] * dpdu.y + m[2] * dpdu.z, m[4] * dpdu.x + m[5] * dpdu.y + m[6] * dpdu.z, m[8] * dpdu.x + m[9] * dpdu.y + m[10] * dpdu.z});
+    } else {
+        r.dpdu_n = mk(0, 0, 0);
+    }
+    return r;
+}
+
 // FULL = false: the scene is known to hold rectangles only (the workgroup kernel's instantiations, see HomogeneousMediumT::kSimpleScene)
 template <bool FULL = true>
 VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
@@ -885,6 +1033,21 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
             best.n = V3{T.nx, T.ny, T.nz};
         }
     }
+    if (FULL && S.n_spheres > 0) {  // wave-uniform.  Every sphere against the RAY's tMax (BasicIntersect rejects on interval bounds
+        // of t against the tMax it is given), the closest by t; a sphere hit's `p` is the object-space point (kSpherePrim)
+        for (int i = 0; i < S.n_spheres; ++i) {
+            float t;
+            V3 pObj;
+            if (sphere_intersect(S.spheres[i], o, d, tMax, &t, &pObj) && t < best.t) {
+                best.hit = true;
+                best.t = t;
+                best.quad = kSpherePrim + i;
+                best.p = pObj;
+                best.perr = mk(0, 0, 0);
+                best.n = sphere_interaction<false>(S.spheres[i], pObj).n;
+            }
+        }
+    }
     return best;
 }
 template <bool FULL = true>
@@ -895,7 +1058,40 @@ VLEAF bool scene_intersect_any(const DScene &S, V3 o, V3 d, float tMax) {
         any = any || rect_hit_uv(S.irec[i], o, d, tMax, &t, &u, &v);
     }
     if (FULL && S.n_tris > 0 && !any) any = bvh_any(S, o, d, tMax);
+    if (FULL && S.n_spheres > 0 && !any) {
+        for (int i = 0; i < S.n_spheres; ++i) {
+            float t;
+            V3 pObj;
+            any = any || sphere_intersect(S.spheres[i], o, d, tMax, &t, &pObj);
+        }
+    }
     return any;
+}
+// ---- medium boundaries -----------------------------------------------------------------------------------------------
+// SURF_* flags of the surface a hit names (rectangle: LDS copy; triangle / sphere: the scene arrays)
+VDEV int surf_flags(const DScene &S, int prim) {
+    if (is_tri(prim)) return S.tris[tri_of(prim)].flags;
+    if (is_sphere(prim)) return S.spheres[sphere_of(prim)].flags;
+    return quad_at(prim).flags;
+}
+// SurfaceInteraction::pi of a hit named by (prim, p, perr)
+VDEV P3i surf_pi(const DScene &S, int prim, V3 p, V3 perr) {
+    if (is_sphere(prim)) return sphere_interaction<false>(S.spheres[sphere_of(prim)], p).pi;
+    return p3i_from_err(p, perr);
+}
+// Dot(Vector3f, Normal3f) (vecmath.h:1064-1068): FMA(n.x, v.x, SumOfProducts(n.y, v.y, n.z, v.z)) (math.h:577-583)
+VDEV float dot_vn(V3 v, V3 n) {
+    const float cd = n.z * v.z;
+    const float sop = __builtin_fmaf(n.y, v.y, cd);
+    const float err = __builtin_fmaf(n.z, v.z, -cd);
+    return __builtin_fmaf(n.x, v.x, sop + err);
+}
+// Interaction::GetMedium(w) (interaction.h:117-121) with one medium: true = the scene's medium.  `medium`: the
+// interaction's own member (the medium of the ray that hit a non-transition surface / of a medium interaction).
+VDEV bool get_medium(int flags, V3 n, V3 w, bool medium) {
+    const int iface = flags >> SURF_IFACE_SHIFT;
+    if (iface) return dot_vn(w, n) > 0 ? (iface & VSPG_IFACE_OUTSIDE) != 0 : (iface & VSPG_IFACE_INSIDE) != 0;
+    return medium;
 }
 
 // ---------------------------------------------------------------------------------------

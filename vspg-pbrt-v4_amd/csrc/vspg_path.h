@@ -37,6 +37,15 @@ VDEV Bsdf bsdf_make_tri(const DTri &T) {  // DiffuseMaterial on a triangle: BSDF
     b.has_lobes = T.Kd[0] != 0 || T.Kd[1] != 0 || T.Kd[2] != 0;
     return b;
 }
+VDEV Bsdf bsdf_make_sphere(const DSphere &sp_, const SphereSurf &ss) {  // BSDF(ns, dpdus) of the transformed interaction (bsdf.h:25-26)
+    Bsdf b;
+    b.frame.x = ss.dpdu_n;
+    b.frame.z = ss.n;
+    b.frame.y = cross(b.frame.z, b.frame.x);
+    b.R = lds(sp_.Kd);
+    b.has_lobes = sp_.has_lobes != 0;
+    return b;
+}
 VDEV Spec bsdf_f(const Bsdf &b, V3 woR, V3 wiR) {
     V3 wi = b.frame.to_local(wiR), wo = b.frame.to_local(woR);
     if (wo.z == 0) return sp(0.f);
@@ -139,7 +148,11 @@ struct PrevCtx {
     template <bool FULL = true>
     VDEV LsCtx expand(const DScene &S) const {
         LsCtx c;
-        if (quad >= 0) {
+        if (FULL && is_sphere(quad)) {  // p = the object-space hit point (kSpherePrim)
+            const SphereSurf ss = sphere_interaction<false>(S.spheres[sphere_of(quad)], p);
+            c.pi = ss.pi;
+            c.n = ss.n;
+        } else if (quad >= 0) {
             const DQuad &q = quad_at(quad);
             c.pi = p3i_from_err(p, ld3(q.perr));
             c.n = ld3(q.n);
@@ -237,6 +250,10 @@ struct Intr {
     V3 n;
     V3 wo;
     float g;
+    // medium boundaries (read only where S.has_boundaries): Interaction::medium -- the medium of the ray that reached a
+    // non-transition surface, of the medium interaction itself -- and the surface's SURF_* flags (GetMedium, interaction.h:117-121)
+    bool medium;
+    int sflags;
 };
 // v * (T_maj / T_maj[ch]) (:1083-1084, :1236-1238, :723-724).  In a grey medium every channel of T_maj IS T_maj[ch] (built from
 // one value, HomogeneousMediumT / GridMediumT): the quotient is x / x -- exactly 1 for every finite non-zero x -- and v * 1 is v.
@@ -262,7 +279,64 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
     Rng rng;
     rng.set_sequence(hash_v3(lo), hash_v3(ld));  // :1193
     pc.shadow_ray();
-    if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
+    // ratio tracking (:1207-1232)
+    auto ratio_cb = [&](V3, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+        float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
+        if constexpr (Medium::kNullZero) {
+            // sigma_n == 0: T_ray *= T_maj * 0 / pdf is an exact 0 for a positive finite pdf (T_maj is
+            // finite), whatever the Russian roulette below draws; the callback's `!T_ray -> return false`
+            // follows.  (pdf == 0 -- a FastExp underflow over ~175 mean free paths -- keeps the generic code.)
+            if (pdf > 0 && !isinf_(pdf)) {
+                T_ray = sp(0.f);
+                return false;
+            }
+        }
+        Spec sigma_n = medium.sigma_n(mp, sigma_maj);
+        T_ray = T_ray * (T_maj * sigma_n / pdf);
+        r_l = r_l * (T_maj * sigma_maj / pdf);
+        r_u = r_u * (T_maj * sigma_n / pdf);
+        Spec Tr = T_ray / avg(r_l + r_u);
+        if (maxc(Tr) < 0.05f) {
+            float q = 0.75f;
+            if (rng.uniform() < q)
+                T_ray = sp(0.f);
+            else
+                T_ray = T_ray / (1 - q);
+        }
+        if (!nonzero(T_ray)) return false;
+        return true;
+    };
+    if (kFull && S.has_boundaries) {
+        // The loop of :1195-1244 over the segments of the light ray: Intersect(lightRay, 1 - ShadowEpsilon) finds the CLOSEST hit;
+        // one with a material blocks, an interface ends the segment and the ray goes on from it, in the medium its far side
+        // holds (si->intr.SpawnRayTo(ls->pLight), :1243).
+        bool lmed = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, intr.n, ld, intr.medium);  // r.medium = GetMedium(r.d)
+        while (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
+            const Isect si = scene_intersect<true>(S, lo, ld, 1 - kShadowEps);
+            int sfl = 0;
+            if (si.hit) {
+                sfl = surf_flags(S, si.quad);
+                if (!(sfl & SURF_INTERFACE)) return sp(0.f);
+            }
+            if (lmed) {
+                VSPG_PROF(PS_NEE_TR);
+                const float tMax = si.hit ? si.t : 1 - kShadowEps;
+                const float us = rng.uniform();
+                const Spec T_maj = sample_T_maj(medium, lo, ld, tMax, us, rng, ch, ratio_cb);
+                T_ray = mul_tmaj_ratio<Medium::kGrey>(T_ray, T_maj, ch);
+                r_l = mul_tmaj_ratio<Medium::kGrey>(r_l, T_maj, ch);
+                r_u = mul_tmaj_ratio<Medium::kGrey>(r_u, T_maj, ch);
+            }
+            if (!nonzero(T_ray)) return sp(0.f);
+            if (!si.hit) break;
+            const P3i spi = surf_pi(S, si.quad, si.p, si.perr);
+            const V3 nf = offset_ray_origin(spi, si.n, ls.pLight.mid() - spi.mid());
+            const V3 nt = offset_ray_origin(ls.pLight, ls.nLight, nf - ls.pLight.mid());
+            lo = nf;
+            ld = nt - nf;
+            lmed = get_medium(sfl, si.n, ld, lmed);
+        }
+    } else if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
         // every surface here carries a material: any hit is an opaque blocker (:1197-1200)
 #ifndef VSPG_EXP_NOANYHIT
         if (scene_intersect_any<kFull>(S, lo, ld, 1 - kShadowEps)) return sp(0.f);
@@ -271,34 +345,7 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
             VSPG_PROF(PS_NEE_TR);
             float tMax = 1 - kShadowEps;
             float us = rng.uniform();
-            Spec T_maj = sample_T_maj(medium, lo, ld, tMax, us, rng, ch,
-                                      [&](V3, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
-                                          // ratio tracking (:1207-1232)
-                                          float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
-                                          if constexpr (Medium::kNullZero) {
-                                              // sigma_n == 0: T_ray *= T_maj * 0 / pdf is an exact 0 for a positive finite pdf (T_maj is
-                                              // finite), whatever the Russian roulette below draws; the callback's `!T_ray -> return false`
-                                              // follows.  (pdf == 0 -- a FastExp underflow over ~175 mean free paths -- keeps the generic code.)
-                                              if (pdf > 0 && !isinf_(pdf)) {
-                                                  T_ray = sp(0.f);
-                                                  return false;
-                                              }
-                                          }
-                                          Spec sigma_n = medium.sigma_n(mp, sigma_maj);
-                                          T_ray = T_ray * (T_maj * sigma_n / pdf);
-                                          r_l = r_l * (T_maj * sigma_maj / pdf);
-                                          r_u = r_u * (T_maj * sigma_n / pdf);
-                                          Spec Tr = T_ray / avg(r_l + r_u);
-                                          if (maxc(Tr) < 0.05f) {
-                                              float q = 0.75f;
-                                              if (rng.uniform() < q)
-                                                  T_ray = sp(0.f);
-                                              else
-                                                  T_ray = T_ray / (1 - q);
-                                          }
-                                          if (!nonzero(T_ray)) return false;
-                                          return true;
-                                      });
+            Spec T_maj = sample_T_maj(medium, lo, ld, tMax, us, rng, ch, ratio_cb);
             T_ray = mul_tmaj_ratio<Medium::kGrey>(T_ray, T_maj, ch);
             r_l = mul_tmaj_ratio<Medium::kGrey>(r_l, T_maj, ch);
             r_u = mul_tmaj_ratio<Medium::kGrey>(r_u, T_maj, ch);
@@ -373,6 +420,7 @@ struct PathState {
     float vsp0;  // primary-ray VSP of this pixel, loaded when the path starts (hides the HBM latency)
     float pce;   // guided builds, rrguiding: the pixel's contribution estimate (0 = none); guideRR = rrguiding && buffer ready
     bool guideRR;
+    bool in_medium;  // ray.medium != nullptr.  Constant without medium boundaries (S.has_boundaries == 0); simple-scene kernels never read it
     GuideState gs;  // guided builds only: the previous vertex's distribution for the secondary-ray VSP
 };
 
@@ -664,8 +712,12 @@ struct Vertex {
 
 // the part of the path-loop iteration between distance sampling and the vertex, for a path that reached
 // the surface (:350-412): emission with MIS, ISG bookkeeping, depth test
+// Returns LI_END (the path is over), LI_VERTEX (it stands at a surface vertex) or -- full scenes with medium boundaries --
+// LI_SKIP: the hit has no BSDF (Material "interface"), SkipIntersection moved the ray past it (:399-404) and the path loop
+// goes round again without a vertex.  LI_END is 0: callers that cannot meet LI_SKIP read the result as a bool.
+enum { LI_END = 0, LI_VERTEX = 1, LI_SKIP = 2 };
 template <bool FULL = true, class PC>
-VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, const Isect &si, Spec tw) {
+VDEV int li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, const Isect &si, Spec tw) {
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     VSPG_PROF(PS_SURF_PRE);
     if constexpr (kRec) pc.rec.add_transmittance_weight(tw);  // :350
@@ -688,11 +740,11 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
                 if constexpr (kRec) pc.rec.add_infinite_light_emission(st.ro + st.rd * kGuidingInfiniteLightDistance, Le, w_b);  // :369
             }
         }
-        return false;
+        return LI_END;
     }
-    const bool tri_hit = FULL && is_tri(si.quad);
+    const bool tri_hit = FULL && (is_tri(si.quad) || is_sphere(si.quad));
     const DQuad &q = quad_at(tri_hit ? 0 : si.quad);
-    Spec Le = !tri_hit && q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377 (triangles carry no area light)
+    Spec Le = !tri_hit && q.is_light ? light_L(q, si.n, -st.rd) : sp(0.f);  // :377 (triangles and spheres carry no area light)
     float w_direct = 0.f;
     if (nonzero(Le)) {
         if (st.depth == 0 || st.specularBounce) {
@@ -709,6 +761,15 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
             w_direct = w_l;
         }
     }
+    if (FULL && S.has_boundaries) {  // :399-404: GetBSDF of an interface material returns no BSDF -- a medium boundary
+        const int sfl = surf_flags(S, si.quad);
+        if (sfl & SURF_INTERFACE) {
+            // isect.SkipIntersection(&ray, si->tHit) (interaction.cpp:91-97): ray = SpawnRay(ray.d), medium = GetMedium(ray.d)
+            st.ro = offset_ray_origin(surf_pi(S, si.quad, si.p, si.perr), si.n, st.rd);
+            st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(sfl, si.n, st.rd, st.in_medium);
+            return LI_SKIP;
+        }
+    }
     if constexpr (kRec) {
         pc.rec.new_segment(st.ro + st.rd * si.t, false);                // guiding_newSurfacePathSegment (:406)
         if (nonzero(Le)) pc.rec.add_surface_emission(Le, w_direct);      // :409-412
@@ -717,14 +778,14 @@ VDEV bool li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc,
         isg.valid = true;
         isg.surface_event = true;
     }
-    if (st.depth++ >= S.prm.maxdepth) return false;
+    if (st.depth++ >= S.prm.maxdepth) return LI_END;
     pc.surface_hit();
-    return true;
+    return LI_VERTEX;
 }
 
 template <class Medium, bool GUIDED = false, int SEG = SEG_ANY, class PC>
-VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
-                       PathState &st, int ch, Sampler &sampler, IsgSample &isg, PC &pc, Vertex &vx) {
+VDEV int li_segment_a(const DScene &S, const Medium &medium, const float *vsp_buf, int vsp_ready, int px, int py,
+                      PathState &st, int ch, Sampler &sampler, IsgSample &isg, PC &pc, Vertex &vx) {
     VSPG_PROF(PS_SEGMENT);
     pc.segment();
     Isect si;
@@ -741,7 +802,10 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
     vx.perr = si.perr;
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     Spec tw = sp(1.f);  // transmittanceWeight (:317)
-    if (S.medium_type != VSPG_MEDIUM_NONE) {  // ray.medium: one medium fills the scene (an escaping ray is sampled too, tMax = Infinity)
+    // :318 `if (ray.medium && !std::isinf(tMax))`: a ray that escapes the scene is not sampled (rounds 1-3 did: wrong).  Without
+    // medium boundaries every ray is in the scene's medium.
+    const bool in_medium = Medium::kSimpleScene || !S.has_boundaries ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
+    if (in_medium && si.hit) {
         Rng rng;
         {
             VSPG_PROF(PS_HASHRNG);
@@ -750,12 +814,12 @@ VDEV bool li_segment_a(const DScene &S, const Medium &medium, const float *vsp_b
             rng.set_sequence(hash0, hash1);
         }
         DistEvent ev = sample_distance<Medium, GUIDED, SEG>(S, medium, vsp_buf, vsp_ready, px, py, st, tMax, ch, sampler, rng, isg, pc, tw);
-        if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return false;  // :343-344
+        if (ev.kind == EV_TERMINATE || !nonzero(st.beta) || !nonzero(st.r_u)) return LI_END;  // :343-344
         if (ev.kind == EV_SCATTER) {
             vx.volume = true;
             vx.p = ev.p;
             vx.g = ev.g;
-            return true;
+            return LI_VERTEX;
         }
     }
     return li_surface_pre<!Medium::kSimpleScene>(S, st, isg, pc, si, tw);
@@ -803,19 +867,30 @@ VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, V
         intr.wo = -st.rd;
         intr.g = vg;
         bsdf.has_lobes = false;
+        intr.medium = true;  // MediumInteraction(p, wo, time, ray.medium, phase): a scatter happens inside the medium
+        intr.sflags = 0;
     } else {
-        if (FULL && is_tri(vx.quad)) {
+        intr.medium = FULL ? st.in_medium : true;
+        intr.sflags = FULL && S.has_boundaries ? surf_flags(S, vx.quad) : 0;
+        si.perr = vx.perr;
+        if (FULL && is_sphere(vx.quad)) {  // vx.p = the object-space hit point (kSpherePrim)
+            const DSphere &sph = S.spheres[sphere_of(vx.quad)];
+            const SphereSurf ss = sphere_interaction(sph, vx.p);
+            si.n = ss.n;
+            bsdf = bsdf_make_sphere(sph, ss);
+            intr.pi = ss.pi;
+        } else if (FULL && is_tri(vx.quad)) {
             const DTri &T = S.tris[tri_of(vx.quad)];
             si.n = V3{T.nx, T.ny, T.nz};
             bsdf = bsdf_make_tri(T);
+            intr.pi = p3i_from_err(si.p, vx.perr);
         } else {
             const DQuad &q = quad_at(vx.quad);
             si.n = ld3(q.n);
             bsdf = bsdf_make<GREY_KD>(q);
+            intr.pi = p3i_from_err(si.p, vx.perr);
         }
-        si.perr = vx.perr;
         intr.is_surface = true;
-        intr.pi = p3i_from_err(si.p, vx.perr);
         intr.n = si.n;
         intr.wo = normalize(-st.rd);  // Interaction ctor normalises wo (interaction.h:31-32)
         intr.g = 0;
@@ -830,6 +905,7 @@ VDEV float vertex_pre(const DScene &S, const PathState &st, Sampler &sampler, co
     }
     return survivalProb;
 }
+template <bool FULL = true>
 VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Vertex &vx, const VertexCtx &c, float survivalProb) {
     const bool volume_vertex = vx.volume;
     const V3 vp = vx.p;
@@ -899,8 +975,9 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
     st.r_l = st.r_u / pdf;  // misPdf == pdf without guiding
     st.specularBounce = false;
     st.anyNonSpecularBounces = true;
-    st.ro = offset_ray_origin(intr.pi, si.n, wi);  // SpawnRay (interaction.h:99-101)
+    st.ro = offset_ray_origin(intr.pi, si.n, wi);  // SpawnRay (interaction.h:99-101) ...
     st.rd = wi;
+    if (FULL && S.has_boundaries) st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, si.n, wi, st.in_medium);  // ... with GetMedium(wi)
 
     if (!nonzero(st.beta)) return false;
     if (st.depth > S.prm.minrrdepth) {
@@ -928,7 +1005,7 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
         Spec Ld = sample_Ld(S, medium, c.intr, &c.bsdf, ch, sampler, st.r_u, pc);
         st.L = st.L + st.beta * Ld;
     }
-    return vertex_tail(S, st, sampler, vx, c, survivalProb);
+    return vertex_tail<!Medium::kSimpleScene>(S, st, sampler, vx, c, survivalProb);
 }
 
 template <class Medium, bool GUIDED = false, class PC>
@@ -936,7 +1013,8 @@ VDEV bool li_segment(const DScene &S, const Medium &medium, const float *vsp_buf
                      PathState &st, int ch, Sampler &sampler, IsgSample &isg, PC &pc, float *glds = nullptr,
                      int gstride = 0) {
     Vertex vx;
-    if (!li_segment_a<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, vx)) return false;
+    const int a = li_segment_a<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, vx);
+    if (a != LI_VERTEX) return a != LI_END;  // LI_SKIP: a medium boundary was crossed, the loop goes round again
     return li_segment_b<Medium, GUIDED, false>(S, medium, st, ch, sampler, pc, vx, glds, gstride);
 }
 
@@ -1196,6 +1274,7 @@ VDEV bool li_vertex_guided_impl(const DScene &S, const Medium &medium, PathState
         st.anyNonSpecularBounces = true;
         st.ro = offset_ray_origin(intr.pi, si.n, wi);
         st.rd = wi;
+        if (!Medium::kSimpleScene && S.has_boundaries) st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, si.n, wi, st.in_medium);
         if (nonzero(st.beta)) {
             if (!st.guideRR && st.depth > S.prm.minrrdepth) {  // :597-600
                 Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;
@@ -1264,6 +1343,7 @@ VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, P
     st.gs.vsp_next = -1.f;
     st.pce = 0.f;
     st.guideRR = false;
+    st.in_medium = S.camera_in_medium != 0;  // CameraBase::medium (scene.cpp:153-155)
     isg.valid = false;
     isg.surface_event = false;
     isg.vsp_used = -1.f;

@@ -118,6 +118,7 @@ enum {  // bits above the LDS pool's FL_* (which end at 1 << 19)
     WFL_NOWALK = 1 << 21,    // the resampling routine returned before its traversal (tau == 0)
     WFL_GUIDE = 1 << 22,     // the segment is VSP-guided
     WFL_SHADOW_WALK = 1 << 23,   // NEE of the previous vertex: a ratio-tracking walk is out; its result is added by the next k_wf_vertex
+    WFL_INMED = 1 << 24,     // ray.medium != nullptr (only read in scenes with medium boundaries, DScene::has_boundaries)
     WFL_HIT = 1 << 25,       // the segment's ray hit a surface
     WFL_DELTA = 1 << 27,     // that NEE sampled a delta light (DistantLight)
     WFL_DEAD = 1 << 28,      // the path ended at the previous vertex; only that NEE result is still to be added
@@ -329,7 +330,7 @@ VDEV void wf_store_path(const WfPool &P, unsigned slot, const PathState &st, con
     P.i(WF_PCQ, slot) = st.prevCtx.quad;
     if (is_tri(st.prevCtx.quad)) P.set3(WF_PCE, slot, st.prevCtx.perr);
     P.store_rng(WF_RNG, slot, sampler.rng);
-    P.u(WF_FLAGS, slot) = pool_pack_flags(st, ch, isg, extra_flags);
+    P.u(WF_FLAGS, slot) = pool_pack_flags(st, ch, isg, extra_flags | (st.in_medium ? (uint32_t)WFL_INMED : 0u));
     P.f(WF_RRC, slot) = st.rr_correction;
     P.f(WF_VSP, slot) = isg.vsp_used;  // (the pixel's primary VSP itself is consumed by the first segment's begin)
 }
@@ -365,6 +366,7 @@ VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sample
     st.gs.vsp_next = -1.f;
     st.pce = 0.f;
     st.guideRR = false;
+    st.in_medium = (fl & WFL_INMED) != 0;
     return fl;
 }
 
@@ -405,7 +407,10 @@ VDEV void wf_finish_path(const WfArgs &a, unsigned slot, const PathState &st, co
 
 // ---- a15 cut at the shadow walk: SampleLd up to the transmittance estimate (:1136-1204) ... ------------------------
 struct ShadowSetup {
-    int status;  // 0: no contribution; 1: ratio-tracking walk needed; 2: contributes with T_ray = 1 (no medium on the way)
+    int status;  // 0: no contribution; 1: ratio-tracking walk needed; 2: contributes with T_ray = 1 (no medium on the way);
+                 // 3 (medium boundaries): the light ray crosses the medium more than once -- estimated in the lane, Ld below
+    float tMax;  // status 1: where the walk's segment ends, in units of ld (1 - ShadowEpsilon, or the interface the ray leaves the medium through)
+    Spec Ld;
     Spec f_hat, L;
     float p_l, scatterPDF;
     V3 lo, ld;
@@ -413,11 +418,13 @@ struct ShadowSetup {
     float us;
     bool delta_light;
 };
-template <class PC, class GD = GDist>
-VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *bsdf, Sampler &sampler, PC &pc, const GD *gd = nullptr,
-                                 bool use_gd = false) {
+template <class Medium, class PC, class GD = GDist>
+VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Medium &medium, int ch, Spec r_p, const Intr &intr, const Bsdf *bsdf, Sampler &sampler, PC &pc,
+                                 const GD *gd = nullptr, bool use_gd = false) {
     ShadowSetup r;
     r.status = 0;
+    r.tMax = 1 - kShadowEps;
+    r.Ld = sp(0.f);
     r.f_hat = r.L = sp(0.f);
     r.p_l = r.scatterPDF = r.us = 0.f;
     r.lo = r.ld = mk(0, 0, 0);
@@ -464,6 +471,59 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Intr &intr, const Bsdf *
     r.lo = pf;
     r.ld = pt - pf;
     r.rng.set_sequence(hash_v3(r.lo), hash_v3(r.ld));  // :1193
+    if (S.has_boundaries) {
+        // Medium boundaries: the light ray is a chain of segments (:1195-1244), each ending at the closest hit -- a surface with a
+        // material blocks, an interface hands the ray on in the medium of its far side.  Which segments there are is geometry
+        // (no random number decides it), so the chain is walked HERE; what is left for the walk kernel is the ratio tracking
+        // inside the medium.  A bounding shape is usually convex: at most ONE segment lies in the medium, and it becomes the
+        // shadow-walk job, with its own origin, direction and end.  (The private RNG draws `u` at the start of a medium segment
+        // and nowhere else outside the tracking: the job's first uniform is the same number.)  A ray that crosses the medium more
+        // than once is estimated in the lane (sample_Ld_shadow, the per-lane kernels' code).
+        V3 lo = r.lo, ld = r.ld;
+        bool lmed = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, intr.n, ld, intr.medium);
+        int n_med = 0;
+        V3 jlo = lo, jld = ld;
+        float jt = 1 - kShadowEps;
+        bool blocked = false;
+        while (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
+            const Isect si = scene_intersect(S, lo, ld, 1 - kShadowEps);
+            int sfl = 0;
+            if (si.hit) {
+                sfl = surf_flags(S, si.quad);
+                if (!(sfl & SURF_INTERFACE)) { blocked = true; break; }
+            }
+            if (lmed) {
+                if (n_med == 0) { jlo = lo; jld = ld; jt = si.hit ? si.t : 1 - kShadowEps; }
+                n_med++;
+            }
+            if (!si.hit) break;
+            const P3i spi = surf_pi(S, si.quad, si.p, si.perr);
+            const V3 nf = offset_ray_origin(spi, si.n, ls.pLight.mid() - spi.mid());
+            const V3 nt = offset_ray_origin(ls.pLight, ls.nLight, nf - ls.pLight.mid());
+            lo = nf;
+            ld = nt - nf;
+            lmed = get_medium(sfl, si.n, ld, lmed);
+        }
+        if (blocked) {
+            pc.shadow_ray();
+            return r;  // status 0.  (The reference may have returned 0 earlier, at a medium segment whose estimate died: 0 either way.)
+        }
+        if (n_med >= 2) {
+            r.Ld = sample_Ld_shadow<Medium>(S, medium, intr, ch, ls, r.f_hat, r.p_l, r.scatterPDF, r_p, pc, r.delta_light);  // (counts the shadow ray)
+            r.status = 3;
+            return r;
+        }
+        pc.shadow_ray();
+        r.status = 2;
+        if (n_med == 1) {
+            r.lo = jlo;
+            r.ld = jld;
+            r.tMax = jt;
+            r.us = r.rng.uniform();
+            r.status = 1;
+        }
+        return r;
+    }
     pc.shadow_ray();
     r.status = 2;
     if (!(r.ld.x == 0 && r.ld.y == 0 && r.ld.z == 0)) {
@@ -640,7 +700,9 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
     P.i(WF_VXG, slot) = si.quad;
     P.f(WF_VXT, slot) = si.t;
     if (is_tri(si.quad)) P.set3(WF_VXE, slot, si.perr);
-    if (S.medium_type != VSPG_MEDIUM_NONE) {
+    // :318 `if (ray.medium && !std::isinf(tMax))`: no distance sampling for a ray outside the medium or one that escapes the scene
+    const bool in_medium = !S.has_boundaries ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
+    if (in_medium && si.hit) {
         Rng rng;
         {
             uint64_t hash0 = hash_float(sampler.get1d());
@@ -648,6 +710,11 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
             rng.set_sequence(hash0, hash1);
         }
         bool guide = false;
+        if (S.has_boundaries && st.depth == 0) {  // the camera segment may reach the medium through a boundary, an iteration or more after
+            int px, py;                           // the path started: the pixel's primary VSP is read where it is used
+            wf_pixel_of(slot, a.tilesX, &px, &py);
+            st.vsp0 = (a.vsp_ready & VSP_READY) ? a.vsp_buf[(size_t)py * S.xres + px] : 0.5f;
+        }
         const float vsp = fetch_vsp<GUIDED>(S, st, &guide);
         if (st.depth == 0) isg.vsp_used = guide ? vsp : -1.f;
         const float u = sampler.get1d();
@@ -1016,19 +1083,19 @@ VDEV int wf_vertex(const WfArgs &a, const DScene &S, const Medium &medium, unsig
             S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, nullptr, 0, [&](const auto &gd, bool use_gd) {
                 nee = true;
                 beta_nee = st.beta;
-                ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc, &gd, use_gd);
+                ss = sample_Ld_begin(S, medium, ch, st.r_u, c.intr, &c.bsdf, sampler, pc, &gd, use_gd);
                 return sp(0.f);
             });
     } else {
         survivalProb = vertex_pre(S, st, sampler, vx);
         if (S.prm.usenee && (vx.volume || c.bsdf.has_lobes)) {  // :479 / :833
             nee = true;
-            ss = sample_Ld_begin(S, c.intr, &c.bsdf, sampler, pc);
+            ss = sample_Ld_begin(S, medium, ch, st.r_u, c.intr, &c.bsdf, sampler, pc);
         }
     }
     if (nee) {
         if (ss.status == 1) {
-            const float tM = (1 - kShadowEps) * len(ss.ld);
+            const float tM = ss.tMax * len(ss.ld);
             const V3 rdn = normalize(ss.ld);
             const auto iter = medium.sample_ray(ss.lo, rdn, tM);
             if (iter.tMin >= iter.tMax) {
@@ -1052,6 +1119,8 @@ VDEV int wf_vertex(const WfArgs &a, const DScene &S, const Medium &medium, unsig
             Spec Ld = sp(0.f);
             if (ss.status == 2)
                 Ld = sample_Ld_end<G>(false, ss.delta_light, sp(1.f), sp(1.f), sp(1.f), sp(1.f), ch, ss.f_hat, ss.L, ss.p_l, ss.scatterPDF, st.r_u);
+            else if (ss.status == 3)
+                Ld = ss.Ld;
             st.L = st.L + beta_nee * Ld;
             if constexpr (TRAIN) pc.rec.add_scattered_direct_light(Ld);
         }
@@ -1129,6 +1198,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
             }
             Vertex vx;
             int kind = EV_PASS;
+            bool skipped = false;  // the segment ended on an interface (no BSDF): no vertex, the next segment begins behind it
             if (fl & WFL_DEAD) {
                 // the path ended at the previous vertex; that addition was all it waited for
             } else {
@@ -1143,6 +1213,9 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                     const DTri &T = S.tris[tri_of(si.quad)];
                     si.n = V3{T.nx, T.ny, T.nz};
                     si.perr = P.v3(WF_VXE, slot);
+                } else if (is_sphere(si.quad)) {  // si.p = the object-space hit point (kSpherePrim)
+                    si.n = sphere_interaction<false>(S.spheres[sphere_of(si.quad)], si.p).n;
+                    si.perr = mk(0, 0, 0);
                 } else {
                     const DQuad &q = quad_at(si.quad);
                     si.n = ld3(q.n);
@@ -1231,13 +1304,23 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                 } else if (kind == EV_SCATTER) {
                     alive = true;
                 } else {
-                    alive = li_surface_pre(S, st, isg, pc, si, sp(1.f));
+                    const int pre = li_surface_pre(S, st, isg, pc, si, sp(1.f));
+                    alive = pre != LI_END;
+                    skipped = pre == LI_SKIP;
                 }
             }
             if (!alive) {
                 wf_finish_path(a, slot, st, isg);
                 pc.path();
                 wf_rec_finish(a, slot, pc.rec);
+            } else if (skipped) {  // :399-404: SkipIntersection moved the ray past the boundary; the path loop goes round again
+                wf_rec_store(a, slot, pc.rec);
+                if constexpr (GUIDED) {  // (gs.vsp_next: the previous vertex's estimate stays the next segment's -- no vertex in between)
+                    wf_store_path<G>(P, slot, st, sampler, ch, isg, FL_LIVE);
+                } else {
+                    wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
+                }
+                next = true;
             } else {
                 // ---- li_segment_b: the vertex (wf_vertex), then the next segment's begin ---------------------------------------
                 uint32_t extra = 0u;
@@ -1330,6 +1413,7 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
                 const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
                 if constexpr (TRAIN) wf_rec_load(a, slot, pc.rec);
                 if constexpr (GUIDED) st.gs.vsp_next = P.f(WF_GSVSP, slot);
+                if (S.has_boundaries && st.depth == 0) st.vsp0 = (a.vsp_ready & VSP_READY) ? a.vsp_buf[(size_t)py * S.xres + px] : 0.5f;  // (see wf_segment_begin)
                 if (fl & WFL_SHADOW_WALK) {  // the previous vertex's NEE (:483 / :836 from the estimate on)
                     const WfShadowResult sr = wf_load_shadow_result(P, slot, a.compact_results != 0);
                     const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, sr.T_ray, sr.r_l, sr.r_u,
@@ -1348,11 +1432,16 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
             }
             if (run) {
                 Vertex vx;
-                const bool alive = li_segment_a<Medium, GUIDED, SEG_ANY>(S, medium, a.vsp_buf, a.vsp_ready, px, py, st, ch, sampler, isg, pc, vx);
-                if (!alive) {
+                const int alive = li_segment_a<Medium, GUIDED, SEG_ANY>(S, medium, a.vsp_buf, a.vsp_ready, px, py, st, ch, sampler, isg, pc, vx);
+                if (alive == LI_END) {
                     wf_finish_path(a, slot, st, isg);
                     pc.path();
                     wf_rec_finish(a, slot, pc.rec);
+                } else if (alive == LI_SKIP) {  // a medium boundary was crossed (:399-404): the loop goes round again, no vertex
+                    wf_rec_store(a, slot, pc.rec);
+                    if constexpr (GUIDED) P.f(WF_GSVSP, slot) = st.gs.vsp_next;
+                    wf_store_path<G>(P, slot, st, sampler, ch, isg, FL_LIVE);
+                    next = true;
                 } else {
                     uint32_t extra = 0u;
                     const int fate = wf_vertex<Medium, GUIDED, TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, vx, &extra, &shadow);

@@ -105,8 +105,10 @@ struct GraphicsState {
     float Le[3] = {0, 0, 0};
     bool twoSided = false;
     bool reverseOrientation = false;
+    bool interfaceMaterial = false;   // Material "interface" (also "none", ""): no BSDF, the surface only separates media (scene.cpp:1340)
     std::string insideMedium, outsideMedium;
 };
+struct MediumNames { std::string inside, outside; };   // a shape's MediumInterface, resolved once the scene's medium is known
 struct NamedMedium {
     std::string type;
     ParameterDictionary params;
@@ -138,6 +140,8 @@ class Parser {
     float eye[3] = {0, 0, 0}, look[3] = {0, 0, -1}, up[3] = {0, 1, 0}, fov = 90.f;
     std::string cameraMedium;
     std::vector<VspgQuad> quads;
+    std::vector<VspgSphere> spheres;
+    std::vector<MediumNames> quadMedia, sphereMedia, triMedia;   // per rectangle / sphere / triangle
 
     [[noreturn]] void fail(const std::string &msg) const {
         const int line = pos < tok.size() ? tok[pos].line : (tok.empty() ? 0 : tok.back().line);
@@ -314,7 +318,14 @@ class Parser {
         }
     }
     void set_material(const std::string &type, ParameterDictionary &p) {
-        if (type != "diffuse") fail("Material \"" + type + "\": only \"diffuse\" is inside this build's scope");
+        if (type == "interface" || type == "none" || type.empty()) {  // a null Material (scene.cpp:1340, materials.cpp:736): medium boundaries
+            (void)p.GetOneString("type", "");
+            p.ReportUnused();
+            gs.interfaceMaterial = true;
+            return;
+        }
+        if (type != "diffuse") fail("Material \"" + type + "\": only \"diffuse\" and \"interface\" are inside this build's scope");
+        gs.interfaceMaterial = false;
         float kd[3] = {0.5f, 0.5f, 0.5f};
         if (!p.GetOneRGB("reflectance", kd) && p.Has("reflectance")) { const float f = p.GetOneFloat("reflectance", 0.5f); kd[0] = kd[1] = kd[2] = f; }
         (void)p.GetOneString("type", "");
@@ -356,6 +367,10 @@ class Parser {
         for (int i = 0; i < 3; ++i)
             for (int k = 0; k < 3; ++k) sd->triP.push_back(v[i][k]);
         for (int k = 0; k < 3; ++k) sd->triKd.push_back(gs.Kd[k]);
+        // the geometric normal Normalize(Cross(p0 - p2, p1 - p2)) flips with reverseOrientation ^ transformSwapsHandedness
+        // (shapes.h:934-936) -- the vertices above are already in render space, as the reference's TriangleMesh keeps them
+        sd->triFlags.push_back((gs.interfaceMaterial ? VSPG_TRI_INTERFACE : 0) | (gs.reverseOrientation != swaps_handedness(gs.ctm) ? VSPG_TRI_FLIP_NORMAL : 0));
+        triMedia.push_back(MediumNames{gs.insideMedium, gs.outsideMedium});
     }
     static bool swaps_handedness(const M4 &m) {  // Transform::SwapsHandedness (util/transform.cpp): det of the upper 3x3 < 0
         const float det = m.m[0][0] * (m.m[1][1] * m.m[2][2] - m.m[1][2] * m.m[2][1]) - m.m[0][1] * (m.m[1][0] * m.m[2][2] - m.m[1][2] * m.m[2][0]) +
@@ -364,16 +379,29 @@ class Parser {
     }
     void shape(const std::string &type, ParameterDictionary &p) {
         if (!world) fail("Shape before WorldBegin");
-        // One medium fills the scene in this build (the camera's).  Every surface here is opaque, so a shape's two media never
-        // meet along a ray: a shape is consistent with that as long as ONE of its sides is the camera's medium (the floor under
-        // a cloud: MediumInterface "" "cloud").  A shape that bounds two OTHER media would render wrongly without a word -- refuse
-        // it (interaction.h:117-121 picks the medium per side in the reference); a one-sided match is accepted with a warning.
-        if (gs.insideMedium != cameraMedium && gs.outsideMedium != cameraMedium)
-            fail("Shape with MediumInterface \"" + gs.insideMedium + "\" \"" + gs.outsideMedium + "\": this build renders ONE medium filling the scene, the camera's (\"" +
-                 cameraMedium + "\"); media bounded by shapes are outside its scope");
-        if (gs.insideMedium != gs.outsideMedium) {
-            const std::string w = "MediumInterface \"" + gs.insideMedium + "\" \"" + gs.outsideMedium + "\" on a shape: the camera's medium (\"" + cameraMedium + "\") is used on both sides";
-            if (std::find(sd->warnings.begin(), sd->warnings.end(), w) == sd->warnings.end()) sd->warnings.push_back(w);
+        // MediumInterface (round 4): the shape keeps its inside / outside medium NAMES; finish() turns them into "the scene's medium"
+        // or "no medium" once it is known which medium the scene holds (this build holds one: a second one is refused there).
+        if (gs.interfaceMaterial && gs.areaLight) fail("an area light on a shape with the \"interface\" material is outside this build's scope");
+        if (type == "sphere") {
+            const float radius = p.GetOneFloat("radius", 1.f);
+            const float zmin = p.GetOneFloat("zmin", -radius), zmax = p.GetOneFloat("zmax", radius), phimax = p.GetOneFloat("phimax", 360.f);
+            p.ReportUnused();
+            if (!(radius > 0)) fail("sphere: radius must be positive");
+            if (zmin > -radius || zmax < radius || phimax < 360.f) fail("partial spheres (zmin / zmax / phimax) are outside this build's scope");
+            if (gs.areaLight) fail("emissive spheres are outside this build's scope (emission lives on rectangles)");
+            if (spheres.size() >= VSPG_MAX_SPHERES) fail("more than " + std::to_string(VSPG_MAX_SPHERES) + " spheres");
+            VspgSphere sp;
+            std::memset(&sp, 0, sizeof sp);
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) sp.render_from_object[4 * i + j] = gs.ctm.m[i][j];
+            if (vspg_transform_inverse(sp.render_from_object, sp.object_from_render) != 0) fail(std::string("sphere: ") + vspg_last_error());
+            sp.radius = radius;
+            for (int k = 0; k < 3; ++k) sp.Kd[k] = gs.Kd[k];
+            sp.reverse_orientation = gs.reverseOrientation;   // (the handedness of the CTM is the library's to find: Sphere's constructor, shapes.h:122)
+            sp.material = gs.interfaceMaterial ? VSPG_MATERIAL_INTERFACE : VSPG_MATERIAL_DIFFUSE;
+            spheres.push_back(sp);
+            sphereMedia.push_back(MediumNames{gs.insideMedium, gs.outsideMedium});
+            return;
         }
         std::vector<float> P = p.GetPoint3Array("P");
         if (p.Has("N") || p.Has("uv") || p.Has("S")) fail("shading normals / tangents / (u,v) on meshes are outside this build's scope");
@@ -405,14 +433,16 @@ class Parser {
                 // BilinearPatch flips n when reverseOrientation ^ transformSwapsHandedness (shapes.h:1163-1164, shapes.cpp:1267-1270):
                 // a mirroring CTM turns the patch's parametrisation over
                 q.reverse_orientation = gs.reverseOrientation != swaps_handedness(gs.ctm);
+                q.material = gs.interfaceMaterial ? VSPG_MATERIAL_INTERFACE : VSPG_MATERIAL_DIFFUSE;
                 quads.push_back(q);
+                quadMedia.push_back(MediumNames{gs.insideMedium, gs.outsideMedium});
             } else {
                 add_triangle(p00, p10, p11);
                 add_triangle(p00, p11, p01);
             }
         } else if (type == "trianglemesh") {
-            // (a triangle's orientation -- reverseOrientation ^ transformSwapsHandedness, shapes.h:925-927 -- has no effect here:
-            // triangles carry a diffuse BSDF and no emission, and both are symmetric in the sign of n)
+            // (a triangle's orientation -- reverseOrientation ^ transformSwapsHandedness, shapes.h:934-936 -- travels as a flag: only a
+            // medium transition can tell the two sides of a diffuse triangle apart)
             std::vector<int> idx = p.GetIntArray("indices");
             p.ReportUnused();
             if (P.size() % 3) fail("trianglemesh: \"P\" must hold whole points (a multiple of three floats)");
@@ -424,7 +454,7 @@ class Parser {
                 add_triangle(&W[3 * idx[i]], &W[3 * idx[i + 1]], &W[3 * idx[i + 2]]);
             }
         } else {
-            fail("Shape \"" + type + "\": only \"bilinearmesh\" and \"trianglemesh\" are inside this build's scope");
+            fail("Shape \"" + type + "\": only \"bilinearmesh\", \"trianglemesh\" and \"sphere\" are inside this build's scope");
         }
     }
     void finish() {
@@ -435,10 +465,31 @@ class Parser {
         for (int i = 0; i < s.n_quads; ++i) s.quads[i] = quads[i];
         if (!haveLookAt) { eye[0] = eye[1] = eye[2] = 0; look[0] = 0; look[1] = 0; look[2] = 1; up[0] = 0; up[1] = 1; up[2] = 0; }
         if (vspg_camera_look_at(&s.camera, eye, look, up, fov, sd->xres, sd->yres) != 0) throw Error(std::string("Camera: ") + vspg_last_error());
+        s.n_spheres = (int)spheres.size();
+        for (int i = 0; i < s.n_spheres; ++i) s.spheres[i] = spheres[i];
+        // The scene's medium: the library holds ONE (include/vspg.h).  Every name a camera or a shape refers to must be that one
+        // (or "", no medium); a second medium is refused by name.
+        std::string theMedium = cameraMedium;
+        auto see = [&](const std::string &name) {
+            if (name.empty()) return;
+            if (theMedium.empty()) theMedium = name;
+            else if (name != theMedium)
+                throw Error("scene file: media \"" + theMedium + "\" and \"" + name + "\" are both in use -- this build renders ONE medium per scene (with or without boundaries)");
+        };
+        for (const auto *v : {&quadMedia, &sphereMedia, &triMedia})
+            for (const MediumNames &m : *v) { see(m.inside); see(m.outside); }
+        auto bits = [&](const MediumNames &m) {
+            return (!theMedium.empty() && m.inside == theMedium ? VSPG_IFACE_INSIDE : 0) | (!theMedium.empty() && m.outside == theMedium ? VSPG_IFACE_OUTSIDE : 0);
+        };
+        for (int i = 0; i < s.n_quads; ++i) s.quads[i].medium_interface = bits(quadMedia[i]);
+        for (int i = 0; i < s.n_spheres; ++i) s.spheres[i].medium_interface = bits(sphereMedia[i]);
+        for (size_t i = 0; i < triMedia.size(); ++i) sd->triFlags[i] |= bits(triMedia[i]) << VSPG_TRI_IFACE_SHIFT;
+        s.camera_outside_medium = !theMedium.empty() && cameraMedium != theMedium;   // CameraBase::medium = the outside medium at the Camera directive
         s.medium.type = VSPG_MEDIUM_NONE;
-        if (!cameraMedium.empty()) {
+        if (!theMedium.empty()) {
+            const std::string cameraMedium = theMedium;   // (the block below creates the scene's medium, whoever named it)
             auto it = media.find(cameraMedium);
-            if (it == media.end()) throw Error("medium \"" + cameraMedium + "\" (the camera's) is not defined");
+            if (it == media.end()) throw Error("medium \"" + cameraMedium + "\" is not defined");
             ParameterDictionary p = it->second.params;
             (void)p.GetOneString("type", "");
             if (it->second.type == "nanovdb") {  // ResolveFilename (media.cpp:686): relative to the scene file's directory
@@ -461,6 +512,7 @@ class Parser {
             s.n_triangles = (int)(sd->triP.size() / 9);
             s.tri_p = sd->triP.data();
             s.tri_kd = sd->triKd.data();
+            s.tri_flags = sd->triFlags.data();
         }
     }
 };

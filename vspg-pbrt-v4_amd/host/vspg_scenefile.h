@@ -9,16 +9,18 @@
 //
 // Directives: LookAt, Camera "perspective" (fov), Sampler (pixelsamples, seed), PixelFilter "box", Film "rgb"
 // (xresolution, yresolution, filename), Integrator, Option (ignored), ColorSpace (ignored), WorldBegin, AttributeBegin/End,
-// Identity, Translate, Scale, Rotate, Transform, ConcatTransform, ReverseOrientation, Material "diffuse" (reflectance),
-// MakeNamedMaterial / NamedMaterial ("diffuse"), AreaLightSource "diffuse" (L, scale, twosided), LightSource "infinite"
+// Identity, Translate, Scale, Rotate, Transform, ConcatTransform, ReverseOrientation, Material "diffuse" (reflectance) / "interface",
+// MakeNamedMaterial / NamedMaterial ("diffuse", "interface"), AreaLightSource "diffuse" (L, scale, twosided), LightSource "infinite"
 // (L, scale; no image) / "distant" (L, scale, from, to), MakeNamedMedium ("homogeneous", "uniformgrid"), MediumInterface,
 // Include (as a directive, and -- beyond pbrt -- inside a parameter list, for the block the reference's nanovdb2pbrt prints),
 // Shape "bilinearmesh" (one patch: a parallelogram becomes a rectangle, anything else two triangles) / "trianglemesh"
-// (P, indices).  Anything else is an Error naming the directive: nothing is silently dropped.
+// (P, indices) / "sphere" (radius; full spheres).  Anything else is an Error naming the directive: nothing is silently dropped.
 //
-// Conventions of this build: render space == world space (pbrt's --render-coord-sys world); ONE medium fills
-// the scene -- the camera's (the "outside" medium of the MediumInterface in effect at the Camera directive); emission on
-// rectangles only; the film is written as PFM (OpenEXR is an absent submodule).
+// Conventions of this build: render space == world space (pbrt's --render-coord-sys world); ONE medium per scene,
+// with the reference's boundaries (round 4): every shape carries its MediumInterface and its material -- an "interface" material
+// makes it a pure medium boundary (guidedvolpathvspgintegrator.cpp:399-404) -- and the camera starts in the "outside" medium of the
+// MediumInterface in effect at the Camera directive (scene.cpp:153-155); a second medium in the same scene is refused by name;
+// emission on rectangles only; the film is written as PFM (OpenEXR is an absent submodule).
 #pragma once
 #include <memory>
 #include <string>
@@ -31,6 +33,7 @@ namespace vspg {
 struct SceneDescription {
     VspgScene scene;                     // pointers inside refer to the vectors below: keep the description alive while creating
     std::vector<float> density, leScale, triP, triKd;
+    std::vector<int32_t> triFlags;       // VSPG_TRI_* per triangle (material, MediumInterface, orientation)
     std::string integratorName = "volpath";
     ParameterDictionary integratorParams;
     int xres = 1280, yres = 720;         // Film defaults (film.cpp)
