@@ -258,11 +258,14 @@ def parse_args():
     ap.add_argument("--yres", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline and relmse legs")
     ap.add_argument("--no-generic", action="store_true", help="skip the generic-instantiation leg")
-    ap.add_argument("--workload", choices=["fog", "fog-guided", "cloud", "cloud-nvdb", "cloud-guided", "cloud-nvdb-guided"], default="fog",
+    ap.add_argument("--workload", choices=["fog", "fog-guided", "cloud", "cloud-nvdb", "cloud-guided", "cloud-nvdb-guided", "cloud-scene", "cloud-scene-nvdb",
+                                           "cloud-scene-guided", "cloud-scene-nvdb-guided"], default="fog",
                     help="fog = BASELINE.json's metric workload (default); fog-guided = the same scene with the reference's DEFAULT "
                          "integrator options (directional guiding + secondary-ray VSP: cache query in the loop; the field trains "
                          "in-loop during untimed waves, reported separately); cloud = procedural heterogeneous GridMedium "
-                         "(configs 3-4 stand-in); cloud-nvdb = the same grid with NanoVDBMedium semantics (64^3 majorants)")
+                         "(configs 3-4 stand-in); cloud-nvdb = the same grid with NanoVDBMedium semantics (64^3 majorants); "
+                         "cloud-scene* = the same cloud in the SHAPE of the reference's cloud scenes: camera in vacuum, the medium behind an "
+                         "interface-material bounding sphere (MediumInterface + Material \"interface\"), ground, sun + sky")
     ap.add_argument("--diag-maxdepth", type=int, default=None,
                     help="DIAGNOSTIC ONLY (not the benchmark config): override maxdepth to time parts of the path")
     ap.add_argument("--train-waves", type=int, default=16, help="fog-guided: in-loop training waves before the timed region")
@@ -324,7 +327,9 @@ def main():
     W, H = args.xres, args.yres
     fog = args.workload in ("fog", "fog-guided")
     guided = args.workload.endswith("-guided")
-    scene = (pkg.fog_box_scene(W, H) if fog else pkg.cloud_box_scene(W, H, args.grid, shape=args.cloud_shape) if args.workload in ("cloud", "cloud-guided")
+    bounded = args.workload.startswith("cloud-scene")
+    scene = (pkg.fog_box_scene(W, H) if fog else pkg.cloud_scene(W, H, args.grid, shape=args.cloud_shape, nvdb="nvdb" in args.workload) if bounded
+             else pkg.cloud_box_scene(W, H, args.grid, shape=args.cloud_shape) if args.workload in ("cloud", "cloud-guided")
              else pkg.nanovdb_box_scene(W, H, args.grid, shape=args.cloud_shape))
     prm = pkg.app_f_params()
     if args.diag_maxdepth is not None:
@@ -453,8 +458,9 @@ def main():
                   "primary + secondary VSP), field trained in-loop for %d waves before the timed region" % (W, H, args.train_waves))
         else:
             metric = "Mpaths/sec on a procedural %d^3 cloud grid (not BASELINE.json's metric workload)" % args.grid
-            wl = "cloud-box %dx%d, %s %d^3 value noise%s, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
-                W, H, "GridMedium" if args.workload in ("cloud", "cloud-guided") else "NanoVDBMedium (brick layout, 64^3 majorants)", args.grid,
+            wl = "%s %dx%d, %s %d^3 value noise%s, sigma_t 8, albedo 0.99, g 0.877, resampling" % (
+                "cloud scene (camera in vacuum, medium behind an interface-material sphere, ground, sun + sky)" if bounded else "cloud-box",
+                W, H, "GridMedium" if "nvdb" not in args.workload else "NanoVDBMedium (brick layout, 64^3 majorants)", args.grid,
                 " inside a ball (80 % empty voxels)" if args.cloud_shape == "blob" else "")
             if guided:  # config 5's shape: secondary-ray VSP + cache train + query on a heterogeneous medium
                 wl += ("; the reference's default options (surface RIS + volume MIS guiding, primary + secondary VSP), field trained "

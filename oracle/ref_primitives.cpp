@@ -16,6 +16,7 @@
 // media_sampleTMaj.h, the integrator; SampledGrid's constructors CHECK through util/print.cpp, which needs
 // double-conversion -- see DESIGN.md.
 #include <pbrt/pbrt.h>
+#include <pbrt/interaction.h>
 #include <pbrt/ray.h>
 #include <pbrt/samplers.h>
 #include <pbrt/util/hash.h>
@@ -366,6 +367,133 @@ int main() {
             pf(v.x); printf(","); pf(v.y); printf(","); pf(v.z); printf(",");
             pf(f.y.x); printf(","); pf(f.y.y); printf(","); pf(f.y.z); printf(",");
             pf(l.x); printf(","); pf(l.y); printf(","); pf(l.z); printf(","); pf(w.x); printf(","); pf(w.y); printf(","); pf(w.z); printf("]");
+        }
+        printf("],\n");
+    }
+    // ---- round 4: Interval arithmetic (util/math.h:818-1010 over util/float.h:199-297), the arithmetic under Sphere::BasicIntersect ----
+    {
+        printf("\"interval_ops\": [");
+        bool first = true;
+        for (int i = 0; i < 96; ++i) {
+            auto iv = [&]() {
+                Float c = (i % 3 == 0 ? 4.f : 1.f) * (2 * U() - 1), w = (i % 5 == 0) ? 0.f : (i % 2 ? 1e-6f : 0.3f) * U();
+                return Interval(c - w, c + w);
+            };
+            Interval a = iv(), b = iv();
+            Float f = (i % 4 == 0) ? -.5f : ((i % 4 == 1) ? 2.f : 3 * (2 * U() - 1));
+            Interval r[7] = {a + b, a - b, a * b, a / b, Sqr(a), Sqrt(Abs(a)), f * a};
+            sep(first); printf("[");
+            pf(a.LowerBound()); printf(","); pf(a.UpperBound()); printf(","); pf(b.LowerBound()); printf(","); pf(b.UpperBound()); printf(","); pf(f);
+            for (int k = 0; k < 7; ++k) { printf(","); pf(r[k].LowerBound()); printf(","); pf(r[k].UpperBound()); }
+            printf("]");
+        }
+        printf("],\n");
+    }
+    // ---- Shape "sphere".  shapes.h itself does not link here (util/mesh.h's STAT counters -> util/stats.cpp -> print.cpp ->
+    //      the absent double-conversion), so the two member functions' statement sequences (Sphere::BasicIntersect shapes.h:147-229,
+    //      InteractionFromIntersection :237-284; full sphere) are evaluated HERE on the reference's own types -- Interval, Point3fi,
+    //      Vector3fi, Transform, SurfaceInteraction and Transform::operator()(SurfaceInteraction) as compiled from
+    //      util/transform.cpp: every arithmetic operation is the reference's; what is pinned is the oracle's C restatement of it. ----
+    {
+        printf("\"sphere\": [");
+        bool first = true;
+        for (int i = 0; i < 160; ++i) {
+            Transform T;
+            switch (i % 5) {
+            case 0: T = Transform(); break;
+            case 1: T = Translate(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1)); break;
+            case 2: T = Translate(Vector3f(U(), U(), U())) * Scale(0.5f + U(), 0.5f + U(), 0.5f + U()); break;
+            case 3: T = Translate(Vector3f(U(), -U(), U())) * Rotate(360 * U(), Normalize(Vector3f(U(), U(), U() + 0.1f))) * Scale(1 + U(), 1, 0.5f + U()); break;
+            default: T = Scale(-1, 1, 1) * Translate(Vector3f(0.2f, 0.1f, -0.3f)); break;   // swaps handedness
+            }
+            const Transform Ti = Inverse(T);
+            const Transform *renderFromObject = &T, *objectFromRender = &Ti;
+            const Float radius = 0.5f + 1.5f * U();
+            const bool reverseOrientation = (i % 7) == 3;
+            const bool transformSwapsHandedness = T.SwapsHandedness();
+            const Float zMin = -radius, zMax = radius, thetaZMin = std::acos(Clamp(std::min(zMin, zMax) / radius, -1, 1)),
+                        thetaZMax = std::acos(Clamp(std::max(zMin, zMax) / radius, -1, 1)), phiMax = Radians(Clamp(360.f, 0, 360));
+            Point3f c = T(Point3f(0, 0, 0));
+            Point3f o = (i % 4 == 0) ? c + Vector3f(0.3f * (2 * U() - 1), 0.3f * (2 * U() - 1), 0.3f * (2 * U() - 1))   // inside
+                                     : c + 4.f * Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1));
+            Vector3f d = (i % 4 == 0 || i % 3) ? Normalize(c + Vector3f(radius * (2 * U() - 1), radius * (2 * U() - 1), radius * (2 * U() - 1)) - o)
+                                               : Normalize(Vector3f(2 * U() - 1, 2 * U() - 1, 2 * U() - 1));
+            if (i % 11 == 5) d = 3.f * d;   // an unnormalised direction (shadow rays)
+            const Float tMax = (i % 9 == 8) ? 3.5f : Infinity;
+            Ray r(o, d);
+            // -- BasicIntersect
+            bool hit = false;
+            Float tHit = 0, phi = 0;
+            Point3f pHit;
+            do {
+                Point3fi oi = (*objectFromRender)(Point3fi(r.o));
+                Vector3fi di = (*objectFromRender)(Vector3fi(r.d));
+                Interval t0, t1;
+                Interval a = Sqr(di.x) + Sqr(di.y) + Sqr(di.z);
+                Interval b = 2 * (di.x * oi.x + di.y * oi.y + di.z * oi.z);
+                Interval cc = Sqr(oi.x) + Sqr(oi.y) + Sqr(oi.z) - Sqr(Interval(radius));
+                Vector3fi v(oi - b / (2 * a) * di);
+                Interval length = Length(v);
+                Interval discrim = 4 * a * (Interval(radius) + length) * (Interval(radius) - length);
+                if (discrim.LowerBound() < 0) break;
+                Interval rootDiscrim = Sqrt(discrim);
+                Interval q;
+                if ((Float)b < 0) q = -.5f * (b - rootDiscrim);
+                else q = -.5f * (b + rootDiscrim);
+                t0 = q / a;
+                t1 = cc / q;
+                if (t0.LowerBound() > t1.LowerBound()) pstd::swap(t0, t1);
+                if (t0.UpperBound() > tMax || t1.LowerBound() <= 0) break;
+                Interval tShapeHit = t0;
+                if (tShapeHit.LowerBound() <= 0) {
+                    tShapeHit = t1;
+                    if (tShapeHit.UpperBound() > tMax) break;
+                }
+                pHit = Point3f(oi) + (Float)tShapeHit * Vector3f(di);
+                pHit *= radius / Distance(pHit, Point3f(0, 0, 0));
+                if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
+                phi = std::atan2(pHit.y, pHit.x);
+                if (phi < 0) phi += 2 * Pi;
+                if ((zMin > -radius && pHit.z < zMin) || (zMax < radius && pHit.z > zMax) || phi > phiMax) break;  // (never: full sphere)
+                tHit = Float(tShapeHit);
+                hit = true;
+            } while (false);
+            const SquareMatrix<4> &M = T.GetMatrix(), &MI = T.GetInverseMatrix();
+            sep(first); printf("[");
+            for (int rr = 0; rr < 4; ++rr) for (int c2 = 0; c2 < 4; ++c2) { pf(M[rr][c2]); printf(","); }
+            for (int rr = 0; rr < 4; ++rr) for (int c2 = 0; c2 < 4; ++c2) { pf(MI[rr][c2]); printf(","); }
+            pf(radius); printf(",%d,", reverseOrientation ? 1 : 0);
+            pf(o.x); printf(","); pf(o.y); printf(","); pf(o.z); printf(","); pf(d.x); printf(","); pf(d.y); printf(","); pf(d.z); printf(","); pf(tMax);
+            printf(",%d", hit ? 1 : 0);
+            if (hit) {
+                // -- InteractionFromIntersection
+                Float u = phi / phiMax;
+                Float cosTheta = pHit.z / radius;
+                Float theta = SafeACos(cosTheta);
+                Float vv = (theta - thetaZMin) / (thetaZMax - thetaZMin);
+                Float zRadius = std::sqrt(Sqr(pHit.x) + Sqr(pHit.y));
+                Float cosPhi = pHit.x / zRadius, sinPhi = pHit.y / zRadius;
+                Vector3f dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
+                Float sinTheta = SafeSqrt(1 - Sqr(cosTheta));
+                Vector3f dpdv = (thetaZMax - thetaZMin) * Vector3f(pHit.z * cosPhi, pHit.z * sinPhi, -radius * sinTheta);
+                Vector3f pError = gamma(5) * Abs((Vector3f)pHit);
+                bool flipNormal = reverseOrientation ^ transformSwapsHandedness;
+                Vector3f woObject = (*objectFromRender)(-r.d);
+                SurfaceInteraction si = (*renderFromObject)(SurfaceInteraction(Point3fi(pHit, pError), Point2f(u, vv), woObject, dpdu, dpdv,
+                                                                               Normal3f(0, 0, 0), Normal3f(0, 0, 0), 0.f, flipNormal));
+                Vector3f du = Normalize(si.shading.dpdu);
+                printf(","); pf(tHit);
+                printf(","); pf(pHit.x); printf(","); pf(pHit.y); printf(","); pf(pHit.z);
+                printf(","); pf(si.pi.x.LowerBound()); printf(","); pf(si.pi.y.LowerBound()); printf(","); pf(si.pi.z.LowerBound());
+                printf(","); pf(si.pi.x.UpperBound()); printf(","); pf(si.pi.y.UpperBound()); printf(","); pf(si.pi.z.UpperBound());
+                printf(","); pf(si.n.x); printf(","); pf(si.n.y); printf(","); pf(si.n.z);
+                printf(","); pf(du.x); printf(","); pf(du.y); printf(","); pf(du.z);
+                // SpawnRay(ray.d) from the hit (SkipIntersection, interaction.cpp:91-97) and GetMedium's test Dot(w, n) > 0 (interaction.h:117-121)
+                Point3f so = OffsetRayOrigin(si.pi, si.n, r.d);
+                printf(","); pf(so.x); printf(","); pf(so.y); printf(","); pf(so.z);
+                printf(",%d", Dot(r.d, si.n) > 0 ? 1 : 0);
+            }
+            printf("]");
         }
         printf("]\n");
     }

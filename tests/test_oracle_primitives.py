@@ -254,3 +254,57 @@ def test_channel_idx():
     # evaluate_pixel_sample -- check the formula against the reference's outputs
     for u, ch in G["channel_idx"]:
         assert min(int(np.floor(np.float32(fh(u)) * np.float32(3))), 2) == ch
+
+
+def _fhx(t):
+    return float("inf") if t == "inf" else (float("-inf") if t == "-inf" else fh(t))
+
+
+def test_interval_arithmetic(oracle, pkg):
+    """Interval +, -, *, /, Sqr, Sqrt(Abs()), Float * Interval of the REFERENCE (util/math.h:818-1010 over the CPU rounding
+    helpers of util/float.h:199-297) -- the arithmetic under Sphere::BasicIntersect: the oracle reproduces both bounds bit for bit."""
+    out = (C.c_float * 2)()
+    n = 0
+    for row in G["interval_ops"]:
+        v = [_fhx(t) for t in row]
+        alo, ahi, blo, bhi, f = v[:5]
+        for op in range(7):
+            oracle.oracle_interval_op(op, alo, ahi, blo, bhi, f, out)
+            want = v[5 + 2 * op: 7 + 2 * op]
+            for a, b in zip(out, want):
+                assert same(a, b) or (np.isnan(a) and np.isnan(b)), (op, row)
+            n += 1
+    assert n == 96 * 7
+
+
+def test_sphere_against_the_reference_types(oracle, pkg):
+    """Shape "sphere": Sphere::BasicIntersect (shapes.h:147-229) and InteractionFromIntersection (:237-284) + the transform of
+    the interaction to render space -- evaluated by the golden generator on the reference's own Interval / Point3fi / Vector3fi /
+    Transform / SurfaceInteraction classes (oracle/ref_primitives.cpp: shapes.h itself does not link here) -- against the oracle's
+    C restatement: hit or miss, tHit, the object-space point, the interaction point's BOUNDS, the normal, the shading tangent,
+    the origin SkipIntersection spawns the next ray from and the side GetMedium picks: all bit for bit, over identity /
+    translated / scaled / rotated / mirrored spheres, rays from inside and outside, finite tMax, unnormalised directions."""
+    P = pkg
+    hits = 0
+    for row in G["sphere"]:
+        v = [_fhx(t) if isinstance(t, str) else t for t in row]
+        sp = P.VspgSphere()
+        sp.render_from_object[:] = v[0:16]
+        sp.object_from_render[:] = v[16:32]
+        sp.radius, sp.reverse_orientation = v[32], int(v[33])
+        o, d, tMax, want_hit = v[34:37], v[37:40], v[40], int(v[41])
+        hit, t = C.c_int(), C.c_float()
+        plo, phi, n, du = P.f3(), P.f3(), P.f3(), P.f3()
+        oracle.oracle_sphere_intersect(C.byref(sp), P.f3(*o), P.f3(*d), C.c_float(tMax), C.byref(hit), C.byref(t), plo, phi, n, du)
+        assert hit.value == want_hit, row
+        if not want_hit:
+            continue
+        hits += 1
+        assert same(t.value, v[42])
+        for got, want in ((plo, v[46:49]), (phi, v[49:52]), (n, v[52:55]), (du, v[55:58])):
+            assert all(same(a, b) for a, b in zip(got, want)), (list(got), want)
+        h2, pobj, so, side = C.c_int(), P.f3(), P.f3(), C.c_int()
+        oracle.oracle_sphere_skip(C.byref(sp), P.f3(*o), P.f3(*d), C.c_float(tMax), C.byref(h2), pobj, so, C.byref(side))
+        assert h2.value == 1 and all(same(a, b) for a, b in zip(pobj, v[43:46])) and all(same(a, b) for a, b in zip(so, v[58:61]))
+        assert side.value == int(v[61])
+    assert hits >= 90

@@ -311,6 +311,73 @@ def nanovdb_box_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed
     return s
 
 
+def add_quad(scene, p00, e1, e2, kd=(0.5, 0.5, 0.5), le=(0, 0, 0), material=0, iface=0, reverse=0, two_sided=0):
+    """One more rectangle p00 + u e1 + v e2 (normal = normalize(e1 x e2), negated by `reverse`); material / iface: MATERIAL_*, IFACE_*."""
+    k = scene.n_quads
+    assert k < VSPG_MAX_QUADS
+    q = scene.quads[k]
+    q.p00[:] = p00
+    q.e1[:] = e1
+    q.e2[:] = e2
+    q.Kd[:] = kd
+    q.Le[:] = le
+    q.two_sided, q.reverse_orientation, q.material, q.medium_interface = two_sided, reverse, material, iface
+    scene.n_quads = k + 1
+    return scene
+
+
+def add_sphere(scene, center, radius, material=0, iface=0, kd=(0.5, 0.5, 0.5), scale=(1, 1, 1), reverse=0):
+    """Shape "sphere" under Translate(center) * Scale(scale)."""
+    import numpy as np
+    k = scene.n_spheres
+    assert k < VSPG_MAX_SPHERES
+    sp = scene.spheres[k]
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0], m[1, 1], m[2, 2] = scale
+    m[0, 3], m[1, 3], m[2, 3] = center
+    inv = np.linalg.inv(m.astype(np.float64)).astype(np.float32)
+    sp.render_from_object[:] = [float(x) for x in m.reshape(16)]
+    sp.object_from_render[:] = [float(x) for x in inv.reshape(16)]
+    sp.radius = radius
+    sp.Kd[:] = kd
+    sp.reverse_orientation, sp.material, sp.medium_interface = reverse, material, iface
+    scene.n_spheres = k + 1
+    return scene
+
+
+def cloud_scene(xres, yres, n=256, sigma_t=8.0, albedo=0.99, g=0.877, seed=5, shape="noise", nvdb=False):
+    """The shape of the reference's cloud scenes (BASELINE configs 3-5): the camera in VACUUM, the procedural n^3 cloud inside an
+    interface-material bounding sphere (MediumInterface "cloud" "" + Material "interface"), a diffuse ground under it, a
+    distant light and a uniform sky -- no closed box, no emissive geometry."""
+    lib = load()
+    s = VspgScene()
+    _check(lib, lib.vspg_camera_look_at(C.byref(s.camera), f3(0.0, 0.6, -4.2), f3(0.0, 0.15, 0.0), f3(0, 1, 0), 38.0, xres, yres))
+    dens = procedural_cloud_density(n, seed, shape)
+    m = s.medium
+    m.type = MEDIUM_NANOVDB if nvdb else MEDIUM_GRID
+    m.sigma_a[:] = (sigma_t * (1 - albedo),) * 3
+    m.sigma_s[:] = (sigma_t * albedo,) * 3
+    m.g = g
+    m.nx = m.ny = m.nz = n
+    m.bounds_min[:] = (-0.8, -0.5, -0.8)
+    m.bounds_max[:] = (0.8, 0.9, 0.8)
+    m.density = dens.ctypes.data_as(C.POINTER(C.c_float))
+    s._density_keepalive = dens
+    if nvdb:
+        for k in range(3):
+            m.index_min[k] = 0
+            m.voxel_size[k] = (m.bounds_max[k] - m.bounds_min[k]) / n
+            m.grid_origin[k] = m.bounds_min[k]
+        m.density_offset = 0.0
+        m.majorant_scale = 1.0
+    s.camera_outside_medium = 1
+    add_sphere(s, (0.0, 0.2, 0.0), 1.34, material=MATERIAL_INTERFACE, iface=IFACE_INSIDE)
+    add_quad(s, (-6, -1.2, -6), (0, 0, 12), (12, 0, 0), kd=(0.4, 0.35, 0.3))   # ground, n = +y
+    add_infinite_light(s, LIGHT_DISTANT, (6.0, 5.5, 5.0), (0.4, 0.8, -0.3))
+    add_infinite_light(s, LIGHT_UNIFORM_INFINITE, (0.25, 0.35, 0.5))
+    return s
+
+
 def set_medium_transform(scene, m):
     """renderFromMedium = the row-major 4x4 `m` (affine); the inverse is filled by vspg_transform_inverse."""
     import numpy as np

@@ -185,8 +185,22 @@ int main() {
             for (const auto &w : a->warnings) warned = warned || w.find("halton") != std::string::npos;
             CHECK(warned);  // every sampler runs as "independent", and says so
         }
-        // a shape that bounds two media, neither of them the camera's: refused, not rendered wrongly
-        CHECK(throws([&] { (void)ParseSceneString(head + "MakeNamedMedium \"m\" \"string type\" \"homogeneous\"\nMediumInterface \"m\" \"m\"\nShape \"bilinearmesh\" " + quadP + "\n"); }));
+        {   // medium boundaries (round 4): shapes keep their MediumInterface, the camera its side; two media in one scene are refused by name
+            const std::string mm = "MakeNamedMedium \"m\" \"string type\" \"homogeneous\"\n";
+            auto a = ParseSceneString(head + mm + "MediumInterface \"m\" \"m\"\nShape \"bilinearmesh\" " + quadP + "\n");   // both sides in m: not a transition
+            CHECK(a->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS && a->scene.camera_outside_medium == 1);
+            CHECK(a->scene.quads[0].medium_interface == (VSPG_IFACE_INSIDE | VSPG_IFACE_OUTSIDE) && a->scene.quads[0].material == VSPG_MATERIAL_DIFFUSE);
+            auto b = ParseSceneString(head + mm + "MediumInterface \"m\" \"\"\nMaterial \"interface\"\nTranslate 1 2 3\nScale 2 2 2\nShape \"sphere\" \"float radius\" 0.5\n"
+                                             "Material \"diffuse\"\nMediumInterface \"\" \"\"\nShape \"trianglemesh\" \"point3 P\" [ 0 0 0  1 0 0  0 1 0 ]\n");
+            CHECK(b->scene.n_spheres == 1 && b->scene.spheres[0].material == VSPG_MATERIAL_INTERFACE && b->scene.spheres[0].medium_interface == VSPG_IFACE_INSIDE);
+            CHECK(b->scene.spheres[0].radius == 0.5f && b->scene.spheres[0].render_from_object[3] == 1.f && b->scene.spheres[0].render_from_object[0] == 2.f &&
+                  b->scene.spheres[0].object_from_render[0] == 0.5f && b->scene.spheres[0].object_from_render[3] == -0.5f);
+            CHECK(b->scene.n_triangles == 1 && b->scene.tri_flags && b->scene.tri_flags[0] == 0 && b->scene.camera_outside_medium == 1);
+            auto c3 = ParseSceneString(head + mm + "Scale -1 1 1\nMediumInterface \"\" \"m\"\nMaterial \"none\"\nShape \"trianglemesh\" \"point3 P\" [ 0 0 0  1 0 0  0 1 0 ]\n");
+            CHECK(c3->scene.tri_flags[0] == (VSPG_TRI_INTERFACE | VSPG_TRI_FLIP_NORMAL | (VSPG_IFACE_OUTSIDE << VSPG_TRI_IFACE_SHIFT)));
+            CHECK(throws([&] { (void)ParseSceneString(head + mm + "MakeNamedMedium \"n\" \"string type\" \"homogeneous\"\nMediumInterface \"m\" \"n\"\nShape \"sphere\"\n"); }));
+            CHECK(throws([&] { (void)ParseSceneString(head + "Shape \"sphere\" \"float phimax\" 180\n"); }));
+        }
     }
     std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: ok\n", fails);
     return fails ? 1 : 0;

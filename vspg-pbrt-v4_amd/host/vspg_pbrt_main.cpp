@@ -33,9 +33,20 @@ int main(int argc, char **argv) {
         if (seed >= 0) sd->seed = seed;
         if (!out.empty()) sd->filmFilename = out;
         for (const auto &w : sd->warnings) std::fprintf(stderr, "Warning: %s\n", w.c_str());
-        std::printf("scene: %d rectangles, %d triangles, %d infinite lights, medium type %d%s, film %dx%d @ %d spp, integrator \"%s\"\n",
+        std::printf("scene: %d rectangles, %d triangles, %d infinite lights, medium type %d%s, film %dx%d @ %d spp, integrator \"%s\"",
                     sd->scene.n_quads, sd->scene.n_triangles, sd->scene.n_infinite_lights, sd->scene.medium.type,
                     sd->scene.medium.has_transform ? " (placed)" : "", sd->xres, sd->yres, sd->pixelSamples, sd->integratorName.c_str());
+        {   // medium boundaries: spheres, interface-material surfaces, medium transitions, the camera's side
+            int n_interface = 0, n_transition = 0;
+            auto transition = [](int b) { b &= VSPG_IFACE_INSIDE | VSPG_IFACE_OUTSIDE; return b == VSPG_IFACE_INSIDE || b == VSPG_IFACE_OUTSIDE; };
+            for (int i = 0; i < sd->scene.n_quads; ++i) { n_interface += sd->scene.quads[i].material == VSPG_MATERIAL_INTERFACE; n_transition += transition(sd->scene.quads[i].medium_interface); }
+            for (int i = 0; i < sd->scene.n_spheres; ++i) { n_interface += sd->scene.spheres[i].material == VSPG_MATERIAL_INTERFACE; n_transition += transition(sd->scene.spheres[i].medium_interface); }
+            for (size_t i = 0; i < sd->triFlags.size(); ++i) { n_interface += (sd->triFlags[i] & VSPG_TRI_INTERFACE) != 0; n_transition += transition(sd->triFlags[i] >> VSPG_TRI_IFACE_SHIFT); }
+            if (sd->scene.n_spheres || n_interface || n_transition || sd->scene.camera_outside_medium)
+                std::printf("; %d spheres, %d interface-material surfaces, %d medium transitions, camera %s the medium", sd->scene.n_spheres, n_interface, n_transition,
+                            sd->scene.camera_outside_medium ? "outside" : "in");
+        }
+        std::printf("\n");
         if (parseOnly) return 0;
         auto integrator = vspg::CreateIntegrator(*sd, device);
         std::printf("%s\n", integrator->ToString().c_str());
