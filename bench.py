@@ -496,7 +496,13 @@ def main():
                          "issue_bound": issue, "pmc_note": pmc_note,
                          "kernel": ("wavefront pipeline: " if pipeline else "") + kernel_name, "kernel_ms": kern_ms,
                          "density_queries_per_path": dq_rank / max(1, paths_rank),
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "note": note},
+                         # the NEE shadow rays' ratio tracking fetches densities too (8 voxels + a majorant per tentative collision); SURVEY 8d's
+                         # model counts like the reference's densityQueryCount (:692, :886), which leaves them out: reported beside it, so that
+                         # traffic / algorithmic bytes can be split into work the model omits and waste
+                         "shadow_density_queries_per_path": cnt.get("shadow_density_queries", 0) / max(1, paths_rank) if not fog else 0.0,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_bytes_incl_shadow_queries_per_launch": bytes_per_launch + (cnt.get("shadow_density_queries", 0) * B_DENSITY_QUERY / max(1, args.steps) if not fog else 0.0),
+                         "note": note},
         }
         out["film_weight_ok"] = film_weight_ok
         if ranks_seen is not None:

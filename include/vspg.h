@@ -246,6 +246,8 @@ typedef struct VspgCounters {
     uint64_t surface_hits;      /* "Surface interactions" */
     uint64_t density_queries;   /* tentative collisions ("Integrator/Density query") */
     uint64_t shadow_rays;
+    uint64_t shadow_density_queries; /* tentative collisions of the NEE shadow rays' ratio tracking in a HETEROGENEOUS medium (8 voxels + a
+                                        majorant each, like density_queries; the reference's densityQueryCount does not count them) */
 } VspgCounters;
 
 /* ---- guiding field (spatial-directional cache) -------------------------------------------

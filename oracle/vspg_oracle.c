@@ -814,7 +814,7 @@ typedef struct { /* LightSampleContext (base/light.h) */
 } lsctx_t;
 
 typedef struct {
-    uint64_t segments, volume_scatters, surface_hits, density_queries, shadow_rays;
+    uint64_t segments, volume_scatters, surface_hits, density_queries, shadow_rays, shadow_queries;
 } path_counters_t;
 
 typedef struct {
@@ -2361,11 +2361,13 @@ typedef struct {
     int ch;
     spec T_ray, r_l, r_u;
     rng_t *rng;
+    path_counters_t *pc;
 } shadow_cb_ctx_t;
 
 static int shadow_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, spec T_maj, int nds) {
     (void)p; (void)nds;
     shadow_cb_ctx_t *c = (shadow_cb_ctx_t *)vctx;
+    if (c->pc && medium_is_grid_like(c->r->scene.medium.type)) c->pc->shadow_queries++; /* VspgCounters.shadow_density_queries */
     spec sigma_n = s_clamp_zero(s_sub(s_sub(sigma_maj, mp->sigma_a), mp->sigma_s));
     float pdf = T_maj.c[c->ch] * sigma_maj.c[c->ch];
     c->T_ray = s_mul(c->T_ray, s_divf(s_mul(T_maj, sigma_n), pdf));
@@ -2470,7 +2472,7 @@ static spec sample_Ld(const OracleRenderer *r, const intr_t *intr, const gwrap_t
             float tMax = si.hit ? si.t : 1 - SHADOW_EPS;
             float us = rng_float(&rng);
             shadow_cb_ctx_t c;
-            c.r = r; c.ch = ch; c.T_ray = T_ray; c.r_l = r_l; c.r_u = r_u; c.rng = &rng;
+            c.r = r; c.ch = ch; c.T_ray = T_ray; c.r_l = r_l; c.r_u = r_u; c.rng = &rng; c.pc = pc;
             spec T_maj = sample_T_maj(r, lo, ld, tMax, us, &rng, ch, shadow_cb, &c);
             T_ray = c.T_ray; r_l = c.r_l; r_u = c.r_u;
             T_ray = s_mul(T_ray, s_divf(T_maj, T_maj.c[ch]));
@@ -3589,6 +3591,7 @@ static void counters_merge(VspgCounters *dst, const path_counters_t *pc, uint64_
     dst->surface_hits += pc->surface_hits;
     dst->density_queries += pc->density_queries;
     dst->shadow_rays += pc->shadow_rays;
+    dst->shadow_density_queries += pc->shadow_queries;
 }
 
 int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int wave_start,
@@ -3635,7 +3638,7 @@ int oracle_render_window(OracleRenderer *r, int x0, int y0, int x1, int y1, int 
         counters_merge(&total, &pc, paths);
     }
     counters_merge(&r->counters, &(path_counters_t){total.segments, total.volume_scatters, total.surface_hits,
-                                                    total.density_queries, total.shadow_rays},
+                                                    total.density_queries, total.shadow_rays, total.shadow_density_queries},
                    total.paths);
     r->in_wave = 0;
     return 0;

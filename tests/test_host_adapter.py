@@ -482,6 +482,10 @@ def test_scene_file_with_medium_boundaries(host_build, gpu_pkg, tmp_path):
     add_quad(s, (-6, -1.2, -6), (0, 0, 12), (12, 0, 0), kd=(.4, .35, .3))
     P.add_infinite_light(s, P.LIGHT_UNIFORM_INFINITE, (.25, .35, .5))
     P.add_infinite_light(s, P.LIGHT_DISTANT, (6, 5.5, 5), (0.4, 0.8, -0.3))
+    # (the scene-file reader normalises `from - to` in float, add_infinite_light in double: hand over the reader's bits)
+    wf = np.float32([0.4, 0.8, -0.3])
+    lf = np.sqrt(np.float32(np.float32(np.float32(wf[0] * wf[0]) + np.float32(wf[1] * wf[1])) + np.float32(wf[2] * wf[2])))
+    s.infinite_lights[1].w_light[:] = [float(np.float32(x / lf)) for x in wf]
     prm = P.app_f_params()
     r = P.Renderer(s, prm, W, H)
     assert r.kernel_name().startswith("k_wf_dist_walk")
@@ -496,6 +500,8 @@ def test_scene_file_with_medium_boundaries(host_build, gpu_pkg, tmp_path):
     si = rng.integers(0, 256, n).astype(np.int32)
     c = oracle_lib.OracleRenderer(s, prm, W, H)
     Lc, sc = c.trace_paths(xy, si)
+    r.close()
+    r = P.Renderer(s, prm, W, H)          # (a fresh renderer: the one above has updated its VSP buffer, the oracle's is untouched)
     Lg, sg = r.trace_paths(xy, si)
     assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
     r.close()

@@ -102,7 +102,7 @@ class VspgRenderConfig(C.Structure):
 class VspgCounters(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("volume_scatters", C.c_uint64),
                 ("surface_hits", C.c_uint64), ("density_queries", C.c_uint64),
-                ("shadow_rays", C.c_uint64)]
+                ("shadow_rays", C.c_uint64), ("shadow_density_queries", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -18,6 +18,11 @@
 #include "vspg_wg_kernel.h"
 #include "vspg_guided_wg.h"
 #include "vspg_wavefront.h"
+#include "vspg_wf_launch.h"
+#ifdef VSPG_SINGLE_TU  // diagnostic builds that read device-side globals of the pipeline kernels (VSPG_WF_STATS, VSPG_PROFILE, VSPG_WF_DEBUG)
+#include "vspg_wf_grid.hip"
+#include "vspg_wf_nvdb.hip"
+#endif
 
 using namespace vspg;
 
@@ -34,7 +39,7 @@ static_assert(kBlock == kGuideBlock, "the guiding scratch in LDS is sized for kB
 constexpr int kWavesPerSimd = VSPG_WAVES_PER_SIMD;  // register budget of k_render_wave: 512 / kWavesPerSimd VGPRs
 constexpr int kBlocksPerCU = kWavesPerSimd;         // persistent 256-thread blocks per CU == resident blocks
 constexpr int kChunk = 64;        // dynamic work items a wavefront claims per atomic (one 8x8 pixel tile)
-constexpr int kNumCounters = 6;  // paths, segments, volume_scatters, surface_hits, density_queries, shadow_rays
+constexpr int kNumCounters = 7;  // paths, segments, volume_scatters, surface_hits, density_queries, shadow_rays, shadow_density_queries
 
 template <class PC>
 __device__ __forceinline__ void flush_counters(const PC &pc, uint32_t paths, unsigned long long *g) {
@@ -47,6 +52,7 @@ __device__ __forceinline__ void flush_counters(const PC &pc, uint32_t paths, uns
     atomicAdd(&s[3], pc.surface_hits);
     atomicAdd(&s[4], pc.density_queries);
     atomicAdd(&s[5], pc.shadow_rays);
+    atomicAdd(&s[6], pc.shadow_queries);
     __syncthreads();
     if (threadIdx.x < kNumCounters) atomicAdd(&g[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(kBlock, kWavesPerSimd) void k_render_wave(const DSc
     float *glds = nullptr;
     if constexpr (GUIDED) glds = guide_lds();
     typename std::conditional<TRAIN, PathCountersT<PathRecorder>, PathCounters>::type pc;
-    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = 0;
+    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = pc.shadow_queries = 0;
     if constexpr (TRAIN) {
         pc.rec.base = train.segbuf;  // re-pointed at the lane's work item when a path starts
         pc.rec.stride = (int)train.n_items;
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     const WaveCounters pc{s_counters};
 #else
     struct LaneCounters : PathCounters { uint32_t paths; VDEV void path() { paths++; } } pc;
-    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = pc.paths = 0;
+    pc.segments = pc.volume_scatters = pc.surface_hits = pc.density_queries = pc.shadow_rays = pc.shadow_queries = pc.paths = 0;
 #endif
 
     stage_scene_lds(S);
@@ -1034,6 +1040,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
     atomicAdd(&s_counters[CNT_PATHS], pc.paths); atomicAdd(&s_counters[CNT_SEGMENTS], pc.segments);
     atomicAdd(&s_counters[CNT_VOLUME_SCATTERS], pc.volume_scatters); atomicAdd(&s_counters[CNT_SURFACE_HITS], pc.surface_hits);
     atomicAdd(&s_counters[CNT_DENSITY_QUERIES], pc.density_queries); atomicAdd(&s_counters[CNT_SHADOW_RAYS], pc.shadow_rays);
+    atomicAdd(&s_counters[CNT_SHADOW_QUERIES], pc.shadow_queries);
     __syncthreads();
 #endif
     if (threadIdx.x < CNT_COUNT) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_counters[threadIdx.x]);
@@ -1126,7 +1133,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     using Rec = typename std::conditional<TRAIN, PathRecorder, NullRecorder>::type;
     typename std::conditional<GUIDED, WaveCountersT<Rec>, LaneCounters>::type pc = [&] {
         if constexpr (GUIDED) { WaveCountersT<Rec> c; c.c = s_counters; return c; }
-        else { LaneCounters c; c.segments = c.volume_scatters = c.surface_hits = c.density_queries = c.shadow_rays = c.paths = 0; return c; }
+        else { LaneCounters c; c.segments = c.volume_scatters = c.surface_hits = c.density_queries = c.shadow_rays = c.shadow_queries = c.paths = 0; return c; }
     }();
     // a18, training launches (one sample per pixel): a path's records go to ITS column of the wave's record buffer -- the
     // column of its work item, which the pixel names (tile-ordered items: vspg_render_wave sizes the buffer by them)
@@ -1358,6 +1365,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
         atomicAdd(&s_counters[CNT_PATHS], pc.paths); atomicAdd(&s_counters[CNT_SEGMENTS], pc.segments);
         atomicAdd(&s_counters[CNT_VOLUME_SCATTERS], pc.volume_scatters); atomicAdd(&s_counters[CNT_SURFACE_HITS], pc.surface_hits);
         atomicAdd(&s_counters[CNT_DENSITY_QUERIES], pc.density_queries); atomicAdd(&s_counters[CNT_SHADOW_RAYS], pc.shadow_rays);
+    atomicAdd(&s_counters[CNT_SHADOW_QUERIES], pc.shadow_queries);
     }
     __syncthreads();
     if (threadIdx.x < CNT_COUNT) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_counters[threadIdx.x]);
@@ -2442,12 +2450,10 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
     return 0;
 }
 
-// One pass of the wavefront pipeline: sample index `sample` of every pixel.
-// WalkMedium: the instantiation the two walk kernels run -- the grey one whenever the medium's coefficients are bitwise grey
-// (a third of the per-channel divisions / FastExp of a tracking step), also under the guided dense kernels, which have no
-// grey instantiation of their own: the walks read and write none of the fields whose layout depends on it.
-template <class Medium, bool GUIDED = false, bool TRAIN = false, class WalkMedium = Medium>
-static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
+// One pass of the wavefront pipeline: sample index `sample` of every pixel.  The pipeline's kernels are instantiated in their own
+// translation units (vspg_wf_grid.hip / vspg_wf_nvdb.hip: wf_dispatch_*, vspg_wf_launch.h), which `make -j` builds beside this one;
+// here the pass is prepared -- buffers, grids, streams -- and handed over as a plain WfLaunch.
+static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb, bool guided, bool train, bool grey) {
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
     const size_t items = (size_t)tilesX * tilesY * 64;
     // Path-loop iterations of a pass.  Without medium boundaries every iteration ends at a vertex and raises the depth: maxdepth + 1
@@ -2468,7 +2474,8 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
         r->wf_items = items;
     }
     HIPCHK(hipMemsetAsync(r->wf_iters, 0, (size_t)n_iters * sizeof(WfIter), s));
-    WfArgs a;
+    WfLaunch L;
+    WfArgs &a = L.a;
     a.scene = r->dscene;
     a.P = WfPool{r->wf_pool, items};
     a.film = r->film;
@@ -2489,15 +2496,15 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     a.rec_cap = train_rec_capacity(r->prm.maxdepth);
     {   // (VSPG_WF_COMPACT=0: the full layout for a grey medium too -- same results, for A/B runs)
         const char *e = getenv("VSPG_WF_COMPACT");
-        a.compact_results = WalkMedium::kGrey != 0 && !(e && e[0] == '0') ? 1 : 0;
+        a.compact_results = grey && !(e && e[0] == '0') ? 1 : 0;
     }
-    if (TRAIN) {  // a18: the pass records path segments; PropagateSamples (k_propagate) follows it
+    if (train) {  // a18: the pass records path segments; PropagateSamples (k_propagate) follows it
         a.train = TrainArgs{r->segbuf, r->seg_count, r->samples, r->train_counters, r->sample_capacity, (unsigned)items};
         HIPCHK(hipMemsetAsync(r->seg_count, 0, items * sizeof(int), s));
     }
     {   // tuning knobs (defaults measured on the 256^3 cloud stand-in)
         const char *e1 = getenv("VSPG_WF_ROUNDS"), *e2 = getenv("VSPG_WF_REFILL");
-        a.walk_rounds = e1 ? atoi(e1) : WalkMedium::kAdvanceRounds;
+        a.walk_rounds = e1 ? atoi(e1) : (nvdb ? GridMediumT<true>::kAdvanceRounds : GridMediumT<false>::kAdvanceRounds);
         a.walk_refill = e2 ? atoi(e2) : kWfRefill;
         if (a.walk_rounds < 1) a.walk_rounds = 1;
         if (a.walk_refill < 1) a.walk_refill = 1;
@@ -2509,80 +2516,35 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s) {
     // workgroups per CU of each, within their launch bounds)
     static const int walk_blocks = [] { const char *e = getenv("VSPG_WF_WALK_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= kWfWalkWavesPerSimd ? v : kWfWalkWavesPerSimd; }();
     static const int shadow_blocks = [] { const char *e = getenv("VSPG_WF_SHADOW_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= kWfShadowWavesPerSimd ? v : kWfShadowWavesPerSimd; }();
-    unsigned dense = (unsigned)r->num_cus * 8u, walk = (unsigned)r->num_cus * (unsigned)walk_blocks;
-    if (dense > max_blocks) dense = max_blocks;
-    unsigned swalk = (unsigned)r->num_cus * (unsigned)shadow_blocks;
-    if (walk > max_blocks) walk = max_blocks;
-    if (swalk > max_blocks) swalk = max_blocks;
+    L.dense = (unsigned)r->num_cus * 8u;
+    L.walk = (unsigned)r->num_cus * (unsigned)walk_blocks;
+    L.swalk = (unsigned)r->num_cus * (unsigned)shadow_blocks;
+    if (L.dense > max_blocks) L.dense = max_blocks;
+    if (L.walk > max_blocks) L.walk = max_blocks;
+    if (L.swalk > max_blocks) L.swalk = max_blocks;
     // The shadow walk of iteration i runs beside the distance walk of iteration i + 1, on the renderer's second stream; the
     // vertex kernel of iteration i + 1 waits for both (it adds the shadow walk's result first thing).  VSPG_WF_SERIAL=1 keeps
     // everything on the caller's stream (same results; for A/B runs and debugging).
-    const bool serial = [] { const char *e = getenv("VSPG_WF_SERIAL"); return e && *e && *e != '0'; }();  // (read per pass: a test flips it)
-    if (!serial && !r->wf_stream2) {
+    L.serial = [] { const char *e = getenv("VSPG_WF_SERIAL"); return e && *e && *e != '0'; }();  // (read per pass: a test flips it)
+    if (!L.serial && !r->wf_stream2) {
         HIPCHK(hipStreamCreateWithFlags(&r->wf_stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_vertex, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_shadow, hipEventDisableTiming));
     }
-    const hipStream_t s2 = serial ? s : r->wf_stream2;
-    // (medium boundaries) has the list of iteration `it` run dry?  One small read-back per iteration past the ones every pass needs.
-    auto list_empty = [&](int it, bool *empty) -> int {
-        unsigned int na = 0;
-        HIPCHK(hipMemcpyAsync(&na, &r->wf_iters[it].n_active, sizeof na, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        *empty = na == 0;
-        return 0;
-    };
-    auto check_drained = [&]() -> int {
-        if (!bnd) return 0;
-        bool empty = true;
-        if (int rc = list_empty(max_iters, &empty)) return rc;
-        if (!empty) return fail(VSPG_ESCOPE, "paths still alive after the pipeline's iteration cap: more medium-boundary crossings per vertex than a pass provides for");
-        return 0;
-    };
-    if (r->prm.vspsamplingmethod != VSPG_VSP_RESAMPLING) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
-        for (int it = 0; it < max_iters; ++it) {
-            if (bnd && it > base_iters) {
-                bool empty = false;
-                if (int rc = list_empty(it, &empty)) return rc;
-                if (empty) break;
-            }
-            hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
-            if (bnd || it < r->prm.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
-        }
-        HIPCHK(hipGetLastError());
-        if (int rc = check_drained()) return rc;
-        if (TRAIN) {
-            hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a.train, a.rec_cap);
-            HIPCHK(hipGetLastError());
-        }
-        return 0;
-    }
-    hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a);
-    for (int it = 0; it < max_iters; ++it) {
-        if (bnd && it > base_iters) {
-            bool empty = false;
-            if (int rc = list_empty(it, &empty)) return rc;
-            if (empty) break;
-        }
-        hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
-        if (it > 0 && !serial) HIPCHK(hipStreamWaitEvent(s, r->wf_ev_shadow, 0));
-        hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
-        if (bnd || it < r->prm.maxdepth) {
-            // (guided: the next segments begin BEFORE the shadow walk starts -- launched after it, the dense begin kernel crawled in
-            // the slots the persistent walk left over and the next distance walk waited for it)
-            if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it + 1);
-            if (!serial) {
-                HIPCHK(hipEventRecord(r->wf_ev_vertex, s));
-                HIPCHK(hipStreamWaitEvent(s2, r->wf_ev_vertex, 0));
-            }
-            hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s2, a, it);
-            if (!serial) HIPCHK(hipEventRecord(r->wf_ev_shadow, s2));
-        }
-    }
-    HIPCHK(hipGetLastError());
-    if (bnd && !serial) HIPCHK(hipStreamWaitEvent(s, r->wf_ev_shadow, 0));  // (the last shadow walk finds an empty list; the caller's stream still waits for it)
-    if (int rc = check_drained()) return rc;
-    if (TRAIN) {
+    L.s = s;
+    L.s2 = L.serial ? s : r->wf_stream2;
+    L.ev_vertex = r->wf_ev_vertex;
+    L.ev_shadow = r->wf_ev_shadow;
+    L.bnd = bnd;
+    L.nds = r->prm.vspsamplingmethod != VSPG_VSP_RESAMPLING;
+    L.maxdepth = r->prm.maxdepth;
+    L.base_iters = base_iters;
+    L.max_iters = max_iters;
+    const int rc = nvdb ? wf_dispatch_nvdb(L, guided, train, grey) : wf_dispatch_grid(L, guided, train, grey);
+    if (rc == WF_E_NOT_DRAINED)
+        return fail(VSPG_ESCOPE, "paths still alive after the pipeline's iteration cap: more medium-boundary crossings per vertex than a pass provides for");
+    if (rc != 0) return fail(VSPG_EHIP, std::string("the wavefront pipeline: ") + hipGetErrorName((hipError_t)rc));
+    if (train) {
         hipLaunchKernelGGL(k_propagate, dim3((unsigned)((items + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a.train, a.rec_cap);
         HIPCHK(hipGetLastError());
     }
@@ -3193,16 +3155,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
 #endif
         for (int w = first; w < wave_end; w += sc > 1 ? sc : 1) {
             const hipStream_t hs = (hipStream_t)stream;
-            const bool grey = r->medium_grey, tr = r->training;
-            int rc;
-            // (a grey medium runs the kGrey instantiations of the dense kernels too, guided or not: r_u / r_l / the pdfs in one quad,
-            // no per-channel majorant ratios)
-            if (guided && nvdb) rc = tr ? (grey ? wf_render_pass<NanoDenseMediumGrey, true, true, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true, true>(r, w, hs))
-                                        : (grey ? wf_render_pass<NanoDenseMediumGrey, true, false, NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium, true>(r, w, hs));
-            else if (guided) rc = tr ? (grey ? wf_render_pass<GridMediumGrey, true, true, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true, true>(r, w, hs))
-                                     : (grey ? wf_render_pass<GridMediumGrey, true, false, GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium, true>(r, w, hs));
-            else if (nvdb) rc = grey ? wf_render_pass<NanoDenseMediumGrey>(r, w, hs) : wf_render_pass<NanoDenseMedium>(r, w, hs);
-            else rc = grey ? wf_render_pass<GridMediumGrey>(r, w, hs) : wf_render_pass<GridMedium>(r, w, hs);
+            const int rc = wf_render_pass(r, w, hs, nvdb, guided, guided && r->training, r->medium_grey);
             if (rc) return rc;
         }
 #ifdef VSPG_WF_DEBUG
@@ -3564,6 +3517,7 @@ int vspg_get_counters(VspgRenderer *r, VspgCounters *out, void *stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     out->paths = h[0]; out->segments = h[1]; out->volume_scatters = h[2];
     out->surface_hits = h[3]; out->density_queries = h[4]; out->shadow_rays = h[5];
+    out->shadow_density_queries = h[6];
     return 0;
 }
 int vspg_reset_counters(VspgRenderer *r, void *stream) {

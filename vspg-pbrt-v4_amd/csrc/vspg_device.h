@@ -591,6 +591,19 @@ struct DScene {
     // LightSampler::Create(prm.lightsampler, lights): lsamp.mode is UNIFORM wherever the pick is trivial
     DLightSampler lsamp;
 };
+// DScene::has_boundaries as the path code reads it.  (-DVSPG_NO_BOUNDARIES: a diagnostic build without the boundary code, to price
+// its presence in the kernels that serve scenes without boundaries -- same results on those scenes.)
+// BND: what the instantiation knows at compile time -- 0: no boundaries (the code for them is not compiled in: the wavefront
+// pipeline's instantiations for scenes where the medium fills everything keep their round-3 shape), 1: boundaries, -1: decided at
+// run time (the per-lane kernels, which serve everything).  Medium types carry it as kBnd.
+#ifdef VSPG_NO_BOUNDARIES
+template <int BND> VDEV bool has_bnd(const DScene &) { return false; }
+#else
+template <int BND> VDEV bool has_bnd(const DScene &S) {
+    if constexpr (BND >= 0) return BND != 0;
+    else return S.has_boundaries != 0;
+}
+#endif
 // vsp_ready as handed to the path functions: bit 0 = the VSP buffer holds estimates; bit 1 = a debug path trace
 // (vspg_trace_paths), which does not feed the per-pixel buffers
 enum { VSP_READY = 1, VSP_NO_FEED = 2 };
@@ -1127,6 +1140,7 @@ struct HomogeneousMediumT {
     static constexpr int kGrey = GREY;   // 0 none, 1 medium spectra, 2 medium spectra + surface reflectances
     static constexpr bool kNullZero = NULLZERO;
     static constexpr bool kSimpleScene = SIMPLE;
+    static constexpr int kBnd = -1;  // medium boundaries: decided at run time (has_bnd; simple-scene kernels never ask)
     // constants live in the workgroup's LDS copy (s_scene_medium, staged by stage_scene_lds)
     static VDEV Spec m3(int o) {
         if constexpr (GREY) {
@@ -1178,8 +1192,9 @@ VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis
 // grid (media.h:686-719): index-space trilinear sampling a + w (b - a) with background 0 outside the index
 // bounding box, "densityoffset", 64^3 majorants read from HBM / L2 (1 MB: too large for LDS).  The sparse
 // NanoVDB tree and its sampler are absent from the reference tree: parity unpinned for the fetch itself.
-template <bool NVDB, bool GREY = false>
+template <bool NVDB, bool GREY = false, int BND = -1>
 struct GridMediumT {
+    static constexpr int kBnd = BND;  // medium boundaries known at compile time (0 / 1) or decided at run time (-1): has_bnd
     static constexpr int kRes = NVDB ? kMajResNvdb : kMajRes;
     // wavefront walk kernels: majorant-cell advances tried per tracking step before the collision code runs (a 64^3
     // majorant grid has 4x as many cell crossings per tentative collision as the 16^3 one)
@@ -1445,9 +1460,9 @@ using GridMedium = GridMediumT<false>;
 using GridMediumGrey = GridMediumT<false, true>;
 using NanoDenseMedium = GridMediumT<true>;
 using NanoDenseMediumGrey = GridMediumT<true, true>;
-template <bool NVDB, bool GREY>
-VDEV GridMediumT<NVDB, GREY> make_grid(const DScene &S, const float *majorant) {
-    return GridMediumT<NVDB, GREY>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
+template <bool NVDB, bool GREY, int BND = -1>
+VDEV GridMediumT<NVDB, GREY, BND> make_grid(const DScene &S, const float *majorant) {
+    return GridMediumT<NVDB, GREY, BND>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
                              majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
                              S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le), S.has_xform ? S.minv : nullptr};
 }
@@ -1455,9 +1470,9 @@ template <class M> struct MediumMaker;
 template <int GREY, bool NZ, bool SIMPLE> struct MediumMaker<HomogeneousMediumT<GREY, NZ, SIMPLE>> {
     static VDEV HomogeneousMediumT<GREY, NZ, SIMPLE> make(const DScene &, const float *) { return HomogeneousMediumT<GREY, NZ, SIMPLE>{}; }
 };
-template <bool NVDB, bool GREY> struct MediumMaker<GridMediumT<NVDB, GREY>> {
-    static VDEV GridMediumT<NVDB, GREY> make(const DScene &S, const float *majorant) {
-        return make_grid<NVDB, GREY>(S, majorant ? majorant : S.majorant);
+template <bool NVDB, bool GREY, int BND> struct MediumMaker<GridMediumT<NVDB, GREY, BND>> {
+    static VDEV GridMediumT<NVDB, GREY, BND> make(const DScene &S, const float *majorant) {
+        return make_grid<NVDB, GREY, BND>(S, majorant ? majorant : S.majorant);
     }
 };
 

@@ -185,18 +185,19 @@ VDEV float light_pdf_li(const DQuad &q, const LsCtx &ctx, V3 wi) {  // shapes.cp
 //   PathCounters  one set per lane in registers (per-lane kernels; k_trace_paths reports segments per path);
 //   WaveCounters  one set per workgroup in LDS: the active lanes of a wavefront are counted with a
 //                 ballot and one lane adds the total -- no per-lane registers, ~10 instructions per count.
-enum { CNT_PATHS = 0, CNT_SEGMENTS, CNT_VOLUME_SCATTERS, CNT_SURFACE_HITS, CNT_DENSITY_QUERIES, CNT_SHADOW_RAYS, CNT_COUNT };
+enum { CNT_PATHS = 0, CNT_SEGMENTS, CNT_VOLUME_SCATTERS, CNT_SURFACE_HITS, CNT_DENSITY_QUERIES, CNT_SHADOW_RAYS, CNT_SHADOW_QUERIES, CNT_COUNT };
 // Either sink also carries the a18 recorder (`rec`): NullRecorder everywhere except the training
 // instantiations of the per-lane kernel (vspg_train.h).
 template <class REC>
 struct PathCountersT {
-    uint32_t segments, volume_scatters, surface_hits, density_queries, shadow_rays;
+    uint32_t segments, volume_scatters, surface_hits, density_queries, shadow_rays, shadow_queries;
     REC rec;
     VDEV void segment() { segments++; }
     VDEV void volume_scatter() { volume_scatters++; }
     VDEV void surface_hit() { surface_hits++; }
     VDEV void density_query() { density_queries++; }
     VDEV void shadow_ray() { shadow_rays++; }
+    VDEV void shadow_query() { shadow_queries++; }
 };
 using PathCounters = PathCountersT<NullRecorder>;
 template <class REC>
@@ -213,6 +214,7 @@ struct WaveCountersT {
     VDEV void surface_hit() const { add(CNT_SURFACE_HITS); }
     VDEV void density_query() const { add(CNT_DENSITY_QUERIES); }
     VDEV void shadow_ray() const { add(CNT_SHADOW_RAYS); }
+    VDEV void shadow_query() const { add(CNT_SHADOW_QUERIES); }
 };
 using WaveCounters = WaveCountersT<NullRecorder>;
 
@@ -250,7 +252,7 @@ struct Intr {
     V3 n;
     V3 wo;
     float g;
-    // medium boundaries (read only where S.has_boundaries): Interaction::medium -- the medium of the ray that reached a
+    // medium boundaries (read only where has_bnd(S)): Interaction::medium -- the medium of the ray that reached a
     // non-transition surface, of the medium interaction itself -- and the surface's SURF_* flags (GetMedium, interaction.h:117-121)
     bool medium;
     int sflags;
@@ -281,6 +283,7 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
     pc.shadow_ray();
     // ratio tracking (:1207-1232)
     auto ratio_cb = [&](V3, const MediumProps &mp, Spec sigma_maj, Spec T_maj, bool) {
+        if constexpr (!Medium::kSingleSegment) pc.shadow_query();  // heterogeneous media: a density fetch, as in the distance walk
         float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
         if constexpr (Medium::kNullZero) {
             // sigma_n == 0: T_ray *= T_maj * 0 / pdf is an exact 0 for a positive finite pdf (T_maj is
@@ -306,7 +309,7 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
         if (!nonzero(T_ray)) return false;
         return true;
     };
-    if (kFull && S.has_boundaries) {
+    if (kFull && has_bnd<Medium::kBnd>(S)) {
         // The loop of :1195-1244 over the segments of the light ray: Intersect(lightRay, 1 - ShadowEpsilon) finds the CLOSEST hit;
         // one with a material blocks, an interface ends the segment and the ray goes on from it, in the medium its far side
         // holds (si->intr.SpawnRayTo(ls->pLight), :1243).
@@ -420,7 +423,7 @@ struct PathState {
     float vsp0;  // primary-ray VSP of this pixel, loaded when the path starts (hides the HBM latency)
     float pce;   // guided builds, rrguiding: the pixel's contribution estimate (0 = none); guideRR = rrguiding && buffer ready
     bool guideRR;
-    bool in_medium;  // ray.medium != nullptr.  Constant without medium boundaries (S.has_boundaries == 0); simple-scene kernels never read it
+    bool in_medium;  // ray.medium != nullptr.  Constant without medium boundaries (has_bnd(S) == 0); simple-scene kernels never read it
     GuideState gs;  // guided builds only: the previous vertex's distribution for the secondary-ray VSP
 };
 
@@ -716,7 +719,7 @@ struct Vertex {
 // LI_SKIP: the hit has no BSDF (Material "interface"), SkipIntersection moved the ray past it (:399-404) and the path loop
 // goes round again without a vertex.  LI_END is 0: callers that cannot meet LI_SKIP read the result as a bool.
 enum { LI_END = 0, LI_VERTEX = 1, LI_SKIP = 2 };
-template <bool FULL = true, class PC>
+template <bool FULL = true, int BND = -1, class PC>
 VDEV int li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, const Isect &si, Spec tw) {
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     VSPG_PROF(PS_SURF_PRE);
@@ -761,7 +764,7 @@ VDEV int li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, 
             w_direct = w_l;
         }
     }
-    if (FULL && S.has_boundaries) {  // :399-404: GetBSDF of an interface material returns no BSDF -- a medium boundary
+    if (FULL && has_bnd<BND>(S)) {  // :399-404: GetBSDF of an interface material returns no BSDF -- a medium boundary
         const int sfl = surf_flags(S, si.quad);
         if (sfl & SURF_INTERFACE) {
             // isect.SkipIntersection(&ray, si->tHit) (interaction.cpp:91-97): ray = SpawnRay(ray.d), medium = GetMedium(ray.d)
@@ -804,7 +807,7 @@ VDEV int li_segment_a(const DScene &S, const Medium &medium, const float *vsp_bu
     Spec tw = sp(1.f);  // transmittanceWeight (:317)
     // :318 `if (ray.medium && !std::isinf(tMax))`: a ray that escapes the scene is not sampled (rounds 1-3 did: wrong).  Without
     // medium boundaries every ray is in the scene's medium.
-    const bool in_medium = Medium::kSimpleScene || !S.has_boundaries ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
+    const bool in_medium = Medium::kSimpleScene || !has_bnd<Medium::kBnd>(S) ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
     if (in_medium && si.hit) {
         Rng rng;
         {
@@ -822,7 +825,7 @@ VDEV int li_segment_a(const DScene &S, const Medium &medium, const float *vsp_bu
             return LI_VERTEX;
         }
     }
-    return li_surface_pre<!Medium::kSimpleScene>(S, st, isg, pc, si, tw);
+    return li_surface_pre<!Medium::kSimpleScene, Medium::kBnd>(S, st, isg, pc, si, tw);
 }
 
 // GREG: the guiding scratch lives in registers (GStoreReg, the workgroup kernel) instead of the lane's LDS column (glds, gstride)
@@ -846,7 +849,7 @@ struct VertexCtx {
     Intr intr;
     Bsdf bsdf;
 };
-template <bool GREY_KD = false, bool FULL = true>
+template <bool GREY_KD = false, bool FULL = true, int BND = -1>
 VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, VertexCtx &c) {
     Isect &si = c.si;
     Intr &intr = c.intr;
@@ -871,7 +874,7 @@ VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, V
         intr.sflags = 0;
     } else {
         intr.medium = FULL ? st.in_medium : true;
-        intr.sflags = FULL && S.has_boundaries ? surf_flags(S, vx.quad) : 0;
+        intr.sflags = FULL && has_bnd<BND>(S) ? surf_flags(S, vx.quad) : 0;
         si.perr = vx.perr;
         if (FULL && is_sphere(vx.quad)) {  // vx.p = the object-space hit point (kSpherePrim)
             const DSphere &sph = S.spheres[sphere_of(vx.quad)];
@@ -905,7 +908,7 @@ VDEV float vertex_pre(const DScene &S, const PathState &st, Sampler &sampler, co
     }
     return survivalProb;
 }
-template <bool FULL = true>
+template <bool FULL = true, int BND = -1>
 VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Vertex &vx, const VertexCtx &c, float survivalProb) {
     const bool volume_vertex = vx.volume;
     const V3 vp = vx.p;
@@ -977,7 +980,7 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
     st.anyNonSpecularBounces = true;
     st.ro = offset_ray_origin(intr.pi, si.n, wi);  // SpawnRay (interaction.h:99-101) ...
     st.rd = wi;
-    if (FULL && S.has_boundaries) st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, si.n, wi, st.in_medium);  // ... with GetMedium(wi)
+    if (FULL && has_bnd<BND>(S)) st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, si.n, wi, st.in_medium);  // ... with GetMedium(wi)
 
     if (!nonzero(st.beta)) return false;
     if (st.depth > S.prm.minrrdepth) {
@@ -996,7 +999,7 @@ template <class Medium, bool GUIDED = false, bool GREG = false, class PC>
 VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int ch, Sampler &sampler, PC &pc,
                        const Vertex &vx, float *glds = nullptr, int gstride = 0) {
     VertexCtx c;
-    vertex_setup<(Medium::kGrey >= 2), !Medium::kSimpleScene>(S, st, vx, c);
+    vertex_setup<(Medium::kGrey >= 2), !Medium::kSimpleScene, Medium::kBnd>(S, st, vx, c);
     if constexpr (GUIDED)
         return li_vertex_guided<Medium, GUIDED, GREG>(S, medium, st, ch, sampler, pc, vx.volume, vx.p, vx.g, c.si, c.intr, c.bsdf, glds, gstride);
     const float survivalProb = vertex_pre(S, st, sampler, vx);
@@ -1005,7 +1008,7 @@ VDEV bool li_segment_b(const DScene &S, const Medium &medium, PathState &st, int
         Spec Ld = sample_Ld(S, medium, c.intr, &c.bsdf, ch, sampler, st.r_u, pc);
         st.L = st.L + st.beta * Ld;
     }
-    return vertex_tail<!Medium::kSimpleScene>(S, st, sampler, vx, c, survivalProb);
+    return vertex_tail<!Medium::kSimpleScene, Medium::kBnd>(S, st, sampler, vx, c, survivalProb);
 }
 
 template <class Medium, bool GUIDED = false, class PC>
@@ -1274,7 +1277,7 @@ VDEV bool li_vertex_guided_impl(const DScene &S, const Medium &medium, PathState
         st.anyNonSpecularBounces = true;
         st.ro = offset_ray_origin(intr.pi, si.n, wi);
         st.rd = wi;
-        if (!Medium::kSimpleScene && S.has_boundaries) st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, si.n, wi, st.in_medium);
+        if (!Medium::kSimpleScene && has_bnd<Medium::kBnd>(S)) st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(intr.sflags, si.n, wi, st.in_medium);
         if (nonzero(st.beta)) {
             if (!st.guideRR && st.depth > S.prm.minrrdepth) {  // :597-600
                 Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;

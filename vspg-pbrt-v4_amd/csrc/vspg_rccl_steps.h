@@ -123,17 +123,17 @@ int vspg_rccl_sum_counters(VspgRenderer *r, void *comm, void *stream, VspgCounte
     VspgCounters c;
     int rc = vspg_get_counters(r, &c, stream);
     if (rc) return rc;
-    unsigned long long h[6] = {c.paths, c.segments, c.volume_scatters, c.surface_hits, c.density_queries, c.shadow_rays};
+    unsigned long long h[7] = {c.paths, c.segments, c.volume_scatters, c.surface_hits, c.density_queries, c.shadow_rays, c.shadow_density_queries};
     unsigned long long *d = nullptr;
     HCHK(hipMalloc(&d, sizeof h));
     HCHK(hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, (hipStream_t)stream));
-    const int nr = VSPG_TRANSPORT::sum_u64(comm, d, 6, (hipStream_t)stream);
+    const int nr = VSPG_TRANSPORT::sum_u64(comm, d, 7, (hipStream_t)stream);
     hipError_t he = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(d);
     if (nr != 0 || he != hipSuccess) return VSPG_EHIP;
     out->paths = h[0]; out->segments = h[1]; out->volume_scatters = h[2];
-    out->surface_hits = h[3]; out->density_queries = h[4]; out->shadow_rays = h[5];
+    out->surface_hits = h[3]; out->density_queries = h[4]; out->shadow_rays = h[5]; out->shadow_density_queries = h[6];
     return 0;
 }
 

@@ -471,7 +471,7 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Medium &medium, int ch, 
     r.lo = pf;
     r.ld = pt - pf;
     r.rng.set_sequence(hash_v3(r.lo), hash_v3(r.ld));  // :1193
-    if (S.has_boundaries) {
+    if (has_bnd<Medium::kBnd>(S)) {
         // Medium boundaries: the light ray is a chain of segments (:1195-1244), each ending at the closest hit -- a surface with a
         // material blocks, an interface hands the ray on in the medium of its far side.  Which segments there are is geometry
         // (no random number decides it), so the chain is walked HERE; what is left for the walk kernel is the ratio tracking
@@ -649,7 +649,7 @@ template <class REC>
 struct WfCountersT : PathCountersT<REC> {
     uint32_t paths;
     VDEV void path() { paths++; }
-    VDEV void zero() { this->segments = this->volume_scatters = this->surface_hits = this->density_queries = this->shadow_rays = paths = 0; }
+    VDEV void zero() { this->segments = this->volume_scatters = this->surface_hits = this->density_queries = this->shadow_rays = this->shadow_queries = paths = 0; }
 };
 using WfCounters = WfCountersT<NullRecorder>;
 template <class REC>
@@ -657,7 +657,7 @@ VDEV void wf_flush_counters(const WfCountersT<REC> &pc, unsigned long long *g) {
     __shared__ unsigned int s_c[CNT_COUNT];
     if (threadIdx.x < CNT_COUNT) s_c[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t v[CNT_COUNT] = {pc.paths, pc.segments, pc.volume_scatters, pc.surface_hits, pc.density_queries, pc.shadow_rays};
+    const uint32_t v[CNT_COUNT] = {pc.paths, pc.segments, pc.volume_scatters, pc.surface_hits, pc.density_queries, pc.shadow_rays, pc.shadow_queries};
     for (int k = 0; k < CNT_COUNT; ++k) {
         uint32_t x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
@@ -701,7 +701,7 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
     P.f(WF_VXT, slot) = si.t;
     if (is_tri(si.quad)) P.set3(WF_VXE, slot, si.perr);
     // :318 `if (ray.medium && !std::isinf(tMax))`: no distance sampling for a ray outside the medium or one that escapes the scene
-    const bool in_medium = !S.has_boundaries ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
+    const bool in_medium = !has_bnd<Medium::kBnd>(S) ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
     if (in_medium && si.hit) {
         Rng rng;
         {
@@ -710,7 +710,7 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
             rng.set_sequence(hash0, hash1);
         }
         bool guide = false;
-        if (S.has_boundaries && st.depth == 0) {  // the camera segment may reach the medium through a boundary, an iteration or more after
+        if (has_bnd<Medium::kBnd>(S) && st.depth == 0) {  // the camera segment may reach the medium through a boundary, an iteration or more after
             int px, py;                           // the path started: the pixel's primary VSP is read where it is used
             wf_pixel_of(slot, a.tilesX, &px, &py);
             st.vsp0 = (a.vsp_ready & VSP_READY) ? a.vsp_buf[(size_t)py * S.xres + px] : 0.5f;
@@ -1065,7 +1065,7 @@ VDEV int wf_vertex(const WfArgs &a, const DScene &S, const Medium &medium, unsig
     constexpr int G = Medium::kGrey;
     bool shadow = false;
     VertexCtx c;
-    vertex_setup<false>(S, st, vx, c);
+    vertex_setup<false, true, Medium::kBnd>(S, st, vx, c);
     float survivalProb = 1.f;
     uint32_t extra = 0u;
     ShadowSetup ss;
@@ -1126,7 +1126,7 @@ VDEV int wf_vertex(const WfArgs &a, const DScene &S, const Medium &medium, unsig
         }
     }
     // ---- Russian roulette + new direction (:842-874 / :487-606); the guided vertex has done both ------------------
-    if constexpr (!GUIDED) cont = vertex_tail(S, st, sampler, vx, c, survivalProb);
+    if constexpr (!GUIDED) cont = vertex_tail<true, Medium::kBnd>(S, st, sampler, vx, c, survivalProb);
     if (!cont) {
         if (shadow) {  // its shadow walk is out: the slot stays listed for that one addition
             wf_rec_store(a, slot, pc.rec);
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                 } else if (kind == EV_SCATTER) {
                     alive = true;
                 } else {
-                    const int pre = li_surface_pre(S, st, isg, pc, si, sp(1.f));
+                    const int pre = li_surface_pre<true, Medium::kBnd>(S, st, isg, pc, si, sp(1.f));
                     alive = pre != LI_END;
                     skipped = pre == LI_SKIP;
                 }
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
                 const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
                 if constexpr (TRAIN) wf_rec_load(a, slot, pc.rec);
                 if constexpr (GUIDED) st.gs.vsp_next = P.f(WF_GSVSP, slot);
-                if (S.has_boundaries && st.depth == 0) st.vsp0 = (a.vsp_ready & VSP_READY) ? a.vsp_buf[(size_t)py * S.xres + px] : 0.5f;  // (see wf_segment_begin)
+                if (has_bnd<Medium::kBnd>(S) && st.depth == 0) st.vsp0 = (a.vsp_ready & VSP_READY) ? a.vsp_buf[(size_t)py * S.xres + px] : 0.5f;  // (see wf_segment_begin)
                 if (fl & WFL_SHADOW_WALK) {  // the previous vertex's NEE (:483 / :836 from the estimate on)
                     const WfShadowResult sr = wf_load_shadow_result(P, slot, a.compact_results != 0);
                     const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, sr.T_ray, sr.r_l, sr.r_u,
@@ -1476,6 +1476,8 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
     const WfPool &P = a.P;
     WfIter *I = &a.iters[it];
     const unsigned n = I->n_shadow;
+    WfCounters pc;
+    pc.zero();
     WfClaim claim{0u, 0u, false, 0u};
     bool active = false, result = false;
     unsigned slot = 0;
@@ -1523,6 +1525,7 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
             w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
             const V3 p = ro + rdn * t;
             const MediumProps mp = medium.sample_point(p);
+            pc.shadow_query();
             // ratio tracking (:1207-1232)
             const Spec sigma_maj = w.sigma_maj, T_maj = w.T_maj;
             const float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
@@ -1550,6 +1553,7 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
             result = true;
         }
     }
+    wf_flush_counters(pc, a.counters);
 }
 
 }  // namespace vspg

@@ -1,0 +1,116 @@
+// vspg_wf_launch.h -- the host side of one wavefront-pipeline pass: the kernel launches of vspg_wavefront.h in order.
+//
+// The pipeline's kernels are the bulk of the library's device code (dense kernels x {medium layout, grey, guided, training,
+// medium boundaries}): they are instantiated in translation units of their own -- vspg_wf_grid.hip (GridMedium) and
+// vspg_wf_nvdb.hip (NanoVDB semantics) -- which `make -j` compiles beside vspg_capi.hip.  vspg_capi.hip prepares a pass (buffers,
+// grid sizes, streams) as a plain WfLaunch and calls wf_dispatch_grid / wf_dispatch_nvdb; those pick the instantiation and run
+// wf_run_pass below.  Return value: 0, a hipError_t, or WF_E_NOT_DRAINED.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vspg_wavefront.h"
+
+namespace vspg {
+
+struct WfLaunch {
+    WfArgs a;
+    unsigned dense, walk, swalk;   // grid sizes: dense kernels, distance walk, shadow walk
+    bool serial;                   // everything on one stream (VSPG_WF_SERIAL)
+    bool bnd;                      // the scene has medium boundaries: the BND instantiations, iterations until the list runs dry
+    bool nds;                      // vspsamplingmethod "nds": segment + vertex in one dense kernel
+    int maxdepth, base_iters, max_iters;
+    hipStream_t s, s2;
+    hipEvent_t ev_vertex, ev_shadow;
+};
+constexpr int WF_E_NOT_DRAINED = -1000;
+
+int wf_dispatch_grid(const WfLaunch &L, bool guided, bool train, bool grey);
+int wf_dispatch_nvdb(const WfLaunch &L, bool guided, bool train, bool grey);
+
+#define WFCHK(expr)                               \
+    do {                                          \
+        const hipError_t e_ = (expr);             \
+        if (e_ != hipSuccess) return (int)e_;     \
+    } while (0)
+
+// Medium: the dense kernels' instantiation (its kBnd says whether the boundary code is compiled in); WalkMedium: the two walk
+// kernels' -- the grey layout whenever the medium's coefficients are bitwise grey, never the boundary flavour (a walk job is a ray
+// segment inside the medium: boundaries are the dense kernels' business).
+template <class Medium, bool GUIDED, bool TRAIN, class WalkMedium>
+int wf_run_pass(const WfLaunch &L) {
+    const WfArgs &a = L.a;
+    const hipStream_t s = L.s, s2 = L.s2;
+    const bool bnd = L.bnd, serial = L.serial;
+    // (medium boundaries) has the list of iteration `it` run dry?  One small read-back per iteration past the ones every pass needs.
+    auto list_empty = [&](int it, bool *empty) -> int {
+        unsigned int na = 0;
+        WFCHK(hipMemcpyAsync(&na, &a.iters[it].n_active, sizeof na, hipMemcpyDeviceToHost, s));
+        WFCHK(hipStreamSynchronize(s));
+        *empty = na == 0;
+        return 0;
+    };
+    if (L.nds) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
+        for (int it = 0; it < L.max_iters; ++it) {
+            if (bnd && it > L.base_iters) {
+                bool empty = false;
+                if (const int rc = list_empty(it, &empty)) return rc;
+                if (empty) break;
+            }
+            hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a, it);
+            if (bnd || it < L.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(L.swalk), dim3(kWfBlock), 0, s, a, it);
+        }
+    } else {
+        hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a);
+        for (int it = 0; it < L.max_iters; ++it) {
+            if (bnd && it > L.base_iters) {
+                bool empty = false;
+                if (const int rc = list_empty(it, &empty)) return rc;
+                if (empty) break;
+            }
+            hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(L.walk), dim3(kWfBlock), 0, s, a, it);
+            if (it > 0 && !serial) WFCHK(hipStreamWaitEvent(s, L.ev_shadow, 0));
+            hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a, it);
+            if (bnd || it < L.maxdepth) {
+                // (guided: the next segments begin BEFORE the shadow walk starts -- launched after it, the dense begin kernel crawled in
+                // the slots the persistent walk left over and the next distance walk waited for it)
+                if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a, it + 1);
+                if (!serial) {
+                    WFCHK(hipEventRecord(L.ev_vertex, s));
+                    WFCHK(hipStreamWaitEvent(s2, L.ev_vertex, 0));
+                }
+                hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(L.swalk), dim3(kWfBlock), 0, s2, a, it);
+                if (!serial) WFCHK(hipEventRecord(L.ev_shadow, s2));
+            }
+        }
+        if (bnd && !serial) WFCHK(hipStreamWaitEvent(s, L.ev_shadow, 0));  // (the last shadow walk finds an empty list; the caller's stream still waits for it)
+    }
+    WFCHK(hipGetLastError());
+    if (bnd) {
+        bool empty = true;
+        if (const int rc = list_empty(L.max_iters, &empty)) return rc;
+        if (!empty) return WF_E_NOT_DRAINED;
+    }
+    return 0;
+}
+
+// one medium layout's instantiations: {grey, chromatic} x {unguided, guided, guided + training} x {no boundaries, boundaries}
+template <bool NVDB>
+int wf_dispatch(const WfLaunch &L, bool guided, bool train, bool grey) {
+#define VSPG_WF_CASE(GREY, BNDV)                                                                                        \
+    do {                                                                                                                \
+        using M = GridMediumT<NVDB, GREY, BNDV>;                                                                        \
+        using WM = GridMediumT<NVDB, GREY>;                                                                             \
+        if (guided && train) return wf_run_pass<M, true, true, WM>(L);                                                  \
+        if (guided) return wf_run_pass<M, true, false, WM>(L);                                                          \
+        return wf_run_pass<M, false, false, WM>(L);                                                                     \
+    } while (0)
+    if (L.bnd) {
+        if (grey) VSPG_WF_CASE(true, 1);
+        VSPG_WF_CASE(false, 1);
+    }
+    if (grey) VSPG_WF_CASE(true, 0);
+    VSPG_WF_CASE(false, 0);
+#undef VSPG_WF_CASE
+}
+
+}  // namespace vspg
