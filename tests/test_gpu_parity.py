@@ -631,6 +631,77 @@ def test_full_size_guided_wave_properties(gpu_pkg):
     assert np.array_equal(a[xy[:, 1], xy[:, 0], :3].view(np.uint32), Lc.astype(np.float32).view(np.uint32)), "film != oracle paths"
 
 
+@pytest.mark.parametrize("shape", ["box", "scene"])
+def test_full_size_guided_cloud_wave_properties(gpu_pkg, shape):
+    """Config 5's shape at 1920x1080: a 256^3 density grid with NanoVDBMedium semantics (64^3 majorants) AND a temperature grid
+    (accepted under "resampling": the path never evaluates volume emission there), the reference's DEFAULT
+    options (surface RIS + volume MIS guiding, primary + secondary VSP), the field trained in the loop for four waves.  `box`: the
+    medium fills the fog box (rounds 1-3); `scene`: the reference's scene shape -- camera in vacuum, the medium behind an
+    interface-material sphere, ground, sun + sky (round 4).  With that field and that image-space buffer in place: one wave on
+    the wavefront pipeline (default) and on the per-lane kernel -- every pixel one sample, counters consistent, the two films
+    bit-identical, 20 000 random pixels equal to their replayed paths on the device AND to the oracle's paths."""
+    import time
+    P = gpu_pkg
+    W, H = 1920, 1080
+    t0 = time.time()
+    scene = P.nanovdb_box_scene(W, H, 256) if shape == "box" else P.cloud_scene(W, H, 256, nvdb=True)
+    temp = (300.0 + 1500.0 * np.clip(P.procedural_cloud_density(256, seed=11), 0, 1)).astype(np.float32)
+    scene.medium.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+    scene.medium.nvdb_le_scale, scene.medium.temperature_offset, scene.medium.temperature_scale = 2.0, 0.0, 1.0
+    prm = P.default_params()
+    prm.guide_num_training_waves = 4
+    t = P.Renderer(scene, prm, W, H)
+    assert t.kernel_name() == "k_wf_dist_walk<NanoDenseMedium,guided,train>"
+    for w in range(4):
+        t.render_wave(w, w + 1)
+        t.post_process_wave()
+    st = t.training_stats()
+    assert st["training"] == 0 and st["iteration"] == 4, st
+    fields = []
+    for vol in (0, 1):
+        nodes, regs, nn, nr = t.get_guiding_field(vol)
+        assert nn >= 3 and nr >= 2, (vol, nn, nr)
+        fields.append(P.Field(list(nodes)[:nn], list(regs)[:nr]))
+    vsp, ready = t.vsp_buffer()
+    assert ready
+    t.close()
+    rng = np.random.default_rng(9)
+    xy = np.stack([rng.integers(0, W, 20000), rng.integers(0, H, 20000)], -1).astype(np.int32)
+    si = np.full(len(xy), 4, dtype=np.int32)
+    films = {}
+    for kernel in (None, "lane"):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            r = P.Renderer(scene, prm, W, H)
+            r.set_guiding_field(fields[0], fields[1])
+            r.load_vsp_buffer(vsp)
+            r.render_wave(4, 5)
+            film = r.film()
+            cnt = r.counters()
+            assert cnt["paths"] == W * H and W * H <= cnt["segments"] <= 30 * W * H
+            assert cnt["density_queries"] > 0 and cnt["shadow_density_queries"] > 0
+            assert np.array_equal(film[..., 3], np.ones((H, W), dtype=np.float32)) and np.isfinite(film).all()
+            got = film[xy[:, 1], xy[:, 0], :3]
+            L, _ = r.trace_paths(xy, si)
+            assert np.array_equal(got.view(np.uint32), L.astype(np.float32).view(np.uint32)), r.kernel_name()
+            films[r.kernel_name()] = (film, cnt)
+            r.close()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    assert sorted(films) == ["k_render_wave<NanoDenseMedium,guided>", "k_wf_dist_walk<NanoDenseMedium,guided>"], sorted(films)
+    (a, ca), (b, cb) = films.values()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca == cb
+    c = oracle_lib.OracleRenderer(scene, prm, W, H)
+    c.set_guiding_field(fields[0], fields[1])
+    c.load_vsp_buffer(vsp)
+    Lc, _ = c.trace_paths(xy, si)
+    c.close()
+    assert np.array_equal(a[xy[:, 1], xy[:, 0], :3].view(np.uint32), Lc.astype(np.float32).view(np.uint32)), "film != oracle paths"
+    print("config-5 shape (%s): %.1f s" % (shape, time.time() - t0))
+    assert time.time() - t0 < 90
+
+
 def test_render_waves_vs_oracle(pair):
     P, g, c = pair
     for w in range(6):  # waves 1,2,4 trigger image-space VSP updates
@@ -1448,7 +1519,7 @@ def test_triangle_terrain_vs_oracle(gpu_pkg, medium):
     Lc0, _ = c.trace_paths(xy[::7], np.zeros(len(xy[::7]), dtype=np.int32))
     assert np.array_equal(L0[::7].view(np.uint32), Lc0.view(np.uint32))
     g.close()
-    if medium == "cloud":
+    if medium in ("cloud", "fog"):   # fog: the workgroup kernel's full-scene instantiation (round 4) against the per-lane kernel
         os.environ["VSPG_KERNEL"] = "lane"
         try:
             g2 = P.Renderer(scene, prm, W, H, seed=6)
@@ -1570,7 +1641,7 @@ def test_light_samplers_vs_oracle(gpu_pkg, sampler, medium):
     assert np.mean(np.all(np.abs(ig - ic) <= 1e-5 * (1 + np.abs(ic)), axis=-1)) == 1.0
     names = {g.kernel_name()}
     g.close(); c.close()
-    if medium == "cloud":   # the wavefront pipeline (default) and the per-lane kernel
+    if medium in ("cloud", "fog"):   # the wavefront pipeline (default) and the per-lane kernel   # fog: the workgroup kernel's full-scene instantiation (round 4) against the per-lane kernel
         os.environ["VSPG_KERNEL"] = "lane"
         try:
             g2 = P.Renderer(scene, prm, W, H, seed=9)
@@ -1613,7 +1684,7 @@ def test_infinite_lights_vs_oracle(gpu_pkg, medium):
     assert np.mean(np.all(np.abs(ig - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
     names = {g.kernel_name()}
     g.close()
-    if medium == "cloud":
+    if medium in ("cloud", "fog"):   # fog: the workgroup kernel's full-scene instantiation (round 4) against the per-lane kernel
         os.environ["VSPG_KERNEL"] = "lane"
         try:
             g2 = P.Renderer(scene, prm, W, H, seed=9)
@@ -1666,7 +1737,7 @@ def test_guiding_with_triangles_and_infinite_lights_vs_oracle(gpu_pkg, medium):
     assert np.mean(np.all(np.abs(ig - ic) <= 1e-4 * (1 + np.abs(ic)), axis=-1)) == 1.0
     names = {g.kernel_name()}
     g.close(); c.close()
-    if medium == "cloud":
+    if medium == "cloud":   # (guided fog over a full scene stays on the per-lane kernel)
         os.environ["VSPG_KERNEL"] = "lane"
         try:
             g2 = P.Renderer(scene, prm, W, H, seed=9)
@@ -2610,8 +2681,10 @@ def test_medium_boundaries_vs_oracle(gpu_pkg, name, options):
             on_kernel(kernel)
         finally:
             os.environ.pop("VSPG_KERNEL", None)
+    # heterogeneous media: the wavefront pipeline AND the per-lane kernel; homogeneous media: the workgroup kernel's full-scene
+    # instantiation AND the per-lane kernel (guided renders over a full scene: the per-lane kernel only)
     het = scene.medium.type != P.MEDIUM_HOMOGENEOUS
-    assert len(names) == (2 if het else 1), names   # heterogeneous media: the wavefront pipeline AND the per-lane kernel
+    assert len(names) == (2 if het or options != "defaults" else 1), names
     assert np.isfinite(Lc).all() and Lc.max() > 0
     if name.startswith("cloud-scene"):
         assert sc.max() >= 5      # paths that enter, scatter, leave and hit the ground: boundary crossings are iterations of the loop

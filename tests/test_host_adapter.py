@@ -529,3 +529,34 @@ def test_scene_file_with_medium_boundaries(host_build, gpu_pkg, tmp_path):
         os.environ.pop("VSPG_KERNEL", None)
     assert np.array_equal(sl, sc) and np.array_equal(Ll.view(np.uint32), Lc.view(np.uint32))
     c.close()
+
+
+@pytest.mark.gpu
+def test_config1_plumbing_run_512x512_at_64spp(host_build, tmp_path):
+    """BASELINE config 1 at its size -- the fog box, 512x512 @ 64 spp, through `vspg_pbrt tests/scenes/fog_box.pbrt` (the host adapter's
+    Integrator::Create / Render / PostProcessWave loop) -- against the oracle rendering the same 64 waves: every pixel 64 samples,
+    relMSE far below BASELINE's 1e-4 (float film sums on the device, double in the oracle), the image within float-sum tolerance."""
+    import oracle_lib
+    exe = os.path.join(host_build, "vspg_pbrt")
+    text = open(os.path.join(SCENES, "fog_box.pbrt")).read()
+    text = text.replace('"integer xresolution" 64', '"integer xresolution" 512').replace('"integer yresolution" 48', '"integer yresolution" 512')
+    assert '"integer xresolution" 512' in text and '"integer yresolution" 512' in text
+    sc = tmp_path / "fog512.pbrt"
+    sc.write_text(text)
+    out = tmp_path / "fog512.pfm"
+    a = subprocess.run([exe, str(sc), "--outfile", str(out), "--spp", "64"], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout + a.stderr
+    assert "paths %d " % (512 * 512 * 64) in a.stdout
+    img = read_pfm(str(out))
+    W = H = 512
+    c = oracle_lib.OracleRenderer(oracle_lib.fog_box_scene(W, H), oracle_lib.app_f_params(), W, H)
+    for w in range(64):
+        c.render_wave(w, w + 1, 16)
+        c.post_process_wave()
+    f = c.film_f64()
+    c.close()
+    assert np.all(f[..., 3] == 64)
+    ref = f[..., :3] / f[..., 3:4]
+    rel = (img - ref) ** 2 / (ref ** 2 + 1e-4)
+    print("config 1: relMSE %.3e, max abs diff %.3e" % (rel.mean(), np.abs(img - ref).max()))
+    assert rel.mean() < 1e-9 and np.mean(np.abs(img - ref) <= 1e-4 * (1 + ref)) == 1.0

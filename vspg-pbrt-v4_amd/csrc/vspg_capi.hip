@@ -709,6 +709,8 @@ constexpr int wg_pool_paths(int list_bytes_per_path, int other_bytes) {
 // 1080p wave) -- so the records the grey instantiations save are not spent on more paths there.
 template <int GREY> constexpr int kWgPoolHomogT = wg_pool_paths<PoolLayout<false, GREY>>(14, VSPG_WG_OTHER) < 512 ? wg_pool_paths<PoolLayout<false, GREY>>(14, VSPG_WG_OTHER) : 512;  // k_render_wave_wg: + s_item
 template <int GREY> constexpr int kWg2PoolHomogT = wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) < VSPG_WG_NP_CAP ? wg_pool_paths<PoolLayout<false, GREY>>(10, VSPG_WG_OTHER) : VSPG_WG_NP_CAP;
+// full scenes (triangles, spheres, infinite lights, medium boundaries): the generic record + isg.vsp_used; the stage_scene_lds copy is the same
+constexpr int kWg2PoolFull = wg_pool_paths<PoolLayout<false, 0, false, true>>(10, VSPG_WG_OTHER) < VSPG_WG_NP_CAP ? wg_pool_paths<PoolLayout<false, 0, false, true>>(10, VSPG_WG_OTHER) : VSPG_WG_NP_CAP;
 // guided: every path counts (320 -> 384 -> 416 paths: 2.14 -> 1.86 -> 1.78 ms per trained 1080p wave)
 #ifndef VSPG_WGG_NP_G0
 #define VSPG_WGG_NP_G0 wg_pool_paths<PoolLayout<true, 0>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8)
@@ -1107,7 +1109,12 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     const unsigned local_total = local_tiles * 64u;
     reset_sibling_head(work_head);
 
-    using LY = PoolLayout<GUIDED, Medium::kGrey, TRAIN>;
+    // FULL: a scene beyond rectangles and area lights -- triangles (BVH), spheres, infinite lights, non-uniform light samplers, medium
+    // boundaries (round 4: these used to fall to the per-lane kernel).  The phases are the same; a segment may end on an interface
+    // (LI_SKIP: the path goes round again without a vertex) and a path beyond the camera segment may still be at depth 0.
+    constexpr bool FULL = !Medium::kSimpleScene;
+    static_assert(!FULL || !GUIDED, "the workgroup kernel's guided vertex (vspg_guided_wg.h) is built for rectangle scenes");
+    using LY = PoolLayout<GUIDED, Medium::kGrey, TRAIN, FULL>;
     constexpr int NF = LY::COUNT;
     static_assert(!TRAIN || GUIDED, "segment recording belongs to the guided instantiations");
     __shared__ float s_pool[NF * NP];
@@ -1210,7 +1217,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
             if (base >= nA + nSpare) break;
             VSPG_PROF(PS_WG_A);
             const unsigned i = base + (unsigned)lane;
-            bool toV = false, toS = false, restart = false, freed = false;
+            bool toV = false, toS = false, restart = false, freed = false, skipped = false;
             int slot = 0;
             if (i >= nA && i < nA + nSpare) {  // a free slot no new path took this iteration: it stays free
                 slot = s_free[par][nFresh + (i - nA)];
@@ -1223,6 +1230,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                 int ch = 0, pxy = 0;
                 Vertex vx;
                 bool alive = false, valid = true;
+                int seg = LI_END;
                 if (i < nPrim) {
                     int px, py, smp;
                     if (i < nFresh) {
@@ -1261,11 +1269,12 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                         P.i(LY::PIXEL, slot) = pxy;
                         P.i(LY::SAMPLE, slot) = smp;
                         if constexpr (TRAIN) { (void)rec_bind(pxy); pc.rec.reset(); }
-                        alive = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
-                                                                          isg, pc, vx);
+                        seg = li_segment_a<Medium, GUIDED, SEG_PRIMARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
+                                                                        isg, pc, vx);
+                        alive = seg != LI_END;
                         if (alive) {
-                            pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE | (vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
-                            pool_store_vertex<GUIDED, Medium::kGrey>(P, slot, vx);
+                            pool_store_full<GUIDED, Medium::kGrey, FULL>(P, slot, st, sampler, ch, isg, FL_LIVE | (seg == LI_VERTEX && vx.volume ? (uint32_t)FL_VX_VOLUME : 0u));
+                            if (seg == LI_VERTEX) pool_store_vertex<GUIDED, Medium::kGrey>(P, slot, vx);
                             if constexpr (TRAIN) pool_store_rec<LY>(P, slot, pc.rec);
                         }
                     } else {
@@ -1273,18 +1282,24 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                     }
                 } else {
                     slot = s_listA[par][NP - 1 - (int)(i - nPrim)];
-                    const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
+                    const uint32_t fl = pool_load<GUIDED, Medium::kGrey, FULL>(P, slot, S, st, sampler, &ch, isg);
                     pxy = P.i(LY::PIXEL, slot);
                     const int px = pxy & 0xffff, py = (int)((unsigned)pxy >> 16);
                     if constexpr (TRAIN) { (void)rec_bind(pxy); pool_load_rec<LY>(P, slot, pc.rec); }
-                    alive = li_segment_a<Medium, GUIDED, SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
-                                                                        isg, pc, vx);
-                    if (alive) {
-                        pool_store_a<Medium::kGrey, GUIDED>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                    // (full scenes: a path that crossed a medium boundary on its camera segment is still at depth 0 here)
+                    seg = li_segment_a<Medium, GUIDED, FULL ? SEG_ANY : SEG_SECONDARY>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler,
+                                                                                      isg, pc, vx);
+                    alive = seg != LI_END;
+                    if (seg == LI_SKIP) {
+                        pool_store_full<GUIDED, Medium::kGrey, FULL>(P, slot, st, sampler, ch, isg, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD));
+                    } else if (alive) {
+                        pool_store_a<Medium::kGrey, GUIDED, FULL>(P, slot, st, sampler, ch, isg, vx, fl & (FL_LIVE | FL_GS_SCATTER | FL_GS_FIELD | FL_INMED));
                         if constexpr (TRAIN) pool_store_rec<LY>(P, slot, pc.rec);
                     }
                 }
-                if (alive) {
+                if (seg == LI_SKIP) {        // a medium boundary was crossed (:399-404): no vertex, the next segment starts behind it
+                    skipped = true;
+                } else if (alive) {
                     toV = vx.volume;
                     toS = !vx.volume;
                 } else if (valid) {
@@ -1301,6 +1316,7 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
             list_push_back(toS, slot, s_listB + NP - 1, &s_cnt[D_BS + par]);
             list_push(restart, slot, s_listA[nxt], &s_cnt[D_A0 + nxt]);
             list_push(freed, slot, s_free[nxt], &s_cnt[D_NFREE + nxt]);
+            if constexpr (FULL) list_push_back(skipped, slot, s_listA[nxt] + NP - 1, &s_cnt[D_A1 + nxt]);  // joins the paths the vertex phase sends on
         }
         { VSPG_PROF(PS_WG_BAR_A); __syncthreads(); }
         // the segment phase's inputs are consumed (every wave read the counts before it entered the phase)
@@ -1338,10 +1354,10 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
                         isg.vsp_used = P.f(LY::VSP, slot);  // (depth >= 1 at a vertex: the slot holds isg.vsp_used)
                     }
                 } else {
-                    const uint32_t fl = pool_load<GUIDED, Medium::kGrey>(P, slot, S, st, sampler, &ch, isg);
-                    const Vertex vx = pool_load_vertex<GUIDED, Medium::kGrey>(P, slot, fl);
+                    const uint32_t fl = pool_load<GUIDED, Medium::kGrey, FULL>(P, slot, S, st, sampler, &ch, isg);
+                    const Vertex vx = pool_load_vertex<GUIDED, Medium::kGrey, FULL>(P, slot, fl);
                     alive = li_segment_b<Medium, GUIDED, GUIDED>(S, medium, st, ch, sampler, pc, vx, glds, kWgBlock);
-                    if (alive) pool_store_full<GUIDED, Medium::kGrey>(P, slot, st, sampler, ch, isg, FL_LIVE);
+                    if (alive) pool_store_full<GUIDED, Medium::kGrey, FULL>(P, slot, st, sampler, ch, isg, FL_LIVE);
                 }
                 if (alive) {
                     cont = true;
@@ -3005,11 +3021,24 @@ static bool guided_grey_simple(const VspgRenderer *r) {
     return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS && r->medium_grey && r->surfaces_grey && r->null_zero && r->hscene.n_tris == 0 &&
            r->hscene.n_inf == 0 && r->hscene.lsamp.mode == VSPG_LIGHTSAMPLER_UNIFORM && !has_boundaries_or_spheres(r) && !getenv("VSPG_NO_GREY_GUIDED");
 }
+// a scene of rectangles and area lights only, one medium filling it: what the workgroup kernel's specialised instantiations are built for
+static bool scene_is_simple(const VspgRenderer *r) {
+    return r->hscene.n_tris == 0 && r->hscene.n_inf == 0 && r->hscene.lsamp.mode == VSPG_LIGHTSAMPLER_UNIFORM && !has_boundaries_or_spheres(r);
+}
+// Round 4: everything else over a homogeneous medium, unguided -- triangles (BVH), spheres, infinite lights, power / BVH light samplers,
+// medium boundaries -- runs the workgroup kernel's FULL-scene instantiation (k_render_wave_wg2<HomogeneousMedium>) instead of the
+// per-lane kernel; VSPG_KERNEL=lane keeps the per-lane kernel (tests compare the two).
+static bool uses_wg_full(const VspgRenderer *r) {
+    const char *kenv = kernel_env();
+    if (kenv && strcmp(kenv, "wg") != 0) return false;
+    return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS && !wants_guiding(r->prm) && !scene_is_simple(r);
+}
 static bool uses_wg_kernel(const VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID;
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (uses_wg_guided(r)) return true;
+    if (uses_wg_full(r)) return true;
     const char *kenv = kernel_env();
     const bool want_wg = kenv ? strcmp(kenv, "wg") == 0 : !grid;
     // (the TrBuffer's running mean needs a pixel's samples in order: the per-lane kernel owns a pixel per launch)
@@ -3037,7 +3066,7 @@ static bool uses_wf_pipeline(const VspgRenderer *r) {
 // VSPG_KERNEL=wg stay on it.
 static bool uses_wg2(const VspgRenderer *r) {
     if (!uses_wg_kernel(r) || r->scene.medium.type == VSPG_MEDIUM_GRID) return false;
-    if (uses_wg_guided(r)) return true;
+    if (uses_wg_guided(r) || uses_wg_full(r)) return true;
     const char *e = getenv("VSPG_WG_SCHED");
     return !(e && e[0] == '1');
 }
@@ -3081,6 +3110,7 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
         if (r->training) return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>" : "k_render_wave_wg2<HomogeneousMedium,guided,train>";
         return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>" : "k_render_wave_wg2<HomogeneousMedium,guided>";
     }
+    if (uses_wg_full(r)) return "k_render_wave_wg2<HomogeneousMedium>";
     if (uses_wg_kernel(r) && uses_wg2(r)) {
         if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg2<HomogeneousMediumT<2,true>>";
         if (r->medium_grey && r->surfaces_grey) return "k_render_wave_wg2<HomogeneousMediumT<2,false>>";
@@ -3235,6 +3265,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                                    tiles_magic, static_tiles, work_head, ws_prev, ws_out, r->counters, targs);
             else if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, true, kWg2PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided);
             else if (gwg) VSPG_LAUNCH_WG2(HomogeneousMediumSimple, true, kWg2PoolGuidedT<0>, kWgBlockGuided, kWgWavesGuided);
+            else if (uses_wg_full(r)) VSPG_LAUNCH_WG2(HomogeneousMedium, false, kWg2PoolFull, kWgBlockHomog, kWgWavesHomog);
             else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG2(HomogeneousMediumGreySceneNullZero, false, kWg2PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);
             else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGreyScene, false, kWg2PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog);
             else if (r->medium_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGrey, false, kWg2PoolHomogT<1>, kWgBlockHomog, kWgWavesHomog);

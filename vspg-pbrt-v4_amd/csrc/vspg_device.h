@@ -640,14 +640,16 @@ VDEV void stage_scene_lds(const DScene &S) {
 VDEV const DQuad &quad_at(int i) { return s_scene_quads[i]; }
 VDEV const DQuad &light_quad_at(int lightIndex) { return s_scene_quads[s_scene_light_quads[lightIndex]]; }
 
-// `quad`: rectangle index >= 0, or -2 - (triangle position in S.tris) for a triangle hit; perr = the hit point's error
-// bound (rectangles: the rectangle's constant one; triangles: gamma(7) * (|b0 p0| + |b1 p1| + |b2 p2|), shapes.h:929-930)
+// A hit is (prim, three floats): `quad` = rectangle index >= 0, -2 - (triangle position in S.tris), or kSpherePrim + sphere; `p` = the
+// re-projected point on a rectangle, the BARYCENTRICS (b0, b1, b2) of a triangle hit, the object-space point of a sphere hit.
+// The interaction point with its error bounds (surf_pi), the normal and the shading frame are pure functions of the two,
+// recomputed where they are read -- nothing else crosses a phase or kernel boundary (round 4: the per-hit error bound used to
+// travel beside the point, three more floats per vertex and per previous-vertex context).
 struct Isect {
     bool hit;
     float t;
     int quad;
     V3 p, n;
-    V3 perr;
 };
 VDEV bool is_tri(int prim) { return prim <= -2; }
 VDEV int tri_of(int prim) { return -2 - prim; }
@@ -1029,20 +1031,15 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
     const DQuad &q = quad_at(best.quad);  // per-lane index: LDS copy
     best.p = quad_point(q, bu, bv);
     best.n = ld3(q.n);
-    best.perr = ld3(q.perr);
     if (FULL && S.n_tris > 0) {  // wave-uniform: rectangles win ties (they are tested first, strictly closer)
         int tp = 0;
         TriHit h;
         if (bvh_closest(S, o, d, best.t, &tp, &h)) {
             const DTri &T = S.tris[tp];
-            const V3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
             best.hit = true;
             best.t = h.t;
             best.quad = -2 - tp;
-            best.p = p0 * h.b0 + p1 * h.b1 + p2 * h.b2;  // pHit = b0 p0 + b1 p1 + b2 p2 (shapes.h:922)
-            const V3 s = vabs(p0 * h.b0) + vabs(p1 * h.b1) + vabs(p2 * h.b2);
-            constexpr float g7 = (7 * kMachineEps) / (1 - 7 * kMachineEps);
-            best.perr = V3{g7 * s.x, g7 * s.y, g7 * s.z};
+            best.p = V3{h.b0, h.b1, h.b2};  // the barycentrics name the hit (tri_pi)
             best.n = V3{T.nx, T.ny, T.nz};
         }
     }
@@ -1056,7 +1053,6 @@ VLEAF Isect scene_intersect(const DScene &S, V3 o, V3 d, float tMax) {
                 best.t = t;
                 best.quad = kSpherePrim + i;
                 best.p = pObj;
-                best.perr = mk(0, 0, 0);
                 best.n = sphere_interaction<false>(S.spheres[i], pObj).n;
             }
         }
@@ -1087,10 +1083,20 @@ VDEV int surf_flags(const DScene &S, int prim) {
     if (is_sphere(prim)) return S.spheres[sphere_of(prim)].flags;
     return quad_at(prim).flags;
 }
-// SurfaceInteraction::pi of a hit named by (prim, p, perr)
-VDEV P3i surf_pi(const DScene &S, int prim, V3 p, V3 perr) {
-    if (is_sphere(prim)) return sphere_interaction<false>(S.spheres[sphere_of(prim)], p).pi;
-    return p3i_from_err(p, perr);
+// Triangle::InteractionFromIntersection (shapes.h:922-930): pHit = b0 p0 + b1 p1 + b2 p2, pError = gamma(7) (|b0 p0| + |b1 p1| + |b2 p2|)
+VDEV P3i tri_pi(const DTri &T, V3 b) {
+    const V3 p0 = ld3(T.p0), p1 = ld3(T.p1), p2 = ld3(T.p2);
+    const V3 p = p0 * b.x + p1 * b.y + p2 * b.z;
+    const V3 s = vabs(p0 * b.x) + vabs(p1 * b.y) + vabs(p2 * b.z);
+    constexpr float g7 = (7 * kMachineEps) / (1 - 7 * kMachineEps);
+    return p3i_from_err(p, V3{g7 * s.x, g7 * s.y, g7 * s.z});
+}
+// SurfaceInteraction::pi of the hit (prim, p)
+template <bool FULL = true>
+VDEV P3i surf_pi(const DScene &S, int prim, V3 p) {
+    if (FULL && is_sphere(prim)) return sphere_interaction<false>(S.spheres[sphere_of(prim)], p).pi;
+    if (FULL && is_tri(prim)) return tri_pi(S.tris[tri_of(prim)], p);
+    return p3i_from_err(p, ld3(quad_at(prim).perr));
 }
 // Dot(Vector3f, Normal3f) (vecmath.h:1064-1068): FMA(n.x, v.x, SumOfProducts(n.y, v.y, n.z, v.z)) (math.h:577-583)
 VDEV float dot_vn(V3 v, V3 n) {

@@ -142,9 +142,8 @@ struct LsCtx {  // LightSampleContext
 // {Point3fi(p, pError), n} is a pure function of the two; a medium vertex (quad < 0) is the exact
 // point with n = 0.  Expanded only where it is read (emitter hit by a non-specular path).
 struct PrevCtx {
-    V3 p;
+    V3 p;      // as Isect::p: point on a rectangle / barycentrics of a triangle hit / object-space point on a sphere / the medium vertex
     int quad;
-    V3 perr;  // triangle vertices only (a rectangle's bound is a constant of the rectangle)
     template <bool FULL = true>
     VDEV LsCtx expand(const DScene &S) const {
         LsCtx c;
@@ -158,7 +157,7 @@ struct PrevCtx {
             c.n = ld3(q.n);
         } else if (FULL && is_tri(quad)) {
             const DTri &T = S.tris[tri_of(quad)];
-            c.pi = p3i_from_err(p, perr);
+            c.pi = tri_pi(T, p);
             c.n = V3{T.nx, T.ny, T.nz};
         } else {
             c.pi = p3i_exact(p);
@@ -332,7 +331,7 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
             }
             if (!nonzero(T_ray)) return sp(0.f);
             if (!si.hit) break;
-            const P3i spi = surf_pi(S, si.quad, si.p, si.perr);
+            const P3i spi = surf_pi(S, si.quad, si.p);
             const V3 nf = offset_ray_origin(spi, si.n, ls.pLight.mid() - spi.mid());
             const V3 nt = offset_ray_origin(ls.pLight, ls.nLight, nf - ls.pLight.mid());
             lo = nf;
@@ -706,11 +705,10 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
 // per-lane kernels simply call one after the other.  Same operations, same order per path.
 struct Vertex {
     bool volume;
-    V3 p;      // volume: scatter position; surface: re-projected hit point (si.p)
+    V3 p;      // volume: scatter position; surface: Isect::p (point on a rectangle / barycentrics / object-space point on a sphere)
     float g;   // volume: HG asymmetry
-    int quad;  // surface: rectangle index, or -2 - triangle (Isect::quad)
+    int quad;  // surface: rectangle index, -2 - triangle, kSpherePrim + sphere (Isect::quad)
     float t;   // surface: tHit (only the guided build needs it, for p = ray.o + tHit * ray.d)
-    V3 perr;   // surface: error bound of p (Isect::perr)
 };
 
 // the part of the path-loop iteration between distance sampling and the vertex, for a path that reached
@@ -768,7 +766,7 @@ VDEV int li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, 
         const int sfl = surf_flags(S, si.quad);
         if (sfl & SURF_INTERFACE) {
             // isect.SkipIntersection(&ray, si->tHit) (interaction.cpp:91-97): ray = SpawnRay(ray.d), medium = GetMedium(ray.d)
-            st.ro = offset_ray_origin(surf_pi(S, si.quad, si.p, si.perr), si.n, st.rd);
+            st.ro = offset_ray_origin(surf_pi(S, si.quad, si.p), si.n, st.rd);
             st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(sfl, si.n, st.rd, st.in_medium);
             return LI_SKIP;
         }
@@ -802,7 +800,6 @@ VDEV int li_segment_a(const DScene &S, const Medium &medium, const float *vsp_bu
     vx.g = 0;
     vx.quad = si.quad;
     vx.t = si.t;
-    vx.perr = si.perr;
     constexpr bool kRec = std::remove_reference<decltype(pc.rec)>::type::kActive;
     Spec tw = sp(1.f);  // transmittanceWeight (:317)
     // :318 `if (ray.medium && !std::isinf(tMax))`: a ray that escapes the scene is not sampled (rounds 1-3 did: wrong).  Without
@@ -875,7 +872,6 @@ VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, V
     } else {
         intr.medium = FULL ? st.in_medium : true;
         intr.sflags = FULL && has_bnd<BND>(S) ? surf_flags(S, vx.quad) : 0;
-        si.perr = vx.perr;
         if (FULL && is_sphere(vx.quad)) {  // vx.p = the object-space hit point (kSpherePrim)
             const DSphere &sph = S.spheres[sphere_of(vx.quad)];
             const SphereSurf ss = sphere_interaction(sph, vx.p);
@@ -886,12 +882,12 @@ VDEV void vertex_setup(const DScene &S, const PathState &st, const Vertex &vx, V
             const DTri &T = S.tris[tri_of(vx.quad)];
             si.n = V3{T.nx, T.ny, T.nz};
             bsdf = bsdf_make_tri(T);
-            intr.pi = p3i_from_err(si.p, vx.perr);
+            intr.pi = tri_pi(T, vx.p);
         } else {
             const DQuad &q = quad_at(vx.quad);
             si.n = ld3(q.n);
             bsdf = bsdf_make<GREY_KD>(q);
-            intr.pi = p3i_from_err(si.p, vx.perr);
+            intr.pi = p3i_from_err(si.p, ld3(q.perr));
         }
         intr.is_surface = true;
         intr.n = si.n;
@@ -935,7 +931,6 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
         VSPG_PROF(PS_SURF_SAMPLE);
         st.prevCtx.p = si.p;  // :487 LightSampleContext(isect)
         st.prevCtx.quad = vx.quad;
-        st.prevCtx.perr = vx.perr;
         (void)sampler.get1d();  // u (unused by DiffuseBxDF)
         float u20 = sampler.get1d(), u21 = sampler.get1d();
         // BSDF::Sample_f / DiffuseBxDF::Sample_f (bsdf.h:58-78, bxdfs.h:47-58)
@@ -1113,7 +1108,6 @@ VDEV bool li_vertex_guided_impl(const DScene &S, const Medium &medium, PathState
     } else {
         st.prevCtx.p = si.p;
         st.prevCtx.quad = si.quad;
-        st.prevCtx.perr = si.perr;
     }
     const V3 wo = -st.rd;
     float usel = 0;  // surface: the MIS selector u; volume: u0 doubles as selector
@@ -1336,7 +1330,6 @@ VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, P
     st.r_l = sp(1.f);
     st.prevCtx.p = mk(0, 0, 0);
     st.prevCtx.quad = -1;
-    st.prevCtx.perr = mk(0, 0, 0);
     st.depth = 0;
     st.specularBounce = false;
     st.anyNonSpecularBounces = false;

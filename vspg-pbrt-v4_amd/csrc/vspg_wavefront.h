@@ -96,8 +96,7 @@ enum {
     WF_SRL = 100,     // 3  ... r_l
     WF_SRU = 104,     // 3  ... r_u
     WF_STMAJ = 108,   // 3  ... residual T_maj
-    WF_PCE = 112,     // 3  previous light-sample context: error bound (triangle vertices)
-    WF_VXE = 116,     // 3  vertex: error bound of the hit point
+    // (112..119: round 3 kept the per-hit error bounds of triangle hits here; a hit is (prim, three floats) now, Isect)
     // guided pipeline: the whole vertex (cache init, NEE set-up, Russian roulette, new direction) runs in k_wf_seg_end
     WF_BNEE = 120,    // 3  the throughput the NEE saw (the vertex code has since moved st.beta on) | +3: WF_GSVSP
     WF_GSVSP = 123,   // 1  VolumeScatterProbability(ray.d) of the vertex for the next segment (gs.vsp_next)
@@ -328,7 +327,6 @@ VDEV void wf_store_path(const WfPool &P, unsigned slot, const PathState &st, con
     }
     P.set3(WF_PCP, slot, st.prevCtx.p);
     P.i(WF_PCQ, slot) = st.prevCtx.quad;
-    if (is_tri(st.prevCtx.quad)) P.set3(WF_PCE, slot, st.prevCtx.perr);
     P.store_rng(WF_RNG, slot, sampler.rng);
     P.u(WF_FLAGS, slot) = pool_pack_flags(st, ch, isg, extra_flags | (st.in_medium ? (uint32_t)WFL_INMED : 0u));
     P.f(WF_RRC, slot) = st.rr_correction;
@@ -349,7 +347,6 @@ VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sample
     }
     st.prevCtx.p = P.v3(WF_PCP, slot);
     st.prevCtx.quad = P.i(WF_PCQ, slot);
-    st.prevCtx.perr = is_tri(st.prevCtx.quad) ? P.v3(WF_PCE, slot) : mk(0, 0, 0);
     P.load_rng(WF_RNG, slot, sampler.rng);
     const uint32_t fl = P.u(WF_FLAGS, slot);
     st.depth = (int)(fl & FL_DEPTH_MASK);
@@ -497,7 +494,7 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Medium &medium, int ch, 
                 n_med++;
             }
             if (!si.hit) break;
-            const P3i spi = surf_pi(S, si.quad, si.p, si.perr);
+            const P3i spi = surf_pi(S, si.quad, si.p);
             const V3 nf = offset_ray_origin(spi, si.n, ls.pLight.mid() - spi.mid());
             const V3 nt = offset_ray_origin(ls.pLight, ls.nLight, nf - ls.pLight.mid());
             lo = nf;
@@ -699,7 +696,6 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
     P.set3(WF_VXP, slot, si.p);
     P.i(WF_VXG, slot) = si.quad;
     P.f(WF_VXT, slot) = si.t;
-    if (is_tri(si.quad)) P.set3(WF_VXE, slot, si.perr);
     // :318 `if (ray.medium && !std::isinf(tMax))`: no distance sampling for a ray outside the medium or one that escapes the scene
     const bool in_medium = !has_bnd<Medium::kBnd>(S) ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
     if (in_medium && si.hit) {
@@ -1212,21 +1208,16 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k
                 if (is_tri(si.quad)) {
                     const DTri &T = S.tris[tri_of(si.quad)];
                     si.n = V3{T.nx, T.ny, T.nz};
-                    si.perr = P.v3(WF_VXE, slot);
                 } else if (is_sphere(si.quad)) {  // si.p = the object-space hit point (kSpherePrim)
                     si.n = sphere_interaction<false>(S.spheres[sphere_of(si.quad)], si.p).n;
-                    si.perr = mk(0, 0, 0);
                 } else {
-                    const DQuad &q = quad_at(si.quad);
-                    si.n = ld3(q.n);
-                    si.perr = ld3(q.perr);
+                    si.n = ld3(quad_at(si.quad).n);
                 }
                 vx.volume = false;
                 vx.p = si.p;
                 vx.g = 0;
                 vx.quad = si.quad;
                 vx.t = si.t;
-                vx.perr = si.perr;
                 if (!(fl & WFL_NODIST)) {
                     // ---- sample_distance after the traversal (:721-802) ---------------------------------------------
                     const bool guide = (fl & WFL_GUIDE) != 0;

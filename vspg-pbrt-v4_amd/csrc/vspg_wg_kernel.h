@@ -27,7 +27,7 @@ namespace vspg {
 // room, so more paths fit the LDS a workgroup may use (the pool's size is what the phases' list lengths, i.e. the wavefronts'
 // occupancy with work, hang on: 320 -> 384 paths took the guided kernel from 2.14 to 1.86 ms per wave).
 //   unguided: 33 dwords generic, 29 with a grey medium, 27 with grey surfaces too;  guided: 37 / 33 / 31.
-template <bool GUIDED, int GREY, bool TRAIN = false>
+template <bool GUIDED, int GREY, bool TRAIN = false, bool FULL = false>
 struct PoolLayout {
     static constexpr int RO = 0;                                  // 3
     static constexpr int RD = 3;                                  // 3
@@ -53,7 +53,10 @@ struct PoolLayout {
     // (appended LAST: every other field sits at the same offset with and without it, so the helpers below need not know)
     // training launches (a18): the recorder's state between phases, packed (pool_store_rec); the records themselves go straight to HBM
     static constexpr int REC = GUIDED ? VXP + 3 : GS;             // 1 (pool_store_rec)
-    static constexpr int COUNT = REC + (TRAIN ? 1 : 0);
+    // full scenes (round 4: triangles, spheres, infinite lights, medium boundaries on the workgroup kernel): a path may cross medium
+    // boundaries at depth 0, so isg.vsp_used has to be kept BESIDE the pixel's primary VSP (the VSP slot), not instead of it
+    static constexpr int VSPU = REC + (TRAIN ? 1 : 0);            // 1 (FULL only)
+    static constexpr int COUNT = VSPU + (FULL ? 1 : 0);
 };
 enum {
     FL_DEPTH_MASK = 0xff,
@@ -68,6 +71,7 @@ enum {
     FL_RESTART = 1 << 17,       // slot's pixel has another sample to start
     FL_VX_VOLUME = 1 << 18,
     FL_DONE = 1 << 19,          // finished path parked for the film flush: PF_L = final radiance, PF_VSP = isg.vsp_used
+    FL_INMED = 1 << 24,         // full scenes: ray.medium != nullptr (same bit as the pipeline's WFL_INMED)
 };
 
 struct Pool {
@@ -99,6 +103,7 @@ VDEV void pool_load_rec(const Pool &P, int slot, PathRecorder &rec) {
 }
 VDEV void pool_store_rec(const Pool &, int, const NullRecorder &) {}
 VDEV void pool_load_rec(const Pool &, int, NullRecorder &) {}
+VDEV bool fl_in_medium(uint32_t fl) { return (fl & FL_INMED) != 0; }
 VDEV uint32_t pool_pack_flags(const PathState &st, int ch, const IsgSample &isg, uint32_t keep_flags) {
     uint32_t fl = keep_flags | (uint32_t)(st.depth & FL_DEPTH_MASK) | ((uint32_t)ch << FL_CH_SHIFT);
     if (st.specularBounce) fl |= FL_SPECULAR;
@@ -147,10 +152,14 @@ VDEV void pool_store_ru_rl(const Pool &P, int slot, const PathState &st) {
         P.sets(LY::RL, slot, st.r_l);
     }
 }
-template <bool GUIDED, int GREY = 0>
+template <bool GUIDED, int GREY = 0, bool FULL = false>
 VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                           uint32_t keep_flags) {
     using LY = PoolLayout<GUIDED, GREY>;
+    if constexpr (FULL) {
+        keep_flags = (keep_flags & ~(uint32_t)FL_INMED) | (st.in_medium ? (uint32_t)FL_INMED : 0u);
+        P.f(PoolLayout<GUIDED, GREY, false, true>::VSPU, slot) = isg.vsp_used;
+    }
     P.set3(LY::RO, slot, st.ro);
     P.set3(LY::RD, slot, st.rd);
     P.sets(LY::L, slot, st.L);
@@ -177,10 +186,11 @@ VDEV void pool_store_vertex(const Pool &P, int slot, const Vertex &vx) {
 }
 // after li_segment_a: only what that half changes (L, beta, r_u, r_l, sampler, depth / ISG flags) plus
 // the vertex it stopped at; ray, previous context, rr_correction and guiding state are untouched
-template <int GREY = 0, bool GUIDED = false>
+template <int GREY = 0, bool GUIDED = false, bool FULL = false>
 VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampler &sampler, int ch, const IsgSample &isg,
                        const Vertex &vx, uint32_t keep_flags) {
     using LY = PoolLayout<GUIDED, GREY>;
+    if constexpr (FULL) P.f(PoolLayout<GUIDED, GREY, false, true>::VSPU, slot) = isg.vsp_used;  // (in_medium does not change inside a segment that reaches a vertex)
     P.sets(LY::L, slot, st.L);
     pool_store_beta<LY, GREY>(P, slot, st.beta);
     pool_store_ru_rl<LY, GREY>(P, slot, st);
@@ -191,7 +201,7 @@ VDEV void pool_store_a(const Pool &P, int slot, const PathState &st, const Sampl
     P.f(LY::VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
     pool_store_vertex<GUIDED, GREY>(P, slot, vx);
 }
-template <bool GUIDED = false, int GREY = 0>
+template <bool GUIDED = false, int GREY = 0, bool FULL = false>
 VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
     using LY = PoolLayout<GUIDED, GREY>;
     Vertex vx;
@@ -199,13 +209,12 @@ VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
     vx.p = P.v3(LY::VXP, slot);
     vx.g = vx.volume ? P.f(LY::VXG, slot) : 0.f;
     vx.quad = vx.volume ? -1 : P.i(LY::VXG, slot);
-    __builtin_assume(vx.quad >= -1);
+    if constexpr (!FULL) __builtin_assume(vx.quad >= -1);
     vx.t = P.f(LY::VXT, slot);
-    vx.perr = vx.volume ? mk(0, 0, 0) : ld3(quad_at(vx.quad).perr);
     return vx;
 }
 
-template <bool GUIDED, int GREY = 0>
+template <bool GUIDED, int GREY = 0, bool FULL = false>
 VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st, Sampler &sampler, int *ch, IsgSample &isg) {
     using LY = PoolLayout<GUIDED, GREY>;
     st.ro = P.v3(LY::RO, slot);
@@ -221,8 +230,7 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     }
     st.prevCtx.p = P.v3(LY::PCP, slot);
     st.prevCtx.quad = P.i(LY::PCQ, slot);
-    st.prevCtx.perr = mk(0, 0, 0);  // (triangle scenes run the per-lane / wavefront kernels)
-    __builtin_assume(st.prevCtx.quad >= -1);
+    if constexpr (!FULL) __builtin_assume(st.prevCtx.quad >= -1);
     sampler.rng.state = (uint64_t)P.u(LY::RNG + 0, slot) | ((uint64_t)P.u(LY::RNG + 1, slot) << 32);
     sampler.rng.inc = (uint64_t)P.u(LY::RNG + 2, slot) | ((uint64_t)P.u(LY::RNG + 3, slot) << 32);
     const uint32_t fl = P.u(LY::FLAGS, slot);
@@ -238,6 +246,10 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     const float v = P.f(LY::VSP, slot);
     st.vsp0 = v;
     isg.vsp_used = st.depth == 0 ? -1.f : v;
+    if constexpr (FULL) {  // (PoolLayout::VSPU: appended behind every other field, whatever TRAIN says -- unguided full-scene pools do not train)
+        isg.vsp_used = P.f(PoolLayout<GUIDED, GREY, false, true>::VSPU, slot);
+        st.in_medium = (fl_in_medium(P.u(LY::FLAGS, slot)));
+    }
     if constexpr (GUIDED) {
         st.gs.vsp_next = P.f(LY::GS, slot);
         st.pce = 0.f;        // (guided RR is served by the per-lane kernels)
