@@ -2922,6 +2922,13 @@ static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
         if (selectSurface) {
             *c->beta = s_mul(*c->beta, s_scale(rc.sel_num, resamplingFactorScalar));
             *c->r_u = s_mul(*c->r_u, rc.sel_den);
+            /* SUBSTITUTION (:766, and :792 below): the reference tests IsInf(beta.y(lambda)) / IsInf(r_u.y(lambda)) -- the CIE-Y weighted
+             * mean of the three channels, weights Y(lambda_i) / pdf(lambda_i) at the SAMPLED wavelengths (spectrum.cpp:252-256; they
+             * need atanh / cosh of the wavelength sample and the tabulated CIE curve).  This restatement tests "some channel is
+             * infinite".  The two agree unless a weight is exactly 0 (Y(lambda) vanishes at the ends of the visible range: 0 * inf is
+             * NaN, not Inf), infinities of both signs meet (NaN), or the finite weighted sum itself overflows: in those corners the
+             * reference carries the path on with a non-finite throughput that the radiance clean-up (integrators.cpp:308-318)
+             * blacks out anyway, this side ends the path here -- same pixel value, zero.  Noted in DESIGN.md section 6. */
             if (s_has_nan(*c->beta) || s_has_nan(*c->r_u) || s_has_inf(*c->beta) || s_has_inf(*c->r_u)) {
                 c->terminated = 1;
                 return;

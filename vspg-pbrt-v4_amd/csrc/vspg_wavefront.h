@@ -637,6 +637,12 @@ constexpr int kWfRefill = 16;
 #ifndef VSPG_WF_VERTEX_WAVES
 #define VSPG_WF_VERTEX_WAVES 3   // launch bound of the unguided vertex kernel (waves per SIMD)
 #endif
+#ifndef VSPG_WF_VERTEX_WAVES_GUIDED
+#define VSPG_WF_VERTEX_WAVES_GUIDED 2   // ... of the guided one (its product mixture lives in registers).  Measured at 3 (168 VGPRs, round 4, same
+#endif                                  // box): cloud-guided 9.6 -> 10.9 ms per wave -- the spills cost more than the third wavefront hides
+#ifndef VSPG_WF_VERTEX_WAVES_BND
+#define VSPG_WF_VERTEX_WAVES_BND 2      // ... of the unguided one with the medium-boundary code compiled in (the light ray's segment chain, the
+#endif                                  // interface skip): at 3 it spills ~300 B per lane; 2 measured 6.19 against 6.50 ms per cloud-scene wave
 #ifndef VSPG_WF_CLAIM
 #define VSPG_WF_CLAIM 128
 #endif
@@ -1145,7 +1151,7 @@ VDEV int wf_vertex(const WfArgs &a, const DScene &S, const Medium &medium, unsig
 // direction sampling, the next segment's VSP -- with the product mixture in registers (GStoreReg; ~240 VGPRs: 2 waves per SIMD)
 // TRAIN (a18, with GUIDED): the pass records path segments (the NEE's result reaches its record when it is added to L)
 template <class Medium, bool GUIDED = false, bool TRAIN = false>
-__global__ __launch_bounds__(kWfBlock, GUIDED ? 2 : VSPG_WF_VERTEX_WAVES) void k_wf_vertex(WfArgs a, int it) {
+__global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (Medium::kBnd == 1 ? VSPG_WF_VERTEX_WAVES_BND : VSPG_WF_VERTEX_WAVES)) void k_wf_vertex(WfArgs a, int it) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
     const WfPool &P = a.P;
