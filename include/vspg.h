@@ -146,12 +146,14 @@ typedef struct VspgMedium {
     int32_t has_transform;
     float render_from_medium[16];
     float medium_from_render[16];
-    /* VSPG_MEDIUM_NANOVDB only -- the temperature grid of NanoVDBMedium (media.h:724-735; config 5 "explosion"):
-     * Le(p) = nvdb_le_scale * Blackbody((T(p) - temperature_offset) * temperature_scale).  The path adds volume emission in
-     * the DELTA-TRACKING callback only (guidedvolpathvspgintegrator.cpp:895-906); a heterogeneous medium under the default
-     * "vspsamplingmethod" "resampling" never evaluates it, so with that method the grid is accepted and
-     * has no effect on the result (it is not even copied).  With "nds" the emission would be sampled -- blackbody emission
-     * at RGB-mode wavelengths (App. C #13) is outside this build's scope: VSPG_ESCOPE.  HOST pointer, same layout as density. */
+    /* Temperature grid of an emissive GridMedium (media.h:333-341; "temperature", media.cpp:276-302) or NanoVDBMedium (media.h:724-735;
+     * config 5 "explosion"): as many samples as `density`, same layout -- for NanoVDB the same index bounding box and index-to-world
+     * map (the .nvdb reader checks).  Where the scaled temperature T' = (T(p) - temperature_offset) * temperature_scale exceeds 100,
+     *   Le(p) = scale * BlackbodySpectrum(T').Sample(lambda),  scale = nvdb_le_scale (NanoVDB) / the le_scale grid's value (GridMedium)
+     * at the path's three sampled wavelengths, which the RGB build stores as R, G, B.  The path adds volume
+     * emission in the DELTA-TRACKING callback only (guidedvolpathvspgintegrator.cpp:895-906): under "vspsamplingmethod" "nds";
+     * a heterogeneous medium under the default "resampling" never evaluates it and the grid has no effect on
+     * the result.  A GridMedium with both Le and temperature is VSPG_EINVAL (media.cpp:307-308).  HOST pointer; NULL = none. */
     const float *temperature;
     float nvdb_le_scale, temperature_offset, temperature_scale;
 } VspgMedium;
@@ -501,6 +503,10 @@ int vspg_libm_log1m_batch(VspgRenderer *r, int n, const float *x, float *out, vo
 /* out[i] = powf(x[i], y[i]) as the kernels evaluate it (the std::pow of the NDS+ bias,
  * src/pbrt/cpu/guidedvolpathvspgintegrator.cpp:937): bit-identical to glibc 2.35's powf. */
 int vspg_libm_powf_batch(VspgRenderer *r, int n, const float *x, const float *y, float *out, void *stream);
+/* out6[6 i ..] = {lambda_0..2, Le_0..2}: the wavelengths of SampledWavelengths::SampleVisible(u[i]) (util/spectrum.h:369-386; the
+ * host's atanhf, bit for bit) and BlackbodySpectrum(T[i]).Sample(lambda) (:568-588) as the kernels evaluate a temperature grid's
+ * emission (media.h:333-341, :724-735). */
+int vspg_blackbody_batch(VspgRenderer *r, int n, const float *u, const float *T, float *out6, void *stream);
 
 #ifdef __cplusplus
 }

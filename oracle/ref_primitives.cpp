@@ -495,6 +495,49 @@ int main() {
             }
             printf("]");
         }
+        printf("],\n");
+    }
+    // ---- volume emission of a temperature grid in the RGB build.  The wavelengths are the reference's own
+    //      SampledWavelengths::SampleVisible (spectrum.h:369-386 over SampleVisibleWavelengths, util/sampling.h:169-171, i.e. the host's
+    //      atanhf).  Blackbody() itself does not link here (its CHECK(!IsNaN(Le)) pulls LogFatal -> util/log.cpp -> print.cpp ->
+    //      double-conversion, absent): as for the sphere, the generator evaluates the STATEMENT SEQUENCE of Blackbody() (spectrum.h:83-94)
+    //      and of BlackbodySpectrum's constructor and Sample() (:568-588) with the reference's own FastExp and Pow<5> (util/math.h), as
+    //      NanoVDBMedium::Le reaches them (media.h:724-735) ----
+    {
+        auto blackbody = [](Float lambda, Float T) -> Float {
+            if (T <= 0)
+                return 0;
+            const Float c = 299792458.f;
+            const Float h = 6.62606957e-34f;
+            const Float kb = 1.3806488e-23f;
+            Float l = lambda * 1e-9f;
+            Float Le = (2 * h * c * c) / (Pow<5>(l) * (FastExp((h * c) / (l * kb * T)) - 1));
+            return Le;
+        };
+        printf("\"blackbody\": [");
+        bool first = true;
+        for (int i = 0; i < 192; ++i) {
+            Float u = U();
+            if (i == 0) u = 0.f;
+            if (i == 1) u = 0x1.fffffep-1f;
+            if (i == 2) u = 1.f / 3.f;
+            if (i == 3) u = 2.f / 3.f;
+            Float T = 100.f + U() * U() * 11900.f;  // the Le() threshold is 100 K; explosion-like grids reach a few thousand
+            if (i % 16 == 5) T = 100.0001f + U();
+            if (i % 16 == 9) T = 20000.f + 60000.f * U();
+            SampledWavelengths swl = SampledWavelengths::SampleVisible(u);
+            Float lambdaMax = 2.8977721e-3f / T;
+            Float normalizationFactor = 1 / blackbody(lambdaMax * 1e9f, T);
+            SampledSpectrum Le;
+            for (int c = 0; c < NSpectrumSamples; ++c)
+                Le[c] = blackbody(swl[c], T) * normalizationFactor;
+            sep(first);
+            printf("[");
+            pf(u); printf(","); pf(T);
+            for (int c = 0; c < 3; ++c) { printf(","); pf(swl[c]); }
+            for (int c = 0; c < 3; ++c) { printf(","); pf(Le[c]); }
+            printf("]");
+        }
         printf("]\n");
     }
     printf("}\n");

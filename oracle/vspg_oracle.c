@@ -235,6 +235,45 @@ float oracle_fast_exp(float x) {
     return b2f(bits);
 }
 static inline spec s_fast_exp(spec a) { spec r; for (int i = 0; i < 3; ++i) r.c[i] = oracle_fast_exp(a.c[i]); return r; }
+
+/* SampledWavelengths::SampleVisible in the RGB build (util/spectrum.h:369-386): three wavelengths from the sample lu that also
+ * picks the hero channel, lambda_i = SampleVisibleWavelengths(up_i) = 538 - 138.888889 atanh(0.85691062 - 1.82750197 up_i)
+ * (util/sampling.h:169-171; std::atanh(float) is the host's atanhf).  Only volume emission of a temperature grid reads them. */
+static void sample_visible_wavelengths(float u, float lambda[3]) {
+    for (int i = 0; i < 3; ++i) {
+        float up = u + (float)i / 3;
+        if (up > 1) up -= 1;
+        lambda[i] = 538 - 138.888889f * atanhf(0.85691062f - 1.82750197f * up);
+    }
+}
+/* Blackbody(lambda, T) (util/spectrum.h:83-94): Planck's law with FastExp and Pow<5> (util/math.h:294-309: ((l l)(l l)) l) */
+static float blackbody(float lambda, float T) {
+    if (T <= 0) return 0;
+    const float c = 299792458.f;
+    const float h = 6.62606957e-34f;
+    const float kb = 1.3806488e-23f;
+    float l = lambda * 1e-9f;
+    float l2 = l * l * 1.f;
+    float l5 = l2 * l2 * l;
+    float Le = (2 * h * c * c) / (l5 * (oracle_fast_exp((h * c) / (l * kb * T)) - 1));
+    return Le;
+}
+/* BlackbodySpectrum(T).Sample(lambda) (util/spectrum.h:568-588): normalised by the value at Wien's peak; in the RGB build the three
+ * sampled wavelengths' values ARE the R, G, B channels */
+static spec blackbody_sample(float T, const float lambda[3]) {
+    float lambdaMax = 2.8977721e-3f / T;
+    float normalizationFactor = 1 / blackbody(lambdaMax * 1e9f, T);
+    spec s;
+    for (int i = 0; i < 3; ++i) s.c[i] = blackbody(lambda[i], T) * normalizationFactor;
+    return s;
+}
+/* test API: [lambda0..2, Le0..2] of SampleVisible(u) and BlackbodySpectrum(T).Sample (golden "blackbody") */
+void oracle_blackbody(float u, float T, float *out6) {
+    float lambda[3];
+    sample_visible_wavelengths(u, lambda);
+    spec s = blackbody_sample(T, lambda);
+    for (int i = 0; i < 3; ++i) { out6[i] = lambda[i]; out6[3 + i] = s.c[i]; }
+}
 /* util/sampling.h:222-225 -- float log */
 float oracle_sample_exponential(float u, float a) { return -logf(1 - u) / a; }
 /* util/float.h:164-193 */
@@ -750,6 +789,11 @@ void oracle_sphere_intersect(const VspgSphere *sp, const float o[3], const float
 typedef struct {
     spec sigma_a, sigma_s, Le;
     float g; /* HG phase */
+    /* temperature grids: MediumProperties::Le is BlackbodySpectrum(temp).Sample(lambda) times a scale (media.h:333-341, :724-735).
+     * SamplePoint here has no wavelengths at hand, so it records the two factors and medium_Le() below finishes the product where
+     * the path reads mp.Le (the delta-tracking callback, the only reader: guidedvolpathvspgintegrator.cpp:895-906).
+     * bb_temp = 0: Le above is the value. */
+    float bb_temp, bb_scale;
 } medium_props_t; /* MediumProperties, media.h:77-82 */
 
 typedef struct lightsampler lightsampler_t; /* "light samplers" section below */
@@ -779,6 +823,7 @@ struct OracleRenderer {
     float *density;
     float *majorant;
     float *le_scale; /* emissive GridMedium: the LeScale grid (copied), NULL = not emissive */
+    float *temperature; /* temperature grid of an emissive GridMedium / NanoVDBMedium (copied), NULL = none */
     int le_dim[3];
     /* film: RGBFilm::Pixel (film.h:314-318) */
     double *film; /* W*H*4 */
@@ -1244,13 +1289,15 @@ static majiter_t medium_sample_ray(const OracleRenderer *r, v3 o, v3 d, float tM
  * nanovdb::SampleFromVoxels<Tree, 1, false>: ijk = floor(x), uvw = x - ijk, the 8 corner values (background 0
  * outside the index bounding box), lerp(a, b, w) = a + w (b - a) along z, then y, then x.  NanoVDB itself is
  * absent from the reference tree (submodule not vendored): PARITY UNPINNED for this fetch. */
-static float nvdb_value(const OracleRenderer *r, int i, int j, int k) {
+static float nvdb_value_of(const OracleRenderer *r, const float *values, int i, int j, int k) {
     const VspgMedium *m = &r->scene.medium;
     int x = i - m->index_min[0], y = j - m->index_min[1], z = k - m->index_min[2];
     if (x < 0 || y < 0 || z < 0 || x >= m->nx || y >= m->ny || z >= m->nz) return 0.f;
-    return r->density[((size_t)z * m->ny + y) * m->nx + x];
+    return values[((size_t)z * m->ny + y) * m->nx + x];
 }
-static float nvdb_sample(const OracleRenderer *r, v3 p) {
+static float nvdb_value(const OracleRenderer *r, int i, int j, int k) { return nvdb_value_of(r, r->density, i, j, k); }
+/* values: the density grid, or the temperature grid (same index bounding box and index-to-world map: include/vspg.h) */
+static float nvdb_sample_of(const OracleRenderer *r, const float *values, v3 p) {
     const VspgMedium *m = &r->scene.medium;
     float inv[3] = {1.0f / m->voxel_size[0], 1.0f / m->voxel_size[1], 1.0f / m->voxel_size[2]};
     float x = (p.x - m->grid_origin[0]) * inv[0], y = (p.y - m->grid_origin[1]) * inv[1], z = (p.z - m->grid_origin[2]) * inv[2];
@@ -1258,14 +1305,17 @@ static float nvdb_sample(const OracleRenderer *r, v3 p) {
     int i = (int)fx, j = (int)fy, k = (int)fz;
     float u = x - fx, v = y - fy, w = z - fz;
 #define NLERP(a, b, t) ((a) + (t) * ((b) - (a)))
-    float a00 = NLERP(nvdb_value(r, i, j, k), nvdb_value(r, i, j, k + 1), w);
-    float a01 = NLERP(nvdb_value(r, i, j + 1, k), nvdb_value(r, i, j + 1, k + 1), w);
-    float a10 = NLERP(nvdb_value(r, i + 1, j, k), nvdb_value(r, i + 1, j, k + 1), w);
-    float a11 = NLERP(nvdb_value(r, i + 1, j + 1, k), nvdb_value(r, i + 1, j + 1, k + 1), w);
+#define NV(a, b, c) nvdb_value_of(r, values, a, b, c)
+    float a00 = NLERP(NV(i, j, k), NV(i, j, k + 1), w);
+    float a01 = NLERP(NV(i, j + 1, k), NV(i, j + 1, k + 1), w);
+    float a10 = NLERP(NV(i + 1, j, k), NV(i + 1, j, k + 1), w);
+    float a11 = NLERP(NV(i + 1, j + 1, k), NV(i + 1, j + 1, k + 1), w);
     float b0 = NLERP(a00, a01, v), b1 = NLERP(a10, a11, v);
     return NLERP(b0, b1, u);
+#undef NV
 #undef NLERP
 }
+static float nvdb_sample(const OracleRenderer *r, v3 p) { return nvdb_sample_of(r, r->density, p); }
 /* NanoVDBMedium ctor, "Initialize majorantGrid" (media.cpp:600-671) */
 static void build_majorant_grid_nvdb(OracleRenderer *r) {
     const VspgMedium *m = &r->scene.medium;
@@ -1304,6 +1354,7 @@ static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
     mp.sigma_s = s_from(m->sigma_s);
     mp.Le = s_from(m->Le);
     mp.g = m->g;
+    mp.bb_temp = 0.f; mp.bb_scale = 0.f;
     if (medium_is_grid_like(m->type)) {
         /* p = renderFromMedium.ApplyInverse(p) (media.h:322 / :693); identity: p unchanged */
         if (m->has_transform) p = apply_inverse_point(m->medium_from_render, p);
@@ -1312,19 +1363,36 @@ static medium_props_t medium_sample_point(const OracleRenderer *r, v3 p) {
         if (m->type == VSPG_MEDIUM_NANOVDB) { /* media.h:686-703 */
             d = nvdb_sample(r, p);
             d += m->density_offset;
+            if (r->temperature) { /* NanoVDBMedium::Le (media.h:724-735), whatever IsEmissive() says (SamplePoint does not ask) */
+                float temp = nvdb_sample_of(r, r->temperature, p);
+                temp = (temp - m->temperature_offset) * m->temperature_scale;
+                if (temp > 100.f) { mp.bb_temp = temp; mp.bb_scale = m->nvdb_le_scale; }
+            }
         } else {
             v3 po = bounds_offset(m, p);
             d = grid_lookup(r, po);
             if (r->le_scale) { /* isEmissive (media.h:326-342): Le = scale * Le_spec.Sample(lambda) where the scale is positive */
                 float scale = sgrid_lookup(r->le_scale, r->le_dim[0], r->le_dim[1], r->le_dim[2], po);
-                if (scale > 0) Le = s_scale(s_from(m->Le), scale); /* SampledSpectrum operator*(Float, s): s * a */
+                if (scale > 0) {
+                    if (r->temperature) { /* media.h:333-341 */
+                        float temp = sgrid_lookup(r->temperature, m->nx, m->ny, m->nz, po);
+                        temp = (temp - m->temperature_offset) * m->temperature_scale;
+                        if (temp > 100.f) { mp.bb_temp = temp; mp.bb_scale = scale; }
+                    } else
+                        Le = s_scale(s_from(m->Le), scale); /* SampledSpectrum operator*(Float, s): s * a */
+                }
             }
         }
         mp.sigma_a = s_scale(mp.sigma_a, d);
         mp.sigma_s = s_scale(mp.sigma_s, d);
-        mp.Le = Le; /* temperature grids (blackbody emission) are outside this build's scope */
+        mp.Le = Le;
     }
     return mp;
+}
+/* mp.Le as the reference's SamplePoint(p, lambda) would have returned it (see medium_props_t) */
+static spec medium_Le(const medium_props_t *mp, const float lambda[3]) {
+    if (mp->bb_temp > 0) return s_scale(blackbody_sample(mp->bb_temp, lambda), mp->bb_scale);
+    return mp->Le;
 }
 static int medium_is_homogeneous(const OracleRenderer *r) { return r->scene.medium.type == VSPG_MEDIUM_HOMOGENEOUS; }
 
@@ -2585,6 +2653,7 @@ static void rec_add_scatter_data(pathrec_t *rec, int volume, spec weight, v3 wi,
 typedef struct {
     const OracleRenderer *r;
     int ch;
+    const float *lambda;         /* the path's SampledWavelengths (temperature-grid emission only) */
     int px, py;                  /* pPixel */
     int guideRR;                 /* :276-285 */
     spec pixelContributionEstimate;
@@ -2749,12 +2818,13 @@ static int delta_cb(void *vctx, v3 p, const medium_props_t *mp, spec sigma_maj, 
         c->terminated = 1;
         return 0;
     }
-    if (*c->depth < r->prm.maxdepth && s_nonzero(mp->Le)) {
+    const spec mpLe = medium_Le(mp, c->lambda);
+    if (*c->depth < r->prm.maxdepth && s_nonzero(mpLe)) {
         float pdf = sigma_maj.c[ch] * T_maj.c[ch];
         spec betap = s_divf(s_mul(*c->beta, T_maj), pdf);
         spec r_e = s_divf(s_mul(s_mul(*c->r_u, sigma_maj), T_maj), pdf);
         if (s_nonzero(r_e))
-            *c->L = s_add(*c->L, s_divf(s_mul(s_mul(betap, mp->sigma_a), mp->Le), s_avg(r_e)));
+            *c->L = s_add(*c->L, s_divf(s_mul(s_mul(betap, mp->sigma_a), mpLe), s_avg(r_e)));
     }
     spec sigma_t = s_add(mp->sigma_s, mp->sigma_a);
     float pScatter = sigma_t.c[ch] / sigma_maj.c[ch];
@@ -2985,7 +3055,7 @@ static void sample_distance(sd_ctx_t *c, int px, int py, float tMax) {
 /* ------------------------------------------------------------------------------------ */
 /* a16: Li (guidedvolpathvspgintegrator.cpp:262-635)                                      */
 /* ------------------------------------------------------------------------------------ */
-static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sampler_t *sampler,
+static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, const float lambda[3], sampler_t *sampler,
                isg_sample_t *isg, path_counters_t *pc, pathrec_t *rec) {
     float rr_correction = 1.0f;
     spec L = S1(0.f), beta = S1(1.f), r_u = S1(1.f), r_l = S1(1.f);
@@ -3024,7 +3094,7 @@ static spec Li(const OracleRenderer *r, int px, int py, v3 ro, v3 rd, int ch, sa
             rng_set_sequence2(&rng, hash0, hash1);
             sd_ctx_t c;
             memset(&c, 0, sizeof c);
-            c.r = r; c.ch = ch; c.px = px; c.py = py; c.sampler = sampler; c.rng = &rng;
+            c.r = r; c.ch = ch; c.lambda = lambda; c.px = px; c.py = py; c.sampler = sampler; c.rng = &rng;
             c.guideRR = guideRR; c.pixelContributionEstimate = pixelContributionEstimate;
             c.ray_o = &ro; c.ray_d = &rd; c.depth = &depth;
             c.L = &L; c.beta = &beta; c.r_u = &r_u; c.r_l = &r_l;
@@ -3548,6 +3618,8 @@ static spec evaluate_pixel_sample(const OracleRenderer *r, int px, int py, int s
     float lu = sampler_get1d(&sampler);
     int ch = (int)floorf(lu * 3); /* SampledWavelengths::SampleVisible, spectrum.h:380-384 */
     if (ch > 2) ch = 2;
+    float lambda[3];
+    sample_visible_wavelengths(lu, lambda);
     /* GetCameraSample (samplers.h:796-815) with BoxFilter radius 0.5 (filters.h:67-69) */
     float f0 = sampler_get1d(&sampler), f1 = sampler_get1d(&sampler);
     float fpx = (1 - f0) * -0.5f + f0 * 0.5f;
@@ -3559,7 +3631,7 @@ static spec evaluate_pixel_sample(const OracleRenderer *r, int px, int py, int s
     v3 o, d;
     camera_ray(&r->scene.camera, pfx, pfy, &o, &d);
     if (rec) { rec->n = 0; rec->cur = -1; rec->cap = rec_capacity(r->prm.maxdepth); }
-    spec L = Li(r, px, py, o, d, ch, &sampler, isg, pc, rec);
+    spec L = Li(r, px, py, o, d, ch, lambda, &sampler, isg, pc, rec);
     /* L = cameraRay->weight * L with weight 1; NaN / Inf -> black (:308-318) */
     if (s_has_nan(L)) L = S1(0.f);
     else if (s_has_inf(L)) L = S1(0.f);
@@ -3738,12 +3810,12 @@ static int validate_params(const VspgScene *scene, const VspgIntegratorParams *p
             return VSPG_EINVAL;
         if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) {
             if (m->type == VSPG_MEDIUM_NANOVDB) return VSPG_EINVAL; /* NanoVDBMedium emits through its temperature grid only */
-            if (m->le_scale && (m->le_nx <= 0 || m->le_ny <= 0 || m->le_nz <= 0)) return VSPG_EINVAL;
+            if (m->temperature) return VSPG_EINVAL; /* "Both \"Le\" and \"temperature\" values were provided." (media.cpp:307-308) */
         }
-        /* temperature grid (media.h:724-735): volume emission is sampled by the delta-tracking routine only (:895-906) -- never
-         * evaluated under "resampling" (accepted, no effect), outside scope under "nds" */
-        if (m->type == VSPG_MEDIUM_NANOVDB && m->temperature && m->nvdb_le_scale > 0 && p->vspsamplingmethod != VSPG_VSP_RESAMPLING)
-            return VSPG_ESCOPE;
+        if (m->type == VSPG_MEDIUM_GRID && (m->temperature || m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0))
+            if (m->le_scale && (m->le_nx <= 0 || m->le_ny <= 0 || m->le_nz <= 0)) return VSPG_EINVAL;
+        /* temperature grids (media.h:333-341, :724-735): volume emission is sampled by the delta-tracking routine only (:895-906) --
+         * under "resampling" a heterogeneous medium never evaluates it */
     }
     return 0;
 }
@@ -3854,7 +3926,13 @@ int oracle_renderer_create(const VspgScene *scene, const VspgIntegratorParams *p
         r->majorant = (float *)calloc((size_t)MR * MR * MR, sizeof(float));
         if (m->type == VSPG_MEDIUM_NANOVDB) build_majorant_grid_nvdb(r);
         else build_majorant_grid(r);
-        if (m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0) { /* isEmissive = Le_spec.MaxValue() > 0 (media.cpp:250) */
+        if (m->temperature) { /* same number of samples as the density grid (media.cpp:283-288; the .nvdb reader checks the bounding boxes) */
+            r->temperature = (float *)malloc(n * sizeof(float));
+            memcpy(r->temperature, m->temperature, n * sizeof(float));
+            r->scene.medium.temperature = r->temperature;
+        }
+        /* isEmissive = temperatureGrid ? true : Le_spec.MaxValue() > 0 (media.cpp:261) */
+        if (m->type == VSPG_MEDIUM_GRID && (m->temperature || m->Le[0] != 0 || m->Le[1] != 0 || m->Le[2] != 0)) {
             if (m->le_scale) {
                 size_t ln = (size_t)m->le_nx * m->le_ny * m->le_nz;
                 r->le_scale = (float *)malloc(ln * sizeof(float));
@@ -3897,7 +3975,7 @@ void oracle_renderer_destroy(OracleRenderer *r) {
     if (!r) return;
     free_field(r, 0); free_field(r, 1);
     free(r->samples);
-    free(r->trbuf); free(r->tr_spp); free(r->le_scale); free(r->contrib);
+    free(r->trbuf); free(r->tr_spp); free(r->le_scale); free(r->temperature); free(r->contrib);
     free(r->film); free(r->isg_stats); free(r->vsp); free(r->density); free(r->majorant); free(r->tris); free(r->lsamp); free(r);
 }
 void oracle_film_read(OracleRenderer *r, float *rgbw) {

@@ -73,7 +73,7 @@ def libm_shim():
         subprocess.check_call(["g++"] + flags + ["-o", out, src, "-lm"])
     lib = C.CDLL(out)
     fp = C.POINTER(C.c_float)
-    for n in ("model_logf", "model_sinf", "model_cosf", "libm_logf", "libm_sinf", "libm_cosf"):
+    for n in ("model_logf", "model_sinf", "model_cosf", "libm_logf", "libm_sinf", "libm_cosf", "model_atanhf", "libm_atanhf", "model_log1pf", "libm_log1pf"):
         getattr(lib, n).argtypes = [C.c_int, fp, fp]
     dp = C.POINTER(C.c_double)
     for n in ("model_log", "libm_log"):

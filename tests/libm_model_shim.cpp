@@ -12,6 +12,11 @@ void model_cosf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y
 void libm_logf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = logf(x[i]); }
 void libm_sinf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = sinf(x[i]); }
 void libm_cosf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = cosf(x[i]); }
+// atanhf / log1pf (the wavelengths of SampledWavelengths::SampleVisible: blackbody emission of temperature grids)
+void model_atanhf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::atanhf_host_exact(x[i]); }
+void model_log1pf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::log1pf_host_exact(x[i]); }
+void libm_atanhf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = atanhf(x[i]); }
+void libm_log1pf(int n, const float *x, float *y) { for (int i = 0; i < n; ++i) y[i] = log1pf(x[i]); }
 // double log (the -std::log(1.0 - x) of the optical-depth-space sampling)
 void model_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = vspg_libm::log_host_exact(x[i]); }
 void libm_log(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = log(x[i]); }

@@ -2437,7 +2437,8 @@ def test_error_conventions_on_device(gpu_pkg):
     prm.maxdepth = -1
     assert create(scene, prm) in (P.VSPG_EINVAL, 0)  # (negative depth is the reference's "no bounce" -- not an error there)
     # NanoVDBMedium emits through its temperature grid only (config 5 "explosion"): the path samples volume emission in the
-    # delta-tracking routine, never under "resampling" -- accepted there (and without effect), refused under "nds"
+    # delta-tracking routine, never under "resampling" -- accepted there (and without effect); under "nds": blackbody emission
+    # (test_temperature_grid_emission_vs_oracle)
     from scenes import nvdb_scene, cloud_density
     dens = cloud_density(8)
     s2 = nvdb_scene(dens, (8, 8, 8), 0.5, 1.0, W=W, H=H)
@@ -2449,7 +2450,14 @@ def test_error_conventions_on_device(gpu_pkg):
     s2.medium.nvdb_le_scale, s2.medium.temperature_offset, s2.medium.temperature_scale = 1.0, 0.0, 1.0
     nds = P.app_f_params()
     nds.vspsamplingmethod = P.VSP_NDS
-    assert create(s2, nds) == P.VSPG_ESCOPE and b"temperature" in lib.vspg_last_error()
+    assert create(s2, nds) == 0
+    from scenes import grid_scene
+    s2g = grid_scene(dens, (8, 8, 8), 0.5, 1.0, W=W, H=H)
+    s2g.medium.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+    s2g.medium.temperature_scale = 1.0
+    assert create(s2g, nds) == 0
+    s2g.medium.Le[:] = (1, 1, 1)     # 'Both "Le" and "temperature" values were provided.' (media.cpp:307-308)
+    assert create(s2g, nds) == P.VSPG_EINVAL and b"temperature" in lib.vspg_last_error()
     hot = P.Renderer(s2, P.app_f_params(), W, H)
     s2.medium.temperature = None
     cold = P.Renderer(s2, P.app_f_params(), W, H)
@@ -2690,3 +2698,160 @@ def test_medium_boundaries_vs_oracle(gpu_pkg, name, options):
         assert sc.max() >= 5      # paths that enter, scatter, leave and hit the ground: boundary crossings are iterations of the loop
     c.close()
     print(name, options, sorted(names))
+
+
+# ---------------------------------------------------------------------------------------------
+# blackbody emission of temperature grids under "nds" (media.h:333-341, :724-735; util/spectrum.h:83-94, :568-588)
+# ---------------------------------------------------------------------------------------------
+def test_device_blackbody_vs_reference_goldens_and_host_atanhf(gpu_pkg, libm_shim):
+    """The kernels' SampleVisible wavelengths (the HOST's atanhf through csrc/vspg_libm.h) and BlackbodySpectrum(T).Sample: bit for bit
+    the golden vectors generated from the reference's headers, the oracle on 30 000 random (u, T), and the running libm's atanhf on
+    4e6 wavelength samples."""
+    import json
+    P = gpu_pkg
+    from scenes import cloud_density, grid_scene
+    g = P.Renderer(grid_scene(cloud_density(8), (8, 8, 8), 0.5, 1.0, W=8, H=8), P.app_f_params(), 8, 8)
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "primitives.json")))["blackbody"]
+    rows = np.array([[float.fromhex(t) for t in row] for row in G], dtype=np.float32)
+    out = g.blackbody_batch(rows[:, 0], rows[:, 1])
+    assert np.array_equal(out.view(np.uint32), rows[:, 2:8].view(np.uint32))
+    rng = np.random.default_rng(17)
+    n = 30000
+    u = rng.random(n, dtype=np.float32)
+    T = (100.0 + rng.random(n) ** 2 * 20000.0).astype(np.float32)
+    dev = g.blackbody_batch(u, T)
+    lib = oracle_lib.load()
+    o6 = (C.c_float * 6)()
+    ref = np.empty((n, 6), dtype=np.float32)
+    for i in range(n):
+        lib.oracle_blackbody(float(u[i]), float(T[i]), o6)
+        ref[i] = o6[:]
+    assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+    n = 4_000_000
+    u = rng.random(n, dtype=np.float32)
+    lam = g.blackbody_batch(u, np.full(n, 3000.0, dtype=np.float32))[:, :3]
+    fp = C.POINTER(C.c_float)
+    for k in range(3):
+        up = u + np.float32(k) / np.float32(3)
+        up = np.where(up > 1, up - np.float32(1), up).astype(np.float32)
+        x = (np.float32(0.85691062) - np.float32(1.82750197) * up).astype(np.float32)
+        a = np.empty_like(x)
+        libm_shim.libm_atanhf(n, x.ctypes.data_as(fp), a.ctypes.data_as(fp))
+        want = (np.float32(538) - np.float32(138.888889) * a).astype(np.float32)
+        assert np.array_equal(lam[:, k].view(np.uint32), want.view(np.uint32)), k
+    g.close()
+
+
+def _temperature_scene(P, kind, W, H):
+    import scenes
+    n = 24
+    dens = scenes.cloud_density(n)
+    if kind == "grid":
+        scene = scenes.grid_scene(dens, (n, n, n), (0.3, 0.35, 0.4), (1.6, 1.4, 1.2), g=0.4, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)
+    elif kind == "grid-lescale":
+        scene = scenes.grid_scene(dens, (n, n, n), 0.4, 1.5, g=0.3, bmin=(-0.8, -0.8, -0.5), bmax=(0.8, 0.7, 0.9), W=W, H=H)   # grey coefficients
+        rng = np.random.default_rng(31)
+        le = np.clip(rng.random((6, 5, 7)).astype(np.float32) * 2 - 0.6, 0, None).astype(np.float32)  # some cells emit nothing
+        scene.medium.le_scale = le.ctypes.data_as(C.POINTER(C.c_float))
+        scene.medium.le_nz, scene.medium.le_ny, scene.medium.le_nx = le.shape
+        scene._le_keepalive = le
+    elif kind == "nvdb":
+        scene = scenes.nvdb_scene(dens, (n, n, n), (0.25, 0.3, 0.35), (3.0, 2.6, 2.2), g=0.5, index_min=(-3, 2, 0), voxel=(0.066, 0.0625, 0.058),
+                                  origin=(-0.6, -0.93, -0.5), density_offset=0.02, majorant_scale=1.25, W=W, H=H)
+    else:                                       # the explosion in the shape of the reference's scenes: camera in vacuum, interface sphere
+        scene = P.cloud_scene(W, H, n, nvdb=True)
+        dens = None
+    m = scene.medium
+    nvox = m.nx * m.ny * m.nz
+    rng = np.random.default_rng(9)
+    base = dens if dens is not None and dens.size == nvox else rng.random(nvox).astype(np.float32)
+    temp = (150.0 + 2600.0 * np.clip(base + 0.3 * rng.random(nvox).astype(np.float32), 0, 1.4)).astype(np.float32)   # some of it below the threshold
+    m.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+    # (the cloud scene's albedo is 0.99 and a sun lights it: a strong LeScale, or its emission disappears in the total)
+    m.temperature_offset, m.temperature_scale, m.nvdb_le_scale = 120.0, 1.3, (200.0 if kind == "nvdb-cloud-scene" else 0.6)
+    scene._temp_keepalive = temp
+    return scene
+
+
+@pytest.mark.parametrize("kind", ["grid", "grid-lescale", "nvdb", "nvdb-cloud-scene"])
+@pytest.mark.parametrize("options", ["app-f", "defaults"])
+def test_temperature_grid_emission_vs_oracle(gpu_pkg, kind, options):
+    """"vspsamplingmethod" "nds" over a medium with a temperature grid: the delta-tracking callback adds
+    sigma_a * scale * BlackbodySpectrum(T').Sample(lambda) at every tentative collision (:895-906).  Replayed paths bit-identical to the
+    oracle's, three post-processed waves' film and the counters equal to the oracle's -- on the wavefront pipeline and on the per-lane
+    kernel; the emission is really there (the same render without the grid is darker); under "resampling" the grid changes nothing."""
+    P = gpu_pkg
+    W, H = 64, 48
+    scene = _temperature_scene(P, kind, W, H)
+    prm = P.app_f_params() if options == "app-f" else P.default_params()
+    prm.vspsamplingmethod = P.VSP_NDS
+    import scenes
+    field = scenes.light_field(P, n=2, bmin=(-3, -3, -3), bmax=(3, 3, 3), light=(0.0, 2.9, 0.0)) if options == "defaults" else None
+    rng = np.random.default_rng(12)
+    n = 8000
+    xy = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 256, n).astype(np.int32)
+    c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=5)
+    if field:
+        c.set_guiding_field(field, field)
+    Lc, sc = c.trace_paths(xy, si)
+    assert np.isfinite(Lc).all() and Lc.max() > 0
+    names, films = set(), []
+    def on_kernel():
+        g = P.Renderer(scene, prm, W, H, seed=5)
+        if field:
+            g.set_guiding_field(field, field)
+        kn = g.kernel_name()
+        names.add(kn)
+        Lg, sg = g.trace_paths(xy, si)
+        same = np.all(Lg.view(np.uint32) == Lc.view(np.uint32), axis=1)
+        assert np.array_equal(sg, sc), (kn, np.flatnonzero(sg != sc)[:5])
+        assert same.all(), (kn, np.flatnonzero(~same)[:5], Lg[~same][:3], Lc[~same][:3])
+        cc = oracle_lib.OracleRenderer(scene, prm, W, H, seed=5)
+        if field:
+            cc.set_guiding_field(field, field)
+        for w in range(3):
+            g.render_wave(w, w + 1)
+            g.post_process_wave()
+            cc.render_wave(w, w + 1)
+            cc.post_process_wave()
+        fg, fc = g.film(), cc.film()
+        assert np.array_equal(fg[..., 3], fc[..., 3])
+        assert np.allclose(fg[..., :3], fc[..., :3], rtol=2e-6, atol=1e-7), kn
+        assert g.counters() == cc.counters(), kn
+        films.append(fg)
+        g.close(); cc.close()
+    for kernel in (None, "lane"):
+        if kernel:
+            os.environ["VSPG_KERNEL"] = kernel
+        try:
+            on_kernel()
+        finally:
+            os.environ.pop("VSPG_KERNEL", None)
+    assert len(names) == 2, names
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))   # pipeline == per-lane kernel, bit for bit
+    # without the temperature grid: darker
+    keep = scene.medium.temperature
+    scene.medium.temperature = None
+    g0 = P.Renderer(scene, prm, W, H, seed=5)
+    if field:
+        g0.set_guiding_field(field, field)
+    for w in range(3):
+        g0.render_wave(w, w + 1)
+        g0.post_process_wave()
+    f0 = g0.film()
+    g0.close()
+    gain = (films[0][..., :3].sum() - f0[..., :3].sum()) / max(f0[..., :3].sum(), 1e-6)
+    print(kind, options, sorted(names), "emission adds %.1f %%" % (100 * gain))
+    assert gain > 0.02
+    # "resampling": the grid is accepted and has no effect (SURVEY App. C #12)
+    rs = P.app_f_params() if options == "app-f" else P.default_params()
+    cold = P.Renderer(scene, rs, W, H, seed=5)
+    scene.medium.temperature = keep
+    hot = P.Renderer(scene, rs, W, H, seed=5)
+    for r in (hot, cold):
+        if field:
+            r.set_guiding_field(field, field)
+        r.render_wave(0, 2)
+    assert np.array_equal(hot.film().view(np.uint32), cold.film().view(np.uint32))
+    hot.close(); cold.close(); c.close()

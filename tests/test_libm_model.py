@@ -140,3 +140,24 @@ def test_sincos_exhaustive(shim, fn):
     tiny = (2.0 ** np.random.default_rng(3).uniform(-126, -30, 2_000_000)).astype(np.float32)
     check(shim, fn, tiny)
     check(shim, fn, -tiny)
+
+
+def test_atanhf_log1pf_equal_host_libm(shim):
+    """std::atanh(float) of SampleVisibleWavelengths (util/sampling.h:169-171) -- the wavelengths a temperature grid's blackbody
+    emission is evaluated at -- and the log1pf under it.  The arguments the path produces are 0.85691062 - 1.82750197 * up with
+    up in [0, 1]: that whole interval is covered float by float (~2.5e7 arguments), the rest of (-1, 1) sampled."""
+    lo, hi = np.float32(0.85691062) - np.float32(1.82750197), np.float32(0.85691062)
+    for a, b in ((np.float32(2.0 ** -30), hi), (np.float32(2.0 ** -30), -lo)):
+        b0, b1 = int(np.float32(a).view(np.uint32)), int(np.float32(b).view(np.uint32))
+        step = 1 << 23
+        for start in range(b0, b1 + 1, step):
+            x = np.arange(start, min(start + step, b1 + 1), dtype=np.uint32).view(np.float32)
+            check(shim, "atanhf", x if a > 0 and b == hi else -x)
+    rng = np.random.default_rng(5)
+    u = rng.random(4_000_000, dtype=np.float32)
+    check(shim, "atanhf", np.float32(0.85691062) - np.float32(1.82750197) * u)
+    check(shim, "atanhf", rng.uniform(-1, 1, 2_000_000).astype(np.float32))
+    check(shim, "atanhf", np.array([0.0, -0.0, 0.5, -0.5, 2.0 ** -28, 2.0 ** -29, float.fromhex('0x1.fffffep-1'), float.fromhex('-0x1.fffffep-1')], dtype=np.float32))
+    check(shim, "log1pf", rng.uniform(-0.999, 40.0, 4_000_000).astype(np.float32))
+    check(shim, "log1pf", (10.0 ** rng.uniform(-12, 6, 2_000_000)).astype(np.float32))
+    check(shim, "log1pf", -(10.0 ** rng.uniform(-12, -0.001, 2_000_000)).astype(np.float32))

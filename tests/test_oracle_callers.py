@@ -79,10 +79,11 @@ def test_distant_light_on_a_floor_is_lambert():
 
 
 def test_uniform_sky_furnace_through_a_cloud():
-    """UniformInfiniteLight reached by escaping rays (:353-374) through a purely scattering cloud (albedo 1), nothing else in the
-    scene: radiance 1 from every direction is a fixed point of the transport equation, so the estimator's mean is 1 -- this
-    exercises the resampling routine with tMax = infinity, the placed-medium transform, Russian roulette and the escaped-ray
-    weights together.  (Paths cut at maxdepth lose their energy: maxdepth is far above the mean path length.)"""
+    """UniformInfiniteLight reached by escaping rays (:353-374) through a purely scattering cloud (albedo 1) inside an
+    interface-material sphere, nothing else in the scene: radiance 1 from every direction is a fixed point of the transport
+    equation, so the estimator's mean is 1 -- this exercises the resampling routine, the placed-medium transform, the boundary
+    crossings (:399-404; a ray that escapes is not sampled, :318, so an open cloud would never be traversed), Russian roulette
+    and the escaped-ray weights together.  (Paths cut at maxdepth lose their energy: maxdepth is far above the mean path length.)"""
     P = load_package()
     W, H = 32, 24
     dens = cloud_density(16)
@@ -90,6 +91,9 @@ def test_uniform_sky_furnace_through_a_cloud():
     for i in range(P.VSPG_MAX_QUADS):
         scene.quads[i] = type(scene.quads[0])()
     scene.n_quads = 0
+    from scenes import add_sphere
+    add_sphere(scene, (0.0, 0.0, 0.1), 1.45, material=P.MATERIAL_INTERFACE, iface=P.IFACE_INSIDE)
+    scene.camera_outside_medium = 0      # the eye (0, 0, -0.95) is inside the sphere: one crossing on the way out
     M = np.eye(4, dtype=np.float32)
     a = 0.4
     M[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ np.diag([0.9, 1.1, 0.8])
@@ -104,7 +108,7 @@ def test_uniform_sky_furnace_through_a_cloud():
     Lc, sc = c.trace_paths(pix, si)
     c.close()
     assert np.isfinite(Lc).all()
-    assert sc.max() < 200 and sc.mean() > 1.3     # the cloud is really traversed, no path reaches the cut
+    assert sc.max() < 200 and sc.mean() > 2.3     # the cloud is really traversed (a crossing + the scatterings), no path reaches the cut
     m = Lc.mean(axis=0)
     se = Lc.std(axis=0) / np.sqrt(len(Lc))
     print("furnace mean", m, "+-", se)

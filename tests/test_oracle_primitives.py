@@ -308,3 +308,20 @@ def test_sphere_against_the_reference_types(oracle, pkg):
         assert h2.value == 1 and all(same(a, b) for a, b in zip(pobj, v[43:46])) and all(same(a, b) for a, b in zip(so, v[58:61]))
         assert side.value == int(v[61])
     assert hits >= 90
+
+
+def test_blackbody_emission_against_the_reference(oracle, pkg):
+    """Volume emission of a temperature grid in the RGB build: the three wavelengths are the REFERENCE's SampledWavelengths::SampleVisible
+    (util/spectrum.h:369-386 over SampleVisibleWavelengths, util/sampling.h:169-171 -- the host's atanhf), the emitted values are the
+    statement sequence of Blackbody() / BlackbodySpectrum (spectrum.h:83-94, :568-588) evaluated by the golden generator with the
+    reference's own FastExp and Pow<5> (Blackbody() itself does not link there: its CHECK pulls LogFatal).  Bit for bit, from the
+    100 K threshold of Le() to 80000 K, and at lu = 0, 1 - ulp, 1/3, 2/3 where `up` wraps."""
+    out = (C.c_float * 6)()
+    lit = 0
+    for row in G["blackbody"]:
+        v = [fh(t) for t in row]
+        oracle.oracle_blackbody(v[0], v[1], out)
+        for a, b in zip(out, v[2:8]):
+            assert same(a, b), row
+        lit += any(x > 0 for x in v[5:8])
+    assert len(G["blackbody"]) == 192 and lit > 120

@@ -195,6 +195,7 @@ SYMBOLS = [
     ("vspg_libm_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
     ("vspg_libm_log1m_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _vp]),
     ("vspg_libm_powf_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
+    ("vspg_blackbody_batch", C.c_int, [_vp, C.c_int, _P(C.c_float), _P(C.c_float), _P(C.c_float), _vp]),
     ("vspg_renderer_get_tr_buffer", C.c_int, [_vp, _P(C.c_float), _P(C.c_int32), _vp]),
     ("vspg_renderer_set_tr_buffer", C.c_int, [_vp, _P(C.c_float), _vp]),
     ("vspg_renderer_set_guiding_field", C.c_int, [_vp, _P(VspgField), _P(VspgField), _vp]),
@@ -550,6 +551,17 @@ class Renderer:
         out = np.empty_like(x)
         fp = _P(C.c_float)
         _check(self.lib, self.lib.vspg_libm_powf_batch(self.h, x.shape[0], x.ctypes.data_as(fp), y.ctypes.data_as(fp),
+                                                      out.ctypes.data_as(fp), _vp(0)))
+        return out
+
+    def blackbody_batch(self, u, T):
+        """[n, 6]: SampleVisible(u)'s three wavelengths and BlackbodySpectrum(T).Sample at them, as the kernels evaluate them."""
+        import numpy as np
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        out = np.empty((u.shape[0], 6), dtype=np.float32)
+        fp = _P(C.c_float)
+        _check(self.lib, self.lib.vspg_blackbody_batch(self.h, u.shape[0], u.ctypes.data_as(fp), T.ctypes.data_as(fp),
                                                       out.ctypes.data_as(fp), _vp(0)))
         return out
 

@@ -1529,6 +1529,13 @@ __global__ __launch_bounds__(kBlock) void k_libm_powf(int n, const float *__rest
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] = vspg_libm::powf_host_exact(x[i], y[i]);
 }
+__global__ __launch_bounds__(kBlock) void k_blackbody(int n, const float *__restrict__ u, const float *__restrict__ T, float *__restrict__ out) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const Spec s = blackbody_sample(T[i], u[i]);
+    for (int k = 0; k < 3; ++k) out[6 * i + k] = sample_visible_wavelength(u[i], k);
+    out[6 * i + 3] = s.r; out[6 * i + 4] = s.g; out[6 * i + 5] = s.b;
+}
 __global__ __launch_bounds__(kBlock) void k_libm_log1m(int n, const float *__restrict__ x, float *__restrict__ out) {
     int i = blockIdx.x * kBlock + threadIdx.x;
     vspg_libm::stage_log_tab_lds();
@@ -1674,6 +1681,7 @@ struct VspgRenderer {
     float4 *octets = nullptr;
     size_t n_bricks = 0;
     float *le_scale = nullptr;  // emissive GridMedium: LeScale grid
+    float *temperature = nullptr;  // temperature grid (raw samples)
     float *majorant = nullptr;  // 16^3 majorant grid
     DTri *tris = nullptr;          // triangle soup in BVH leaf order + the BVH (depth-first, skip links)
     DBvhNode *bvh = nullptr;
@@ -2434,10 +2442,6 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         if ((long long)m.nx * m.ny * m.nz > (1ll << 31)) return fail(VSPG_EINVAL, "density grid too large");
         for (int k = 0; k < 3; ++k)
             if (!(m.bounds_max[k] > m.bounds_min[k])) return fail(VSPG_EINVAL, "grid medium bounds must have positive extent");
-        // IsEmissive (media.h:680): temperatureFloatGrid && LeScale > 0.  Volume emission is sampled by the delta-tracking routine only
-        if (m.type == VSPG_MEDIUM_NANOVDB && m.temperature && m.nvdb_le_scale > 0 && p->vspsamplingmethod != VSPG_VSP_RESAMPLING)
-            return fail(VSPG_ESCOPE, "NanoVDBMedium temperature grid with \"vspsamplingmethod\" \"nds\": blackbody volume emission is outside this build's scope "
-                                     "(under \"resampling\" the path never evaluates it and the grid is accepted)");
         if (m.has_transform) {
             const float *a = m.render_from_medium, *b = m.medium_from_render;
             if (a[12] != 0 || a[13] != 0 || a[14] != 0 || a[15] != 1 || b[12] != 0 || b[13] != 0 || b[14] != 0 || b[15] != 1)
@@ -2448,9 +2452,13 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
         if (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0) {
             if (m.type == VSPG_MEDIUM_NANOVDB)
                 return fail(VSPG_EINVAL, "NanoVDBMedium has no Le spectrum: it emits through its temperature grid (VspgMedium.temperature)");
+            if (m.temperature) return fail(VSPG_EINVAL, "Both \"Le\" and \"temperature\" values were provided.");  // media.cpp:307-308
+        }
+        // temperature grids (media.h:333-341, :724-735): blackbody volume emission, sampled by the delta-tracking routine only
+        // (guidedvolpathvspgintegrator.cpp:895-906) -- under "resampling" a heterogeneous medium never evaluates it
+        if (m.type == VSPG_MEDIUM_GRID && (m.temperature || m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0))
             if (m.le_scale && (m.le_nx <= 0 || m.le_ny <= 0 || m.le_nz <= 0 || (long long)m.le_nx * m.le_ny * m.le_nz > (1ll << 31)))
                 return fail(VSPG_EINVAL, "emissive grid medium: bad Lescale grid size");
-        }
     } else if (scene->medium.type != VSPG_MEDIUM_NONE && scene->medium.type != VSPG_MEDIUM_HOMOGENEOUS)
         return fail(VSPG_EINVAL, "unknown medium type");
     if (scene->n_triangles < 0 || scene->n_triangles > (1 << 27)) return fail(VSPG_EINVAL, "n_triangles out of range");
@@ -2553,6 +2561,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
     L.ev_shadow = r->wf_ev_shadow;
     L.bnd = bnd;
     L.nds = r->prm.vspsamplingmethod != VSPG_VSP_RESAMPLING;
+    L.emit = r->hscene.temperature != nullptr;
     L.maxdepth = r->prm.maxdepth;
     L.base_iters = base_iters;
     L.max_iters = max_iters;
@@ -2725,7 +2734,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     {
         auto same = [](const float *v) { return std::memcmp(&v[0], &v[1], 4) == 0 && std::memcmp(&v[1], &v[2], 4) == 0; };
         const VspgMedium &m = r->scene.medium;
-        r->medium_grey = m.type != VSPG_MEDIUM_NONE && same(m.sigma_a) && same(m.sigma_s) && same(m.Le) && !getenv("VSPG_NO_GREY");
+        r->medium_grey = m.type != VSPG_MEDIUM_NONE && same(m.sigma_a) && same(m.sigma_s) && same(m.Le) && !m.temperature && !getenv("VSPG_NO_GREY");
         r->surfaces_grey = !getenv("VSPG_NO_GREY_KD");
         r->null_zero = m.type == VSPG_MEDIUM_HOMOGENEOUS && !getenv("VSPG_NO_NULLZERO");
         for (int k = 0; k < 3; ++k) r->null_zero = r->null_zero && !(r->hscene.sigma_n_raw[k] > 0) && r->hscene.sigma_n_raw[k] == r->hscene.sigma_n_raw[k];
@@ -2797,7 +2806,16 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
         }
         r->scene.medium.density = nullptr;  // the host array belongs to the caller
         const VspgMedium &m = scene->medium;
-        if (m.type == VSPG_MEDIUM_GRID && (m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0)) {  // isEmissive (media.cpp:250)
+        if (m.temperature) {  // as many samples as the density grid (media.cpp:283-288; the .nvdb reader checks the bounding boxes)
+            CK(hipMalloc(&r->temperature, n * sizeof(float)));
+            CK(hipMemcpy(r->temperature, m.temperature, n * sizeof(float), hipMemcpyHostToDevice));
+            r->hscene.temperature = r->temperature;
+            r->hscene.temperature_offset = m.temperature_offset;
+            r->hscene.temperature_scale = m.temperature_scale;
+            r->hscene.nvdb_le_scale = m.nvdb_le_scale;
+        }
+        // isEmissive = temperatureGrid ? true : Le_spec.MaxValue() > 0 (media.cpp:261)
+        if (m.type == VSPG_MEDIUM_GRID && (m.temperature || m.Le[0] != 0 || m.Le[1] != 0 || m.Le[2] != 0)) {
             const float one = 1.f;  // "Lescale" absent: SampledGrid({1}, 1, 1, 1) (media.cpp:319-320)
             const float *src = m.le_scale ? m.le_scale : &one;
             const int lx = m.le_scale ? m.le_nx : 1, ly = m.le_scale ? m.le_ny : 1, lz = m.le_scale ? m.le_nz : 1;
@@ -2808,7 +2826,7 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             r->hscene.le_nx = lx; r->hscene.le_ny = ly; r->hscene.le_nz = lz;
         }
         r->scene.medium.le_scale = nullptr;
-        r->scene.medium.temperature = nullptr;  // never dereferenced (see vspg.h)
+        r->scene.medium.temperature = nullptr;  // (the host array belongs to the caller)
     }
     if (scene->n_triangles > 0) {
         std::vector<DTri> all;
@@ -2982,6 +3000,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->brick_index) (void)hipFree(r->brick_index);
     if (r->octets) (void)hipFree(r->octets);
     if (r->le_scale) (void)hipFree(r->le_scale);
+    if (r->temperature) (void)hipFree(r->temperature);
     if (r->majorant) (void)hipFree(r->majorant);
     delete r;
     return 0;
@@ -3768,6 +3787,24 @@ int vspg_libm_powf_batch(VspgRenderer *r, int n, const float *x, const float *y,
                        (float *)dout.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_blackbody_batch(VspgRenderer *r, int n, const float *u, const float *T, float *out6, void *stream) {
+    if (!r || !u || !T || !out6 || n < 0) return fail(VSPG_EINVAL, "null argument");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf du, dT, dout;
+    HIPCHK(hipMalloc(&du.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dT.p, (size_t)n * 4));
+    HIPCHK(hipMalloc(&dout.p, (size_t)n * 24));
+    HIPCHK(hipMemcpyAsync(du.p, u, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dT.p, T, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_blackbody, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, n, (const float *)du.p, (const float *)dT.p, (float *)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out6, dout.p, (size_t)n * 24, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }

@@ -315,6 +315,30 @@ VDEV Spec fast_exp(Spec a) {
     return Spec{fast_exp(a.r), fast_exp(a.g), fast_exp(a.b)};
 }
 VDEV float sample_exponential(float u, float a) { return -logf_(1 - u) / a; }  // sampling.h:222
+// ---- blackbody emission of temperature grids in the RGB build ----
+// SampledWavelengths::SampleVisible (util/spectrum.h:369-386): lambda_i = SampleVisibleWavelengths(up_i) (util/sampling.h:169-171),
+// std::atanh(float) = the host's atanhf (vspg_libm.h)
+VDEV float sample_visible_wavelength(float u, int i) {
+    float up = u + (float)i / 3;
+    if (up > 1) up -= 1;
+    return 538 - 138.888889f * vspg_libm::atanhf_host_exact(0.85691062f - 1.82750197f * up);
+}
+VDEV float blackbody(float lambda, float T) {  // Blackbody() (util/spectrum.h:83-94); Pow<5>(l) = ((l l)(l l)) l (util/math.h:294-309)
+    if (T <= 0) return 0;
+    const float c = 299792458.f;
+    const float h = 6.62606957e-34f;
+    const float kb = 1.3806488e-23f;
+    float l = lambda * 1e-9f;
+    float l2 = l * l;
+    float l5 = l2 * l2 * l;
+    return (2 * h * c * c) / (l5 * (fast_exp((h * c) / (l * kb * T)) - 1));
+}
+VDEV Spec blackbody_sample(float T, float lu) {  // BlackbodySpectrum(T).Sample(lambda) (util/spectrum.h:568-588)
+    float lambdaMax = 2.8977721e-3f / T;
+    float normalizationFactor = 1 / blackbody(lambdaMax * 1e9f, T);
+    return Spec{blackbody(sample_visible_wavelength(lu, 0), T) * normalizationFactor, blackbody(sample_visible_wavelength(lu, 1), T) * normalizationFactor,
+                blackbody(sample_visible_wavelength(lu, 2), T) * normalizationFactor};
+}
 VDEV int sample_discrete2(float w0, float w1, float u) {  // sampling.h:79-113, two weights
     float sumWeights = 0;
     sumWeights += w0;
@@ -575,6 +599,10 @@ struct DScene {
     // emissive GridMedium (media.h:326-342): the LeScale grid, null = not emissive
     const float *le_scale;
     int32_t le_nx, le_ny, le_nz;
+    // temperature grid of an emissive GridMedium / NanoVDBMedium (media.h:333-341, :724-735): raw samples in the density grid's
+    // layout (only the delta-tracking callback's emission reads it: eight plain loads, no bricks), null = none
+    const float *temperature;
+    float temperature_offset, temperature_scale, nvdb_le_scale;
     // integrator parameters
     VspgIntegratorParams prm;
     // render config
@@ -1120,6 +1148,9 @@ struct MediumProps {
     Spec sigma_a, sigma_s, Le;
     float g;
     Spec sigma_t;  // sigma_s + sigma_a
+    // temperature grids (media.h:333-341, :724-735): Le = bb_scale * BlackbodySpectrum(bb_temp).Sample(lambda), finished by
+    // medium_Le() where the path reads mp.Le (the delta-tracking callback is the only reader); bb_temp = 0: Le above is the value
+    float bb_temp = 0.f, bb_scale = 0.f;
 };
 struct MajSeg {
     float tMin, tMax;
@@ -1178,6 +1209,7 @@ struct HomogeneousMediumT {
     // SampleDiscrete({1, 0}, u) returns 0 for every u in [0, 1) -- the first collision of the
     // distance-sampling walk is always a real one (no null collisions in a homogeneous medium).
     static constexpr bool kAlwaysRealCollision = true;
+    static constexpr bool kEmit = false;  // (no temperature grid)
 };
 using HomogeneousMedium = HomogeneousMediumT<0>;
 using HomogeneousMediumSimple = HomogeneousMediumT<0, false, true>;
@@ -1198,9 +1230,13 @@ VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis
 // grid (media.h:686-719): index-space trilinear sampling a + w (b - a) with background 0 outside the index
 // bounding box, "densityoffset", 64^3 majorants read from HBM / L2 (1 MB: too large for LDS).  The sparse
 // NanoVDB tree and its sampler are absent from the reference tree: parity unpinned for the fetch itself.
-template <bool NVDB, bool GREY = false, int BND = -1>
+template <bool NVDB, bool GREY = false, int BND = -1, bool EMIT = false>
 struct GridMediumT {
     static constexpr int kBnd = BND;  // medium boundaries known at compile time (0 / 1) or decided at run time (-1): has_bnd
+    // blackbody emission of a temperature grid compiled in: the per-lane kernels (BND = -1: whatever the scene holds) and the NDS
+    // pipeline's emissive instantiations.  Elsewhere the code is left out: in the NDS kernel it costs 16-176 B of scratch per lane
+    // whether or not the scene has a temperature grid (the resampling kernels never read Le and are the same either way).
+    static constexpr bool kEmit = EMIT || BND < 0;
     static constexpr int kRes = NVDB ? kMajResNvdb : kMajRes;
     // wavefront walk kernels: majorant-cell advances tried per tracking step before the collision code runs (a 64^3
     // majorant grid has 4x as many cell crossings per tentative collision as the 16^3 one)
@@ -1222,6 +1258,8 @@ struct GridMediumT {
     int lnx, lny, lnz;
     Spec Le;
     const float *minv;      // rows 0..2 of mInv when renderFromMedium is not the identity, else null (wave-uniform)
+    const float *temperature;  // temperature grid (raw, nx ny nz; null = none): blackbody emission
+    float t_offset, t_scale, t_lescale;  // t_lescale: NanoVDBMedium's LeScale (a GridMedium scales by its LeScale grid)
 
     // Transform::ApplyInverse(Point3<T>) (util/transform.h:387-398), affine matrix
     VDEV V3 to_medium(V3 p) const {
@@ -1437,24 +1475,51 @@ struct GridMediumT {
         const float b0 = a00 + v * (a01 - a00), b1 = a10 + v * (a11 - a10);
         return b0 + u * (b1 - b0);
     }
-    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703 (temperature grids are out of scope)
+    // the temperature grid through nanovdb's sampler (see lookup_index; same index bounding box and index-to-world map as the density grid)
+    VDEV float lookup_index_raw(const float *data, V3 x) const {
+        const float fx = __builtin_floorf(x.x), fy = __builtin_floorf(x.y), fz = __builtin_floorf(x.z);
+        const float cx = fmax_(fmin_(fx, 1e9f), -1e9f), cy = fmax_(fmin_(fy, 1e9f), -1e9f), cz = fmax_(fmin_(fz, 1e9f), -1e9f);
+        const int i = (int)cx - imx, j = (int)cy - imy, k = (int)cz - imz;
+        const float u = x.x - fx, v = x.y - fy, w = x.z - fz;
+        auto at = [&](int a, int b, int c) { return GridMediumT::at(data, nx, ny, nz, a, b, c); };
+        const float v000 = at(i, j, k), v001 = at(i, j, k + 1), v010 = at(i, j + 1, k), v011 = at(i, j + 1, k + 1);
+        const float v100 = at(i + 1, j, k), v101 = at(i + 1, j, k + 1), v110 = at(i + 1, j + 1, k), v111 = at(i + 1, j + 1, k + 1);
+        const float a00 = v000 + w * (v001 - v000), a01 = v010 + w * (v011 - v010);
+        const float a10 = v100 + w * (v101 - v100), a11 = v110 + w * (v111 - v110);
+        const float b0 = a00 + v * (a01 - a00), b1 = a10 + v * (a11 - a10);
+        return b0 + u * (b1 - b0);
+    }
+    VDEV MediumProps sample_point(V3 p) const {  // media.h:316-345 / :686-703
         float d;
         Spec le = sp(0.f);
+        float bb_temp = 0.f, bb_scale = 0.f;
         p = to_medium(p);  // renderFromMedium.ApplyInverse(p) (media.h:322 / :693)
         if constexpr (NVDB) {
             const V3 xi = V3{(p.x - origin.x) * inv_voxel.x, (p.y - origin.y) * inv_voxel.y, (p.z - origin.z) * inv_voxel.z};
             d = lookup_index(xi);
             d += density_offset;
+            if (kEmit && temperature) {  // NanoVDBMedium::Le (media.h:724-735); wave-uniform
+                float temp = lookup_index_raw(temperature, xi);
+                temp = (temp - t_offset) * t_scale;
+                if (temp > 100.f) { bb_temp = temp; bb_scale = t_lescale; }
+            }
         } else {
             const V3 po = offset(p);
             d = lookup(po);
             if (le_scale) {  // isEmissive (wave-uniform): Le = scale * Le_spec where the LeScale grid is positive (:326-342)
                 const float scale = lookup(le_scale, lnx, lny, lnz, po);
-                if (scale > 0) le = Le * scale;
+                if (scale > 0) {
+                    if (kEmit && temperature) {  // media.h:333-341
+                        float temp = lookup(temperature, nx, ny, nz, po);
+                        temp = (temp - t_offset) * t_scale;
+                        if (temp > 100.f) { bb_temp = temp; bb_scale = scale; }
+                    } else
+                        le = Le * scale;
+                }
             }
         }
         Spec sa = sigma_a * d, ss = sigma_s * d;
-        return MediumProps{sa, ss, le, g, ss + sa};
+        return MediumProps{sa, ss, le, g, ss + sa, bb_temp, bb_scale};
     }
     VDEV Spec sigma_n(const MediumProps &mp, Spec sigma_maj) const { return clamp_zero(sigma_maj - mp.sigma_a - mp.sigma_s); }
     VDEV bool is_homogeneous() const { return false; }
@@ -1466,19 +1531,20 @@ using GridMedium = GridMediumT<false>;
 using GridMediumGrey = GridMediumT<false, true>;
 using NanoDenseMedium = GridMediumT<true>;
 using NanoDenseMediumGrey = GridMediumT<true, true>;
-template <bool NVDB, bool GREY, int BND = -1>
-VDEV GridMediumT<NVDB, GREY, BND> make_grid(const DScene &S, const float *majorant) {
-    return GridMediumT<NVDB, GREY, BND>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
+template <bool NVDB, bool GREY, int BND = -1, bool EMIT = false>
+VDEV GridMediumT<NVDB, GREY, BND, EMIT> make_grid(const DScene &S, const float *majorant) {
+    return GridMediumT<NVDB, GREY, BND, EMIT>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
                              majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
-                             S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le), S.has_xform ? S.minv : nullptr};
+                             S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le), S.has_xform ? S.minv : nullptr,
+                             S.temperature, S.temperature_offset, S.temperature_scale, S.nvdb_le_scale};
 }
 template <class M> struct MediumMaker;
 template <int GREY, bool NZ, bool SIMPLE> struct MediumMaker<HomogeneousMediumT<GREY, NZ, SIMPLE>> {
     static VDEV HomogeneousMediumT<GREY, NZ, SIMPLE> make(const DScene &, const float *) { return HomogeneousMediumT<GREY, NZ, SIMPLE>{}; }
 };
-template <bool NVDB, bool GREY, int BND> struct MediumMaker<GridMediumT<NVDB, GREY, BND>> {
-    static VDEV GridMediumT<NVDB, GREY, BND> make(const DScene &S, const float *majorant) {
-        return make_grid<NVDB, GREY, BND>(S, majorant ? majorant : S.majorant);
+template <bool NVDB, bool GREY, int BND, bool EMIT> struct MediumMaker<GridMediumT<NVDB, GREY, BND, EMIT>> {
+    static VDEV GridMediumT<NVDB, GREY, BND, EMIT> make(const DScene &S, const float *majorant) {
+        return make_grid<NVDB, GREY, BND, EMIT>(S, majorant ? majorant : S.majorant);
     }
 };
 

@@ -431,4 +431,89 @@ VSPG_HD float cosf_host_exact(float y) {
     return sincosf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
 }
 
+// ---- atanhf (std::atanh(float) of SampleVisibleWavelengths, util/sampling.h:169-171: the wavelengths a temperature grid's
+// blackbody emission is evaluated at).  glibc 2.35: sysdeps/ieee754/flt-32/e_atanhf.c (0.5 * log1pf(...)) over s_log1pf.c, the
+// fdlibm float code; x86-64 has no multiarch variant of either, so the build is the baseline one: every operation a separately
+// rounded FLOAT operation, no fused multiply-add.  tests/test_libm_model.py checks the pair against the running libm. ----
+VSPG_HD float log1pf_host_exact(float x) {
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f, Lp4 = 2.2222198546e-01f,
+                Lp5 = 1.8183572590e-01f, Lp6 = 1.5313838422e-01f, Lp7 = 1.4798198640e-01f;
+    float hfsq, f = 0, c = 0, s, z, R, u;
+    int32_t k, hx, hu = 0, ax;
+    hx = (int32_t)asuint(x);
+    ax = hx & 0x7fffffff;
+    k = 1;
+    if (hx < 0x3ed413d7) {  // x < 0.41422
+        if (ax >= 0x3f800000) {  // x <= -1
+            if (x == -1.0f) return -__builtin_inff();
+            return __builtin_nanf("");
+        }
+        if (ax < 0x31000000) {  // |x| < 2^-29
+            if (ax < 0x24800000) return x;  // |x| < 2^-54
+            return x - x * x * 0.5f;
+        }
+        if (hx > 0 || hx <= (int32_t)0xbe95f61f) {  // -0.2929 < x < 0.41422
+            k = 0;
+            f = x;
+            hu = 1;
+        }
+    }
+    if (hx >= 0x7f800000) return x + x;
+    if (k != 0) {
+        if (hx < 0x5a000000) {
+            u = 1.0f + x;
+            hu = (int32_t)asuint(u);
+            k = (hu >> 23) - 127;
+            c = (k > 0) ? 1.0f - (u - x) : x - (u - 1.0f);  // correction term
+            c /= u;
+        } else {
+            u = x;
+            hu = (int32_t)asuint(u);
+            k = (hu >> 23) - 127;
+            c = 0;
+        }
+        hu &= 0x007fffff;
+        if (hu < 0x3504f7) {
+            u = asfloat((uint32_t)hu | 0x3f800000u);  // normalize u
+        } else {
+            k += 1;
+            u = asfloat((uint32_t)hu | 0x3f000000u);  // normalize u/2
+            hu = (0x00800000 - hu) >> 2;
+        }
+        f = u - 1.0f;
+    }
+    hfsq = 0.5f * f * f;
+    if (hu == 0) {  // |f| < 2^-20
+        if (f == 0.0f) {
+            if (k == 0) return 0.0f;
+            c += k * ln2_lo;
+            return k * ln2_hi + c;
+        }
+        R = hfsq * (1.0f - 0.66666666666666666f * f);
+        if (k == 0) return f - R;
+        return k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
+    }
+    s = f / (2.0f + f);
+    z = s * s;
+    R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
+}
+VSPG_HD float atanhf_host_exact(float x) {
+    const float xa = __builtin_fabsf(x);
+    float t;
+    if (xa < 0.5f) {
+        if (xa < 0x1.0p-28f) return x;
+        t = xa + xa;
+        t = 0.5f * log1pf_host_exact(t + t * xa / (1.0f - xa));
+    } else if (xa < 1.0f) {
+        t = 0.5f * log1pf_host_exact((xa + xa) / (1.0f - xa));
+    } else {
+        if (xa > 1.0f) return __builtin_nanf("");
+        return x > 0 ? __builtin_inff() : -__builtin_inff();
+    }
+    return __builtin_copysignf(t, x);
+}
+
 }  // namespace vspg_libm

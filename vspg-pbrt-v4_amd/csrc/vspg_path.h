@@ -422,6 +422,7 @@ struct PathState {
     float vsp0;  // primary-ray VSP of this pixel, loaded when the path starts (hides the HBM latency)
     float pce;   // guided builds, rrguiding: the pixel's contribution estimate (0 = none); guideRR = rrguiding && buffer ready
     bool guideRR;
+    float lu;        // the wavelength sample (its lambdas: blackbody emission of a temperature grid only; dead code elsewhere)
     bool in_medium;  // ray.medium != nullptr.  Constant without medium boundaries (has_bnd(S) == 0); simple-scene kernels never read it
     GuideState gs;  // guided builds only: the previous vertex's distribution for the secondary-ray VSP
 };
@@ -605,11 +606,14 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 ev.kind = EV_TERMINATE;
                 return false;
             }
-            if (st.depth < S.prm.maxdepth && nonzero(mp.Le)) {  // :895-906
+            Spec mpLe = mp.Le;  // MediumProperties::Le as SamplePoint(p, lambda) returns it (see MediumProps)
+            if constexpr (Medium::kEmit)
+                if (mp.bb_temp > 0.f) mpLe = blackbody_sample(mp.bb_temp, st.lu) * mp.bb_scale;
+            if (st.depth < S.prm.maxdepth && nonzero(mpLe)) {  // :895-906
                 float pdf = ch_of(sigma_maj, ch) * ch_of(T_maj, ch);
                 Spec betap = st.beta * T_maj / pdf;
                 Spec r_e = st.r_u * sigma_maj * T_maj / pdf;
-                if (nonzero(r_e)) st.L = st.L + betap * mp.sigma_a * mp.Le / avg(r_e);
+                if (nonzero(r_e)) st.L = st.L + betap * mp.sigma_a * mpLe / avg(r_e);
             }
             Spec sigma_t = mp.sigma_t;
             float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
@@ -1309,6 +1313,7 @@ VDEV void start_path(const DScene &S, const float *vsp_buf, int vsp_ready, int p
 }
 VDEV void start_path_common(const DScene &S, int px, int py, Sampler &sampler, PathState &st, int *ch, IsgSample &isg) {
     float lu = sampler.get1d();
+    st.lu = lu;
     int c = (int)__builtin_floorf(lu * 3);  // SampledWavelengths::SampleVisible (spectrum.h:380-384)
     *ch = c > 2 ? 2 : c;
     // GetCameraSample (samplers.h:796-815), BoxFilter radius .5 (filters.h:67-69)

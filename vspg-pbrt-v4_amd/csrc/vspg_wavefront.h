@@ -364,6 +364,7 @@ VDEV uint32_t wf_load_path(const WfPool &P, unsigned slot, PathState &st, Sample
     st.pce = 0.f;
     st.guideRR = false;
     st.in_medium = (fl & WFL_INMED) != 0;
+    st.lu = 0.f;  // only k_wf_segment_vertex reads it (a temperature grid's emission) and recomputes it there
     return fl;
 }
 
@@ -1411,6 +1412,11 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
                 if constexpr (TRAIN) wf_rec_load(a, slot, pc.rec);
                 if constexpr (GUIDED) st.gs.vsp_next = P.f(WF_GSVSP, slot);
                 if (has_bnd<Medium::kBnd>(S) && st.depth == 0) st.vsp0 = (a.vsp_ready & VSP_READY) ? a.vsp_buf[(size_t)py * S.xres + px] : 0.5f;  // (see wf_segment_begin)
+                if (Medium::kEmit && S.temperature) {  // the wavelength sample is the pixel sample's first number: drawn again rather than carried in the record
+                    Sampler s0;
+                    s0.start_pixel_sample(px, py, S.seed, a.jump);
+                    st.lu = s0.get1d();
+                }
                 if (fl & WFL_SHADOW_WALK) {  // the previous vertex's NEE (:483 / :836 from the estimate on)
                     const WfShadowResult sr = wf_load_shadow_result(P, slot, a.compact_results != 0);
                     const Spec Ld = sample_Ld_end<G>(true, (fl & WFL_DELTA) != 0, sr.T_ray, sr.r_l, sr.r_u,

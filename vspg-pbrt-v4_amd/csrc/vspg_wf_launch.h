@@ -18,6 +18,7 @@ struct WfLaunch {
     bool serial;                   // everything on one stream (VSPG_WF_SERIAL)
     bool bnd;                      // the scene has medium boundaries: the BND instantiations, iterations until the list runs dry
     bool nds;                      // vspsamplingmethod "nds": segment + vertex in one dense kernel
+    bool emit;                     // ... over a medium with a temperature grid: the NDS kernel's emissive instantiations
     int maxdepth, base_iters, max_iters;
     hipStream_t s, s2;
     hipEvent_t ev_vertex, ev_shadow;
@@ -36,7 +37,8 @@ int wf_dispatch_nvdb(const WfLaunch &L, bool guided, bool train, bool grey);
 // Medium: the dense kernels' instantiation (its kBnd says whether the boundary code is compiled in); WalkMedium: the two walk
 // kernels' -- the grey layout whenever the medium's coefficients are bitwise grey, never the boundary flavour (a walk job is a ray
 // segment inside the medium: boundaries are the dense kernels' business).
-template <class Medium, bool GUIDED, bool TRAIN, class WalkMedium>
+// NDS_ONLY: only the "nds" branch is instantiated (the emissive media: their other kernels would be the plain medium's over again).
+template <class Medium, bool GUIDED, bool TRAIN, class WalkMedium, bool NDS_ONLY = false>
 int wf_run_pass(const WfLaunch &L) {
     const WfArgs &a = L.a;
     const hipStream_t s = L.s, s2 = L.s2;
@@ -59,7 +61,7 @@ int wf_run_pass(const WfLaunch &L) {
             hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a, it);
             if (bnd || it < L.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(L.swalk), dim3(kWfBlock), 0, s, a, it);
         }
-    } else {
+    } else if constexpr (!NDS_ONLY) {
         hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a);
         for (int it = 0; it < L.max_iters; ++it) {
             if (bnd && it > L.base_iters) {
@@ -93,7 +95,8 @@ int wf_run_pass(const WfLaunch &L) {
     return 0;
 }
 
-// one medium layout's instantiations: {grey, chromatic} x {unguided, guided, guided + training} x {no boundaries, boundaries}
+// one medium layout's instantiations: {grey, chromatic} x {unguided, guided, guided + training} x {no boundaries, boundaries},
+// + the NDS kernel's for media with a temperature grid
 template <bool NVDB>
 int wf_dispatch(const WfLaunch &L, bool guided, bool train, bool grey) {
 #define VSPG_WF_CASE(GREY, BNDV)                                                                                        \
@@ -104,6 +107,19 @@ int wf_dispatch(const WfLaunch &L, bool guided, bool train, bool grey) {
         if (guided) return wf_run_pass<M, true, false, WM>(L);                                                          \
         return wf_run_pass<M, false, false, WM>(L);                                                                     \
     } while (0)
+    if (L.emit && L.nds) {  // (a medium with a temperature grid is never run on the grey layout: its emission is not grey)
+#define VSPG_WF_EMIT_CASE(BNDV)                                                                                        \
+    do {                                                                                                                \
+        using M = GridMediumT<NVDB, false, BNDV, true>;                                                                 \
+        using WM = GridMediumT<NVDB, false>;                                                                            \
+        if (guided && train) return wf_run_pass<M, true, true, WM, true>(L);                                            \
+        if (guided) return wf_run_pass<M, true, false, WM, true>(L);                                                    \
+        return wf_run_pass<M, false, false, WM, true>(L);                                                               \
+    } while (0)
+        if (L.bnd) VSPG_WF_EMIT_CASE(1);
+        VSPG_WF_EMIT_CASE(0);
+#undef VSPG_WF_EMIT_CASE
+    }
     if (L.bnd) {
         if (grey) VSPG_WF_CASE(true, 1);
         VSPG_WF_CASE(false, 1);

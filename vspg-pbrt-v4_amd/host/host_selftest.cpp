@@ -68,7 +68,19 @@ int main() {
         CHECK(storage.size() == 6 && gm.density == storage.data() && storage[5] == 2.5f);
         CHECK(throws([&] { std::vector<float> st; CreateMedium("uniformgrid", ParameterDictionary::Parse("\"integer nx\" 2 \"float density\" [1 2 3]"), &st); }));  // count mismatch
         CHECK(throws([&] { std::vector<float> st; CreateMedium("uniformgrid", ParameterDictionary::Parse("\"integer nx\" 1"), &st); }));  // no density
-        CHECK(throws([&] { std::vector<float> st; CreateMedium("uniformgrid", ParameterDictionary::Parse("\"float density\" 1 \"float temperature\" 300"), &st); }));
+        {   // "temperature" (media.cpp:276-302, :345-347): as many samples as "density", offset / cutoff / scale, never together with "Le"
+            std::vector<float> st, ls, ts;
+            VspgMedium tm = CreateMedium("uniformgrid", ParameterDictionary::Parse("\"integer nx\" 2 \"float density\" [1 2] \"float temperature\" [300 1500] "
+                                                                                   "\"float temperaturecutoff\" 50 \"float temperaturescale\" 2"), &st, &ls, &ts);
+            CHECK(tm.temperature == ts.data() && ts.size() == 2 && ts[1] == 1500.f && tm.temperature_offset == 50.f && tm.temperature_scale == 2.f);
+            CHECK(tm.Le[0] == 0 && tm.le_scale == nullptr);
+            tm = CreateMedium("uniformgrid", ParameterDictionary::Parse("\"integer nx\" 2 \"float density\" [1 2] \"float temperature\" [300 1500] "
+                                                                        "\"float temperatureoffset\" 7 \"float temperaturecutoff\" 50 \"float Lescale\" [0.5 2]"), &st, &ls, &ts);
+            CHECK(tm.temperature_offset == 7.f && tm.temperature_scale == 1.f && tm.le_scale == ls.data() && tm.le_nx == 2 && ls[1] == 2.f);
+            CHECK(throws([&] { CreateMedium("uniformgrid", ParameterDictionary::Parse("\"float density\" 1 \"float temperature\" [300 400]"), &st, &ls, &ts); }));
+            CHECK(throws([&] { CreateMedium("uniformgrid", ParameterDictionary::Parse("\"float density\" 1 \"float temperature\" 300 \"rgb Le\" [1 1 1]"), &st, &ls, &ts); }));
+            CHECK(throws([&] { CreateMedium("uniformgrid", ParameterDictionary::Parse("\"float density\" 1 \"float temperature\" 300"), &st, &ls); }));  // nowhere to keep the grid
+        }
         CHECK(throws([] { ParameterDictionary::Parse("\"spectrum sigma_a\" \"metal-Au-eta\""); }));   // type outside scope
         CHECK(throws([] { ParameterDictionary::Parse("\"float g\" [ 0.5"); }));                        // missing ]
         ParameterDictionary pd = ParameterDictionary::Parse("\"bool usenee\" false \"string lightsampler\" \"uniform\" \"integer maxdepth\" 7");

@@ -153,14 +153,17 @@ void ParameterDictionary::ReportUnused() const {
 }
 
 // ---------------------------------------------------------------------------------------
-static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<float> *densityStorage, std::vector<float> *leScaleStorage) {
+static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<float> *densityStorage, std::vector<float> *leScaleStorage,
+                                   std::vector<float> *temperatureStorage) {
     // GridMedium::Create (media.cpp:272-361)
     VspgMedium m;
     std::memset(&m, 0, sizeof m);
     std::vector<float> density = p.GetFloatArray("density");
     std::vector<float> temperature = p.GetFloatArray("temperature");
     if (density.empty()) throw Error("No \"density\" value provided for grid medium.");
-    if (!temperature.empty()) throw Error("grid medium \"temperature\" (emissive grids) is outside this build's scope");
+    if (!temperature.empty() && temperature.size() != density.size())
+        throw Error("Different number of samples (" + std::to_string(density.size()) + " vs " + std::to_string(temperature.size()) +
+                    ") provided for \"density\" and \"temperature\".");
     const int nx = p.GetOneInt("nx", 1), ny = p.GetOneInt("ny", 1), nz = p.GetOneInt("nz", 1);
     if ((long long)density.size() != (long long)nx * ny * nz)
         throw Error("Grid medium has " + std::to_string(density.size()) + " density values; expected nx*ny*nz = " +
@@ -169,7 +172,13 @@ static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<flo
     float le[3] = {0.f, 0.f, 0.f};
     const bool hasLe = p.GetOneRGB("Le", le);
     std::vector<float> leScale = p.GetFloatArray("Lescale");
-    const bool emissive = hasLe && (le[0] > 0 || le[1] > 0 || le[2] > 0);  // Le.MaxValue() == 0 -> ConstantSpectrum(0)
+    if (hasLe && !temperature.empty()) throw Error("Both \"Le\" and \"temperature\" values were provided.");
+    // isEmissive = temperatureGrid ? true : Le_spec.MaxValue() > 0 (media.cpp:261); Le.MaxValue() == 0 -> ConstantSpectrum(0)
+    const bool emissive = !temperature.empty() || (hasLe && (le[0] > 0 || le[1] > 0 || le[2] > 0));
+    if (!temperature.empty() && !temperatureStorage)
+        throw Error("CreateMedium(\"uniformgrid\") with \"temperature\" needs a temperatureStorage vector to own the grid");
+    const float temperatureOffset = p.GetOneFloat("temperatureoffset", p.GetOneFloat("temperaturecutoff", 0.f));
+    const float temperatureScale = p.GetOneFloat("temperaturescale", 1.f);
     if (!leScale.empty() && (long long)leScale.size() != (long long)nx * ny * nz)
         throw Error("Expected " + std::to_string(nx) + " x " + std::to_string(ny) + " " + std::to_string(nz) + " = " +
                     std::to_string((long long)nx * ny * nz) + " values for \"Lescale\" but were given " + std::to_string(leScale.size()) + ".");
@@ -204,6 +213,12 @@ static VspgMedium CreateGridMedium(const ParameterDictionary &p, std::vector<flo
             m.le_scale = leScaleStorage->data();
             m.le_nx = nx; m.le_ny = ny; m.le_nz = nz;
         }  // else: the library builds the reference's 1x1x1 grid {LeNorm}
+    }
+    if (!temperature.empty()) {  // media.h:333-341: Le = LeScale.Lookup(p) * BlackbodySpectrum((T(p) - offset) * scale).Sample(lambda)
+        *temperatureStorage = std::move(temperature);
+        m.temperature = temperatureStorage->data();
+        m.temperature_offset = temperatureOffset;
+        m.temperature_scale = temperatureScale;
     }
     return m;
 }
@@ -253,10 +268,12 @@ static VspgMedium CreateNanoVdbMedium(const ParameterDictionary &p, std::vector<
     m.majorant_scale = majorantScale;
     *densityStorage = std::move(dg.dense);
     m.density = densityStorage->data();
-    if (haveT) {  // NanoVDBMedium's temperature grid (media.h:724-735): accepted where the path never evaluates it (include/vspg.h)
+    if (haveT) {  // NanoVDBMedium's temperature grid (media.h:724-735): blackbody emission under "vspsamplingmethod" "nds" (include/vspg.h)
         bool same = true;
         for (int i = 0; i < 3; ++i) same = same && tg.indexMin[i] == dg.indexMin[i] && tg.dim[i] == m.nx * (i == 0) + m.ny * (i == 1) + m.nz * (i == 2);
-        if (!same) throw Error(filename + ": the \"" + temperaturename + "\" grid's index bounding box differs from the density grid's (outside this build's scope)");
+        for (int i = 0; i < 9; ++i) same = same && tg.mat[i] == dg.mat[i];
+        for (int i = 0; i < 3; ++i) same = same && tg.vec[i] == dg.vec[i];
+        if (!same) throw Error(filename + ": the \"" + temperaturename + "\" grid's index bounding box or index-to-world map differs from the density grid's (outside this build's scope)");
         if (!temperatureStorage) throw Error("CreateMedium(\"nanovdb\") with a temperature grid needs a second storage vector to own it");
         *temperatureStorage = std::move(tg.dense);
         m.temperature = temperatureStorage->data();
@@ -268,11 +285,11 @@ static VspgMedium CreateNanoVdbMedium(const ParameterDictionary &p, std::vector<
 }
 
 VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &p, std::vector<float> *densityStorage,
-                        std::vector<float> *leScaleStorage) {
+                        std::vector<float> *leScaleStorage, std::vector<float> *temperatureStorage) {
     VspgMedium m;
     std::memset(&m, 0, sizeof m);
-    if (name == "uniformgrid") return CreateGridMedium(p, densityStorage, leScaleStorage);
-    if (name == "nanovdb") return CreateNanoVdbMedium(p, densityStorage, leScaleStorage);
+    if (name == "uniformgrid") return CreateGridMedium(p, densityStorage, leScaleStorage, temperatureStorage);
+    if (name == "nanovdb") return CreateNanoVdbMedium(p, densityStorage, temperatureStorage ? temperatureStorage : leScaleStorage);
     if (name != "homogeneous")
         throw Error("medium \"" + name + "\": only \"homogeneous\", \"uniformgrid\" and \"nanovdb\" are inside this build's scope");
     // HomogeneousMedium::Create (media.cpp:167-206)

@@ -75,9 +75,12 @@ class ParameterDictionary {
 
 // Medium::Create (media.cpp:816-841): "homogeneous" (HomogeneousMedium::Create :167-206) and "uniformgrid"
 // (GridMedium::Create :272-361; the density array is copied into *densityStorage, which must outlive the
-// renderer creation -- VspgMedium.density points into it); other names -> Error: outside scope
+// renderer creation -- VspgMedium.density points into it; likewise the "Lescale" and "temperature" grids); "nanovdb"
+// (NanoVDBMedium::Create :683-734; its temperature grid goes to temperatureStorage, or to leScaleStorage when that is all the caller
+// passed); other names -> Error: outside scope
 VspgMedium CreateMedium(const std::string &name, const ParameterDictionary &parameters,
-                        std::vector<float> *densityStorage = nullptr, std::vector<float> *leScaleStorage = nullptr);
+                        std::vector<float> *densityStorage = nullptr, std::vector<float> *leScaleStorage = nullptr,
+                        std::vector<float> *temperatureStorage = nullptr);
 
 struct Film {
     int xres = 0, yres = 0;

@@ -496,7 +496,7 @@ class Parser {
                 const std::string fn = p.GetOneString("filename", "");
                 if (!fn.empty() && fn[0] != '/' && !baseDir.empty()) p.String("filename", baseDir + "/" + fn);
             }
-            s.medium = CreateMedium(it->second.type, p, &sd->density, &sd->leScale);
+            s.medium = CreateMedium(it->second.type, p, &sd->density, &sd->leScale, &sd->temperature);
             if (!is_identity(it->second.ctm)) {
                 if (s.medium.type == VSPG_MEDIUM_HOMOGENEOUS) { /* a homogeneous medium has no frame */ }
                 else {

@@ -32,7 +32,7 @@ namespace vspg {
 
 struct SceneDescription {
     VspgScene scene;                     // pointers inside refer to the vectors below: keep the description alive while creating
-    std::vector<float> density, leScale, triP, triKd;
+    std::vector<float> density, leScale, temperature, triP, triKd;
     std::vector<int32_t> triFlags;       // VSPG_TRI_* per triangle (material, MediumInterface, orientation)
     std::string integratorName = "volpath";
     ParameterDictionary integratorParams;
