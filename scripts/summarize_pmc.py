@@ -5,7 +5,13 @@ import collections, csv, glob, json, os, re, sys
 src = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    # a guided run trains its field first: the path kernels of the TRAINED waves are the launches behind the last training kernel
+    # (k_propagate, k_train_*; dispatch order) -- as bench.py's live PMC counts them.  Training kernels themselves are kept.
+    last_train = max([int(r["Dispatch_Id"]) for r in rows if "k_propagate" in r["Kernel_Name"] or "k_train_" in r["Kernel_Name"]], default=-1)
+    for r in rows:
+        if int(r["Dispatch_Id"]) <= last_train and ("k_render_wave" in r["Kernel_Name"] or "k_wf_" in r["Kernel_Name"]):
+            continue
         k = re.sub(r"\(anonymous namespace\)::|vspg::", "", re.sub(r"^void ", "", r["Kernel_Name"])).split("(")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
