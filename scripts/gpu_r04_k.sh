@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, run k: the workgroup kernel's tile stock (claims from the global head prefetched behind the segment phase)
+# round 4, run k: A/B of workgroup-kernel scheduler changes (library variants under build/variants/ against the default), tests first
 mkdir -p gpurun_out/r04
 O=gpurun_out/r04
 step() { local t=$1 log=$2; shift 2; timeout -k 10 $t "$@" > $O/$log 2>&1; local rc=$?; echo "$log rc=$rc"; tail -${TAILN:-3} $O/$log | cut -c1-600; if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -eq 134 ]; then exit $rc; fi; }
