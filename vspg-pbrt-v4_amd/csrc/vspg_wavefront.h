@@ -273,6 +273,7 @@ VDEV void wf_pixel_of(unsigned slot, unsigned tilesX, int *px, int *py) {
 // kWfStageRounds rounds in LDS (wave ballot + prefix count + one LDS atomic per wavefront) and flushes them with ONE
 // global atomic.  List order is irrelevant: every path's result depends on its own state only.
 constexpr int kWfStageRounds = 4;
+constexpr int kWfChainMax = 4;  // no-walk segments a lane runs back to back in one k_wf_vertex pass (boundary scenes) before the path waits for the next iteration
 // The dense kernels' list walk.  Static: workgroup b takes chunks b, b + G, ... (grid stride).  Claimed (VSPG_WF_DENSE_CLAIM, the
 // vertex kernel): chunks of one workgroup's width from a cursor, one returning atomic and one barrier per chunk -- a chunk's cost
 // follows what its paths do (ended, NEE or not, hit or escape), so static shares end on their slowest chunks.
@@ -1181,8 +1182,17 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
         const unsigned idx = base + threadIdx.x;
         bool next = false, walk = false, shadow = false;  // next: the slot goes onto the next iteration's list
         unsigned slot = 0;
-        if (idx < n) {
-            slot = list_in[idx];
+        // Medium boundaries: a segment that needs no distance walk (a ray in vacuum, a ray that escapes, an all-zero majorant run)
+        // has nothing to wait for -- its end, the vertex behind it and the next begin run right here, in the lane that began it,
+        // unless the vertex's NEE sent a shadow walk out (its result must reach L first).  A path through the reference's cloud
+        // scenes spends an iteration less per boundary crossing: every vacuum segment (camera to the bounding sphere, sphere to
+        // ground or sky) used to cost a launch of all three kernels and a trip of the record through HBM.
+        constexpr bool kChain = !GUIDED && Medium::kBnd == 1;
+        if (idx < n) slot = list_in[idx];
+        for (int chain = 0; idx < n; ++chain) {
+            next = false;
+            walk = false;
+            bool again = false;
             PathState st;
             Sampler sampler;
             IsgSample isg;
@@ -1317,6 +1327,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                     wf_store_path<G>(P, slot, st, sampler, ch, isg, FL_LIVE);
                 } else {
                     wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
+                    again = !walk;
                 }
                 next = true;
             } else {
@@ -1332,10 +1343,12 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                         wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE);
                     } else {
                         wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, extra, &walk);
+                        again = !walk && !shadow;
                     }
                     next = true;
                 }
             }
+            if (!kChain || !again || chain >= kWfChainMax) break;
         }
         stA.push(next, slot);
         stB.push(walk, slot);
