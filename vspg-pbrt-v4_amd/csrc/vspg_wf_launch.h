@@ -44,11 +44,20 @@ int wf_run_pass(const WfLaunch &L) {
     const hipStream_t s = L.s, s2 = L.s2;
     const bool bnd = L.bnd, serial = L.serial;
     // (medium boundaries) has the list of iteration `it` run dry?  One small read-back per iteration past the ones every pass needs.
+    // Once the host reads an iteration's list length anyway it sizes that iteration's launches by it: the tail iterations of a
+    // boundary scene hold a few thousand paths, and a full grid of persistent workgroups (each stages the majorant grid into its LDS
+    // before it finds the job list empty) costs 50-60 us per walk launch whatever the list holds.  One lane per job at most: the
+    // tail is bound by the length of a walk, not by throughput.
+    unsigned dense = L.dense, walk = L.walk, swalk = L.swalk;
     auto list_empty = [&](int it, bool *empty) -> int {
         unsigned int na = 0;
         WFCHK(hipMemcpyAsync(&na, &a.iters[it].n_active, sizeof na, hipMemcpyDeviceToHost, s));
         WFCHK(hipStreamSynchronize(s));
         *empty = na == 0;
+        const unsigned blocks = (na + (unsigned)kWfBlock - 1u) / (unsigned)kWfBlock;
+        dense = blocks < L.dense ? (blocks ? blocks : 1u) : L.dense;
+        walk = blocks < L.walk ? (blocks ? blocks : 1u) : L.walk;
+        swalk = blocks < L.swalk ? (blocks ? blocks : 1u) : L.swalk;
         return 0;
     };
     if (L.nds) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
@@ -58,8 +67,8 @@ int wf_run_pass(const WfLaunch &L) {
                 if (const int rc = list_empty(it, &empty)) return rc;
                 if (empty) break;
             }
-            hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a, it);
-            if (bnd || it < L.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(L.swalk), dim3(kWfBlock), 0, s, a, it);
+            hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
+            if (bnd || it < L.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
         }
     } else if constexpr (!NDS_ONLY) {
         hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a);
@@ -69,18 +78,18 @@ int wf_run_pass(const WfLaunch &L) {
                 if (const int rc = list_empty(it, &empty)) return rc;
                 if (empty) break;
             }
-            hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(L.walk), dim3(kWfBlock), 0, s, a, it);
+            hipLaunchKernelGGL(k_wf_dist_walk<WalkMedium>, dim3(walk), dim3(kWfBlock), 0, s, a, it);
             if (it > 0 && !serial) WFCHK(hipStreamWaitEvent(s, L.ev_shadow, 0));
-            hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a, it);
+            hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
             if (bnd || it < L.maxdepth) {
                 // (guided: the next segments begin BEFORE the shadow walk starts -- launched after it, the dense begin kernel crawled in
                 // the slots the persistent walk left over and the next distance walk waited for it)
-                if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a, it + 1);
+                if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it + 1);
                 if (!serial) {
                     WFCHK(hipEventRecord(L.ev_vertex, s));
                     WFCHK(hipStreamWaitEvent(s2, L.ev_vertex, 0));
                 }
-                hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(L.swalk), dim3(kWfBlock), 0, s2, a, it);
+                hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s2, a, it);
                 if (!serial) WFCHK(hipEventRecord(L.ev_shadow, s2));
             }
         }
