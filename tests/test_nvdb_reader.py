@@ -119,6 +119,21 @@ def test_refuses_damaged_files(tool, tmp_path):
     (tmp_path / "wild.nvdb").write_bytes(bytes(bad))
     r = subprocess.run([tool, str(tmp_path / "wild.nvdb")], capture_output=True, text=True)
     assert r.returncode == 1 and ("outside the grid" in r.stderr or "truncated" in r.stderr), r.stderr
+    # ... including offsets chosen to wrap the position arithmetic (near 2^64 as unsigned, hugely negative) and misaligned ones
+    for off in ((1 << 63) - 32, -(1 << 62), -(len(blob) * 4 // 32 * 32), 8256 + 1):
+        bad = bytearray(blob)
+        bad[root_tile + 8: root_tile + 16] = int(off).to_bytes(8, "little", signed=True)
+        (tmp_path / "wrap.nvdb").write_bytes(bytes(bad))
+        r = subprocess.run([tool, str(tmp_path / "wrap.nvdb")], capture_output=True, text=True)
+        assert r.returncode == 1 and ("outside the grid" in r.stderr or "truncated" in r.stderr), (off, r.returncode, r.stderr)
+    # an index bounding box whose extent does not fit 32 bits (max - min + 1 overflows int32)
+    bad = bytearray(blob)
+    meta = 16
+    bad[meta + 88: meta + 92] = (-(1 << 31)).to_bytes(4, "little", signed=True)
+    bad[meta + 100: meta + 104] = ((1 << 31) - 1).to_bytes(4, "little", signed=True)
+    (tmp_path / "bbox.nvdb").write_bytes(bytes(bad))
+    r = subprocess.run([tool, str(tmp_path / "bbox.nvdb")], capture_output=True, text=True)
+    assert r.returncode == 1 and "too large" in r.stderr, r.stderr
 
 
 SCENE = """LookAt 0 0 -0.95   0 0 0   0 1 0

@@ -20,7 +20,7 @@ struct Reader {
     const std::string &file;
     template <class T>
     T at(size_t off) const {
-        if (off + sizeof(T) > buf.size()) throw Error(file + ": truncated NanoVDB file (offset " + std::to_string(off) + ")");
+        if (off > buf.size() || buf.size() - off < sizeof(T)) throw Error(file + ": truncated NanoVDB file (offset " + std::to_string(off) + ")");
         T v;
         std::memcpy(&v, buf.data() + off, sizeof(T));
         return v;
@@ -35,9 +35,21 @@ void decode_grid(const Reader &R, size_t blob, size_t blobSize, NanoVdbFloatGrid
     if (gridType != 1) throw Error(R.file + ": grid \"" + g->name + "\" is not a FloatGrid (grid type " + std::to_string(gridType) + "); only float grids are read");
     for (int i = 0; i < 9; ++i) g->mat[i] = R.at<double>(blob + 296 + 88 + 8 * i);
     for (int i = 0; i < 3; ++i) g->vec[i] = R.at<double>(blob + 296 + 88 + 8 * 18 + 8 * i);
+    // every node position is file-controlled: a position is `bytes` long and lies inside [blob, blob + blobSize) (no wrap-around)
+    const size_t blobEnd = blob + blobSize;  // (the caller checked blob + gridSize <= file size)
+    auto inside = [&](size_t off, size_t bytes) { return off >= blob && off <= blobEnd && blobEnd - off >= bytes; };
+    // a child's position = its parent's + a signed 64-bit offset from the file
+    auto child_at = [&](size_t parent, int64_t rel, const char *what) -> size_t {
+        const bool ok = rel >= 0 ? (uint64_t)rel <= (uint64_t)(blobEnd - parent) : (uint64_t)(-(rel + 1)) + 1u <= (uint64_t)(parent - blob);
+        if (!ok || ((uint64_t)rel & 31u)) throw Error(R.file + ": grid \"" + g->name + "\": " + what + " node offset outside the grid or misaligned");
+        return rel >= 0 ? parent + (size_t)rel : parent - (size_t)(-(rel + 1)) - 1u;
+    };
+    if (blobSize < kGridDataBytes + kTreeDataBytes) throw Error(R.file + ": grid \"" + g->name + "\": grid shorter than its headers");
     const size_t tree = blob + kGridDataBytes;
-    const size_t root = tree + R.at<uint64_t>(tree + 24);
-    if (root + kRootHeaderBytes > blob + blobSize) throw Error(R.file + ": grid \"" + g->name + "\": root node outside the grid");
+    const uint64_t rootRel = R.at<uint64_t>(tree + 24);
+    if (rootRel > blobSize) throw Error(R.file + ": grid \"" + g->name + "\": root node outside the grid");
+    const size_t root = tree + (size_t)rootRel;
+    if (!inside(root, kRootHeaderBytes)) throw Error(R.file + ": grid \"" + g->name + "\": root node outside the grid");
     g->background = R.at<float>(root + 28);
     const uint32_t tableSize = R.at<uint32_t>(root + 24);
     const long long nx = g->dim[0], ny = g->dim[1], nz = g->dim[2];
@@ -48,12 +60,18 @@ void decode_grid(const Reader &R, size_t blob, size_t blobSize, NanoVdbFloatGrid
         g->dense[(size_t)((k * ny + j) * nx + i)] = v;
     };
     auto fill_box = [&](int x0, int y0, int z0, int size, float v) {  // an active tile: constant over size^3 voxels, clipped to the index bbox
-        for (int z = z0 > g->indexMin[2] ? z0 : g->indexMin[2]; z < z0 + size && z < g->indexMin[2] + nz; ++z)
-            for (int y = y0 > g->indexMin[1] ? y0 : g->indexMin[1]; y < y0 + size && y < g->indexMin[1] + ny; ++y)
-                for (int x = x0 > g->indexMin[0] ? x0 : g->indexMin[0]; x < x0 + size && x < g->indexMin[0] + nx; ++x) put(x, y, z, v);
+        const long long o[3] = {x0, y0, z0}, n[3] = {nx, ny, nz};
+        long long lo[3], hi[3];  // (64-bit: o + size and indexMin + dim may pass INT32_MAX)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = o[k] > g->indexMin[k] ? o[k] : (long long)g->indexMin[k];
+            hi[k] = o[k] + size < g->indexMin[k] + n[k] ? o[k] + size : g->indexMin[k] + n[k];
+        }
+        for (long long z = lo[2]; z < hi[2]; ++z)
+            for (long long y = lo[1]; y < hi[1]; ++y)
+                for (long long x = lo[0]; x < hi[0]; ++x) put((int)x, (int)y, (int)z, v);
     };
     auto leaf = [&](size_t off, int x0, int y0, int z0) {
-        if (off + kLeafBytes > blob + blobSize) throw Error(R.file + ": grid \"" + g->name + "\": leaf node outside the grid");
+        if (!inside(off, kLeafBytes)) throw Error(R.file + ": grid \"" + g->name + "\": leaf node outside the grid");
         for (uint32_t n = 0; n < 512; ++n) {  // every value of a leaf is defined (inactive ones hold the background or a tile value)
             const float v = R.at<float>(off + kLeafHeaderBytes + 4 * n);
             put(x0 + (int)(n >> 6), y0 + (int)((n >> 3) & 7), z0 + (int)(n & 7), v);
@@ -61,22 +79,24 @@ void decode_grid(const Reader &R, size_t blob, size_t blobSize, NanoVdbFloatGrid
     };
     auto lower = [&](size_t off, int x0, int y0, int z0) {
         const size_t vmask = off + 32, cmask = off + 32 + 512, table = off + kLowerHeaderBytes;
-        if (table + 4096 * 8 > blob + blobSize) throw Error(R.file + ": grid \"" + g->name + "\": lower node outside the grid");
+        if (!inside(off, kLowerHeaderBytes + 4096 * 8)) throw Error(R.file + ": grid \"" + g->name + "\": lower node outside the grid");
         for (uint32_t n = 0; n < 4096; ++n) {
             const int x = x0 + (int)(n >> 8) * 8, y = y0 + (int)((n >> 4) & 15) * 8, z = z0 + (int)(n & 15) * 8;
-            if (mask_on(R, cmask, n)) leaf(off + (size_t)R.at<int64_t>(table + 8 * n), x, y, z);
+            if (mask_on(R, cmask, n)) leaf(child_at(off, R.at<int64_t>(table + 8 * n), "leaf"), x, y, z);
             else if (mask_on(R, vmask, n)) fill_box(x, y, z, 8, R.at<float>(table + 8 * n));
         }
     };
     auto upper = [&](size_t off, int x0, int y0, int z0) {
         const size_t vmask = off + 32, cmask = off + 32 + 4096, table = off + kUpperHeaderBytes;
-        if (table + 32768 * 8 > blob + blobSize) throw Error(R.file + ": grid \"" + g->name + "\": upper node outside the grid");
+        if (!inside(off, kUpperHeaderBytes + 32768 * 8)) throw Error(R.file + ": grid \"" + g->name + "\": upper node outside the grid");
         for (uint32_t n = 0; n < 32768; ++n) {
             const int x = x0 + (int)(n >> 10) * 128, y = y0 + (int)((n >> 5) & 31) * 128, z = z0 + (int)(n & 31) * 128;
-            if (mask_on(R, cmask, n)) lower(off + (size_t)R.at<int64_t>(table + 8 * n), x, y, z);
+            if (mask_on(R, cmask, n)) lower(child_at(off, R.at<int64_t>(table + 8 * n), "lower"), x, y, z);
             else if (mask_on(R, vmask, n)) fill_box(x, y, z, 128, R.at<float>(table + 8 * n));
         }
     };
+    if (!inside(root, kRootHeaderBytes) || (blobEnd - root - kRootHeaderBytes) / kRootTileBytes < tableSize)
+        throw Error(R.file + ": grid \"" + g->name + "\": root table outside the grid");
     for (uint32_t t = 0; t < tableSize; ++t) {
         const size_t tile = root + kRootHeaderBytes + kRootTileBytes * t;
         const uint64_t key = R.at<uint64_t>(tile);
@@ -84,7 +104,7 @@ void decode_grid(const Reader &R, size_t blob, size_t blobSize, NanoVdbFloatGrid
         // the key holds uint32(coordinate) >> 12 -- 20 significant bits, two's complement -- in fields of 21 bits
         auto field = [](uint64_t k, int shift) { int32_t v = (int32_t)((k >> shift) & 0xfffffu); if (v & 0x80000) v |= ~0xfffff; return v * 4096; };
         const int x0 = field(key, 42), y0 = field(key, 21), z0 = field(key, 0);
-        if (child != 0) upper(root + (size_t)child, x0, y0, z0);
+        if (child != 0) upper(child_at(root, child, "upper"), x0, y0, z0);
         else if (R.at<uint32_t>(tile + 16)) fill_box(x0, y0, z0, 4096, R.at<float>(tile + 20));
     }
 }
@@ -109,7 +129,7 @@ bool ReadNanoVdbFloatGrid(const std::string &filename, const std::string &gridNa
         std::vector<Entry> entries;
         for (uint16_t i = 0; i < gridCount; ++i) {
             const uint32_t nameSize = R.at<uint32_t>(meta + 136);
-            if (meta + kMetaBytes + nameSize > buf.size()) throw Error(filename + ": truncated NanoVDB file (grid names)");
+            if (meta > buf.size() || buf.size() - meta < kMetaBytes || buf.size() - meta - kMetaBytes < nameSize) throw Error(filename + ": truncated NanoVDB file (grid names)");
             std::string name((const char *)buf.data() + meta + kMetaBytes, nameSize ? nameSize - 1 : 0);
             entries.push_back(Entry{meta, name, R.at<uint64_t>(meta), R.at<uint64_t>(meta + 8)});
             meta += kMetaBytes + nameSize;
@@ -118,21 +138,24 @@ bool ReadNanoVdbFloatGrid(const std::string &filename, const std::string &gridNa
         for (const Entry &e : entries) {
             if (e.name == gridName) {
                 if (codec != 0) throw Error(filename + ": compressed NanoVDB file (codec " + std::to_string(codec) + "); only uncompressed files are read");
-                if (blob + e.gridSize > buf.size()) throw Error(filename + ": truncated NanoVDB file (grid \"" + gridName + "\")");
+                if (blob > buf.size() || buf.size() - blob < e.gridSize) throw Error(filename + ": truncated NanoVDB file (grid \"" + gridName + "\")");
                 out->name = e.name;
                 out->activeVoxels = R.at<uint64_t>(e.meta + 24);
                 for (int k = 0; k < 3; ++k) {
                     out->worldMin[k] = R.at<double>(e.meta + 40 + 8 * k);
                     out->worldMax[k] = R.at<double>(e.meta + 64 + 8 * k);
                     out->indexMin[k] = R.at<int32_t>(e.meta + 88 + 4 * k);
-                    out->dim[k] = R.at<int32_t>(e.meta + 100 + 4 * k) - out->indexMin[k] + 1;  // inclusive bbox (nanovdb2pbrt.cpp:103-105)
+                    const int64_t d = (int64_t)R.at<int32_t>(e.meta + 100 + 4 * k) - out->indexMin[k] + 1;  // inclusive bbox (nanovdb2pbrt.cpp:103-105); 64-bit: max - min may pass INT32_MAX
                     out->voxelSize[k] = R.at<double>(e.meta + 112 + 8 * k);
-                    if (out->dim[k] <= 0) throw Error(filename + ": grid \"" + gridName + "\" has an empty index bounding box");
+                    if (d <= 0) throw Error(filename + ": grid \"" + gridName + "\" has an empty index bounding box");
+                    if (d > (1 << 20)) throw Error(filename + ": grid \"" + gridName + "\": index bounding box too large for a dense copy");
+                    out->dim[k] = (int)d;
                 }
                 if ((double)out->dim[0] * out->dim[1] * out->dim[2] > 4e9) throw Error(filename + ": grid \"" + gridName + "\": index bounding box too large for a dense copy");
                 decode_grid(R, blob, e.gridSize, out);
                 return true;
             }
+            if (e.fileSize > buf.size() - (blob < buf.size() ? blob : buf.size())) { blob = buf.size(); break; }  // (a later segment cannot start inside a truncated grid)
             blob += e.fileSize;
         }
         pos = blob;
