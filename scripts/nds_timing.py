@@ -6,8 +6,9 @@ import torch
 import __graft_entry__ as g
 P = g.load_package(); P.load()
 W, H = 1920, 1080
-for kind in ("grid", "nvdb"):
-    scene = P.cloud_box_scene(W, H, 256) if kind == "grid" else P.nanovdb_box_scene(W, H, 256)
+for kind in (sys.argv[1:] or ["grid", "nvdb"]):
+    scene = {"grid": lambda: P.cloud_box_scene(W, H, 256), "nvdb": lambda: P.nanovdb_box_scene(W, H, 256), "scene": lambda: P.cloud_scene(W, H, 256),
+             "scene-nvdb": lambda: P.cloud_scene(W, H, 256, nvdb=True)}[kind]()
     for kernel in ("lane", "wf"):
         os.environ["VSPG_KERNEL"] = kernel
         try:
