@@ -691,21 +691,41 @@ VDEV Medium wf_block_medium(const DScene &S) {
 // ---- the begin of a segment: li_segment_a up to the traversal ----------------------------------------------------------
 // Scene intersection, the segment's RNG, VSP fetch, the resampling routine's prologue; stores the path (with `extra` flags: what
 // the caller still has to say about the PREVIOUS vertex) and, if the traversal has anything to do, the distance-walk job.
-template <class Medium, bool GUIDED, class PC>
+// SKIPS (boundary scenes, passes that record nothing): a segment that needs no distance walk and ends on a non-emissive interface
+// surface -- the camera ray on its way to the cloud's bounding shape, a bounce off the ground back into it -- has no vertex and adds
+// nothing to L: Li's `continue` (:399-404) is taken right here (SkipIntersection, GetMedium: li_surface_pre's skip branch) and the
+// segment behind the boundary begun in its place, instead of a launch of every kernel to find that out.
+template <class Medium, bool GUIDED, bool SKIPS = false, class PC>
 VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &medium, unsigned slot, PathState &st, Sampler &sampler, int ch,
                            IsgSample &isg, PC &pc, uint32_t extra, bool *walk) {
     const WfPool &P = a.P;
     constexpr int G = Medium::kGrey;
     // ---- li_segment_a up to the traversal (:312-325, sample_distance / SampleT_maj_Resampling prologue) --
-    pc.segment();
-    const Isect si = scene_intersect(S, st.ro, st.rd, kInf);
+    Isect si;
+    bool in_medium;
+    for (int chain = 0;; ++chain) {
+        pc.segment();
+        si = scene_intersect(S, st.ro, st.rd, kInf);
+        // :318 `if (ray.medium && !std::isinf(tMax))`: no distance sampling for a ray outside the medium or one that escapes the scene
+        in_medium = !has_bnd<Medium::kBnd>(S) ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
+        if constexpr (SKIPS && Medium::kBnd == 1) {
+            if (!in_medium && si.hit && chain < kWfChainMax) {
+                const int sfl = surf_flags(S, si.quad);
+                const bool emits = !is_tri(si.quad) && !is_sphere(si.quad) && quad_at(si.quad).is_light;
+                if ((sfl & SURF_INTERFACE) && !emits) {
+                    st.ro = offset_ray_origin(surf_pi(S, si.quad, si.p), si.n, st.rd);
+                    st.in_medium = S.medium_type != VSPG_MEDIUM_NONE && get_medium(sfl, si.n, st.rd, st.in_medium);
+                    continue;
+                }
+            }
+        }
+        break;
+    }
     const float tMax = si.hit ? si.t : kInf;
     extra |= FL_LIVE | (si.hit ? (uint32_t)WFL_HIT : 0u);
     P.set3(WF_VXP, slot, si.p);
     P.i(WF_VXG, slot) = si.quad;
     P.f(WF_VXT, slot) = si.t;
-    // :318 `if (ray.medium && !std::isinf(tMax))`: no distance sampling for a ray outside the medium or one that escapes the scene
-    const bool in_medium = !has_bnd<Medium::kBnd>(S) ? S.medium_type != VSPG_MEDIUM_NONE : st.in_medium;
     if (in_medium && si.hit) {
         Rng rng;
         {
@@ -812,7 +832,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_begin(WfArgs a, int it) {
                 int ch;
                 const uint32_t fl = wf_load_path<G>(P, slot, st, sampler, &ch, isg);
                 st.gs.vsp_next = P.f(WF_GSVSP, slot);
-                wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, fl & (uint32_t)(WFL_SHADOW_WALK | WFL_DELTA), &walk);
+                wf_segment_begin<Medium, GUIDED, !TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, fl & (uint32_t)(WFL_SHADOW_WALK | WFL_DELTA), &walk);
             }
         }
         stB.push(walk, slot);
@@ -854,7 +874,7 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_start(WfArgs a) {
                     pc.rec.reset();
                     wf_rec_store(a, slot, pc.rec);
                 }
-                wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
+                wf_segment_begin<Medium, GUIDED, !TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
             }
         }
         stA.push(alive, slot);
@@ -1326,7 +1346,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                 if constexpr (GUIDED) {  // (gs.vsp_next: the previous vertex's estimate stays the next segment's -- no vertex in between)
                     wf_store_path<G>(P, slot, st, sampler, ch, isg, FL_LIVE);
                 } else {
-                    wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
+                    wf_segment_begin<Medium, GUIDED, !TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
                     again = !walk;
                 }
                 next = true;
@@ -1342,7 +1362,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                         P.f(WF_GSVSP, slot) = st.gs.vsp_next;
                         wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE);
                     } else {
-                        wf_segment_begin<Medium, GUIDED>(a, S, medium, slot, st, sampler, ch, isg, pc, extra, &walk);
+                        wf_segment_begin<Medium, GUIDED, !TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, extra, &walk);
                         again = !walk && !shadow;
                     }
                     next = true;
