@@ -2551,18 +2551,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
     // everything on the caller's stream (same results; for A/B runs and debugging).
     L.serial = [] { const char *e = getenv("VSPG_WF_SERIAL"); return e && *e && *e != '0'; }();  // (read per pass: a test flips it)
     if (!L.serial && !r->wf_stream2) {
-        // The shadow walk's stream has the highest stream priority: the walk of iteration i starts ~20 us behind the distance walk of
-        // iteration i + 1 (an event away from the vertex kernel) and is the longer of the two -- the next vertex kernel waits for it.
-        // Ahead in the dispatcher's queue it ends sooner: cloud 8.27-8.34 -> 8.18-8.22 ms per wave, the other workloads unchanged
-        // (gpurun_out/r04/o_prio.txt).  VSPG_WF_S2_PRIO=default|low for the A/B.
-        const char *pe = getenv("VSPG_WF_S2_PRIO");
-        if (pe && pe[0] == 'd') {
-            HIPCHK(hipStreamCreateWithFlags(&r->wf_stream2, hipStreamNonBlocking));
-        } else {
-            int lo = 0, hi = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (lo: the least, numerically greatest; hi: the greatest)
-            HIPCHK(hipStreamCreateWithPriority(&r->wf_stream2, hipStreamNonBlocking, pe && pe[0] == 'l' ? lo : hi));
-        }
+        HIPCHK(hipStreamCreateWithFlags(&r->wf_stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_vertex, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_shadow, hipEventDisableTiming));
     }
