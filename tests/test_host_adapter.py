@@ -164,6 +164,10 @@ def test_scene_files_parse(host_build):
     assert c.returncode == 0, c.stderr
     assert "1 rectangles, 0 triangles, 2 infinite lights, medium type 2, film 64x48 @ 4 spp" in c.stdout
     assert "1 spheres, 1 interface-material surfaces, 1 medium transitions, camera outside the medium" in c.stdout
+    # a medium with a temperature grid (blackbody emission under "nds")
+    d = subprocess.run([exe, os.path.join(SCENES, "fire_boundary.pbrt"), "--parse-only"], capture_output=True, text=True)
+    assert d.returncode == 0, d.stderr
+    assert "1 infinite lights, medium type 2, film 64x48 @ 4 spp" in d.stdout and "temperature grid" in d.stdout
 
 
 def test_scene_file_include(host_build, tmp_path):
@@ -529,6 +533,79 @@ def test_scene_file_with_medium_boundaries(host_build, gpu_pkg, tmp_path):
         os.environ.pop("VSPG_KERNEL", None)
     assert np.array_equal(sl, sc) and np.array_equal(Ll.view(np.uint32), Lc.view(np.uint32))
     c.close()
+
+
+@pytest.mark.gpu
+def test_scene_file_with_a_temperature_grid(host_build, gpu_pkg, tmp_path):
+    """`tests/scenes/fire_boundary.pbrt`: a "uniformgrid" with "temperature" / "temperaturecutoff" / "temperaturescale" / "Lescale"
+    behind an interface sphere, "vspsamplingmethod" "nds" -- blackbody volume emission (media.h:333-341) through the scene-file
+    reader: the file's render is bit-identical to the same scene assembled through the C-ABI, whose replayed paths are the
+    oracle's; without the "temperature" line the picture is darker."""
+    import oracle_lib
+    from scenes import add_quad, add_sphere, empty_scene
+    exe = os.path.join(host_build, "vspg_pbrt")
+    src = os.path.join(SCENES, "fire_boundary.pbrt")
+    out = tmp_path / "fire.pfm"
+    a = subprocess.run([exe, src, "--outfile", str(out)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout + a.stderr
+    img = read_pfm(str(out))
+    cold = tmp_path / "cold.pbrt"
+    lines = [ln for ln in open(src).read().splitlines() if '"float temperature"' not in ln and "temperaturecutoff" not in ln]
+    cold.write_text("\n".join(lines).replace('"rgb sigma_a"', '"float Lescale" [ 1 ] "rgb sigma_a"') + "\n")
+    b = subprocess.run([exe, str(cold), "--outfile", str(tmp_path / "cold.pfm")], capture_output=True, text=True)
+    assert b.returncode != 0 and "Lescale" in (b.stdout + b.stderr)         # 27 values expected: the reader checks the count
+    cold.write_text("\n".join(lines) + "\n")
+    b = subprocess.run([exe, str(cold), "--outfile", str(tmp_path / "cold.pfm")], capture_output=True, text=True)
+    assert b.returncode == 0, b.stdout + b.stderr
+    dark = read_pfm(str(tmp_path / "cold.pfm"))
+    print("fire_boundary mean radiance: with the temperature grid %.4f, without %.4f" % (img.mean(), dark.mean()))
+    assert np.isfinite(img).all() and img.mean() > 1.15 * dark.mean()
+    # the same scene through the C-ABI
+    P = gpu_pkg
+    W, H = 64, 48
+    s = empty_scene(W, H, (0, 0.6, -4.2), (0, 0.15, 0), fov=38.0)
+    m = s.medium
+    m.type = P.MEDIUM_GRID
+    m.sigma_a[:] = (1.5,) * 3
+    m.sigma_s[:] = (2.5,) * 3
+    m.g = 0.4
+    m.nx = m.ny = m.nz = 3
+    m.bounds_min[:] = (-0.8, -0.5, -0.8)
+    m.bounds_max[:] = (0.8, 0.9, 0.8)
+    dens = np.array([0.2, 1, 0.7, 0.1, 0.9, 0.4, 1, 0.6, 0.3, 0.5, 1.2, 0.8, 0.9, 1.3, 0.6, 0.2, 0.7, 0.4, 0, 0.4, 0.1, 0.3, 0.8, 0.2, 0.1, 0.3, 0], dtype=np.float32)
+    temp = np.array([300, 900, 1500, 400, 2400, 1200, 800, 1800, 600, 700, 3000, 2000, 1600, 3400, 1500, 500, 2200, 900, 90, 1100, 300, 600, 1900, 700,
+                     200, 800, 150], dtype=np.float32)
+    lesc = np.array([1, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 1, 2, 3, 2, 1, 2, 1, 0, 1, 1, 1, 2, 1, 1, 1, 0], dtype=np.float32)
+    m.density = dens.ctypes.data_as(C.POINTER(C.c_float))
+    m.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+    m.temperature_offset, m.temperature_scale = 150.0, 1.25
+    m.le_scale = lesc.ctypes.data_as(C.POINTER(C.c_float))
+    m.le_nx = m.le_ny = m.le_nz = 3
+    s.camera_outside_medium = 1
+    add_sphere(s, (0, 0.2, 0), 1.34, material=P.MATERIAL_INTERFACE, iface=P.IFACE_INSIDE)
+    add_quad(s, (-6, -1.2, -6), (0, 0, 12), (12, 0, 0), kd=(.4, .35, .3))
+    P.add_infinite_light(s, P.LIGHT_UNIFORM_INFINITE, (.05, .07, .1))
+    prm = P.app_f_params()
+    prm.vspsamplingmethod = P.VSP_NDS
+    r = P.Renderer(s, prm, W, H)
+    assert r.kernel_name().startswith("k_wf_segment_vertex")
+    for w in range(4):
+        r.render_wave(w, w + 1)
+        r.post_process_wave()
+    f = r.film()
+    r.close()
+    assert np.array_equal(img.view(np.uint32), (f[..., :3] / f[..., 3:4]).astype(np.float32).view(np.uint32))
+    rng = np.random.default_rng(6)
+    n = 10000
+    xy = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    si = rng.integers(0, 256, n).astype(np.int32)
+    c = oracle_lib.OracleRenderer(s, prm, W, H)
+    Lc, sc = c.trace_paths(xy, si)
+    c.close()
+    r = P.Renderer(s, prm, W, H)
+    Lg, sg = r.trace_paths(xy, si)
+    r.close()
+    assert np.array_equal(sg, sc) and np.array_equal(Lg.view(np.uint32), Lc.view(np.uint32))
 
 
 @pytest.mark.gpu

@@ -46,6 +46,7 @@ int main(int argc, char **argv) {
                 std::printf("; %d spheres, %d interface-material surfaces, %d medium transitions, camera %s the medium", sd->scene.n_spheres, n_interface, n_transition,
                             sd->scene.camera_outside_medium ? "outside" : "in");
         }
+        if (sd->scene.medium.temperature) std::printf("; temperature grid (blackbody emission under \"vspsamplingmethod\" \"nds\")");
         std::printf("\n");
         if (parseOnly) return 0;
         auto integrator = vspg::CreateIntegrator(*sd, device);
