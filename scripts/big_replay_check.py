@@ -74,5 +74,27 @@ for name, ls in (("bvh", P.LIGHTSAMPLER_BVH), ("power", P.LIGHTSAMPLER_POWER)):
     ok &= check("five lights, %s light sampler" % name, ml, prm, 60000)
 prm = P.default_params(); prm.lightsampler = P.LIGHTSAMPLER_BVH
 ok &= check("five lights, bvh sampler, guided", ml, prm, 40000, scenes.light_field(P, n=4, light=(0.3, 5.0, -0.4)))
+# round 4: medium boundaries (the reference's cloud-scene shape: camera in vacuum, interface sphere, ground, sun + sky), an interface box of
+# quads around a fog, spheres as diffuse objects, and temperature grids (blackbody emission) under "nds"
+import ctypes as C
+cs = P.cloud_scene(W, H, 256)
+ok &= check("cloud scene (boundaries), App. F", cs, P.app_f_params(), 300000)
+ok &= check("cloud scene, reference defaults", cs, P.default_params(), 100000, scenes.light_field(P, n=4, bmin=(-3, -3, -3), bmax=(3, 3, 3), light=(0.0, 2.9, 0.0)))
+ok &= check("cloud scene, NanoVDB semantics", P.cloud_scene(W, H, 256, nvdb=True), P.app_f_params(), 200000)
+nds = P.app_f_params(); nds.vspsamplingmethod = P.VSP_NDS
+ok &= check("cloud scene under nds", cs, nds, 200000)
+fire = P.cloud_scene(W, H, 256, nvdb=True)
+temp = (150.0 + 2600.0 * np.clip(P.procedural_cloud_density(256, seed=11), 0, 1.4)).astype(np.float32)
+fire.medium.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+fire.medium.temperature_offset, fire.medium.temperature_scale, fire.medium.nvdb_le_scale = 120.0, 1.3, 40.0
+ok &= check("burning cloud scene (blackbody), nds", fire, nds, 200000)
+gfire = P.cloud_box_scene(W, H, 256)
+gfire.medium.temperature = temp.ctypes.data_as(C.POINTER(C.c_float))
+gfire.medium.temperature_offset, gfire.medium.temperature_scale = 120.0, 1.3
+ok &= check("burning GridMedium box (blackbody), nds", gfire, nds, 200000)
+sph = P.fog_box_scene(W, H)
+P.add_sphere(sph, (0.3, -0.5, 0.2), 0.35)
+P.add_sphere(sph, (-0.4, 0.1, -0.1), 0.25, material=P.MATERIAL_INTERFACE, iface=P.IFACE_OUTSIDE)   # a hollow bubble in the fog
+ok &= check("fog + a diffuse sphere + a hollow bubble", sph, P.app_f_params(), 300000)
 print("ALL BIT-IDENTICAL" if ok else "MISMATCH")
 sys.exit(0 if ok else 1)
