@@ -374,7 +374,7 @@ def main():
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(ones.item())
     # untimed: first use of the communicator at the film's size (RCCL sets up channels / buffers lazily)
-    sh.frame_end_allreduce(dist, film, world, r, stream)
+    sh.frame_end_allreduce(dist, film, world, r, stream, torch=torch, device=torch.device("cuda", local_rank))
     torch.cuda.synchronize()
     r.film_clear(stream)
     r.reset_counters(stream)
@@ -393,7 +393,7 @@ def main():
         sync.post_process_step(stream)
     # frame end: the last wave's parked samples enter the film (vspg_flush: k_film_resolve on the render stream), then the film
     # all-reduce over RCCL / xGMI -- both inside the timed region
-    sh.frame_end_allreduce(dist, film, world, r, stream)
+    sh.frame_end_allreduce(dist, film, world, r, stream, torch=torch, device=torch.device("cuda", local_rank))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

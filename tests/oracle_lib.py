@@ -154,9 +154,6 @@ class OracleRenderer:
             ptr = a.ctypes.data_as(C.POINTER(C.c_float))
         assert self.lib.oracle_post_process_step(self.h, int(n_waves), ptr) == 0
 
-    def isg_stats_tensor(self, torch):
-        return torch.from_numpy(self.isg_stats().reshape(-1))
-
     def film(self):
         out = np.empty((self.yres, self.xres, 4), dtype=np.float32)
         self.lib.oracle_film_read(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))

@@ -368,15 +368,16 @@ def test_grey_specialisations_are_bit_identical(gpu_pkg):
 
 @pytest.mark.parametrize("W,H", [(96, 64), (50, 37)])
 def test_workgroup_schedulers_are_bit_identical(gpu_pkg, W, H):
-    """The two schedulers of the workgroup kernel -- k_render_wave_wg (global work head, film flush between the phases) and
-    k_render_wave_wg2 (tiles from a global head, parked samples, two barriers; the default) -- over
+    """The three schedulers of the workgroup kernel -- k_render_wave_wg (global work head, film flush between the phases),
+    k_render_wave_wg2 (tiles from a global head, parked samples, two barriers) and k_render_wave_wg3 (round 5, the default: ring
+    queues in LDS, no workgroup barrier, a pool larger than the workgroup) -- over
     the four homogeneous instantiations, with one-sample launches, a multi-sample launch (restarts, film atomics) and the
     image-space buffer updating in between: same films, same VSP buffers, same counters."""
     P = gpu_pkg
     scene = P.fog_box_scene(W, H)
     for env in ({"VSPG_NO_GREY": "1"}, {"VSPG_NO_GREY_KD": "1"}, {"VSPG_NO_NULLZERO": "1"}, {}):
         out = []
-        for sched in ("1", "2", "2 mixed"):   # "mixed": 3/8 of the frame from the global tile head, the rest dealt out up front
+        for sched in ("1", "2", "2 mixed", "3"):   # "mixed": 3/8 of the frame from the global tile head, the rest dealt out up front; "3": k_render_wave_wg3 (the default)
             os.environ.update(env)
             os.environ["VSPG_WG_SCHED"] = sched[0]
             if sched.endswith("mixed"):
@@ -424,7 +425,7 @@ def test_parked_samples_reach_the_film_whoever_asks_first(gpu_pkg, guided):
             r = P.Renderer(scene, prm, W, H, seed=9)
             if field is not None:
                 r.set_guiding_field(field, field)
-            assert r.kernel_name().startswith("k_render_wave_wg2<")
+            assert r.kernel_name().startswith("k_render_wave_wg3<")
             log = []
             r.render_wave(0, 1)
             log.append(r.film())                       # a read right after a launch
@@ -583,7 +584,7 @@ def test_full_size_guided_wave_properties(gpu_pkg):
     prm = P.default_params()
     prm.guide_num_training_waves = 4
     t = P.Renderer(scene, prm, W, H)
-    assert t.kernel_name() == "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>"
+    assert t.kernel_name() == "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided,train>"
     for w in range(4):
         t.render_wave(w, w + 1)
         t.post_process_wave()
@@ -620,7 +621,7 @@ def test_full_size_guided_wave_properties(gpu_pkg):
             r.close()
         finally:
             os.environ.pop("VSPG_KERNEL", None)
-    assert sorted(films) == ["k_render_wave<HomogeneousMediumT<2,true>,guided>", "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>"]
+    assert sorted(films) == ["k_render_wave<HomogeneousMediumT<2,true>,guided>", "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided>"]
     a, b = films.values()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     c = oracle_lib.OracleRenderer(scene, prm, W, H)
@@ -1839,7 +1840,7 @@ def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
             os.environ.pop("VSPG_KERNEL", None)
             os.environ.pop("VSPG_NO_GREY_GUIDED", None)
     assert sorted(films) == ["k_render_wave<HomogeneousMedium,guided>", "k_render_wave<HomogeneousMediumT<2,true>,guided>",
-                             "k_render_wave_wg2<HomogeneousMedium,guided>", "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>"], sorted(films)
+                             "k_render_wave_wg3<HomogeneousMedium,guided>", "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided>"], sorted(films)
     a = next(iter(films.values()))
     for name, f in films.items():
         assert np.array_equal(a.view(np.uint32), f.view(np.uint32)), name
@@ -1955,7 +1956,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
     # grid media record on the wavefront pipeline, homogeneous ones on the workgroup kernel (round 3): either way the recorder's
     # state travels in the path record
-    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>")
+    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided,train>")
     # (the sample buffer holds one wave's worth -- pixels x (maxdepth + 1) -- between two updates: the capped case fills it with one)
     n_waves = 1 if medium == "homogeneous-capped" else 2
     g.render_wave(0, n_waves)
@@ -1971,7 +1972,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     # homogeneous media the workgroup kernel's generic instantiation
     others = [({"VSPG_KERNEL": "lane"}, "k_render_wave<GridMedium,guided,train>" if medium == "grid" else "k_render_wave<HomogeneousMediumT<2,true>,guided,train>")]
     if medium != "grid":
-        others.append(({"VSPG_NO_GREY_GUIDED": "1"}, "k_render_wave_wg2<HomogeneousMedium,guided,train>"))
+        others.append(({"VSPG_NO_GREY_GUIDED": "1"}, "k_render_wave_wg3<HomogeneousMedium,guided,train>"))
     for env, name in others:
         os.environ.update(env)
         try:

@@ -73,8 +73,9 @@ def _worker_isg(rank, world, port, out_path, steps):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     scene = oracle_lib.fog_box_scene(W, H)
     prm = oracle_lib.app_f_params()
-    r = oracle_lib.OracleRenderer(scene, prm, W, H, shard_index=rank, shard_count=world)
-    sync = sh.ShardSync(dist, r, world, torch)
+    import oracle_shard
+    r = oracle_shard.OracleShard(oracle_lib.OracleRenderer(scene, prm, W, H, shard_index=rank, shard_count=world))
+    sync = sh.ShardSync(dist, r, world, torch, wrap=oracle_shard.host_tensor(torch))
     for step in range(steps):
         w0, w1 = sh.step_wave_range(step, world)
         r.render_wave(w0, w1, 1)

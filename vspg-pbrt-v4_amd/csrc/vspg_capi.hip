@@ -17,6 +17,7 @@
 #include "vspg_path.h"
 #include "vspg_wg_kernel.h"
 #include "vspg_guided_wg.h"
+#include "vspg_wg3.h"
 #include "vspg_wavefront.h"
 #include "vspg_wf_launch.h"
 #ifdef VSPG_SINGLE_TU  // diagnostic builds that read device-side globals of the pipeline kernels (VSPG_WF_STATS, VSPG_PROFILE, VSPG_WF_DEBUG)
@@ -63,12 +64,7 @@ __device__ __forceinline__ void load_contribution_estimate(const DScene &S, int 
     st.pce = st.guideRR ? S.contrib[(size_t)py * S.xres + px] : 0.f;
 }
 
-// The global work head is a PAIR of counters used by alternate launches: a launch zeroes the one the NEXT launch will use
-// (nobody reads it meanwhile, launches of a renderer are stream-ordered), so no memset sits between two waves.
-__device__ __forceinline__ void reset_sibling_head(unsigned int *work_head) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned int *>(reinterpret_cast<uintptr_t>(work_head) ^ 4u) = 0u;
-}
-
+// (reset_sibling_head -- the pair of global work heads used by alternate launches -- lives in vspg_wg3.h)
 // Persistent wavefront kernel with path regeneration.
 //   work item  = one pixel (all its samples [wave_start, wave_end) run in order by the lane that
 //                claims it, so film / ISG statistics are read-modify-written by exactly one lane
@@ -720,6 +716,11 @@ constexpr int kWg2PoolFull = wg_pool_paths<PoolLayout<false, 0, false, true>>(10
 #endif
 template <int GREY> constexpr int kWg2PoolGuidedT = GREY >= 2 ? (VSPG_WGG_NP_G2) : (VSPG_WGG_NP_G0);
 template <int GREY> constexpr int kWg2PoolTrainT = wg_pool_paths<PoolLayout<true, GREY, true>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8);  // + the recorder's state
+// k_render_wave_wg3 (vspg_wg3.h): pools LARGER than the workgroup has lanes -- the slack is what keeps its chunks full
+template <int GREY> constexpr int kWg3PoolHomogT = wg3_pool_paths<PoolLayout<false, GREY>>(VSPG_WG3_OTHER);
+constexpr int kWg3PoolFull = wg3_pool_paths<PoolLayout<false, 0, false, true>>(VSPG_WG3_OTHER);
+template <int GREY> constexpr int kWg3PoolGuidedT = wg3_pool_paths<PoolLayout<true, GREY>>(VSPG_WG3_OTHER + 2 * kKdLdsNodes * 8);
+template <int GREY> constexpr int kWg3PoolTrainT = wg3_pool_paths<PoolLayout<true, GREY, true>>(VSPG_WG3_OTHER + 2 * kKdLdsNodes * 8);
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
@@ -1066,27 +1067,10 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg(
 //   barriers and ~20 % in assignment / flush; the SIMDs issued 44 % of the time (scripts/microbench/issue.hip prices).
 // Multi-sample launches keep the no-return atomics at the point where a path ends (several samples of a pixel per launch).
 enum { D_NFREE = 0, D_A0 = 2, D_A1 = 4, D_CURA = 6, D_BV = 8, D_BS = 10, D_CURB = 12, D_LNEXT = 14, D_COUNT = 15 };
-// ISG code of a finished sample, one float: 0 = no ISG record, +q = volume event, -q = surface event, q = the VSP the primary
-// segment used (or 0.5): q lies in [0.001, 0.999], so the sign is free and nothing is rounded
-VDEV float isg_code(const IsgSample &isg) {
-    if (!isg.valid) return 0.f;
-    const float q = isg.vsp_used >= 0.f ? isg.vsp_used : 0.5f;
-    return isg.surface_event ? -q : q;
-}
+// (isg_code, resolve_sample: vspg_wg3.h)
 #ifndef VSPG_WG2_UNIT_SHIFT
 #define VSPG_WG2_UNIT_SHIFT 6
 #endif
-// one parked sample {L, ISG code} into the film and the image-space statistics (RGBFilm::AddSample + ISG AddSample, the
-// read-modify-write forms: one writer per pixel)
-__device__ __forceinline__ void resolve_sample(float4 s, float4 *film_px, float *isg_px) {
-    const Spec L = Spec{s.x, s.y, s.z};
-    film_add_sample_rmw(film_px, L);
-    IsgSample isg;
-    isg.valid = s.w != 0.f;
-    isg.surface_event = s.w < 0.f;
-    isg.vsp_used = __builtin_fabsf(s.w);
-    isg_add_sample_rmw(isg_px, L, isg);
-}
 template <class Medium, bool GUIDED, int NP, int kWgBlock, int kWgWavesPerSimd, bool TRAIN = false>
 __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg2(
     const DScene *__restrict__ Sp, float4 *__restrict__ film, float *__restrict__ isg_stats, const float *__restrict__ vsp_buf,
@@ -3089,6 +3073,13 @@ static bool uses_wg2(const VspgRenderer *r) {
     const char *e = getenv("VSPG_WG_SCHED");
     return !(e && e[0] == '1');
 }
+// Round 5: the barrier-free scheduler (k_render_wave_wg3, vspg_wg3.h: ring queues in LDS, every wavefront its own scheduler) serves
+// whatever k_render_wave_wg2 served; VSPG_WG_SCHED=2 keeps k_render_wave_wg2 (tests compare the three schedulers).
+static bool uses_wg3(const VspgRenderer *r) {
+    if (!uses_wg2(r)) return false;
+    const char *e = getenv("VSPG_WG_SCHED");
+    return !(e && e[0] == '2');
+}
 // The samples a one-sample wg2 launch parked are resolved by the next such launch; anything else that reads or writes the film or
 // the image-space statistics calls this first (VSPG_WG2_DEFER=0: every launch resolves its own samples at once).
 static bool wg2_defer_enabled() {  // (read per launch: a test flips it)
@@ -3125,16 +3116,19 @@ const char *vspg_renderer_kernel_name(VspgRenderer *r) {
         return nvdb ? (r->medium_grey ? "k_wf_dist_walk<NanoDenseMediumGrey>" : "k_wf_dist_walk<NanoDenseMedium>")
                     : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
     }
+    const bool w3 = uses_wg3(r);
     if (uses_wg_guided(r)) {
-        if (r->training) return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>" : "k_render_wave_wg2<HomogeneousMedium,guided,train>";
-        return guided_grey_simple(r) ? "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>" : "k_render_wave_wg2<HomogeneousMedium,guided>";
+        if (r->training) return guided_grey_simple(r) ? (w3 ? "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided,train>" : "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>")
+                                                      : (w3 ? "k_render_wave_wg3<HomogeneousMedium,guided,train>" : "k_render_wave_wg2<HomogeneousMedium,guided,train>");
+        return guided_grey_simple(r) ? (w3 ? "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided>" : "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>")
+                                     : (w3 ? "k_render_wave_wg3<HomogeneousMedium,guided>" : "k_render_wave_wg2<HomogeneousMedium,guided>");
     }
-    if (uses_wg_full(r)) return "k_render_wave_wg2<HomogeneousMedium>";
+    if (uses_wg_full(r)) return w3 ? "k_render_wave_wg3<HomogeneousMedium>" : "k_render_wave_wg2<HomogeneousMedium>";
     if (uses_wg_kernel(r) && uses_wg2(r)) {
-        if (r->medium_grey && r->surfaces_grey && r->null_zero) return "k_render_wave_wg2<HomogeneousMediumT<2,true>>";
-        if (r->medium_grey && r->surfaces_grey) return "k_render_wave_wg2<HomogeneousMediumT<2,false>>";
-        if (r->medium_grey) return "k_render_wave_wg2<HomogeneousMediumT<1,false>>";
-        return "k_render_wave_wg2<HomogeneousMediumT<0,false>>";
+        if (r->medium_grey && r->surfaces_grey && r->null_zero) return w3 ? "k_render_wave_wg3<HomogeneousMediumT<2,true>>" : "k_render_wave_wg2<HomogeneousMediumT<2,true>>";
+        if (r->medium_grey && r->surfaces_grey) return w3 ? "k_render_wave_wg3<HomogeneousMediumT<2,false>>" : "k_render_wave_wg2<HomogeneousMediumT<2,false>>";
+        if (r->medium_grey) return w3 ? "k_render_wave_wg3<HomogeneousMediumT<1,false>>" : "k_render_wave_wg2<HomogeneousMediumT<1,false>>";
+        return w3 ? "k_render_wave_wg3<HomogeneousMediumT<0,false>>" : "k_render_wave_wg2<HomogeneousMediumT<0,false>>";
     }
     if (uses_wg_kernel(r)) {
         if (grid) return "k_render_wave_wg<GridMedium>";
@@ -3274,6 +3268,20 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
 #define VSPG_LAUNCH_WG2(M, G, NPOOL, BLK, WV)                                                                                         \
     hipLaunchKernelGGL((k_render_wave_wg2<M, G, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
                        r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, static_tiles, work_head, ws_prev, ws_out, r->counters)
+#define VSPG_LAUNCH_WG3(M, G, NPOOL, BLK, WV, TR)                                                                                         \
+    hipLaunchKernelGGL((k_render_wave_wg3<M, G, NPOOL, BLK, WV, TR>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
+                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, work_head, ws_prev, ws_out, r->counters, targs)
+            if (uses_wg3(r)) {
+                if (gwg && train && guided_grey_simple(r)) VSPG_LAUNCH_WG3(HomogeneousMediumGreySceneNullZero, true, kWg3PoolTrainT<2>, kWgBlockGuided, kWgWavesGuided, true);
+                else if (gwg && train) VSPG_LAUNCH_WG3(HomogeneousMediumSimple, true, kWg3PoolTrainT<0>, kWgBlockGuided, kWgWavesGuided, true);
+                else if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG3(HomogeneousMediumGreySceneNullZero, true, kWg3PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided, false);
+                else if (gwg) VSPG_LAUNCH_WG3(HomogeneousMediumSimple, true, kWg3PoolGuidedT<0>, kWgBlockGuided, kWgWavesGuided, false);
+                else if (uses_wg_full(r)) VSPG_LAUNCH_WG3(HomogeneousMedium, false, kWg3PoolFull, kWgBlockHomog, kWgWavesHomog, false);
+                else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG3(HomogeneousMediumGreySceneNullZero, false, kWg3PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog, false);
+                else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG3(HomogeneousMediumGreyScene, false, kWg3PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog, false);
+                else if (r->medium_grey) VSPG_LAUNCH_WG3(HomogeneousMediumGrey, false, kWg3PoolHomogT<1>, kWgBlockHomog, kWgWavesHomog, false);
+                else VSPG_LAUNCH_WG3(HomogeneousMediumSimple, false, kWg3PoolHomogT<0>, kWgBlockHomog, kWgWavesHomog, false);
+            } else
             if (gwg && train && guided_grey_simple(r))
                 hipLaunchKernelGGL((k_render_wave_wg2<HomogeneousMediumGreySceneNullZero, true, kWg2PoolTrainT<2>, kWgBlockGuided, kWgWavesGuided, true>), dim3((unsigned)wblocks),
                                    dim3(kWgBlockGuided), 0, (hipStream_t)stream, r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump,
@@ -3290,6 +3298,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             else if (r->medium_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGrey, false, kWg2PoolHomogT<1>, kWgBlockHomog, kWgWavesHomog);
             else VSPG_LAUNCH_WG2(HomogeneousMediumSimple, false, kWg2PoolHomogT<0>, kWgBlockHomog, kWgWavesHomog);
 #undef VSPG_LAUNCH_WG2
+#undef VSPG_LAUNCH_WG3
             HIPCHK(hipGetLastError());
             if (single) {  // this launch's samples are parked in ws_out (its predecessor's, if any were, have just been resolved)
                 r->ws_cur ^= 1;

@@ -57,8 +57,29 @@ struct ProfScope {
     }
 };
 #define VSPG_PROF(sec) ProfScope prof_scope_##sec(sec)
+// the same for a section a wavefront enters very often (the idle polls of k_render_wave_wg3): time summed in registers, one flush
+struct ProfAccum {
+    int sec;
+    unsigned long long t, n, t0;
+    __device__ __forceinline__ ProfAccum(int s) : sec(s), t(0), n(0), t0(0) {}
+    __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void end() { t += __builtin_amdgcn_s_memtime() - t0; n++; }
+    __device__ __forceinline__ ~ProfAccum() {
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&g_prof[sec][0], t);
+            atomicAdd(&g_prof[sec][1], 64ull * n);
+            atomicAdd(&g_prof[sec][2], n);
+        }
+    }
+};
+#define VSPG_PROF_ACC(name, sec) ProfAccum name(sec)
+#define VSPG_PROF_ACC_BEGIN(name) name.begin()
+#define VSPG_PROF_ACC_END(name) name.end()
 #else
 #define VSPG_PROF(sec)
+#define VSPG_PROF_ACC(name, sec)
+#define VSPG_PROF_ACC_BEGIN(name)
+#define VSPG_PROF_ACC_END(name)
 #endif
 
 // ---------------------------------------------------------------------------------------
