@@ -336,9 +336,13 @@ def add_sphere(scene, center, radius, material=0, iface=0, kd=(0.5, 0.5, 0.5), s
     m = np.eye(4, dtype=np.float32)
     m[0, 0], m[1, 1], m[2, 2] = scale
     m[0, 3], m[1, 3], m[2, 3] = center
-    inv = np.linalg.inv(m.astype(np.float64)).astype(np.float32)
     sp.render_from_object[:] = [float(x) for x in m.reshape(16)]
-    sp.object_from_render[:] = [float(x) for x in inv.reshape(16)]
+    # the inverse as the header and the scene-file reader form it (vspg_transform_inverse: pbrt's float Inverse(), transform.cpp):
+    # the same scaled sphere gets the same matrix bits -- and so the same interval-arithmetic hits -- whichever way it came in
+    inv = (C.c_float * 16)()
+    lib = load()
+    _check(lib, lib.vspg_transform_inverse(sp.render_from_object, inv))
+    sp.object_from_render[:] = list(inv)
     sp.radius = radius
     sp.Kd[:] = kd
     sp.reverse_orientation, sp.material, sp.medium_interface = reverse, material, iface

@@ -70,15 +70,6 @@ __device__ __forceinline__ void reset_sibling_head(unsigned int *work_head) {
 // LDS reads and ONE wait.  A 128-bit read is one LDS instruction: {reserved, committed, head} are a snapshot.
 typedef unsigned int w3_u32x4 __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) w3_u32x4 *w3_lds_v4;
-// committed entries of a queue that nobody has claimed; 0 while a push is between its reservation and its commit (a consumer
-// trusts entries only below a commit count it has seen EQUAL to the reserve count: every reservation below it has been written)
-VDEV int ring_avail(w3_u32x4 q) {
-    if (q.x != q.y) return 0;
-    const int a = (int)(q.y - q.z);
-    return a > 0 ? a : 0;
-}
-// claim n entries from `head` on: true if this wavefront got them
-VDEV bool ring_claim(unsigned int *qc, unsigned head, unsigned n) { return atomicCAS(qc + QC_HEAD, head, head + n) == head; }
 // Every lane hands its slot to the queue its path now belongs to (dq in [0, Q_COUNT), or -1: none): the four reservations are ONE
 // returning LDS atomic (lane q reserves for queue q), then the entries, then the four commits as one atomic.
 template <int NP>
@@ -100,14 +91,17 @@ VDEV void ring_push_all(int dq, unsigned entry, unsigned short (*ring)[NP], unsi
     if (lane < Q_COUNT && myn > 0u) atomicAdd(s_w + lane * QC_STRIDE + QC_COM, myn);
 }
 
+#ifndef VSPG_WG3_IDLE_SLEEP
+#define VSPG_WG3_IDLE_SLEEP 8   // s_sleep argument (x 64 clocks) of a wavefront that found no chunk twice in a row
+#endif
 #ifndef VSPG_WG3_NP_CAP
-#define VSPG_WG3_NP_CAP 640
+#define VSPG_WG3_NP_CAP 768
 #endif
 #ifndef VSPG_WG3_LDS_BUDGET
 #define VSPG_WG3_LDS_BUDGET 81920
 #endif
 #ifndef VSPG_WG3_OTHER
-#define VSPG_WG3_OTHER 5800   // scene records, counters, queue words beside the pool and the rings
+#define VSPG_WG3_OTHER 5200   // scene records, libm tables, counters, queue words beside the pool and the rings (5104 B measured)
 #endif
 // paths per pool: what fits the LDS a workgroup may use when two share a CU -- the record, four ring entries per path, `other`
 // bytes (scene records, counters, staged kd nodes); a multiple of 32
@@ -202,58 +196,77 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg3(
     while (true) {
         VSPG_PROF_ACC_BEGIN(prof_decide);
         VSPG_PROF_ACC_BEGIN(prof_idle);
-        // ---- this wavefront's next chunk (lane 0 decides) ----------------------------------------------
+        // ---- this wavefront's next chunk -----------------------------------------------------------------
+        // Every lane reads the same five 16-byte groups (an LDS broadcast) and readfirstlane makes scalars of them: the whole
+        // decision is SALU work -- the kernel is bound by vector issue, and a wavefront polls here while its siblings compute.
+        // Lane 0 performs the claims.  Order: a FULL chunk of one kind (volume vertices, surface vertices, segments, a fresh
+        // tile) before a vertex chunk mixed from both vertex queues, before partial chunks (only while their producers idle).
         unsigned kind = W3_NONE, pos0 = 0, n0 = 0, pos1 = 0, n1 = 0, q0 = Q_VV, tile = 0;
         {
-            if (lane == 0) {
-                const w3_lds_v4 qw = (w3_lds_v4)(s_w);
-                const w3_u32x4 wVV = qw[Q_VV], wVS = qw[Q_VS], wA = qw[Q_A], wF = qw[Q_F], wM = qw[Q_COUNT];
-                const unsigned hVV = wVV.z, hVS = wVS.z, hA = wA.z, hF = wF.z;
-                const unsigned busyS = wM.x, busyV = wM.y;
-                const bool exh = wM.z != 0u;
-                const int aVV = ring_avail(wVV), aVS = ring_avail(wVS), aA = ring_avail(wA), aF = exh ? 0 : ring_avail(wF);
-                const auto claim_vertex = [&](int a_first, unsigned h_first, unsigned q_first, int a_second, unsigned h_second, unsigned q_second) {
-                    // the larger queue first; a chunk it cannot fill takes the rest from the other one
-                    atomicAdd(s_w + W3_BUSY_V, 1u);
-                    const unsigned na = (unsigned)(a_first < 64 ? a_first : 64);
-                    if (na > 0u && ring_claim(s_w + q_first * QC_STRIDE, h_first, na)) {
-                        kind = W3_VERTEX; q0 = q_first; pos0 = h_first; n0 = na;
-                        const unsigned nb = (unsigned)(a_second < 64 - (int)na ? a_second : 64 - (int)na);
-                        if (nb > 0u && ring_claim(s_w + q_second * QC_STRIDE, h_second, nb)) { pos1 = h_second; n1 = nb; }
-                    } else {
-                        atomicSub(s_w + W3_BUSY_V, 1u);
-                    }
-                };
-                const int aV = aVV + aVS;
-                if (aV >= 64 || (aV > 0 && busyS == 0u)) {  // (a queue in the middle of a push counts as empty this time round)
-                    if (aVV >= aVS) claim_vertex(aVV, hVV, Q_VV, aVS, hVS, Q_VS);
-                    else claim_vertex(aVS, hVS, Q_VS, aVV, hVV, Q_VV);
+            const auto U = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+            const w3_lds_v4 qw = (w3_lds_v4)(s_w);
+            const w3_u32x4 wVV = qw[Q_VV], wVS = qw[Q_VS], wA = qw[Q_A], wF = qw[Q_F], wM = qw[Q_COUNT];
+            const unsigned hVV = U(wVV.z), hVS = U(wVS.z), hA = U(wA.z), hF = U(wF.z);
+            const unsigned busyS = U(wM.x), busyV = U(wM.y), live = U(wM.w);
+            const bool exh = U(wM.z) != 0u;
+            const auto avail = [&](w3_u32x4 q, unsigned head) {  // committed entries nobody has claimed; 0 while a push is between its reservation and its commit
+                const unsigned r = U(q.x), c = U(q.y);
+                const int a = (int)(c - head);
+                return r == c && a > 0 ? a : 0;
+            };
+            const int aVV = avail(wVV, hVV), aVS = avail(wVS, hVS), aA = avail(wA, hA), aF = exh ? 0 : avail(wF, hF);
+            const auto claim = [&](unsigned q, unsigned head, unsigned n) {  // compare-and-swap on the queue's head: this wavefront owns [head, head + n)
+                unsigned old = head + 1u;
+                if (lane == 0) old = atomicCAS(s_w + q * QC_STRIDE + QC_HEAD, head, head + n);
+                return U(old) == head;
+            };
+            const auto bump = [&](int w, int d) { if (lane == 0) atomicAdd(s_w + w, (unsigned)d); };
+            const auto claim_vertex = [&](int a_first, unsigned h_first, unsigned q_first, int a_second, unsigned h_second, unsigned q_second) {
+                // the larger queue first; a chunk it cannot fill takes the rest from the other one
+                bump(W3_BUSY_V, 1);
+                const unsigned na = (unsigned)(a_first < 64 ? a_first : 64);
+                if (na > 0u && claim(q_first, h_first, na)) {
+                    kind = W3_VERTEX; q0 = q_first; pos0 = h_first; n0 = na;
+                    const unsigned nb = (unsigned)(a_second < 64 - (int)na ? a_second : 64 - (int)na);
+                    if (nb > 0u && claim(q_second, h_second, nb)) { pos1 = h_second; n1 = nb; }
+                } else {
+                    bump(W3_BUSY_V, -1);
                 }
-                if (kind == W3_NONE && (aA >= 64 || (aA > 0 && busyV == 0u))) {
-                    atomicAdd(s_w + W3_BUSY_S, 1u);
-                    const unsigned na = (unsigned)(aA < 64 ? aA : 64);
-                    if (ring_claim(s_w + Q_A * QC_STRIDE, hA, na)) { kind = W3_SEGMENT; pos0 = hA; n0 = na; }
-                    else atomicSub(s_w + W3_BUSY_S, 1u);
+            };
+            const auto claim_segment = [&]() {
+                bump(W3_BUSY_S, 1);
+                const unsigned na = (unsigned)(aA < 64 ? aA : 64);
+                if (claim(Q_A, hA, na)) { kind = W3_SEGMENT; pos0 = hA; n0 = na; }
+                else bump(W3_BUSY_S, -1);
+            };
+            const int aV = aVV + aVS;
+            if (aVV >= 64) claim_vertex(aVV, hVV, Q_VV, 0, hVS, Q_VS);
+            else if (aVS >= 64) claim_vertex(aVS, hVS, Q_VS, 0, hVV, Q_VV);
+            else if (aA >= 64) claim_segment();
+            else if (aF >= 64) {
+                bump(W3_BUSY_S, 1);
+                bump(W3_LIVE, 64);  // BEFORE the tile is claimed: `live == 0` then says nobody can still start a path
+                if (claim(Q_F, hF, 64u)) {
+                    kind = W3_FRESH; pos0 = hF; n0 = 64u;
+                    if (lane == 0) tile = atomicAdd(work_head, 1u);
+                    tile = U(tile);
+                } else {
+                    bump(W3_LIVE, -64);
+                    bump(W3_BUSY_S, -1);
                 }
-                if (kind == W3_NONE && aF >= 64) {
-                    atomicAdd(s_w + W3_BUSY_S, 1u);
-                    atomicAdd(s_w + W3_LIVE, 64u);  // BEFORE the tile is claimed: `live == 0` then says nobody can still start a path
-                    if (ring_claim(s_w + Q_F * QC_STRIDE, hF, 64u)) {
-                        kind = W3_FRESH; pos0 = hF; n0 = 64u;
-                        tile = atomicAdd(work_head, 1u);
-                    } else {
-                        atomicSub(s_w + W3_LIVE, 64u);
-                        atomicSub(s_w + W3_BUSY_S, 1u);
-                    }
-                }
-                if (kind == W3_NONE && exh && wM.w == 0u) kind = W3_EXIT;
+            } else if (aV >= 64 || (aV > 0 && busyS == 0u)) {
+                if (aVV >= aVS) claim_vertex(aVV, hVV, Q_VV, aVS, hVS, Q_VS);
+                else claim_vertex(aVS, hVS, Q_VS, aVV, hVV, Q_VV);
+            } else if (aA > 0 && busyV == 0u) {
+                claim_segment();
+            } else if (exh && live == 0u) {
+                kind = W3_EXIT;
             }
-            kind = __builtin_amdgcn_readfirstlane(kind);
         }
         if (kind == W3_EXIT) break;
         if (kind == W3_NONE) {
-            if (idle_polls < 4u) __builtin_amdgcn_s_sleep(1);
-            else __builtin_amdgcn_s_sleep(4);
+            if (idle_polls < 2u) __builtin_amdgcn_s_sleep(2);
+            else __builtin_amdgcn_s_sleep(VSPG_WG3_IDLE_SLEEP);
             // (safety valve: a wavefront that has found nothing for ~10^7 polls -- seconds -- leaves instead of hanging the device;
             //  the launch's counters and film then show the loss)
             VSPG_PROF_ACC_END(prof_idle);
@@ -262,9 +275,6 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg3(
         }
         VSPG_PROF_ACC_END(prof_decide);
         idle_polls = 0;
-        pos0 = __builtin_amdgcn_readfirstlane(pos0); n0 = __builtin_amdgcn_readfirstlane(n0);
-        pos1 = __builtin_amdgcn_readfirstlane(pos1); n1 = __builtin_amdgcn_readfirstlane(n1);
-        q0 = __builtin_amdgcn_readfirstlane(q0); tile = __builtin_amdgcn_readfirstlane(tile);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         if (kind == W3_VERTEX) {

@@ -26,7 +26,7 @@ namespace vspg {
 // grey surfaces, of beta (GREY >= 2) -- see HomogeneousMediumT -- and the fields those instantiations do not store take no
 // room, so more paths fit the LDS a workgroup may use (the pool's size is what the phases' list lengths, i.e. the wavefronts'
 // occupancy with work, hang on: 320 -> 384 paths took the guided kernel from 2.14 to 1.86 ms per wave).
-//   unguided: 33 dwords generic, 29 with a grey medium, 27 with grey surfaces too;  guided: 37 / 33 / 31.
+//   unguided: 31 dwords generic, 27 with a grey medium, 25 with grey surfaces too;  guided: 37 / 33 / 31.
 template <bool GUIDED, int GREY, bool TRAIN = false, bool FULL = false>
 struct PoolLayout {
     static constexpr int RO = 0;                                  // 3
@@ -39,13 +39,16 @@ struct PoolLayout {
     static constexpr int PCQ = PCP + 3;                           // 1  ... its rectangle (int), -1 = medium vertex (exact point, n = 0)
     static constexpr int RNG = PCQ + 1;                           // 4  sampler PCG state / inc (2 x u64)
     static constexpr int FLAGS = RNG + 4;                         // 1  packed: depth, ch, bools, life cycle
-    static constexpr int RRC = FLAGS + 1;                         // 1  rr_correction
-    static constexpr int PIXEL = RRC + 1;                         // 1  pixel (x | y << 16)
+    // (round 5: two fields only guided builds read take no room elsewhere -- k_render_wave_wg3's chunks stay full by the pool's
+    //  slack over the workgroup's lanes, and at 25 dwords the headline instantiation holds 704 paths instead of 640)
+    static constexpr int RRC = FLAGS + 1;                         // 1  rr_correction: guided builds only (without the guiding cache it is
+                                                                  //    1 for the path's whole life: bs->pdf / bs->bsdfPdf of vertex_tail is x / x)
+    static constexpr int PIXEL = RRC + (GUIDED ? 1 : 0);          // 1  pixel (x | y << 16)
     static constexpr int SAMPLE = PIXEL + 1;                      // 1  sample index (int)
     static constexpr int VSP = SAMPLE + 1;                        // 1  isg.vsp_used (the primary VSP itself never leaves the primary phase)
     static constexpr int VXG = VSP + 1;                           // 1  vertex: volume: g; surface: rectangle index (int)
-    static constexpr int VXT = VXG + 1;                           // 1  vertex: surface tHit
-    static constexpr int GS = VXT + 1;                            // 1  guided builds: gs.vsp_next
+    static constexpr int VXT = VXG + 1;                           // 1  vertex: surface tHit: guided builds only (gbsdf.init's p = ray.o + tHit * ray.d)
+    static constexpr int GS = VXT + (GUIDED ? 1 : 0);             // 1  guided builds: gs.vsp_next
     // The vertex position lives only from the segment phase to the vertex phase, the ray origin only from the vertex phase to
     // the next segment phase (the unguided vertex code never reads the old origin): they share three dwords.  Guided builds:
     // gbsdf.init queries the cache at ray.o + tHit * ray.d (guiding.h:85), so the origin must survive.
@@ -173,7 +176,7 @@ VDEV void pool_store_full(const Pool &P, int slot, const PathState &st, const Sa
         P.f(LY::GS, slot) = st.gs.vsp_next;
     }
     P.u(LY::FLAGS, slot) = fl;
-    P.f(LY::RRC, slot) = st.rr_correction;
+    if constexpr (GUIDED) P.f(LY::RRC, slot) = st.rr_correction;
     P.f(LY::VSP, slot) = st.depth == 0 ? st.vsp0 : isg.vsp_used;
 }
 
@@ -182,7 +185,7 @@ VDEV void pool_store_vertex(const Pool &P, int slot, const Vertex &vx) {
     using LY = PoolLayout<GUIDED, GREY>;
     P.set3(LY::VXP, slot, vx.p);
     if (vx.volume) P.f(LY::VXG, slot) = vx.g; else P.i(LY::VXG, slot) = vx.quad;
-    P.f(LY::VXT, slot) = vx.t;
+    if constexpr (GUIDED) P.f(LY::VXT, slot) = vx.t;
 }
 // after li_segment_a: only what that half changes (L, beta, r_u, r_l, sampler, depth / ISG flags) plus
 // the vertex it stopped at; ray, previous context, rr_correction and guiding state are untouched
@@ -210,7 +213,7 @@ VDEV Vertex pool_load_vertex(const Pool &P, int slot, uint32_t fl) {
     vx.g = vx.volume ? P.f(LY::VXG, slot) : 0.f;
     vx.quad = vx.volume ? -1 : P.i(LY::VXG, slot);
     if constexpr (!FULL) __builtin_assume(vx.quad >= -1);
-    vx.t = P.f(LY::VXT, slot);
+    vx.t = GUIDED ? P.f(LY::VXT, slot) : 0.f;  // (unguided vertex code never reads the hit distance)
     return vx;
 }
 
@@ -241,7 +244,7 @@ VDEV uint32_t pool_load(const Pool &P, int slot, const DScene &S, PathState &st,
     st.lastVertexVolume = (fl & FL_LASTVOL) != 0;
     isg.valid = (fl & FL_ISG_VALID) != 0;
     isg.surface_event = (fl & FL_ISG_SURF) != 0;
-    st.rr_correction = P.f(LY::RRC, slot);
+    st.rr_correction = GUIDED ? P.f(LY::RRC, slot) : 1.f;
     st.etaScale = 1;
     const float v = P.f(LY::VSP, slot);
     st.vsp0 = v;
