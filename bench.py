@@ -273,6 +273,7 @@ def parse_args():
     ap.add_argument("--cloud-shape", choices=["noise", "blob"], default="noise",
                     help="cloud workloads: value noise filling the medium's bounds (default) or the same noise inside a ball with empty space around it")
     ap.add_argument("--no-pmc", action="store_true", help="skip the self-profiling child runs (roofline.issue_bound / live traffic)")
+    ap.add_argument("--no-fast-arith", action="store_true", help="skip the tolerance-mode leg (fast_arith)")
     ap.add_argument("--no-reference-defaults", action="store_true", help="skip the reference-default-options leg of the default line")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 watches: waves only, no output
     return ap.parse_args()
@@ -410,6 +411,7 @@ def main():
     segs_rank = cnt["segments"]
     paths_total, segs_total = sh.sum_over_ranks(dist, [paths_rank, segs_rank], world, "cuda")
     kernel_name = r.kernel_name()
+    vsp_trained = r.vsp_buffer(stream)[0].copy() if rank == 0 else None   # (the fast_arith leg loads it: no feedback from film statistics)
     r.close()
 
     if rank == 0:
@@ -535,6 +537,53 @@ def main():
                                             "kernel_ms": sum(a.elapsed_time(b) for a, b in gev) / 16, "kernel": g.kernel_name(),
                                             "note": "same scene through the instantiation a chromatic medium / coloured walls take"}
             g.close()
+        if args.workload in ("fog", "cloud", "cloud-scene") and not args.no_fast_arith and world == 1 and not diag:
+            # the tolerance-mode instantiations (csrc/vspg_arith.h): the same waves through vspg_renderer_set_arithmetic.  Untimed for
+            # `value` (that stays the bit-exact kernel).  relMSE against the EXACT film at equal spp with the same loaded VSP buffer (what
+            # each mode promises is in tests/test_fast_arith.py); flipped paths: replayed (pixel, sample) pairs whose radiance leaves
+            # the exact replay's by more than 1e-5 relative.
+            import numpy as np
+            n_meas = 16 if fog else 6
+            vsp_fixed = vsp_trained
+            rng = np.random.default_rng(11)
+            pix = np.stack([rng.integers(0, W, 20000), rng.integers(0, H, 20000)], axis=1).astype(np.int32)
+            si = rng.integers(0, 4096, 20000).astype(np.int32)
+            films, fa = {}, {}
+            Lx = None
+            for mode, label in ((pkg.ARITH_EXACT, "exact"), (pkg.ARITH_FAST_WEIGHTS, "fast_weights"), (pkg.ARITH_FAST, "fast")):
+                g = pkg.Renderer(scene, prm, W, H, spp=2 + n_meas, seed=0, device=local_rank)
+                g.load_vsp_buffer(vsp_fixed, stream)
+                g.set_arithmetic(mode)
+                for i in range(2):
+                    g.render_wave(i, i + 1, stream)
+                g.reset_counters(stream)
+                gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_meas)]
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                for i in range(n_meas):
+                    gev[i][0].record()
+                    g.render_wave(2 + i, 3 + i, stream)
+                    gev[i][1].record()
+                g.flush(stream)
+                torch.cuda.synchronize()
+                tg = time.perf_counter() - tg
+                paths_m = g.counters()["paths"]
+                films[label] = film_image(g.film())
+                Lg, sg = g.trace_paths(pix, si)
+                if mode == pkg.ARITH_EXACT:
+                    Lx, sx = Lg, sg
+                fa[label] = {"value": paths_m / tg / 1e6, "unit": "Mpaths/s", "steps": n_meas, "ms_per_step": tg / n_meas * 1e3,
+                             "kernel_ms": sum(a.elapsed_time(b) for a, b in gev) / n_meas, "kernel": g.kernel_name()}
+                if mode != pkg.ARITH_EXACT:
+                    ix = films["exact"]
+                    fa[label]["relmse_vs_exact"] = float(((films[label] - ix) ** 2 / (ix ** 2 + RELMSE_EPS)).mean())
+                    fa[label]["flipped_path_frac"] = float(1.0 - np.mean(np.all(np.abs(Lg - Lx) <= 1e-5 * (np.abs(Lx) + 1e-3), axis=1)))
+                    fa[label]["same_segment_count_frac"] = float(np.mean(sg == sx))
+                g.close()
+            fa["note"] = ("csrc/vspg_arith.h: fast_weights = contribution-only quotients through v_rcp_f32 (trajectories stay exact); fast = every division / sqrt "
+                          "at 2.5 ulp + native log / sin / cos (equal in distribution only: the reference seeds shadow-ray RNGs from position bits, :1193). "
+                          "%d spp, VSP buffer loaded (no feedback); kernel_ms = HIP-event time of vspg_render_wave (the whole pipeline pass for the cloud workloads)" % (2 + n_meas))
+            out["fast_arith"] = fa
         if args.workload == "fog" and not args.no_reference_defaults and world == 1 and not diag:
             # the configuration a `guidedvolpathvspg` user gets by default (:1263-1319): directional guiding + secondary-ray VSP,
             # i.e. the cache query in the loop.  The field trains in-loop for the first waves, like the reference's first 128.

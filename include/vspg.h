@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSPG_ABI_VERSION 6
+#define VSPG_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define VSPG_OK 0
@@ -382,6 +382,22 @@ int vspg_renderer_set_exchange(VspgRenderer *r, VspgExchangeFn fn, void *user);
 /* Name of the kernel instantiation vspg_render_wave launches for this renderer as it stands (bench / profile
  * bookkeeping; static storage). */
 const char *vspg_renderer_kernel_name(VspgRenderer *r);
+
+/* The arithmetic the path kernels compute in (ABI 7; csrc/vspg_arith.h).  The reference has no such switch: its float arithmetic is
+ * what its compiler makes of src/pbrt/util/sampling.h:222-225, media_sampleTMaj.h:379-404 ... -- IEEE division, glibc's libm.
+ *   VSPG_ARITH_EXACT         (default) that arithmetic bit for bit: the mode every parity test and the benchmark's `value` run in;
+ *   VSPG_ARITH_FAST_WEIGHTS  quotients that only scale a path's contribution through v_rcp_f32; every path keeps the oracle's
+ *                            trajectory, radiance agrees to float rounding (relMSE vs the exact film ~1e-13);
+ *   VSPG_ARITH_FAST          every division / square root at 2.5 ulp, the hardware's log / sin / cos: the same estimator, but not the
+ *                            oracle's paths (the reference seeds a shadow ray's RNG from the bits of its origin and direction,
+ *                            guidedvolpathvspgintegrator.cpp:1193) -- equal in distribution, validated statistically.
+ * Returns VSPG_ESCOPE (and names the kernel) for configurations without tolerance-mode instantiations: they cover unguided renders of
+ * rectangle scenes over a homogeneous medium and unguided "resampling" renders over a "uniformgrid" medium. */
+#define VSPG_ARITH_EXACT 0
+#define VSPG_ARITH_FAST_WEIGHTS 1
+#define VSPG_ARITH_FAST 2
+int vspg_renderer_set_arithmetic(VspgRenderer *r, int mode);
+int vspg_renderer_get_arithmetic(VspgRenderer *r);
 
 /* Film access.  The film is W*H float4 {sum w*r, sum w*g, sum w*b, sum w} in HBM
  * (the accumulate contract of RGBFilm::AddSample, src/pbrt/film.h:251-267, in float).

@@ -15,7 +15,9 @@ for f in glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv"), rec
     for r in rows:
         if int(r["Dispatch_Id"]) <= last_train and ("k_render_wave" in r["Kernel_Name"] or "k_wf_" in r["Kernel_Name"]):
             continue
-        k = re.sub(r"\(anonymous namespace\)::|vspg::", "", re.sub(r"^void ", "", r["Kernel_Name"])).split("(")[0]
+        k = re.sub(r"\(anonymous namespace\)::|vspg::(?:fastw::|fast::)?", "", re.sub(r"^void ", "", r["Kernel_Name"])).split("(")[0]
+        if "::fastw::" in r["Kernel_Name"] or "::fast::" in r["Kernel_Name"]:  # the tolerance-mode instantiations (csrc/vspg_arith.h) under their own names
+            k = k.split("<")[0] + (".fastw" if "::fastw::" in r["Kernel_Name"] else ".fast") + k[len(k.split("<")[0]):]
         tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[k][r["Counter_Name"]] += 1
 G = lambda m, c: m.get(c, 0.0) / waves

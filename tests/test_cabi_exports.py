@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
     assert {n for n, _, _ in pkg.SYMBOLS} == set(names)
-    assert lib.vspg_abi_version() == 6
+    assert lib.vspg_abi_version() == 7
 
 
 def test_rccl_library_exports_every_declared_symbol(pkg):

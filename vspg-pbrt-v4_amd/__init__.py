@@ -26,6 +26,7 @@ LIGHTSAMPLER_UNIFORM, LIGHTSAMPLER_POWER, LIGHTSAMPLER_BVH = 0, 1, 2
 TMAJ_PLAIN, TMAJ_OPTICAL_DEPTH, TMAJ_RESAMPLING = 0, 1, 2
 
 VSPG_OK, VSPG_EINVAL, VSPG_ENODEVICE, VSPG_EHIP, VSPG_ESCOPE = 0, -1, -2, -3, -4
+ARITH_EXACT, ARITH_FAST_WEIGHTS, ARITH_FAST = 0, 1, 2
 
 f3 = C.c_float * 3
 
@@ -175,6 +176,8 @@ SYMBOLS = [
     ("vspg_post_process_step", C.c_int, [_vp, C.c_int, _vp, _vp]),
     ("vspg_renderer_set_exchange", C.c_int, [_vp, _vp, _vp]),
     ("vspg_renderer_kernel_name", C.c_char_p, [_vp]),
+    ("vspg_renderer_set_arithmetic", C.c_int, [_vp, C.c_int]),
+    ("vspg_renderer_get_arithmetic", C.c_int, [_vp]),
     ("vspg_flush", C.c_int, [_vp, _vp]),
     ("vspg_film_device_ptr", C.c_int, [_vp, _P(_vp), _P(C.c_size_t)]),
     ("vspg_film_read", C.c_int, [_vp, _P(C.c_float), _vp]),
@@ -486,6 +489,13 @@ class Renderer:
 
     def kernel_name(self):
         return (self.lib.vspg_renderer_kernel_name(self.h) or b"").decode()
+
+    def set_arithmetic(self, mode):
+        """ARITH_EXACT (default) / ARITH_FAST_WEIGHTS / ARITH_FAST (include/vspg.h, csrc/vspg_arith.h)."""
+        _check(self.lib, self.lib.vspg_renderer_set_arithmetic(self.h, int(mode)))
+
+    def arithmetic(self):
+        return int(self.lib.vspg_renderer_get_arithmetic(self.h))
 
     def post_process_wave(self, stream=None):
         _check(self.lib, self.lib.vspg_post_process_wave(self.h, _vp(stream or 0)))

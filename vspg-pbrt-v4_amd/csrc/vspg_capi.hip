@@ -18,6 +18,7 @@
 #include "vspg_wg_kernel.h"
 #include "vspg_guided_wg.h"
 #include "vspg_wg3.h"
+#include "vspg_trace.h"
 #include "vspg_wavefront.h"
 #include "vspg_wf_launch.h"
 #ifdef VSPG_SINGLE_TU  // diagnostic builds that read device-side globals of the pipeline kernels (VSPG_WF_STATS, VSPG_PROFILE, VSPG_WF_DEBUG)
@@ -56,12 +57,6 @@ __device__ __forceinline__ void flush_counters(const PC &pc, uint32_t paths, uns
     atomicAdd(&s[6], pc.shadow_queries);
     __syncthreads();
     if (threadIdx.x < kNumCounters) atomicAdd(&g[threadIdx.x], (unsigned long long)s[threadIdx.x]);
-}
-
-// guided RR (:274-285): the pixel's contribution estimate, once the image-space buffer is ready
-__device__ __forceinline__ void load_contribution_estimate(const DScene &S, int px, int py, PathState &st) {
-    st.guideRR = S.prm.rrguiding && S.contrib_ready;
-    st.pce = st.guideRR ? S.contrib[(size_t)py * S.xres + px] : 0.f;
 }
 
 // (reset_sibling_head -- the pair of global work heads used by alternate launches -- lives in vspg_wg3.h)
@@ -717,7 +712,6 @@ constexpr int kWg2PoolFull = wg_pool_paths<PoolLayout<false, 0, false, true>>(10
 template <int GREY> constexpr int kWg2PoolGuidedT = GREY >= 2 ? (VSPG_WGG_NP_G2) : (VSPG_WGG_NP_G0);
 template <int GREY> constexpr int kWg2PoolTrainT = wg_pool_paths<PoolLayout<true, GREY, true>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8);  // + the recorder's state
 // k_render_wave_wg3 (vspg_wg3.h): pools LARGER than the workgroup has lanes -- the slack is what keeps its chunks full
-template <int GREY> constexpr int kWg3PoolHomogT = wg3_pool_paths<PoolLayout<false, GREY>>(VSPG_WG3_OTHER);
 constexpr int kWg3PoolFull = wg3_pool_paths<PoolLayout<false, 0, false, true>>(VSPG_WG3_OTHER);
 template <int GREY> constexpr int kWg3PoolGuidedT = wg3_pool_paths<PoolLayout<true, GREY>>(VSPG_WG3_OTHER + 2 * kKdLdsNodes * 8);
 template <int GREY> constexpr int kWg3PoolTrainT = wg3_pool_paths<PoolLayout<true, GREY, true>>(VSPG_WG3_OTHER + 2 * kKdLdsNodes * 8);
@@ -1379,34 +1373,7 @@ __global__ __launch_bounds__(kBlock) void k_film_resolve(size_t npix, const floa
     resolve_sample(wave_samples[i], film + i, isg_stats + i * VSPG_ISG_STATS);
 }
 
-template <class Medium, bool GUIDED>
-__global__ __launch_bounds__(kBlock) void k_trace_paths(const DScene *__restrict__ Sp, const float *__restrict__ vsp_buf,
-                                                        int vsp_ready, int n, const int32_t *__restrict__ pixel_xy,
-                                                        const int32_t *__restrict__ sample_index, float *__restrict__ out_L,
-                                                        int32_t *__restrict__ out_seg) {
-    const DScene &S = *Sp;
-    stage_scene_lds(S);
-    __syncthreads();
-    int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const Medium medium = MediumMaker<Medium>::make(S, S.majorant);
-    int px = pixel_xy[2 * i], py = pixel_xy[2 * i + 1];
-    PathCounters pc = {0, 0, 0, 0, 0};
-    Sampler sampler;
-    PathState st;
-    IsgSample isg;
-    int ch;
-    float *glds = nullptr;
-    if constexpr (GUIDED) glds = guide_lds();
-    start_path(S, vsp_buf, vsp_ready, px, py, sample_index[i], sampler, st, &ch, isg);
-    if constexpr (GUIDED) load_contribution_estimate(S, px, py, st);
-    while (li_segment<Medium, GUIDED>(S, medium, vsp_buf, vsp_ready, px, py, st, ch, sampler, isg, pc, glds, kBlock)) {
-    }
-    Spec L = finish_radiance(st.L);
-    out_L[3 * i] = L.r; out_L[3 * i + 1] = L.g; out_L[3 * i + 2] = L.b;
-    if (out_seg) out_seg[i] = (int32_t)pc.segments;
-}
-
+// (k_trace_paths: vspg_trace.h)
 template <class Medium>
 __global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict__ Sp, int variant, int n,
                                                        const VspgTmajQuery *__restrict__ q, VspgTmajResult *__restrict__ out) {
@@ -1623,6 +1590,8 @@ struct VspgRenderer {
     VspgScene scene;
     VspgIntegratorParams prm;
     VspgRenderConfig cfg;
+    int arith = VSPG_ARITH_EXACT;   // vspg_renderer_set_arithmetic (vspg_arith.h): which instantiations the path kernels are launched from
+    std::string kernel_name_buf;
     DScene hscene;
     DScene *dscene = nullptr;
     float4 *film = nullptr;
@@ -2549,7 +2518,11 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
     L.maxdepth = r->prm.maxdepth;
     L.base_iters = base_iters;
     L.max_iters = max_iters;
-    const int rc = nvdb ? wf_dispatch_nvdb(L, guided, train, grey) : wf_dispatch_grid(L, guided, train, grey);
+    // (tolerance modes: vspg_renderer_set_arithmetic accepted the renderer only if vspg_fast.hip holds its instantiation)
+    const int rc = r->arith == VSPG_ARITH_FAST_WEIGHTS ? vspg_arith1_wf_grid(&L, grey ? 1 : 0)
+                   : r->arith == VSPG_ARITH_FAST     ? vspg_arith2_wf_grid(&L, grey ? 1 : 0)
+                   : nvdb                            ? wf_dispatch_nvdb(L, guided, train, grey)
+                                                     : wf_dispatch_grid(L, guided, train, grey);
     if (rc == WF_E_NOT_DRAINED)
         return fail(VSPG_ESCOPE, "paths still alive after the pipeline's iteration cap: more medium-boundary crossings per vertex than a pass provides for");
     if (rc != 0) return fail(VSPG_EHIP, std::string("the wavefront pipeline: ") + hipGetErrorName((hipError_t)rc));
@@ -3080,6 +3053,13 @@ static bool uses_wg3(const VspgRenderer *r) {
     const char *e = getenv("VSPG_WG_SCHED");
     return !(e && e[0] == '2');
 }
+static bool arith_covered(const VspgRenderer *r) {
+    if (kernel_env() || getenv("VSPG_WG_SCHED")) return false;  // (the cross-check kernels exist in exact arithmetic only)
+    if (wants_guiding(r->prm) || r->hscene.tr_calc) return false;
+    if (uses_wf_pipeline(r))
+        return r->scene.medium.type == VSPG_MEDIUM_GRID && r->prm.vspsamplingmethod == VSPG_VSP_RESAMPLING && r->hscene.temperature == nullptr;
+    return uses_wg3(r) && !uses_wg_guided(r) && !uses_wg_full(r);
+}
 // The samples a one-sample wg2 launch parked are resolved by the next such launch; anything else that reads or writes the film or
 // the image-space statistics calls this first (VSPG_WG2_DEFER=0: every launch resolves its own samples at once).
 static bool wg2_defer_enabled() {  // (read per launch: a test flips it)
@@ -3100,8 +3080,27 @@ static int flush_parked_samples(VspgRenderer *r, hipStream_t s) {
     r->ws_parked = false;
     return 0;
 }
+static const char *kernel_name_exact(VspgRenderer *r);
 const char *vspg_renderer_kernel_name(VspgRenderer *r) {
     if (!r) return "";
+    if (r->arith == VSPG_ARITH_EXACT) return kernel_name_exact(r);
+    r->kernel_name_buf = std::string(r->arith == VSPG_ARITH_FAST_WEIGHTS ? "fastw::" : "fast::") + kernel_name_exact(r);  // (the inline namespace of vspg_fast.hip's symbols)
+    return r->kernel_name_buf.c_str();
+}
+// Which instantiations a renderer's path kernels are launched from (vspg_arith.h).  The tolerance modes exist for the unguided
+// rectangle-scene workgroup kernel and the unguided resampling pipeline over GridMedium; anything else is refused by name.
+static bool arith_covered(const VspgRenderer *r);
+int vspg_renderer_set_arithmetic(VspgRenderer *r, int mode) {
+    if (!r) return fail(VSPG_EINVAL, "null renderer");
+    if (mode != VSPG_ARITH_EXACT && mode != VSPG_ARITH_FAST_WEIGHTS && mode != VSPG_ARITH_FAST) return fail(VSPG_EINVAL, "unknown arithmetic mode");
+    if (mode != VSPG_ARITH_EXACT && !arith_covered(r))
+        return fail(VSPG_ESCOPE, "the tolerance-mode instantiations cover unguided renders of rectangle scenes over a homogeneous medium and unguided "
+                                 "\"resampling\" renders over a uniformgrid medium (this renderer runs " + std::string(kernel_name_exact(r)) + ")");
+    r->arith = mode;
+    return 0;
+}
+int vspg_renderer_get_arithmetic(VspgRenderer *r) { return r ? r->arith : VSPG_EINVAL; }
+static const char *kernel_name_exact(VspgRenderer *r) {
     const bool grid = r->scene.medium.type == VSPG_MEDIUM_GRID, nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
     const bool guided = wants_guiding(r->prm);
     if (uses_wf_pipeline(r) && r->prm.vspsamplingmethod != VSPG_VSP_RESAMPLING) {
@@ -3277,10 +3276,14 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
                 else if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG3(HomogeneousMediumGreySceneNullZero, true, kWg3PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided, false);
                 else if (gwg) VSPG_LAUNCH_WG3(HomogeneousMediumSimple, true, kWg3PoolGuidedT<0>, kWgBlockGuided, kWgWavesGuided, false);
                 else if (uses_wg_full(r)) VSPG_LAUNCH_WG3(HomogeneousMedium, false, kWg3PoolFull, kWgBlockHomog, kWgWavesHomog, false);
-                else if (r->medium_grey && r->surfaces_grey && r->null_zero) VSPG_LAUNCH_WG3(HomogeneousMediumGreySceneNullZero, false, kWg3PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog, false);
-                else if (r->medium_grey && r->surfaces_grey) VSPG_LAUNCH_WG3(HomogeneousMediumGreyScene, false, kWg3PoolHomogT<2>, kWgBlockHomog, kWgWavesHomog, false);
-                else if (r->medium_grey) VSPG_LAUNCH_WG3(HomogeneousMediumGrey, false, kWg3PoolHomogT<1>, kWgBlockHomog, kWgWavesHomog, false);
-                else VSPG_LAUNCH_WG3(HomogeneousMediumSimple, false, kWg3PoolHomogT<0>, kWgBlockHomog, kWgWavesHomog, false);
+                else {  // the unguided rectangle-scene instantiations (the headline workload): also built in the tolerance modes
+                    static_assert(kWgBlockHomog == VSPG_WG_BLOCK && kWgWavesHomog == VSPG_WG_WAVES, "wg3_launch_unguided's launch shape");
+                    const Wg3Launch L3{r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, work_head, ws_prev, ws_out,
+                                       r->counters, (unsigned)wblocks, (hipStream_t)stream, r->medium_grey ? (r->surfaces_grey ? 2 : 1) : 0,
+                                       r->medium_grey && r->surfaces_grey && r->null_zero ? 1 : 0};
+                    const int lrc = r->arith == VSPG_ARITH_FAST_WEIGHTS ? vspg_arith1_wg3(&L3) : r->arith == VSPG_ARITH_FAST ? vspg_arith2_wg3(&L3) : wg3_launch_unguided(L3);
+                    if (lrc != 0) return fail(VSPG_EHIP, std::string("k_render_wave_wg3: ") + hipGetErrorName((hipError_t)lrc));
+                }
             } else
             if (gwg && train && guided_grey_simple(r))
                 hipLaunchKernelGGL((k_render_wave_wg2<HomogeneousMediumGreySceneNullZero, true, kWg2PoolTrainT<2>, kWgBlockGuided, kWgWavesGuided, true>), dim3((unsigned)wblocks),
@@ -3615,6 +3618,11 @@ int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy, const int3
     hipLaunchKernelGGL((k_trace_paths<M, G>), dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, r->dscene, r->vsp, \
                        r->vsp_ready | VSP_NO_FEED, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p)
     const bool nvdb = r->scene.medium.type == VSPG_MEDIUM_NANOVDB;
+    if (r->arith != VSPG_ARITH_EXACT) {  // the replay in the renderer's arithmetic (set_arithmetic accepted unguided homogeneous / uniformgrid only)
+        const TraceLaunch T{r->dscene, r->vsp, r->vsp_ready | VSP_NO_FEED, n, (const int32_t *)dp.p, (const int32_t *)ds.p, (float *)dl.p, (int32_t *)dg.p, s, grid ? 1 : 0};
+        const int trc = r->arith == VSPG_ARITH_FAST_WEIGHTS ? vspg_arith1_trace(&T) : vspg_arith2_trace(&T);
+        if (trc != 0) return fail(VSPG_EHIP, std::string("k_trace_paths: ") + hipGetErrorName((hipError_t)trc));
+    } else
     if (nvdb && guided) VSPG_LAUNCH_TRACE(NanoDenseMedium, true);
     else if (nvdb) VSPG_LAUNCH_TRACE(NanoDenseMedium, false);
     else if (grid && guided) VSPG_LAUNCH_TRACE(GridMedium, true);

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/vspg.h"
+#include "vspg_arith.h"
 #include "vspg_libm.h"
 
 #define VDEV __device__ __forceinline__
@@ -31,7 +32,7 @@ __device__ unsigned int g_dbg_err[8];
 #define VLEAF __device__ __forceinline__
 #endif
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 // ---------------------------------------------------------------------------------------
 // diagnostic build only (-DVSPG_PROFILE, csrc/Makefile target `prof`): per-section wave time,
@@ -170,12 +171,38 @@ VDEV Spec operator/(Spec a, float f) {
     }
     return Spec{a.r / f, a.g / f, a.b / f};
 }
+// ---- WEIGHT quotients (vspg_arith.h) -------------------------------------------------------------------------------------
+// wdiv(a, b) is a / b at a site whose result only scales a path's contribution (throughput, MIS weights, pdfs, reservoir and
+// roulette probabilities): never a distance, a direction or a point.  kArith == 0: the IEEE division the reference performs, bit
+// for bit.  kArith >= 1: a * v_rcp_f32(b) (1 ulp reciprocal; the same special cases: x / 0 = inf, 0 / 0 = nan, x / inf = 0).
+constexpr int kArith = VSPG_ARITH;
+VDEV float wrcp(float b) {
+    if constexpr (kArith >= 1) return __builtin_amdgcn_rcpf(b);
+    else return 1 / b;
+}
+VDEV float wdiv(float a, float b) {
+    if constexpr (kArith >= 1) return a * __builtin_amdgcn_rcpf(b);
+    else return a / b;
+}
+VDEV Spec wdiv(Spec a, float f) {
+    if constexpr (kArith >= 1) {
+        const float r = __builtin_amdgcn_rcpf(f);
+        return Spec{a.r * r, a.g * r, a.b * r};
+    } else {
+        return a / f;
+    }
+}
+VDEV Spec wdiv(Spec a, Spec b) {
+    if constexpr (kArith >= 1) return Spec{a.r * __builtin_amdgcn_rcpf(b.r), a.g * __builtin_amdgcn_rcpf(b.g), a.b * __builtin_amdgcn_rcpf(b.b)};
+    else return a / b;
+}
 VDEV bool nonzero(Spec a) { return a.r != 0 || a.g != 0 || a.b != 0; }  // spectrum.h:263-268
-VDEV float avg(Spec a) {  // spectrum.h:288-294
+VDEV float avg(Spec a) {  // spectrum.h:288-294 (its callers weigh and decide with it: MIS weights, Russian roulette)
     float s = a.r;
     s += a.g;
     s += a.b;
-    return s / 3;
+    if constexpr (kArith >= 1) return s * 0.333333343f;
+    else return s / 3;
 }
 VDEV float maxc(Spec a) { return fmax_(fmax_(a.r, a.g), a.b); }
 VDEV Spec clamp_zero(Spec a) { return Spec{fmax_(0.f, a.r), fmax_(0.f, a.g), fmax_(0.f, a.b)}; }
@@ -309,10 +336,23 @@ struct Sampler {
 // libm: float functions reproduce the host glibc bit for bit (vspg_libm.h); the reference's
 // `std::log(1.0 - x)` in media_sampleTMaj.h is DOUBLE precision -> the double log of vspg_libm.h, rounded once
 // ---------------------------------------------------------------------------------------
-VLEAF float logf_(float x) { return vspg_libm::logf_host_exact(x); }
-VLEAF float sinf_(float x) { return vspg_libm::sinf_host_exact(x); }
-VLEAF float cosf_(float x) { return vspg_libm::cosf_host_exact(x); }
-VLEAF float neg_log1m_d(float x) { return (float)(-vspg_libm::log_host_exact(1.0 - (double)x)); }  // -std::log(1.0 - x)
+// (kArith == 2, vspg_arith.h: the hardware's v_log_f32 / v_sin_f32 / v_cos_f32 -- 1 ulp log2, sin / cos of an argument in turns)
+VLEAF float logf_(float x) {
+    if constexpr (kArith >= 2) return __builtin_amdgcn_logf(x) * 0.693147182f;
+    else return vspg_libm::logf_host_exact(x);
+}
+VLEAF float sinf_(float x) {
+    if constexpr (kArith >= 2) return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.159154937f));
+    else return vspg_libm::sinf_host_exact(x);
+}
+VLEAF float cosf_(float x) {
+    if constexpr (kArith >= 2) return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * 0.159154937f));
+    else return vspg_libm::cosf_host_exact(x);
+}
+VLEAF float neg_log1m_d(float x) {  // -std::log(1.0 - x)
+    if constexpr (kArith >= 2) return -(__builtin_amdgcn_logf(1 - x) * 0.693147182f);
+    else return (float)(-vspg_libm::log_host_exact(1.0 - (double)x));
+}
 
 // ---------------------------------------------------------------------------------------
 // a3: FastExp / SampleExponential / SampleDiscrete
@@ -381,7 +421,7 @@ VDEV float henyey_greenstein(float cosTheta, float g) {  // scattering.h:50-59
     if (g == 0.f && __builtin_fabsf(cosTheta) < kInf) return kInv4Pi;
     g = clampf(g, (float)-.99, (float).99);
     float denom = 1 + sqr(g) + 2 * g * cosTheta;
-    return kInv4Pi * (1 - sqr(g)) / (denom * safe_sqrt(denom));
+    return wdiv(kInv4Pi * (1 - sqr(g)), denom * safe_sqrt(denom));
 }
 VDEV void coordinate_system(V3 v1, V3 *v2, V3 *v3) {  // vecmath.h:1007-1013
     float sign = __builtin_copysignf(1.f, v1.z);
@@ -1661,7 +1701,7 @@ VDEV Spec sample_T_maj_resampling(const Medium &medium, V3 ro, V3 rd, float tMax
             totalLength = minTotalLength;
         }
         float expNegTotalLength = fast_exp(-totalLength);
-        *vrc = vsp / (1 - expNegTotalLength);
+        *vrc = wdiv(vsp, 1 - expNegTotalLength);
     }
     Spec T_maj = sp(1.f);
     bool done = false;
@@ -1708,7 +1748,7 @@ VDEV Spec sample_T_maj_resampling(const Medium &medium, V3 ro, V3 rd, float tMax
 // a8: SampleT_maj_OpticalDepthSpace (media_sampleTMaj.h:269-491)
 // ---------------------------------------------------------------------------------------
 VDEV Spec ruf_from(float alpha, Spec tp) {  // SampledSpectrum(a)/tp + SampledSpectrum(1-a)
-    return sp(alpha) / tp + sp(1 - alpha);
+    return wdiv(sp(alpha), tp) + sp(1 - alpha);
 }
 template <class Medium, class F>
 VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float u, Rng &rng, int ch,
@@ -1821,9 +1861,9 @@ VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float
             if (NDS || !passThrough) tpScale = tpScale * tpStep;
             if (passThrough) {
                 if (NDS) {
-                    tpScale = tpScale / (1.0f - fast_exp(-t_n + t_v));
+                    tpScale = wdiv(tpScale, 1.0f - fast_exp(-t_n + t_v));
                 } else {
-                    tpScale = tpScale * (fast_exp(nMaj * -t_v_current) / (1 - vsp));
+                    tpScale = tpScale * wdiv(fast_exp(nMaj * -t_v_current), 1 - vsp);
                 }
                 *r_u_factor = ruf_from(alpha, tpScale);
                 overTheEnd = true;
@@ -1863,4 +1903,4 @@ VDEV Spec sample_T_maj_ods(const Medium &medium, V3 ro, V3 rd, float tMax, float
     return sp(1.f);
 }
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg

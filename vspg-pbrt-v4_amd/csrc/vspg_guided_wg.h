@@ -19,7 +19,7 @@
 #pragma once
 #include "vspg_wg_kernel.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 // DField::lobes, per region 1 + 2 GK float4:  [0] {pivot, n_lobes (int bits)}   [1 + 2k] {mu_k, distance_k}   [2 + 2k] {weight_k, b_k, kappa_k (clamped), vsp_k}
 constexpr int kRegionLobeQuads = 1 + 2 * GK;
@@ -524,4 +524,4 @@ VDEV bool li_vertex_guided_wg(const DScene &S, const Medium &medium, const Pool 
     return true;
 }
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg

@@ -16,7 +16,7 @@
 #pragma once
 #include "vspg_device.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 constexpr int GK = VSPG_FIELD_LOBES;
 constexpr float kTwoPi = 6.28318530717958647692f;
@@ -384,4 +384,4 @@ struct GuideState {
     float vsp_next;
 };
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg

@@ -10,7 +10,7 @@
 #pragma once
 #include "vspg_device.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 // lightSampler.Sample(ctx, u) where the pick is not uniform: p = ctx.p(), n = ctx.ns (0 at a medium vertex)
 VDEV float light_importance(const DLightNode &nd, V3 p, V3 n) {  // CompactLightBounds::Importance (lightsamplers.h:144-206)
@@ -142,4 +142,4 @@ VDEV float light_sampler_pmf(const DScene &S, V3 p, V3 n, int lightIndex) {
     return pm;
 }
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg

@@ -8,7 +8,7 @@
 #include "vspg_lightsampler.h"
 #include "vspg_train.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 // ---------------------------------------------------------------------------------------
 // DiffuseBxDF behind BSDF (src/pbrt/bxdfs.h:31-80, src/pbrt/bsdf.h:20-88)
@@ -96,14 +96,14 @@ VDEV bool light_sample_li(const DQuad &q, V3 ctxp, float u0, float u1, LightLi *
     V3 c = cross(dpdu, dpdv);
     V3 n = normalize(c);
     if (dot(n, ld3(q.n)) < 0) n = -n;  // reverseOrientation
-    float pdf = 1 / len(c);
+    float pdf = wrcp(len(c));
     P3i pint = p3i_from_err(p, ld3(q.perr));
     p = pint.mid();
     V3 wi = p - ctxp;
     if (len2(wi) == 0) return false;
     wi = normalize(wi);
     V3 d = ctxp - p;
-    pdf /= absdot(n, -wi) / len2(d);
+    pdf = wdiv(pdf, wdiv(absdot(n, -wi), len2(d)));
     if (isinf_(pdf)) return false;
     if (pdf == 0) return false;
     Spec Le = light_L(q, n, -wi);
@@ -173,7 +173,7 @@ VDEV float light_pdf_li(const DQuad &q, const LsCtx &ctx, V3 wi) {  // shapes.cp
     if (!quad_intersect(q, o, wi, kInf, &t, &p)) return 0;
     p = p3i_from_err(p, ld3(q.perr)).mid();
     V3 d = ctx.pi.mid() - p;
-    float pdf = (1 / q.area) * (len2(d) / absdot(ld3(q.n), -wi));
+    float pdf = wrcp(q.area) * wdiv(len2(d), absdot(ld3(q.n), -wi));
     return isinf_(pdf) ? 0 : pdf;
 }
 
@@ -263,7 +263,7 @@ template <int GREY>
 VDEV Spec mul_tmaj_ratio(Spec v, Spec T_maj, int ch) {
     const float tm = ch_of(T_maj, ch);
     if (GREY >= 1 && tm > 0.f && tm < kInf) return v;
-    return v * (T_maj / tm);
+    return v * wdiv(T_maj, tm);
 }
 // sample_Ld from the shadow ray on (:1190-1251): lightRay = intr.SpawnRayTo(ls->pLight), the ratio-tracked transmittance,
 // the estimate.  (Its own function since round 3: the workgroup kernel's guided vertex runs the two halves of sample_Ld at
@@ -294,16 +294,16 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
             }
         }
         Spec sigma_n = medium.sigma_n(mp, sigma_maj);
-        T_ray = T_ray * (T_maj * sigma_n / pdf);
-        r_l = r_l * (T_maj * sigma_maj / pdf);
-        r_u = r_u * (T_maj * sigma_n / pdf);
-        Spec Tr = T_ray / avg(r_l + r_u);
+        T_ray = T_ray * wdiv(T_maj * sigma_n, pdf);
+        r_l = r_l * wdiv(T_maj * sigma_maj, pdf);
+        r_u = r_u * wdiv(T_maj * sigma_n, pdf);
+        Spec Tr = wdiv(T_ray, avg(r_l + r_u));
         if (maxc(Tr) < 0.05f) {
             float q = 0.75f;
             if (rng.uniform() < q)
                 T_ray = sp(0.f);
             else
-                T_ray = T_ray / (1 - q);
+                T_ray = wdiv(T_ray, 1 - q);
         }
         if (!nonzero(T_ray)) return false;
         return true;
@@ -356,8 +356,8 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
     }
     r_l = r_l * (r_p * p_l);
     r_u = r_u * (r_p * scatterPDF);
-    if (kFull && delta_light) return f_hat * T_ray * ls.L / avg(r_l);  // IsDeltaLight (:1248-1249)
-    return f_hat * T_ray * ls.L / avg(r_l + r_u);
+    if (kFull && delta_light) return wdiv(f_hat * T_ray * ls.L, avg(r_l));  // IsDeltaLight (:1248-1249)
+    return wdiv(f_hat * T_ray * ls.L, avg(r_l + r_u));
 }
 
 template <class Medium, class PC, class GD = GDist>
@@ -379,7 +379,7 @@ VDEV Spec sample_Ld(const DScene &S, const Medium &medium, const Intr &intr, con
     } else if (have_light) {
         int li = (int)(u * (float)n_all);
         lightIndex = li < n_all - 1 ? li : n_all - 1;
-        lightPmf = 1.f / (float)n_all;
+        lightPmf = wrcp((float)n_all);
     }
     float ul0 = sampler.get1d(), ul1 = sampler.get1d();
     if (!have_light) return sp(0.f);
@@ -513,13 +513,13 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 pc.density_query();
                 Spec sigma_t = mp.sigma_t;
                 Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
-                float wi = ch_of(sigma_t / sigma_maj * trRatioEst, ch);
+                float wi = ch_of(wdiv(sigma_t, sigma_maj) * trRatioEst, ch);
                 if (wi > 0) {
                     weightSum += wi;
-                    if (sampler.get1d() < wi / weightSum) {
+                    if (sampler.get1d() < wdiv(wi, weightSum)) {
                         float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
-                        sel_num = beta_rs * T_maj * mp.sigma_s / pdf;
-                        sel_den = r_u_rs * T_maj * sigma_t / pdf;
+                        sel_num = wdiv(beta_rs * T_maj * mp.sigma_s, pdf);
+                        sel_den = wdiv(r_u_rs * T_maj * sigma_t, pdf);
                         sel_p = p;
                         sel_g = mp.g;
                         sel_wi = wi;
@@ -527,9 +527,9 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                     }
                 }
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
-                beta_rs = beta_rs * (T_maj * sigma_n / pdf);
-                r_u_rs = r_u_rs * (T_maj * sigma_n / pdf);
-                trRatioEst = trRatioEst * (sigma_n / sigma_maj);
+                beta_rs = beta_rs * wdiv(T_maj * sigma_n, pdf);
+                r_u_rs = r_u_rs * wdiv(T_maj * sigma_n, pdf);
+                trRatioEst = trRatioEst * wdiv(sigma_n, sigma_maj);
                 return true;
             });
         beta_rs = mul_tmaj_ratio<Medium::kGrey>(beta_rs, T_maj, ch);
@@ -539,7 +539,7 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
             const size_t pix = (size_t)py * S.xres + px;
             const int n = S.tr_spp[pix] + 1;
             S.tr_spp[pix] = n;
-            const float alpha = 1.f / (float)n;
+            const float alpha = wrcp((float)n);
             float *t = S.tr_rgb + pix * 3;
             t[0] = (1.f - alpha) * t[0] + alpha * trRatioEst.r;
             t[1] = (1.f - alpha) * t[1] + alpha * trRatioEst.g;
@@ -550,19 +550,19 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
         if (guide && trScalar < 1 && trScalar > 0 && weightSum > 0) {
             float volRatio = vrc * S.prm.vspmisratio + (1 - trScalar) * (1 - S.prm.vspmisratio);
             float surfRatio = 1 - volRatio;
-            surf_wi = surfRatio / volRatio * weightSum;
+            surf_wi = wdiv(surfRatio, volRatio) * weightSum;
         }
         weightSum += surf_wi;
         bool selectSurface = false;
         if (weightSum == 0) return ev;
-        if (sampler.get1d() < surf_wi / weightSum) {
+        if (sampler.get1d() < wdiv(surf_wi, weightSum)) {
             sel_wi = surf_wi;
             sel_sTTr = trScalar;
             sel_num = beta_rs;
             sel_den = r_u_rs;
             selectSurface = true;
         }
-        float factor = weightSum * sel_sTTr / sel_wi;
+        float factor = wdiv(weightSum * sel_sTTr, sel_wi);
         if (!selectSurface) {
             if (st.depth == 0) {
                 isg.valid = true;
@@ -611,12 +611,12 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 if (mp.bb_temp > 0.f) mpLe = blackbody_sample(mp.bb_temp, st.lu) * mp.bb_scale;
             if (st.depth < S.prm.maxdepth && nonzero(mpLe)) {  // :895-906
                 float pdf = ch_of(sigma_maj, ch) * ch_of(T_maj, ch);
-                Spec betap = st.beta * T_maj / pdf;
-                Spec r_e = st.r_u * sigma_maj * T_maj / pdf;
-                if (nonzero(r_e)) st.L = st.L + betap * mp.sigma_a * mpLe / avg(r_e);
+                Spec betap = wdiv(st.beta * T_maj, pdf);
+                Spec r_e = wdiv(st.r_u * sigma_maj * T_maj, pdf);
+                if (nonzero(r_e)) st.L = st.L + wdiv(betap * mp.sigma_a * mpLe, avg(r_e));
             }
             Spec sigma_t = mp.sigma_t;
-            float pScatter = ch_of(sigma_t, ch) / ch_of(sigma_maj, ch);
+            float pScatter = wdiv(ch_of(sigma_t, ch), ch_of(sigma_maj, ch));
             // NDS+ (:929-938): bias the real/null-collision probability of the PRIMARY ray by the cached transmittance.
             // With a homogeneous medium pScatter == 1 and every NDS+ factor is exactly 1: compiled out.
             bool NDS_plus = false;
@@ -644,9 +644,9 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
                 }
                 pc.volume_scatter();
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
-                st.beta = st.beta * (T_maj * mp.sigma_s / pdf);
+                st.beta = st.beta * wdiv(T_maj * mp.sigma_s, pdf);
                 // grey medium: T_maj * sigma_t is, channel by channel, the very product pdf is -- x / x == 1 (see mul_tmaj_ratio)
-                if (!(Medium::kGrey >= 1 && pdf > 0.f && pdf < kInf)) st.r_u = st.r_u * (T_maj * sigma_t / pdf);
+                if (!(Medium::kGrey >= 1 && pdf > 0.f && pdf < kInf)) st.r_u = st.r_u * wdiv(T_maj * sigma_t, pdf);
                 if (NDS_plus) st.r_u = st.r_u * (sigma_maj * pScatter / sigma_t);  // :975-976
                 st.r_u = st.r_u * r_u_factor;
                 if constexpr (kRec) {  // :978-986 (beta_factor is 1)
@@ -663,15 +663,15 @@ VDEV DistEvent sample_distance(const DScene &S, const Medium &medium, const floa
             } else {
                 Spec sigma_n = medium.sigma_n(mp, sigma_maj);
                 float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
-                st.beta = st.beta * (T_maj * sigma_n / pdf);
+                st.beta = st.beta * wdiv(T_maj * sigma_n, pdf);
                 if constexpr (kRec) tw = tw * (T_maj * sigma_n / pdf);  // :1067
                 if (pdf == 0) {
                     st.beta = sp(0.f);
                     if constexpr (kRec) tw = sp(0.f);
                 }
-                st.r_u = st.r_u * (T_maj * sigma_n / pdf);
+                st.r_u = st.r_u * wdiv(T_maj * sigma_n, pdf);
                 if (NDS_plus) st.r_u = st.r_u * (sigma_maj * (1 - pScatter) / sigma_n);  // :1072-1073
-                st.r_l = st.r_l * (T_maj * sigma_maj / pdf);
+                st.r_l = st.r_l * wdiv(T_maj * sigma_maj, pdf);
                 return nonzero(st.beta) && nonzero(st.r_u);
             }
         };
@@ -732,15 +732,15 @@ VDEV int li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, 
             Spec Le = lds(S.inf_L[k]);  // UniformInfiniteLight::Le / DistantLight::Le (lights.cpp:1014-1017, lights.h:291-293)
             if (S.inf_type[k] == VSPG_LIGHT_DISTANT && st.depth != 0) Le = sp(0.f);
             if (st.depth == 0 || st.specularBounce) {
-                st.L = st.L + st.beta * Le / avg(st.r_u);
+                st.L = st.L + wdiv(st.beta * Le, avg(st.r_u));
                 if constexpr (kRec) pc.rec.add_infinite_light_emission(st.ro + st.rd * kGuidingInfiniteLightDistance, Le, 1.0f);  // :361
             } else {
                 // lightSampler.PMF * light.PDF_Li(prevIntrContext, ray.d, true): both light types return 0 for the incomplete PDF
                 const float pmf = S.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM ? light_sampler_pmf(S, st.prevCtx.template expand<FULL>(S).pi.mid(), st.prevCtx.template expand<FULL>(S).n, S.n_lights + k)
-                                                                            : 1.f / (float)n_all;
+                                                                            : wrcp((float)n_all);
                 const float lightPDF = pmf * 0.f;
                 st.r_l = st.r_l * lightPDF;
-                const float w_b = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.f;
+                const float w_b = S.prm.usenee ? wrcp(avg(st.r_u + st.r_l)) : 1.f;
                 st.L = st.L + st.beta * w_b * Le;
                 if constexpr (kRec) pc.rec.add_infinite_light_emission(st.ro + st.rd * kGuidingInfiniteLightDistance, Le, w_b);  // :369
             }
@@ -753,15 +753,15 @@ VDEV int li_surface_pre(const DScene &S, PathState &st, IsgSample &isg, PC &pc, 
     float w_direct = 0.f;
     if (nonzero(Le)) {
         if (st.depth == 0 || st.specularBounce) {
-            st.L = st.L + st.beta * Le / avg(st.r_u);
+            st.L = st.L + wdiv(st.beta * Le, avg(st.r_u));
             w_direct = 1.0f;
         } else {
             const LsCtx pctx = st.prevCtx.template expand<FULL>(S);
             const float pmf = FULL && S.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM ? light_sampler_pmf(S, pctx.pi.mid(), pctx.n, S.lsamp.light_of_quad[si.quad])
-                                                                                 : 1.f / (float)(FULL ? S.n_lights + S.n_inf : S.n_lights);
+                                                                                 : wrcp((float)(FULL ? S.n_lights + S.n_inf : S.n_lights));
             float lightPDF = pmf * light_pdf_li(q, pctx, st.rd);
             st.r_l = st.r_l * lightPDF;
-            float w_l = S.prm.usenee ? 1.0f / avg(st.r_u + st.r_l) : 1.0f;
+            float w_l = S.prm.usenee ? wrcp(avg(st.r_u + st.r_l)) : 1.0f;
             st.L = st.L + st.beta * w_l * Le;
             w_direct = w_l;
         }
@@ -903,7 +903,7 @@ VDEV float vertex_pre(const DScene &S, const PathState &st, Sampler &sampler, co
     float survivalProb = 1.f;
     (void)sampler.get1d();  // v: gbsdf.init / gphase.init with an untrained field (:457-458, :809-810)
     if (vx.volume && st.depth > S.prm.minrrdepth) {  // :817-830: survival probability BEFORE the NEE
-        Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction;
+        Spec rrw = wdiv(st.beta, avg(st.r_u)) * st.rr_correction;
         survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
     }
     return survivalProb;
@@ -927,7 +927,7 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
         if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {  // :842-849
             float q = fmax_(0.f, 1 - survivalProb);
             if (sampler.get1d() < q) return false;
-            st.beta = st.beta / (1 - q);
+            st.beta = wdiv(st.beta, 1 - q);
         }
         float u0 = sampler.get1d(), u1 = sampler.get1d();
         ang = hg_pre(vg, u0, u1, &a0, &a1);  // a0 = sinTheta, a1 = cosTheta
@@ -952,7 +952,7 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
         // ps->p / ps->pdf: the phase function's value IS its pdf, so the weight is x / x -- exactly 1 for every finite non-zero
         // x (pdf == 0 returned above), and beta * 1 is beta; the division only runs where it is not (an infinite or NaN pdf)
         if (!(pdf < kInf)) st.beta = st.beta * (pdf / pdf);
-        st.r_l = st.r_u / pdf;
+        st.r_l = wdiv(st.r_u, pdf);
         st.prevCtx.p = vp;
         st.prevCtx.quad = -1;
         st.ro = vp;
@@ -972,9 +972,9 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
     V3 wi = bsdf.frame.from_local(wl);
     st.lastVertexVolume = false;
     if (!(pdf < kInf)) st.rr_correction *= pdf / pdf;  // bs->pdf / bs->bsdfPdf == x / x == 1 for finite non-zero x (pdf == 0 returned above)
-    Spec bsdfWeight = f * absdot(wi, si.n) / pdf;
+    Spec bsdfWeight = wdiv(f * absdot(wi, si.n), pdf);
     st.beta = st.beta * bsdfWeight;
-    st.r_l = st.r_u / pdf;  // misPdf == pdf without guiding
+    st.r_l = wdiv(st.r_u, pdf);  // misPdf == pdf without guiding
     st.specularBounce = false;
     st.anyNonSpecularBounces = true;
     st.ro = offset_ray_origin(intr.pi, si.n, wi);  // SpawnRay (interaction.h:99-101) ...
@@ -983,13 +983,13 @@ VDEV bool vertex_tail(const DScene &S, PathState &st, Sampler &sampler, const Ve
 
     if (!nonzero(st.beta)) return false;
     if (st.depth > S.prm.minrrdepth) {
-        Spec rrw = (st.beta / avg(st.r_u)) * st.rr_correction * st.etaScale;
+        Spec rrw = wdiv(st.beta, avg(st.r_u)) * st.rr_correction * st.etaScale;
         survivalProb = st.specularBounce ? 0.95f : standard_throughput_rr(rrw);
     }
     if (survivalProb < 1 && st.depth > S.prm.minrrdepth) {
         float qq = fmax_(0.f, 1 - survivalProb);
         if (sampler.get1d() < qq) return false;
-        st.beta = st.beta / (1 - qq);
+        st.beta = wdiv(st.beta, 1 - qq);
     }
     return true;
 }
@@ -1438,4 +1438,4 @@ VDEV void isg_add_sample(float *st, Spec L, const IsgSample &isg) {
     }
 }
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg

@@ -9,7 +9,7 @@
 #pragma once
 #include "vspg_guiding.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 // ---- segment records: per lane, SoA over lanes in HBM -----------------------------------------
 enum {
@@ -369,4 +369,4 @@ VDEV void region_init_lobes(VspgFieldRegion &R) {
     }
 }
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg

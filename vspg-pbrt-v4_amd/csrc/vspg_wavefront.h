@@ -38,7 +38,7 @@
 #include "vspg_path.h"
 #include "vspg_wg_kernel.h"  // flag bits, list_push
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 // ---- path record: groups of kWfGroup floats, group-major: field f of slot s at base[((f / kWfGroup) * n + s) * kWfGroup + f % kWfGroup] --
 // A 3-vector / spectrum / RNG state sits inside ONE 16-byte quad, so a lane moves it with one dwordx3 / dwordx4 access.  With
@@ -441,7 +441,7 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Medium &medium, int ch, 
     } else if (have_light) {  // UniformLightSampler::Sample (lightsamplers.h:33-38)
         int li = (int)(u * (float)n_all);
         lightIndex = li < n_all - 1 ? li : n_all - 1;
-        lightPmf = 1.f / (float)n_all;
+        lightPmf = wrcp((float)n_all);
     }
     float ul0 = sampler.get1d(), ul1 = sampler.get1d();
     if (!have_light) return r;
@@ -548,8 +548,8 @@ VDEV Spec sample_Ld_end(bool walked, bool delta_light, Spec T_ray, Spec r_l, Spe
     if (!nonzero(T_ray)) return sp(0.f);
     r_l = r_l * (r_p * p_l);
     r_u = r_u * (r_p * scatterPDF);
-    if (delta_light) return f_hat * T_ray * Ll / avg(r_l);  // IsDeltaLight (:1248-1249)
-    return f_hat * T_ray * Ll / avg(r_l + r_u);
+    if (delta_light) return wdiv(f_hat * T_ray * Ll, avg(r_l));  // IsDeltaLight (:1248-1249)
+    return wdiv(f_hat * T_ray * Ll, avg(r_l + r_u));
 }
 
 // ---- one tracking step of a walk (media_sampleTMaj.h:66-114 == :190-246), cut where the callback sits --------------
@@ -781,7 +781,7 @@ VDEV void wf_segment_begin(const WfArgs &a, const DScene &S, const Medium &mediu
                     totalLength = minTotalLength;
                 }
                 float expNegTotalLength = fast_exp(-totalLength);
-                vrc = vsp / (1 - expNegTotalLength);
+                vrc = wdiv(vsp, 1 - expNegTotalLength);
             }
             wf_store_iter(P, slot, iter, ch);
             P.set3(WF_RDN, slot, rdn);
@@ -1050,21 +1050,21 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
             const Spec sigma_maj = w.sigma_maj, T_maj = w.T_maj;
             const Spec sigma_t = mp.sigma_t;
             const Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
-            const float wi = ch_of(sigma_t / sigma_maj * trRatioEst, ch);
+            const float wi = ch_of(wdiv(sigma_t, sigma_maj) * trRatioEst, ch);
             if (wi > 0) {
                 weightSum += wi;
-                if (sampler.get1d() < wi / weightSum) {
+                if (sampler.get1d() < wdiv(wi, weightSum)) {
                     const float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
-                    sel_num = beta_rs * T_maj * mp.sigma_s / pdf;
-                    sel_den = r_u_rs * T_maj * sigma_t / pdf;
+                    sel_num = wdiv(beta_rs * T_maj * mp.sigma_s, pdf);
+                    sel_den = wdiv(r_u_rs * T_maj * sigma_t, pdf);
                     sel_p = p;
                     sel_wi = wi;
                 }
             }
             const float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
-            beta_rs = beta_rs * (T_maj * sigma_n / pdf);
-            r_u_rs = r_u_rs * (T_maj * sigma_n / pdf);
-            trRatioEst = trRatioEst * (sigma_n / sigma_maj);
+            beta_rs = beta_rs * wdiv(T_maj * sigma_n, pdf);
+            r_u_rs = r_u_rs * wdiv(T_maj * sigma_n, pdf);
+            trRatioEst = trRatioEst * wdiv(sigma_n, sigma_maj);
             w.T_maj = sp(1.f);
             w.tMin = t;
         } else if (active && r == WALK_END) {
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                         const size_t pix = (size_t)py * S.xres + px;
                         const int ns = S.tr_spp[pix] + 1;
                         S.tr_spp[pix] = ns;
-                        const float alpha = 1.f / (float)ns;
+                        const float alpha = wrcp((float)ns);
                         float *tb = S.tr_rgb + pix * 3;
                         tb[0] = (1.f - alpha) * tb[0] + alpha * trRatioEst.r;
                         tb[1] = (1.f - alpha) * tb[1] + alpha * trRatioEst.g;
@@ -1286,19 +1286,19 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                     if (guide && trScalar < 1 && trScalar > 0 && weightSum > 0) {
                         float volRatio = vrc * S.prm.vspmisratio + (1 - trScalar) * (1 - S.prm.vspmisratio);
                         float surfRatio = 1 - volRatio;
-                        surf_wi = surfRatio / volRatio * weightSum;
+                        surf_wi = wdiv(surfRatio, volRatio) * weightSum;
                     }
                     weightSum += surf_wi;
                     if (weightSum != 0) {
                         bool selectSurface = false;
-                        if (sampler.get1d() < surf_wi / weightSum) {
+                        if (sampler.get1d() < wdiv(surf_wi, weightSum)) {
                             sel_wi = surf_wi;
                             sel_sTTr = trScalar;
                             sel_num = beta_rs;
                             sel_den = r_u_rs;
                             selectSurface = true;
                         }
-                        const float factor = weightSum * sel_sTTr / sel_wi;
+                        const float factor = wdiv(weightSum * sel_sTTr, sel_wi);
                         bool term = false;
                         if (!selectSurface) {
                             if (st.depth == 0) {
@@ -1566,14 +1566,14 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
             const Spec sigma_maj = w.sigma_maj, T_maj = w.T_maj;
             const float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
             const Spec sigma_n = medium.sigma_n(mp, sigma_maj);
-            T_ray = T_ray * (T_maj * sigma_n / pdf);
-            r_l = r_l * (T_maj * sigma_maj / pdf);
-            r_u = r_u * (T_maj * sigma_n / pdf);
-            const Spec Tr = T_ray / avg(r_l + r_u);
+            T_ray = T_ray * wdiv(T_maj * sigma_n, pdf);
+            r_l = r_l * wdiv(T_maj * sigma_maj, pdf);
+            r_u = r_u * wdiv(T_maj * sigma_n, pdf);
+            const Spec Tr = wdiv(T_ray, avg(r_l + r_u));
             if (maxc(Tr) < 0.05f) {
                 const float q = 0.75f;
                 if (w.rng.uniform() < q) T_ray = sp(0.f);
-                else T_ray = T_ray / (1 - q);
+                else T_ray = wdiv(T_ray, 1 - q);
             }
             if (!nonzero(T_ray)) {  // the callback stops the traversal: SampleT_maj returns 1
                 T_res = sp(1.f);
@@ -1592,4 +1592,4 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
     wf_flush_counters(pc, a.counters);
 }
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg

@@ -10,7 +10,7 @@
 
 #include "vspg_wavefront.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 struct WfLaunch {
     WfArgs a;
@@ -38,7 +38,8 @@ int wf_dispatch_nvdb(const WfLaunch &L, bool guided, bool train, bool grey);
 // kernels' -- the grey layout whenever the medium's coefficients are bitwise grey, never the boundary flavour (a walk job is a ray
 // segment inside the medium: boundaries are the dense kernels' business).
 // NDS_ONLY: only the "nds" branch is instantiated (the emissive media: their other kernels would be the plain medium's over again).
-template <class Medium, bool GUIDED, bool TRAIN, class WalkMedium, bool NDS_ONLY = false>
+// NO_NDS: only the resampling pipeline is instantiated (the fast-arithmetic translation units, vspg_fast.hip).
+template <class Medium, bool GUIDED, bool TRAIN, class WalkMedium, bool NDS_ONLY = false, bool NO_NDS = false>
 int wf_run_pass(const WfLaunch &L) {
     const WfArgs &a = L.a;
     const hipStream_t s = L.s, s2 = L.s2;
@@ -60,7 +61,8 @@ int wf_run_pass(const WfLaunch &L) {
         swalk = blocks < L.swalk ? (blocks ? blocks : 1u) : L.swalk;
         return 0;
     };
-    if (L.nds) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
+    if (!NO_NDS && L.nds) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
+      if constexpr (!NO_NDS) {
         for (int it = 0; it < L.max_iters; ++it) {
             if (bnd && it > L.base_iters) {
                 bool empty = false;
@@ -70,6 +72,7 @@ int wf_run_pass(const WfLaunch &L) {
             hipLaunchKernelGGL((k_wf_segment_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
             if (bnd || it < L.maxdepth) hipLaunchKernelGGL(k_wf_shadow_walk<WalkMedium>, dim3(swalk), dim3(kWfBlock), 0, s, a, it);
         }
+      }
     } else if constexpr (!NDS_ONLY) {
         hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a);
         for (int it = 0; it < L.max_iters; ++it) {
@@ -138,4 +141,29 @@ int wf_dispatch(const WfLaunch &L, bool guided, bool train, bool grey) {
 #undef VSPG_WF_CASE
 }
 
-}  // namespace vspg
+// the unguided resampling pipeline only: {grey, chromatic} x {no boundaries, boundaries} (vspg_fast.hip)
+template <bool NVDB>
+int wf_dispatch_unguided(const WfLaunch &L, bool grey) {
+    if (L.nds || L.emit) return WF_E_NOT_DRAINED - 1;  // (the caller routes those to the exact instantiations)
+#define VSPG_WF_UCASE(GREY, BNDV) return wf_run_pass<GridMediumT<NVDB, GREY, BNDV>, false, false, GridMediumT<NVDB, GREY>, false, true>(L)
+    if (L.bnd) {
+        if (grey) VSPG_WF_UCASE(true, 1);
+        VSPG_WF_UCASE(false, 1);
+    }
+    if (grey) VSPG_WF_UCASE(true, 0);
+    VSPG_WF_UCASE(false, 0);
+#undef VSPG_WF_UCASE
+}
+
+VSPG_NS_END  // namespace vspg
+
+// The fast-arithmetic translation units (vspg_fast.hip compiled with -DVSPG_ARITH=1 / 2, vspg_arith.h) behind plain C entry points:
+// their types live in an inline namespace of their own, so the launch records cross as untyped pointers (same struct, same source).
+extern "C" {
+int vspg_arith1_wg3(const void *wg3_launch);
+int vspg_arith2_wg3(const void *wg3_launch);
+int vspg_arith1_wf_grid(const void *wf_launch, int grey);
+int vspg_arith2_wf_grid(const void *wf_launch, int grey);
+int vspg_arith1_trace(const void *trace_launch);
+int vspg_arith2_trace(const void *trace_launch);
+}

@@ -33,7 +33,7 @@
 #include "vspg_path.h"
 #include "vspg_wg_kernel.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 enum { Q_VV = 0, Q_VS = 1, Q_A = 2, Q_F = 3, Q_COUNT = 4 };
 enum { QC_RES = 0, QC_COM = 1, QC_HEAD = 2, QC_STRIDE = 4 };
@@ -440,4 +440,43 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg3(
     if (threadIdx.x < CNT_COUNT) atomicAdd(&counters[threadIdx.x], (unsigned long long)s_counters[threadIdx.x]);
 }
 
-}  // namespace vspg
+// ---- host side: the unguided rectangle-scene instantiations behind one call (what vspg_capi.hip launches for them, and what the
+// fast-arithmetic translation units export: vspg_fast.hip, vspg_arith.h) -------------------------------------------------------
+#ifndef VSPG_WG_WAVES
+#define VSPG_WG_WAVES 4
+#endif
+#ifndef VSPG_WG_BLOCK
+#define VSPG_WG_BLOCK 512
+#endif
+struct Wg3Launch {
+    const DScene *dscene;
+    float4 *film;
+    float *isg_stats;
+    const float *vsp;
+    int vsp_ready, wave_end, first_sample, single_sample;
+    PcgJump jump;
+    unsigned int tiles_magic;
+    unsigned int *work_head;
+    const float4 *ws_prev;
+    float4 *ws_out;
+    unsigned long long *counters;
+    unsigned int blocks;
+    hipStream_t stream;
+    int grey;          // 0: chromatic; 1: grey medium; 2: grey medium and grey surfaces (HomogeneousMediumT)
+    int null_zero;     // ... whose null-collision coefficient is exactly 0
+};
+template <int GREY> constexpr int kWg3PoolHomogT = wg3_pool_paths<PoolLayout<false, GREY>>(VSPG_WG3_OTHER);
+inline int wg3_launch_unguided(const Wg3Launch &L) {
+#define VSPG_WG3_GO(M, NPOOL)                                                                                                                \
+    hipLaunchKernelGGL((k_render_wave_wg3<M, false, NPOOL, VSPG_WG_BLOCK, VSPG_WG_WAVES, false>), dim3(L.blocks), dim3(VSPG_WG_BLOCK), 0, L.stream, \
+                       L.dscene, L.film, L.isg_stats, L.vsp, L.vsp_ready, L.wave_end, L.first_sample, L.single_sample, L.jump, L.tiles_magic,  \
+                       L.work_head, L.ws_prev, L.ws_out, L.counters, TrainArgs{nullptr, nullptr, nullptr, nullptr, 0, 0})
+    if (L.grey >= 2 && L.null_zero) VSPG_WG3_GO(HomogeneousMediumGreySceneNullZero, kWg3PoolHomogT<2>);
+    else if (L.grey >= 2) VSPG_WG3_GO(HomogeneousMediumGreyScene, kWg3PoolHomogT<2>);
+    else if (L.grey == 1) VSPG_WG3_GO(HomogeneousMediumGrey, kWg3PoolHomogT<1>);
+    else VSPG_WG3_GO(HomogeneousMediumSimple, kWg3PoolHomogT<0>);
+#undef VSPG_WG3_GO
+    return (int)hipGetLastError();
+}
+
+VSPG_NS_END  // namespace vspg

@@ -19,7 +19,7 @@
 #pragma once
 #include "vspg_path.h"
 
-namespace vspg {
+VSPG_NS_BEGIN
 
 // ---- LDS pool record (field-major SoA: field f of slot s at base[f * NP + s]) ----------------
 // The record is laid out per kernel instantiation (round 3): a grey medium parks ONE channel of r_u / r_l (GREY >= 1) and, with
@@ -289,4 +289,4 @@ VDEV void list_push_back(bool pred, int slot, unsigned short *last, unsigned int
     if (pred) *(last - (int)(base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull)))) = (unsigned short)slot;
 }
 
-}  // namespace vspg
+VSPG_NS_END  // namespace vspg
