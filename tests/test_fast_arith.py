@@ -169,7 +169,7 @@ def test_arithmetic_modes_are_refused_where_no_instantiation_exists(gpu_pkg):
     r.set_guiding_field(f, f)
     with pytest.raises(P.VspgError) as e:
         r.set_arithmetic(P.ARITH_FAST)
-    assert e.value.code == P.VSPG_ESCOPE and "k_render_wave_wg3" in str(e.value)
+    assert e.value.code == P.VSPG_ESCOPE and "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>" in str(e.value)
     assert r.arithmetic() == P.ARITH_EXACT
     r.set_arithmetic(P.ARITH_EXACT)
     r.close()

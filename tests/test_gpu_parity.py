@@ -425,7 +425,7 @@ def test_parked_samples_reach_the_film_whoever_asks_first(gpu_pkg, guided):
             r = P.Renderer(scene, prm, W, H, seed=9)
             if field is not None:
                 r.set_guiding_field(field, field)
-            assert r.kernel_name().startswith("k_render_wave_wg3<")
+            assert r.kernel_name().startswith("k_render_wave_wg2<" if guided else "k_render_wave_wg3<")
             log = []
             r.render_wave(0, 1)
             log.append(r.film())                       # a read right after a launch
@@ -584,7 +584,7 @@ def test_full_size_guided_wave_properties(gpu_pkg):
     prm = P.default_params()
     prm.guide_num_training_waves = 4
     t = P.Renderer(scene, prm, W, H)
-    assert t.kernel_name() == "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided,train>"
+    assert t.kernel_name() == "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>"
     for w in range(4):
         t.render_wave(w, w + 1)
         t.post_process_wave()
@@ -621,7 +621,7 @@ def test_full_size_guided_wave_properties(gpu_pkg):
             r.close()
         finally:
             os.environ.pop("VSPG_KERNEL", None)
-    assert sorted(films) == ["k_render_wave<HomogeneousMediumT<2,true>,guided>", "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided>"]
+    assert sorted(films) == ["k_render_wave<HomogeneousMediumT<2,true>,guided>", "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>"]
     a, b = films.values()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     c = oracle_lib.OracleRenderer(scene, prm, W, H)
@@ -1840,7 +1840,7 @@ def test_guided_workgroup_kernel_equals_per_lane_kernel(gpu_pkg):
             os.environ.pop("VSPG_KERNEL", None)
             os.environ.pop("VSPG_NO_GREY_GUIDED", None)
     assert sorted(films) == ["k_render_wave<HomogeneousMedium,guided>", "k_render_wave<HomogeneousMediumT<2,true>,guided>",
-                             "k_render_wave_wg3<HomogeneousMedium,guided>", "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided>"], sorted(films)
+                             "k_render_wave_wg2<HomogeneousMedium,guided>", "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided>"], sorted(films)
     a = next(iter(films.values()))
     for name, f in films.items():
         assert np.array_equal(a.view(np.uint32), f.view(np.uint32)), name
@@ -1956,7 +1956,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
     # grid media record on the wavefront pipeline, homogeneous ones on the workgroup kernel (round 3): either way the recorder's
     # state travels in the path record
-    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg3<HomogeneousMediumT<2,true>,guided,train>")
+    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>")
     # (the sample buffer holds one wave's worth -- pixels x (maxdepth + 1) -- between two updates: the capped case fills it with one)
     n_waves = 1 if medium == "homogeneous-capped" else 2
     g.render_wave(0, n_waves)
@@ -1972,7 +1972,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     # homogeneous media the workgroup kernel's generic instantiation
     others = [({"VSPG_KERNEL": "lane"}, "k_render_wave<GridMedium,guided,train>" if medium == "grid" else "k_render_wave<HomogeneousMediumT<2,true>,guided,train>")]
     if medium != "grid":
-        others.append(({"VSPG_NO_GREY_GUIDED": "1"}, "k_render_wave_wg3<HomogeneousMedium,guided,train>"))
+        others.append(({"VSPG_NO_GREY_GUIDED": "1"}, "k_render_wave_wg2<HomogeneousMedium,guided,train>"))
     for env, name in others:
         os.environ.update(env)
         try:

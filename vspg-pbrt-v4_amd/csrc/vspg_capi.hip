@@ -711,10 +711,6 @@ constexpr int kWg2PoolFull = wg_pool_paths<PoolLayout<false, 0, false, true>>(10
 #endif
 template <int GREY> constexpr int kWg2PoolGuidedT = GREY >= 2 ? (VSPG_WGG_NP_G2) : (VSPG_WGG_NP_G0);
 template <int GREY> constexpr int kWg2PoolTrainT = wg_pool_paths<PoolLayout<true, GREY, true>>(10, VSPG_WG_OTHER + 2 * kKdLdsNodes * 8);  // + the recorder's state
-// k_render_wave_wg3 (vspg_wg3.h): pools LARGER than the workgroup has lanes -- the slack is what keeps its chunks full
-constexpr int kWg3PoolFull = wg3_pool_paths<PoolLayout<false, 0, false, true>>(VSPG_WG3_OTHER);
-template <int GREY> constexpr int kWg3PoolGuidedT = wg3_pool_paths<PoolLayout<true, GREY>>(VSPG_WG3_OTHER + 2 * kKdLdsNodes * 8);
-template <int GREY> constexpr int kWg3PoolTrainT = wg3_pool_paths<PoolLayout<true, GREY, true>>(VSPG_WG3_OTHER + 2 * kKdLdsNodes * 8);
 constexpr int kWgChunk = 256;  // work items (4 pixel tiles) a workgroup claims per global atomic
 enum { C_A0 = 0, C_A1 = 2, C_CURA = 4, C_BV = 6, C_BS = 7, C_CURB = 8, C_NFREE = 9, C_NASSIGN = 11, C_RNEXT = 12, C_REND = 13,
        C_EXH = 14, C_RTX = 15, C_RTY = 16, C_COUNT = 17 };
@@ -3048,8 +3044,11 @@ static bool uses_wg2(const VspgRenderer *r) {
 }
 // Round 5: the barrier-free scheduler (k_render_wave_wg3, vspg_wg3.h: ring queues in LDS, every wavefront its own scheduler) serves
 // whatever k_render_wave_wg2 served; VSPG_WG_SCHED=2 keeps k_render_wave_wg2 (tests compare the three schedulers).
+// It lives on the pool's slack over the workgroup's lanes (HISTORY round 5), which the larger records do not leave: the guided /
+// training instantiations (544 / 448 paths for 512 lanes: reference-default trained wave 1.45 ms against 1.42) and the full-scene one
+// (512) stay on k_render_wave_wg2.
 static bool uses_wg3(const VspgRenderer *r) {
-    if (!uses_wg2(r)) return false;
+    if (!uses_wg2(r) || uses_wg_guided(r) || uses_wg_full(r)) return false;
     const char *e = getenv("VSPG_WG_SCHED");
     return !(e && e[0] == '2');
 }
@@ -3267,16 +3266,8 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
 #define VSPG_LAUNCH_WG2(M, G, NPOOL, BLK, WV)                                                                                         \
     hipLaunchKernelGGL((k_render_wave_wg2<M, G, NPOOL, BLK, WV>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
                        r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, static_tiles, work_head, ws_prev, ws_out, r->counters)
-#define VSPG_LAUNCH_WG3(M, G, NPOOL, BLK, WV, TR)                                                                                         \
-    hipLaunchKernelGGL((k_render_wave_wg3<M, G, NPOOL, BLK, WV, TR>), dim3((unsigned)wblocks), dim3(BLK), 0, (hipStream_t)stream, r->dscene, \
-                       r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, work_head, ws_prev, ws_out, r->counters, targs)
             if (uses_wg3(r)) {
-                if (gwg && train && guided_grey_simple(r)) VSPG_LAUNCH_WG3(HomogeneousMediumGreySceneNullZero, true, kWg3PoolTrainT<2>, kWgBlockGuided, kWgWavesGuided, true);
-                else if (gwg && train) VSPG_LAUNCH_WG3(HomogeneousMediumSimple, true, kWg3PoolTrainT<0>, kWgBlockGuided, kWgWavesGuided, true);
-                else if (gwg && guided_grey_simple(r)) VSPG_LAUNCH_WG3(HomogeneousMediumGreySceneNullZero, true, kWg3PoolGuidedT<2>, kWgBlockGuided, kWgWavesGuided, false);
-                else if (gwg) VSPG_LAUNCH_WG3(HomogeneousMediumSimple, true, kWg3PoolGuidedT<0>, kWgBlockGuided, kWgWavesGuided, false);
-                else if (uses_wg_full(r)) VSPG_LAUNCH_WG3(HomogeneousMedium, false, kWg3PoolFull, kWgBlockHomog, kWgWavesHomog, false);
-                else {  // the unguided rectangle-scene instantiations (the headline workload): also built in the tolerance modes
+                {  // the unguided rectangle-scene instantiations (the headline workload): also built in the tolerance modes
                     static_assert(kWgBlockHomog == VSPG_WG_BLOCK && kWgWavesHomog == VSPG_WG_WAVES, "wg3_launch_unguided's launch shape");
                     const Wg3Launch L3{r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, work_head, ws_prev, ws_out,
                                        r->counters, (unsigned)wblocks, (hipStream_t)stream, r->medium_grey ? (r->surfaces_grey ? 2 : 1) : 0,
@@ -3301,7 +3292,6 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             else if (r->medium_grey) VSPG_LAUNCH_WG2(HomogeneousMediumGrey, false, kWg2PoolHomogT<1>, kWgBlockHomog, kWgWavesHomog);
             else VSPG_LAUNCH_WG2(HomogeneousMediumSimple, false, kWg2PoolHomogT<0>, kWgBlockHomog, kWgWavesHomog);
 #undef VSPG_LAUNCH_WG2
-#undef VSPG_LAUNCH_WG3
             HIPCHK(hipGetLastError());
             if (single) {  // this launch's samples are parked in ws_out (its predecessor's, if any were, have just been resolved)
                 r->ws_cur ^= 1;
