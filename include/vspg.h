@@ -476,6 +476,26 @@ typedef struct VspgTmajResult {
 } VspgTmajResult;
 
 enum { VSPG_TMAJ_PLAIN = 0, VSPG_TMAJ_OPTICAL_DEPTH = 1, VSPG_TMAJ_RESAMPLING = 2 };
+
+/* Ray queries against the renderer's geometry (ABI 7): the batch driver behind the replays of the reference's own shape tests
+ * (src/pbrt/shapes_test.cpp: Triangle Watertight / Reintersect / BadCases, FullSphere Reintersect) -- what Integrator::Intersect
+ * (cpu/integrators.cpp:341-349) returns for `ray`, then, from that hit, the ray Interaction::SpawnRay(w) (`mode` 1,
+ * interaction.h:99-101) or Interaction::SpawnRayTo(point w) (`mode` 2, interaction.h:104-108, ray.h:93-98) intersected again with
+ * tMax2: closest hit (Intersect) and any hit (IntersectP). */
+typedef struct {
+    float o[3], d[3], tMax;
+    int32_t mode;          /* 0: the first intersection only; 1: SpawnRay(w); 2: SpawnRayTo(w) */
+    float w[3], tMax2;
+} VspgRayQuery;
+typedef struct {
+    int32_t hit;           /* the first ray hit something */
+    int32_t prim;          /* rectangle index | 1000000 + triangle index in the caller's soup | 2000000 + sphere index */
+    float t, p[3], n[3];   /* tHit, the interaction point (midpoint of pi), the surface normal */
+    float o2[3], d2[3];    /* the spawned ray */
+    int32_t hit2, any2;    /* Intersect / IntersectP of the spawned ray */
+    float t2;
+} VspgRayResult;
+int vspg_ray_batch(VspgRenderer *r, int n, const VspgRayQuery *q, VspgRayResult *out, void *stream);
 /* Replaces SampleT_maj / SampleT_maj_OpticalDepthSpace / SampleT_maj_Resampling
  * (src/pbrt/media_sampleTMaj.h:49-117, 269-491, 136-248) on the renderer's medium with a
  * recording callback. */

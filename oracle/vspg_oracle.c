@@ -1006,6 +1006,36 @@ static int scene_intersect_any(const OracleRenderer *r, v3 o, v3 d, float tMax) 
     return 0;
 }
 
+/* The reference's shape tests replayed (shapes_test.cpp): Intersect(ray), then Interaction::SpawnRay(w) (interaction.h:99-101:
+ * OffsetRayOrigin(pi, n, w), direction w) or SpawnRayTo(p2) (interaction.h:104-108 over ray.h:93-98: d = p2 - Point3f(pi), origin
+ * OffsetRayOrigin(pi, n, d)) and Intersect / IntersectP of that ray. */
+int oracle_ray_batch(OracleRenderer *r, int n, const VspgRayQuery *q, VspgRayResult *out) {
+    for (int i = 0; i < n; ++i) {
+        VspgRayResult *o = &out[i];
+        memset(o, 0, sizeof *o);
+        const isect_t si = scene_intersect(r, v3_from(q[i].o), v3_from(q[i].d), q[i].tMax);
+        if (!si.hit) continue;
+        const p3i pi = isect_pi(&si);
+        const v3 pm = p3i_mid(pi);
+        o->hit = 1;
+        o->prim = si.sphere >= 0 ? 2000000 + si.sphere : (si.tri >= 0 ? 1000000 + r->tris[si.tri].id : si.quad);
+        o->t = si.t;
+        o->p[0] = pm.x; o->p[1] = pm.y; o->p[2] = pm.z;
+        o->n[0] = si.n.x; o->n[1] = si.n.y; o->n[2] = si.n.z;
+        if (q[i].mode == 0) continue;
+        const v3 w = v3_from(q[i].w);
+        const v3 d2 = q[i].mode == 1 ? w : v_sub(w, pm);
+        const v3 o2 = offset_ray_origin(pi, si.n, d2);
+        o->o2[0] = o2.x; o->o2[1] = o2.y; o->o2[2] = o2.z;
+        o->d2[0] = d2.x; o->d2[1] = d2.y; o->d2[2] = d2.z;
+        const isect_t s2 = scene_intersect(r, o2, d2, q[i].tMax2);
+        o->hit2 = s2.hit;
+        o->t2 = s2.hit ? s2.t : 0.f;
+        o->any2 = scene_intersect_any(r, o2, d2, q[i].tMax2);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* a5/a6: media -- majorant iterators                                                     */
 /* ------------------------------------------------------------------------------------ */

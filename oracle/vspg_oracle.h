@@ -97,6 +97,8 @@ int oracle_trace_paths(OracleRenderer *r, int n, const int32_t *pixel_xy,
                        const int32_t *sample_index, float *out_L, int32_t *out_segments);
 int oracle_sample_tmaj_batch(OracleRenderer *r, int variant, int n, const VspgTmajQuery *q,
                              VspgTmajResult *out);
+/* Integrator::Intersect for n rays, then SpawnRay / SpawnRayTo from the hit and Intersect / IntersectP of that ray (VspgRayQuery) */
+int oracle_ray_batch(OracleRenderer *r, int n, const VspgRayQuery *q, VspgRayResult *out);
 
 int oracle_renderer_set_guiding_field(OracleRenderer *r, const VspgField *surface_field,
                                       const VspgField *volume_field);

@@ -68,6 +68,7 @@ def load():
         "oracle_reset_counters": (None, [vp]),
         "oracle_trace_paths": (C.c_int, [vp, C.c_int, p(C.c_int32), p(C.c_int32), p(C.c_float), p(C.c_int32)]),
         "oracle_sample_tmaj_batch": (C.c_int, [vp, C.c_int, C.c_int, p(P.VspgTmajQuery), p(P.VspgTmajResult)]),
+        "oracle_ray_batch": (C.c_int, [vp, C.c_int, p(P.VspgRayQuery), p(P.VspgRayResult)]),
         "oracle_renderer_set_guiding_field": (C.c_int, [vp, p(P.VspgField), p(P.VspgField)]),
         "oracle_guiding_query_batch": (C.c_int, [vp, C.c_int, C.c_float, C.c_int, p(C.c_float), p(C.c_float), p(C.c_float),
                                                  p(C.c_float), p(C.c_int32), p(C.c_float), p(C.c_float), p(C.c_float),
@@ -212,6 +213,12 @@ class OracleRenderer:
                                          seg.ctypes.data_as(C.POINTER(C.c_int32)))
         assert rc == 0
         return L, seg
+
+    def ray_batch(self, queries):
+        q = np.ascontiguousarray(queries, dtype=self.P.RAY_QUERY_DTYPE)
+        out = np.zeros(len(q), dtype=self.P.RAY_RESULT_DTYPE)
+        assert self.lib.oracle_ray_batch(self.h, len(q), q.ctypes.data_as(C.POINTER(self.P.VspgRayQuery)), out.ctypes.data_as(C.POINTER(self.P.VspgRayResult))) == 0
+        return out
 
     def sample_tmaj_batch(self, variant, queries):
         n = len(queries)

@@ -151,6 +151,20 @@ class VspgTmajQuery(C.Structure):
                 ("channel", C.c_int32), ("stop_after", C.c_int32)]
 
 
+class VspgRayQuery(C.Structure):
+    _fields_ = [("o", f3), ("d", f3), ("tMax", C.c_float), ("mode", C.c_int32), ("w", f3), ("tMax2", C.c_float)]
+
+
+class VspgRayResult(C.Structure):
+    _fields_ = [("hit", C.c_int32), ("prim", C.c_int32), ("t", C.c_float), ("p", f3), ("n", f3), ("o2", f3), ("d2", f3),
+                ("hit2", C.c_int32), ("any2", C.c_int32), ("t2", C.c_float)]
+
+
+RAY_QUERY_DTYPE = [("o", "<f4", 3), ("d", "<f4", 3), ("tMax", "<f4"), ("mode", "<i4"), ("w", "<f4", 3), ("tMax2", "<f4")]
+RAY_RESULT_DTYPE = [("hit", "<i4"), ("prim", "<i4"), ("t", "<f4"), ("p", "<f4", 3), ("n", "<f4", 3), ("o2", "<f4", 3), ("d2", "<f4", 3),
+                    ("hit2", "<i4"), ("any2", "<i4"), ("t2", "<f4")]
+
+
 class VspgTmajResult(C.Structure):
     _fields_ = [("T_maj", f3), ("r_u_factor", f3), ("last_t", C.c_float), ("last_p", f3),
                 ("n_callbacks", C.c_int32), ("sum_sigt_over_maj", C.c_float),
@@ -176,6 +190,7 @@ SYMBOLS = [
     ("vspg_post_process_step", C.c_int, [_vp, C.c_int, _vp, _vp]),
     ("vspg_renderer_set_exchange", C.c_int, [_vp, _vp, _vp]),
     ("vspg_renderer_kernel_name", C.c_char_p, [_vp]),
+    ("vspg_ray_batch", C.c_int, [_vp, C.c_int, _P(VspgRayQuery), _P(VspgRayResult), _vp]),
     ("vspg_renderer_set_arithmetic", C.c_int, [_vp, C.c_int]),
     ("vspg_renderer_get_arithmetic", C.c_int, [_vp]),
     ("vspg_flush", C.c_int, [_vp, _vp]),
@@ -599,6 +614,15 @@ class Renderer:
                                                    L.ctypes.data_as(_P(C.c_float)),
                                                    seg.ctypes.data_as(_P(C.c_int32)), _vp(0)))
         return L, seg
+
+    def ray_batch(self, queries):
+        """queries: numpy structured array of RAY_QUERY_DTYPE; returns one of RAY_RESULT_DTYPE (vspg_ray_batch)."""
+        import numpy as np
+        q = np.ascontiguousarray(queries, dtype=RAY_QUERY_DTYPE)
+        out = np.zeros(len(q), dtype=RAY_RESULT_DTYPE)
+        assert q.itemsize == C.sizeof(VspgRayQuery) and out.itemsize == C.sizeof(VspgRayResult)
+        _check(self.lib, self.lib.vspg_ray_batch(self.h, len(q), q.ctypes.data_as(_P(VspgRayQuery)), out.ctypes.data_as(_P(VspgRayResult)), None))
+        return out
 
     def sample_tmaj_batch(self, variant, queries):
         n = len(queries)

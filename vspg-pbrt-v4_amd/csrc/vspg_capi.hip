@@ -1370,6 +1370,42 @@ __global__ __launch_bounds__(kBlock) void k_film_resolve(size_t npix, const floa
 }
 
 // (k_trace_paths: vspg_trace.h)
+// vspg_ray_batch (include/vspg.h): Integrator::Intersect, then Interaction::SpawnRay / SpawnRayTo from the hit and Intersect /
+// IntersectP of the spawned ray -- the full-scene intersection code of the path kernels (rectangles, BVH triangles, spheres)
+__global__ __launch_bounds__(kBlock) void k_ray_batch(const DScene *__restrict__ Sp, int n, const VspgRayQuery *__restrict__ q, VspgRayResult *__restrict__ out) {
+    const DScene &S = *Sp;
+    stage_scene_lds(S);
+    __syncthreads();
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    VspgRayResult o;
+    o.hit = 0; o.prim = 0; o.t = 0.f; o.hit2 = 0; o.any2 = 0; o.t2 = 0.f;
+    for (int k = 0; k < 3; ++k) o.p[k] = o.n[k] = o.o2[k] = o.d2[k] = 0.f;
+    const VspgRayQuery Q = q[i];
+    const Isect si = scene_intersect<true>(S, ld3(Q.o), ld3(Q.d), Q.tMax);
+    if (si.hit) {
+        const P3i pi = surf_pi<true>(S, si.quad, si.p);
+        const V3 pm = pi.mid();
+        o.hit = 1;
+        o.prim = is_sphere(si.quad) ? 2000000 + sphere_of(si.quad) : (is_tri(si.quad) ? 1000000 + S.tris[tri_of(si.quad)].id : si.quad);
+        o.t = si.t;
+        o.p[0] = pm.x; o.p[1] = pm.y; o.p[2] = pm.z;
+        o.n[0] = si.n.x; o.n[1] = si.n.y; o.n[2] = si.n.z;
+        if (Q.mode != 0) {
+            const V3 w = ld3(Q.w);
+            const V3 d2 = Q.mode == 1 ? w : w - pm;
+            const V3 o2 = offset_ray_origin(pi, si.n, d2);
+            o.o2[0] = o2.x; o.o2[1] = o2.y; o.o2[2] = o2.z;
+            o.d2[0] = d2.x; o.d2[1] = d2.y; o.d2[2] = d2.z;
+            const Isect s2 = scene_intersect<true>(S, o2, d2, Q.tMax2);
+            o.hit2 = s2.hit ? 1 : 0;
+            o.t2 = s2.hit ? s2.t : 0.f;
+            o.any2 = scene_intersect_any<true>(S, o2, d2, Q.tMax2) ? 1 : 0;
+        }
+    }
+    out[i] = o;
+}
+
 template <class Medium>
 __global__ __launch_bounds__(kBlock) void k_tmaj_batch(const DScene *__restrict__ Sp, int variant, int n,
                                                        const VspgTmajQuery *__restrict__ q, VspgTmajResult *__restrict__ out) {
@@ -3623,6 +3659,22 @@ int vspg_trace_paths(VspgRenderer *r, int n, const int32_t *pixel_xy, const int3
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_L, dl.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     if (out_segments) HIPCHK(hipMemcpyAsync(out_segments, dg.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vspg_ray_batch(VspgRenderer *r, int n, const VspgRayQuery *q, VspgRayResult *out, void *stream) {
+    if (!r || n < 0 || (n > 0 && (!q || !out))) return fail(VSPG_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf dq, dout;
+    HIPCHK(hipMalloc(&dq.p, (size_t)n * sizeof(VspgRayQuery)));
+    HIPCHK(hipMalloc(&dout.p, (size_t)n * sizeof(VspgRayResult)));
+    HIPCHK(hipMemcpyAsync(dq.p, q, (size_t)n * sizeof(VspgRayQuery), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ray_batch, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, r->dscene, n, (const VspgRayQuery *)dq.p, (VspgRayResult *)dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * sizeof(VspgRayResult), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
