@@ -346,7 +346,11 @@ int vspg_renderer_set_guiding_field(VspgRenderer *r, const VspgField *surface_fi
 /* Replaces one wave of ImageTileIntegrator::Render -- the ParallelFor2D over all pixels
  * for sample indices [wave_start, wave_end) (src/pbrt/cpu/integrators.cpp:183-207),
  * i.e. EvaluatePixelSample -> Li -> SampleDistance -> film.AddSample for every pixel.
- * Asynchronous on `stream`. */
+ * Asynchronous on `stream` -- with one exception: a scene with MEDIUM BOUNDARIES over a grid / NanoVDB medium (the wavefront
+ * pipeline's boundary flavour) runs path-loop iterations until its path list is empty, and the emptiness test is a host read:
+ * the call then synchronises `stream` once per iteration past the ones every pass needs and once at the end of every sample
+ * pass (a host that overlaps work on other streams should issue that work first).  A pass whose list does not run dry
+ * within the iteration cap returns VSPG_ESCOPE after the samples of the paths that did finish have entered the film. */
 int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream);
 
 /* Replaces GuidedVolPathVSPGIntegrator::PostProcessWave

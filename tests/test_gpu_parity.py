@@ -2822,15 +2822,18 @@ def test_temperature_grid_emission_vs_oracle(gpu_pkg, kind, options):
         assert g.counters() == cc.counters(), kn
         films.append(fg)
         g.close(); cc.close()
-    for kernel in (None, "lane"):
+    # ("wg": the workgroup kernel's pool record has no room for the wavelength sample -- a medium with a temperature grid is routed
+    #  to the per-lane kernel instead, vspg_capi.hip: uses_wg_kernel; round 4 ran k_render_wave_wg with an uninitialised sample)
+    for kernel in (None, "lane", "wg"):
         if kernel:
             os.environ["VSPG_KERNEL"] = kernel
         try:
             on_kernel()
         finally:
             os.environ.pop("VSPG_KERNEL", None)
-    assert len(names) == 2, names
-    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32))   # pipeline == per-lane kernel, bit for bit
+    assert len(names) == 2 and not any("k_render_wave_wg" in k for k in names), names
+    for f in films[1:]:
+        assert np.array_equal(films[0].view(np.uint32), f.view(np.uint32))   # pipeline == per-lane kernel, bit for bit
     # without the temperature grid: darker
     keep = scene.medium.temperature
     scene.medium.temperature = None

@@ -1669,7 +1669,7 @@ struct VspgRenderer {
     float *temperature = nullptr;  // temperature grid (raw samples)
     float *majorant = nullptr;  // 16^3 majorant grid
     DTri *tris = nullptr;          // triangle soup in BVH leaf order + the BVH (depth-first, skip links)
-    DBvhNode *bvh = nullptr;
+    DBvh4Node *bvh = nullptr;
     // wavefront pipeline (vspg_wavefront.h): path SoA, lists and per-iteration control blocks, allocated at first use
     float *wf_pool = nullptr;
     // k_render_wave_wg2: one {L, ISG code} per pixel of a one-sample launch.  The samples of launch w enter the film at the start of
@@ -2231,6 +2231,14 @@ static std::vector<float> build_majorant_grid(const VspgMedium &m) {
 // layout with skip links -- see DBvhNode).  cpu/aggregates.cpp:529-640 is what it stands in for; WHICH triangles a ray
 // tests never changes a result (vspg_device.h: bvh_closest), so the builder is free.
 namespace bvhbuild {
+// the binary tree the builder grows first, depth-first: an inner node's first child is the next node, `skip` is the index behind
+// its subtree (so its second child sits at nodes[first child].skip)
+struct DBvhNode {
+    float bmin[3];
+    int32_t skip;
+    float bmax[3];
+    int32_t leaf;    // >= 0: first triangle * 8 + count (1..7); -1: inner node
+};
 struct Box { float lo[3], hi[3]; };
 static Box empty_box() { return Box{{kInf, kInf, kInf}, {-kInf, -kInf, -kInf}}; }
 static void grow(Box &b, const float *p) { for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], p[k]); b.hi[k] = std::max(b.hi[k], p[k]); } }
@@ -2240,25 +2248,63 @@ static float area(const Box &b) {
     return dx < 0 ? 0.f : 2 * (dx * dy + dy * dz + dz * dx);
 }
 struct Builder {
-    const float *p;                 // 9 floats per triangle
+    const float *p = nullptr;       // 9 floats per triangle
     std::vector<int> order;         // triangle indices, permuted in place
     std::vector<Box> tbox;
     std::vector<float> cen;         // 3 per triangle
     std::vector<DBvhNode> nodes;
     std::vector<signed char> split_axis;   // per node: the axis its children were separated along (inner nodes)
-    // The traversal has no stack: its order is the array's.  So the tree is laid out EIGHT times, once per sign pattern of a ray
-    // direction: at every inner node the child on the side the ray comes from goes first (near-first traversal, which lets the
-    // running closest distance cull the far child), each layout with its own skip links.  A ray walks the layout of its octant.
-    void emit(int node, int oct, std::vector<DBvhNode> &out) const {
-        const int idx = (int)out.size();
-        out.push_back(nodes[node]);
-        if (nodes[node].leaf < 0) {
-            const int left = node + 1, right = nodes[left].skip;   // (base layout: left subtree first)
-            const bool right_first = (oct >> split_axis[node]) & 1;  // the ray runs towards -axis: the upper child is nearer
-            emit(right_first ? right : left, oct, out);
-            emit(right_first ? left : right, oct, out);
+    // The device tree (DBvh4Node): an inner node takes its two children and, while it holds fewer than four, replaces the inner child
+    // of the largest surface area by that child's two children.  Returns the node's index; *depth: levels below and including it.
+    bool balanced = false;          // median splits only: the fallback that bounds the depth for the traversal's stack
+    std::vector<DBvh4Node> nodes4;
+    int collapse(int node, int *depth) {
+        const int me = (int)nodes4.size();
+        nodes4.push_back(DBvh4Node{});
+        int kids[4], nk = 0;
+        if (nodes[node].leaf >= 0) {
+            kids[nk++] = node;  // (a soup that fits one leaf: a root with one child)
+        } else {
+            kids[nk++] = node + 1;
+            kids[nk++] = nodes[node + 1].skip;
+            while (nk < 4) {
+                int pick = -1;
+                float pa = -1.f;
+                for (int k = 0; k < nk; ++k)
+                    if (nodes[kids[k]].leaf < 0) {
+                        const Box b{{nodes[kids[k]].bmin[0], nodes[kids[k]].bmin[1], nodes[kids[k]].bmin[2]}, {nodes[kids[k]].bmax[0], nodes[kids[k]].bmax[1], nodes[kids[k]].bmax[2]}};
+                        const float ar = area(b);
+                        if (ar > pa) { pa = ar; pick = k; }
+                    }
+                if (pick < 0) break;
+                const int c = kids[pick];
+                kids[pick] = c + 1;
+                kids[nk++] = nodes[c + 1].skip;
+            }
         }
-        out[idx].skip = (int)out.size();
+        int dmax = 0;
+        for (int k = 0; k < 4; ++k) {
+            DBvh4Node &N = nodes4[me];  // (re-taken every round: the recursion below grows the vector)
+            if (k >= nk) {
+                N.lox[k] = N.loy[k] = N.loz[k] = kInf; N.hix[k] = N.hiy[k] = N.hiz[k] = -kInf;
+                N.child[k] = kBvhAbsent;
+                continue;
+            }
+            const DBvhNode &c = nodes[kids[k]];
+            N.lox[k] = c.bmin[0]; N.loy[k] = c.bmin[1]; N.loz[k] = c.bmin[2];
+            N.hix[k] = c.bmax[0]; N.hiy[k] = c.bmax[1]; N.hiz[k] = c.bmax[2];
+            if (c.leaf >= 0) {
+                N.child[k] = -c.leaf - 1;
+            } else {
+                int dk = 0;
+                const int idx = collapse(kids[k], &dk);
+                nodes4[me].child[k] = idx;
+                dmax = dk > dmax ? dk : dmax;
+            }
+        }
+        for (int k = 0; k < 4; ++k) nodes4[me].pad[k] = 0;
+        *depth = dmax + 1;
+        return me;
     }
 #ifndef VSPG_BVH_LEAF
 #define VSPG_BVH_LEAF 2
@@ -2281,7 +2327,7 @@ struct Builder {
         int axis = 0;
         for (int k = 1; k < 3; ++k) if (cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
         int mid = -1;
-        if (n > kLeafMax) {  // binned SAH over all three axes: the cheapest of the 3 x (NB - 1) candidate planes
+        if (n > kLeafMax && !balanced) {  // binned SAH over all three axes: the cheapest of the 3 x (NB - 1) candidate planes
             constexpr int NB = 16;
             float best = kInf; int bs = -1, baxis = -1;
             for (int ax = 0; ax < 3; ++ax) {
@@ -2306,7 +2352,7 @@ struct Builder {
                 mid = (int)(it - order.begin());
             }
         }
-        if (n > 7 && (mid <= lo || mid >= hi)) {  // no useful split but too many for a leaf: median by index
+        if ((n > 7 || (balanced && n > kLeafMax)) && (mid <= lo || mid >= hi)) {  // no useful split but too many for a leaf (or the balanced fallback): median by index
             mid = lo + n / 2;
             std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
                              [&](int a, int c) { return cen[3 * a + axis] < cen[3 * c + axis]; });
@@ -2842,18 +2888,27 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
             for (size_t i = 0; i < all.size(); ++i) sorted[i] = all[B.order[i]];
             CK(hipMalloc(&r->tris, sorted.size() * sizeof(DTri)));
             CK(hipMemcpy(r->tris, sorted.data(), sorted.size() * sizeof(DTri), hipMemcpyHostToDevice));
-            std::vector<DBvhNode> layouts;   // eight direction-ordered layouts, back to back (see Builder::emit)
-            layouts.reserve(8 * B.nodes.size());
-            for (int oct = 0; oct < 8; ++oct) {
-                std::vector<DBvhNode> one;
-                one.reserve(B.nodes.size());
-                B.emit(0, oct, one);
-                layouts.insert(layouts.end(), one.begin(), one.end());
+            int depth4 = 0;
+            B.collapse(0, &depth4);
+            if (3 * depth4 + 1 > kBvhStack) {  // a degenerate soup made the SAH tree too deep for the traversal's stack: median splits
+                bvhbuild::Builder B2;
+                B2.balanced = true;
+                B2.p = B.p; B2.tbox = B.tbox; B2.cen = B.cen;
+                B2.order.resize(all.size());
+                for (size_t i = 0; i < all.size(); ++i) B2.order[i] = (int)i;
+                B2.nodes.reserve(2 * all.size());
+                B2.build(0, (int)all.size());
+                B2.collapse(0, &depth4);
+                if (3 * depth4 + 1 > kBvhStack) { vspg_renderer_destroy(r); return fail(VSPG_ESCOPE, "triangle soup too large for the BVH traversal's stack"); }
+                B.order = B2.order;
+                B.nodes4 = B2.nodes4;
+                for (size_t i = 0; i < all.size(); ++i) sorted[i] = all[B.order[i]];
+                CK(hipMemcpy(r->tris, sorted.data(), sorted.size() * sizeof(DTri), hipMemcpyHostToDevice));
             }
-            CK(hipMalloc(&r->bvh, layouts.size() * sizeof(DBvhNode)));
-            CK(hipMemcpy(r->bvh, layouts.data(), layouts.size() * sizeof(DBvhNode), hipMemcpyHostToDevice));
+            CK(hipMalloc(&r->bvh, B.nodes4.size() * sizeof(DBvh4Node)));
+            CK(hipMemcpy(r->bvh, B.nodes4.data(), B.nodes4.size() * sizeof(DBvh4Node), hipMemcpyHostToDevice));
             r->hscene.n_tris = (int32_t)sorted.size();
-            r->hscene.n_bvh_nodes = (int32_t)B.nodes.size();
+            r->hscene.n_bvh_nodes = (int32_t)B.nodes4.size();
             r->hscene.tris = r->tris;
             r->hscene.bvh = r->bvh;
         }
@@ -3054,6 +3109,8 @@ static bool uses_wg_kernel(const VspgRenderer *r) {
     // are built for rectangle scenes with area lights only (HomogeneousMediumT::kSimpleScene)
     if (r->hscene.n_tris > 0 || r->hscene.n_inf > 0 || has_boundaries_or_spheres(r)) return false;
     if (r->hscene.lsamp.mode != VSPG_LIGHTSAMPLER_UNIFORM) return false;  // power / BVH picks of a multi-light scene: the full-scene kernels
+    // (a temperature grid's blackbody emission needs the path's wavelength sample, which k_render_wave_wg's pool record does not carry)
+    if (grid && r->hscene.temperature) return false;
     return !guided && !nvdb && want_wg && !(kenv && strcmp(kenv, "lane") == 0) && !(r->hscene.tr_calc && grid);
 }
 // "wf" = the multi-kernel wavefront pipeline (vspg_wavefront.h): heterogeneous media whose every segment runs the
@@ -3225,7 +3282,7 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
         };
         const size_t nb = (size_t)r->hscene.bnx * r->hscene.bny * r->hscene.bnz;
         const void *bufs[6] = {r->tris, r->bvh, r->brick_index, r->octets, r->dscene, r->majorant};
-        const size_t sizes[6] = {(size_t)r->hscene.n_tris * sizeof(DTri), (size_t)r->hscene.n_bvh_nodes * 8 * sizeof(DBvhNode), nb * 4, r->n_bricks * 512 * 32,
+        const size_t sizes[6] = {(size_t)r->hscene.n_tris * sizeof(DTri), (size_t)r->hscene.n_bvh_nodes * sizeof(DBvh4Node), nb * 4, r->n_bricks * 512 * 32,
                                  sizeof(DScene), (size_t)16 * 16 * 16 * 4};
         unsigned long long before[6];
         for (int k = 0; k < 6; ++k) before[k] = checksum(bufs[k], sizes[k]);

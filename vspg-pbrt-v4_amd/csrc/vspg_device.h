@@ -598,15 +598,20 @@ struct DSphere {
     float Kd[3];
     int32_t flip, has_lobes, flags;
 };
-// BVH in depth-first order (own builder, vspg_capi.hip): an inner node's first child is the next node; `skip` is where
-// the traversal continues when the node is missed or its subtree is done -- no stack, no per-lane scratch.  S.bvh holds
-// EIGHT layouts of the same tree, n_bvh_nodes each, one per sign pattern of a ray direction (near child first).
-struct DBvhNode {
-    float bmin[3];
-    int32_t skip;
-    float bmax[3];
-    int32_t leaf;    // >= 0: first triangle * 8 + count (1..7); -1: inner node
+// Four-wide BVH (round 5; own builder in vspg_capi.hip: binned SAH over triangles, then every inner node absorbs the children of
+// its largest children until it has four).  A node is the BOXES OF ITS CHILDREN, structure-of-arrays -- one 128-byte fetch tests
+// four boxes, and a ray makes half as many dependent fetches on its way down as through the binary tree of rounds 1-4 -- plus
+// what each child is: >= 0 an inner node's index, < 0 a leaf -(first triangle * 8 + count) - 1 (count 1..7), kBvhAbsent: no child.
+// The traversal keeps the hit children it has not visited on a small per-lane stack (cpu/aggregates.cpp:529-590 does the same
+// with `nodesToVisit[64]`); the builder keeps the tree shallow enough for it (kBvhStack).
+struct DBvh4Node {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int32_t child[4];
+    int32_t pad[4];
 };
+static_assert(sizeof(DBvh4Node) == 128, "one node = eight 16-byte loads");
+constexpr int32_t kBvhAbsent = (int32_t)0x80000000;
+constexpr int kBvhStack = 48;   // entries; a node leaves at most three behind per level, the builder bounds the depth at 15
 struct DScene {
     int32_t n_quads, n_lights;
     int32_t n_tris, n_bvh_nodes;
@@ -616,7 +621,7 @@ struct DScene {
     int32_t n_spheres, has_boundaries, camera_in_medium, pad_b;
     DSphere spheres[VSPG_MAX_SPHERES];
     const DTri *tris;          // in BVH leaf order
-    const DBvhNode *bvh;
+    const DBvh4Node *bvh;
     // infinite lights (light order: the emissive rectangles, then these); scene_radius: Bounds3::BoundingSphere of the scene bounds
     int32_t n_inf;
     int32_t inf_type[VSPG_MAX_INFINITE_LIGHTS];
@@ -746,6 +751,7 @@ VDEV int tri_of(int prim) { return -2 - prim; }
 // interaction point with its error bounds, the normal and the shading frame are pure functions of it (sphere_interaction),
 // recomputed where they are read -- three floats name the hit, as (p, rectangle) does for a rectangle.
 constexpr int kSpherePrim = 32;
+static_assert(VSPG_MAX_QUADS <= kSpherePrim, "rectangle indices lie below the first sphere primitive");
 VDEV bool is_sphere(int prim) { return prim >= kSpherePrim; }
 VDEV int sphere_of(int prim) { return prim - kSpherePrim; }
 
@@ -892,43 +898,71 @@ VDEV bool tri_intersect(V3 o, const TriRay &R, float tMax, V3 p0, V3 p1, V3 p2, 
     return true;
 }
 // slab test for the traversal only: a conservative SUPERSET test (every triangle whose hit distance is <= tLimit lies in a
-// box this accepts), so which boxes are visited never changes a result
-VDEV bool bvh_box_hit(const float4 &lo, const float4 &hi, V3 o, V3 inv, float tLimit) {
+// box this accepts), so which boxes are visited never changes a result.  *t_near: where the ray enters the box.
+VDEV bool bvh_box_hit(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 inv, float tLimit, float *t_near) {
     float t0 = 0.f, t1 = tLimit;
-    float a = (lo.x - o.x) * inv.x, b = (hi.x - o.x) * inv.x;
+    float a = (lox - o.x) * inv.x, b = (hix - o.x) * inv.x;
     t0 = fmax_(t0, fmin_(a, b)); t1 = fmin_(t1, fmax_(a, b) * 1.00001f);
-    a = (lo.y - o.y) * inv.y; b = (hi.y - o.y) * inv.y;
+    a = (loy - o.y) * inv.y; b = (hiy - o.y) * inv.y;
     t0 = fmax_(t0, fmin_(a, b)); t1 = fmin_(t1, fmax_(a, b) * 1.00001f);
-    a = (lo.z - o.z) * inv.z; b = (hi.z - o.z) * inv.z;
+    a = (loz - o.z) * inv.z; b = (hiz - o.z) * inv.z;
     t0 = fmax_(t0, fmin_(a, b)); t1 = fmin_(t1, fmax_(a, b) * 1.00001f);
+    *t_near = t0;
     return !(t0 > t1);  // NaN (0 * inf on a slab boundary) keeps the node
 }
-// (Tried: the "while-while" loop shape -- every lane walks to its next leaf, then the triangle tests run together: 8-18 % slower
-//  than this single loop on the terrain scenes of scripts/tri_timing.py.)
-// closest triangle hit with distance < tMax: every triangle is tested against the RAY's tMax (never against the running
-// closest distance -- the test's acceptance would then depend on the visiting order), candidates compare by (t, id)
-VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, TriHit *best) {
+// One traversal for both queries.  ANY = false: the closest triangle hit with distance < tMax -- every triangle is tested against
+// the RAY's tMax (never against the running closest distance: the test's acceptance would then depend on the visiting order),
+// candidates compare by (t, id), boxes beyond the closest hit so far are culled with slack.  ANY = true: whether any triangle is
+// hit before tMax.  A single loop: a lane is at an inner node (four box tests, the nearest hit child next, the others stacked) or
+// at a leaf (its triangles) -- the "while-while" shape (every lane walks to its next leaf, then the triangle tests run together)
+// measured 8-18 % slower on the binary tree of round 2.
+template <bool ANY>
+VDEV bool bvh_traverse(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, TriHit *best) {
     const V3 inv = V3{1 / d.x, 1 / d.y, 1 / d.z};
     const TriRay R = tri_ray(d);
+    int st_ref[kBvhStack];
+    float st_t[ANY ? 1 : kBvhStack];
+    int sp = 0;
     bool found = false;
     int best_id = 0x7fffffff;
     float limit = tMax;
-    int i = 0;
-    // the layout of the ray's octant: near child first at every inner node (vspg_capi.hip, bvhbuild::Builder::emit)
-    const DBvhNode *const nodes = S.bvh + (size_t)((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) * (size_t)S.n_bvh_nodes;
-    while (i < S.n_bvh_nodes) {
-        const float4 *nd = reinterpret_cast<const float4 *>(nodes + i);
-        const float4 lo = nd[0], hi = nd[1];
-        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
-        // cull with slack: the box may touch the triangle exactly where it is hit
-        if (bvh_box_hit(lo, hi, o, inv, found ? limit * 1.00001f : limit)) {
-            if (leaf >= 0) {
-                const int first = leaf >> 3, cnt = leaf & 7;
-                for (int k = 0; k < cnt; ++k) {
-                    const DTri &T = S.tris[first + k];
-                    TriHit h;
-                    if (tri_intersect(o, R, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax &&
-                        (!found || h.t < best->t || (h.t == best->t && T.id < best_id))) {
+    int ref = 0;  // the root
+    while (true) {
+        int next = kBvhAbsent;
+        if (ref >= 0) {
+            const float4 *nd = reinterpret_cast<const float4 *>(S.bvh + ref);
+            const float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5];
+            const int4 ch = *reinterpret_cast<const int4 *>(nd + 6);
+            const float lim = !ANY && found ? limit * 1.00001f : limit;  // cull with slack: the box may touch the triangle exactly where it is hit
+            float next_t = kInf;
+            const auto child = [&](float bx0, float by0, float bz0, float bx1, float by1, float bz1, int c) {
+                float tn;
+                if (c != kBvhAbsent && bvh_box_hit(bx0, by0, bz0, bx1, by1, bz1, o, inv, lim, &tn)) {
+                    int push = c;
+                    float push_t = tn;
+                    if (tn < next_t || next == kBvhAbsent) {  // the nearest hit child is visited next, the others wait
+                        push = next; push_t = next_t;
+                        next = c; next_t = tn;
+                    }
+                    if (push != kBvhAbsent) {
+                        st_ref[sp] = push;
+                        if constexpr (!ANY) st_t[sp] = push_t;
+                        sp++;
+                    }
+                }
+            };
+            child(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ch.x);
+            child(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ch.y);
+            child(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ch.z);
+            child(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ch.w);
+        } else {
+            const int leaf = -ref - 1, first = leaf >> 3, cnt = leaf & 7;
+            for (int k = 0; k < cnt; ++k) {
+                const DTri &T = S.tris[first + k];
+                TriHit h;
+                if (tri_intersect(o, R, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax) {
+                    if constexpr (ANY) return true;
+                    if (!found || h.t < best->t || (h.t == best->t && T.id < best_id)) {
                         found = true;
                         *best = h;
                         best_id = T.id;
@@ -936,42 +970,22 @@ VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, Tri
                         limit = h.t;
                     }
                 }
-                i = skip;
-            } else {
-                i = i + 1;
             }
-        } else {
-            i = skip;
         }
+        // what waits: the most recent first; entries beyond the closest hit so far are dropped unvisited
+        while (next == kBvhAbsent) {
+            if (sp == 0) return found;
+            --sp;
+            if (ANY || !(st_t[sp] > (found ? limit * 1.00001f : limit))) next = st_ref[sp];
+        }
+        ref = next;
     }
-    return found;
 }
+VDEV bool bvh_closest(const DScene &S, V3 o, V3 d, float tMax, int *tri_pos, TriHit *best) { return bvh_traverse<false>(S, o, d, tMax, tri_pos, best); }
 VDEV bool bvh_any(const DScene &S, V3 o, V3 d, float tMax) {
-    const V3 inv = V3{1 / d.x, 1 / d.y, 1 / d.z};
-    const TriRay R = tri_ray(d);
-    int i = 0;
-    const DBvhNode *const nodes = S.bvh + (size_t)((d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0)) * (size_t)S.n_bvh_nodes;
-    while (i < S.n_bvh_nodes) {
-        const float4 *nd = reinterpret_cast<const float4 *>(nodes + i);
-        const float4 lo = nd[0], hi = nd[1];
-        const int skip = __float_as_int(lo.w), leaf = __float_as_int(hi.w);
-        if (bvh_box_hit(lo, hi, o, inv, tMax)) {
-            if (leaf >= 0) {
-                const int first = leaf >> 3, cnt = leaf & 7;
-                for (int k = 0; k < cnt; ++k) {
-                    const DTri &T = S.tris[first + k];
-                    TriHit h;
-                    if (tri_intersect(o, R, tMax, ld3(T.p0), ld3(T.p1), ld3(T.p2), &h) && h.t < tMax) return true;
-                }
-                i = skip;
-            } else {
-                i = i + 1;
-            }
-        } else {
-            i = skip;
-        }
-    }
-    return false;
+    int tp;
+    TriHit h;
+    return bvh_traverse<true>(S, o, d, tMax, &tp, &h);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -336,7 +336,7 @@ VDEV Spec sample_Ld_shadow(const DScene &S, const Medium &medium, const Intr &in
             const V3 nt = offset_ray_origin(ls.pLight, ls.nLight, nf - ls.pLight.mid());
             lo = nf;
             ld = nt - nf;
-            lmed = get_medium(sfl, si.n, ld, lmed);
+            lmed = S.medium_type != VSPG_MEDIUM_NONE && get_medium(sfl, si.n, ld, lmed);  // (no medium: IFACE bits on a surface name nothing)
         }
     } else if (!(ld.x == 0 && ld.y == 0 && ld.z == 0)) {
         // every surface here carries a material: any hit is an opaque blocker (:1197-1200)

@@ -501,7 +501,7 @@ VDEV ShadowSetup sample_Ld_begin(const DScene &S, const Medium &medium, int ch, 
             const V3 nt = offset_ray_origin(ls.pLight, ls.nLight, nf - ls.pLight.mid());
             lo = nf;
             ld = nt - nf;
-            lmed = get_medium(sfl, si.n, ld, lmed);
+            lmed = S.medium_type != VSPG_MEDIUM_NONE && get_medium(sfl, si.n, ld, lmed);
         }
         if (blocked) {
             pc.shadow_ray();
