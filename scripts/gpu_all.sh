@@ -1,7 +1,7 @@
 #!/bin/bash
 # the whole GPU suite + smoke + the bench lines (stops after a step that was killed)
 mkdir -p gpurun_out
-T=${1:-r04}
+T=${1:-r05}
 step() { local t=$1 log=$2; shift 2; timeout -k 10 $t "$@" > gpurun_out/$log 2>&1; local rc=$?; echo "$log rc=$rc"; tail -${TAILN:-3} gpurun_out/$log | cut -c1-400; if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -eq 134 ]; then exit $rc; fi; }
 step 900 ${T}_tests_gpu.log python -m pytest tests -m gpu -q -x
 step 200 ${T}_smoke.log python -c "import __graft_entry__ as g; g.smoke()"

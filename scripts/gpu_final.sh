@@ -1,6 +1,6 @@
 #!/bin/bash
 # measurement of record: kernel-trace stats + PMC passes for the bench workloads (own runs, --pmc never mixed with trace domains)
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-all}   # trace | pmc | all (the two parts fit one gpurun call each)
 mkdir -p gpurun_out/final
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
