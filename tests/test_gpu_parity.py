@@ -2068,6 +2068,43 @@ def test_wavefront_pipeline_concurrent_walks_equal_single_stream_order(gpu_pkg, 
         assert np.array_equal(f.view(np.uint32), results[0][0].view(np.uint32))
 
 
+@pytest.mark.parametrize("shape", ["box", "box-guided", "scene", "scene-nvdb"])
+def test_merged_walk_kernel_equals_the_two_walk_kernels(gpu_pkg, shape):
+    """Round 5: the shadow walks of iteration i and the distance walks of iteration i + 1 as ONE persistent kernel over one job
+    stream (k_wf_walk: the default for boundary scenes and guided pipelines) against the two kernels side by side on two streams
+    (the default for dense unguided clouds): VSPG_WF_MERGED=1 / 0 give the same film and counters bit for bit, at a size where
+    wavefronts really hold both kinds of job."""
+    P = gpu_pkg
+    W, H = 960, 540
+    guided = shape.endswith("guided")
+    scene = P.cloud_box_scene(W, H, 64) if shape.startswith("box") else P.cloud_scene(W, H, 64, nvdb=shape.endswith("nvdb"))
+    prm = P.default_params() if guided else P.app_f_params()
+    if not guided:
+        prm.vspsamplingmethod = P.VSP_RESAMPLING
+    field = None
+    if guided:
+        import scenes
+        field = scenes.light_field(P, n=4)
+    results = []
+    for merged in ("1", "0", "1"):
+        os.environ["VSPG_WF_MERGED"] = merged
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=6)
+            if field is not None:
+                r.set_guiding_field(field, field)
+            assert r.kernel_name().startswith("k_wf_dist_walk")
+            for w in range(3):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            results.append((r.film(), r.counters()))
+            r.close()
+        finally:
+            os.environ.pop("VSPG_WF_MERGED", None)
+    assert results[0][1]["shadow_density_queries"] > 0 and results[0][1]["density_queries"] > 0
+    for f, c in results[1:]:
+        assert c == results[0][1]
+        assert np.array_equal(f.view(np.uint32), results[0][0].view(np.uint32))
+
+
 @pytest.mark.parametrize("kind", ["grid", "nvdb"])
 def test_guided_wavefront_pipeline_equals_per_lane_kernel(gpu_pkg, kind):
     """The reference-default guided configuration over a heterogeneous medium with a field in place (config 5's query side):

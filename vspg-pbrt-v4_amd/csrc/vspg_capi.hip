@@ -2594,9 +2594,11 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
     L.dense = (unsigned)r->num_cus * 8u;
     L.walk = (unsigned)r->num_cus * (unsigned)walk_blocks;
     L.swalk = (unsigned)r->num_cus * (unsigned)shadow_blocks;
+    L.mwalk = (unsigned)r->num_cus * (unsigned)kWfMergedWavesPerSimd;
     if (L.dense > max_blocks) L.dense = max_blocks;
     if (L.walk > max_blocks) L.walk = max_blocks;
     if (L.swalk > max_blocks) L.swalk = max_blocks;
+    if (L.mwalk > max_blocks) L.mwalk = max_blocks;
     // The shadow walk of iteration i runs beside the distance walk of iteration i + 1, on the renderer's second stream; the
     // vertex kernel of iteration i + 1 waits for both (it adds the shadow walk's result first thing).  VSPG_WF_SERIAL=1 keeps
     // everything on the caller's stream (same results; for A/B runs and debugging).
@@ -2606,6 +2608,11 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_vertex, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&r->wf_ev_shadow, hipEventDisableTiming));
     }
+    // both walks of an iteration as ONE kernel where the job lists are short or a third kernel sits in the chain (boundary scenes,
+    // guided pipelines); side by side on two streams for dense unguided clouds (k_wf_walk, vspg_wavefront.h: measured both ways).
+    // VSPG_WF_MERGED=0|1 overrides (read per pass: tests and A/Bs flip it).
+    L.merged = bnd || guided;
+    if (const char *e = getenv("VSPG_WF_MERGED")) { if (e[0] == '0') L.merged = false; else if (e[0] == '1') L.merged = true; }
     L.s = s;
     L.s2 = L.serial ? s : r->wf_stream2;
     L.ev_vertex = r->wf_ev_vertex;

@@ -570,7 +570,7 @@ enum { WALK_MOVED = 0, WALK_COLLISION = 1, WALK_END = 2 };
 // advance: everything up to (not including) the collision.  Returns WALK_COLLISION with *t_out set when a tentative collision
 // was drawn inside the current segment, WALK_END when the iterator ran out, WALK_MOVED otherwise (call again).
 template <class Medium, bool CAP>
-VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out) {
+VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out, int cap = 10000) {
     if (!w.in_seg) {
         MajSeg seg;
         // (An empty cell costs a whole tracking round here -- T_maj *= FastExp(-0) == 1 and nothing else.  Crossing a RUN of empty
@@ -597,7 +597,7 @@ VDEV int walk_advance(WalkState<Medium> &w, int ch, float scale, float *t_out) {
     const float t = w.tMin + sample_exponential(w.u, smaj);
     w.u = w.rng.uniform();
     if (t < w.seg_tMax) {
-        if (CAP && w.count > 10000) {  // media_sampleTMaj.h:216-219: leaves the inner loop only
+        if (CAP && w.count > cap) {  // media_sampleTMaj.h:216-219: leaves the inner loop only
             w.in_seg = false;
             return WALK_MOVED;
         }
@@ -635,6 +635,10 @@ constexpr int kWfBlock = 256;
 #endif
 constexpr int kWfWalkWavesPerSimd = VSPG_WF_WALK_WAVES;  // launch bound of the walk kernels (register budget 128)
 constexpr int kWfShadowWavesPerSimd = VSPG_WF_SHADOW_WAVES;  // the shadow walk carries less state (<= 96 registers)
+#ifndef VSPG_WF_MERGED_WAVES
+#define VSPG_WF_MERGED_WAVES 4   // (5: 96 VGPRs + 12-36 B of scratch; measured slower on every workload but NanoVDB semantics)
+#endif
+constexpr int kWfMergedWavesPerSimd = VSPG_WF_MERGED_WAVES;  // k_wf_walk (both kinds of job: the two kinds' running state shares registers)
 constexpr int kWfRefill = 16;
 #ifndef VSPG_WF_VERTEX_WAVES
 #define VSPG_WF_VERTEX_WAVES 3   // launch bound of the unguided vertex kernel (waves per SIMD)
@@ -961,6 +965,38 @@ VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, 
         const unsigned take = cnt - served < avail ? cnt - served : avail;
         if (want && !got && rank >= served && rank < served + take) {
             *slot_out = list[c.next + (rank - served)];
+            got = true;
+        }
+        c.next += take;
+        served += take;
+    }
+    return got;
+}
+
+// the same over a job STREAM without a list of its own: hands out positions (k_wf_walk maps them to its two lists)
+VDEV bool wf_claim_index(WfClaim &c, bool want, unsigned n, unsigned int *head, unsigned *index_out) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long need = __ballot(want);
+    const unsigned cnt = (unsigned)__popcll(need);
+    const unsigned rank = (unsigned)__popcll(need & ((1ull << lane) - 1ull));
+    bool got = false;
+    unsigned served = 0;
+    while (served < cnt) {
+        if (c.next >= c.end) {
+            if (c.exhausted) break;
+            const unsigned sz = wf_claim_size(n, c.seen);
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(head, sz);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n) { c.exhausted = true; break; }
+            c.next = base;
+            c.end = base + sz < n ? base + sz : n;
+            c.seen = c.end;
+        }
+        const unsigned avail = c.end - c.next;
+        const unsigned take = cnt - served < avail ? cnt - served : avail;
+        if (want && !got && rank >= served && rank < served + take) {
+            *index_out = c.next + (rank - served);
             got = true;
         }
         c.next += take;
@@ -1585,6 +1621,156 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
             }
         } else if (active && r == WALK_END) {
             T_res = w.T_maj;
+            active = false;
+            result = true;
+        }
+    }
+    wf_flush_counters(pc, a.counters);
+}
+
+// ---- BOTH walks of a path-loop iteration in one persistent kernel (round 5) ---------------------------------------------------------
+// The shadow walks of iteration i and the distance walks of iteration i + 1 are produced by the same vertex kernel and consumed by
+// the same next one; as two kernels side by side (rounds 2-4) each drained on its own -- 30 % of a walk kernel's loop iterations ran
+// in wavefronts with no job left to claim, at 15 lanes -- and each kept its own wavefronts resident.  Here they are ONE job stream
+// (the shadow jobs first, then the distance jobs; one cursor): a lane runs one job of either kind, a wavefront refills its idle lanes
+// from whatever is next, the majorant-cell advance (DDA step, exponential sample, the tentative-collision draw) is the same code
+// for both kinds and only the collision's callback differs: the reservoir update (:691-719) or ratio tracking (:1207-1232).  A
+// wavefront holds both kinds only around the point where the stream changes kind.  Per job nothing changes: same bits.
+// Measured (same box, ms per 1080p wave, merged / two kernels side by side): cloud-scene 5.26 / 5.56, cloud-scene-guided 7.57 / 8.00,
+// cloud-guided 9.37 / 9.53 -- but the all-filling cloud 8.75 / 8.19-8.41 and NanoVDB semantics 14.4 / 12.8: side by side the two
+// kernels keep more wavefronts resident (four of the distance walk's + five of the shadow walk's compete for a SIMD's registers),
+// which is what long, dense job lists want; short lists (boundary scenes: 7-9 iterations over thinning lists) and the guided
+// pipelines (a third kernel, k_wf_begin, in the chain) want fewer launches and tails.  The host picks accordingly (wf_render_pass).
+// it_d / it_s: the iteration whose distance / shadow jobs run, -1: none.
+template <class Medium>
+__global__ __launch_bounds__(kWfBlock, kWfMergedWavesPerSimd) void k_wf_walk(WfArgs a, int it_d, int it_s) {
+    const DScene &S = *a.scene;
+    const Medium medium = wf_block_medium<Medium>(S);
+    const WfPool &P = a.P;
+    const unsigned n_s = it_s >= 0 ? a.iters[it_s].n_shadow : 0u, n_d = it_d >= 0 ? a.iters[it_d].n_walk : 0u;
+    const unsigned n = n_s + n_d;
+    unsigned int *const head = it_d >= 0 ? &a.iters[it_d].pad[0] : &a.iters[it_s].pad[1];  // (the control blocks are zeroed once per pass)
+    WfCounters pc;
+    pc.zero();
+    WfClaim claim{0u, 0u, false, 0u};
+    bool active = false, result = false, shadow = false;
+    unsigned slot = 0;
+    WalkState<Medium> w;
+    w.iter = medium.empty_iter();
+    w.sigma_maj = sp(0.f); w.seg_tMax = w.tMin = 0.f; w.T_maj = sp(1.f); w.u = 0.f; w.rng.state = w.rng.inc = 0; w.count = 0; w.in_seg = false;
+    V3 ro = mk(0, 0, 0), rdn = mk(0, 0, 1);
+    float scale = 1.f;
+    int ch = 0;
+    Sampler sampler;
+    sampler.rng.state = sampler.rng.inc = 0;
+    // one set of registers for the two kinds' running state: reservoir {trRatioEst, beta_rs, r_u_rs} | ratio tracking {T_ray, r_l, r_u}
+    Spec xa = sp(1.f), xb = sp(1.f), xc = sp(1.f);
+    float weightSum = 0, sel_wi = 0;
+    Spec sel_num = sp(0.f), sel_den = sp(0.f);   // (shadow jobs: sel_num carries the residual T_maj)
+    V3 sel_p = mk(0, 0, 0);
+    while (true) {
+        const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
+        if (n_idle == 64u || (n_idle >= (unsigned)a.walk_refill && !(claim.exhausted && claim.next >= claim.end))) {
+            if (result) {  // park the finished walk's result
+                if (shadow) {
+                    wf_store_shadow_result(P, slot, a.compact_results != 0, WfShadowResult{xa, xb, xc, sel_num});
+                } else {
+                    wf_store_walk_result(P, slot, a.compact_results != 0, WfWalkResult{w.T_maj, xa, xb, xc, sel_num, sel_den, weightSum, sel_wi, sel_p});
+                    P.store_rng(WF_RNG, slot, sampler.rng);
+                }
+                result = false;
+            }
+            unsigned idx = 0;
+            if (wf_claim_index(claim, !active, n, head, &idx)) {
+                shadow = idx < n_s;
+                slot = shadow ? a.list_shadow[idx] : a.list_walk[idx - n_s];
+                w.in_seg = false;
+                w.T_maj = sp(1.f);
+                w.count = 0;
+                xa = xb = xc = sp(1.f);
+                if (shadow) {
+                    w.iter = wf_load_iter(P, slot, medium, &ch, WF_SIT, WF_SITP);
+                    w.u = P.f(WF_SWU2, slot);
+                    P.load_rng(WF_SWRNG, slot, w.rng);
+                    ro = P.v3(WF_SLO, slot);
+                    rdn = P.v3(WF_SRDN, slot);
+                    scale = 1.f;
+                } else {
+                    w.iter = wf_load_iter(P, slot, medium, &ch);
+                    w.u = P.f(WF_WU, slot);
+                    P.load_rng(WF_WRNG, slot, w.rng);
+                    ro = P.v3(WF_RO, slot);
+                    rdn = P.v3(WF_RDN, slot);
+                    scale = P.f(WF_MSCALE, slot);
+                    P.load_rng(WF_RNG, slot, sampler.rng);
+                    weightSum = 0; sel_wi = 0;
+                    sel_num = sel_den = sp(0.f);
+                    sel_p = mk(0, 0, 0);
+                }
+                active = true;
+            }
+            if (__ballot(active) == 0ull) break;  // nothing in flight and the stream has run out
+        }
+        // ---- one tracking step ------------------------------------------------------------------------------------
+        float t = 0.f;
+        int r = WALK_MOVED;
+        const int cap = shadow ? 0x7fffffff : 10000;  // (the 10 000-collision guard belongs to the resampling routine only, media_sampleTMaj.h:216-219)
+        if (active) r = walk_advance<Medium, true>(w, ch, scale, &t, cap);
+        for (int rr = 1; rr < a.walk_rounds; ++rr) {
+            const bool again = active && r == WALK_MOVED;
+            if (__popcll(__ballot(again)) < 8) break;
+            if (again) r = walk_advance<Medium, true>(w, ch, scale, &t, cap);
+        }
+        if (active && r == WALK_COLLISION) {
+            w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
+            const V3 p = ro + rdn * t;
+            const MediumProps mp = medium.sample_point(p);
+            const Spec sigma_maj = w.sigma_maj, T_maj = w.T_maj;
+            if (shadow) {  // ratio tracking (:1207-1232): xa = T_ray, xb = r_l, xc = r_u
+                pc.shadow_query();
+                const float pdf = ch_of(T_maj, ch) * ch_of(sigma_maj, ch);
+                const Spec sigma_n = medium.sigma_n(mp, sigma_maj);
+                xa = xa * wdiv(T_maj * sigma_n, pdf);
+                xb = xb * wdiv(T_maj * sigma_maj, pdf);
+                xc = xc * wdiv(T_maj * sigma_n, pdf);
+                const Spec Tr = wdiv(xa, avg(xb + xc));
+                if (maxc(Tr) < 0.05f) {
+                    const float q = 0.75f;
+                    if (w.rng.uniform() < q) xa = sp(0.f);
+                    else xa = wdiv(xa, 1 - q);
+                }
+                if (!nonzero(xa)) {  // the callback stops the traversal: SampleT_maj returns 1
+                    sel_num = sp(1.f);
+                    active = false;
+                    result = true;
+                } else {
+                    w.T_maj = sp(1.f);
+                    w.tMin = t;
+                }
+            } else {  // the resampling callback (:691-719): xa = trRatioEst, xb = beta_rs, xc = r_u_rs; it never stops the traversal
+                pc.density_query();
+                const Spec sigma_t = mp.sigma_t;
+                const Spec sigma_n = clamp_zero(sigma_maj - sigma_t);
+                const float wi = ch_of(wdiv(sigma_t, sigma_maj) * xa, ch);
+                if (wi > 0) {
+                    weightSum += wi;
+                    if (sampler.get1d() < wdiv(wi, weightSum)) {
+                        const float pdf = ch_of(T_maj, ch) * ch_of(sigma_t, ch);
+                        sel_num = wdiv(xb * T_maj * mp.sigma_s, pdf);
+                        sel_den = wdiv(xc * T_maj * sigma_t, pdf);
+                        sel_p = p;
+                        sel_wi = wi;
+                    }
+                }
+                const float pdf = ch_of(T_maj, ch) * ch_of(sigma_n, ch);
+                xb = xb * wdiv(T_maj * sigma_n, pdf);
+                xc = xc * wdiv(T_maj * sigma_n, pdf);
+                xa = xa * wdiv(sigma_n, sigma_maj);
+                w.T_maj = sp(1.f);
+                w.tMin = t;
+            }
+        } else if (active && r == WALK_END) {
+            if (shadow) sel_num = w.T_maj;  // the residual majorant transmittance (T_res)
             active = false;
             result = true;
         }

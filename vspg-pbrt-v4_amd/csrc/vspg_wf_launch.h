@@ -14,8 +14,9 @@ VSPG_NS_BEGIN
 
 struct WfLaunch {
     WfArgs a;
-    unsigned dense, walk, swalk;   // grid sizes: dense kernels, distance walk, shadow walk
+    unsigned dense, walk, swalk, mwalk;   // grid sizes: dense kernels, distance walk, shadow walk, the merged walk (k_wf_walk)
     bool serial;                   // everything on one stream (VSPG_WF_SERIAL)
+    bool merged;                   // both walks of an iteration in ONE kernel (k_wf_walk: the default; VSPG_WF_MERGED=0: two kernels side by side)
     bool bnd;                      // the scene has medium boundaries: the BND instantiations, iterations until the list runs dry
     bool nds;                      // vspsamplingmethod "nds": segment + vertex in one dense kernel
     bool emit;                     // ... over a medium with a temperature grid: the NDS kernel's emissive instantiations
@@ -49,7 +50,7 @@ int wf_run_pass(const WfLaunch &L) {
     // boundary scene hold a few thousand paths, and a full grid of persistent workgroups (each stages the majorant grid into its LDS
     // before it finds the job list empty) costs 50-60 us per walk launch whatever the list holds.  One lane per job at most: the
     // tail is bound by the length of a walk, not by throughput.
-    unsigned dense = L.dense, walk = L.walk, swalk = L.swalk;
+    unsigned dense = L.dense, walk = L.walk, swalk = L.swalk, mwalk = L.mwalk;
     auto list_empty = [&](int it, bool *empty) -> int {
         unsigned int na = 0;
         WFCHK(hipMemcpyAsync(&na, &a.iters[it].n_active, sizeof na, hipMemcpyDeviceToHost, s));
@@ -59,6 +60,7 @@ int wf_run_pass(const WfLaunch &L) {
         dense = blocks < L.dense ? (blocks ? blocks : 1u) : L.dense;
         walk = blocks < L.walk ? (blocks ? blocks : 1u) : L.walk;
         swalk = blocks < L.swalk ? (blocks ? blocks : 1u) : L.swalk;
+        mwalk = blocks < L.mwalk ? (blocks ? blocks : 1u) : L.mwalk;
         return 0;
     };
     if (!NO_NDS && L.nds) {  // NDS / NDS+: segment + vertex in one kernel, the NEE's walk regrouped
@@ -75,6 +77,26 @@ int wf_run_pass(const WfLaunch &L) {
       }
     } else if constexpr (!NDS_ONLY) {
         hipLaunchKernelGGL((k_wf_start<Medium, GUIDED, TRAIN>), dim3(L.dense), dim3(kWfBlock), 0, s, a);
+        if (L.merged) {
+            // vertex(it) hands out the shadow jobs of iteration it AND (itself or through k_wf_begin) the distance jobs of it + 1; the
+            // next vertex kernel consumes both: one walk kernel between them, one stream
+            int shadow_out = -1;  // the iteration whose shadow jobs wait for a walk
+            for (int it = 0; it < L.max_iters; ++it) {
+                if (bnd && it > L.base_iters) {
+                    bool empty = false;
+                    if (const int rc = list_empty(it, &empty)) return rc;
+                    if (empty) break;
+                }
+                hipLaunchKernelGGL(k_wf_walk<WalkMedium>, dim3(mwalk), dim3(kWfBlock), 0, s, a, it, shadow_out);
+                hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
+                shadow_out = -1;
+                if (bnd || it < L.maxdepth) {
+                    if constexpr (GUIDED) hipLaunchKernelGGL((k_wf_begin<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it + 1);
+                    shadow_out = it;
+                }
+            }
+            if (shadow_out >= 0) hipLaunchKernelGGL(k_wf_walk<WalkMedium>, dim3(mwalk), dim3(kWfBlock), 0, s, a, -1, shadow_out);
+        } else {
         for (int it = 0; it < L.max_iters; ++it) {
             if (bnd && it > L.base_iters) {
                 bool empty = false;
@@ -97,6 +119,7 @@ int wf_run_pass(const WfLaunch &L) {
             }
         }
         if (bnd && !serial) WFCHK(hipStreamWaitEvent(s, L.ev_shadow, 0));  // (the last shadow walk finds an empty list; the caller's stream still waits for it)
+    }
     }
     WFCHK(hipGetLastError());
     if (bnd) {
