@@ -469,8 +469,9 @@ def main():
                        "in-loop for %d waves before the timed region" % args.train_waves)
         if pipeline:
             note = ("achieved = ALGORITHMIC bytes (SURVEY 8d: 256 B per segment + 76 B per path + 36 B per density query) / the time of one "
-                    "wave's launches of the wavefront pipeline (k_wf_start, then k_wf_dist_walk, k_wf_vertex, k_wf_shadow_walk x (maxdepth + 1) "
-                    "iterations; the path records live in HBM): `kernel` names the pipeline by its walk kernel, `kernel_ms` is the whole wave")
+                    "wave's launches of the wavefront pipeline (k_wf_start, then k_wf_dist_walk, k_wf_vertex, k_wf_shadow_walk -- or k_wf_walk for both "
+                    "walks, k_wf_vertex -- x (maxdepth + 1) iterations; the path records live in HBM): `kernel` names the pipeline by its walk "
+                    "kernel, `kernel_ms` is the whole wave")
         else:
             note = ("achieved = ALGORITHMIC bytes (SURVEY 8d) / kernel time: the path state lives in LDS, so this is a notional rate -- the "
                     "kernel is bound by vector issue and latency (issue_bound), not by HBM")

@@ -274,6 +274,8 @@ void oracle_blackbody(float u, float T, float *out6) {
     spec s = blackbody_sample(T, lambda);
     for (int i = 0; i < 3; ++i) { out6[i] = lambda[i]; out6[3 + i] = s.c[i]; }
 }
+/* test API: Blackbody(lambda [nm], T) itself, for the reference's own known answers (util/spectrum_test.cpp:19-48) */
+float oracle_blackbody_radiance(float lambda_nm, float T) { return blackbody(lambda_nm, T); }
 /* util/sampling.h:222-225 -- float log */
 float oracle_sample_exponential(float u, float a) { return -logf(1 - u) / a; }
 /* util/float.h:164-193 */

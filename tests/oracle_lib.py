@@ -82,6 +82,7 @@ def load():
         "oracle_scene_fog_box": (C.c_int, [p(P.VspgScene), C.c_int, C.c_int]),
         "oracle_interval_op": (None, [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float * 2]),
         "oracle_blackbody": (None, [C.c_float, C.c_float, C.c_float * 6]),
+        "oracle_blackbody_radiance": (C.c_float, [C.c_float, C.c_float]),
         "oracle_sphere_skip": (None, [p(P.VspgSphere), f3, f3, C.c_float, p(C.c_int), f3, f3, p(C.c_int)]),
         "oracle_sphere_intersect": (None, [p(P.VspgSphere), f3, f3, C.c_float, p(C.c_int), p(C.c_float), f3, f3, f3, f3]),
     }

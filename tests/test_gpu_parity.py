@@ -652,7 +652,7 @@ def test_full_size_guided_cloud_wave_properties(gpu_pkg, shape):
     prm = P.default_params()
     prm.guide_num_training_waves = 4
     t = P.Renderer(scene, prm, W, H)
-    assert t.kernel_name() == "k_wf_dist_walk<NanoDenseMedium,guided,train>"
+    assert t.kernel_name() == "k_wf_walk<NanoDenseMedium,guided,train>"   # (guided pipelines: both walks in one kernel)
     for w in range(4):
         t.render_wave(w, w + 1)
         t.post_process_wave()
@@ -690,7 +690,7 @@ def test_full_size_guided_cloud_wave_properties(gpu_pkg, shape):
             r.close()
         finally:
             os.environ.pop("VSPG_KERNEL", None)
-    assert sorted(films) == ["k_render_wave<NanoDenseMedium,guided>", "k_wf_dist_walk<NanoDenseMedium,guided>"], sorted(films)
+    assert sorted(films) == ["k_render_wave<NanoDenseMedium,guided>", "k_wf_walk<NanoDenseMedium,guided>"], sorted(films)
     (a, ca), (b, cb) = films.values()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca == cb
     c = oracle_lib.OracleRenderer(scene, prm, W, H)
@@ -1956,7 +1956,7 @@ def test_training_samples_bit_identical_to_oracle(gpu_pkg, medium):
     c = oracle_lib.OracleRenderer(scene, prm, W, H, seed=3)
     # grid media record on the wavefront pipeline, homogeneous ones on the workgroup kernel (round 3): either way the recorder's
     # state travels in the path record
-    assert g.kernel_name() == ("k_wf_dist_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>")
+    assert g.kernel_name() == ("k_wf_walk<GridMedium,guided,train>" if medium == "grid" else "k_render_wave_wg2<HomogeneousMediumT<2,true>,guided,train>")
     # (the sample buffer holds one wave's worth -- pixels x (maxdepth + 1) -- between two updates: the capped case fills it with one)
     n_waves = 1 if medium == "homogeneous-capped" else 2
     g.render_wave(0, n_waves)
@@ -2092,7 +2092,7 @@ def test_merged_walk_kernel_equals_the_two_walk_kernels(gpu_pkg, shape):
             r = P.Renderer(scene, prm, W, H, seed=6)
             if field is not None:
                 r.set_guiding_field(field, field)
-            assert r.kernel_name().startswith("k_wf_dist_walk")
+            assert r.kernel_name().startswith("k_wf_walk" if merged == "1" else "k_wf_dist_walk")
             for w in range(3):
                 r.render_wave(w, w + 1); r.post_process_wave()
             results.append((r.film(), r.counters()))

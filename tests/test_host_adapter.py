@@ -492,7 +492,7 @@ def test_scene_file_with_medium_boundaries(host_build, gpu_pkg, tmp_path):
     s.infinite_lights[1].w_light[:] = [float(np.float32(x / lf)) for x in wf]
     prm = P.app_f_params()
     r = P.Renderer(s, prm, W, H)
-    assert r.kernel_name().startswith("k_wf_dist_walk")
+    assert r.kernel_name().startswith(("k_wf_dist_walk", "k_wf_walk"))
     for w in range(4):
         r.render_wave(w, w + 1)
         r.post_process_wave()

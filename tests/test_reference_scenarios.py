@@ -10,6 +10,7 @@ oracle_ray_batch (Integrator::Intersect, Interaction::SpawnRay / SpawnRayTo, Int
   FullSphere, Reintersect     shapes_test.cpp:339-355 over TestReintersectConvex :251-316
   Triangle, BadCases          shapes_test.cpp:435-449
   {BVH,Power,Uniform}LightSampling, PdfMethod   lightsamplers_test.cpp:276-350 (the lights here: emissive rectangles, a sky, a sun)
+  Spectrum, Blackbody         util/spectrum_test.cpp:19-48 (Planck's law against spectralcalc.com's values, Wien's displacement law)
 
 Scenario generators mirror the reference's float arithmetic where it decides what is tested (vertices, rays); a random transform
 is "a random transform of that family" (Scale * Translate * Rotate, shapes_test.cpp:318-335), not pbrt's bits."""
@@ -382,3 +383,68 @@ def _pdf_method(P, sampler):
 def test_light_sampling_pdf_method(sampler):
     """sampledLight->p == distrib.PMF(intr, sampledLight->light) for 100 points p in [-1, 2)^3 (lightsamplers_test.cpp:276-350)."""
     _pdf_method(load_package(), sampler)   # (device == oracle for the samplers: test_gpu_parity.py::test_light_samplers_vs_oracle)
+
+
+# ---- Spectrum, Blackbody (util/spectrum_test.cpp:19-48) ---------------------------------------------------------------------------
+# The oracle's Blackbody() / BlackbodySpectrum are a restatement of util/spectrum.h:83-94, :568-588 whose goldens were transcribed on
+# the reference's types (DESIGN 6); this is the reference's OWN known-answer test for the function: Planck's law at four
+# (lambda, T) pairs against an independent calculator, and Wien's displacement law.
+BLACKBODY_KNOWN = [(483, 6000, 3.1849e13), (600, 6000, 2.86772e13), (500, 3700, 1.59845e12), (600, 4500, 7.46497e12)]   # :27-32 {lambda, T, expected radiance}
+BLACKBODY_WIEN_T = [2700, 3000, 4500, 5600, 6000]                                                                          # :42
+
+
+def test_spectrum_blackbody():
+    lib = oracle_lib.load()
+    B = lambda lam, T: float(lib.oracle_blackbody_radiance(C.c_float(lam), C.c_float(T)))
+    for lam, T, expected in BLACKBODY_KNOWN:
+        assert abs(B(lam, T) - expected) / expected < .001, (lam, T, B(lam, T), expected)   # :36 EXPECT_LT(err(Blackbody(lambda, T), LeExpected), .001)
+    for T in BLACKBODY_WIEN_T:
+        lmax = f32(f32(2.8977721e-3) / f32(T)) * f32(1e9)                                   # :43 (Float arithmetic)
+        lo, hi = f32(.99 * float(lmax)), f32(1.01 * float(lmax))                            # :44 Float(.99 * lambdaMax) -- the product in double
+        assert B(lo, T) < B(lmax, T) > B(hi, T), T                                          # :45-46
+
+
+def _u_for_wavelength(lam):
+    """SampleVisibleWavelengths inverted (util/sampling.h:169-171: lambda = 538 - 138.888889 atanh(0.85691062 - 1.82750197 u))."""
+    return (0.85691062 - math.tanh((538.0 - lam) / 138.888889)) / 1.82750197
+
+
+def _planck64(lam_nm, T):
+    c, h, kb = 299792458.0, 6.62606957e-34, 1.3806488e-23
+    l = lam_nm * 1e-9
+    return 2 * h * c * c / (l ** 5 * (math.exp(h * c / (l * kb * T)) - 1))
+
+
+@pytest.mark.gpu
+def test_spectrum_blackbody_on_device(gpu_pkg):
+    """The device has no raw Blackbody() entry: vspg_blackbody_batch gives SampleVisible(u)'s wavelengths and BlackbodySpectrum(T).Sample
+    at them -- Blackbody(lambda, T) / Blackbody(lambdaMax, T).  u is chosen so that the first wavelength IS the scenario's (to 1e-3 nm;
+    the tolerance of the known answers is 1e-3 relative, d ln B / d ln lambda is O(1)), the normalisation is undone with Planck's law
+    in double.  Wien's law: the three wavelengths around the peak as three entries; only the peaks the visible sampler reaches
+    (360-830 nm: T >= 4500 K)."""
+    P = gpu_pkg
+    g = P.Renderer(P.fog_box_scene(16, 16), P.app_f_params(), 16, 16)
+    u = np.float32([_u_for_wavelength(l) for l, _, _ in BLACKBODY_KNOWN])
+    T = np.float32([t for _, t, _ in BLACKBODY_KNOWN])
+    out = g.blackbody_batch(u, T)
+    for (lam, t, expected), row in zip(BLACKBODY_KNOWN, out):
+        assert abs(float(row[0]) - lam) < 2e-3, (lam, row[0])
+        lmax = 2.8977721e-3 / t * 1e9
+        val = float(row[3]) * _planck64(lmax, t)
+        assert abs(val - expected) / expected < .0015, (lam, t, val, expected)   # .001 of the reference's test + the FastExp normalisation's own error
+    for t in BLACKBODY_WIEN_T:
+        lmax = 2.8977721e-3 / t * 1e9
+        if not 365 < lmax < 820:
+            continue
+        lams = [.99 * lmax, lmax, 1.01 * lmax]
+        row = g.blackbody_batch(np.float32([_u_for_wavelength(l) for l in lams]), np.float32([t] * 3))
+        assert all(abs(float(row[i, 0]) - lams[i]) < 2e-3 for i in range(3))
+        assert row[0, 3] < row[1, 3] > row[2, 3], (t, row[:, 3])
+        assert abs(float(row[1, 3]) - 1) < 1e-5   # normalised by the value at Wien's peak (spectrum.h:577-580)
+    # and bit for bit the oracle's, at these inputs
+    lib = oracle_lib.load()
+    o6 = (C.c_float * 6)()
+    for i in range(len(u)):
+        lib.oracle_blackbody(float(u[i]), float(T[i]), o6)
+        assert np.array_equal(np.float32(list(o6)).view(np.uint32), out[i].view(np.uint32))
+    g.close()

@@ -1643,7 +1643,7 @@ struct VspgRenderer {
     VspgIntegratorParams prm;
     VspgRenderConfig cfg;
     int arith = VSPG_ARITH_EXACT;   // vspg_renderer_set_arithmetic (vspg_arith.h): which instantiations the path kernels are launched from
-    std::string kernel_name_buf;
+    std::string kernel_name_buf, kernel_name_buf2;
     DScene hscene;
     DScene *dscene = nullptr;
     float4 *film = nullptr;
@@ -2528,6 +2528,11 @@ static int validate(const VspgScene *scene, const VspgIntegratorParams *p, const
 // One pass of the wavefront pipeline: sample index `sample` of every pixel.  The pipeline's kernels are instantiated in their own
 // translation units (vspg_wf_grid.hip / vspg_wf_nvdb.hip: wf_dispatch_*, vspg_wf_launch.h), which `make -j` builds beside this one;
 // here the pass is prepared -- buffers, grids, streams -- and handed over as a plain WfLaunch.
+static bool wf_merged_walks(const VspgRenderer *r, bool guided) {
+    bool merged = r->hscene.has_boundaries != 0 || guided;
+    if (const char *e = getenv("VSPG_WF_MERGED")) { if (e[0] == '0') merged = false; else if (e[0] == '1') merged = true; }
+    return merged;
+}
 static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb, bool guided, bool train, bool grey) {
     const int tilesX = (r->cfg.xres + 7) / 8, tilesY = (r->cfg.yres + 7) / 8;
     const size_t items = (size_t)tilesX * tilesY * 64;
@@ -2611,8 +2616,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
     // both walks of an iteration as ONE kernel where the job lists are short or a third kernel sits in the chain (boundary scenes,
     // guided pipelines); side by side on two streams for dense unguided clouds (k_wf_walk, vspg_wavefront.h: measured both ways).
     // VSPG_WF_MERGED=0|1 overrides (read per pass: tests and A/Bs flip it).
-    L.merged = bnd || guided;
-    if (const char *e = getenv("VSPG_WF_MERGED")) { if (e[0] == '0') L.merged = false; else if (e[0] == '1') L.merged = true; }
+    L.merged = wf_merged_walks(r, guided);
     L.s = s;
     L.s2 = L.serial ? s : r->wf_stream2;
     L.ev_vertex = r->wf_ev_vertex;
@@ -3229,10 +3233,14 @@ static const char *kernel_name_exact(VspgRenderer *r) {
                     : (r->medium_grey ? "k_wf_segment_vertex<GridMediumGrey>" : "k_wf_segment_vertex<GridMedium>");
     }
     if (uses_wf_pipeline(r)) {
-        if (guided && r->training) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided,train>" : "k_wf_dist_walk<GridMedium,guided,train>";
-        if (guided) return nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided>" : "k_wf_dist_walk<GridMedium,guided>";
-        return nvdb ? (r->medium_grey ? "k_wf_dist_walk<NanoDenseMediumGrey>" : "k_wf_dist_walk<NanoDenseMedium>")
-                    : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
+        // the pipeline is named by its walk kernel: k_wf_dist_walk (beside k_wf_shadow_walk), or k_wf_walk where one kernel runs both
+        const char *n = guided && r->training ? (nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided,train>" : "k_wf_dist_walk<GridMedium,guided,train>")
+                        : guided ? (nvdb ? "k_wf_dist_walk<NanoDenseMedium,guided>" : "k_wf_dist_walk<GridMedium,guided>")
+                        : nvdb ? (r->medium_grey ? "k_wf_dist_walk<NanoDenseMediumGrey>" : "k_wf_dist_walk<NanoDenseMedium>")
+                               : (r->medium_grey ? "k_wf_dist_walk<GridMediumGrey>" : "k_wf_dist_walk<GridMedium>");
+        if (!wf_merged_walks(r, guided)) return n;
+        r->kernel_name_buf2 = std::string("k_wf_walk") + (n + sizeof("k_wf_dist_walk") - 1);
+        return r->kernel_name_buf2.c_str();
     }
     const bool w3 = uses_wg3(r);
     if (uses_wg_guided(r)) {

@@ -1305,8 +1305,15 @@ VDEV int sel3i(int a0, int a1, int a2, int axis) { return axis == 0 ? a0 : (axis
 // grid (media.h:686-719): index-space trilinear sampling a + w (b - a) with background 0 outside the index
 // bounding box, "densityoffset", 64^3 majorants read from HBM / L2 (1 MB: too large for LDS).  The sparse
 // NanoVDB tree and its sampler are absent from the reference tree: parity unpinned for the fetch itself.
-template <bool NVDB, bool GREY = false, int BND = -1, bool EMIT = false>
+#ifndef VSPG_NVDB_MAJ_GLOBAL
+#define VSPG_NVDB_MAJ_GLOBAL 1   // (0: the 64^3 majorants through the generic pointer as well, for A/B builds)
+#endif
+// MAJLDS: `majorant` points into the block's LDS (the pipeline kernels' copy of a 16^3 grid, wf_block_medium): the iterator reads it
+// with LDS instructions.  Through the generic pointer the member is, the compiler emits a flat load per majorant cell -- issued to
+// the LDS and the vector-memory path alike, waited for on both counters (seen in the ISA of the walk kernels, round 5).
+template <bool NVDB, bool GREY = false, int BND = -1, bool EMIT = false, bool MAJLDS = false>
 struct GridMediumT {
+    static constexpr bool kMajLds = MAJLDS;
     static constexpr int kBnd = BND;  // medium boundaries known at compile time (0 / 1) or decided at run time (-1): has_bnd
     // blackbody emission of a temperature grid compiled in: the per-lane kernels (BND = -1: whatever the scene holds) and the NDS
     // pipeline's emissive instantiations.  Elsewhere the code is left out: in the NDS kernel it costs 16-176 B of scratch per lane
@@ -1368,7 +1375,10 @@ struct GridMediumT {
                 return false;
             }
 #endif
-            float md = maj[vx + kRes * (vy + kRes * vz)];
+            float md;
+            if constexpr (MAJLDS) md = ((const float __attribute__((address_space(3))) *)maj)[vx + kRes * (vy + kRes * vz)];
+            else if constexpr (kRes != kMajRes && VSPG_NVDB_MAJ_GLOBAL) md = *((const float VSPG_GLOBAL_AS *)maj + (vx + kRes * (vy + kRes * vz)));  // 64^3: never staged in LDS
+            else md = maj[vx + kRes * (vy + kRes * vz)];
             s->tMin = tMin;
             s->tMax = tVoxelExit;
             s->sigma_maj = sigma_t * md;
@@ -1606,9 +1616,9 @@ using GridMedium = GridMediumT<false>;
 using GridMediumGrey = GridMediumT<false, true>;
 using NanoDenseMedium = GridMediumT<true>;
 using NanoDenseMediumGrey = GridMediumT<true, true>;
-template <bool NVDB, bool GREY, int BND = -1, bool EMIT = false>
-VDEV GridMediumT<NVDB, GREY, BND, EMIT> make_grid(const DScene &S, const float *majorant) {
-    return GridMediumT<NVDB, GREY, BND, EMIT>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
+template <bool NVDB, bool GREY, int BND = -1, bool EMIT = false, bool MAJLDS = false>
+VDEV GridMediumT<NVDB, GREY, BND, EMIT, MAJLDS> make_grid(const DScene &S, const float *majorant) {
+    return GridMediumT<NVDB, GREY, BND, EMIT, MAJLDS>{GREY ? sp(S.sigma_a[0]) : lds(S.sigma_a), GREY ? sp(S.sigma_s[0]) : lds(S.sigma_s), S.g, S.nx, S.ny, S.nz, ld3(S.bounds_min), ld3(S.bounds_max), S.brick_index, S.octets, S.bnx, S.bny,
                              majorant, S.index_min[0], S.index_min[1], S.index_min[2], ld3(S.inv_voxel), ld3(S.grid_origin),
                              S.density_offset, S.le_scale, S.le_nx, S.le_ny, S.le_nz, lds(S.Le), S.has_xform ? S.minv : nullptr,
                              S.temperature, S.temperature_offset, S.temperature_scale, S.nvdb_le_scale};
@@ -1617,9 +1627,9 @@ template <class M> struct MediumMaker;
 template <int GREY, bool NZ, bool SIMPLE> struct MediumMaker<HomogeneousMediumT<GREY, NZ, SIMPLE>> {
     static VDEV HomogeneousMediumT<GREY, NZ, SIMPLE> make(const DScene &, const float *) { return HomogeneousMediumT<GREY, NZ, SIMPLE>{}; }
 };
-template <bool NVDB, bool GREY, int BND, bool EMIT> struct MediumMaker<GridMediumT<NVDB, GREY, BND, EMIT>> {
-    static VDEV GridMediumT<NVDB, GREY, BND, EMIT> make(const DScene &S, const float *majorant) {
-        return make_grid<NVDB, GREY, BND, EMIT>(S, majorant ? majorant : S.majorant);
+template <bool NVDB, bool GREY, int BND, bool EMIT, bool MAJLDS> struct MediumMaker<GridMediumT<NVDB, GREY, BND, EMIT, MAJLDS>> {
+    static VDEV GridMediumT<NVDB, GREY, BND, EMIT, MAJLDS> make(const DScene &S, const float *majorant) {
+        return make_grid<NVDB, GREY, BND, EMIT, MAJLDS>(S, majorant ? majorant : S.majorant);
     }
 };
 

@@ -680,6 +680,7 @@ VDEV void wf_flush_counters(const WfCountersT<REC> &pc, unsigned long long *g) {
 template <class Medium>
 VDEV Medium wf_block_medium(const DScene &S) {
     const float *maj_ptr = nullptr;
+    static_assert(!Medium::kMajLds || Medium::kRes == kMajRes, "GridMediumT's MAJLDS: only the 16^3 majorant grid has an LDS copy");
     if constexpr (Medium::kRes == kMajRes) {
         __shared__ float s_maj[kMajRes * kMajRes * kMajRes];
         const float4 *src = reinterpret_cast<const float4 *>(S.majorant);

@@ -132,12 +132,18 @@ int wf_run_pass(const WfLaunch &L) {
 
 // one medium layout's instantiations: {grey, chromatic} x {unguided, guided, guided + training} x {no boundaries, boundaries},
 // + the NDS kernel's for media with a temperature grid
+// the pipeline's kernels read a 16^3 majorant grid from their block's LDS copy with LDS instructions (GridMediumT's MAJLDS;
+// -DVSPG_WF_MAJ_LDS=0: through the generic pointer, as rounds 2-4 did -- for A/B builds)
+#ifndef VSPG_WF_MAJ_LDS
+#define VSPG_WF_MAJ_LDS 1
+#endif
+template <bool NVDB> constexpr bool kWfMajLds = !NVDB && VSPG_WF_MAJ_LDS != 0;
 template <bool NVDB>
 int wf_dispatch(const WfLaunch &L, bool guided, bool train, bool grey) {
 #define VSPG_WF_CASE(GREY, BNDV)                                                                                        \
     do {                                                                                                                \
-        using M = GridMediumT<NVDB, GREY, BNDV>;                                                                        \
-        using WM = GridMediumT<NVDB, GREY>;                                                                             \
+        using M = GridMediumT<NVDB, GREY, BNDV, false, kWfMajLds<NVDB>>;                                                          \
+        using WM = GridMediumT<NVDB, GREY, -1, false, kWfMajLds<NVDB>>;                                                           \
         if (guided && train) return wf_run_pass<M, true, true, WM>(L);                                                  \
         if (guided) return wf_run_pass<M, true, false, WM>(L);                                                          \
         return wf_run_pass<M, false, false, WM>(L);                                                                     \
@@ -145,8 +151,8 @@ int wf_dispatch(const WfLaunch &L, bool guided, bool train, bool grey) {
     if (L.emit && L.nds) {  // (a medium with a temperature grid is never run on the grey layout: its emission is not grey)
 #define VSPG_WF_EMIT_CASE(BNDV)                                                                                        \
     do {                                                                                                                \
-        using M = GridMediumT<NVDB, false, BNDV, true>;                                                                 \
-        using WM = GridMediumT<NVDB, false>;                                                                            \
+        using M = GridMediumT<NVDB, false, BNDV, true, kWfMajLds<NVDB>>;                                                          \
+        using WM = GridMediumT<NVDB, false, -1, false, kWfMajLds<NVDB>>;                                                          \
         if (guided && train) return wf_run_pass<M, true, true, WM, true>(L);                                            \
         if (guided) return wf_run_pass<M, true, false, WM, true>(L);                                                    \
         return wf_run_pass<M, false, false, WM, true>(L);                                                               \
@@ -168,7 +174,7 @@ int wf_dispatch(const WfLaunch &L, bool guided, bool train, bool grey) {
 template <bool NVDB>
 int wf_dispatch_unguided(const WfLaunch &L, bool grey) {
     if (L.nds || L.emit) return WF_E_NOT_DRAINED - 1;  // (the caller routes those to the exact instantiations)
-#define VSPG_WF_UCASE(GREY, BNDV) return wf_run_pass<GridMediumT<NVDB, GREY, BNDV>, false, false, GridMediumT<NVDB, GREY>, false, true>(L)
+#define VSPG_WF_UCASE(GREY, BNDV) return wf_run_pass<GridMediumT<NVDB, GREY, BNDV, false, kWfMajLds<NVDB>>, false, false, GridMediumT<NVDB, GREY, -1, false, kWfMajLds<NVDB>>, false, true>(L)
     if (L.bnd) {
         if (grey) VSPG_WF_UCASE(true, 1);
         VSPG_WF_UCASE(false, 1);
