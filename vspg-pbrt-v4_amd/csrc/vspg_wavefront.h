@@ -280,6 +280,9 @@ constexpr int kWfChainMax = 4;  // no-walk segments a lane runs back to back in 
 #ifndef VSPG_WF_DENSE_CLAIM
 #define VSPG_WF_DENSE_CLAIM 1
 #endif
+#ifndef VSPG_WF_REGROUP
+#define VSPG_WF_REGROUP 1   // boundary scenes: links of a no-walk chain regrouped over a workgroup's lanes (k_wf_vertex); 0: run by the lane that began them
+#endif
 struct WfStage {
     unsigned int *buf;   // LDS, kWfStageRounds * block entries
     unsigned int *cnt;   // LDS
@@ -1226,27 +1229,82 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
     __syncthreads();
     const WfStage stA{s_stage[0], &s_cnt[0]}, stB{s_stage[1], &s_cnt[1]}, stC{s_stage[2], &s_cnt[2]};
     int round = 0;
+    // Medium boundaries: a segment that needs no distance walk (a ray in vacuum, a ray that escapes, an all-zero majorant run)
+    // has nothing to wait for -- its end, the vertex behind it and the next begin run in this same launch, unless the vertex's
+    // NEE sent a shadow walk out (its result must reach L first).  A path through the reference's cloud scenes spends an
+    // iteration less per boundary crossing: every vacuum segment (camera to the bounding sphere, sphere to ground or sky) used
+    // to cost a launch of all three kernels and a trip of the record through HBM.  Round 4 ran such a chain in the lane that
+    // began it, while the rest of its wavefront waited (lane utilisation 0.36 on the cloud scene); round 5 REGROUPS: the slot
+    // goes onto a ring in the workgroup's LDS (the path is in its record anyway -- every link of a chain starts from there) and
+    // the workgroup takes its next 256 paths from the ring whenever that holds as many, from the list otherwise, and drains the
+    // ring at the end.  Per path the same links in the same order; which lane runs them is nobody's business.
+    constexpr bool kChain = !GUIDED && Medium::kBnd == 1;
+    constexpr bool kRegroup = kChain && VSPG_WF_DENSE_CLAIM != 0 && VSPG_WF_REGROUP != 0;
+    constexpr unsigned kRing = 8 * kWfBlock;  // (occupancy stays below four blocks' worth: a list round is taken only under one block's, and sees pushes a round late)
+    enum { SRC_LIST = 0, SRC_RING = 1, SRC_RETRY = 2, SRC_DONE = 3 };
+    __shared__ unsigned int s_ring[kRegroup ? kRing : 1], s_tail;
+    if (threadIdx.x == 0) s_tail = 0;  // (ordered before the first push by the first round's barrier)
+    unsigned ring_head = 0;            // thread 0's
+    int prev_src = SRC_LIST;
+    bool exhausted = false;
 #if VSPG_WF_DENSE_CLAIM
-    __shared__ unsigned int s_chunk[2];
+    __shared__ unsigned int s_chunk[2][3];  // per round {source, base, count}
     for (;; ++round) {
-        if (threadIdx.x == 0) s_chunk[round & 1] = atomicAdd(&I->dense_head, (unsigned)kWfBlock);
+        if (threadIdx.x == 0) {
+            unsigned src = SRC_LIST, base = 0, cnt = kWfBlock;
+            if constexpr (kRegroup) {
+                const unsigned avail = *(volatile unsigned int *)&s_tail - ring_head;
+                if (avail >= (unsigned)kWfBlock || (exhausted && avail > 0u)) {
+                    src = SRC_RING;
+                    base = ring_head;
+                    cnt = avail < (unsigned)kWfBlock ? avail : (unsigned)kWfBlock;
+                    ring_head += cnt;
+                } else if (!exhausted) {
+                    base = atomicAdd(&I->dense_head, (unsigned)kWfBlock);
+                    if (base >= n) {
+                        exhausted = true;
+                        src = SRC_RETRY;
+                    }
+                } else {
+                    // nothing on the ring as seen from here -- but a slower wavefront may still be pushing (last round's links):
+                    // one empty round, whose barrier orders those pushes before the next look; empty twice in a row is empty
+                    src = prev_src == SRC_RETRY ? SRC_DONE : SRC_RETRY;
+                }
+                prev_src = (int)src;
+            } else {
+                base = atomicAdd(&I->dense_head, (unsigned)kWfBlock);
+                if (base >= n) src = SRC_DONE;
+            }
+            s_chunk[round & 1][0] = src; s_chunk[round & 1][1] = base; s_chunk[round & 1][2] = cnt;
+        }
         __syncthreads();  // (two slots: the next claim is written while a slow wavefront may still be reading this one)
-        const unsigned base = s_chunk[round & 1];
-        if (base >= n) break;
+        const unsigned src = s_chunk[round & 1][0], base = s_chunk[round & 1][1], cnt = s_chunk[round & 1][2];
+        if (src == SRC_DONE) break;
+        bool have = false;
+        unsigned slot = 0;
+        int chain0 = 0;
+        if (src == SRC_LIST) {
+            have = base + threadIdx.x < n;
+            if (have) slot = list_in[base + threadIdx.x];
+        } else if (src == SRC_RING) {
+            have = threadIdx.x < cnt;
+            if (have) {
+                const unsigned e = s_ring[(base + threadIdx.x) % kRing];
+                slot = e & 0x0fffffffu;
+                chain0 = (int)(e >> 28);
+            }
+        }
 #else
     for (unsigned base = blockIdx.x * kWfBlock; base < n; base += gridDim.x * kWfBlock, ++round) {
-#endif
-        const unsigned idx = base + threadIdx.x;
-        bool next = false, walk = false, shadow = false;  // next: the slot goes onto the next iteration's list
+        const bool have = base + threadIdx.x < n;
         unsigned slot = 0;
-        // Medium boundaries: a segment that needs no distance walk (a ray in vacuum, a ray that escapes, an all-zero majorant run)
-        // has nothing to wait for -- its end, the vertex behind it and the next begin run right here, in the lane that began it,
-        // unless the vertex's NEE sent a shadow walk out (its result must reach L first).  A path through the reference's cloud
-        // scenes spends an iteration less per boundary crossing: every vacuum segment (camera to the bounding sphere, sphere to
-        // ground or sky) used to cost a launch of all three kernels and a trip of the record through HBM.
-        constexpr bool kChain = !GUIDED && Medium::kBnd == 1;
-        if (idx < n) slot = list_in[idx];
-        for (int chain = 0; idx < n; ++chain) {
+        const int chain0 = 0;
+        if (have) slot = list_in[base + threadIdx.x];
+#endif
+        bool next = false, walk = false, shadow = false;  // next: the slot goes onto the next iteration's list
+        bool requeue = false;
+        int chain = chain0;
+        for (; have; ++chain) {
             next = false;
             walk = false;
             bool again = false;
@@ -1374,6 +1432,10 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                     skipped = pre == LI_SKIP;
                 }
             }
+            // (the next segment's begin -- scene intersection, majorant pre-pass -- has ONE call site behind both ways into it: a
+            // wavefront that holds crossings and vertices runs it once, not once per kind)
+            bool begin = false;
+            uint32_t extra = 0u;
             if (!alive) {
                 wf_finish_path(a, slot, st, isg);
                 pc.path();
@@ -1383,13 +1445,11 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                 if constexpr (GUIDED) {  // (gs.vsp_next: the previous vertex's estimate stays the next segment's -- no vertex in between)
                     wf_store_path<G>(P, slot, st, sampler, ch, isg, FL_LIVE);
                 } else {
-                    wf_segment_begin<Medium, GUIDED, !TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, 0u, &walk);
-                    again = !walk;
+                    begin = true;
                 }
                 next = true;
             } else {
                 // ---- li_segment_b: the vertex (wf_vertex), then the next segment's begin ---------------------------------------
-                uint32_t extra = 0u;
                 const int fate = wf_vertex<Medium, GUIDED, TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, vx, &extra, &shadow);
                 if (fate == WFV_DEAD_LISTED) {
                     next = true;
@@ -1399,13 +1459,34 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
                         P.f(WF_GSVSP, slot) = st.gs.vsp_next;
                         wf_store_path<G>(P, slot, st, sampler, ch, isg, extra | FL_LIVE);
                     } else {
-                        wf_segment_begin<Medium, GUIDED, !TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, extra, &walk);
-                        again = !walk && !shadow;
+                        begin = true;
                     }
                     next = true;
                 }
             }
+            if constexpr (!GUIDED) {
+                if (begin) {
+                    wf_segment_begin<Medium, GUIDED, !TRAIN>(a, S, medium, slot, st, sampler, ch, isg, pc, extra, &walk);
+                    again = !walk && !shadow;  // (a crossing has no NEE: `shadow` is the vertex's)
+                }
+            }
             if (!kChain || !again || chain >= kWfChainMax) break;
+            if constexpr (kRegroup) {  // the next link runs in whichever lane the ring hands it to
+                requeue = true;
+                next = false;
+                break;
+            }
+        }
+        if constexpr (kRegroup) {
+            const unsigned long long m = __ballot(requeue);
+            if (m != 0ull) {
+                const int lane = threadIdx.x & 63;
+                const int leader = __ffsll((long long)m) - 1;
+                unsigned int rb = 0;
+                if (lane == leader) rb = atomicAdd(&s_tail, (unsigned int)__popcll(m));
+                rb = __shfl(rb, leader);
+                if (requeue) s_ring[(rb + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))) % kRing] = slot | ((unsigned)(chain + 1) << 28);
+            }
         }
         stA.push(next, slot);
         stB.push(walk, slot);
