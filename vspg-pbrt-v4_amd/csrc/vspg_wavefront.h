@@ -273,7 +273,10 @@ VDEV void wf_pixel_of(unsigned slot, unsigned tilesX, int *px, int *py) {
 // kWfStageRounds rounds in LDS (wave ballot + prefix count + one LDS atomic per wavefront) and flushes them with ONE
 // global atomic.  List order is irrelevant: every path's result depends on its own state only.
 constexpr int kWfStageRounds = 4;
-constexpr int kWfChainMax = 4;  // no-walk segments a lane runs back to back in one k_wf_vertex pass (boundary scenes) before the path waits for the next iteration
+#ifndef VSPG_WF_CHAIN_MAX
+#define VSPG_WF_CHAIN_MAX 4
+#endif
+constexpr int kWfChainMax = VSPG_WF_CHAIN_MAX;  // no-walk segments a lane runs back to back in one k_wf_vertex pass (boundary scenes) before the path waits for the next iteration
 // The dense kernels' list walk.  Static: workgroup b takes chunks b, b + G, ... (grid stride).  Claimed (VSPG_WF_DENSE_CLAIM, the
 // vertex kernel): chunks of one workgroup's width from a cursor, one returning atomic and one barrier per chunk -- a chunk's cost
 // follows what its paths do (ended, NEE or not, hit or escape), so static shares end on their slowest chunks.
@@ -1240,7 +1243,11 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
     // ring at the end.  Per path the same links in the same order; which lane runs them is nobody's business.
     constexpr bool kChain = !GUIDED && Medium::kBnd == 1;
     constexpr bool kRegroup = kChain && VSPG_WF_DENSE_CLAIM != 0 && VSPG_WF_REGROUP != 0;
-    constexpr unsigned kRing = 8 * kWfBlock;  // (occupancy stays below four blocks' worth: a list round is taken only under one block's, and sees pushes a round late)
+    // Ring size: a list round is taken only while fewer than one block's worth (B = 256) of links are SEEN waiting, and what is seen
+    // lags the truth by at most the previous round's pushes (<= B): the true occupancy at a decision is < 2 B, after a list round
+    // < 3 B, and a ring round never raises it; the entries being read plus a round's pushes stay under 4 B.  Sized at twice that
+    // (4 B measured the same: 4.47 against 4.46 ms, although it leaves room for a fourth resident workgroup per CU).
+    constexpr unsigned kRing = 8 * kWfBlock;
     enum { SRC_LIST = 0, SRC_RING = 1, SRC_RETRY = 2, SRC_DONE = 3 };
     __shared__ unsigned int s_ring[kRegroup ? kRing : 1], s_tail;
     if (threadIdx.x == 0) s_tail = 0;  // (ordered before the first push by the first round's barrier)
