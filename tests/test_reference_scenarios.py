@@ -11,6 +11,7 @@ oracle_ray_batch (Integrator::Intersect, Interaction::SpawnRay / SpawnRayTo, Int
   Triangle, BadCases          shapes_test.cpp:435-449
   {BVH,Power,Uniform}LightSampling, PdfMethod   lightsamplers_test.cpp:276-350 (the lights here: emissive rectangles, a sky, a sun)
   Spectrum, Blackbody         util/spectrum_test.cpp:19-48 (Planck's law against spectralcalc.com's values, Wien's displacement law)
+  SampleDiscrete, Basics      util/sampling_test.cpp:26-42 (the two-weight cases: the form the path uses, media_sampleTMaj / :635)
 
 Scenario generators mirror the reference's float arithmetic where it decides what is tested (vertices, rays); a random transform
 is "a random transform of that family" (Scale * Translate * Rotate, shapes_test.cpp:318-335), not pbrt's bits."""
@@ -448,3 +449,12 @@ def test_spectrum_blackbody_on_device(gpu_pkg):
         lib.oracle_blackbody(float(u[i]), float(T[i]), o6)
         assert np.array_equal(np.float32(list(o6)).view(np.uint32), out[i].view(np.uint32))
     g.close()
+
+
+# ---- SampleDiscrete, Basics (util/sampling_test.cpp:26-42): the two-weight cases -- the delta-tracking callback's event choice ------
+def test_sample_discrete_basics():
+    lib = oracle_lib.load()
+    sd = lambda w0, w1, u: int(lib.oracle_sample_discrete2(C.c_float(w0), C.c_float(w1), C.c_float(u)))
+    assert sd(0.5, 0.5, 0.) == 0        # :32
+    assert sd(0.5, 0.5, 0.499) == 0     # :35
+    assert sd(0.5, 0.5, 0.5) == 1       # :39
