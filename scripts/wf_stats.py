@@ -5,8 +5,11 @@ from __graft_entry__ import load_package
 P = load_package(); lib = P.load()
 wl = sys.argv[1] if len(sys.argv) > 1 else "cloud"
 W, H = 1920, 1080
-scene = P.cloud_box_scene(W, H, 256) if wl == "cloud" else P.nanovdb_box_scene(W, H, 256)
-r = P.Renderer(scene, P.app_f_params(), W, H, spp=4)
+scene = (P.cloud_box_scene(W, H, 256) if wl == "cloud" else P.cloud_scene(W, H, 256) if wl == "cloud-scene" else P.nanovdb_box_scene(W, H, 256))
+prm = P.app_f_params()
+if wl == "cloud-scene":  # bench.py's options for the boundary scene
+    prm.vspsamplingmethod = P.VSP_RESAMPLING
+r = P.Renderer(scene, prm, W, H, spp=4)
 out = (C.c_ulonglong * 16)()
 r.render_wave(0, 1); lib.vspg_wf_stats_read(out)
 r.render_wave(1, 2); lib.vspg_wf_stats_read(out)

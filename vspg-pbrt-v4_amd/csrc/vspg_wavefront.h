@@ -1757,6 +1757,7 @@ __global__ __launch_bounds__(kWfBlock, kWfMergedWavesPerSimd) void k_wf_walk(WfA
     float weightSum = 0, sel_wi = 0;
     Spec sel_num = sp(0.f), sel_den = sp(0.f);   // (shadow jobs: sel_num carries the residual T_maj)
     V3 sel_p = mk(0, 0, 0);
+    VSPG_WF_STAT_DECL;
     while (true) {
         const unsigned n_idle = (unsigned)__popcll(__ballot(!active));
         if (n_idle == 64u || (n_idle >= (unsigned)a.walk_refill && !(claim.exhausted && claim.next >= claim.end))) {
@@ -1804,12 +1805,16 @@ __global__ __launch_bounds__(kWfBlock, kWfMergedWavesPerSimd) void k_wf_walk(WfA
         float t = 0.f;
         int r = WALK_MOVED;
         const int cap = shadow ? 0x7fffffff : 10000;  // (the 10 000-collision guard belongs to the resampling routine only, media_sampleTMaj.h:216-219)
+        VSPG_WF_STAT(0, 0, 1); VSPG_WF_STAT(0, 1, __popcll(__ballot(active))); VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(active)));
+        if (claim.exhausted && claim.next >= claim.end) { VSPG_WF_STAT(0, 7, 1); VSPG_WF_STAT(0, 6, __popcll(__ballot(active))); }  // draining: no job left to claim
         if (active) r = walk_advance<Medium, true>(w, ch, scale, &t, cap);
         for (int rr = 1; rr < a.walk_rounds; ++rr) {
             const bool again = active && r == WALK_MOVED;
             if (__popcll(__ballot(again)) < 8) break;
+            VSPG_WF_STAT(0, 2, 1); VSPG_WF_STAT(0, 3, __popcll(__ballot(again)));
             if (again) r = walk_advance<Medium, true>(w, ch, scale, &t, cap);
         }
+        VSPG_WF_STAT(0, 4, __ballot(active && r == WALK_COLLISION) != 0ull); VSPG_WF_STAT(0, 5, __popcll(__ballot(active && r == WALK_COLLISION)));
         if (active && r == WALK_COLLISION) {
             w.T_maj = w.T_maj * fast_exp(w.sigma_maj * -(t - w.tMin));
             const V3 p = ro + rdn * t;
@@ -1864,6 +1869,7 @@ __global__ __launch_bounds__(kWfBlock, kWfMergedWavesPerSimd) void k_wf_walk(WfA
             result = true;
         }
     }
+    VSPG_WF_STAT_FLUSH(0);
     wf_flush_counters(pc, a.counters);
 }
 
