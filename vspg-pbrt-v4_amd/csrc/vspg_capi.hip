@@ -2589,6 +2589,7 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
         if (a.walk_rounds < 1) a.walk_rounds = 1;
         if (a.walk_refill < 1) a.walk_refill = 1;
         if (a.walk_refill > 64) a.walk_refill = 64;
+
     }
     // persistent grids: the dense kernels stride over their list, the walk kernels pull jobs
     const unsigned max_blocks = (unsigned)((items + kWfBlock - 1) / kWfBlock);
@@ -2617,6 +2618,10 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
     // guided pipelines); side by side on two streams for dense unguided clouds (k_wf_walk, vspg_wavefront.h: measured both ways).
     // VSPG_WF_MERGED=0|1 overrides (read per pass: tests and A/Bs flip it).
     L.merged = wf_merged_walks(r, guided);
+    // job cursors of the merged walk kernel's stream: boundary scenes' short lists are dealt out to kWfSegs of them (wf_claim_refill;
+    // VSPG_WF_SEGS=1|8 overrides, read per pass)
+    L.segs = bnd ? kWfSegs : 1;
+    if (const char *e = getenv("VSPG_WF_SEGS")) L.segs = atoi(e) > 1 ? kWfSegs : 1;
     L.s = s;
     L.s2 = L.serial ? s : r->wf_stream2;
     L.ev_vertex = r->wf_ev_vertex;

@@ -212,10 +212,16 @@ struct WfIter {
     unsigned int dense_head;     // chunk cursor of this iteration's vertex kernel (VSPG_WF_DENSE_CLAIM)
     unsigned int n_walk;         // distance-walk jobs
     unsigned int n_shadow;       // shadow-walk jobs
-    unsigned int walk_head;      // job cursors of the two walk kernels
+    unsigned int walk_head;      // (round 5: the walk kernels' job cursors are seg_head below)
     unsigned int shadow_head;
     unsigned int pad[2];
+    unsigned int pad2[24];       // (the header fills a 128-byte line of its own)
+    // Job cursors of the walk kernels: up to kWfSegs per list, each on a 128-byte line of its own (wf_claim_refill).
+    // [0] distance walk  [1] shadow walk  [2], [3] k_wf_walk (launched with / without distance jobs)
+    unsigned int seg_head[4][8][32];
 };
+constexpr int kWfSegs = 8;
+static_assert(sizeof(WfIter) == 128 + 4 * 8 * 128, "WfIter: a header line + the cursor lines");
 struct WfArgs {
     const DScene *scene;
     WfPool P;
@@ -940,7 +946,9 @@ struct WfClaim {
     unsigned next, end;
     bool exhausted;
     unsigned seen;   // the list position of this wavefront's latest claim (an estimate of the global cursor)
+    unsigned seg, tried;  // the stretch this wavefront claims from, stretches it has found run out
 };
+VDEV WfClaim wf_claim_init(int segs) { return WfClaim{0u, 0u, false, 0u, blockIdx.x % (unsigned)segs, 0u}; }
 VDEV unsigned wf_claim_size(unsigned n, unsigned seen) {
     if (VSPG_WF_CLAIM_MODE == 0) return (unsigned)kWfClaim;
     const unsigned waves = gridDim.x * (blockDim.x >> 6);
@@ -948,6 +956,41 @@ VDEV unsigned wf_claim_size(unsigned n, unsigned seen) {
     unsigned sz = left / (waves * (unsigned)VSPG_WF_CLAIM_DIV);
     sz = sz < (unsigned)VSPG_WF_CLAIM_MIN ? (unsigned)VSPG_WF_CLAIM_MIN : sz;
     return sz > (unsigned)VSPG_WF_CLAIM_MAX ? (unsigned)VSPG_WF_CLAIM_MAX : sz;
+}
+// the next chunk of list positions for a wavefront.  With ONE cursor per list the cursor is a hot word where lists are short and
+// walks brief: a returning atomic per 73 jobs is 18 k of them per launch on the boundary scene, against ~88 per microsecond that one
+// address serves (round 5: claims twice as large measured 3.5 % faster there, and cost tails elsewhere).  So the list may be dealt
+// out to SEGS cursors (each on a 128-byte line of its own) in stripes of 16 chunks, stripe j to cursor
+// j % segs: every cursor serves the whole length of the list, a chunk never straddles two stripes (the chunk size is fixed per
+// launch), and a cursor's positions grow with it, so one that has passed the end has run out for good: `segs` of them found so = the
+// list is exhausted.  A wavefront starts at its workgroup's cursor and moves round.  The host deals boundary scenes' job streams
+// (k_wf_walk<Medium, kWfSegs>) out to 8 cursors (cloud-scene 4.47 -> 4.26 ms) and leaves the others at one: the all-filling cloud's wave took 8.5 % LONGER with 8 --
+// its walks are long, the cursor is not its problem, and one front sweeping the image keeps the density fetches of the whole chip
+// in one part of the volume.
+template <unsigned SEGS>
+VDEV bool wf_claim_refill(WfClaim &c, unsigned n, unsigned int *heads) {
+    constexpr unsigned segs = SEGS;
+    static_assert(VSPG_WF_CLAIM_MODE != 2, "striped cursors need a chunk size that is fixed per launch");
+    const int lane = threadIdx.x & 63;
+    const unsigned sz = wf_claim_size(n, c.seen), stripe = sz * 16u;
+    auto pos_of = [&](unsigned base) { return ((base / stripe) * segs + c.seg) * stripe + base % stripe; };
+    while (c.tried < segs) {
+        // (a look before the returning atomic: cursors only grow, so one seen past the end is, and a wavefront at the end of the
+        // list finds that out with plain loads instead of a round of atomics)
+        unsigned pos = n;
+        if (lane == 0 && (segs == 1u || pos_of(__hip_atomic_load(&heads[c.seg * 32u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < n)) pos = pos_of(atomicAdd(&heads[c.seg * 32u], sz));
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        if (pos < n) {
+            c.next = pos;
+            c.end = pos + sz < n ? pos + sz : n;
+            c.seen = c.end;
+            return true;
+        }
+        c.seg = (c.seg + 1u) % segs;
+        c.tried++;
+    }
+    c.exhausted = true;
+    return false;
 }
 VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, unsigned int *head, unsigned *slot_out) {
     const int lane = threadIdx.x & 63;
@@ -958,15 +1001,7 @@ VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, 
     unsigned served = 0;
     while (served < cnt) {
         if (c.next >= c.end) {
-            if (c.exhausted) break;
-            const unsigned sz = wf_claim_size(n, c.seen);
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(head, sz);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= n) { c.exhausted = true; break; }
-            c.next = base;
-            c.end = base + sz < n ? base + sz : n;
-            c.seen = c.end;
+            if (c.exhausted || !wf_claim_refill<1u>(c, n, head)) break;
         }
         const unsigned avail = c.end - c.next;
         const unsigned take = cnt - served < avail ? cnt - served : avail;
@@ -981,6 +1016,7 @@ VDEV bool wf_claim(WfClaim &c, bool want, const unsigned int *list, unsigned n, 
 }
 
 // the same over a job STREAM without a list of its own: hands out positions (k_wf_walk maps them to its two lists)
+template <unsigned SEGS>
 VDEV bool wf_claim_index(WfClaim &c, bool want, unsigned n, unsigned int *head, unsigned *index_out) {
     const int lane = threadIdx.x & 63;
     const unsigned long long need = __ballot(want);
@@ -990,15 +1026,7 @@ VDEV bool wf_claim_index(WfClaim &c, bool want, unsigned n, unsigned int *head, 
     unsigned served = 0;
     while (served < cnt) {
         if (c.next >= c.end) {
-            if (c.exhausted) break;
-            const unsigned sz = wf_claim_size(n, c.seen);
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(head, sz);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= n) { c.exhausted = true; break; }
-            c.next = base;
-            c.end = base + sz < n ? base + sz : n;
-            c.seen = c.end;
+            if (c.exhausted || !wf_claim_refill<SEGS>(c, n, head)) break;
         }
         const unsigned avail = c.end - c.next;
         const unsigned take = cnt - served < avail ? cnt - served : avail;
@@ -1022,7 +1050,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
     const unsigned n = I->n_walk;
     WfCounters pc;
     pc.zero();
-    WfClaim claim{0u, 0u, false, 0u};
+    WfClaim claim = wf_claim_init(1);
     bool active = false, result = false;  // result: a finished walk whose result is still in registers
     unsigned slot = 0;
     WalkState<Medium> w;
@@ -1047,7 +1075,7 @@ __global__ __launch_bounds__(kWfBlock, kWfWalkWavesPerSimd) void k_wf_dist_walk(
                 result = false;
             }
             unsigned ns = 0;
-            if (wf_claim(claim, !active, a.list_walk, n, &I->walk_head, &ns)) {
+            if (wf_claim(claim, !active, a.list_walk, n, &I->seg_head[0][0][0], &ns)) {
                 slot = ns;
                 w.iter = wf_load_iter(P, slot, medium, &ch);
                 w.in_seg = false;
@@ -1639,7 +1667,7 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
     const unsigned n = I->n_shadow;
     WfCounters pc;
     pc.zero();
-    WfClaim claim{0u, 0u, false, 0u};
+    WfClaim claim = wf_claim_init(1);
     bool active = false, result = false;
     unsigned slot = 0;
     WalkState<Medium> w;
@@ -1656,7 +1684,7 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
                 result = false;
             }
             unsigned ns = 0;
-            if (wf_claim(claim, !active, a.list_shadow, n, &I->shadow_head, &ns)) {
+            if (wf_claim(claim, !active, a.list_shadow, n, &I->seg_head[1][0][0], &ns)) {
                 slot = ns;
                 w.iter = wf_load_iter(P, slot, medium, &ch, WF_SIT, WF_SITP);
                 w.in_seg = false;
@@ -1731,17 +1759,19 @@ __global__ __launch_bounds__(kWfBlock, kWfShadowWavesPerSimd) void k_wf_shadow_w
 // which is what long, dense job lists want; short lists (boundary scenes: 7-9 iterations over thinning lists) and the guided
 // pipelines (a third kernel, k_wf_begin, in the chain) want fewer launches and tails.  The host picks accordingly (wf_render_pass).
 // it_d / it_s: the iteration whose distance / shadow jobs run, -1: none.
-template <class Medium>
+// SEGS: job cursors the stream is dealt out to (wf_claim_refill; a template parameter: as a kernel argument it cost every walk kernel
+// scalar-register spills in its loop).
+template <class Medium, int SEGS = 1>
 __global__ __launch_bounds__(kWfBlock, kWfMergedWavesPerSimd) void k_wf_walk(WfArgs a, int it_d, int it_s) {
     const DScene &S = *a.scene;
     const Medium medium = wf_block_medium<Medium>(S);
     const WfPool &P = a.P;
     const unsigned n_s = it_s >= 0 ? a.iters[it_s].n_shadow : 0u, n_d = it_d >= 0 ? a.iters[it_d].n_walk : 0u;
     const unsigned n = n_s + n_d;
-    unsigned int *const head = it_d >= 0 ? &a.iters[it_d].pad[0] : &a.iters[it_s].pad[1];  // (the control blocks are zeroed once per pass)
+    unsigned int *const head = it_d >= 0 ? &a.iters[it_d].seg_head[2][0][0] : &a.iters[it_s].seg_head[3][0][0];  // (the control blocks are zeroed once per pass)
     WfCounters pc;
     pc.zero();
-    WfClaim claim{0u, 0u, false, 0u};
+    WfClaim claim = wf_claim_init(SEGS);
     bool active = false, result = false, shadow = false;
     unsigned slot = 0;
     WalkState<Medium> w;
@@ -1771,7 +1801,7 @@ __global__ __launch_bounds__(kWfBlock, kWfMergedWavesPerSimd) void k_wf_walk(WfA
                 result = false;
             }
             unsigned idx = 0;
-            if (wf_claim_index(claim, !active, n, head, &idx)) {
+            if (wf_claim_index<(unsigned)SEGS>(claim, !active, n, head, &idx)) {
                 shadow = idx < n_s;
                 slot = shadow ? a.list_shadow[idx] : a.list_walk[idx - n_s];
                 w.in_seg = false;

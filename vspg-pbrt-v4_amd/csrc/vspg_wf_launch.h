@@ -16,6 +16,7 @@ struct WfLaunch {
     WfArgs a;
     unsigned dense, walk, swalk, mwalk;   // grid sizes: dense kernels, distance walk, shadow walk, the merged walk (k_wf_walk)
     bool serial;                   // everything on one stream (VSPG_WF_SERIAL)
+    int segs;                      // job cursors of k_wf_walk's stream (1 or kWfSegs: wf_claim_refill)
     bool merged;                   // both walks of an iteration in ONE kernel (k_wf_walk: the default; VSPG_WF_MERGED=0: two kernels side by side)
     bool bnd;                      // the scene has medium boundaries: the BND instantiations, iterations until the list runs dry
     bool nds;                      // vspsamplingmethod "nds": segment + vertex in one dense kernel
@@ -87,7 +88,8 @@ int wf_run_pass(const WfLaunch &L) {
                     if (const int rc = list_empty(it, &empty)) return rc;
                     if (empty) break;
                 }
-                hipLaunchKernelGGL(k_wf_walk<WalkMedium>, dim3(mwalk), dim3(kWfBlock), 0, s, a, it, shadow_out);
+                if (L.segs > 1) hipLaunchKernelGGL((k_wf_walk<WalkMedium, kWfSegs>), dim3(mwalk), dim3(kWfBlock), 0, s, a, it, shadow_out);
+                else hipLaunchKernelGGL((k_wf_walk<WalkMedium, 1>), dim3(mwalk), dim3(kWfBlock), 0, s, a, it, shadow_out);
                 hipLaunchKernelGGL((k_wf_vertex<Medium, GUIDED, TRAIN>), dim3(dense), dim3(kWfBlock), 0, s, a, it);
                 shadow_out = -1;
                 if (bnd || it < L.maxdepth) {
@@ -95,7 +97,10 @@ int wf_run_pass(const WfLaunch &L) {
                     shadow_out = it;
                 }
             }
-            if (shadow_out >= 0) hipLaunchKernelGGL(k_wf_walk<WalkMedium>, dim3(mwalk), dim3(kWfBlock), 0, s, a, -1, shadow_out);
+            if (shadow_out >= 0) {
+                if (L.segs > 1) hipLaunchKernelGGL((k_wf_walk<WalkMedium, kWfSegs>), dim3(mwalk), dim3(kWfBlock), 0, s, a, -1, shadow_out);
+                else hipLaunchKernelGGL((k_wf_walk<WalkMedium, 1>), dim3(mwalk), dim3(kWfBlock), 0, s, a, -1, shadow_out);
+            }
         } else {
         for (int it = 0; it < L.max_iters; ++it) {
             if (bnd && it > L.base_iters) {
