@@ -1654,6 +1654,8 @@ struct VspgRenderer {
     float *vsp = nullptr;
     unsigned long long *counters = nullptr;
     unsigned int *work_head = nullptr;   // two counters, used by alternate launches (reset_sibling_head)
+    unsigned int *work_head8_raw = nullptr, *work_head8 = nullptr;  // k_render_wave_wg3's: two sets of kWg3Heads cursors, 2 KB-aligned
+    unsigned int head8_parity = 0;
     unsigned int head_parity = 0;
     VspgKdNode *fnodes[2] = {nullptr, nullptr};        // guiding fields (device copies)
     VspgFieldRegion *fregions[2] = {nullptr, nullptr};
@@ -2964,6 +2966,10 @@ int vspg_renderer_create(const VspgScene *scene, const VspgIntegratorParams *par
     CK(hipMemset(r->counters, 0, kNumCounters * sizeof(unsigned long long)));
     CK(hipMalloc(&r->work_head, 2 * sizeof(unsigned int)));
     CK(hipMemset(r->work_head, 0, 2 * sizeof(unsigned int)));
+    CK(hipMalloc(&r->work_head8_raw, 4 * (size_t)kWg3HeadSetBytes));
+    CK(hipMemset(r->work_head8_raw, 0, 4 * (size_t)kWg3HeadSetBytes));
+    r->work_head8 = reinterpret_cast<unsigned int *>((reinterpret_cast<uintptr_t>(r->work_head8_raw) + 2 * (uintptr_t)kWg3HeadSetBytes - 1) &
+                                                     ~(2 * (uintptr_t)kWg3HeadSetBytes - 1));  // (the sibling set is at address ^ kWg3HeadSetBytes)
     {
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, cfg->device));
@@ -3046,6 +3052,7 @@ int vspg_renderer_destroy(VspgRenderer *r) {
     if (r->vsp) (void)hipFree(r->vsp);
     if (r->counters) (void)hipFree(r->counters);
     if (r->work_head) (void)hipFree(r->work_head);
+    if (r->work_head8_raw) (void)hipFree(r->work_head8_raw);
     for (int f = 0; f < 2; ++f) {
         if (r->fnodes[f]) (void)hipFree(r->fnodes[f]);
         if (r->fregions[f]) (void)hipFree(r->fregions[f]);
@@ -3402,7 +3409,11 @@ int vspg_render_wave(VspgRenderer *r, int wave_start, int wave_end, void *stream
             if (uses_wg3(r)) {
                 {  // the unguided rectangle-scene instantiations (the headline workload): also built in the tolerance modes
                     static_assert(kWgBlockHomog == VSPG_WG_BLOCK && kWgWavesHomog == VSPG_WG_WAVES, "wg3_launch_unguided's launch shape");
-                    const Wg3Launch L3{r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, work_head, ws_prev, ws_out,
+                    // (its tile cursors: a pair of sets of its own, alternating like the counter pair of the other kernels -- which this launch leaves alone)
+                    unsigned int *const head8 = r->work_head8 + (r->head8_parity & 1u) * (unsigned)(kWg3HeadSetBytes / 4);
+                    r->head8_parity ^= 1u;
+                    r->head_parity ^= 1u;  // (undo the toggle above: no launch used that pair)
+                    const Wg3Launch L3{r->dscene, r->film, r->isg_stats, r->vsp, r->vsp_ready, wave_end, first, single, jump, tiles_magic, head8, ws_prev, ws_out,
                                        r->counters, (unsigned)wblocks, (hipStream_t)stream, r->medium_grey ? (r->surfaces_grey ? 2 : 1) : 0,
                                        r->medium_grey && r->surfaces_grey && r->null_zero ? 1 : 0};
                     const int lrc = r->arith == VSPG_ARITH_FAST_WEIGHTS ? vspg_arith1_wg3(&L3) : r->arith == VSPG_ARITH_FAST ? vspg_arith2_wg3(&L3) : wg3_launch_unguided(L3);

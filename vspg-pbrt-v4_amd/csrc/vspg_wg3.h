@@ -59,6 +59,7 @@ __device__ __forceinline__ void resolve_sample(float4 s, float4 *film_px, float 
     isg.vsp_used = __builtin_fabsf(s.w);
     isg_add_sample_rmw(isg_px, L, isg);
 }
+constexpr int kWg3Heads = 8, kWg3HeadSetBytes = kWg3Heads * 128;  // k_render_wave_wg3's tile cursors (see the kernel)
 // The global work head is a PAIR of counters used by alternate launches: a launch zeroes the one the NEXT launch will use
 // (nobody reads it meanwhile, launches of a renderer are stream-ordered), so no memset sits between two waves.
 __device__ __forceinline__ void reset_sibling_head(unsigned int *work_head) {
@@ -123,7 +124,14 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg3(
     const unsigned n_tiles = (unsigned)(tilesX * tilesY);
     const int lane = threadIdx.x & 63;
     const int sample_step = S.shard_count > 1 ? S.shard_count : 1;
-    reset_sibling_head(work_head);
+    // The tile head: kWg3Heads cursors, each on a 128-byte line of its own, cursor k handing out tiles k, k + kWg3Heads, ...  One cursor
+    // was a returning atomic per 8x8 tile on ONE address -- 32 400 of them per 1080p launch, at the ~88 per microsecond a hot word
+    // serves more than half the kernel's time in the atomic unit's queue.  A wavefront starts at its workgroup's cursor (workgroups go
+    // round the XCDs) and moves on when one has run out (it looks before it asks: cursors only grow).  The heads are a PAIR of sets
+    // used by alternate launches, 1 KB apart: a launch zeroes the set the next one will use (reset_sibling_head's scheme).
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)kWg3Heads)
+        reinterpret_cast<unsigned int *>(reinterpret_cast<uintptr_t>(work_head) ^ (uintptr_t)kWg3HeadSetBytes)[threadIdx.x * 32u] = 0u;
+    unsigned wseg = blockIdx.x % (unsigned)kWg3Heads, wtried = 0u;
 
     constexpr bool FULL = !Medium::kSimpleScene;
     static_assert(!FULL || !GUIDED, "the workgroup kernel's guided vertex (vspg_guided_wg.h) is built for rectangle scenes");
@@ -248,8 +256,19 @@ __global__ __launch_bounds__(kWgBlock, kWgWavesPerSimd) void k_render_wave_wg3(
                 bump(W3_LIVE, 64);  // BEFORE the tile is claimed: `live == 0` then says nobody can still start a path
                 if (claim(Q_F, hF, 64u)) {
                     kind = W3_FRESH; pos0 = hF; n0 = 64u;
-                    if (lane == 0) tile = atomicAdd(work_head, 1u);
-                    tile = U(tile);
+                    tile = n_tiles;
+                    while (wtried < (unsigned)kWg3Heads) {
+                        unsigned c = 0xffffffffu;
+                        if (lane == 0 && __hip_atomic_load(work_head + wseg * 32u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (unsigned)kWg3Heads + wseg < n_tiles)
+                            c = atomicAdd(work_head + wseg * 32u, 1u);
+                        c = U(c);
+                        if (c != 0xffffffffu && c * (unsigned)kWg3Heads + wseg < n_tiles) {
+                            tile = c * (unsigned)kWg3Heads + wseg;
+                            break;
+                        }
+                        wseg = (wseg + 1u) % (unsigned)kWg3Heads;
+                        ++wtried;
+                    }
                 } else {
                     bump(W3_LIVE, -64);
                     bump(W3_BUSY_S, -1);
