@@ -208,20 +208,22 @@ VDEV WfShadowResult wf_load_shadow_result(const WfPool &P, unsigned slot, bool c
 
 // per-iteration control block (one per path-loop iteration, zeroed once per launch of the pipeline)
 struct WfIter {
+    // (every word below that kernels hammer with atomics sits on a 128-byte line of its own: the three list counters are bumped by
+    // every workgroup of a dense kernel every few rounds, the chunk cursor once per round)
     unsigned int n_active;       // list entries of this iteration: paths with a segment in flight (+ WFL_DEAD ones awaiting their NEE)
+    unsigned int pad0[31];
     unsigned int dense_head;     // chunk cursor of this iteration's vertex kernel (VSPG_WF_DENSE_CLAIM)
+    unsigned int pad1[31];
     unsigned int n_walk;         // distance-walk jobs
+    unsigned int pad2[31];
     unsigned int n_shadow;       // shadow-walk jobs
-    unsigned int walk_head;      // (round 5: the walk kernels' job cursors are seg_head below)
-    unsigned int shadow_head;
-    unsigned int pad[2];
-    unsigned int pad2[24];       // (the header fills a 128-byte line of its own)
+    unsigned int pad3[31];
     // Job cursors of the walk kernels: up to kWfSegs per list, each on a 128-byte line of its own (wf_claim_refill).
     // [0] distance walk  [1] shadow walk  [2], [3] k_wf_walk (launched with / without distance jobs)
     unsigned int seg_head[4][8][32];
 };
 constexpr int kWfSegs = 8;
-static_assert(sizeof(WfIter) == 128 + 4 * 8 * 128, "WfIter: a header line + the cursor lines");
+static_assert(sizeof(WfIter) == 4 * 128 + 4 * 8 * 128, "WfIter: four header lines + the cursor lines");
 struct WfArgs {
     const DScene *scene;
     WfPool P;
@@ -319,6 +321,33 @@ struct WfStage {
         __syncthreads();
     }
 };
+
+// Two or three stages flushed together: their global atomics travel side by side (threads 0..N-1 ask, one each) and the workgroup
+// pays three barriers, not three per list.  Same protocol as WfStage::flush.
+template <int N>
+VDEV void wf_flush_stages(const WfStage (&st)[N], unsigned int *const (&list)[N], unsigned int *const (&gcount)[N], unsigned int *s_base) {
+    __syncthreads();
+    unsigned int c[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[k] = *st[k].cnt;
+    if (threadIdx.x < (unsigned)N) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (threadIdx.x == (unsigned)k && c[k]) s_base[k] = atomicAdd(gcount[k], c[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)N) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (threadIdx.x == (unsigned)k) *st[k].cnt = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const unsigned int b = s_base[k];
+        for (unsigned int i = threadIdx.x; i < c[k]; i += blockDim.x) list[k][b + i] = st[k].buf[i];
+    }
+    __syncthreads();
+}
 
 // With a grey medium r_u and r_l are one float each: they share ONE quad with the NEE's two pdfs -- {r_u, r_l, scatterPDF, p_l}
 // -- instead of two (every quad a lane touches is a line of its own once the lists have thinned out).
@@ -896,13 +925,9 @@ __global__ __launch_bounds__(kWfBlock, 3) void k_wf_start(WfArgs a) {
         }
         stA.push(alive, slot);
         stB.push(walk, slot);
-        if ((round % kWfStageRounds) == kWfStageRounds - 1) {
-            stA.flush(a.list_active, &I->n_active, &s_gbase[0]);
-            stB.flush(a.list_walk, &I->n_walk, &s_gbase[1]);
-        }
+        if ((round % kWfStageRounds) == kWfStageRounds - 1) wf_flush_stages<2>({stA, stB}, {a.list_active, a.list_walk}, {&I->n_active, &I->n_walk}, s_gbase);
     }
-    stA.flush(a.list_active, &I->n_active, &s_gbase[0]);
-    stB.flush(a.list_walk, &I->n_walk, &s_gbase[1]);
+    wf_flush_stages<2>({stA, stB}, {a.list_active, a.list_walk}, {&I->n_active, &I->n_walk}, s_gbase);
     wf_flush_counters(pc, a.counters);
 }
 
@@ -1526,15 +1551,10 @@ __global__ __launch_bounds__(kWfBlock, GUIDED ? VSPG_WF_VERTEX_WAVES_GUIDED : (M
         stA.push(next, slot);
         stB.push(walk, slot);
         stC.push(shadow, slot);
-        if ((round % kWfStageRounds) == kWfStageRounds - 1) {
-            stA.flush(list_out, &In->n_active, &s_gbase[0]);
-            stB.flush(a.list_walk, &In->n_walk, &s_gbase[1]);
-            stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[2]);
-        }
+        if ((round % kWfStageRounds) == kWfStageRounds - 1)
+            wf_flush_stages<3>({stA, stB, stC}, {list_out, a.list_walk, a.list_shadow}, {&In->n_active, &In->n_walk, &I->n_shadow}, s_gbase);
     }
-    stA.flush(list_out, &In->n_active, &s_gbase[0]);
-    stB.flush(a.list_walk, &In->n_walk, &s_gbase[1]);
-    stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[2]);
+    wf_flush_stages<3>({stA, stB, stC}, {list_out, a.list_walk, a.list_shadow}, {&In->n_active, &In->n_walk, &I->n_shadow}, s_gbase);
     wf_flush_counters(pc, a.counters);
 }
 
@@ -1647,13 +1667,9 @@ __global__ __launch_bounds__(kWfBlock, 2) void k_wf_segment_vertex(WfArgs a, int
         }
         stA.push(next, slot);
         stC.push(shadow, slot);
-        if ((round % kWfStageRounds) == kWfStageRounds - 1) {
-            stA.flush(list_out, &In->n_active, &s_gbase[0]);
-            stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
-        }
+        if ((round % kWfStageRounds) == kWfStageRounds - 1) wf_flush_stages<2>({stA, stC}, {list_out, a.list_shadow}, {&In->n_active, &I->n_shadow}, s_gbase);
     }
-    stA.flush(list_out, &In->n_active, &s_gbase[0]);
-    stC.flush(a.list_shadow, &I->n_shadow, &s_gbase[1]);
+    wf_flush_stages<2>({stA, stC}, {list_out, a.list_shadow}, {&In->n_active, &I->n_shadow}, s_gbase);
     wf_flush_counters(pc, a.counters);
 }
 
