@@ -2602,7 +2602,8 @@ static int wf_render_pass(VspgRenderer *r, int sample, hipStream_t s, bool nvdb,
     L.dense = (unsigned)r->num_cus * 8u;
     L.walk = (unsigned)r->num_cus * (unsigned)walk_blocks;
     L.swalk = (unsigned)r->num_cus * (unsigned)shadow_blocks;
-    L.mwalk = (unsigned)r->num_cus * (unsigned)kWfMergedWavesPerSimd;
+    const int merged_blocks = [] { const char *e = getenv("VSPG_WF_MERGED_BLOCKS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= kWfMergedWavesPerSimd ? v : kWfMergedWavesPerSimd; }();  // (read per pass)
+    L.mwalk = (unsigned)r->num_cus * (unsigned)merged_blocks;
     if (L.dense > max_blocks) L.dense = max_blocks;
     if (L.walk > max_blocks) L.walk = max_blocks;
     if (L.swalk > max_blocks) L.swalk = max_blocks;
