@@ -10,6 +10,9 @@ from conftest import load_package
 import oracle_lib, scenes
 P = load_package(); P.load()
 W, H = 1920, 1080
+if len(sys.argv) > 1 and "x" in sys.argv[1] and sys.argv[1].replace("x", "").isdigit():  # full_size_film_check.py 3840x2160 [workload ...]
+    W, H = (int(v) for v in sys.argv.pop(1).split("x"))
+print("%d x %d" % (W, H), flush=True)
 WL = {"fog": lambda: P.fog_box_scene(W, H), "cloud": lambda: P.cloud_box_scene(W, H, 256), "cloud-nvdb": lambda: P.nanovdb_box_scene(W, H, 256),
       "cloud-scene": lambda: P.cloud_scene(W, H, 256), "cloud-scene-nvdb": lambda: P.cloud_scene(W, H, 256, nvdb=True)}
 ok = True
