@@ -2105,6 +2105,41 @@ def test_merged_walk_kernel_equals_the_two_walk_kernels(gpu_pkg, shape):
         assert np.array_equal(f.view(np.uint32), results[0][0].view(np.uint32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["scene", "scene-nvdb", "box-guided"])
+def test_job_cursors_do_not_change_the_render(gpu_pkg, shape):
+    """Round 5: k_wf_walk's job stream dealt out to eight striped cursors (boundary scenes' default) or handed out by one (everything
+    else's): VSPG_WF_SEGS=8 / 1 decide who runs which walk when, nothing else -- same film, same counters, bit for bit; at a size
+    where a list spans many stripes and wavefronts move from cursor to cursor."""
+    P = gpu_pkg
+    W, H = 960, 540
+    guided = shape.endswith("guided")
+    scene = P.cloud_box_scene(W, H, 64) if shape.startswith("box") else P.cloud_scene(W, H, 64, nvdb=shape.endswith("nvdb"))
+    prm = P.default_params() if guided else P.app_f_params()
+    field = None
+    if guided:
+        import scenes
+        field = scenes.light_field(P, n=4)
+    results = []
+    for segs in ("8", "1", "8"):
+        os.environ["VSPG_WF_SEGS"] = segs
+        try:
+            r = P.Renderer(scene, prm, W, H, seed=9)
+            if field is not None:
+                r.set_guiding_field(field, field)
+            assert r.kernel_name().startswith("k_wf_walk")
+            for w in range(3):
+                r.render_wave(w, w + 1); r.post_process_wave()
+            results.append((r.film(), r.counters()))
+            r.close()
+        finally:
+            os.environ.pop("VSPG_WF_SEGS", None)
+    assert results[0][1]["density_queries"] > 0
+    for f, c in results[1:]:
+        assert c == results[0][1]
+        assert np.array_equal(f.view(np.uint32), results[0][0].view(np.uint32))
+
+
 @pytest.mark.parametrize("kind", ["grid", "nvdb"])
 def test_guided_wavefront_pipeline_equals_per_lane_kernel(gpu_pkg, kind):
     """The reference-default guided configuration over a heterogeneous medium with a field in place (config 5's query side):
